@@ -1,0 +1,381 @@
+#!/usr/bin/env python3
+"""Golden-vector generator. Runs ONLY in the build container, where the upstream
+reference is mounted read-only at /root/reference; nothing here is needed on the
+GPU box. It imports the reference *unmodified*, loads the deterministic weights of
+`insenticap_model_amd.synth` through `load_state_dict`, runs it on the seeded
+synthetic inputs and writes small `.npz` fixtures next to this file.
+
+Only data (inputs are re-derivable from seeds; expected outputs are stored) is
+committed - no reference source, bytecode or pickled module.
+
+    python tests/golden/make_golden.py            # all cases
+    python tests/golden/make_golden.py tiny cfg1  # selected cases
+
+Observation hooks used (the reference code itself is not edited):
+  * a forward hook on `captioner.drop` records each dropout keep-mask in call order;
+  * `torch.multinomial` is wrapped to record the raw draws;
+  * `captioner.forward_step` is wrapped to record fed tokens and top-2 margins.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = os.environ.get('INSENTICAP_REFERENCE', '/root/reference')
+sys.path.insert(0, ROOT)
+sys.path.insert(0, REF)
+
+from insenticap_model_amd import synth  # noqa: E402
+from models.captioner import Captioner, XECriterion  # noqa: E402  (reference)
+from self_critical.utils import RewardCriterion  # noqa: E402      (reference)
+
+torch.set_num_threads(8)
+
+
+def build_reference(V, settings, seed, dropout_p=None):
+    st = dict(settings)
+    if dropout_p is not None:
+        st['dropout_p'] = dropout_p
+    cap = Captioner(synth.make_idx2word(V), synth.SENTIMENT_CATEGORIES, st)
+    w = synth.make_weights(V, settings, seed=seed)
+    missing = cap.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()}, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    assert list(cap.state_dict().keys()) == list(w.keys()), 'state_dict order differs'
+    return cap
+
+
+def T(d, *keys):
+    return [torch.from_numpy(np.asarray(d[k])) for k in keys]
+
+
+class StepSpy:
+    """Wraps captioner.forward_step: records fed token ids and top-2 margins."""
+
+    def __init__(self, cap):
+        self.cap = cap
+        self.orig = cap.forward_step
+        self.fed, self.margins = [], []
+        cap.forward_step = self
+
+    def __call__(self, it, *a, **k):
+        logp, state = self.orig(it, *a, **k)
+        self.fed.append(it.detach().clone())
+        top2 = torch.topk(logp.detach(), 2, dim=1).values
+        self.margins.append((top2[:, 0] - top2[:, 1]).clone())
+        return logp, state
+
+    def close(self):
+        self.cap.forward_step = self.orig
+
+    def fed_matrix(self):
+        return torch.stack(self.fed, dim=1).numpy()
+
+    def margin_matrix(self):
+        return torch.stack(self.margins, dim=1).numpy()
+
+
+class DropSpy:
+    def __init__(self, cap):
+        self.masks = []
+        self.h = cap.drop.register_forward_hook(self._hook)
+
+    def _hook(self, mod, inp, out):
+        if mod.training:
+            self.masks.append((out.detach() != 0).numpy())
+
+    def close(self):
+        self.h.remove()
+
+
+class MultinomialSpy:
+    def __init__(self):
+        self.draws = []
+        self.orig = torch.multinomial
+        torch.multinomial = self
+
+    def __call__(self, *a, **k):
+        r = self.orig(*a, **k)
+        self.draws.append(r.detach().clone().view(-1))
+        return r
+
+    def close(self):
+        torch.multinomial = self.orig
+
+
+def grads_of(cap):
+    return {k: (p.grad.detach().numpy().copy() if p.grad is not None else None)
+            for k, p in cap.named_parameters()}
+
+
+def clamp_adam_reference(cap, lr, clip=0.1):
+    """train_xe.py:189-192 order: backward done by caller; clamp; Adam.step."""
+    optim, _, _ = cap.get_optim_criterion(lr)
+    for group in optim.param_groups:
+        for prm in group['params']:
+            if prm.grad is not None:
+                prm.grad.data.clamp_(-clip, clip)
+    optim.step()
+    return {k: v.detach().numpy().copy() for k, v in cap.state_dict().items()}
+
+
+def grad_digest(g):
+    """Small per-tensor fingerprint for big tensors: sum, abs-sum, l2, 64 strided samples."""
+    flat = g.reshape(-1).astype(np.float64)
+    n = flat.size
+    idx = (np.arange(64, dtype=np.int64) * 2654435761 % n)
+    return np.concatenate([[flat.sum(), np.abs(flat).sum(), np.sqrt((flat ** 2).sum())],
+                           flat[idx]])
+
+
+def xe_train_iteration(cap, d, s2s, lr, out, prefix, full_grads):
+    """One train_xe.py inner step (train_xe.py:155-192) in eval-mode dropout with grad on."""
+    xe_crit, da_crit = XECriterion(), torch.nn.MSELoss()
+    fc, att, cpt, caps, lab = T(d, 'fc_feats', 'att_feats', 'cpt_words', 'captions', 'senti_labels')
+    cap.zero_grad()
+    pred = cap(fc, att, cpt, caps, lab, 0.0, mode='xe')
+    xe_loss = xe_crit(pred, caps[:, 1:], d['lengths'])
+    da_loss = da_crit(cap.cpt_feats, cap.fc_feats.detach())
+    out[prefix + 'xe_logp'] = pred.detach().numpy() if full_grads else pred.detach().numpy()[:, :, :32]
+    out[prefix + 'xe_logp_tgt'] = pred.detach().gather(2, caps[:, 1:].unsqueeze(2)).squeeze(2).numpy()
+    out[prefix + 'xe_fc_feats'] = cap.fc_feats.detach().numpy()
+    out[prefix + 'xe_cpt_feats'] = cap.cpt_feats.detach().numpy()
+    out[prefix + 'xe_cont_weights'] = cap.cont_weights.detach().numpy()
+    scaps, scpt, ssw, slab = T(s2s, 'captions', 'cpt_words', 'senti_words', 'senti_labels')
+    pred2 = cap(scaps, scpt, ssw, slab, 0.0, mode='seq2seq')
+    s2s_loss = xe_crit(pred2, scaps[:, 1:], s2s['lengths'])
+    out[prefix + 's2s_logp'] = pred2.detach().numpy() if full_grads else pred2.detach().numpy()[:, :, :32]
+    out[prefix + 's2s_logp_tgt'] = pred2.detach().gather(2, scaps[:, 1:].unsqueeze(2)).squeeze(2).numpy()
+    out[prefix + 's2s_senti_weights'] = cap.senti_weights.detach().numpy()
+    all_loss = xe_loss + da_loss + s2s_loss
+    all_loss.backward()
+    out[prefix + 'losses'] = np.array([float(xe_loss), float(da_loss), float(s2s_loss)], np.float64)
+    for k, g in grads_of(cap).items():
+        if g is None:   # gate-fusion weights are unused in xe/seq2seq (captioner.py:101-103)
+            continue
+        if full_grads:
+            out[prefix + 'grad/' + k] = g
+        else:
+            out[prefix + 'gdig/' + k] = grad_digest(g)
+    newp = clamp_adam_reference(cap, lr)
+    for k, v in newp.items():
+        if full_grads:
+            out[prefix + 'adam/' + k] = v
+        else:
+            out[prefix + 'adig/' + k] = grad_digest(v)
+
+
+def rollout_cases(cap, d, Tlen, out, prefix):
+    fc, att, cpt, sw, lab = T(d, 'fc_feats', 'att_feats', 'cpt_words', 'senti_words', 'senti_labels')
+    cap.eval()
+    spy = StepSpy(cap)
+    with torch.no_grad():
+        seq, lp, mk = cap(fc, att, cpt, sw, lab, Tlen, 1, mode='rl')
+    spy.close()
+    out[prefix + 'greedy_seq'] = seq.numpy()
+    out[prefix + 'greedy_logprobs'] = lp.numpy()
+    out[prefix + 'greedy_masks'] = mk.numpy()
+    out[prefix + 'greedy_margins'] = spy.margin_matrix()
+    out[prefix + 'greedy_cont_weights'] = cap.cont_weights.numpy()
+    out[prefix + 'greedy_senti_weights'] = cap.senti_weights.numpy()
+    out[prefix + 'greedy_gate_weights'] = cap.cont_senti_weights.numpy()
+    out[prefix + 'greedy_fc_feats'] = cap.fc_feats.numpy()
+    out[prefix + 'greedy_cpt_feats'] = cap.cpt_feats.numpy()
+
+    # sampled rollout (eval-mode dropout, grad on) + REINFORCE loss + grads
+    torch.manual_seed(1234)
+    ms = MultinomialSpy()
+    cap.zero_grad()
+    seq, lp, mk = cap(fc, att, cpt, sw, lab, Tlen, 0, mode='rl')
+    ms.close()
+    draws = torch.stack(ms.draws, dim=1).numpy()
+    out[prefix + 'sample_draws'] = draws
+    out[prefix + 'sample_seq'] = seq.numpy()
+    out[prefix + 'sample_logprobs'] = lp.detach().numpy()
+    out[prefix + 'sample_masks'] = mk.numpy()
+    rng = np.random.default_rng(77)
+    reward = np.repeat(rng.normal(size=(seq.shape[0], 1)), seq.shape[1], 1).astype(np.float32)
+    out[prefix + 'sample_reward'] = reward
+    loss = RewardCriterion()(lp, mk, torch.from_numpy(reward))
+    loss.backward()
+    out[prefix + 'sample_rl_loss'] = np.array([float(loss)])
+    return grads_of(cap)
+
+
+def beam_cases(cap, d, Tlen, out, prefix, n_images, beams):
+    fc, att, sw, lab = T(d, 'fc_feats', 'att_feats', 'senti_words', 'senti_labels')
+    for b in beams:
+        for senti in (0, 1):
+            caps_all, scores_all = [], []
+            for i in range(n_images):
+                with torch.no_grad():
+                    if senti:
+                        c, s = cap.sample(fc[i], att[i], sw[i], lab[i:i + 1], b, 1, Tlen)
+                    else:
+                        c, s = cap.sample(fc[i], att[i], None, None, b, 1, Tlen)
+                caps_all.append(list(c) + [''] * (b - len(c)))
+                scores_all.append(list(s) + [np.nan] * (b - len(s)))
+            out[prefix + 'beam%d_senti%d_caps' % (b, senti)] = np.array(caps_all)
+            out[prefix + 'beam%d_senti%d_scores' % (b, senti)] = np.array(scores_all, np.float64)
+    # decoding_constraint off, one setting
+    caps_all, scores_all = [], []
+    for i in range(n_images):
+        with torch.no_grad():
+            c, s = cap.sample(fc[i], att[i], sw[i], lab[i:i + 1], beams[0], 0, Tlen)
+        caps_all.append(list(c))
+        scores_all.append(list(s))
+    out[prefix + 'beam%d_nocons_caps' % beams[0]] = np.array(caps_all)
+    out[prefix + 'beam%d_nocons_scores' % beams[0]] = np.array(scores_all, np.float64)
+
+
+def case_tiny():
+    """Tiny dims, full tensors incl. every gradient and post-Adam parameter."""
+    V, st, seed = 64, synth.TINY_SETTINGS, 1
+    B, R, Tlen = 6, 6, 8
+    out = {}
+    d = synth.make_inputs(B, V, st, regions=R, seq_len=Tlen, seed=11)
+    s2s = synth.make_inputs(4, V, st, regions=R, seq_len=Tlen, seed=12)
+    cap = build_reference(V, st, seed)
+    cap.eval()
+    xe_train_iteration(cap, d, s2s, 4e-4, out, 'it/', full_grads=True)
+
+    cap = build_reference(V, st, seed)
+    g = rollout_cases(cap, d, Tlen, out, 'rl/')
+    for k, v in g.items():
+        if v is not None:
+            out['rl/grad/' + k] = v
+    # rows 3..5 all emit <EOS> before T: pins the early `break` (captioner.py:343-344),
+    # after which trailing seq / seq_logprobs / seq_masks columns stay zero
+    de = {k: (v[3:6] if isinstance(v, np.ndarray) else v[3:6]) for k, v in d.items()}
+    cap = build_reference(V, st, seed)
+    rollout_cases(cap, de, Tlen, out, 'early/')
+    assert out['early/greedy_masks'][:, -1].sum() == 0, 'early case does not end early'
+    cap = build_reference(V, st, seed)
+    beam_cases(cap, d, Tlen, out, 'beam/', n_images=B, beams=(3, 5))
+
+    # 4-D grid input [B,h,w,F] must behave like [B,h*w,F] (captioner.py:208)
+    dg = synth.make_inputs(B, V, st, regions=R, seq_len=Tlen, seed=11, grid=(2, 3))
+    cap.eval()
+    fc, att, cpt, caps, lab = T(dg, 'fc_feats', 'att_feats', 'cpt_words', 'captions', 'senti_labels')
+    with torch.no_grad():
+        out['grid/xe_logp'] = cap(fc, att, cpt, caps, lab, 0.0, mode='xe').numpy()
+
+    # train mode with dropout p=0.5: masks recorded and stored (bool)
+    cap = build_reference(V, st, seed)
+    cap.train()
+    torch.manual_seed(99)
+    ds = DropSpy(cap)
+    fc, att, cpt, caps, lab = T(d, 'fc_feats', 'att_feats', 'cpt_words', 'captions', 'senti_labels')
+    cap.zero_grad()
+    pred = cap(fc, att, cpt, caps, lab, 0.0, mode='xe')
+    loss = XECriterion()(pred, caps[:, 1:], d['lengths'])
+    loss.backward()
+    ds.close()
+    names = ['fc', 'att', 'label'] + ['out%d' % i for i in range(Tlen)]
+    assert len(ds.masks) == len(names), len(ds.masks)
+    for n, m in zip(names, ds.masks):
+        out['drop/mask_' + n] = m
+    out['drop/xe_logp'] = pred.detach().numpy()
+    out['drop/loss'] = np.array([float(loss)])
+    for k, v in grads_of(cap).items():
+        if v is not None:
+            out['drop/grad/' + k] = v
+
+    # seq2seq in train mode with dropout: masks order cpt, words, label, out*
+    cap = build_reference(V, st, seed)
+    cap.train()
+    torch.manual_seed(98)
+    ds = DropSpy(cap)
+    scaps, scpt, ssw, slab = T(s2s, 'captions', 'cpt_words', 'senti_words', 'senti_labels')
+    pred = cap(scaps, scpt, ssw, slab, 0.0, mode='seq2seq')
+    ds.close()
+    names = ['cpt', 'words', 'label'] + ['out%d' % i for i in range(Tlen)]
+    assert len(ds.masks) == len(names), len(ds.masks)
+    for n, m in zip(names, ds.masks):
+        out['drop_s2s/mask_' + n] = m
+    out['drop_s2s/logp'] = pred.detach().numpy()
+
+    # scheduled sampling, dropout disabled (p=0) so train mode is deterministic given draws
+    cap = build_reference(V, st, seed, dropout_p=0.0)
+    cap.train()
+    torch.manual_seed(5)
+    spy = StepSpy(cap)
+    pred = cap(fc, att, cpt, caps, lab, 0.5, mode='xe')
+    spy.close()
+    out['ss/fed_tokens'] = spy.fed_matrix()
+    out['ss/xe_logp'] = pred.detach().numpy()
+    assert (out['ss/fed_tokens'] != caps[:, :-1].numpy()).any(), 'ss never triggered'
+    np.savez_compressed(os.path.join(HERE, 'tiny.npz'), **out)
+    print('tiny: %d arrays' % len(out))
+
+
+def case_cfg1():
+    """BASELINE.json configs[0]: B=4, 36x2048 feats, V=10k, T=20 (digests for big tensors)."""
+    V, st, seed = 10000, synth.DEFAULT_SETTINGS, 0
+    B, R, Tlen = 4, 36, 20
+    out = {}
+    d = synth.make_inputs(B, V, st, regions=R, seq_len=Tlen, seed=1)
+    s2s = synth.make_inputs(5, V, st, regions=R, seq_len=Tlen, seed=2)
+    cap = build_reference(V, st, seed)
+    rollout_g = rollout_cases(cap, d, Tlen, out, 'rl/')
+    for k, v in rollout_g.items():
+        if v is not None:
+            out['rl/gdig/' + k] = grad_digest(v)
+    beam_cases(cap, d, Tlen, out, 'beam/', n_images=2, beams=(5,))
+    cap = build_reference(V, st, seed)
+    cap.eval()
+    xe_train_iteration(cap, d, s2s, 4e-4, out, 'it/', full_grads=False)
+    np.savez_compressed(os.path.join(HERE, 'cfg1.npz'), **out)
+    print('cfg1: %d arrays' % len(out))
+
+
+def case_b128():
+    """BASELINE.json configs[1] shape: B=128 XE forward+backward, digests only; plus
+    greedy at B=128 (token ids, logprobs, margins)."""
+    V, st, seed = 10000, synth.DEFAULT_SETTINGS, 0
+    B, R, Tlen = 128, 36, 20
+    out = {}
+    d = synth.make_inputs(B, V, st, regions=R, seq_len=Tlen, seed=21)
+    s2s = synth.make_inputs(80, V, st, regions=R, seq_len=Tlen, seed=22)
+    cap = build_reference(V, st, seed)
+    fc, att, cpt, sw, lab = T(d, 'fc_feats', 'att_feats', 'cpt_words', 'senti_words', 'senti_labels')
+    cap.eval()
+    spy = StepSpy(cap)
+    with torch.no_grad():
+        seq, lp, mk = cap(fc, att, cpt, sw, lab, Tlen, 1, mode='rl')
+    spy.close()
+    out['rl/greedy_seq'] = seq.numpy()
+    out['rl/greedy_logprobs'] = lp.numpy()
+    out['rl/greedy_masks'] = mk.numpy()
+    out['rl/greedy_margins'] = spy.margin_matrix()
+    xe_crit, da_crit = XECriterion(), torch.nn.MSELoss()
+    caps = torch.from_numpy(d['captions'])
+    cap.zero_grad()
+    pred = cap(fc, att, cpt, caps, lab, 0.0, mode='xe')
+    xe_loss = xe_crit(pred, caps[:, 1:], d['lengths'])
+    da_loss = da_crit(cap.cpt_feats, cap.fc_feats.detach())
+    scaps, scpt, ssw, slab = T(s2s, 'captions', 'cpt_words', 'senti_words', 'senti_labels')
+    pred2 = cap(scaps, scpt, ssw, slab, 0.0, mode='seq2seq')
+    s2s_loss = xe_crit(pred2, scaps[:, 1:], s2s['lengths'])
+    (xe_loss + da_loss + s2s_loss).backward()
+    out['it/losses'] = np.array([float(xe_loss), float(da_loss), float(s2s_loss)], np.float64)
+    out['it/xe_logp_tgt'] = pred.detach().gather(2, caps[:, 1:].unsqueeze(2)).squeeze(2).numpy()
+    out['it/s2s_logp_tgt'] = pred2.detach().gather(2, scaps[:, 1:].unsqueeze(2)).squeeze(2).numpy()
+    for k, g in grads_of(cap).items():
+        if g is not None:
+            out['it/gdig/' + k] = grad_digest(g)
+    newp = clamp_adam_reference(cap, 4e-4)
+    for k, v in newp.items():
+        out['it/adig/' + k] = grad_digest(v)
+    np.savez_compressed(os.path.join(HERE, 'b128.npz'), **out)
+    print('b128: %d arrays' % len(out))
+
+
+CASES = {'tiny': case_tiny, 'cfg1': case_cfg1, 'b128': case_b128}
+
+if __name__ == '__main__':
+    which = sys.argv[1:] or list(CASES)
+    for name in which:
+        CASES[name]()
