@@ -1,0 +1,55 @@
+"""Builds libinsenticap_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
+
+    python -m insenticap_model_amd._build [--force]
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+LIB_DIR = os.path.join(HERE, 'lib')
+LIB_PATH = os.path.join(LIB_DIR, 'libinsenticap_hip.so')
+SOURCES = ['gemm_f32.hip', 'attention.hip', 'pointwise.hip']
+HEADERS = [os.path.join(CSRC, 'common.h'),
+           os.path.join(os.path.dirname(HERE), 'include', 'insenticap_hip.h')]
+FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-Wall', '-Wno-unused-function']
+
+
+def _hipcc():
+    for c in (os.environ.get('HIPCC'), '/opt/rocm/bin/hipcc', 'hipcc'):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    raise RuntimeError('hipcc not found')
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    os.makedirs(LIB_DIR, exist_ok=True)
+    hipcc = _hipcc()
+    objs = []
+    for s in SOURCES:
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(LIB_DIR, s.replace('.hip', '.o'))
+        if force or _stale(obj, [src] + HEADERS):
+            cmd = [hipcc] + FLAGS + ['-c', src, '-o', obj]
+            if verbose:
+                print(' '.join(cmd))
+            subprocess.check_call(cmd)
+        objs.append(obj)
+    if force or _stale(LIB_PATH, objs):
+        cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB_PATH] + objs
+        if verbose:
+            print(' '.join(cmd))
+        subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+if __name__ == '__main__':
+    print(build(force='--force' in sys.argv, verbose=True))

@@ -1,0 +1,116 @@
+"""ctypes binding of libinsenticap_hip.so (include/insenticap_hip.h).
+
+There is deliberately NO fallback: if the shared library is missing or a call returns a
+non-zero status the product raises.  (The CPU oracle under oracle/ is test infrastructure
+and is never imported from here.)
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libinsenticap_hip.so')
+
+ISC_MAX_SEG = 4
+
+c_f32p = C.c_void_p  # device pointers travel as integers
+
+
+class Seg(C.Structure):
+    _fields_ = [('A', C.c_void_p), ('W', C.c_void_p), ('lda', C.c_int32), ('ldw', C.c_int32),
+                ('K', C.c_int32), ('_pad', C.c_int32)]
+
+
+class LinearProblem(C.Structure):
+    _fields_ = [('seg', Seg * ISC_MAX_SEG), ('nseg', C.c_int32), ('M', C.c_int32), ('N', C.c_int32),
+                ('relu', C.c_int32), ('bias0', C.c_void_p), ('bias1', C.c_void_p), ('bias2', C.c_void_p),
+                ('keep_mask', C.c_void_p), ('mask_scale', C.c_float), ('ldc', C.c_int32),
+                ('C', C.c_void_p), ('C_pre', C.c_void_p)]
+
+
+class LstmProblem(C.Structure):
+    _fields_ = [('seg', Seg * ISC_MAX_SEG), ('nseg', C.c_int32), ('M', C.c_int32), ('H', C.c_int32),
+                ('_pad', C.c_int32), ('b_ih', C.c_void_p), ('b_hh', C.c_void_p),
+                ('c_prev', C.c_void_p), ('h_out', C.c_void_p), ('c_out', C.c_void_p),
+                ('gates_out', C.c_void_p), ('h_keep_mask', C.c_void_p), ('mask_scale', C.c_float),
+                ('hdrop_out', C.c_void_p)]
+
+
+class ScanProblem(C.Structure):
+    _fields_ = [('P', C.c_void_p), ('V', C.c_void_p), ('q', C.c_void_p), ('q2', C.c_void_p),
+                ('w', C.c_void_p), ('w_bias', C.c_void_p), ('R', C.c_int32), ('A', C.c_int32),
+                ('D', C.c_int32), ('_pad', C.c_int32), ('out', C.c_void_p), ('alpha_out', C.c_void_p),
+                ('alpha_ld', C.c_int64)]
+
+
+class RolloutStep(C.Structure):
+    _fields_ = [('B', C.c_int32), ('V', C.c_int32), ('T', C.c_int32), ('t', C.c_int32),
+                ('n_tile', C.c_int32), ('W', C.c_int32),
+                ('part_max', C.c_void_p), ('part_sum', C.c_void_p), ('part_idx', C.c_void_p),
+                ('logits', C.c_void_p), ('ld_logits', C.c_int64),
+                ('forced', C.c_void_p), ('sample_u', C.c_void_p), ('eos_id', C.c_int64),
+                ('seq', C.c_void_p), ('seq_logprobs', C.c_void_p), ('seq_masks', C.c_void_p),
+                ('unfinished', C.c_void_p), ('alive', C.c_void_p), ('raw_tokens', C.c_void_p),
+                ('emb', C.c_void_p), ('xt_add', C.c_void_p), ('xt_next', C.c_void_p)]
+
+
+# name -> (restype, argtypes); every symbol include/insenticap_hip.h declares
+SIGNATURES = {
+    'isc_abi_version': (C.c_int, []),
+    'isc_target_arch': (C.c_char_p, []),
+    'isc_linear_fwd': (C.c_int, [C.POINTER(LinearProblem), C.c_int, C.c_void_p]),
+    'isc_lstm_fwd': (C.c_int, [C.POINTER(LstmProblem), C.c_void_p]),
+    'isc_vocab_fwd': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int,
+                                C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                C.c_void_p]),
+    'isc_logsoftmax_apply': (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p]),
+    'isc_attn_scan_fwd': (C.c_int, [C.POINTER(ScanProblem), C.c_int, C.c_int, C.c_void_p]),
+    'isc_gate_mix_fwd': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                   C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    'isc_embed_relu_fwd': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p,
+                                     C.c_int, C.c_void_p, C.c_void_p]),
+    'isc_embed_relu_mean_fwd': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
+                                          C.c_void_p, C.c_void_p]),
+    'isc_embed_senti_words_fwd': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int64,
+                                            C.c_int, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
+    'isc_rollout_finalize': (C.c_int, [C.POINTER(RolloutStep), C.c_void_p]),
+    'isc_beam_topk': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int,
+                                C.c_void_p, C.c_void_p, C.c_void_p]),
+    'isc_xe_loss_fwd': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                  C.c_void_p, C.c_void_p]),
+}
+
+_ERRORS = {-1: 'ISC_E_NULL (required pointer is null)', -2: 'ISC_E_SHAPE (unsupported size)',
+           -3: 'ISC_E_ALIGN (pointer / leading dimension not 16-byte aligned)',
+           -4: 'ISC_E_WORKSPACE'}
+
+_lib = None
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    """Load (once) and type every entry point. Raises HipLibraryError when the library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryError(
+            'libinsenticap_hip.so not found at %s - build it with '
+            '`python -m insenticap_model_amd._build` (hipcc, gfx950). There is no CPU fallback.' % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError => header/library mismatch, surfaced loudly
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = _ERRORS.get(rc, 'hipError_t %d' % rc if rc > 0 else 'error %d' % rc)
+        raise HipLibraryError('%s failed: %s' % (what, msg))

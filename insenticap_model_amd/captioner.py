@@ -1,0 +1,455 @@
+"""MI355X-native `Captioner`: same constructor, attributes, call modes and 40-tensor
+`state_dict` as the reference class (/root/reference/models/captioner.py:120-424), with the
+decode arithmetic executed by libinsenticap_hip.so instead of stock torch ops.
+
+The nn.Module containers below exist only to own the parameters under the reference's
+names (checkpoint compatibility); their `forward`s are never called.
+PyTorch is used for device memory, streams and (in train mode) random numbers only.
+"""
+import torch
+import torch.nn as nn
+
+from . import _lib, ops
+from ._lib import RolloutStep
+
+
+class ContentAttention(nn.Module):
+    def __init__(self, settings):
+        super().__init__()
+        self.h2att = nn.Linear(settings['rnn_hid_dim'], settings['att_hid_dim'])
+        self.att_alpha = nn.Linear(settings['att_hid_dim'], 1)
+
+
+class SentiAttention(nn.Module):
+    def __init__(self, settings):
+        super().__init__()
+        self.h2word = nn.Linear(settings['rnn_hid_dim'], settings['att_hid_dim'])
+        self.label2word = nn.Linear(settings['word_emb_dim'], settings['att_hid_dim'])
+        self.word_alpha = nn.Linear(settings['att_hid_dim'], 1)
+
+
+class Attention(nn.Module):
+    def __init__(self, settings):
+        super().__init__()
+        self.cont_att = ContentAttention(settings)
+        self.senti_att = SentiAttention(settings)
+        self.h2att = nn.Linear(settings['rnn_hid_dim'], settings['att_hid_dim'])
+        self.cont2att = nn.Linear(settings['feat_emb_dim'], settings['att_hid_dim'])
+        self.senti2att = nn.Linear(settings['feat_emb_dim'], settings['att_hid_dim'])
+        self.att_alpha = nn.Linear(settings['att_hid_dim'], 1)
+
+
+class _Pro:
+    """Step-invariant tensors of one call (captioner.py:198-214 / 247-261 / 294-315)."""
+    fc_e = None      # [B,E]   what the att-LSTM sees (after dropout)
+    att_e3 = None    # [B,R,E] embedded regions (after dropout)
+    att_p3 = None    # [B,R,A] att2att projection
+    words_e3 = None  # [B,M,W] embedded sentiment words
+    words_p3 = None  # [B,M,A]
+    label_e = None   # [B,W]   sentiment-label embedding (added to every xt)
+    label_w = None   # [B,A]   label2word(label_e): step-invariant term of the senti attention
+    B = R = Mw = 0
+
+
+class Captioner(nn.Module):
+    def __init__(self, idx2word, sentiment_categories, settings):
+        super().__init__()
+        self.idx2word = idx2word
+        self.pad_id = idx2word.index('<PAD>')
+        self.unk_id = idx2word.index('<UNK>')
+        self.sos_id = idx2word.index('<SOS>') if '<SOS>' in idx2word else self.pad_id
+        # the reference guards <EOS> with the presence of '<SOS>' (captioner.py:128)
+        self.eos_id = idx2word.index('<EOS>') if '<SOS>' in idx2word else self.pad_id
+        self.neu_idx = sentiment_categories.index('neutral')
+        self.vocab_size = len(idx2word)
+        self.settings = dict(settings)
+        W, F, FA = settings['word_emb_dim'], settings['fc_feat_dim'], settings['att_feat_dim']
+        E, H, A = settings['feat_emb_dim'], settings['rnn_hid_dim'], settings['att_hid_dim']
+        for name, v in (('word_emb_dim', W), ('fc_feat_dim', F), ('att_feat_dim', FA),
+                        ('feat_emb_dim', E), ('rnn_hid_dim', H), ('att_hid_dim', A)):
+            if v % 32:
+                raise ValueError('%s=%d: the HIP kernels need dimensions that are multiples of 32' % (name, v))
+        if W != E:
+            # the gate mixes v_hat [E] with e_hat [W] elementwise (captioner.py:117 and the
+            # "TODO now: word_emb_dim == feat_emb_dim" at :157)
+            raise ValueError('word_emb_dim must equal feat_emb_dim')
+        self.drop = nn.Dropout(settings['dropout_p'])
+        self.word_embed = nn.Sequential(nn.Embedding(self.vocab_size, W, padding_idx=self.pad_id), nn.ReLU())
+        self.senti_label_embed = nn.Sequential(nn.Embedding(len(sentiment_categories), W), nn.ReLU())
+        self.fc_embed = nn.Sequential(nn.Linear(F, E), nn.ReLU())
+        self.cpt2fc = nn.Sequential(nn.Linear(W, E), nn.ReLU())
+        self.att_embed = nn.Sequential(nn.Linear(FA, E), nn.ReLU())
+        self.att_lstm = nn.LSTMCell(H + E + W, H)
+        self.att2att = nn.Sequential(nn.Linear(E, A), nn.ReLU())
+        self.senti2att = nn.Sequential(nn.Linear(W, A), nn.ReLU())
+        self.attention = Attention(settings)
+        self.lang_lstm = nn.LSTMCell(H + E, H)
+        self.classifier = nn.Linear(H, self.vocab_size)
+        self.fc_feats = self.cpt_feats = None
+        self.cont_weights, self.senti_weights, self.cont_senti_weights = [], [], []
+
+    # ------------------------------------------------------------------ plumbing
+    def _p(self):
+        p = {k: v.detach() for k, v in self.named_parameters()}
+        if not p['classifier.weight'].is_cuda:
+            raise _lib.HipLibraryError('Captioner parameters are on the CPU: call .to("cuda") - '
+                                       'this implementation has no CPU path')
+        return p
+
+    @property
+    def _dev(self):
+        return self.classifier.weight.device
+
+    def _new(self, *shape, dtype=torch.float32):
+        return torch.empty(shape, dtype=dtype, device=self._dev)
+
+    def _zeros(self, *shape, dtype=torch.float32):
+        return torch.zeros(shape, dtype=dtype, device=self._dev)
+
+    def init_hidden(self, bsz):
+        H = self.att_lstm.hidden_size
+        return (self._zeros(2, bsz, H), self._zeros(2, bsz, H))
+
+    def _f32(self, x):
+        ops.require_device(x)
+        return x.contiguous() if x.dtype == torch.float32 else x.float().contiguous()
+
+    def _ids(self, x):
+        ops.require_device(x)
+        return x.long().contiguous()
+
+    def _mask_source(self, masks):
+        """Returns f(key, *shape) -> (uint8 keep-mask or None, scale). `masks`: explicit dict
+        (tests replay the reference's masks); otherwise drawn with torch's RNG in train mode."""
+        p_drop = self.drop.p
+        scale = 1.0 / (1.0 - p_drop) if p_drop < 1.0 else 0.0
+
+        def f(key, *shape):
+            if masks is not None:
+                m = masks.get(key)
+                if m is None:
+                    return None, 1.0
+                return m.to(device=self._dev, dtype=torch.uint8).reshape(shape).contiguous(), scale
+            if not self.training or p_drop == 0.0:
+                return None, 1.0
+            return (torch.rand(shape, device=self._dev) >= p_drop).to(torch.uint8), scale
+        return f
+
+    # ------------------------------------------------------------------ prologue
+    def _prologue(self, p, mode, fc=None, att=None, cpt_words=None, senti_words=None, senti_labels=None,
+                  masks=None):
+        P = _Pro()
+        st = self.settings
+        E, A, Wd = st['feat_emb_dim'], st['att_hid_dim'], st['word_emb_dim']
+        mask_for = self._mask_source(masks)
+        first = []   # small independent problems that share one launch
+        if mode != 'seq2seq':
+            fc = self._f32(fc)
+            B = fc.shape[0]
+            att = self._f32(att).reshape(B, -1, att.shape[-1])
+            R = att.shape[1]
+            P.B, P.R = B, R
+            m, sc = mask_for('fc', B, E)
+            P.fc_e = self._new(B, E)
+            self.fc_feats = self._new(B, E) if m is not None else P.fc_e
+            first.append(ops.linear_problem([(fc, p['fc_embed.0.weight'])], P.fc_e, p['fc_embed.0.bias'],
+                                            relu=True, keep_mask=m, mask_scale=sc,
+                                            out_pre=self.fc_feats if m is not None else None))
+        else:
+            B = cpt_words.shape[0]
+            P.B = B
+        if cpt_words is not None:
+            cmean = self._new(B, Wd)
+            ops.embed_relu_mean_fwd(p['word_embed.0.weight'], self._ids(cpt_words), cmean)
+            cpt = self._new(B, E)
+            if mode == 'seq2seq':
+                m, sc = mask_for('cpt', B, E)
+                self.cpt_feats = self._new(B, E) if m is not None else cpt
+                first.append(ops.linear_problem([(cmean, p['cpt2fc.0.weight'])], cpt, p['cpt2fc.0.bias'],
+                                                relu=True, keep_mask=m, mask_scale=sc,
+                                                out_pre=self.cpt_feats if m is not None else None))
+                P.fc_e = cpt          # captioner.py:250-251: fc_feats := dropout(cpt_feats)
+            else:
+                self.cpt_feats = cpt
+                first.append(ops.linear_problem([(cmean, p['cpt2fc.0.weight'])], cpt, p['cpt2fc.0.bias'],
+                                                relu=True))
+        ops.linear_fwd(first)
+        if senti_labels is not None:
+            P.label_e = self._new(B, Wd)
+            ops.embed_relu_fwd(p['senti_label_embed.0.weight'], self._ids(senti_labels).reshape(-1), P.label_e)
+            m, sc = mask_for('label', B, Wd)
+            if m is not None:
+                P.label_e = P.label_e * (m.float() * sc)   # [B,W] elementwise, train mode only
+            if senti_words is not None:
+                P.label_w = self._new(B, A)
+                ops.linear_fwd([ops.linear_problem(
+                    [(P.label_e, p['attention.senti_att.label2word.weight'])], P.label_w,
+                    p['attention.senti_att.label2word.bias'])])
+        second = []
+        if mode != 'seq2seq':
+            m, sc = mask_for('att', B * R, E)
+            att_e = self._new(B * R, E)
+            ops.linear_fwd([ops.linear_problem([(att.reshape(B * R, -1), p['att_embed.0.weight'])], att_e,
+                                               p['att_embed.0.bias'], relu=True, keep_mask=m, mask_scale=sc)])
+            att_p = self._new(B * R, A)
+            second.append(ops.linear_problem([(att_e, p['att2att.0.weight'])], att_p,
+                                             p['att2att.0.bias'], relu=True))
+            P.att_e3, P.att_p3 = att_e.view(B, R, E), att_p.view(B, R, A)
+        if senti_words is not None:
+            sw = self._ids(senti_words).reshape(B, -1)
+            P.Mw = sw.shape[1] + 1
+            m, sc = mask_for('words', B * P.Mw, Wd)
+            words_e = self._new(B * P.Mw, Wd)
+            ops.embed_senti_words_fwd(p['word_embed.0.weight'], sw, self.pad_id, words_e, m, sc)
+            words_p = self._new(B * P.Mw, A)
+            second.append(ops.linear_problem([(words_e, p['senti2att.0.weight'])], words_p,
+                                             p['senti2att.0.bias'], relu=True))
+            P.words_e3, P.words_p3 = words_e.view(B, P.Mw, Wd), words_p.view(B, P.Mw, A)
+        if second:
+            ops.linear_fwd(second)
+        return P
+
+    # ------------------------------------------------------------------ one decode step
+    def _alloc_step_ws(self, rows, P):
+        st = self.settings
+        E, A = st['feat_emb_dim'], st['att_hid_dim']
+        has_cont, has_senti = P.att_e3 is not None, P.words_e3 is not None
+        ws = {}
+        if has_cont:
+            ws['qa'], ws['v'] = self._new(rows, A), self._new(rows, E)
+        if has_senti:
+            ws['qw'], ws['s'] = self._new(rows, A), self._new(rows, E)
+        if has_cont and has_senti:
+            ws['z'], ws['f'] = self._new(rows, A), self._new(rows, E)
+        n_tile = (self.vocab_size + 127) // 128
+        ws['pmax'] = self._new(rows, n_tile)
+        ws['psum'] = self._new(rows, n_tile)
+        ws['pidx'] = self._new(rows, n_tile, dtype=torch.int32)
+        return ws
+
+    def _step(self, p, P, ws, xt, h_cur, c_cur, h_nxt, c_nxt, alpha_c=None, alpha_s=None, beta=None,
+              logits=None, out_mask=None, out_scale=1.0):
+        """forward_step (captioner.py:168-186) on `rows` sequences. State buffers are [2,rows,H];
+        reads *_cur, writes *_nxt, the vocabulary tile statistics and (optionally) raw logits."""
+        st = self.settings
+        E, H = st['feat_emb_dim'], st['rnn_hid_dim']
+        Wih, Whh = p['att_lstm.weight_ih'], p['att_lstm.weight_hh']
+        rows = xt.shape[0]
+        # att-LSTM over cat[h_lang_prev, fc, xt] (captioner.py:174) without materialising the cat
+        ops.lstm_fwd([(h_cur[1], Wih[:, 0:H]), (P.fc_e, Wih[:, H:H + E]), (xt, Wih[:, H + E:]),
+                      (h_cur[0], Whh)],
+                     p['att_lstm.bias_ih'], p['att_lstm.bias_hh'], c_cur[0], h_nxt[0], c_nxt[0])
+        h1 = h_nxt[0]
+        has_cont, has_senti = P.att_e3 is not None, P.words_e3 is not None
+        probs, scans = [], []
+        if has_cont:
+            probs.append(ops.linear_problem([(h1, p['attention.cont_att.h2att.weight'])], ws['qa'],
+                                            p['attention.cont_att.h2att.bias']))
+            scans.append(ops.scan_problem(P.att_p3, P.att_e3, ws['qa'],
+                                          p['attention.cont_att.att_alpha.weight'],
+                                          p['attention.cont_att.att_alpha.bias'], ws['v'], alpha_c))
+        if has_senti:
+            probs.append(ops.linear_problem([(h1, p['attention.senti_att.h2word.weight'])], ws['qw'],
+                                            p['attention.senti_att.h2word.bias']))
+            scans.append(ops.scan_problem(P.words_p3, P.words_e3, ws['qw'],
+                                          p['attention.senti_att.word_alpha.weight'],
+                                          p['attention.senti_att.word_alpha.bias'], ws['s'], alpha_s,
+                                          q2=P.label_w))
+        ops.linear_fwd(probs)
+        ops.attn_scan_fwd(scans, rows)
+        if has_cont and has_senti:
+            # z = cont2att(v) + senti2att(s) + h2att(h1): one 3-segment contraction (captioner.py:107-110)
+            ops.linear_fwd([ops.linear_problem(
+                [(ws['v'], p['attention.cont2att.weight']), (ws['s'], p['attention.senti2att.weight']),
+                 (h1, p['attention.h2att.weight'])], ws['z'], p['attention.cont2att.bias'],
+                p['attention.senti2att.bias'], p['attention.h2att.bias'])])
+            ops.gate_mix_fwd(ws['z'], p['attention.att_alpha.weight'], p['attention.att_alpha.bias'],
+                             ws['v'], ws['s'], ws['f'], beta)
+            feat = ws['f']
+        else:
+            feat = ws['v'] if has_cont else ws['s']
+        Wih2, Whh2 = p['lang_lstm.weight_ih'], p['lang_lstm.weight_hh']
+        hdrop = self._new(rows, H) if out_mask is not None else None
+        ops.lstm_fwd([(feat, Wih2[:, 0:E]), (h1, Wih2[:, E:E + H]), (h_cur[1], Whh2)],
+                     p['lang_lstm.bias_ih'], p['lang_lstm.bias_hh'], c_cur[1], h_nxt[1], c_nxt[1],
+                     h_keep_mask=out_mask, mask_scale=out_scale, hdrop_out=hdrop)
+        ops.vocab_fwd(hdrop if hdrop is not None else h_nxt[1], p['classifier.weight'],
+                      p['classifier.bias'], ws['pmax'], ws['psum'], ws['pidx'], logits)
+
+    def _set_weights(self, aC, aS, bG, steps):
+        """attention._get_weights (captioner.py:83-94): per-step weights concatenated along dim 1."""
+        B = (aC if aC is not None else aS).shape[0]
+        self.cont_weights = aC[:, :steps].reshape(B, -1) if aC is not None else []
+        self.senti_weights = aS[:, :steps].reshape(B, -1) if aS is not None else []
+        self.cont_senti_weights = bG[:, :steps] if bG is not None else []
+
+    # ------------------------------------------------------------------ modes
+    def forward(self, *args, **kwargs):
+        mode = kwargs.pop('mode', 'xe')
+        return getattr(self, 'forward_' + mode)(*args, **kwargs)
+
+    def _needs_grad(self):
+        return torch.is_grad_enabled() and any(q.requires_grad for q in self.parameters())
+
+    def _teacher_forced(self, p, P, tokens_in, ss_prob, masks):
+        """Unroll feeding tokens_in[:, i] (with scheduled sampling in train mode,
+        captioner.py:218-234). Returns log-probs [B,T,V]."""
+        B, T = tokens_in.shape
+        V, Wd = self.vocab_size, self.settings['word_emb_dim']
+        R, Mw = P.R, P.Mw
+        h, c = [self._zeros(2, B, self.att_lstm.hidden_size) for _ in range(2)], \
+               [self._zeros(2, B, self.att_lstm.hidden_size) for _ in range(2)]
+        ws = self._alloc_step_ws(B, P)
+        out = self._new(B, T, V)
+        aC = self._new(B, T, R) if P.att_e3 is not None else None
+        aS = self._new(B, T, Mw) if P.words_e3 is not None else None
+        bG = self._new(B, T) if (aC is not None and aS is not None) else None
+        xt = self._new(B, Wd)
+        mask_for = self._mask_source(masks)
+        emb = p['word_embed.0.weight']
+        for i in range(T):
+            it = tokens_in[:, i]
+            if self.training and i >= 1 and ss_prob > 0.0:
+                sample_mask = torch.rand(B, device=self._dev) < ss_prob
+                if bool(sample_mask.any()):
+                    drawn = torch.multinomial(out[:, i - 1].detach().exp(), 1).view(-1)
+                    it = torch.where(sample_mask, drawn, it)
+            ops.embed_relu_fwd(emb, it.contiguous(), xt, add=P.label_e)
+            om, osc = mask_for('out%d' % i, B, self.att_lstm.hidden_size)
+            cur, nxt = i & 1, (i + 1) & 1
+            logits = out[:, i]
+            self._step(p, P, ws, xt, h[cur], c[cur], h[nxt], c[nxt],
+                       aC[:, i] if aC is not None else None, aS[:, i] if aS is not None else None,
+                       bG[:, i:i + 1] if bG is not None else None, logits, om, osc)
+            ops.logsoftmax_apply(logits, ws['pmax'], ws['psum'])
+        self._set_weights(aC, aS, bG, T)
+        return out
+
+    def forward_xe(self, fc_feats, att_feats, cpt_words, captions, senti_labels, ss_prob=0.0, _masks=None):
+        if self._needs_grad():
+            from .autograd import xe_with_grad
+            return xe_with_grad(self, 'xe', fc_feats, att_feats, cpt_words, None, captions, senti_labels,
+                                ss_prob, _masks)
+        p = self._p()
+        P = self._prologue(p, 'xe', fc_feats, att_feats, cpt_words, None, senti_labels, _masks)
+        return self._teacher_forced(p, P, self._ids(captions)[:, :-1], ss_prob, _masks)
+
+    def forward_seq2seq(self, senti_captions, cpt_words, senti_words, senti_labels, ss_prob=0.0, _masks=None):
+        if self._needs_grad():
+            from .autograd import xe_with_grad
+            return xe_with_grad(self, 'seq2seq', None, None, cpt_words, senti_words, senti_captions,
+                                senti_labels, ss_prob, _masks)
+        p = self._p()
+        P = self._prologue(p, 'seq2seq', None, None, cpt_words, senti_words, senti_labels, _masks)
+        return self._teacher_forced(p, P, self._ids(senti_captions)[:, :-1], ss_prob, _masks)
+
+    def forward_rl(self, fc_feats, att_feats, cpt_words, senti_words, senti_labels, max_seq_len, sample_max,
+                   _replay=None, _masks=None):
+        """Greedy (`sample_max=1`) or sampled roll-out (captioner.py:290-349) with the whole T-step loop
+        enqueued without a host sync; `_replay` [B,T] forces the raw draws (parity tests)."""
+        if not sample_max and self._needs_grad():
+            from .autograd import rollout_with_grad
+            return rollout_with_grad(self, fc_feats, att_feats, cpt_words, senti_words, senti_labels,
+                                     max_seq_len, _replay, _masks)
+        return self._rollout(fc_feats, att_feats, cpt_words, senti_words, senti_labels, max_seq_len,
+                             sample_max, _replay, _masks)[:3]
+
+    def _rollout(self, fc_feats, att_feats, cpt_words, senti_words, senti_labels, T, sample_max, replay,
+                 masks):
+        p = self._p()
+        P = self._prologue(p, 'rl', fc_feats, att_feats, cpt_words, senti_words, senti_labels, masks)
+        B, V = P.B, self.vocab_size
+        H, Wd = self.att_lstm.hidden_size, self.settings['word_emb_dim']
+        h = [self._zeros(2, B, H) for _ in range(2)]
+        c = [self._zeros(2, B, H) for _ in range(2)]
+        ws = self._alloc_step_ws(B, P)
+        seq = self._zeros(B, T, dtype=torch.int64)
+        seq_logprobs, seq_masks = self._zeros(B, T), self._zeros(B, T)
+        raw = self._zeros(B, T, dtype=torch.int64)
+        unfinished = torch.ones(B, dtype=torch.int32, device=self._dev)
+        alive = self._zeros(T + 1, dtype=torch.int32)
+        alive[0] = B
+        aC, aS, bG = self._zeros(B, T, P.R), self._zeros(B, T, P.Mw), self._zeros(B, T)
+        xt = [self._new(B, Wd) for _ in range(2)]
+        emb = p['word_embed.0.weight']
+        sos = torch.full((B,), self.sos_id, dtype=torch.int64, device=self._dev)
+        ops.embed_relu_fwd(emb, sos, xt[0], add=P.label_e)
+        need_logits = (not sample_max)
+        logits = self._new(B, V) if need_logits else None
+        forced = sample_u = None
+        if not sample_max:
+            if replay is not None:
+                forced = self._ids(replay)
+            else:
+                sample_u = torch.rand(B, T, device=self._dev)
+        mask_for = self._mask_source(masks)
+        rs = RolloutStep()
+        rs.B, rs.V, rs.T, rs.n_tile, rs.W = B, V, T, ws['pmax'].shape[1], Wd
+        rs.part_max, rs.part_sum, rs.part_idx = ws['pmax'].data_ptr(), ws['psum'].data_ptr(), ws['pidx'].data_ptr()
+        rs.logits, rs.ld_logits = ops.ptr(logits), V
+        rs.forced, rs.sample_u = ops.ptr(forced), ops.ptr(sample_u)
+        rs.eos_id = self.eos_id
+        rs.seq, rs.seq_logprobs, rs.seq_masks = seq.data_ptr(), seq_logprobs.data_ptr(), seq_masks.data_ptr()
+        rs.unfinished, rs.alive, rs.raw_tokens = unfinished.data_ptr(), alive.data_ptr(), raw.data_ptr()
+        rs.emb, rs.xt_add = emb.data_ptr(), ops.ptr(P.label_e)
+        for t in range(T):
+            cur, nxt = t & 1, (t + 1) & 1
+            om, osc = mask_for('out%d' % t, B, H)
+            self._step(p, P, ws, xt[cur], h[cur], c[cur], h[nxt], c[nxt], aC[:, t], aS[:, t], bG[:, t:t + 1],
+                       logits, om, osc)
+            rs.t = t
+            rs.xt_next = xt[nxt].data_ptr()
+            ops.rollout_finalize(rs)
+        # one host read per roll-out: number of steps the reference would have executed
+        alive_h = alive.cpu()
+        steps = T
+        for t in range(T):
+            if int(alive_h[t + 1]) == 0:
+                steps = t + 1
+                break
+        self._set_weights(aC, aS, bG, steps)
+        return seq, seq_logprobs, seq_masks, raw, steps
+
+    # ------------------------------------------------------------------ beam search
+    def sample(self, fc_feat, att_feat, senti_words=None, senti_label=None,
+               beam_size=3, decoding_constraint=1, max_seq_len=16):
+        """Beam search for ONE image (captioner.py:351-420): returns (captions, scores)."""
+        caps, scores, _ = self.sample_batch(
+            fc_feat.reshape(1, -1), att_feat.reshape(1, -1, att_feat.shape[-1]),
+            None if senti_words is None else senti_words.reshape(1, -1),
+            None if senti_label is None else senti_label.reshape(1),
+            beam_size, decoding_constraint, max_seq_len)
+        return caps[0], scores[0]
+
+    @torch.no_grad()
+    def sample_batch(self, fc_feats, att_feats, senti_words=None, senti_labels=None,
+                     beam_size=3, decoding_constraint=1, max_seq_len=16):
+        """Beam search for I images at once: every step runs ONE batched decode step over I*beam rows
+        and one device top-k; candidate bookkeeping follows the reference exactly (fp64 score sums,
+        stable ordering, ended beams carried, captioner.py:378-411).
+        Returns (captions[I][beam], scores[I][beam], id_sequences[I][beam])."""
+        from .beam import beam_search_batch
+        self.eval()
+        return beam_search_batch(self, fc_feats, att_feats, senti_words, senti_labels, beam_size,
+                                 decoding_constraint, max_seq_len)
+
+    def get_optim_criterion(self, lr, weight_decay=0):
+        return torch.optim.Adam(self.parameters(), lr=lr, weight_decay=weight_decay), \
+            XECriterion(), nn.MSELoss()  # xe, domain align
+
+
+class XECriterion(nn.Module):
+    """Masked NLL with a global token mean (captioner.py:427-440)."""
+
+    def forward(self, pred, target, lengths):
+        max_len = max(lengths)
+        if pred.size(1) != max_len:
+            raise ValueError('pred.size(1)=%d must equal max(lengths)=%d' % (pred.size(1), max_len))
+        if pred.requires_grad:
+            from .autograd import xe_criterion_with_grad
+            return xe_criterion_with_grad(pred, target, lengths)
+        ops.require_device(pred, target)
+        out2 = torch.empty(2, dtype=torch.float32, device=pred.device)
+        ln = torch.tensor(lengths, dtype=torch.int32, device=pred.device)
+        ops.xe_loss_fwd(pred.contiguous(), target.long().contiguous(), ln, out2)
+        return out2[0] / out2[1]

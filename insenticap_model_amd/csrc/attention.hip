@@ -1,0 +1,186 @@
+// Additive-attention scan and gate fusion (captioner.py:23-35, 50-62, 96-118) for gfx950.
+//
+// One 256-thread workgroup (4 wavefronts) per (batch row, scan problem).  The scan is the
+// HBM-bound part of the decode step: per row it streams P[b] (R x A projected features) and
+// V[b] (R x D features) exactly once - 2*R*512*4 B = 147,456 B for the 36-region content
+// scan - with 16-byte-per-lane coalesced loads (a wavefront reads one contiguous 1 KiB of a
+// region row per instruction), never writing the [B,R,A] tanh temporaries that the
+// reference's six separate torch ops re-read and re-write.
+//   phase 1  wave w scores regions w, w+4, ...:  e_r = w . tanh(P[b,r,:] + q[b,:] (+ q2[b,:]))
+//            (64-lane butterfly reduction, one score per wave-iteration)
+//   phase 2  softmax over the R scores in LDS
+//   phase 3  out[b,:] = sum_r alpha_r V[b,r,:]  (threads own a float4 of D; region groups are
+//            combined through LDS in a fixed order => deterministic)
+#include "common.h"
+
+struct DevScan {
+    const float *P, *V, *q, *q2, *w, *w_bias;
+    int R, A, D;
+    float *out, *alpha_out;
+    long long alpha_ld;
+};
+struct DevScanLaunch {
+    DevScan p[2];
+};
+
+template <int NA>  // float4 per lane along A: A <= 256*NA
+__global__ __launch_bounds__(256) void attn_scan_kernel(const DevScanLaunch L) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const DevScan &S = L.p[blockIdx.y];
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int R = S.R, A = S.A, D = S.D;
+    float *sc = smem;                      // [R] scores -> alphas
+    float *part = smem + ((R + 3) & ~3);   // [ngrp][D] partial weighted sums
+
+    // ---- phase 1: scores
+    const int na4 = A >> 2;
+    float4 qv[NA], wv[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int a4 = lane + 64 * i;
+        if (a4 < na4) {
+            qv[i] = reinterpret_cast<const float4 *>(S.q + (long long)b * A)[a4];
+            if (S.q2) {
+                const float4 t = reinterpret_cast<const float4 *>(S.q2 + (long long)b * A)[a4];
+                qv[i].x += t.x; qv[i].y += t.y; qv[i].z += t.z; qv[i].w += t.w;
+            }
+            wv[i] = reinterpret_cast<const float4 *>(S.w)[a4];
+        } else {
+            qv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            wv[i] = qv[i];
+        }
+    }
+    const float4 *Pb = reinterpret_cast<const float4 *>(S.P + (long long)b * R * A);
+    const float w_bias = S.w_bias ? S.w_bias[0] : 0.f;
+    for (int r = wave; r < R; r += 4) {
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int a4 = lane + 64 * i;
+            if (a4 < na4) {
+                const float4 p = Pb[(long long)r * na4 + a4];
+                acc += wv[i].x * tanhf(p.x + qv[i].x);
+                acc += wv[i].y * tanhf(p.y + qv[i].y);
+                acc += wv[i].z * tanhf(p.z + qv[i].z);
+                acc += wv[i].w * tanhf(p.w + qv[i].w);
+            }
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) sc[r] = acc + w_bias;
+    }
+    __syncthreads();
+
+    // ---- phase 2: softmax (every thread redundantly folds the R scores: LDS broadcasts)
+    float mx = -INFINITY;
+    for (int r = 0; r < R; ++r) mx = fmaxf(mx, sc[r]);
+    float z = 0.f;
+    for (int r = 0; r < R; ++r) z += expf(sc[r] - mx);
+    const float inv = 1.0f / z;
+    __syncthreads();
+    for (int r = tid; r < R; r += 256) {
+        const float a = expf(sc[r] - mx) * inv;
+        sc[r] = a;
+        if (S.alpha_out) S.alpha_out[(long long)b * S.alpha_ld + r] = a;
+    }
+    __syncthreads();
+
+    // ---- phase 3: weighted sum
+    const int nd4 = D >> 2;
+    const float4 *Vb = reinterpret_cast<const float4 *>(S.V + (long long)b * R * D);
+    if (nd4 <= 256) {
+        const int ngrp = 256 / nd4;             // region groups working in parallel
+        const int d4 = tid % nd4, grp = tid / nd4;
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (grp < ngrp) {
+            for (int r = grp; r < R; r += ngrp) {
+                const float a = sc[r];
+                const float4 v = Vb[(long long)r * nd4 + d4];
+                o.x += a * v.x; o.y += a * v.y; o.z += a * v.z; o.w += a * v.w;
+            }
+            reinterpret_cast<float4 *>(part)[grp * nd4 + d4] = o;
+        }
+        __syncthreads();
+        if (tid < nd4) {
+            float4 s = reinterpret_cast<float4 *>(part)[tid];
+            for (int g = 1; g < ngrp; ++g) {
+                const float4 v = reinterpret_cast<float4 *>(part)[g * nd4 + tid];
+                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            }
+            reinterpret_cast<float4 *>(S.out + (long long)b * D)[tid] = s;
+        }
+    } else {
+        for (int d4 = tid; d4 < nd4; d4 += 256) {
+            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int r = 0; r < R; ++r) {
+                const float a = sc[r];
+                const float4 v = Vb[(long long)r * nd4 + d4];
+                o.x += a * v.x; o.y += a * v.y; o.z += a * v.z; o.w += a * v.w;
+            }
+            reinterpret_cast<float4 *>(S.out + (long long)b * D)[d4] = o;
+        }
+    }
+}
+
+extern "C" int isc_attn_scan_fwd(const isc_scan_problem *pr, int n_prob, int B, void *stream) {
+    if (!pr) return ISC_E_NULL;
+    if (n_prob < 1 || n_prob > 2 || B <= 0) return ISC_E_SHAPE;
+    DevScanLaunch L = {};
+    int maxA = 0;
+    size_t lds = 0;
+    for (int i = 0; i < n_prob; ++i) {
+        const isc_scan_problem &q = pr[i];
+        if (!q.P || !q.V || !q.q || !q.w || !q.out) return ISC_E_NULL;
+        if (q.R <= 0 || q.A <= 0 || q.D <= 0 || (q.A & 3) || (q.D & 3) || q.A > 1024) return ISC_E_SHAPE;
+        if (!isc_aligned16(q.P) || !isc_aligned16(q.V) || !isc_aligned16(q.q) || !isc_aligned16(q.w) ||
+            !isc_aligned16(q.out) || (q.q2 && !isc_aligned16(q.q2)))
+            return ISC_E_ALIGN;
+        DevScan &d = L.p[i];
+        d.P = q.P; d.V = q.V; d.q = q.q; d.q2 = q.q2; d.w = q.w; d.w_bias = q.w_bias;
+        d.R = q.R; d.A = q.A; d.D = q.D; d.out = q.out; d.alpha_out = q.alpha_out; d.alpha_ld = q.alpha_ld;
+        if (q.A > maxA) maxA = q.A;
+        const int nd4 = q.D / 4;
+        const size_t part = nd4 <= 256 ? (size_t)(256 / nd4) * q.D : 0;
+        const size_t need = (((size_t)q.R + 3) & ~(size_t)3) + part;
+        if (need > lds) lds = need;
+    }
+    lds *= sizeof(float);
+    if (lds > 60000) return ISC_E_SHAPE;
+    dim3 grid(B, n_prob), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (maxA <= 256) hipLaunchKernelGGL(attn_scan_kernel<1>, grid, block, lds, st, L);
+    else if (maxA <= 512) hipLaunchKernelGGL(attn_scan_kernel<2>, grid, block, lds, st, L);
+    else hipLaunchKernelGGL(attn_scan_kernel<4>, grid, block, lds, st, L);
+    ISC_LAUNCH_CHECK();
+    return ISC_OK;
+}
+
+// beta = sigmoid(w . tanh(z) + w_bias); out = beta*v + (1-beta)*s.  One wavefront per row.
+__global__ __launch_bounds__(256) void gate_mix_kernel(const float *z, const float *w, const float *w_bias,
+                                                       const float *v, const float *s, int B, int A,
+                                                       int D, float *out, float *beta_out,
+                                                       long long beta_ld) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    float acc = 0.f;
+    for (int a = lane; a < A; a += 64) acc += w[a] * tanhf(z[(long long)b * A + a]);
+    acc = wave_sum(acc);
+    const float beta = isc_sigmoid(acc + (w_bias ? w_bias[0] : 0.f));
+    if (lane == 0 && beta_out) beta_out[(long long)b * beta_ld] = beta;
+    for (int d = lane; d < D; d += 64) {
+        const long long o = (long long)b * D + d;
+        out[o] = beta * v[o] + (1.0f - beta) * s[o];
+    }
+}
+
+extern "C" int isc_gate_mix_fwd(const float *z, const float *w, const float *w_bias, const float *v,
+                                const float *s, int B, int A, int D, float *out, float *beta_out,
+                                int64_t beta_ld, void *stream) {
+    if (!z || !w || !v || !s || !out) return ISC_E_NULL;
+    if (B <= 0 || A <= 0 || D <= 0) return ISC_E_SHAPE;
+    hipLaunchKernelGGL(gate_mix_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, z, w,
+                       w_bias, v, s, B, A, D, out, beta_out, (long long)beta_ld);
+    ISC_LAUNCH_CHECK();
+    return ISC_OK;
+}

@@ -1,0 +1,416 @@
+// fp32 MFMA (v_mfma_f32_32x32x2_f32) grouped, K-segmented "NT" GEMM with fused epilogues.
+//
+//   acc[M,N] = sum_s A_s[M,K_s] * W_s[N,K_s]^T          (s = up to 4 K-segments)
+//
+// K-segments replace the reference's torch.cat([...],1) in front of nn.LSTMCell / nn.Linear
+// (captioner.py:174,180 and the three summed projections of :107-110): no concatenated
+// activation buffer and no packed weight copy is ever materialised - every segment reads the
+// caller's tensors where they live.  Up to 3 independent problems share one launch.
+//
+// Tiling for gfx950: 256-thread workgroup = 4 wavefronts of 64; each wave owns a
+// 32 x (32*TN) accumulator built from 32x32x2 fp32 MFMAs (exact fp32 FMA chains, so the
+// result matches an fp32 CPU GEMM to rounding-order noise - bf16/TF32-like paths would
+// break the 1e-4 log-prob parity bound).  Two tile shapes:
+//   L: 128 x 128 (4 waves stacked in M, TN=4)  - batch-sized problems
+//   S:  32 x 128 (4 waves side by side in N)   - small-M problems (beam rows, B<=128)
+// K is consumed in 32-wide chunks, global -> registers -> LDS (double buffered, rows padded
+// to 36 floats so that the ds_read_b128 fragment reads are bank-conflict free), one
+// barrier per chunk.  The finished tile is staged through LDS once so that every epilogue
+// sees (row, col) coordinates and writes full, coalesced rows.
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define BK 32
+#define LDT 36  // padded LDS row (floats): 36*r mod 64 is a distinct multiple of 4 for 16 rows
+
+enum { EPI_LINEAR = 0, EPI_LSTM = 1, EPI_VOCAB = 2 };
+
+struct DevSeg {
+    const float *A;
+    const float *W;
+    int lda, ldw, K, pad;
+};
+
+struct DevProb {
+    DevSeg seg[ISC_MAX_SEG];
+    int nseg, M, N, relu;
+    const float *bias0, *bias1, *bias2;
+    const uint8_t *mask;
+    float mask_scale;
+    int ldc;
+    float *C, *C_pre;
+    // lstm
+    const float *c_prev;
+    float *h_out, *c_out, *gates_out, *hdrop;
+    const uint8_t *hmask;
+    int H, m_fastest;
+    // vocab
+    float *pmax, *psum;
+    int *pidx;
+    long long ld_logits;
+    int tiles_m, tiles_n, tile_start, ntile_total;
+};
+
+struct DevLaunch {
+    DevProb p[3];
+    int nprob, total_tiles;
+};
+
+template <int WM, int WN, int TN, int EPI>
+__global__ __launch_bounds__(256) void gemm_kernel(const DevLaunch L) {
+    constexpr int BM = 32 * WM;
+    constexpr int BN = 32 * TN * WN;
+    constexpr int LDC = BN + 4;
+    constexpr int A_LD = BM / 32;  // float4 loads per thread per chunk
+    constexpr int B_LD = BN / 32;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *As = smem;                    // [2][BM][LDT]
+    float *Bs = smem + 2 * BM * LDT;     // [2][BN][LDT]
+    float *Cs = smem;                    // [BM][LDC] (after the K loop)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+
+    // XCD-aware tile order: blocks with equal blockIdx%8 share an XCD (and its L2); give each
+    // XCD one contiguous run of logical tiles so that neighbours re-use A / W panels from L2.
+    int logical;
+    {
+        const int nt = L.total_tiles, bid = blockIdx.x;
+        const int q = nt >> 3, r = nt & 7, xcd = bid & 7, j = bid >> 3;
+        logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    }
+    int pi = 0;
+    if (L.nprob > 1 && logical >= L.p[1].tile_start) pi = 1;
+    if (L.nprob > 2 && logical >= L.p[2].tile_start) pi = 2;
+    const DevProb &P = L.p[pi];
+    const int t = logical - P.tile_start;
+    int tm, tn;
+    if (P.m_fastest) { tm = t % P.tiles_m; tn = t / P.tiles_m; }
+    else             { tm = t / P.tiles_n; tn = t % P.tiles_n; }
+    const int M = P.M, N = P.N;
+    const int row0 = tm * BM, col0 = tn * BN;
+
+    // global-load coordinates: thread -> (row = tid/8 + 32*i, 16-byte column c4 = tid%8)
+    const int lr = tid >> 3, lc = (tid & 7) * 4;
+    // weight row of tile row n: LSTM tiles interleave the 4 gates of 32 hidden units
+    long long wrow[B_LD];
+    bool wok[B_LD];
+#pragma unroll
+    for (int i = 0; i < B_LD; ++i) {
+        const int n = lr + 32 * i;
+        if (EPI == EPI_LSTM) {
+            wrow[i] = (long long)(n >> 5) * P.H + tn * 32 + (n & 31);
+            wok[i] = true;
+        } else {
+            wrow[i] = col0 + n;
+            wok[i] = (col0 + n) < N;
+        }
+    }
+    bool aok[A_LD];
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i) aok[i] = (row0 + lr + 32 * i) < M;
+
+    f32x16 acc[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    int nchunks = 0;
+    for (int s = 0; s < P.nseg; ++s) nchunks += P.seg[s].K / BK;
+
+    float4 ra[A_LD], rb[B_LD];
+    int cs = 0, ck = 0;  // segment / k-offset of the chunk being loaded
+    auto gload = [&]() {
+        const DevSeg sg = P.seg[cs];
+        const float *Ab = sg.A + (long long)(row0 + lr) * sg.lda + ck + lc;
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i)
+            ra[i] = aok[i] ? *reinterpret_cast<const float4 *>(Ab + (long long)(32 * i) * sg.lda)
+                           : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < B_LD; ++i)
+            rb[i] = wok[i] ? *reinterpret_cast<const float4 *>(sg.W + wrow[i] * sg.ldw + ck + lc)
+                           : make_float4(0.f, 0.f, 0.f, 0.f);
+        ck += BK;
+        if (ck >= sg.K) { ck = 0; ++cs; }
+    };
+    auto sstore = [&](int buf) {
+        float *a = As + buf * BM * LDT + lr * LDT + lc;
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i) *reinterpret_cast<float4 *>(a + 32 * i * LDT) = ra[i];
+        float *b = Bs + buf * BN * LDT + lr * LDT + lc;
+#pragma unroll
+        for (int i = 0; i < B_LD; ++i) *reinterpret_cast<float4 *>(b + 32 * i * LDT) = rb[i];
+    };
+
+    gload();
+    sstore(0);
+    __syncthreads();
+
+    const int frow = lane & 31, fk = (lane >> 5) * 4;
+    for (int c = 0; c < nchunks; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < nchunks) gload();
+        const float *a_base = As + buf * BM * LDT + (wm * 32 + frow) * LDT + fk;
+        const float *b_base = Bs + buf * BN * LDT + (wn * TN * 32 + frow) * LDT + fk;
+#pragma unroll
+        for (int kb = 0; kb < BK / 8; ++kb) {
+            const float4 a = *reinterpret_cast<const float4 *>(a_base + kb * 8);
+            float4 b[TN];
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                b[j] = *reinterpret_cast<const float4 *>(b_base + j * 32 * LDT + kb * 8);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[j].x, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[j].y, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[j].z, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[j].w, acc[j], 0, 0, 0);
+            }
+        }
+        if (c + 1 < nchunks) sstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    // stage the tile: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const int col = (wn * TN + j) * 32 + (lane & 31);
+            Cs[row * LDC + col] = acc[j][r];
+        }
+    __syncthreads();
+
+    if (EPI == EPI_LINEAR) {
+        const bool vec = (P.ldc & 3) == 0;
+        for (int idx = tid; idx < BM * (BN / 4); idx += 256) {
+            const int row = idx / (BN / 4), c4 = (idx % (BN / 4)) * 4;
+            const int gm = row0 + row, gn = col0 + c4;
+            if (gm >= M || gn >= N) continue;
+            float4 v = *reinterpret_cast<const float4 *>(Cs + row * LDC + c4);
+            float o[4] = {v.x, v.y, v.z, v.w}, pre[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int n = gn + e;
+                if (n < N) {
+                    if (P.bias0) o[e] += P.bias0[n];
+                    if (P.bias1) o[e] += P.bias1[n];
+                    if (P.bias2) o[e] += P.bias2[n];
+                    if (P.relu) o[e] = fmaxf(o[e], 0.f);
+                    pre[e] = o[e];
+                    if (P.mask) o[e] = o[e] * (float)P.mask[(long long)gm * N + n] * P.mask_scale;
+                }
+            }
+            float *dst = P.C + (long long)gm * P.ldc + gn;
+            if (vec && gn + 3 < N) {
+                *reinterpret_cast<float4 *>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+                if (P.C_pre)
+                    *reinterpret_cast<float4 *>(P.C_pre + (long long)gm * P.ldc + gn) =
+                        make_float4(pre[0], pre[1], pre[2], pre[3]);
+            } else {
+                for (int e = 0; e < 4 && gn + e < N; ++e) {
+                    dst[e] = o[e];
+                    if (P.C_pre) P.C_pre[(long long)gm * P.ldc + gn + e] = pre[e];
+                }
+            }
+        }
+    } else if (EPI == EPI_LSTM) {
+        const int H = P.H;
+        for (int idx = tid; idx < BM * 32; idx += 256) {
+            const int row = idx >> 5, u = idx & 31;
+            const int gm = row0 + row, unit = tn * 32 + u;
+            if (gm >= M) continue;
+            const float *cr = Cs + row * LDC + u;
+            float gi = cr[0] + P.bias0[unit] + P.bias1[unit];
+            float gf = cr[32] + P.bias0[H + unit] + P.bias1[H + unit];
+            float gg = cr[64] + P.bias0[2 * H + unit] + P.bias1[2 * H + unit];
+            float go = cr[96] + P.bias0[3 * H + unit] + P.bias1[3 * H + unit];
+            gi = isc_sigmoid(gi);
+            gf = isc_sigmoid(gf);
+            gg = tanhf(gg);
+            go = isc_sigmoid(go);
+            const long long o = (long long)gm * H + unit;
+            const float c2 = gf * P.c_prev[o] + gi * gg;
+            const float h2 = go * tanhf(c2);
+            P.c_out[o] = c2;
+            P.h_out[o] = h2;
+            if (P.hmask) P.hdrop[o] = h2 * (float)P.hmask[o] * P.mask_scale;
+            if (P.gates_out) {
+                float *g = P.gates_out + (long long)gm * 4 * H + unit;
+                g[0] = gi; g[H] = gf; g[2 * H] = gg; g[3 * H] = go;
+            }
+        }
+    } else {  // EPI_VOCAB
+        const bool vec = P.C && (P.ld_logits & 3) == 0;
+        // bias add (+ optional logits store), -inf beyond the vocabulary
+        for (int idx = tid; idx < BM * (BN / 4); idx += 256) {
+            const int row = idx / (BN / 4), c4 = (idx % (BN / 4)) * 4;
+            const int gm = row0 + row, gn = col0 + c4;
+            float *cp = Cs + row * LDC + c4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) cp[e] = (gn + e < N) ? cp[e] + P.bias0[gn + e] : -INFINITY;
+            if (P.C && gm < M && gn < N) {
+                float *dst = P.C + (long long)gm * P.ld_logits + gn;
+                if (vec && gn + 3 < N) *reinterpret_cast<float4 *>(dst) = *reinterpret_cast<float4 *>(cp);
+                else for (int e = 0; e < 4 && gn + e < N; ++e) dst[e] = cp[e];
+            }
+        }
+        __syncthreads();
+        // per-row tile statistics: each wave owns BM/4 rows, a lane owns columns lane, lane+64
+        for (int rr = 0; rr < BM / 4; ++rr) {
+            const int row = wave * (BM / 4) + rr, gm = row0 + row;
+            if (gm >= M) break;  // wave-uniform
+            const float v0 = Cs[row * LDC + lane], v1 = Cs[row * LDC + 64 + lane];
+            float mx = v0; int ix = lane;
+            if (v1 > mx) { mx = v1; ix = lane + 64; }
+            wave_argmax(mx, ix);
+            const float s = wave_sum(expf(v0 - mx) + expf(v1 - mx));
+            if (lane == 0) {
+                const long long o = (long long)gm * P.ntile_total + tn;
+                P.pmax[o] = mx;
+                P.psum[o] = s;
+                P.pidx[o] = col0 + ix;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- host side
+static int check_segs(const isc_seg *seg, int nseg) {
+    if (nseg < 1 || nseg > ISC_MAX_SEG) return ISC_E_SHAPE;
+    for (int s = 0; s < nseg; ++s) {
+        if (!seg[s].A || !seg[s].W) return ISC_E_NULL;
+        if (seg[s].K <= 0 || (seg[s].K % BK) != 0) return ISC_E_SHAPE;
+        if ((seg[s].lda & 3) || (seg[s].ldw & 3)) return ISC_E_ALIGN;
+        if (!isc_aligned16(seg[s].A) || !isc_aligned16(seg[s].W)) return ISC_E_ALIGN;
+    }
+    return ISC_OK;
+}
+
+static void copy_segs(DevProb &d, const isc_seg *seg, int nseg) {
+    d.nseg = nseg;
+    for (int s = 0; s < nseg; ++s) {
+        d.seg[s].A = seg[s].A; d.seg[s].W = seg[s].W;
+        d.seg[s].lda = seg[s].lda; d.seg[s].ldw = seg[s].ldw; d.seg[s].K = seg[s].K; d.seg[s].pad = 0;
+    }
+}
+
+template <int WM, int WN, int TN, int EPI>
+static int launch_cfg(const DevLaunch &L, hipStream_t st) {
+    constexpr int BM = 32 * WM, BN = 32 * TN * WN;
+    constexpr size_t k_bytes = (size_t)2 * (BM + BN) * LDT * sizeof(float);
+    constexpr size_t c_bytes = (size_t)BM * (BN + 4) * sizeof(float);
+    constexpr size_t lds = k_bytes > c_bytes ? k_bytes : c_bytes;
+    static bool attr_set = false;  // idempotent; a benign race only repeats the same call
+    if (!attr_set && lds > 65536) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_kernel<WM, WN, TN, EPI>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_kernel<WM, WN, TN, EPI>), dim3(L.total_tiles), dim3(256), lds, st, L);
+    ISC_LAUNCH_CHECK();
+    return ISC_OK;
+}
+
+// Tile shape choice: the 128x128 tile needs >= ~1 tile per CU to pay; below that the
+// 32-row tile quadruples the number of workgroups.
+static bool use_small_tile(long long tiles_large, int max_m) {
+    return max_m <= 64 || tiles_large < 160;
+}
+
+static void finish_tiling(DevLaunch &L, bool small) {
+    const int BM = small ? 32 : 128, BN = 128;
+    int start = 0;
+    for (int i = 0; i < L.nprob; ++i) {
+        DevProb &p = L.p[i];
+        p.tiles_m = (p.M + BM - 1) / BM;
+        p.tiles_n = (p.N + BN - 1) / BN;
+        p.tile_start = start;
+        long long wbytes = 0, abytes = 0;
+        for (int s = 0; s < p.nseg; ++s) { wbytes += (long long)p.N * p.seg[s].K; abytes += (long long)p.M * p.seg[s].K; }
+        p.m_fastest = wbytes > abytes;  // partition the larger operand across XCDs
+        start += p.tiles_m * p.tiles_n;
+    }
+    L.total_tiles = start;
+}
+
+extern "C" int isc_linear_fwd(const isc_linear_problem *pr, int n_prob, void *stream) {
+    if (!pr) return ISC_E_NULL;
+    if (n_prob < 1 || n_prob > 3) return ISC_E_SHAPE;
+    DevLaunch L = {};
+    L.nprob = n_prob;
+    long long tiles_large = 0;
+    int max_m = 0;
+    for (int i = 0; i < n_prob; ++i) {
+        const isc_linear_problem &q = pr[i];
+        int rc = check_segs(q.seg, q.nseg);
+        if (rc) return rc;
+        if (!q.C) return ISC_E_NULL;
+        if (q.M <= 0 || q.N <= 0) return ISC_E_SHAPE;
+        if (q.keep_mask && q.ldc != q.N) return ISC_E_SHAPE;
+        DevProb &d = L.p[i];
+        copy_segs(d, q.seg, q.nseg);
+        d.M = q.M; d.N = q.N; d.relu = q.relu;
+        d.bias0 = q.bias0; d.bias1 = q.bias1; d.bias2 = q.bias2;
+        d.mask = q.keep_mask; d.mask_scale = q.mask_scale;
+        d.ldc = q.ldc; d.C = q.C; d.C_pre = q.C_pre;
+        tiles_large += (long long)((q.M + 127) / 128) * ((q.N + 127) / 128);
+        if (q.M > max_m) max_m = q.M;
+    }
+    const bool small = use_small_tile(tiles_large, max_m);
+    finish_tiling(L, small);
+    return small ? launch_cfg<1, 4, 1, EPI_LINEAR>(L, (hipStream_t)stream)
+                 : launch_cfg<4, 1, 4, EPI_LINEAR>(L, (hipStream_t)stream);
+}
+
+extern "C" int isc_lstm_fwd(const isc_lstm_problem *q, void *stream) {
+    if (!q) return ISC_E_NULL;
+    int rc = check_segs(q->seg, q->nseg);
+    if (rc) return rc;
+    if (!q->b_ih || !q->b_hh || !q->c_prev || !q->h_out || !q->c_out) return ISC_E_NULL;
+    if (q->M <= 0 || q->H <= 0 || (q->H % 32) != 0) return ISC_E_SHAPE;
+    if (q->h_keep_mask && !q->hdrop_out) return ISC_E_NULL;
+    DevLaunch L = {};
+    L.nprob = 1;
+    DevProb &d = L.p[0];
+    copy_segs(d, q->seg, q->nseg);
+    d.M = q->M; d.N = 4 * q->H; d.H = q->H;
+    d.bias0 = q->b_ih; d.bias1 = q->b_hh;
+    d.c_prev = q->c_prev; d.h_out = q->h_out; d.c_out = q->c_out; d.gates_out = q->gates_out;
+    d.hmask = q->h_keep_mask; d.mask_scale = q->mask_scale; d.hdrop = q->hdrop_out;
+    const long long tiles_large = (long long)((q->M + 127) / 128) * (q->H / 32);
+    const bool small = use_small_tile(tiles_large, q->M);
+    finish_tiling(L, small);
+    return small ? launch_cfg<1, 4, 1, EPI_LSTM>(L, (hipStream_t)stream)
+                 : launch_cfg<4, 1, 4, EPI_LSTM>(L, (hipStream_t)stream);
+}
+
+extern "C" int isc_vocab_fwd(const float *h, int ldh, const float *W, int ldw, const float *bias,
+                             int M, int V, int K, float *logits, int64_t ld_logits,
+                             float *part_max, float *part_sum, int32_t *part_idx, void *stream) {
+    if (!h || !W || !bias || !part_max || !part_sum || !part_idx) return ISC_E_NULL;
+    isc_seg sg = {h, W, ldh, ldw, K, 0};
+    int rc = check_segs(&sg, 1);
+    if (rc) return rc;
+    if (M <= 0 || V <= 0) return ISC_E_SHAPE;
+    DevLaunch L = {};
+    L.nprob = 1;
+    DevProb &d = L.p[0];
+    copy_segs(d, &sg, 1);
+    d.M = M; d.N = V; d.bias0 = bias;
+    d.C = logits; d.ld_logits = ld_logits;
+    d.pmax = part_max; d.psum = part_sum; d.pidx = part_idx;
+    d.ntile_total = (V + 127) / 128;
+    const long long tiles_large = (long long)((M + 127) / 128) * d.ntile_total;
+    const bool small = use_small_tile(tiles_large, M);
+    finish_tiling(L, small);
+    return small ? launch_cfg<1, 4, 1, EPI_VOCAB>(L, (hipStream_t)stream)
+                 : launch_cfg<4, 1, 4, EPI_VOCAB>(L, (hipStream_t)stream);
+}

@@ -1,0 +1,357 @@
+// Embedding gathers, roll-out bookkeeping, log-softmax finalisation, beam top-k and the
+// masked-NLL criterion (captioner.py:170-172, 201-202, 307-311, 329-344, 394-408, 427-440).
+#include "common.h"
+
+// ------------------------------------------------------------------ embeddings
+__global__ __launch_bounds__(256) void embed_relu_kernel(const float *emb, int W, const int64_t *ids,
+                                                         long long ids_stride, const float *add,
+                                                         int B, float *out) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const long long id = ids[(long long)b * ids_stride];
+    const float4 *src = reinterpret_cast<const float4 *>(emb + id * W);
+    const float4 *ad = add ? reinterpret_cast<const float4 *>(add + (long long)b * W) : nullptr;
+    float4 *dst = reinterpret_cast<float4 *>(out + (long long)b * W);
+    for (int i = lane; i < (W >> 2); i += 64) {
+        float4 v = src[i];
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        if (ad) { const float4 a = ad[i]; v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w; }
+        dst[i] = v;
+    }
+}
+
+extern "C" int isc_embed_relu_fwd(const float *emb, int V, int W, const int64_t *ids,
+                                  int64_t ids_stride, const float *add, int B, float *out,
+                                  void *stream) {
+    if (!emb || !ids || !out) return ISC_E_NULL;
+    if (B <= 0 || V <= 0 || W <= 0 || (W & 3)) return ISC_E_SHAPE;
+    hipLaunchKernelGGL(embed_relu_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, emb, W,
+                       ids, (long long)ids_stride, add, B, out);
+    ISC_LAUNCH_CHECK();
+    return ISC_OK;
+}
+
+__global__ __launch_bounds__(256) void embed_relu_mean_kernel(const float *emb, int W, const int64_t *ids,
+                                                              int C, int B, float *out) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    for (int i = lane; i < W; i += 64) {
+        float s = 0.f;
+        for (int c = 0; c < C; ++c) s += fmaxf(emb[ids[(long long)b * C + c] * W + i], 0.f);
+        out[(long long)b * W + i] = s / (float)C;
+    }
+}
+
+extern "C" int isc_embed_relu_mean_fwd(const float *emb, int V, int W, const int64_t *ids, int C,
+                                       int B, float *out, void *stream) {
+    if (!emb || !ids || !out) return ISC_E_NULL;
+    if (B <= 0 || V <= 0 || W <= 0 || C <= 0) return ISC_E_SHAPE;
+    hipLaunchKernelGGL(embed_relu_mean_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream,
+                       emb, W, ids, C, B, out);
+    ISC_LAUNCH_CHECK();
+    return ISC_OK;
+}
+
+__global__ __launch_bounds__(256) void embed_senti_words_kernel(const float *emb, int W,
+                                                                const int64_t *ids, int n_words,
+                                                                long long pad_id, int B,
+                                                                const uint8_t *mask, float scale,
+                                                                float *out) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);  // row = b*(n_words+1) + m
+    const int Mw = n_words + 1;
+    if (row >= B * Mw) return;
+    const int b = row / Mw, m = row % Mw;
+    const long long id = (m == 0) ? pad_id : ids[(long long)b * n_words + (m - 1)];
+    for (int i = lane; i < W; i += 64) {
+        float v = fmaxf(emb[id * W + i], 0.f);
+        if (mask) v = v * (float)mask[(long long)row * W + i] * scale;
+        out[(long long)row * W + i] = v;
+    }
+}
+
+extern "C" int isc_embed_senti_words_fwd(const float *emb, int V, int W, const int64_t *ids,
+                                         int n_words, int64_t pad_id, int B,
+                                         const uint8_t *keep_mask, float mask_scale, float *out,
+                                         void *stream) {
+    if (!emb || !ids || !out) return ISC_E_NULL;
+    if (B <= 0 || V <= 0 || W <= 0 || n_words <= 0) return ISC_E_SHAPE;
+    const int rows = B * (n_words + 1);
+    hipLaunchKernelGGL(embed_senti_words_kernel, dim3((rows + 3) / 4), dim3(256), 0,
+                       (hipStream_t)stream, emb, W, ids, n_words, (long long)pad_id, B, keep_mask,
+                       mask_scale, out);
+    ISC_LAUNCH_CHECK();
+    return ISC_OK;
+}
+
+// ------------------------------------------------------------------ row statistics helper
+// Folds the per-tile (max, sumexp, argmax) triples of one row: returns the global max, its
+// vocabulary index (smallest index on ties) and S = sum exp(x - gmax).  All 64 lanes get
+// the result.
+__device__ __forceinline__ void fold_row_stats(const float *pmax, const float *psum, const int *pidx,
+                                               int n_tile, int lane, float &gmax, int &gidx, float &S) {
+    float mx = -INFINITY;
+    int ix = 0x7fffffff;
+    for (int i = lane; i < n_tile; i += 64) {
+        const float v = pmax[i];
+        const int id = pidx ? pidx[i] : i;
+        if (v > mx || (v == mx && id < ix)) { mx = v; ix = id; }
+    }
+    wave_argmax(mx, ix);
+    float s = 0.f;
+    for (int i = lane; i < n_tile; i += 64) s += psum[i] * expf(pmax[i] - mx);
+    S = wave_sum(s);
+    gmax = mx;
+    gidx = ix;
+}
+
+// ------------------------------------------------------------------ roll-out step
+struct DevRollout {
+    int B, V, T, t, n_tile, W;
+    const float *part_max, *part_sum;
+    const int *part_idx;
+    const float *logits;
+    long long ld_logits;
+    const int64_t *forced;
+    const float *sample_u;
+    long long eos_id;
+    int64_t *seq;
+    float *seq_logprobs, *seq_masks;
+    int *unfinished, *alive;
+    int64_t *raw_tokens;
+    const float *emb, *xt_add;
+    float *xt_next;
+};
+
+__global__ __launch_bounds__(256) void rollout_finalize_kernel(const DevRollout R) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= R.B) return;
+    // the reference `break`s once no row is unfinished (captioner.py:343-344): later steps
+    // leave seq / seq_logprobs / seq_masks at their zero initialisation
+    if (R.alive[R.t] == 0) return;
+    float gmax, S;
+    int gidx;
+    fold_row_stats(R.part_max + (long long)b * R.n_tile, R.part_sum + (long long)b * R.n_tile,
+                   R.part_idx + (long long)b * R.n_tile, R.n_tile, lane, gmax, gidx, S);
+    const float logS = logf(S);
+    long long it;
+    float lp;
+    if (R.forced) {
+        it = R.forced[(long long)b * R.T + R.t];
+        lp = (R.logits[(long long)b * R.ld_logits + it] - gmax) - logS;
+    } else if (R.sample_u) {
+        // inverse-CDF sampling from softmax(logits) with a caller-supplied uniform
+        const float target = R.sample_u[(long long)b * R.T + R.t] * S;
+        const float *x = R.logits + (long long)b * R.ld_logits;
+        float run = 0.f;
+        int pick = -1;
+        for (int base = 0; base < R.V && pick < 0; base += 64) {
+            const int i = base + lane;
+            const float e = (i < R.V) ? expf(x[i] - gmax) : 0.f;
+            float incl = e;  // inclusive prefix sum over the wave
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const float n = __shfl_up(incl, o, 64);
+                if (lane >= o) incl += n;
+            }
+            const unsigned long long hit = __ballot((run + incl > target) && i < R.V);
+            if (hit) pick = base + __ffsll((long long)hit) - 1;
+            run += __shfl(incl, 63, 64);
+        }
+        if (pick < 0) pick = gidx;  // target == S after rounding
+        it = pick;
+        lp = (x[it] - gmax) - logS;
+    } else {
+        it = gidx;
+        lp = -logS;  // log_softmax at the arg-max: (x_max - x_max) - log S
+    }
+    const int u = R.unfinished[b];
+    const long long itm = u ? it : 0;  // finished rows feed <PAD> (id 0): `it * unfinished`
+    const int u2 = u && (itm != R.eos_id);
+    if (lane == 0) {
+        const long long o = (long long)b * R.T + R.t;
+        R.seq_masks[o] = (float)u;
+        R.seq[o] = itm;
+        R.seq_logprobs[o] = lp;
+        if (R.raw_tokens) R.raw_tokens[o] = it;
+        R.unfinished[b] = u2;
+        if (u2) atomicAdd(&R.alive[R.t + 1], 1);
+    }
+    if (R.xt_next) {
+        const float4 *src = reinterpret_cast<const float4 *>(R.emb + itm * R.W);
+        const float4 *ad = R.xt_add ? reinterpret_cast<const float4 *>(R.xt_add + (long long)b * R.W) : nullptr;
+        float4 *dst = reinterpret_cast<float4 *>(R.xt_next + (long long)b * R.W);
+        for (int i = lane; i < (R.W >> 2); i += 64) {
+            float4 v = src[i];
+            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+            if (ad) { const float4 a = ad[i]; v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w; }
+            dst[i] = v;
+        }
+    }
+}
+
+extern "C" int isc_rollout_finalize(const isc_rollout_step *s, void *stream) {
+    if (!s) return ISC_E_NULL;
+    if (!s->part_max || !s->part_sum || !s->part_idx || !s->seq || !s->seq_logprobs || !s->seq_masks ||
+        !s->unfinished || !s->alive || !s->emb)
+        return ISC_E_NULL;
+    if ((s->forced || s->sample_u) && !s->logits) return ISC_E_NULL;
+    if (s->B <= 0 || s->T <= 0 || s->t < 0 || s->t >= s->T || (s->W & 3)) return ISC_E_SHAPE;
+    DevRollout R;
+    R.B = s->B; R.V = s->V; R.T = s->T; R.t = s->t; R.n_tile = s->n_tile; R.W = s->W;
+    R.part_max = s->part_max; R.part_sum = s->part_sum; R.part_idx = s->part_idx;
+    R.logits = s->logits; R.ld_logits = s->ld_logits; R.forced = s->forced; R.sample_u = s->sample_u;
+    R.eos_id = s->eos_id; R.seq = s->seq; R.seq_logprobs = s->seq_logprobs; R.seq_masks = s->seq_masks;
+    R.unfinished = s->unfinished; R.alive = s->alive; R.raw_tokens = s->raw_tokens;
+    R.emb = s->emb; R.xt_add = s->xt_add; R.xt_next = s->xt_next;
+    hipLaunchKernelGGL(rollout_finalize_kernel, dim3((s->B + 3) / 4), dim3(256), 0, (hipStream_t)stream, R);
+    ISC_LAUNCH_CHECK();
+    return ISC_OK;
+}
+
+// ------------------------------------------------------------------ log-softmax apply
+__global__ __launch_bounds__(256) void logsoftmax_apply_kernel(float *logits, long long ld, int M, int V,
+                                                               const float *pmax, const float *psum,
+                                                               int n_tile, float *lse_out) {
+    __shared__ float sh[2];
+    const int m = blockIdx.x;
+    const int tid = threadIdx.x;
+    if (tid < 64) {
+        float gmax, S;
+        int gi;
+        fold_row_stats(pmax + (long long)m * n_tile, psum + (long long)m * n_tile, nullptr, n_tile, tid,
+                       gmax, gi, S);
+        if (tid == 0) {
+            sh[0] = gmax;
+            sh[1] = logf(S);
+            if (lse_out) lse_out[m] = gmax + sh[1];
+        }
+    }
+    __syncthreads();
+    const float gmax = sh[0], logS = sh[1];
+    float *x = logits + (long long)m * ld;
+    for (int i = blockIdx.y * 256 + tid; i < V; i += gridDim.y * 256) x[i] = (x[i] - gmax) - logS;
+}
+
+extern "C" int isc_logsoftmax_apply(float *logits, int64_t ld_logits, int M, int V,
+                                    const float *part_max, const float *part_sum, float *lse_out,
+                                    void *stream) {
+    if (!logits || !part_max || !part_sum) return ISC_E_NULL;
+    if (M <= 0 || V <= 0) return ISC_E_SHAPE;
+    const int n_tile = (V + 127) / 128;
+    int gy = (V + 2047) / 2048;
+    if (gy < 1) gy = 1;
+    hipLaunchKernelGGL(logsoftmax_apply_kernel, dim3(M, gy), dim3(256), 0, (hipStream_t)stream, logits,
+                       (long long)ld_logits, M, V, part_max, part_sum, n_tile, lse_out);
+    ISC_LAUNCH_CHECK();
+    return ISC_OK;
+}
+
+// ------------------------------------------------------------------ beam top-k
+// One workgroup per live beam row; `beam` rounds of a block-wide arg-max over the masked
+// log-probabilities (rows are few: images x beam).  Ties resolve to the smaller word id.
+__global__ __launch_bounds__(256) void beam_topk_kernel(const float *logits, long long ld,
+                                                        const float *pmax, const float *psum, int n_tile,
+                                                        int V, int beam, const int64_t *last_word,
+                                                        long long pad_id, long long sos_id,
+                                                        long long unk_id, int mask_special, int cons,
+                                                        float *top_val, int64_t *top_idx) {
+    __shared__ float sv[4];
+    __shared__ int si[4];
+    __shared__ float sh[2];
+    __shared__ int chosen[16];
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < 64) {
+        float gmax, S;
+        int gi;
+        fold_row_stats(pmax + (long long)row * n_tile, psum + (long long)row * n_tile, nullptr, n_tile,
+                       tid, gmax, gi, S);
+        if (tid == 0) { sh[0] = gmax; sh[1] = logf(S); }
+    }
+    __syncthreads();
+    const float gmax = sh[0], logS = sh[1];
+    const float *x = logits + (long long)row * ld;
+    const long long last = last_word[row];
+    for (int k = 0; k < beam; ++k) {
+        float mx = -INFINITY;
+        int ix = 0x7fffffff;
+        for (int i = tid; i < V; i += 256) {
+            bool banned = false;
+            if (mask_special && (i == pad_id || i == sos_id || i == unk_id)) banned = true;
+            if (cons && i == last) banned = true;
+            for (int j = 0; j < k; ++j) banned |= (chosen[j] == i);
+            const float v = banned ? -INFINITY : (x[i] - gmax) - logS;
+            // banned entries still take part as -inf (torch.sort keeps them, at the tail)
+            if (v > mx || (v == mx && i < ix)) { mx = v; ix = i; }
+        }
+        wave_argmax(mx, ix);
+        if (lane == 0) { sv[wave] = mx; si[wave] = ix; }
+        __syncthreads();
+        if (tid == 0) {
+            float bm = sv[0];
+            int bi = si[0];
+            for (int w = 1; w < 4; ++w)
+                if (sv[w] > bm || (sv[w] == bm && si[w] < bi)) { bm = sv[w]; bi = si[w]; }
+            chosen[k] = bi;
+            top_val[(long long)row * beam + k] = bm;
+            top_idx[(long long)row * beam + k] = bi;
+        }
+        __syncthreads();
+    }
+}
+
+extern "C" int isc_beam_topk(const float *logits, int64_t ld_logits, const float *part_max,
+                             const float *part_sum, int n_tile, int rows, int V, int beam,
+                             const int64_t *last_word, int64_t pad_id, int64_t sos_id, int64_t unk_id,
+                             int mask_special, int decoding_constraint, float *top_val,
+                             int64_t *top_idx, void *stream) {
+    if (!logits || !part_max || !part_sum || !last_word || !top_val || !top_idx) return ISC_E_NULL;
+    if (rows <= 0 || V <= 0 || beam <= 0 || beam > 16 || beam > V) return ISC_E_SHAPE;
+    hipLaunchKernelGGL(beam_topk_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, logits,
+                       (long long)ld_logits, part_max, part_sum, n_tile, V, beam, last_word,
+                       (long long)pad_id, (long long)sos_id, (long long)unk_id, mask_special,
+                       decoding_constraint, top_val, top_idx);
+    ISC_LAUNCH_CHECK();
+    return ISC_OK;
+}
+
+// ------------------------------------------------------------------ XECriterion
+// Single workgroup, fixed reduction order => bitwise reproducible loss.
+__global__ __launch_bounds__(256) void xe_loss_kernel(const float *logp, const int64_t *target,
+                                                      const int *lengths, int B, int T, int V,
+                                                      float *out2) {
+    __shared__ float ss[4], sn[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float s = 0.f, n = 0.f;
+    for (int i = tid; i < B * T; i += 256) {
+        const int b = i / T, t = i % T;
+        if (t < lengths[b]) {
+            s -= logp[(long long)i * V + target[i]];
+            n += 1.f;
+        }
+    }
+    s = wave_sum(s);
+    n = wave_sum(n);
+    if (lane == 0) { ss[wave] = s; sn[wave] = n; }
+    __syncthreads();
+    if (tid == 0) {
+        out2[0] = (ss[0] + ss[1]) + (ss[2] + ss[3]);
+        out2[1] = (sn[0] + sn[1]) + (sn[2] + sn[3]);
+    }
+}
+
+extern "C" int isc_xe_loss_fwd(const float *logp, const int64_t *target, const int32_t *lengths,
+                               int B, int T, int V, float *out2, void *stream) {
+    if (!logp || !target || !lengths || !out2) return ISC_E_NULL;
+    if (B <= 0 || T <= 0 || V <= 0) return ISC_E_SHAPE;
+    hipLaunchKernelGGL(xe_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logp, target, lengths,
+                       B, T, V, out2);
+    ISC_LAUNCH_CHECK();
+    return ISC_OK;
+}
+
+extern "C" int isc_abi_version(void) { return 1; }
+extern "C" const char *isc_target_arch(void) { return "gfx950"; }

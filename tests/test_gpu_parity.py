@@ -1,0 +1,300 @@
+"""Parity of the HIP path (through the C-ABI library) against the CPU oracle and the golden
+vectors produced by the reference. Run on the MI355X box: pytest -m gpu."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import case_setup, trusted_prefix
+from insenticap_model_amd import Captioner, XECriterion, ops, synth
+
+pytestmark = pytest.mark.gpu
+
+LOGP_TOL = 1e-4   # BASELINE.json north_star: log-probs within 1e-4 fp32
+
+
+def dev():
+    assert torch.cuda.is_available(), 'GPU tests need a ROCm device'
+    return torch.device('cuda:0')
+
+
+def make_captioner(name):
+    c, st, w, d, s2s = case_setup(name)
+    cap = Captioner(synth.make_idx2word(c['V']), synth.SENTIMENT_CATEGORIES, st)
+    cap.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()})
+    cap.to(dev()).eval()
+    return cap, c, st, w, d, s2s
+
+
+def T(d, k):
+    return torch.from_numpy(np.asarray(d[k])).to(dev())
+
+
+def oracle():
+    from oracle import captioner_oracle as O
+    return O
+
+
+# ----------------------------------------------------------------------------- kernels
+@pytest.mark.parametrize('M,N,K1,K2', [(4, 512, 512, 0), (128, 512, 2048, 0), (300, 1536, 512, 512),
+                                       (2048, 512, 512, 0), (37, 64, 32, 64), (1000, 10000 // 8 * 4, 512, 0)])
+def test_linear_kernel_vs_fp64(M, N, K1, K2):
+    g = torch.Generator().manual_seed(M * 7 + N)
+    x1 = torch.randn(M, K1, generator=g)
+    w1 = torch.randn(N, K1, generator=g) / K1 ** 0.5
+    b = torch.randn(N, generator=g)
+    ref = x1.double() @ w1.double().t() + b.double()
+    segs = [(x1.to(dev()), w1.to(dev()))]
+    if K2:
+        x2 = torch.randn(M, K2, generator=g)
+        w2 = torch.randn(N, K2, generator=g) / K2 ** 0.5
+        ref = ref + x2.double() @ w2.double().t()
+        segs.append((x2.to(dev()), w2.to(dev())))
+    ref = torch.relu(ref)
+    out = torch.empty(M, N, device=dev())
+    ops.linear_fwd([ops.linear_problem(segs, out, b.to(dev()), relu=True)])
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out.cpu().numpy(), ref.float().numpy(), atol=2e-5, rtol=1e-5)
+
+
+def test_linear_grouped_and_views():
+    """3 problems in one launch; A given as a strided view, W as a column slice."""
+    g = torch.Generator().manual_seed(5)
+    big = torch.randn(70, 96, generator=g).to(dev())
+    wfull = torch.randn(64, 160, generator=g).to(dev())
+    outs, probs, refs = [], [], []
+    for i, (a, w) in enumerate([(big[:, 0:32], wfull[:, 32:64]), (big[:, 32:96], wfull[:, 96:160]),
+                                (big[:, 64:96], wfull[:32, 0:32])]):
+        o = torch.empty(a.shape[0], w.shape[0], device=dev())
+        probs.append(ops.linear_problem([(a, w)], o))
+        outs.append(o)
+        refs.append(a.double().cpu() @ w.double().cpu().t())
+    ops.linear_fwd(probs)
+    torch.cuda.synchronize()
+    for o, r in zip(outs, refs):
+        np.testing.assert_allclose(o.cpu().numpy(), r.float().numpy(), atol=2e-5)
+
+
+@pytest.mark.parametrize('M,H', [(3, 32), (128, 512), (700, 512)])
+def test_lstm_kernel_vs_fp64(M, H):
+    g = torch.Generator().manual_seed(M + H)
+    E = H
+    x = torch.randn(M, E, generator=g)
+    h = torch.randn(M, H, generator=g) * 0.5
+    c = torch.randn(M, H, generator=g)
+    wih = torch.randn(4 * H, E, generator=g) / E ** 0.5
+    whh = torch.randn(4 * H, H, generator=g) / H ** 0.5
+    bih, bhh = torch.randn(4 * H, generator=g), torch.randn(4 * H, generator=g)
+    gates = x.double() @ wih.double().t() + bih.double() + h.double() @ whh.double().t() + bhh.double()
+    i, f, gg, o = gates.chunk(4, dim=1)
+    c2 = torch.sigmoid(f) * c.double() + torch.sigmoid(i) * torch.tanh(gg)
+    h2 = torch.sigmoid(o) * torch.tanh(c2)
+    D = dev()
+    ho, co = torch.empty(M, H, device=D), torch.empty(M, H, device=D)
+    go = torch.empty(M, 4 * H, device=D)
+    ops.lstm_fwd([(x.to(D), wih.to(D)), (h.to(D), whh.to(D))], bih.to(D), bhh.to(D), c.to(D), ho, co, gates_out=go)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(ho.cpu().numpy(), h2.float().numpy(), atol=2e-5)
+    np.testing.assert_allclose(co.cpu().numpy(), c2.float().numpy(), atol=2e-5)
+    act = torch.cat([torch.sigmoid(i), torch.sigmoid(f), torch.tanh(gg), torch.sigmoid(o)], dim=1)
+    np.testing.assert_allclose(go.cpu().numpy(), act.float().numpy(), atol=2e-5)
+
+
+@pytest.mark.parametrize('M,V,K', [(5, 64, 32), (130, 10000, 512), (64, 9487, 512)])
+def test_vocab_kernel_logsoftmax(M, V, K):
+    g = torch.Generator().manual_seed(V)
+    h = torch.randn(M, K, generator=g)
+    w = torch.randn(V, K, generator=g) * 0.3
+    b = torch.randn(V, generator=g)
+    ref = torch.log_softmax(h.double() @ w.double().t() + b.double(), dim=1)
+    D = dev()
+    nt = (V + 127) // 128
+    pm, ps = torch.empty(M, nt, device=D), torch.empty(M, nt, device=D)
+    pi = torch.empty(M, nt, dtype=torch.int32, device=D)
+    logits = torch.empty(M, V, device=D)
+    ops.vocab_fwd(h.to(D), w.to(D), b.to(D), pm, ps, pi, logits)
+    ops.logsoftmax_apply(logits, pm, ps)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(logits.cpu().numpy(), ref.float().numpy(), atol=5e-5)
+    # arg-max from the tile statistics
+    best = pm.cpu().argmax(dim=1)
+    am = pi.cpu()[torch.arange(M), best].long()
+    assert (am == ref.argmax(dim=1)).all()
+
+
+@pytest.mark.parametrize('B,R,A', [(3, 6, 32), (64, 36, 512), (5, 196, 512), (9, 11, 512)])
+def test_attention_scan_vs_fp64(B, R, A):
+    g = torch.Generator().manual_seed(B * R)
+    Pm = torch.randn(B, R, A, generator=g)
+    Vm = torch.randn(B, R, A, generator=g)
+    q = torch.randn(B, A, generator=g)
+    q2 = torch.randn(B, A, generator=g)
+    w = torch.randn(1, A, generator=g) * 0.3
+    wb = torch.randn(1, generator=g)
+    e = (torch.tanh(Pm.double() + q.double().unsqueeze(1) + q2.double().unsqueeze(1)) @ w.double().t()).squeeze(-1) + wb.double()
+    al = torch.softmax(e, dim=-1)
+    ref = torch.bmm(al.unsqueeze(1), Vm.double()).squeeze(1)
+    D = dev()
+    out, alpha = torch.empty(B, A, device=D), torch.empty(B, R, device=D)
+    ops.attn_scan_fwd([ops.scan_problem(Pm.to(D), Vm.to(D), q.to(D), w.to(D), wb.to(D), out, alpha, q2=q2.to(D))], B)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(alpha.cpu().numpy(), al.float().numpy(), atol=2e-6)
+    np.testing.assert_allclose(out.cpu().numpy(), ref.float().numpy(), atol=1e-5)
+
+
+# ----------------------------------------------------------------------------- end to end
+def test_tiny_xe_and_seq2seq_forward_vs_golden(golden):
+    g = golden('tiny')
+    cap, c, st, w, d, s2s = make_captioner('tiny')
+    with torch.no_grad():
+        logp = cap(T(d, 'fc_feats'), T(d, 'att_feats'), T(d, 'cpt_words'), T(d, 'captions'),
+                   T(d, 'senti_labels'), 0.0, mode='xe')
+    np.testing.assert_allclose(logp.cpu().numpy(), g['it/xe_logp'], atol=LOGP_TOL)
+    np.testing.assert_allclose(cap.fc_feats.cpu().numpy(), g['it/xe_fc_feats'], atol=1e-5)
+    np.testing.assert_allclose(cap.cpt_feats.cpu().numpy(), g['it/xe_cpt_feats'], atol=1e-5)
+    np.testing.assert_allclose(cap.cont_weights.cpu().numpy(), g['it/xe_cont_weights'], atol=1e-5)
+    assert cap.senti_weights == [] and cap.cont_senti_weights == []
+    loss = XECriterion()(logp, T(d, 'captions')[:, 1:], d['lengths'])
+    np.testing.assert_allclose(float(loss), g['it/losses'][0], rtol=2e-5)
+    with torch.no_grad():
+        logp2 = cap(T(s2s, 'captions'), T(s2s, 'cpt_words'), T(s2s, 'senti_words'), T(s2s, 'senti_labels'),
+                    0.0, mode='seq2seq')
+    np.testing.assert_allclose(logp2.cpu().numpy(), g['it/s2s_logp'], atol=LOGP_TOL)
+    np.testing.assert_allclose(cap.senti_weights.cpu().numpy(), g['it/s2s_senti_weights'], atol=1e-5)
+    loss2 = XECriterion()(logp2, T(s2s, 'captions')[:, 1:], s2s['lengths'])
+    np.testing.assert_allclose(float(loss2), g['it/losses'][2], rtol=2e-5)
+    # 4-D grid input == flat regions
+    dg = synth.make_inputs(c['B'], c['V'], st, regions=c['R'], seq_len=c['T'], seed=c['in_seed'], grid=(2, 3))
+    with torch.no_grad():
+        lg = cap(T(dg, 'fc_feats'), T(dg, 'att_feats'), T(dg, 'cpt_words'), T(dg, 'captions'),
+                 T(dg, 'senti_labels'), 0.0, mode='xe')
+    np.testing.assert_allclose(lg.cpu().numpy(), g['grid/xe_logp'], atol=LOGP_TOL)
+
+
+@pytest.mark.parametrize('prefix', ['rl/', 'early/'])
+def test_tiny_rollouts_vs_golden(golden, prefix):
+    g = golden('tiny')
+    cap, c, st, w, d, _ = make_captioner('tiny')
+    if prefix == 'early/':
+        d = {k: v[3:6] for k, v in d.items()}
+    a = (T(d, 'fc_feats'), T(d, 'att_feats'), T(d, 'cpt_words'), T(d, 'senti_words'), T(d, 'senti_labels'))
+    with torch.no_grad():
+        seq, lp, mk = cap(*a, c['T'], 1, mode='rl')
+    assert seq.dtype == torch.int64
+    assert (seq.cpu().numpy() == g[prefix + 'greedy_seq']).all()          # token-exact
+    assert (mk.cpu().numpy() == g[prefix + 'greedy_masks']).all()
+    np.testing.assert_allclose(lp.cpu().numpy(), g[prefix + 'greedy_logprobs'], atol=LOGP_TOL)
+    for attr, key in (('cont_weights', 'cont'), ('senti_weights', 'senti'), ('cont_senti_weights', 'gate')):
+        ref = g[prefix + 'greedy_%s_weights' % key]
+        got = getattr(cap, attr).cpu().numpy()
+        assert got.shape == ref.shape, (attr, got.shape, ref.shape)       # early break => fewer steps
+        np.testing.assert_allclose(got, ref, atol=1e-5)
+    np.testing.assert_allclose(cap.fc_feats.cpu().numpy(), g[prefix + 'greedy_fc_feats'], atol=1e-5)
+    np.testing.assert_allclose(cap.cpt_feats.cpu().numpy(), g[prefix + 'greedy_cpt_feats'], atol=1e-5)
+    # sampled roll-out, replaying the reference's raw multinomial draws
+    with torch.no_grad():
+        seq, lp, mk = cap.forward_rl(*a, c['T'], 0, _replay=torch.from_numpy(g[prefix + 'sample_draws']).to(dev()))
+    assert (seq.cpu().numpy() == g[prefix + 'sample_seq']).all()
+    assert (mk.cpu().numpy() == g[prefix + 'sample_masks']).all()
+    np.testing.assert_allclose(lp.cpu().numpy(), g[prefix + 'sample_logprobs'], atol=LOGP_TOL)
+
+
+def test_tiny_beam_vs_golden(golden):
+    g = golden('tiny')
+    cap, c, st, w, d, _ = make_captioner('tiny')
+    fc, att, sw, lab = T(d, 'fc_feats'), T(d, 'att_feats'), T(d, 'senti_words'), T(d, 'senti_labels')
+    for b in (3, 5):
+        for s in (0, 1):
+            caps, scores, _ = cap.sample_batch(fc, att, sw if s else None, lab if s else None, b, 1, c['T'])
+            for i in range(c['B']):
+                assert caps[i] == list(g['beam/beam%d_senti%d_caps' % (b, s)][i]), (b, s, i)
+                np.testing.assert_allclose(scores[i], g['beam/beam%d_senti%d_scores' % (b, s)][i], atol=2e-4)
+    caps, scores, _ = cap.sample_batch(fc, att, sw, lab, 3, 0, c['T'])
+    for i in range(c['B']):
+        assert caps[i] == list(g['beam/beam3_nocons_caps'][i])
+    # the reference's one-image API
+    cp, sc = cap.sample(fc[1], att[1], sw[1], lab[1:2], 3, 1, c['T'])
+    assert cp == list(g['beam/beam3_senti1_caps'][1])
+
+
+def test_tiny_dropout_and_scheduled_sampling_replay(golden):
+    g = golden('tiny')
+    cap, c, st, w, d, s2s = make_captioner('tiny')
+    masks = {k: torch.from_numpy(g['drop/mask_' + k]) for k in ('fc', 'att', 'label')}
+    for i in range(c['T']):
+        masks['out%d' % i] = torch.from_numpy(g['drop/mask_out%d' % i])
+    with torch.no_grad():
+        logp = cap.forward_xe(T(d, 'fc_feats'), T(d, 'att_feats'), T(d, 'cpt_words'), T(d, 'captions'),
+                              T(d, 'senti_labels'), 0.0, _masks=masks)
+    np.testing.assert_allclose(logp.cpu().numpy(), g['drop/xe_logp'], atol=2e-4)
+    masks = {k: torch.from_numpy(g['drop_s2s/mask_' + k]) for k in ('cpt', 'words', 'label')}
+    for i in range(c['T']):
+        masks['out%d' % i] = torch.from_numpy(g['drop_s2s/mask_out%d' % i])
+    with torch.no_grad():
+        logp = cap.forward_seq2seq(T(s2s, 'captions'), T(s2s, 'cpt_words'), T(s2s, 'senti_words'),
+                                   T(s2s, 'senti_labels'), 0.0, _masks=masks)
+    np.testing.assert_allclose(logp.cpu().numpy(), g['drop_s2s/logp'], atol=2e-4)
+    # scheduled sampling: feed the tokens the reference fed
+    fed = torch.from_numpy(g['ss/fed_tokens']).to(dev())
+    caps = torch.cat([fed, fed[:, -1:]], dim=1)      # forward_xe feeds captions[:, :-1]
+    with torch.no_grad():
+        logp = cap.forward_xe(T(d, 'fc_feats'), T(d, 'att_feats'), T(d, 'cpt_words'), caps,
+                              T(d, 'senti_labels'), 0.0)
+    np.testing.assert_allclose(logp.cpu().numpy(), g['ss/xe_logp'], atol=LOGP_TOL)
+
+
+@pytest.mark.parametrize('name', ['cfg1', 'b128'])
+def test_fullsize_greedy_token_exact(golden, name):
+    """BASELINE.json configs[0]/[1] shapes (36x2048 feats, V=10k, T=20): token-exact where the
+    reference's own top-1/top-2 margin is above fp32 reassociation noise."""
+    g = golden(name)
+    cap, c, st, w, d, _ = make_captioner(name)
+    a = (T(d, 'fc_feats'), T(d, 'att_feats'), T(d, 'cpt_words'), T(d, 'senti_words'), T(d, 'senti_labels'))
+    with torch.no_grad():
+        seq, lp, mk = cap(*a, c['T'], 1, mode='rl')
+    seq, lp, mk = seq.cpu().numpy(), lp.cpu().numpy(), mk.cpu().numpy()
+    gm = g['rl/greedy_margins']
+    gm = np.pad(gm, ((0, 0), (0, c['T'] - gm.shape[1])))
+    n = trusted_prefix(gm, g['rl/greedy_masks'], 2e-3)
+    assert n.mean() >= 0.8 * c['T']
+    for b in range(c['B']):
+        assert (seq[b, :n[b]] == g['rl/greedy_seq'][b, :n[b]]).all(), b
+        assert (mk[b, :n[b]] == g['rl/greedy_masks'][b, :n[b]]).all(), b
+        np.testing.assert_allclose(lp[b, :n[b]], g['rl/greedy_logprobs'][b, :n[b]], atol=LOGP_TOL)
+
+
+def test_cfg1_beam5_and_xe_vs_golden(golden):
+    g = golden('cfg1')
+    cap, c, st, w, d, s2s = make_captioner('cfg1')
+    fc, att, sw, lab = T(d, 'fc_feats'), T(d, 'att_feats'), T(d, 'senti_words'), T(d, 'senti_labels')
+    caps, scores, _ = cap.sample_batch(fc[:2], att[:2], sw[:2], lab[:2], 5, 1, c['T'])
+    for i in range(2):
+        assert caps[i] == list(g['beam/beam5_senti1_caps'][i])
+        np.testing.assert_allclose(scores[i], g['beam/beam5_senti1_scores'][i], atol=1e-3)
+    with torch.no_grad():
+        logp = cap(fc, att, T(d, 'cpt_words'), T(d, 'captions'), lab, 0.0, mode='xe')
+    np.testing.assert_allclose(logp.cpu().numpy()[:, :, :32], g['it/xe_logp'], atol=LOGP_TOL)
+    tgt = logp.gather(2, T(d, 'captions')[:, 1:].unsqueeze(2)).squeeze(2).cpu().numpy()
+    np.testing.assert_allclose(tgt, g['it/xe_logp_tgt'], atol=LOGP_TOL)
+    loss = XECriterion()(logp, T(d, 'captions')[:, 1:], d['lengths'])
+    np.testing.assert_allclose(float(loss), g['it/losses'][0], rtol=2e-5)
+
+
+def test_large_batch_properties():
+    """BASELINE-size batch (B=1024): size-independent properties - rows are independent
+    (row-in-batch == row-alone), masks are monotone, tokens after <EOS> are <PAD>."""
+    cap, c, st, w, _, _ = make_captioner('cfg1')
+    B, Tn = 1024, 20
+    d = synth.make_inputs(B, c['V'], st, regions=36, seq_len=Tn, seed=77)
+    a = [T(d, k) for k in ('fc_feats', 'att_feats', 'cpt_words', 'senti_words', 'senti_labels')]
+    with torch.no_grad():
+        seq, lp, mk = cap(*a, Tn, 1, mode='rl')
+        sub = [x[100:164] for x in a]
+        seq2, lp2, mk2 = cap(*sub, Tn, 1, mode='rl')
+    assert (seq[100:164] == seq2).all()
+    np.testing.assert_allclose(lp[100:164].cpu().numpy(), lp2.cpu().numpy(), atol=1e-5)
+    mkc, sq = mk.cpu().numpy(), seq.cpu().numpy()
+    assert (np.diff(mkc, axis=1) <= 0).all()
+    assert (sq[mkc == 0] == 0).all()
+    eos_pos = (sq == cap.eos_id) & (mkc == 1)
+    assert (eos_pos.sum(1) <= 1).all()
+    assert np.isfinite(lp.cpu().numpy()).all()
