@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""Headline benchmark: captions/sec, greedy decode (Captioner.forward_rl, sample_max=1) over
+pre-extracted 36x2048 region features, V=10k, length 20, sentiment-word attention on
+(BASELINE.json metric). One "step" = one greedy roll-out of a batch of B captions per GPU,
+inputs resident in HBM, weights random-init of the reference architecture.
+
+    python bench.py [--gpus N --steps K --warmup W --batch B]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Images are independent, so multi-GPU is a pure shard of the batch (no data-path collective):
+weak scaling, value = N*B*K captions / max-over-ranks time.
+
+Extra objects on the JSON line:
+  roofline      dominant kernel (largest share of the decode step): achieved algorithmic
+                FLOP/s (or B/s) from HIP events recorded inside the timed region
+  roofline_kernels   the same for every kernel of the step (incl. the HBM-bound attention scan)
+  cpu_baseline  the CPU oracle (a port of the reference, oracle/) timed on this box's host
+                cores on a bounded sample of the same workload
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from insenticap_model_amd import Captioner, ops, synth  # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E spec peak (6.3 TB/s achievable)
+V, R, T = 10000, 36, 20
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--batch', type=int, default=2048, help='captions per GPU per step')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-seconds', type=float, default=15.0)
+    return ap.parse_args()
+
+
+def device_inputs(B, seed, dev):
+    d = synth.make_inputs(B, V, synth.DEFAULT_SETTINGS, regions=R, seq_len=T, seed=seed)
+    keys = ('fc_feats', 'att_feats', 'cpt_words', 'senti_words', 'senti_labels')
+    return [torch.from_numpy(d[k]).to(dev) for k in keys], d
+
+
+def usable_cores():
+    """Host cores this process may actually use: min(affinity mask, cgroup CPU quota), capped
+    at 64 (the fp32 CPU GEMMs of this workload stop scaling well before that)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        with open('/sys/fs/cgroup/cpu.max') as f:
+            quota, period = f.read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 64))
+
+
+def cpu_baseline(weights, seconds):
+    """Times the oracle's greedy roll-out (same shapes, B=128 chunks) for about `seconds`."""
+    from oracle import captioner_oracle as O
+    cores = usable_cores()
+    torch.set_num_threads(cores)
+    p = O.to_params(weights)
+    ids = O.Ids(synth.make_idx2word(V), synth.SENTIMENT_CATEGORIES)
+    Bc = 128
+    d = synth.make_inputs(Bc, V, synth.DEFAULT_SETTINGS, regions=R, seq_len=T, seed=3)
+    a = [torch.from_numpy(d[k]) for k in ('fc_feats', 'att_feats', 'cpt_words', 'senti_words', 'senti_labels')]
+    with torch.no_grad():
+        O.forward_rl(p, ids, *[x[:8] for x in a], 2, 1)    # warm-up (thread pool, allocator)
+        n, t0 = 0, time.perf_counter()
+        while True:
+            O.forward_rl(p, ids, *a, T, 1)
+            n += 1
+            el = time.perf_counter() - t0
+            if el >= seconds or n >= 50:
+                break
+    return dict(value=round(n * Bc / el, 2), unit='captions/s', cores=cores, kind='port',
+                sample='%d greedy roll-outs of B=%d (T=%d, R=%d, V=%d) by oracle/captioner_oracle.py, '
+                       'torch CPU fp32, %d threads, %.1f s' % (n, Bc, T, R, V, cores, el))
+
+
+def roofline_entry(name, rec):
+    ms = rec['avg_ms']
+    if rec['flops'] > 0:
+        ach = rec['flops'] / (ms * 1e-3) / 1e12
+        return dict(kernel=name, bound='mfma', achieved=round(ach, 3), peak=PEAK_FP32_MFMA_TFLOPS,
+                    unit='TFLOP/s', frac=round(ach / PEAK_FP32_MFMA_TFLOPS, 4), traffic=None,
+                    avg_us=round(ms * 1e3, 2), launches_timed=rec['n'])
+    ach = rec['bytes'] / (ms * 1e-3) / 1e9
+    return dict(kernel=name, bound='hbm', achieved=round(ach, 2), peak=PEAK_HBM_GBS, unit='GB/s',
+                frac=round(ach / PEAK_HBM_GBS, 4), traffic=None, avg_us=round(ms * 1e3, 2),
+                launches_timed=rec['n'])
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+    dev = torch.device('cuda', local if world > 1 else 0)
+    torch.cuda.set_device(dev)
+    B = args.batch
+
+    weights = synth.make_weights(V, synth.DEFAULT_SETTINGS, seed=0)
+    cap = Captioner(synth.make_idx2word(V), synth.SENTIMENT_CATEGORIES, synth.DEFAULT_SETTINGS)
+    cap.load_state_dict({k: torch.from_numpy(v) for k, v in weights.items()})
+    cap.to(dev).eval()
+    inputs, _ = device_inputs(B, 100 + rank, dev)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            cap(*inputs, T, 1, mode='rl')
+        barrier()
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            # HIP events around every kernel of ONE decode step of this roll-out (-1 = prologue)
+            ops.TIMER.arm_step = (k % (T + 1)) - 1
+            seq, lp, mk = cap(*inputs, T, 1, mode='rl')
+        barrier()
+        el = time.perf_counter() - t0
+    ops.TIMER.arm_step = None
+    if world > 1:
+        tt = torch.tensor([el], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        el = float(tt)
+    if rank != 0:
+        return
+
+    total = world * B * args.steps
+    summ = ops.TIMER.summary()
+    # share of one roll-out: step kernels run T times, prologue kernels once
+    entries = []
+    for name, rec in summ.items():
+        e = roofline_entry(name, rec)
+        e['phase'] = rec['phase']
+        e['per_rollout_ms'] = round(rec['avg_ms'] * (1 if rec['phase'] == 'prologue' else T), 3)
+        entries.append(e)
+    entries.sort(key=lambda e: -e['per_rollout_ms'])
+    out = {
+        'metric': 'captions/sec (greedy, 36-region feats, len-20)',
+        'value': round(total / el, 1), 'unit': 'captions/s',
+        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': round(el / args.steps * 1e3, 3),
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': 'greedy decode forward_rl(sample_max=1): B=%d captions/GPU/step, R=%d '
+                               'regions x 2048, V=%d, T=%d, sentiment-word attention + gate on, '
+                               'prologue included, random-init reference-architecture weights' % (B, R, V, T),
+                   'batch_per_gpu': B, 'parallelism': 'dp%d (batch shard, no collective)' % world},
+        'roofline': entries[0] if entries else None,
+        'roofline_kernels': entries[1:],
+    }
+    if not args.no_cpu_baseline and world == 1:
+        out['cpu_baseline'] = cpu_baseline(weights, args.cpu_seconds)
+    print(json.dumps(out))
+
+
+if __name__ == '__main__':
+    main()

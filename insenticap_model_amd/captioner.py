@@ -357,7 +357,10 @@ class Captioner(nn.Module):
     def _rollout(self, fc_feats, att_feats, cpt_words, senti_words, senti_labels, T, sample_max, replay,
                  masks):
         p = self._p()
+        arm = ops.TIMER.arm_step          # bench.py: time the kernels of ONE step (-1: the prologue)
+        ops.TIMER.armed, ops.TIMER.phase = (arm == -1), 'prologue'
         P = self._prologue(p, 'rl', fc_feats, att_feats, cpt_words, senti_words, senti_labels, masks)
+        ops.TIMER.armed, ops.TIMER.phase = False, 'step'
         B, V = P.B, self.vocab_size
         H, Wd = self.att_lstm.hidden_size, self.settings['word_emb_dim']
         h = [self._zeros(2, B, H) for _ in range(2)]
@@ -395,11 +398,13 @@ class Captioner(nn.Module):
         for t in range(T):
             cur, nxt = t & 1, (t + 1) & 1
             om, osc = mask_for('out%d' % t, B, H)
+            ops.TIMER.armed = (arm == t)
             self._step(p, P, ws, xt[cur], h[cur], c[cur], h[nxt], c[nxt], aC[:, t], aS[:, t], bG[:, t:t + 1],
                        logits, om, osc)
             rs.t = t
             rs.xt_next = xt[nxt].data_ptr()
             ops.rollout_finalize(rs)
+        ops.TIMER.armed = False
         # one host read per roll-out: number of steps the reference would have executed
         alive_h = alive.cpu()
         steps = T

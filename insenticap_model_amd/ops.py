@@ -12,6 +12,50 @@ def stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+class KernelTimer:
+    """Optional per-launch timing with HIP events recorded on the stream the kernels run on
+    (torch's current stream). bench.py arms it for one decode step per timed roll-out; when
+    `armed` is False the wrappers below add no work."""
+
+    def __init__(self):
+        self.armed = False
+        self.arm_step = None   # decode step whose kernels get timed (-1 = prologue, None = off)
+        self.phase = 'step'    # 'prologue' kernels run once per roll-out, 'step' kernels T times
+        self.records = []   # (name, start_event, end_event, flops, bytes)
+
+    def begin(self):
+        if not self.armed:
+            return None
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def end(self, e0, name, flops=0.0, nbytes=0.0):
+        if e0 is None:
+            return
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        self.records.append((name, e0, e1, flops, nbytes, self.phase))
+
+    def summary(self):
+        """name -> dict(n, avg_ms, flops, bytes); call after a device synchronize."""
+        out = {}
+        for name, e0, e1, fl, nb, ph in self.records:
+            d = out.setdefault(name, dict(n=0, total_ms=0.0, flops=fl, bytes=nb, phase=ph))
+            d['n'] += 1
+            d['total_ms'] += e0.elapsed_time(e1)
+        for d in out.values():
+            d['avg_ms'] = d['total_ms'] / d['n']
+        return out
+
+
+TIMER = KernelTimer()
+
+
+def _seg_k(segs):
+    return sum(a.shape[1] for a, _ in segs)
+
+
 def ptr(t):
     return None if t is None else t.data_ptr()
 
@@ -59,7 +103,12 @@ def linear_problem(segs, out, bias0=None, bias1=None, bias2=None, relu=False, ke
 def linear_fwd(problems):
     lib = _lib.load()
     arr = (LinearProblem * len(problems))(*problems)
+    e0 = TIMER.begin()
     check(lib.isc_linear_fwd(arr, len(problems), stream()), 'isc_linear_fwd')
+    if e0 is not None:
+        fl = sum(2.0 * q.M * q.N * sum(q.seg[i].K for i in range(q.nseg)) for q in problems)
+        TIMER.end(e0, 'linear[' + '+'.join('%dx%dx%d' % (q.M, q.N, sum(q.seg[i].K for i in range(q.nseg)))
+                                          for q in problems) + ']', fl)
 
 
 def lstm_fwd(segs, b_ih, b_hh, c_prev, h_out, c_out, gates_out=None, h_keep_mask=None,
@@ -76,7 +125,11 @@ def lstm_fwd(segs, b_ih, b_hh, c_prev, h_out, c_out, gates_out=None, h_keep_mask
     p.h_keep_mask = ptr(h_keep_mask)
     p.mask_scale = mask_scale
     p.hdrop_out = ptr(hdrop_out)
+    e0 = TIMER.begin()
     check(lib.isc_lstm_fwd(C.byref(p), stream()), 'isc_lstm_fwd')
+    if e0 is not None:
+        k = _seg_k(segs)
+        TIMER.end(e0, 'lstm[%dx%dx%d]' % (p.M, 4 * p.H, k), 2.0 * p.M * 4 * p.H * k)
 
 
 def vocab_fwd(h, W, bias, part_max, part_sum, part_idx, logits=None):
@@ -85,9 +138,11 @@ def vocab_fwd(h, W, bias, part_max, part_sum, part_idx, logits=None):
     V = W.shape[0]
     assert h.stride(1) == 1 and W.stride(1) == 1
     ld = logits.stride(0) if logits is not None else 0
+    e0 = TIMER.begin()
     check(lib.isc_vocab_fwd(h.data_ptr(), h.stride(0), W.data_ptr(), W.stride(0), bias.data_ptr(), M, V, K,
                             ptr(logits), ld, part_max.data_ptr(), part_sum.data_ptr(),
                             part_idx.data_ptr(), stream()), 'isc_vocab_fwd')
+    TIMER.end(e0, 'vocab[%dx%dx%d]' % (M, V, K), 2.0 * M * V * K)
 
 
 def logsoftmax_apply(logits, part_max, part_sum, lse_out=None):
@@ -116,7 +171,12 @@ def scan_problem(P, V, q, w, w_bias, out, alpha_out=None, q2=None):
 def attn_scan_fwd(problems, B):
     lib = _lib.load()
     arr = (ScanProblem * len(problems))(*problems)
+    e0 = TIMER.begin()
     check(lib.isc_attn_scan_fwd(arr, len(problems), B, stream()), 'isc_attn_scan_fwd')
+    if e0 is not None:
+        # algorithmic bytes: P and V streamed once per row (B*2*R*E*4 for the content scan)
+        nb = sum(4.0 * B * q.R * (q.A + q.D) for q in problems)
+        TIMER.end(e0, 'attn_scan[' + '+'.join('%dx%dx%d' % (B, q.R, q.A) for q in problems) + ']', 0.0, nb)
 
 
 def gate_mix_fwd(z, w, w_bias, v, s, out, beta_out=None):
@@ -125,8 +185,10 @@ def gate_mix_fwd(z, w, w_bias, v, s, out, beta_out=None):
     D = v.shape[1]
     assert z.is_contiguous() and v.is_contiguous() and s.is_contiguous() and out.is_contiguous()
     bl = beta_out.stride(0) if beta_out is not None else 0
+    e0 = TIMER.begin()
     check(lib.isc_gate_mix_fwd(z.data_ptr(), w.data_ptr(), ptr(w_bias), v.data_ptr(), s.data_ptr(), B, A, D,
                                out.data_ptr(), ptr(beta_out), bl, stream()), 'isc_gate_mix_fwd')
+    TIMER.end(e0, 'gate_mix[%dx%d]' % (B, A), 0.0, 4.0 * B * (A + 3 * D))
 
 
 def embed_relu_fwd(emb, ids, out, add=None):
@@ -158,7 +220,9 @@ def embed_senti_words_fwd(emb, ids, pad_id, out, keep_mask=None, mask_scale=1.0)
 
 def rollout_finalize(step):
     lib = _lib.load()
+    e0 = TIMER.begin()
     check(lib.isc_rollout_finalize(C.byref(step), stream()), 'isc_rollout_finalize')
+    TIMER.end(e0, 'rollout_finalize[%d]' % step.B, 0.0, 4.0 * step.B * (3 * step.n_tile + 2 * step.W))
 
 
 def beam_topk(logits, part_max, part_sum, last_word, beam, pad_id, sos_id, unk_id, mask_special,
