@@ -61,9 +61,22 @@ typedef struct {
     int32_t ldc;
     float *C;                   /* [M,N] */
     float *C_pre;               /* optional: activation before the mask (captioner.fc_feats attr) */
+    int32_t accumulate;         /* C += result (gradient accumulation) */
+    int32_t _pad;
 } isc_linear_problem;
 
 int isc_linear_fwd(const isc_linear_problem *probs_host, int n_prob, void *stream);
+
+/* Backward-pass contractions of the same layers (what autograd derives for nn.Linear /
+ * nn.LSTMCell / the classifier in train_xe.py:190, decoder.py:165), on the same MFMA kernel:
+ *   ISC_LAYOUT_NN  C[M,N] (+)= sum_s A_s[M,K_s] * W_s[K_s,N]      dX = dY * W
+ *                  (W_s row-major [K_s,N]: an nn.Linear weight [out=K_s, in=N] as stored)
+ *   ISC_LAYOUT_TN  C[M,N] (+)= sum_s A_s[K_s,M]^T * W_s[K_s,N]    dW = dY^T * X
+ *                  (contraction over the K_s batch rows; A_s = dY [rows, M], W_s = X [rows, N])
+ * bias/relu/mask fields are ignored except bias0..2 (added), M/N/ldc %4 == 0. */
+#define ISC_LAYOUT_NN 1
+#define ISC_LAYOUT_TN 2
+int isc_gemm_bwd(const isc_linear_problem *probs_host, int n_prob, int layout, void *stream);
 
 /* Fused LSTMCell: gates = sum_seg A_s W_s^T + b_ih + b_hh (row blocks i,f,g,o of 4H),
  * c' = sig(f) c + sig(i) tanh(g), h' = sig(o) tanh(c').  Replaces nn.LSTMCell at
@@ -176,6 +189,69 @@ int isc_beam_topk(const float *logits, int64_t ld_logits, const float *part_max,
  * logp [B,T,V] contiguous, target [B,T] int64, lengths [B] int32. */
 int isc_xe_loss_fwd(const float *logp, const int64_t *target, const int32_t *lengths, int B,
                     int T, int V, float *out2, void *stream);
+
+/* ------------------------------------------------------------------ backward (BPTT) */
+
+/* d logits = d logp - softmax * rowsum(d logp)  (autograd of F.log_softmax, captioner.py:183).
+ * Output rows have stride ld_out >= V; the padding columns are zero-filled. remap_T > 0
+ * writes input row (b,t) = b*T+t to output row t*B+b (time-major copy for the BPTT sweep). */
+int isc_logsoftmax_bwd(const float *dlogp, const float *logp, int64_t ld_in, int M, int V,
+                       float *dlogits, int64_t ld_out, int remap_T, void *stream);
+
+/* Pointwise part of the LSTMCell backward (captioner.py:175,181): from d h (= dh + dh2),
+ * d c_next and the saved activated gates produces d(pre-activation gates) [M,4H] and d c_prev.
+ * dgates_sum (optional) += dgates: the step-invariant fc / label inputs of the att-LSTM only
+ * need the sum over time. */
+int isc_lstm_bwd(const float *dh, const float *dh2, const float *dc_next, const float *gates,
+                 const float *c_prev, const float *c, int M, int H, float *dgates, float *dc_prev,
+                 float *dgates_sum, void *stream);
+
+/* Backward of isc_attn_scan_fwd for one step. dP / dV / dw_rows accumulate over time steps when
+ * `accumulate` is set (first processed step writes). dq [B,A] is also the gradient of q2.
+ * dw_rows [B,A]: per-row partial of d w (column-summed once after the loop; deterministic). */
+typedef struct {
+    const float *P, *V, *q, *q2, *w, *alpha, *dout;
+    int64_t alpha_ld;
+    int32_t R, A, D, accumulate;
+    float *dP, *dV, *dq, *dw_rows;
+} isc_scan_bwd_problem;
+
+int isc_attn_scan_bwd(const isc_scan_bwd_problem *probs_host, int n_prob, int B, void *stream);
+
+/* Backward of isc_gate_mix_fwd: dv = beta*dfeat, ds = (1-beta)*dfeat, dz, per-row partials of
+ * d w (dw_rows [B,A]) and d w_bias (db_rows [B]). */
+int isc_gate_mix_bwd(const float *z, const float *w, const float *v, const float *s, const float *beta,
+                     int64_t beta_ld, const float *dfeat, int B, int A, int D, float *dv, float *ds,
+                     float *dz, float *dw_rows, float *db_rows, int accumulate, void *stream);
+
+/* Embedding + ReLU backward: demb[id(r),:] += scale * dout[r / rows_per_grad,:] * (emb[id(r),:] > 0)
+ * [* mask]. pad_first = n_words+1 selects the sentiment-word layout (row 0 of every image = <PAD>). */
+int isc_embed_relu_bwd(const float *emb, int V, int W, const int64_t *ids, int64_t ids_stride,
+                       int n_rows, int rows_per_grad, int pad_first, int64_t pad_id, const float *dout,
+                       float scale, const uint8_t *keep_mask, float mask_scale, float *demb,
+                       void *stream);
+
+/* out[n] (+)= sum_m x[m,n]  (bias gradients) */
+int isc_colsum(const float *x, int64_t ld, int M, int N, float *out, int accumulate, void *stream);
+
+/* dz = dy * (y > 0) [* mask * scale]  (ReLU + Dropout backward of the prologue layers);
+ * y == NULL skips the ReLU test (pure nn.Dropout backward, captioner.py:182). */
+int isc_relu_mask_bwd(const float *dy, const float *y, const uint8_t *keep_mask, float scale, int64_t n,
+                      float *dz, void *stream);
+
+/* XECriterion backward: dlogp (pre-zeroed [B,T,V]) gets -gout/count at every unmasked target;
+ * sum_count = the two floats written by isc_xe_loss_fwd. */
+int isc_xe_loss_bwd(const int64_t *target, const int32_t *lengths, int B, int T, int V,
+                    const float *gout, const float *sum_count, float *dlogp, void *stream);
+
+/* clip_gradient (train_xe.py:19-23, decoder.py:14-18: elementwise clamp_ to +-clip, in place)
+ * followed by torch.optim.Adam's update (captioner.py:422-423), all tensors in one launch.
+ * Pointer tables are HOST arrays of device pointers. clip <= 0 disables the clamp. */
+#define ISC_ADAM_MAX_TENSORS 48
+int isc_clamp_adam(float *const *params_host, float *const *grads_host, float *const *exp_avg_host,
+                   float *const *exp_avg_sq_host, const int64_t *numel_host, int n_tensors, double lr,
+                   double beta1, double beta2, double eps, double weight_decay, double clip, int step,
+                   void *stream);
 
 #ifdef __cplusplus
 }

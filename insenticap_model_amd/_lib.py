@@ -24,7 +24,7 @@ class LinearProblem(C.Structure):
     _fields_ = [('seg', Seg * ISC_MAX_SEG), ('nseg', C.c_int32), ('M', C.c_int32), ('N', C.c_int32),
                 ('relu', C.c_int32), ('bias0', C.c_void_p), ('bias1', C.c_void_p), ('bias2', C.c_void_p),
                 ('keep_mask', C.c_void_p), ('mask_scale', C.c_float), ('ldc', C.c_int32),
-                ('C', C.c_void_p), ('C_pre', C.c_void_p)]
+                ('C', C.c_void_p), ('C_pre', C.c_void_p), ('accumulate', C.c_int32), ('_pad', C.c_int32)]
 
 
 class LstmProblem(C.Structure):
@@ -40,6 +40,13 @@ class ScanProblem(C.Structure):
                 ('w', C.c_void_p), ('w_bias', C.c_void_p), ('R', C.c_int32), ('A', C.c_int32),
                 ('D', C.c_int32), ('_pad', C.c_int32), ('out', C.c_void_p), ('alpha_out', C.c_void_p),
                 ('alpha_ld', C.c_int64)]
+
+
+class ScanBwdProblem(C.Structure):
+    _fields_ = [('P', C.c_void_p), ('V', C.c_void_p), ('q', C.c_void_p), ('q2', C.c_void_p),
+                ('w', C.c_void_p), ('alpha', C.c_void_p), ('dout', C.c_void_p), ('alpha_ld', C.c_int64),
+                ('R', C.c_int32), ('A', C.c_int32), ('D', C.c_int32), ('accumulate', C.c_int32),
+                ('dP', C.c_void_p), ('dV', C.c_void_p), ('dq', C.c_void_p), ('dw_rows', C.c_void_p)]
 
 
 class RolloutStep(C.Structure):
@@ -58,6 +65,7 @@ SIGNATURES = {
     'isc_abi_version': (C.c_int, []),
     'isc_target_arch': (C.c_char_p, []),
     'isc_linear_fwd': (C.c_int, [C.POINTER(LinearProblem), C.c_int, C.c_void_p]),
+    'isc_gemm_bwd': (C.c_int, [C.POINTER(LinearProblem), C.c_int, C.c_int, C.c_void_p]),
     'isc_lstm_fwd': (C.c_int, [C.POINTER(LstmProblem), C.c_void_p]),
     'isc_vocab_fwd': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int,
                                 C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -79,6 +87,26 @@ SIGNATURES = {
                                 C.c_void_p, C.c_void_p, C.c_void_p]),
     'isc_xe_loss_fwd': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                   C.c_void_p, C.c_void_p]),
+    'isc_logsoftmax_bwd': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p,
+                                     C.c_int64, C.c_int, C.c_void_p]),
+    'isc_lstm_bwd': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                               C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'isc_attn_scan_bwd': (C.c_int, [C.POINTER(ScanBwdProblem), C.c_int, C.c_int, C.c_void_p]),
+    'isc_gate_mix_bwd': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                   C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    'isc_embed_relu_bwd': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_int,
+                                     C.c_int, C.c_int64, C.c_void_p, C.c_float, C.c_void_p, C.c_float,
+                                     C.c_void_p, C.c_void_p]),
+    'isc_colsum': (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    'isc_relu_mask_bwd': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int64, C.c_void_p,
+                                    C.c_void_p]),
+    'isc_xe_loss_bwd': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                  C.c_void_p, C.c_void_p, C.c_void_p]),
+    'isc_clamp_adam': (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                 C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_int, C.c_double,
+                                 C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int,
+                                 C.c_void_p]),
 }
 
 _ERRORS = {-1: 'ISC_E_NULL (required pointer is null)', -2: 'ISC_E_SHAPE (unsupported size)',

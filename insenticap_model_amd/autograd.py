@@ -1,21 +1,435 @@
-"""Backward pass of the decode path (BPTT through the HIP kernels). Filled in by the
-training milestone; until then every entry point fails loudly - there is no silent
-fallback to stock torch autograd."""
+"""Training path: forward with saved activations + hand-written BPTT on the HIP kernels.
+
+The reference relies on stock torch autograd through its per-step op graph
+(train_xe.py:189-190, decoder.py:164-165).  Here one `torch.autograd.Function` covers a whole
+call (prologue + T-step unroll): its forward writes every per-step activation straight into
+time-stacked buffers [T(+1), B, ...], and its backward is a reverse sweep in which
+  * the recurrence only runs input-gradient contractions (isc_gemm_bwd NN) and the
+    pointwise / scan backward kernels, and
+  * every weight gradient is ONE contraction over all T*B rows after the sweep (isc_gemm_bwd TN)
+    - weights are shared across time, so nothing is lost by deferring them.
+torch is used for memory, the autograd hook-up and (train mode) random numbers only.
+"""
+import torch
+
+from . import ops
+
+NN, TN = ops.NN, ops.TN
 
 
-def _nyi(what):
-    raise NotImplementedError(
-        '%s with gradients is not implemented yet in insenticap_model_amd; run under torch.no_grad() '
-        'for inference' % what)
+class _Saved:
+    pass
 
 
-def xe_with_grad(*a, **k):
-    _nyi('forward_xe / forward_seq2seq')
+def _pad32(v):
+    return (v + 31) // 32 * 32
 
 
-def rollout_with_grad(*a, **k):
-    _nyi('sampled forward_rl')
+# ------------------------------------------------------------------------------ forward
+def _train_forward(cap, mode, fc, att, cpt_words, senti_words, tokens_in, senti_labels, ss_prob, masks):
+    """Returns (logp [B,T,V], S). tokens_in [B,T]: ground-truth inputs (column 0 = <SOS>)."""
+    p = cap._p()
+    P = cap._prologue(p, mode, fc, att, cpt_words, senti_words, senti_labels, masks)
+    st = cap.settings
+    E, A, H, Wd, V = st['feat_emb_dim'], st['att_hid_dim'], st['rnn_hid_dim'], st['word_emb_dim'], cap.vocab_size
+    B, T = tokens_in.shape
+    has_c, has_s = P.att_e3 is not None, P.words_e3 is not None
+    S = _Saved()
+    S.p, S.P, S.mode, S.B, S.T = p, P, mode, B, T
+    new, zeros = cap._new, cap._zeros
+    S.h1, S.c1, S.h2, S.c2 = (zeros(T + 1, B, H) for _ in range(4))      # slot 0 = initial zero state
+    S.g1, S.g2 = new(T, B, 4 * H), new(T, B, 4 * H)
+    S.xt, S.tok = new(T, B, Wd), torch.empty(T, B, dtype=torch.int64, device=cap._dev)
+    if has_c:
+        S.qa, S.v, S.aC = new(T, B, A), new(T, B, E), new(B, T, P.R)
+    if has_s:
+        S.qw, S.s, S.aS = new(T, B, A), new(T, B, E), new(B, T, P.Mw)
+    if has_c and has_s:
+        S.z, S.f, S.bG = new(T, B, A), new(T, B, E), new(B, T)
+    mask_for = cap._mask_source(masks)
+    S.out_masks, S.out_scale = [], 1.0
+    S.hdrop = None
+    n_tile = (V + 127) // 128
+    pm, ps = new(B, n_tile), new(B, n_tile)
+    pi = new(B, n_tile, dtype=torch.int32)
+    out = new(B, T, V)
+    emb = p['word_embed.0.weight']
+    for t in range(T):
+        it = tokens_in[:, t]
+        if cap.training and t >= 1 and ss_prob > 0.0:           # scheduled sampling, captioner.py:219-228
+            sample_mask = torch.rand(B, device=cap._dev) < ss_prob
+            if bool(sample_mask.any()):
+                drawn = torch.multinomial(out[:, t - 1].detach().exp(), 1).view(-1)
+                it = torch.where(sample_mask, drawn, it)
+        S.tok[t] = it
+        ops.embed_relu_fwd(emb, S.tok[t], S.xt[t], add=P.label_e)
+        om, osc = mask_for('out%d' % t, B, H)
+        save = {'g1': S.g1[t], 'g2': S.g2[t]}
+        if om is not None:
+            if S.hdrop is None:
+                S.hdrop = new(T, B, H)
+            save['hdrop'] = S.hdrop[t]
+            S.out_scale = osc
+        S.out_masks.append(om)
+        ws = {'pmax': pm, 'psum': ps, 'pidx': pi}
+        if has_c:
+            ws['qa'], ws['v'] = S.qa[t], S.v[t]
+        if has_s:
+            ws['qw'], ws['s'] = S.qw[t], S.s[t]
+        if has_c and has_s:
+            ws['z'], ws['f'] = S.z[t], S.f[t]
+        logits = out[:, t]
+        cap._step(p, P, ws, S.xt[t], (S.h1[t], S.h2[t]), (S.c1[t], S.c2[t]),
+                  (S.h1[t + 1], S.h2[t + 1]), (S.c1[t + 1], S.c2[t + 1]),
+                  S.aC[:, t] if has_c else None, S.aS[:, t] if has_s else None,
+                  S.bG[:, t:t + 1] if (has_c and has_s) else None, logits, om, osc, save=save)
+        ops.logsoftmax_apply(logits, pm, ps)
+    cap._set_weights(S.aC if has_c else None, S.aS if has_s else None,
+                     S.bG if (has_c and has_s) else None, T)
+    S.logp = out
+    return out, S
 
 
-def xe_criterion_with_grad(*a, **k):
-    _nyi('XECriterion')
+# ------------------------------------------------------------------------------ backward
+def _backward(cap, S, dlogp, d_fc_feats, d_cpt_feats):
+    """Returns {param name: gradient}. dlogp [B,T,V] (contiguous), optional gradients of the
+    `fc_feats` (pre-dropout) and `cpt_feats` attributes."""
+    p, P, B, T = S.p, S.P, S.B, S.T
+    st = cap.settings
+    E, A, H, Wd, V = st['feat_emb_dim'], st['att_hid_dim'], st['rnn_hid_dim'], st['word_emb_dim'], cap.vocab_size
+    new, zeros = cap._new, cap._zeros
+    has_c, has_s = P.att_e3 is not None, P.words_e3 is not None
+    gate = has_c and has_s
+    G = {}
+    TB = T * B
+
+    def nn(segs, out, acc=False):
+        return ops.gemm_problem(segs, out, NN, accumulate=acc)
+
+    def tn(a, w, shape=None):
+        out = new(a.shape[1], w.shape[1])
+        ops.gemm_bwd([ops.gemm_problem([(a, w)], out, TN)], TN)
+        return out
+
+    def csum(x, n=None):
+        out = new(x.shape[1])
+        ops.colsum(x, out)
+        return out
+
+    # ---- classifier + log-softmax: outside the recurrence, all T*B rows at once (time-major rows)
+    Vp = _pad32(V)
+    dlogits = new(TB, Vp)
+    ops.logsoftmax_bwd(dlogp, S.logp, dlogits, B * T, V, remap_T=T)
+    Wc = p['classifier.weight']
+    hdrop_tb = (S.hdrop if S.hdrop is not None else S.h2[1:]).reshape(TB, H)
+    dhd = new(TB, H)
+    ops.gemm_bwd([nn([(dlogits, Wc)], dhd)], NN)
+    if V % 4 == 0:
+        dWc = new(V, H)
+        ops.gemm_bwd([ops.gemm_problem([(dlogits[:, :V], hdrop_tb)], dWc, TN)], TN)
+    else:            # vocabulary not a multiple of 4: contract on the zero-padded columns, then trim
+        dWp = new(Vp, H)
+        ops.gemm_bwd([ops.gemm_problem([(dlogits, hdrop_tb)], dWp, TN)], TN)
+        dWc = dWp[:V].contiguous()
+    G['classifier.weight'] = dWc
+    db = new(Vp)
+    ops.colsum(dlogits, db)
+    G['classifier.bias'] = db[:V].contiguous() if Vp != V else db
+    if S.hdrop is not None:     # nn.Dropout on h_lang (captioner.py:182)
+        mk = torch.stack(S.out_masks).reshape(TB, H)
+        ops.relu_mask_bwd(dhd, None, dhd, keep_mask=mk, scale=S.out_scale)
+    dhd = dhd.view(T, B, H)
+
+    Wih1, Whh1 = p['att_lstm.weight_ih'], p['att_lstm.weight_hh']
+    Wih2, Whh2 = p['lang_lstm.weight_ih'], p['lang_lstm.weight_hh']
+    dG1, dG2 = new(T, B, 4 * H), new(T, B, 4 * H)
+    dG1_sum = zeros(B, 4 * H)
+    d_feat, dh1 = new(B, E), new(B, H)
+    dh2_rec, dh1_rec = new(B, H), new(B, H)
+    dc1_rec, dc2_rec = [new(B, H), new(B, H)], [new(B, H), new(B, H)]
+    if has_c:
+        dqa, dv = new(T, B, A), new(B, E)
+        dP_att, dV_att = new(B, P.R, A), new(B, P.R, E)
+        dwc_rows = new(B, A)
+    if has_s:
+        dqw, ds = new(T, B, A), new(B, E)
+        dP_w, dV_w = new(B, P.Mw, A), new(B, P.Mw, Wd)
+        dws_rows = new(B, A)
+    if gate:
+        dz = new(T, B, A)
+        dwg_rows, dbg_rows = new(B, A), new(B)
+    for t in range(T - 1, -1, -1):
+        first = (t == T - 1)
+        cur, nxt = t & 1, (t + 1) & 1
+        # lang-LSTM cell
+        ops.lstm_bwd(dhd[t], None if first else dh2_rec, None if first else dc2_rec[nxt], S.g2[t], S.c2[t],
+                     S.c2[t + 1], dG2[t], dc2_rec[cur])
+        ops.gemm_bwd([nn([(dG2[t], Wih2[:, 0:E])], d_feat), nn([(dG2[t], Wih2[:, E:E + H])], dh1),
+                      nn([(dG2[t], Whh2)], dh2_rec)], NN)
+        # attention
+        scans = []
+        if gate:
+            ops.gate_mix_bwd(S.z[t], p['attention.att_alpha.weight'], S.v[t], S.s[t], S.bG[:, t:t + 1], d_feat,
+                             dv, ds, dz[t], dwg_rows, dbg_rows, not first)
+            ops.gemm_bwd([nn([(dz[t], p['attention.cont2att.weight'])], dv, True),
+                          nn([(dz[t], p['attention.senti2att.weight'])], ds, True),
+                          nn([(dz[t], p['attention.h2att.weight'])], dh1, True)], NN)
+        if has_c:
+            scans.append(ops.scan_bwd_problem(P.att_p3, P.att_e3, S.qa[t], p['attention.cont_att.att_alpha.weight'],
+                                              S.aC[:, t], dv if gate else d_feat, dP_att, dV_att, dqa[t],
+                                              dwc_rows, not first))
+        if has_s:
+            scans.append(ops.scan_bwd_problem(P.words_p3, P.words_e3, S.qw[t],
+                                              p['attention.senti_att.word_alpha.weight'], S.aS[:, t],
+                                              ds if gate else d_feat, dP_w, dV_w, dqw[t], dws_rows, not first,
+                                              q2=P.label_w))
+        ops.attn_scan_bwd(scans, B)
+        segs = []
+        if has_c:
+            segs.append((dqa[t], p['attention.cont_att.h2att.weight']))
+        if has_s:
+            segs.append((dqw[t], p['attention.senti_att.h2word.weight']))
+        ops.gemm_bwd([nn(segs, dh1, True)], NN)
+        # att-LSTM cell
+        ops.lstm_bwd(dh1, None if first else dh1_rec, None if first else dc1_rec[nxt], S.g1[t], S.c1[t],
+                     S.c1[t + 1], dG1[t], dc1_rec[cur], dG1_sum)
+        if t > 0:
+            ops.gemm_bwd([nn([(dG1[t], Wih1[:, 0:H])], dh2_rec, True), nn([(dG1[t], Whh1)], dh1_rec)], NN)
+
+    # ---- weight gradients: one contraction over all T*B rows each
+    dG1f, dG2f = dG1.view(TB, 4 * H), dG2.view(TB, 4 * H)
+    h1_prev, h1_cur = S.h1[:T].reshape(TB, H), S.h1[1:].reshape(TB, H)
+    h2_prev = S.h2[:T].reshape(TB, H)
+    feat_tb = (S.f if gate else (S.v if has_c else S.s)).view(TB, E)
+    gW1 = new(4 * H, H + E + Wd)
+    ops.gemm_bwd([ops.gemm_problem([(dG1f, h2_prev)], gW1[:, 0:H], TN),
+                  ops.gemm_problem([(dG1_sum, P.fc_e)], gW1[:, H:H + E], TN),
+                  ops.gemm_problem([(dG1f, S.xt.view(TB, Wd))], gW1[:, H + E:], TN)], TN)
+    G['att_lstm.weight_ih'] = gW1
+    gW2, gwhh1 = new(4 * H, E + H), new(4 * H, H)
+    ops.gemm_bwd([ops.gemm_problem([(dG1f, h1_prev)], gwhh1, TN),
+                  ops.gemm_problem([(dG2f, feat_tb)], gW2[:, 0:E], TN),
+                  ops.gemm_problem([(dG2f, h1_cur)], gW2[:, E:], TN)], TN)
+    G['att_lstm.weight_hh'] = gwhh1
+    G['lang_lstm.weight_ih'] = gW2
+    G['lang_lstm.weight_hh'] = tn(dG2f, h2_prev)
+    G['att_lstm.bias_ih'] = csum(dG1f)
+    G['att_lstm.bias_hh'] = G['att_lstm.bias_ih'].clone()
+    G['lang_lstm.bias_ih'] = csum(dG2f)
+    G['lang_lstm.bias_hh'] = G['lang_lstm.bias_ih'].clone()
+    # inputs of the att-LSTM: fc (step-invariant), xt = relu(Emb[tok]) + label_e
+    d_fc_e = new(B, E)
+    d_label_e = new(B, Wd) if P.label_e is not None else None
+    dxt = new(TB, Wd)
+    probs = [nn([(dG1_sum, Wih1[:, H:H + E])], d_fc_e), nn([(dG1f, Wih1[:, H + E:])], dxt)]
+    if d_label_e is not None:
+        probs.append(nn([(dG1_sum, Wih1[:, H + E:])], d_label_e))
+    ops.gemm_bwd(probs, NN)
+    emb = p['word_embed.0.weight']
+    dEmb = zeros(V, Wd)
+    ops.embed_relu_bwd(emb, S.tok.view(-1), dxt, dEmb, TB)
+
+    zero1 = lambda: zeros(1)
+    if has_c:
+        dqaf = dqa.view(TB, A)
+        G['attention.cont_att.h2att.weight'] = tn(dqaf, h1_cur)
+        G['attention.cont_att.h2att.bias'] = csum(dqaf)
+        G['attention.cont_att.att_alpha.weight'] = csum(dwc_rows).view(1, A)
+        G['attention.cont_att.att_alpha.bias'] = zero1()       # softmax is shift invariant
+    if has_s:
+        dqwf = dqw.view(TB, A)
+        G['attention.senti_att.h2word.weight'] = tn(dqwf, h1_cur)
+        G['attention.senti_att.h2word.bias'] = csum(dqwf)
+        G['attention.senti_att.word_alpha.weight'] = csum(dws_rows).view(1, A)
+        G['attention.senti_att.word_alpha.bias'] = zero1()
+        # label2word(label_e) enters every step's score: d label_w = sum_t dqw[t]
+        d_label_w = new(B * A)
+        ops.colsum(dqw.view(T, B * A), d_label_w)
+        d_label_w = d_label_w.view(B, A)
+        G['attention.senti_att.label2word.weight'] = tn(d_label_w, P.label_e)
+        G['attention.senti_att.label2word.bias'] = csum(d_label_w)
+        ops.gemm_bwd([nn([(d_label_w, p['attention.senti_att.label2word.weight'])], d_label_e, True)], NN)
+    if gate:
+        dzf = dz.view(TB, A)
+        G['attention.cont2att.weight'] = tn(dzf, S.v.view(TB, E))
+        G['attention.senti2att.weight'] = tn(dzf, S.s.view(TB, E))
+        G['attention.h2att.weight'] = tn(dzf, h1_cur)
+        bz = csum(dzf)
+        G['attention.cont2att.bias'], G['attention.senti2att.bias'], G['attention.h2att.bias'] = \
+            bz, bz.clone(), bz.clone()
+        G['attention.att_alpha.weight'] = csum(dwg_rows).view(1, A)
+        G['attention.att_alpha.bias'] = csum(dbg_rows.view(B, 1))
+
+    # ---- prologue backward
+    if d_label_e is not None:
+        dL = zeros(p['senti_label_embed.0.weight'].shape[0], Wd)
+        ops.embed_relu_bwd(p['senti_label_embed.0.weight'], P.label_ids, d_label_e, dL, B,
+                           keep_mask=P.m_label, mask_scale=P.sc)
+        G['senti_label_embed.0.weight'] = dL
+    if has_c:
+        BR = B * P.R
+        att_e, att_p = P.att_e3.view(BR, E), P.att_p3.view(BR, A)
+        dzp = new(BR, A)
+        ops.relu_mask_bwd(dP_att.view(BR, A), att_p, dzp)
+        G['att2att.0.weight'] = tn(dzp, att_e)
+        G['att2att.0.bias'] = csum(dzp)
+        dVa = dV_att.view(BR, E)
+        ops.gemm_bwd([nn([(dzp, p['att2att.0.weight'])], dVa, True)], NN)
+        dze = new(BR, E)
+        ops.relu_mask_bwd(dVa, att_e, dze, keep_mask=P.m_att, scale=P.sc)
+        G['att_embed.0.weight'] = tn(dze, P.x_att)
+        G['att_embed.0.bias'] = csum(dze)
+    if has_s:
+        BM = B * P.Mw
+        w_e, w_p = P.words_e3.view(BM, Wd), P.words_p3.view(BM, A)
+        dzp = new(BM, A)
+        ops.relu_mask_bwd(dP_w.view(BM, A), w_p, dzp)
+        G['senti2att.0.weight'] = tn(dzp, w_e)
+        G['senti2att.0.bias'] = csum(dzp)
+        dVw = dV_w.view(BM, Wd)
+        ops.gemm_bwd([nn([(dzp, p['senti2att.0.weight'])], dVw, True)], NN)
+        ops.embed_relu_bwd(emb, P.sw_ids, dVw, dEmb, BM, pad_first=P.Mw, pad_id=cap.pad_id,
+                           keep_mask=P.m_words, mask_scale=P.sc)
+    # fc_embed (xe / rl) and cpt2fc
+    d_cpt = None
+    if S.mode != 'seq2seq':
+        dzf = new(B, E)
+        ops.relu_mask_bwd(d_fc_e, P.fc_e, dzf, keep_mask=P.m_fc, scale=P.sc)
+        if d_fc_feats is not None:
+            extra = new(B, E)
+            ops.relu_mask_bwd(d_fc_feats.contiguous(), cap_pre(P, 'fc'), extra)
+            dzf = dzf + extra
+        G['fc_embed.0.weight'] = tn(dzf, P.x_fc)
+        G['fc_embed.0.bias'] = csum(dzf)
+        if d_cpt_feats is not None:
+            d_cpt = new(B, E)
+            ops.relu_mask_bwd(d_cpt_feats.contiguous(), P.cpt, d_cpt)
+    else:
+        d_cpt = new(B, E)       # seq2seq: fc_e := dropout(cpt_feats) (captioner.py:250-251)
+        ops.relu_mask_bwd(d_fc_e, P.cpt, d_cpt, keep_mask=P.m_cpt, scale=P.sc)
+        if d_cpt_feats is not None:
+            extra = new(B, E)
+            ops.relu_mask_bwd(d_cpt_feats.contiguous(), cap_pre(P, 'cpt'), extra)
+            d_cpt = d_cpt + extra
+    if d_cpt is not None:
+        G['cpt2fc.0.weight'] = tn(d_cpt, P.cmean)
+        G['cpt2fc.0.bias'] = csum(d_cpt)
+        dcm = new(B, Wd)
+        ops.gemm_bwd([nn([(d_cpt, p['cpt2fc.0.weight'])], dcm)], NN)
+        C = P.cpt_ids.shape[1]
+        ops.embed_relu_bwd(emb, P.cpt_ids.view(-1), dcm, dEmb, B * C, rows_per_grad=C, scale=1.0 / C)
+    dEmb[cap.pad_id].zero_()     # nn.Embedding(padding_idx=pad_id): the <PAD> row never gets a gradient
+    G['word_embed.0.weight'] = dEmb
+    return G
+
+
+def cap_pre(P, which):
+    """Pre-dropout activation (the tensor the `fc_feats` / `cpt_feats` attribute exposes); equals the
+    post-dropout one in sign wherever the keep-mask is 1, and its gradient ignores the mask."""
+    return P.fc_pre if which == 'fc' else P.cpt_pre
+
+
+class DecodeFn(torch.autograd.Function):
+    """(mode, inputs, *params) -> (logp, cpt_feats[, fc_feats])."""
+
+    @staticmethod
+    def forward(ctx, cap, mode, fc, att, cpt_words, senti_words, tokens_in, senti_labels, ss_prob, masks,
+                names, *params):
+        with torch.no_grad():
+            logp, S = _train_forward(cap, mode, fc, att, cpt_words, senti_words, tokens_in, senti_labels,
+                                     ss_prob, masks)
+        S.P.fc_pre = cap.fc_feats if mode != 'seq2seq' else None
+        S.P.cpt_pre = cap.cpt_feats
+        ctx.cap, ctx.S, ctx.names = cap, S, names
+        ctx.set_materialize_grads(False)
+        outs = [logp, cap.cpt_feats]
+        if mode != 'seq2seq':
+            outs.append(cap.fc_feats)
+        # the attribute tensors alias internal buffers: hand autograd distinct objects
+        return tuple(o if i == 0 else o.clone() for i, o in enumerate(outs))
+
+    @staticmethod
+    def backward(ctx, dlogp, d_cpt, d_fc=None):
+        cap, S = ctx.cap, ctx.S
+        if dlogp is None:
+            dlogp = torch.zeros_like(S.logp)
+        with torch.no_grad():
+            G = _backward(cap, S, dlogp.contiguous(), d_fc, d_cpt)
+        grads = tuple(G.get(n) for n in ctx.names)
+        ctx.S = None
+        return (None,) * 11 + grads
+
+
+def xe_with_grad(cap, mode, fc, att, cpt_words, senti_words, captions, senti_labels, ss_prob, masks):
+    names = [n for n, q in cap.named_parameters() if q.requires_grad]
+    params = [q for _, q in cap.named_parameters() if q.requires_grad]
+    tokens_in = cap._ids(captions)[:, :-1].contiguous()
+    outs = DecodeFn.apply(cap, mode, fc, att, cpt_words, senti_words, tokens_in, senti_labels, ss_prob, masks,
+                          names, *params)
+    logp = outs[0]
+    cap.cpt_feats = outs[1]
+    if mode != 'seq2seq':
+        cap.fc_feats = outs[2]
+    return logp
+
+
+def rollout_with_grad(cap, fc, att, cpt_words, senti_words, senti_labels, T, replay, masks):
+    """Sampled roll-out with REINFORCE gradients (captioner.py:290-349, sample_max=0, train mode):
+    (1) sample on device without a graph, (2) replay the fed tokens through the differentiable
+    unroll and gather log p(token).  Same result as differentiating the sampling loop itself."""
+    with torch.no_grad():
+        if masks is None and cap.training and cap.drop.p > 0:
+            masks = _draw_masks(cap, fc, att, senti_words, T)
+        seq, _, seq_masks, raw, steps = cap._rollout(fc, att, cpt_words, senti_words, senti_labels, T, 0,
+                                                     replay, masks)
+    B = seq.shape[0]
+    sos = torch.full((B, 1), cap.sos_id, dtype=torch.int64, device=seq.device)
+    fed = torch.cat([sos, seq], dim=1)          # forward feeds captions[:, :-1] = [SOS, seq[:, :T-1]]
+    names = [n for n, q in cap.named_parameters() if q.requires_grad]
+    params = [q for _, q in cap.named_parameters() if q.requires_grad]
+    was = cap.training
+    outs = DecodeFn.apply(cap, 'rl', fc, att, cpt_words, senti_words, fed[:, :-1].contiguous(), senti_labels,
+                          0.0, masks if masks is not None else {}, names, *params)
+    cap.train(was)
+    logp = outs[0]
+    cap.cpt_feats, cap.fc_feats = outs[1], outs[2]
+    lp = logp.gather(2, raw.unsqueeze(2)).squeeze(2)
+    live = (torch.arange(T, device=seq.device) < steps).to(lp.dtype)      # zero after the early break
+    return seq, lp * live, seq_masks
+
+
+def _draw_masks(cap, fc, att, senti_words, T):
+    """One set of dropout keep-masks shared by the sampling pass and its differentiable replay."""
+    st = cap.settings
+    E, Wd, H = st['feat_emb_dim'], st['word_emb_dim'], st['rnn_hid_dim']
+    B = fc.shape[0]
+    R = att.reshape(B, -1, att.shape[-1]).shape[1]
+    keep = lambda *s: (torch.rand(s, device=cap._dev) >= cap.drop.p).to(torch.uint8)
+    m = {'fc': keep(B, E), 'att': keep(B * R, E), 'label': keep(B, Wd),
+         'words': keep(B * (senti_words.shape[1] + 1), Wd)}
+    for t in range(T):
+        m['out%d' % t] = keep(B, H)
+    return m
+
+
+class XELossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, target, lengths_i32):
+        out2 = torch.empty(2, dtype=torch.float32, device=pred.device)
+        ops.xe_loss_fwd(pred, target, lengths_i32, out2)
+        ctx.save_for_backward(target, lengths_i32, out2)
+        ctx.shape = pred.shape
+        return out2[0] / out2[1]
+
+    @staticmethod
+    def backward(ctx, g):
+        target, lengths_i32, out2 = ctx.saved_tensors
+        dlogp = torch.zeros(ctx.shape, dtype=torch.float32, device=target.device)
+        ops.xe_loss_bwd(target, lengths_i32, g.reshape(1).contiguous().float(), out2, dlogp)
+        return dlogp, None, None
+
+
+def xe_criterion_with_grad(pred, target, lengths):
+    ops.require_device(pred, target)
+    ln = torch.tensor(lengths, dtype=torch.int32, device=pred.device)
+    return XELossFn.apply(pred.contiguous(), target.long().contiguous(), ln)

@@ -49,6 +49,10 @@ class _Pro:
     label_e = None   # [B,W]   sentiment-label embedding (added to every xt)
     label_w = None   # [B,A]   label2word(label_e): step-invariant term of the senti attention
     B = R = Mw = 0
+    # kept for the backward pass: raw inputs, ids and dropout keep-masks
+    x_fc = x_att = cmean = cpt = cpt_ids = label_ids = sw_ids = None
+    m_fc = m_att = m_cpt = m_label = m_words = None
+    sc = 1.0
 
 
 class Captioner(nn.Module):
@@ -150,6 +154,7 @@ class Captioner(nn.Module):
             R = att.shape[1]
             P.B, P.R = B, R
             m, sc = mask_for('fc', B, E)
+            P.x_fc, P.m_fc, P.sc = fc, m, sc
             P.fc_e = self._new(B, E)
             self.fc_feats = self._new(B, E) if m is not None else P.fc_e
             first.append(ops.linear_problem([(fc, p['fc_embed.0.weight'])], P.fc_e, p['fc_embed.0.bias'],
@@ -160,10 +165,13 @@ class Captioner(nn.Module):
             P.B = B
         if cpt_words is not None:
             cmean = self._new(B, Wd)
-            ops.embed_relu_mean_fwd(p['word_embed.0.weight'], self._ids(cpt_words), cmean)
+            P.cpt_ids = self._ids(cpt_words)
+            ops.embed_relu_mean_fwd(p['word_embed.0.weight'], P.cpt_ids, cmean)
             cpt = self._new(B, E)
+            P.cmean, P.cpt = cmean, cpt
             if mode == 'seq2seq':
                 m, sc = mask_for('cpt', B, E)
+                P.m_cpt, P.sc = m, sc
                 self.cpt_feats = self._new(B, E) if m is not None else cpt
                 first.append(ops.linear_problem([(cmean, p['cpt2fc.0.weight'])], cpt, p['cpt2fc.0.bias'],
                                                 relu=True, keep_mask=m, mask_scale=sc,
@@ -176,8 +184,10 @@ class Captioner(nn.Module):
         ops.linear_fwd(first)
         if senti_labels is not None:
             P.label_e = self._new(B, Wd)
-            ops.embed_relu_fwd(p['senti_label_embed.0.weight'], self._ids(senti_labels).reshape(-1), P.label_e)
+            P.label_ids = self._ids(senti_labels).reshape(-1)
+            ops.embed_relu_fwd(p['senti_label_embed.0.weight'], P.label_ids, P.label_e)
             m, sc = mask_for('label', B, Wd)
+            P.m_label, P.sc = m, sc
             if m is not None:
                 P.label_e = P.label_e * (m.float() * sc)   # [B,W] elementwise, train mode only
             if senti_words is not None:
@@ -188,6 +198,7 @@ class Captioner(nn.Module):
         second = []
         if mode != 'seq2seq':
             m, sc = mask_for('att', B * R, E)
+            P.x_att, P.m_att, P.sc = att.reshape(B * R, -1), m, sc
             att_e = self._new(B * R, E)
             ops.linear_fwd([ops.linear_problem([(att.reshape(B * R, -1), p['att_embed.0.weight'])], att_e,
                                                p['att_embed.0.bias'], relu=True, keep_mask=m, mask_scale=sc)])
@@ -199,6 +210,7 @@ class Captioner(nn.Module):
             sw = self._ids(senti_words).reshape(B, -1)
             P.Mw = sw.shape[1] + 1
             m, sc = mask_for('words', B * P.Mw, Wd)
+            P.sw_ids, P.m_words, P.sc = sw, m, sc
             words_e = self._new(B * P.Mw, Wd)
             ops.embed_senti_words_fwd(p['word_embed.0.weight'], sw, self.pad_id, words_e, m, sc)
             words_p = self._new(B * P.Mw, A)
@@ -228,9 +240,12 @@ class Captioner(nn.Module):
         return ws
 
     def _step(self, p, P, ws, xt, h_cur, c_cur, h_nxt, c_nxt, alpha_c=None, alpha_s=None, beta=None,
-              logits=None, out_mask=None, out_scale=1.0):
-        """forward_step (captioner.py:168-186) on `rows` sequences. State buffers are [2,rows,H];
-        reads *_cur, writes *_nxt, the vocabulary tile statistics and (optionally) raw logits."""
+              logits=None, out_mask=None, out_scale=1.0, save=None):
+        """forward_step (captioner.py:168-186) on `rows` sequences. h/c arguments are indexable
+        pairs (0 = att-LSTM, 1 = lang-LSTM) of [rows,H] tensors; reads *_cur, writes *_nxt, the
+        vocabulary tile statistics and (optionally) raw logits. `save` (training): dict with
+        'g1','g2' [rows,4H] gate buffers and 'hdrop' [rows,H] kept for the backward pass."""
+        save = save or {}
         st = self.settings
         E, H = st['feat_emb_dim'], st['rnn_hid_dim']
         Wih, Whh = p['att_lstm.weight_ih'], p['att_lstm.weight_hh']
@@ -238,7 +253,8 @@ class Captioner(nn.Module):
         # att-LSTM over cat[h_lang_prev, fc, xt] (captioner.py:174) without materialising the cat
         ops.lstm_fwd([(h_cur[1], Wih[:, 0:H]), (P.fc_e, Wih[:, H:H + E]), (xt, Wih[:, H + E:]),
                       (h_cur[0], Whh)],
-                     p['att_lstm.bias_ih'], p['att_lstm.bias_hh'], c_cur[0], h_nxt[0], c_nxt[0])
+                     p['att_lstm.bias_ih'], p['att_lstm.bias_hh'], c_cur[0], h_nxt[0], c_nxt[0],
+                     gates_out=save.get('g1'))
         h1 = h_nxt[0]
         has_cont, has_senti = P.att_e3 is not None, P.words_e3 is not None
         probs, scans = [], []
@@ -269,10 +285,12 @@ class Captioner(nn.Module):
         else:
             feat = ws['v'] if has_cont else ws['s']
         Wih2, Whh2 = p['lang_lstm.weight_ih'], p['lang_lstm.weight_hh']
-        hdrop = self._new(rows, H) if out_mask is not None else None
+        hdrop = None
+        if out_mask is not None:
+            hdrop = save['hdrop'] if 'hdrop' in save else self._new(rows, H)
         ops.lstm_fwd([(feat, Wih2[:, 0:E]), (h1, Wih2[:, E:E + H]), (h_cur[1], Whh2)],
                      p['lang_lstm.bias_ih'], p['lang_lstm.bias_hh'], c_cur[1], h_nxt[1], c_nxt[1],
-                     h_keep_mask=out_mask, mask_scale=out_scale, hdrop_out=hdrop)
+                     gates_out=save.get('g2'), h_keep_mask=out_mask, mask_scale=out_scale, hdrop_out=hdrop)
         ops.vocab_fwd(hdrop if hdrop is not None else h_nxt[1], p['classifier.weight'],
                       p['classifier.bias'], ws['pmax'], ws['psum'], ws['pidx'], logits)
 
@@ -439,7 +457,8 @@ class Captioner(nn.Module):
                                  decoding_constraint, max_seq_len)
 
     def get_optim_criterion(self, lr, weight_decay=0):
-        return torch.optim.Adam(self.parameters(), lr=lr, weight_decay=weight_decay), \
+        from .optim import FusedClampAdam   # a torch.optim.Adam subclass: same state_dict layout
+        return FusedClampAdam(self.parameters(), lr=lr, weight_decay=weight_decay), \
             XECriterion(), nn.MSELoss()  # xe, domain align
 
 

@@ -1,0 +1,402 @@
+// Backward (BPTT) kernels of the decode step - what torch autograd derives for the reference's
+// stock ops (train_xe.py:189-192, decoder.py:161-167) - plus the fused clamp+Adam update
+// (train_xe.py:19-23 / captioner.py:422-423).  All contractions run on the MFMA GEMM
+// (isc_gemm_bwd); this file holds the HBM-bound pointwise / scan parts.
+#include "common.h"
+
+// ------------------------------------------------------------------ log-softmax backward
+// dlogits[m,:] = dlogp[m,:] - exp(logp[m,:]) * sum_v dlogp[m,v];  columns V..ld_out-1 are zeroed
+// (the padded row doubles as the k-minor A operand of dH = dlogits * W_cls).
+__global__ __launch_bounds__(256) void logsoftmax_bwd_kernel(const float *dlogp, const float *logp,
+                                                             long long ld_in, int V, float *dlogits,
+                                                             long long ld_out, int M, int remap_T) {
+    __shared__ float red[4];
+    const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // optional row remap [B,T] -> [T,B]: the time-major copy feeds the per-step BPTT slices
+    const int mo = remap_T > 0 ? (m % remap_T) * (M / remap_T) + m / remap_T : m;
+    const float *g = dlogp + (long long)m * ld_in;
+    const float *lp = logp + (long long)m * ld_in;
+    float s = 0.f;
+    for (int i = tid; i < V; i += 256) s += g[i];
+    s = wave_sum(s);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    const float tot = (red[0] + red[1]) + (red[2] + red[3]);
+    float *o = dlogits + (long long)mo * ld_out;
+    for (int i = tid; i < ld_out; i += 256) o[i] = (i < V) ? g[i] - expf(lp[i]) * tot : 0.f;
+}
+
+extern "C" int isc_logsoftmax_bwd(const float *dlogp, const float *logp, int64_t ld_in, int M, int V,
+                                  float *dlogits, int64_t ld_out, int remap_T, void *stream) {
+    if (!dlogp || !logp || !dlogits) return ISC_E_NULL;
+    if (M <= 0 || V <= 0 || ld_out < V || remap_T < 0 || (remap_T > 0 && M % remap_T)) return ISC_E_SHAPE;
+    hipLaunchKernelGGL(logsoftmax_bwd_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, dlogp, logp,
+                       (long long)ld_in, V, dlogits, (long long)ld_out, M, remap_T);
+    ISC_LAUNCH_CHECK();
+    return ISC_OK;
+}
+
+// ------------------------------------------------------------------ LSTM cell backward (pointwise)
+// gates = activated (i,f,g,o) saved by the forward kernel.
+__global__ __launch_bounds__(256) void lstm_bwd_kernel(const float *dh, const float *dh2, const float *dc_next,
+                                                       const float *gates, const float *c_prev,
+                                                       const float *c, int M, int H, float *dgates,
+                                                       float *dc_prev, float *dgates_sum) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)M * H) return;
+    const int m = (int)(idx / H), u = (int)(idx % H);
+    const float *g = gates + (long long)m * 4 * H + u;
+    const float gi = g[0], gf = g[H], gg = g[2 * H], go = g[3 * H];
+    float d_h = dh[idx];
+    if (dh2) d_h += dh2[idx];
+    const float tc = tanhf(c[idx]);
+    float d_c = d_h * go * (1.f - tc * tc);
+    if (dc_next) d_c += dc_next[idx];
+    const float di = d_c * gg * gi * (1.f - gi);
+    const float df = d_c * c_prev[idx] * gf * (1.f - gf);
+    const float dg = d_c * gi * (1.f - gg * gg);
+    const float d_o = d_h * tc * go * (1.f - go);
+    float *o = dgates + (long long)m * 4 * H + u;
+    o[0] = di; o[H] = df; o[2 * H] = dg; o[3 * H] = d_o;
+    dc_prev[idx] = d_c * gf;
+    if (dgates_sum) {
+        float *a = dgates_sum + (long long)m * 4 * H + u;
+        a[0] += di; a[H] += df; a[2 * H] += dg; a[3 * H] += d_o;
+    }
+}
+
+extern "C" int isc_lstm_bwd(const float *dh, const float *dh2, const float *dc_next, const float *gates,
+                            const float *c_prev, const float *c, int M, int H, float *dgates,
+                            float *dc_prev, float *dgates_sum, void *stream) {
+    if (!dh || !gates || !c_prev || !c || !dgates || !dc_prev) return ISC_E_NULL;
+    if (M <= 0 || H <= 0) return ISC_E_SHAPE;
+    const long long n = (long long)M * H;
+    hipLaunchKernelGGL(lstm_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, dh, dh2, dc_next, gates, c_prev, c, M, H, dgates, dc_prev,
+                       dgates_sum);
+    ISC_LAUNCH_CHECK();
+    return ISC_OK;
+}
+
+// ------------------------------------------------------------------ attention scan backward
+struct DevScanBwd {
+    const float *P, *V, *q, *q2, *w, *alpha, *dout;
+    long long alpha_ld;
+    int R, A, D, accumulate;
+    float *dP, *dV, *dq, *dw_rows;
+};
+struct DevScanBwdLaunch {
+    DevScanBwd p[2];
+};
+
+// One workgroup per (row, problem).  LDS: da[R] (d alpha -> d e), red[ngrp][A] x2 for dq / dw.
+__global__ __launch_bounds__(256) void attn_scan_bwd_kernel(const DevScanBwdLaunch L) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const DevScanBwd &S = L.p[blockIdx.y];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int R = S.R, A = S.A, D = S.D;
+    float *de = smem;                         // [R]
+    float *red = smem + ((R + 3) & ~3);       // [2][ngrp][A]
+    const float *Vb = S.V + (long long)b * R * D;
+    const float *Pb = S.P + (long long)b * R * A;
+    const float *dout = S.dout + (long long)b * D;
+    const float *alpha = S.alpha + (long long)b * S.alpha_ld;
+
+    // d alpha_r = dout . V[r]
+    for (int r = wave; r < R; r += 4) {
+        float acc = 0.f;
+        for (int d = lane; d < D; d += 64) acc += dout[d] * Vb[(long long)r * D + d];
+        acc = wave_sum(acc);
+        if (lane == 0) de[r] = acc;
+    }
+    __syncthreads();
+    float s = 0.f;
+    for (int r = 0; r < R; ++r) s += alpha[r] * de[r];
+    __syncthreads();
+    for (int r = tid; r < R; r += 256) de[r] = alpha[r] * (de[r] - s);   // d e_r (softmax backward)
+    __syncthreads();
+
+    // dV[r,:] (+)= alpha_r * dout
+    float *dVb = S.dV + (long long)b * R * D;
+    for (int i = tid; i < R * D; i += 256) {
+        const int r = i / D, d = i % D;
+        const float v = alpha[r] * dout[d];
+        dVb[i] = S.accumulate ? dVb[i] + v : v;
+    }
+    // dP[r,a] (+)= de_r * w[a] * (1 - tanh^2);  dq[a] = sum_r (...);  dw_rows[b,a] += sum_r de_r * tanh
+    float *dPb = S.dP + (long long)b * R * A;
+    const int ngrp = (A <= 256) ? 256 / A : 1;   // region groups working in parallel
+    const int a0 = (A <= 256) ? tid % A : tid, grp = (A <= 256) ? tid / A : 0;
+    for (int a = a0; a < A; a += (A <= 256 ? A : 256)) {
+        const float qa = S.q[(long long)b * A + a] + (S.q2 ? S.q2[(long long)b * A + a] : 0.f);
+        const float wa = S.w[a];
+        float dq = 0.f, dw = 0.f;
+        if (grp < ngrp) {
+            for (int r = grp; r < R; r += ngrp) {
+                const float t = tanhf(Pb[(long long)r * A + a] + qa);
+                const float gr = de[r] * wa * (1.f - t * t);
+                const long long o = (long long)r * A + a;
+                dPb[o] = S.accumulate ? dPb[o] + gr : gr;
+                dq += gr;
+                dw += de[r] * t;
+            }
+            red[grp * A + a] = dq;
+            red[(ngrp + grp) * A + a] = dw;
+        }
+    }
+    __syncthreads();
+    for (int a = tid; a < A; a += 256) {
+        float dq = 0.f, dw = 0.f;
+        for (int g = 0; g < ngrp; ++g) { dq += red[g * A + a]; dw += red[(ngrp + g) * A + a]; }
+        S.dq[(long long)b * A + a] = dq;
+        float *o = S.dw_rows + (long long)b * A + a;
+        *o = S.accumulate ? *o + dw : dw;
+    }
+}
+
+extern "C" int isc_attn_scan_bwd(const isc_scan_bwd_problem *pr, int n_prob, int B, void *stream) {
+    if (!pr) return ISC_E_NULL;
+    if (n_prob < 1 || n_prob > 2 || B <= 0) return ISC_E_SHAPE;
+    DevScanBwdLaunch L = {};
+    size_t lds = 0;
+    for (int i = 0; i < n_prob; ++i) {
+        const isc_scan_bwd_problem &q = pr[i];
+        if (!q.P || !q.V || !q.q || !q.w || !q.alpha || !q.dout || !q.dP || !q.dV || !q.dq || !q.dw_rows)
+            return ISC_E_NULL;
+        if (q.R <= 0 || q.A <= 0 || q.D <= 0 || q.A > 1024) return ISC_E_SHAPE;
+        if (q.A > 256 && (q.A % 256) != 0) return ISC_E_SHAPE;
+        if (q.A <= 256 && (256 % q.A) != 0) return ISC_E_SHAPE;
+        DevScanBwd &d = L.p[i];
+        d.P = q.P; d.V = q.V; d.q = q.q; d.q2 = q.q2; d.w = q.w; d.alpha = q.alpha; d.dout = q.dout;
+        d.alpha_ld = q.alpha_ld; d.R = q.R; d.A = q.A; d.D = q.D; d.accumulate = q.accumulate;
+        d.dP = q.dP; d.dV = q.dV; d.dq = q.dq; d.dw_rows = q.dw_rows;
+        const int ngrp = q.A <= 256 ? 256 / q.A : 1;
+        const size_t need = (((size_t)q.R + 3) & ~(size_t)3) + (size_t)2 * ngrp * q.A;
+        if (need > lds) lds = need;
+    }
+    lds *= sizeof(float);
+    if (lds > 60000) return ISC_E_SHAPE;
+    hipLaunchKernelGGL(attn_scan_bwd_kernel, dim3(B, n_prob), dim3(256), lds, (hipStream_t)stream, L);
+    ISC_LAUNCH_CHECK();
+    return ISC_OK;
+}
+
+// ------------------------------------------------------------------ gate mix backward
+// feat = beta v + (1-beta) s, beta = sigmoid(u), u = w . tanh(z) + b
+__global__ __launch_bounds__(256) void gate_mix_bwd_kernel(const float *z, const float *w, const float *v,
+                                                           const float *s, const float *beta,
+                                                           long long beta_ld, const float *dfeat, int B,
+                                                           int A, int D, float *dv, float *ds, float *dz,
+                                                           float *dw_rows, float *db_rows, int accumulate) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const float bt = beta[(long long)b * beta_ld];
+    float dot = 0.f;
+    for (int d = lane; d < D; d += 64) {
+        const long long o = (long long)b * D + d;
+        const float g = dfeat[o];
+        dot += g * (v[o] - s[o]);
+        dv[o] = bt * g;
+        ds[o] = (1.f - bt) * g;
+    }
+    dot = wave_sum(dot);
+    const float du = dot * bt * (1.f - bt);
+    for (int a = lane; a < A; a += 64) {
+        const long long o = (long long)b * A + a;
+        const float t = tanhf(z[o]);
+        dz[o] = du * w[a] * (1.f - t * t);
+        dw_rows[o] = accumulate ? dw_rows[o] + du * t : du * t;
+    }
+    if (lane == 0) db_rows[b] = accumulate ? db_rows[b] + du : du;
+}
+
+extern "C" int isc_gate_mix_bwd(const float *z, const float *w, const float *v, const float *s,
+                                const float *beta, int64_t beta_ld, const float *dfeat, int B, int A,
+                                int D, float *dv, float *ds, float *dz, float *dw_rows, float *db_rows,
+                                int accumulate, void *stream) {
+    if (!z || !w || !v || !s || !beta || !dfeat || !dv || !ds || !dz || !dw_rows || !db_rows) return ISC_E_NULL;
+    if (B <= 0 || A <= 0 || D <= 0) return ISC_E_SHAPE;
+    hipLaunchKernelGGL(gate_mix_bwd_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, z, w, v, s,
+                       beta, (long long)beta_ld, dfeat, B, A, D, dv, ds, dz, dw_rows, db_rows, accumulate);
+    ISC_LAUNCH_CHECK();
+    return ISC_OK;
+}
+
+// ------------------------------------------------------------------ embedding backward (scatter-add)
+// demb[ids[r], :] += scale * dout[r / rows_per_grad, :] * (emb[ids[r], :] > 0) [* mask[r,:]*mask_scale]
+__global__ __launch_bounds__(256) void embed_relu_bwd_kernel(const float *emb, int W, const int64_t *ids,
+                                                             long long ids_stride, int n_rows,
+                                                             int rows_per_grad, int pad_first,
+                                                             long long pad_id, const float *dout,
+                                                             float scale, const uint8_t *mask,
+                                                             float mask_scale, float *demb) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n_rows) return;
+    long long id;
+    if (pad_first) {            // senti-word layout: row = b*(n+1)+m, m==0 is the <PAD> prefix
+        const int Mw = pad_first, b = r / Mw, m = r % Mw;
+        id = (m == 0) ? pad_id : ids[(long long)b * (Mw - 1) + (m - 1)];
+    } else {
+        id = ids[(long long)r * ids_stride];
+    }
+    const float *e = emb + id * W;
+    const float *g = dout + (long long)(r / rows_per_grad) * W;
+    float *o = demb + id * W;
+    for (int i = lane; i < W; i += 64) {
+        if (e[i] > 0.f) {
+            float v = g[i] * scale;
+            if (mask) v *= (float)mask[(long long)r * W + i] * mask_scale;
+            atomicAdd(o + i, v);
+        }
+    }
+}
+
+extern "C" int isc_embed_relu_bwd(const float *emb, int V, int W, const int64_t *ids, int64_t ids_stride,
+                                  int n_rows, int rows_per_grad, int pad_first, int64_t pad_id,
+                                  const float *dout, float scale, const uint8_t *keep_mask,
+                                  float mask_scale, float *demb, void *stream) {
+    if (!emb || !ids || !dout || !demb) return ISC_E_NULL;
+    if (n_rows <= 0 || W <= 0 || V <= 0 || rows_per_grad <= 0) return ISC_E_SHAPE;
+    hipLaunchKernelGGL(embed_relu_bwd_kernel, dim3((n_rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, emb,
+                       W, ids, (long long)ids_stride, n_rows, rows_per_grad, pad_first, (long long)pad_id,
+                       dout, scale, keep_mask, mask_scale, demb);
+    ISC_LAUNCH_CHECK();
+    return ISC_OK;
+}
+
+// ------------------------------------------------------------------ column sums (bias gradients)
+__global__ __launch_bounds__(256) void colsum_kernel(const float *x, long long ld, int M, int N, float *out,
+                                                     int accumulate) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + lane;
+    float s = 0.f;
+    if (n < N)
+        for (int m = grp; m < M; m += 4) s += x[(long long)m * ld + n];
+    red[grp][lane] = s;
+    __syncthreads();
+    if (grp == 0 && n < N) {
+        const float t = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+        out[n] = accumulate ? out[n] + t : t;
+    }
+}
+
+extern "C" int isc_colsum(const float *x, int64_t ld, int M, int N, float *out, int accumulate,
+                          void *stream) {
+    if (!x || !out) return ISC_E_NULL;
+    if (M <= 0 || N <= 0) return ISC_E_SHAPE;
+    hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64), dim3(256), 0, (hipStream_t)stream, x,
+                       (long long)ld, M, N, out, accumulate);
+    ISC_LAUNCH_CHECK();
+    return ISC_OK;
+}
+
+// ------------------------------------------------------------------ ReLU (+dropout) backward
+__global__ __launch_bounds__(256) void relu_mask_bwd_kernel(const float *dy, const float *y,
+                                                            const uint8_t *mask, float scale, long long n,
+                                                            float *dz) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float g = (!y || y[i] > 0.f) ? dy[i] : 0.f;
+    if (mask) g *= (float)mask[i] * scale;
+    dz[i] = g;
+}
+
+extern "C" int isc_relu_mask_bwd(const float *dy, const float *y, const uint8_t *keep_mask, float scale,
+                                 int64_t n, float *dz, void *stream) {
+    if (!dy || !dz) return ISC_E_NULL;
+    if (n <= 0) return ISC_E_SHAPE;
+    hipLaunchKernelGGL(relu_mask_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, dy, y, keep_mask, scale, (long long)n, dz);
+    ISC_LAUNCH_CHECK();
+    return ISC_OK;
+}
+
+// ------------------------------------------------------------------ XECriterion backward
+// dlogp must be zero-filled by the caller; scatters -g/count at the target of every unmasked token.
+__global__ __launch_bounds__(256) void xe_loss_bwd_kernel(const int64_t *target, const int *lengths, int B,
+                                                          int T, int V, const float *gout,
+                                                          const float *sum_count, float *dlogp) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * T) return;
+    const int b = i / T, t = i % T;
+    if (t < lengths[b]) dlogp[(long long)i * V + target[i]] = -gout[0] / sum_count[1];
+}
+
+extern "C" int isc_xe_loss_bwd(const int64_t *target, const int32_t *lengths, int B, int T, int V,
+                               const float *gout, const float *sum_count, float *dlogp, void *stream) {
+    if (!target || !lengths || !gout || !sum_count || !dlogp) return ISC_E_NULL;
+    if (B <= 0 || T <= 0 || V <= 0) return ISC_E_SHAPE;
+    hipLaunchKernelGGL(xe_loss_bwd_kernel, dim3((B * T + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       target, lengths, B, T, V, gout, sum_count, dlogp);
+    ISC_LAUNCH_CHECK();
+    return ISC_OK;
+}
+
+// ------------------------------------------------------------------ fused clamp + Adam (multi-tensor)
+struct DevAdam {
+    float *p[ISC_ADAM_MAX_TENSORS];
+    float *g[ISC_ADAM_MAX_TENSORS];
+    float *m[ISC_ADAM_MAX_TENSORS];
+    float *v[ISC_ADAM_MAX_TENSORS];
+    int blk_start[ISC_ADAM_MAX_TENSORS + 1];
+    long long n[ISC_ADAM_MAX_TENSORS];
+    int count;
+    float lr, b1, b2, eps, clip, bc1, bc2_sqrt, wd;
+};
+
+__global__ __launch_bounds__(256) void clamp_adam_kernel(const DevAdam Aa) {
+    int ti = 0;
+    while (ti + 1 < Aa.count && (int)blockIdx.x >= Aa.blk_start[ti + 1]) ++ti;
+    const long long base = ((long long)blockIdx.x - Aa.blk_start[ti]) * 1024;
+    float *p = Aa.p[ti], *g = Aa.g[ti], *m = Aa.m[ti], *v = Aa.v[ti];
+    const long long n = Aa.n[ti];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const long long i = base + k * 256 + threadIdx.x;
+        if (i >= n) break;
+        float gr = g[i];
+        if (Aa.clip > 0.f) { gr = fminf(fmaxf(gr, -Aa.clip), Aa.clip); g[i] = gr; }  // clamp_ is in place
+        if (Aa.wd != 0.f) gr += Aa.wd * p[i];
+        const float mm = Aa.b1 * m[i] + (1.f - Aa.b1) * gr;
+        const float vv = Aa.b2 * v[i] + (1.f - Aa.b2) * gr * gr;
+        m[i] = mm;
+        v[i] = vv;
+        const float denom = sqrtf(vv) / Aa.bc2_sqrt + Aa.eps;
+        p[i] -= (Aa.lr / Aa.bc1) * (mm / denom);
+    }
+}
+
+extern "C" int isc_clamp_adam(float *const *params, float *const *grads, float *const *exp_avg,
+                              float *const *exp_avg_sq, const int64_t *numel, int n_tensors, double lr,
+                              double beta1, double beta2, double eps, double weight_decay, double clip,
+                              int step, void *stream) {
+    if (!params || !grads || !exp_avg || !exp_avg_sq || !numel) return ISC_E_NULL;
+    if (n_tensors <= 0 || step <= 0) return ISC_E_SHAPE;
+    for (int off = 0; off < n_tensors; off += ISC_ADAM_MAX_TENSORS) {
+        DevAdam A = {};
+        const int cnt = (n_tensors - off) < ISC_ADAM_MAX_TENSORS ? (n_tensors - off) : ISC_ADAM_MAX_TENSORS;
+        int blocks = 0;
+        for (int i = 0; i < cnt; ++i) {
+            if (!params[off + i] || !grads[off + i] || !exp_avg[off + i] || !exp_avg_sq[off + i]) return ISC_E_NULL;
+            A.p[i] = params[off + i]; A.g[i] = grads[off + i];
+            A.m[i] = exp_avg[off + i]; A.v[i] = exp_avg_sq[off + i];
+            A.n[i] = numel[off + i];
+            A.blk_start[i] = blocks;
+            blocks += (int)((numel[off + i] + 1023) / 1024);
+        }
+        A.blk_start[cnt] = blocks;
+        A.count = cnt;
+        A.lr = (float)lr; A.b1 = (float)beta1; A.b2 = (float)beta2; A.eps = (float)eps;
+        A.clip = (float)clip; A.wd = (float)weight_decay;
+        // bias corrections in double, like torch.optim.Adam's Python-side scalars
+        A.bc1 = (float)(1.0 - pow(beta1, (double)step));
+        A.bc2_sqrt = (float)sqrt(1.0 - pow(beta2, (double)step));
+        if (blocks == 0) continue;
+        hipLaunchKernelGGL(clamp_adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, A);
+        ISC_LAUNCH_CHECK();
+    }
+    return ISC_OK;
+}

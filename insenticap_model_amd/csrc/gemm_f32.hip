@@ -1,4 +1,5 @@
-// fp32 MFMA (v_mfma_f32_32x32x2_f32) grouped, K-segmented "NT" GEMM with fused epilogues.
+// fp32 MFMA (v_mfma_f32_32x32x2_f32) grouped, K-segmented GEMM (NT forward, NN / TN backward)
+// with fused epilogues.
 //
 //   acc[M,N] = sum_s A_s[M,K_s] * W_s[N,K_s]^T          (s = up to 4 K-segments)
 //
@@ -38,7 +39,7 @@ struct DevProb {
     const float *bias0, *bias1, *bias2;
     const uint8_t *mask;
     float mask_scale;
-    int ldc;
+    int ldc, accumulate;
     float *C, *C_pre;
     // lstm
     const float *c_prev;
@@ -57,17 +58,30 @@ struct DevLaunch {
     int nprob, total_tiles;
 };
 
-template <int WM, int WN, int TN, int EPI>
+// Operand layouts. "k-minor": element (row, k) at ptr[row*ld + k] (contraction index contiguous;
+// activations [M,K] and nn.Linear weights [N,K] in the forward pass).  "k-major": element (row, k)
+// at ptr[k*ld + row] - the operand is read through its transpose, which is how the backward pass
+// consumes them: dX = dY * W uses W [K=N_out, N=K_in] as a k-major B operand ("NN"), and
+// dW = dY^T * X contracts over the batch rows with both operands k-major ("TN").
+template <int ROWS, bool KM>
+struct Tile {
+    // LDS footprint (floats) of one [ROWS x 32] operand tile
+    static constexpr int SIZE = KM ? BK * (ROWS + 4) : ROWS * LDT;
+    static constexpr int NLD = ROWS / 32;  // float4 loads per thread per chunk
+};
+
+template <int WM, int WN, int TN, int EPI, bool AKM, bool BKM>
 __global__ __launch_bounds__(256) void gemm_kernel(const DevLaunch L) {
     constexpr int BM = 32 * WM;
     constexpr int BN = 32 * TN * WN;
     constexpr int LDC = BN + 4;
-    constexpr int A_LD = BM / 32;  // float4 loads per thread per chunk
-    constexpr int B_LD = BN / 32;
+    using TA = Tile<BM, AKM>;
+    using TB = Tile<BN, BKM>;
+    constexpr int A_LD = TA::NLD, B_LD = TB::NLD;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *As = smem;                    // [2][BM][LDT]
-    float *Bs = smem + 2 * BM * LDT;     // [2][BN][LDT]
-    float *Cs = smem;                    // [BM][LDC] (after the K loop)
+    float *As = smem;                     // [2][TA::SIZE]
+    float *Bs = smem + 2 * TA::SIZE;      // [2][TB::SIZE]
+    float *Cs = smem;                     // [BM][LDC] (after the K loop)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -93,10 +107,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(const DevLaunch L) {
     const int M = P.M, N = P.N;
     const int row0 = tm * BM, col0 = tn * BN;
 
-    // global-load coordinates: thread -> (row = tid/8 + 32*i, 16-byte column c4 = tid%8)
+    // ---- global-load coordinates
+    // k-minor tile: thread -> (row = tid/8 + 32*i, k = 4*(tid%8)); k-major tile of ROWS columns:
+    // thread -> (k-row = tid/(ROWS/4) + (1024/ROWS)*i, column = 4*(tid % (ROWS/4)))
     const int lr = tid >> 3, lc = (tid & 7) * 4;
-    // weight row of tile row n: LSTM tiles interleave the 4 gates of 32 hidden units
-    long long wrow[B_LD];
+    constexpr int A_TPR = BM / 4, B_TPR = BN / 4;           // threads per k-row (k-major)
+    const int akr = tid / A_TPR, akc = (tid % A_TPR) * 4;
+    const int bkr = tid / B_TPR, bkc = (tid % B_TPR) * 4;
+    long long wrow[B_LD];   // k-minor B: weight row of tile row n (LSTM tiles interleave the 4 gates)
     bool wok[B_LD];
 #pragma unroll
     for (int i = 0; i < B_LD; ++i) {
@@ -112,6 +130,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const DevLaunch L) {
     bool aok[A_LD];
 #pragma unroll
     for (int i = 0; i < A_LD; ++i) aok[i] = (row0 + lr + 32 * i) < M;
+    const bool a_col_ok = (row0 + akc) < M;   // k-major A: this thread's 4 output rows exist
+    const bool b_col_ok = (col0 + bkc) < N;
 
     f32x16 acc[TN];
 #pragma unroll
@@ -120,57 +140,110 @@ __global__ __launch_bounds__(256) void gemm_kernel(const DevLaunch L) {
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
     int nchunks = 0;
-    for (int s = 0; s < P.nseg; ++s) nchunks += P.seg[s].K / BK;
+    for (int s = 0; s < P.nseg; ++s) nchunks += (P.seg[s].K + BK - 1) / BK;
 
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 ra[A_LD], rb[B_LD];
     int cs = 0, ck = 0;  // segment / k-offset of the chunk being loaded
     auto gload = [&]() {
         const DevSeg sg = P.seg[cs];
-        const float *Ab = sg.A + (long long)(row0 + lr) * sg.lda + ck + lc;
+        if (AKM) {
 #pragma unroll
-        for (int i = 0; i < A_LD; ++i)
-            ra[i] = aok[i] ? *reinterpret_cast<const float4 *>(Ab + (long long)(32 * i) * sg.lda)
-                           : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int i = 0; i < A_LD; ++i) {
+                const int k = ck + akr + (1024 / BM) * i;
+                ra[i] = (a_col_ok && k < sg.K)
+                            ? *reinterpret_cast<const float4 *>(sg.A + (long long)k * sg.lda + row0 + akc)
+                            : zero4;
+            }
+        } else {
+            const float *Ab = sg.A + (long long)(row0 + lr) * sg.lda + ck + lc;
+            const bool kok = (ck + lc) < sg.K;
 #pragma unroll
-        for (int i = 0; i < B_LD; ++i)
-            rb[i] = wok[i] ? *reinterpret_cast<const float4 *>(sg.W + wrow[i] * sg.ldw + ck + lc)
-                           : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int i = 0; i < A_LD; ++i)
+                ra[i] = (aok[i] && kok) ? *reinterpret_cast<const float4 *>(Ab + (long long)(32 * i) * sg.lda)
+                                        : zero4;
+        }
+        if (BKM) {
+#pragma unroll
+            for (int i = 0; i < B_LD; ++i) {
+                const int k = ck + bkr + (1024 / BN) * i;
+                rb[i] = (b_col_ok && k < sg.K)
+                            ? *reinterpret_cast<const float4 *>(sg.W + (long long)k * sg.ldw + col0 + bkc)
+                            : zero4;
+            }
+        } else {
+            const bool kok = (ck + lc) < sg.K;
+#pragma unroll
+            for (int i = 0; i < B_LD; ++i)
+                rb[i] = (wok[i] && kok) ? *reinterpret_cast<const float4 *>(sg.W + wrow[i] * sg.ldw + ck + lc)
+                                        : zero4;
+        }
         ck += BK;
         if (ck >= sg.K) { ck = 0; ++cs; }
     };
     auto sstore = [&](int buf) {
-        float *a = As + buf * BM * LDT + lr * LDT + lc;
+        float *a = As + buf * TA::SIZE;
+        if (AKM) {
 #pragma unroll
-        for (int i = 0; i < A_LD; ++i) *reinterpret_cast<float4 *>(a + 32 * i * LDT) = ra[i];
-        float *b = Bs + buf * BN * LDT + lr * LDT + lc;
+            for (int i = 0; i < A_LD; ++i)
+                *reinterpret_cast<float4 *>(a + (akr + (1024 / BM) * i) * (BM + 4) + akc) = ra[i];
+        } else {
 #pragma unroll
-        for (int i = 0; i < B_LD; ++i) *reinterpret_cast<float4 *>(b + 32 * i * LDT) = rb[i];
+            for (int i = 0; i < A_LD; ++i)
+                *reinterpret_cast<float4 *>(a + (lr + 32 * i) * LDT + lc) = ra[i];
+        }
+        float *b = Bs + buf * TB::SIZE;
+        if (BKM) {
+#pragma unroll
+            for (int i = 0; i < B_LD; ++i)
+                *reinterpret_cast<float4 *>(b + (bkr + (1024 / BN) * i) * (BN + 4) + bkc) = rb[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < B_LD; ++i)
+                *reinterpret_cast<float4 *>(b + (lr + 32 * i) * LDT + lc) = rb[i];
+        }
     };
 
     gload();
     sstore(0);
     __syncthreads();
 
+    // MFMA 32x32x2 operand maps: lane l supplies A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31].
+    // Per 8-deep k-block a lane holds 4 consecutive k (k0 + 4*(l>>5) + t) of its row for both
+    // operands; MFMA t consumes element t, so every k is covered exactly once.
     const int frow = lane & 31, fk = (lane >> 5) * 4;
     for (int c = 0; c < nchunks; ++c) {
         const int buf = c & 1;
         if (c + 1 < nchunks) gload();
-        const float *a_base = As + buf * BM * LDT + (wm * 32 + frow) * LDT + fk;
-        const float *b_base = Bs + buf * BN * LDT + (wn * TN * 32 + frow) * LDT + fk;
+        const float *at = As + buf * TA::SIZE;
+        const float *bt = Bs + buf * TB::SIZE;
 #pragma unroll
         for (int kb = 0; kb < BK / 8; ++kb) {
-            const float4 a = *reinterpret_cast<const float4 *>(a_base + kb * 8);
-            float4 b[TN];
+            float a[4], b[TN][4];
+            if (AKM) {
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
-                b[j] = *reinterpret_cast<const float4 *>(b_base + j * 32 * LDT + kb * 8);
+                for (int e = 0; e < 4; ++e) a[e] = at[(kb * 8 + fk + e) * (BM + 4) + wm * 32 + frow];
+            } else {
+                const float4 v = *reinterpret_cast<const float4 *>(at + (wm * 32 + frow) * LDT + kb * 8 + fk);
+                a[0] = v.x; a[1] = v.y; a[2] = v.z; a[3] = v.w;
+            }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[j].x, acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[j].y, acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[j].z, acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[j].w, acc[j], 0, 0, 0);
+                if (BKM) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        b[j][e] = bt[(kb * 8 + fk + e) * (BN + 4) + (wn * TN + j) * 32 + frow];
+                } else {
+                    const float4 v = *reinterpret_cast<const float4 *>(
+                        bt + ((wn * TN + j) * 32 + frow) * LDT + kb * 8 + fk);
+                    b[j][0] = v.x; b[j][1] = v.y; b[j][2] = v.z; b[j][3] = v.w;
+                }
             }
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[j][e], acc[j], 0, 0, 0);
         }
         if (c + 1 < nchunks) sstore(buf ^ 1);
         __syncthreads();
@@ -202,6 +275,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const DevLaunch L) {
                     if (P.bias0) o[e] += P.bias0[n];
                     if (P.bias1) o[e] += P.bias1[n];
                     if (P.bias2) o[e] += P.bias2[n];
+                    if (P.accumulate) o[e] += P.C[(long long)gm * P.ldc + n];
                     if (P.relu) o[e] = fmaxf(o[e], 0.f);
                     pre[e] = o[e];
                     if (P.mask) o[e] = o[e] * (float)P.mask[(long long)gm * N + n] * P.mask_scale;
@@ -301,22 +375,28 @@ static void copy_segs(DevProb &d, const isc_seg *seg, int nseg) {
     }
 }
 
-template <int WM, int WN, int TN, int EPI>
+template <int WM, int WN, int TN, int EPI, bool AKM, bool BKM>
 static int launch_cfg(const DevLaunch &L, hipStream_t st) {
     constexpr int BM = 32 * WM, BN = 32 * TN * WN;
-    constexpr size_t k_bytes = (size_t)2 * (BM + BN) * LDT * sizeof(float);
+    constexpr size_t k_bytes = (size_t)2 * (Tile<BM, AKM>::SIZE + Tile<BN, BKM>::SIZE) * sizeof(float);
     constexpr size_t c_bytes = (size_t)BM * (BN + 4) * sizeof(float);
     constexpr size_t lds = k_bytes > c_bytes ? k_bytes : c_bytes;
     static bool attr_set = false;  // idempotent; a benign race only repeats the same call
     if (!attr_set && lds > 65536) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_kernel<WM, WN, TN, EPI>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute(
+            reinterpret_cast<const void *>(&gemm_kernel<WM, WN, TN, EPI, AKM, BKM>),
+            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_kernel<WM, WN, TN, EPI>), dim3(L.total_tiles), dim3(256), lds, st, L);
+    hipLaunchKernelGGL((gemm_kernel<WM, WN, TN, EPI, AKM, BKM>), dim3(L.total_tiles), dim3(256), lds, st, L);
     ISC_LAUNCH_CHECK();
     return ISC_OK;
+}
+
+template <int EPI, bool AKM, bool BKM>
+static int launch_any(const DevLaunch &L, bool small, hipStream_t st) {
+    return small ? launch_cfg<1, 4, 1, EPI, AKM, BKM>(L, st) : launch_cfg<4, 1, 4, EPI, AKM, BKM>(L, st);
 }
 
 // Tile shape choice: the 128x128 tile needs >= ~1 tile per CU to pay; below that the
@@ -360,14 +440,47 @@ extern "C" int isc_linear_fwd(const isc_linear_problem *pr, int n_prob, void *st
         d.M = q.M; d.N = q.N; d.relu = q.relu;
         d.bias0 = q.bias0; d.bias1 = q.bias1; d.bias2 = q.bias2;
         d.mask = q.keep_mask; d.mask_scale = q.mask_scale;
-        d.ldc = q.ldc; d.C = q.C; d.C_pre = q.C_pre;
+        d.ldc = q.ldc; d.C = q.C; d.C_pre = q.C_pre; d.accumulate = q.accumulate;
         tiles_large += (long long)((q.M + 127) / 128) * ((q.N + 127) / 128);
         if (q.M > max_m) max_m = q.M;
     }
     const bool small = use_small_tile(tiles_large, max_m);
     finish_tiling(L, small);
-    return small ? launch_cfg<1, 4, 1, EPI_LINEAR>(L, (hipStream_t)stream)
-                 : launch_cfg<4, 1, 4, EPI_LINEAR>(L, (hipStream_t)stream);
+    return launch_any<EPI_LINEAR, false, false>(L, small, (hipStream_t)stream);
+}
+
+// Backward-pass contractions on the same kernel (include/insenticap_hip.h: isc_gemm_bwd).
+extern "C" int isc_gemm_bwd(const isc_linear_problem *pr, int n_prob, int layout, void *stream) {
+    if (!pr) return ISC_E_NULL;
+    if (n_prob < 1 || n_prob > 3 || (layout != ISC_LAYOUT_NN && layout != ISC_LAYOUT_TN)) return ISC_E_SHAPE;
+    DevLaunch L = {};
+    L.nprob = n_prob;
+    long long tiles_large = 0;
+    int max_m = 0;
+    for (int i = 0; i < n_prob; ++i) {
+        const isc_linear_problem &q = pr[i];
+        if (q.nseg < 1 || q.nseg > ISC_MAX_SEG || !q.C) return q.C ? ISC_E_SHAPE : ISC_E_NULL;
+        if (q.M <= 0 || q.N <= 0 || (q.N & 3) || (q.ldc & 3)) return ISC_E_SHAPE;
+        if (layout == ISC_LAYOUT_TN && (q.M & 3)) return ISC_E_SHAPE;
+        for (int s = 0; s < q.nseg; ++s) {
+            const isc_seg &g = q.seg[s];
+            if (!g.A || !g.W) return ISC_E_NULL;
+            // NN with K % 4 != 0 (vocabulary-sized K): the caller pads A's rows to lda with zeros
+            if (g.K <= 0) return ISC_E_SHAPE;
+            if ((g.lda & 3) || (g.ldw & 3) || !isc_aligned16(g.A) || !isc_aligned16(g.W)) return ISC_E_ALIGN;
+        }
+        DevProb &d = L.p[i];
+        copy_segs(d, q.seg, q.nseg);
+        d.M = q.M; d.N = q.N; d.relu = 0;
+        d.bias0 = q.bias0; d.bias1 = q.bias1; d.bias2 = q.bias2;
+        d.ldc = q.ldc; d.C = q.C; d.accumulate = q.accumulate;
+        tiles_large += (long long)((q.M + 127) / 128) * ((q.N + 127) / 128);
+        if (q.M > max_m) max_m = q.M;
+    }
+    const bool small = use_small_tile(tiles_large, max_m);
+    finish_tiling(L, small);
+    return layout == ISC_LAYOUT_NN ? launch_any<EPI_LINEAR, false, true>(L, small, (hipStream_t)stream)
+                                   : launch_any<EPI_LINEAR, true, true>(L, small, (hipStream_t)stream);
 }
 
 extern "C" int isc_lstm_fwd(const isc_lstm_problem *q, void *stream) {
@@ -388,8 +501,7 @@ extern "C" int isc_lstm_fwd(const isc_lstm_problem *q, void *stream) {
     const long long tiles_large = (long long)((q->M + 127) / 128) * (q->H / 32);
     const bool small = use_small_tile(tiles_large, q->M);
     finish_tiling(L, small);
-    return small ? launch_cfg<1, 4, 1, EPI_LSTM>(L, (hipStream_t)stream)
-                 : launch_cfg<4, 1, 4, EPI_LSTM>(L, (hipStream_t)stream);
+    return launch_any<EPI_LSTM, false, false>(L, small, (hipStream_t)stream);
 }
 
 extern "C" int isc_vocab_fwd(const float *h, int ldh, const float *W, int ldw, const float *bias,
@@ -411,6 +523,5 @@ extern "C" int isc_vocab_fwd(const float *h, int ldh, const float *W, int ldw, c
     const long long tiles_large = (long long)((M + 127) / 128) * d.ntile_total;
     const bool small = use_small_tile(tiles_large, M);
     finish_tiling(L, small);
-    return small ? launch_cfg<1, 4, 1, EPI_VOCAB>(L, (hipStream_t)stream)
-                 : launch_cfg<4, 1, 4, EPI_VOCAB>(L, (hipStream_t)stream);
+    return launch_any<EPI_VOCAB, false, false>(L, small, (hipStream_t)stream);
 }

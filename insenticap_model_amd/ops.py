@@ -246,3 +246,141 @@ def xe_loss_fwd(logp, target, lengths_i32, out2):
 
 __all__ = [n for n in dir() if n.endswith('_fwd') or n.endswith('_problem')] + [
     'RolloutStep', 'rollout_finalize', 'beam_topk', 'logsoftmax_apply', 'require_device']
+
+
+# ---------------------------------------------------------------------------- backward
+NN, TN = 1, 2
+
+
+def gemm_problem(segs, out, layout, accumulate=False, bias0=None):
+    """layout NN: out[M,N] (+)= sum_s A_s[M,K] @ W_s[K,N];  TN: out[M,N] (+)= sum_s A_s[K,M]^T @ W_s[K,N].
+    All operands are 2-D views with unit inner stride."""
+    p = LinearProblem()
+    if not 1 <= len(segs) <= _lib.ISC_MAX_SEG:
+        raise ValueError('1..4 K-segments supported')
+    p.nseg = len(segs)
+    p.M, p.N = out.shape
+    for i, (A, W) in enumerate(segs):
+        assert A.dim() == 2 and W.dim() == 2 and A.stride(1) == 1 and W.stride(1) == 1
+        assert A.dtype == torch.float32 and W.dtype == torch.float32
+        s = p.seg[i]
+        s.A, s.W, s.lda, s.ldw = A.data_ptr(), W.data_ptr(), A.stride(0), W.stride(0)
+        if layout == NN:
+            assert A.shape[0] == p.M and W.shape[1] == p.N and A.shape[1] >= W.shape[0], (A.shape, W.shape)
+            s.K = W.shape[0]
+        else:
+            assert A.shape[1] == p.M and W.shape[1] == p.N and A.shape[0] == W.shape[0], (A.shape, W.shape)
+            s.K = A.shape[0]
+    assert out.stride(1) == 1
+    p.ldc, p.C = out.stride(0), out.data_ptr()
+    p.accumulate = int(accumulate)
+    p.bias0 = ptr(bias0)
+    return p
+
+
+def gemm_bwd(problems, layout):
+    lib = _lib.load()
+    arr = (LinearProblem * len(problems))(*problems)
+    e0 = TIMER.begin()
+    check(lib.isc_gemm_bwd(arr, len(problems), layout, stream()), 'isc_gemm_bwd')
+    if e0 is not None:
+        fl = sum(2.0 * q.M * q.N * sum(q.seg[i].K for i in range(q.nseg)) for q in problems)
+        TIMER.end(e0, ('gemm_nn[' if layout == NN else 'gemm_tn[') +
+                  '+'.join('%dx%dx%d' % (q.M, q.N, sum(q.seg[i].K for i in range(q.nseg))) for q in problems) + ']',
+                  fl)
+
+
+def logsoftmax_bwd(dlogp, logp, dlogits, M, V, remap_T=0):
+    """dlogp/logp: M contiguous rows of V; dlogits [M, ld_out>=V] (padding zero-filled).
+    remap_T>0: input rows are (b,t) b-major, output rows (t,b) t-major."""
+    lib = _lib.load()
+    assert dlogp.is_contiguous() and logp.is_contiguous() and dlogits.stride(1) == 1
+    check(lib.isc_logsoftmax_bwd(dlogp.data_ptr(), logp.data_ptr(), V, M, V, dlogits.data_ptr(),
+                                 dlogits.stride(0), remap_T, stream()), 'isc_logsoftmax_bwd')
+
+
+def lstm_bwd(dh, dh2, dc_next, gates, c_prev, c, dgates, dc_prev, dgates_sum=None):
+    lib = _lib.load()
+    M, H = c.shape
+    for x in (dh, dh2, dc_next, gates, c_prev, c, dgates, dc_prev, dgates_sum):
+        assert x is None or x.is_contiguous()
+    check(lib.isc_lstm_bwd(dh.data_ptr(), ptr(dh2), ptr(dc_next), gates.data_ptr(), c_prev.data_ptr(),
+                           c.data_ptr(), M, H, dgates.data_ptr(), dc_prev.data_ptr(), ptr(dgates_sum),
+                           stream()), 'isc_lstm_bwd')
+
+
+def scan_bwd_problem(P, V, q, w, alpha, dout, dP, dV, dq, dw_rows, accumulate, q2=None):
+    s = _lib.ScanBwdProblem()
+    for x in (P, V, q, dout, dP, dV, dq, dw_rows):
+        assert x.is_contiguous()
+    assert alpha.stride(1) == 1
+    s.P, s.V, s.q, s.q2, s.w = P.data_ptr(), V.data_ptr(), q.data_ptr(), ptr(q2), w.data_ptr()
+    s.alpha, s.alpha_ld, s.dout = alpha.data_ptr(), alpha.stride(0), dout.data_ptr()
+    s.R, s.A, s.D = P.shape[1], P.shape[2], V.shape[2]
+    s.accumulate = int(accumulate)
+    s.dP, s.dV, s.dq, s.dw_rows = dP.data_ptr(), dV.data_ptr(), dq.data_ptr(), dw_rows.data_ptr()
+    return s
+
+
+def attn_scan_bwd(problems, B):
+    lib = _lib.load()
+    arr = (_lib.ScanBwdProblem * len(problems))(*problems)
+    e0 = TIMER.begin()
+    check(lib.isc_attn_scan_bwd(arr, len(problems), B, stream()), 'isc_attn_scan_bwd')
+    if e0 is not None:
+        nb = sum(4.0 * B * q.R * 3 * (q.A + q.D) for q in problems)   # read P,V; read-modify-write dP,dV
+        TIMER.end(e0, 'attn_scan_bwd[' + '+'.join('%dx%dx%d' % (B, q.R, q.A) for q in problems) + ']', 0.0, nb)
+
+
+def gate_mix_bwd(z, w, v, s, beta, dfeat, dv, ds, dz, dw_rows, db_rows, accumulate):
+    lib = _lib.load()
+    B, A = z.shape
+    D = v.shape[1]
+    check(lib.isc_gate_mix_bwd(z.data_ptr(), w.data_ptr(), v.data_ptr(), s.data_ptr(), beta.data_ptr(),
+                               beta.stride(0), dfeat.data_ptr(), B, A, D, dv.data_ptr(), ds.data_ptr(),
+                               dz.data_ptr(), dw_rows.data_ptr(), db_rows.data_ptr(), int(accumulate),
+                               stream()), 'isc_gate_mix_bwd')
+
+
+def embed_relu_bwd(emb, ids, dout, demb, n_rows, rows_per_grad=1, scale=1.0, ids_stride=1, pad_first=0,
+                   pad_id=0, keep_mask=None, mask_scale=1.0):
+    lib = _lib.load()
+    V, W = emb.shape
+    assert dout.is_contiguous() and demb.is_contiguous() and ids.dtype == torch.int64
+    check(lib.isc_embed_relu_bwd(emb.data_ptr(), V, W, ids.data_ptr(), ids_stride, n_rows, rows_per_grad,
+                                 pad_first, pad_id, dout.data_ptr(), scale, ptr(keep_mask), mask_scale,
+                                 demb.data_ptr(), stream()), 'isc_embed_relu_bwd')
+
+
+def colsum(x, out, accumulate=False):
+    lib = _lib.load()
+    M, N = x.shape
+    assert x.stride(1) == 1 and out.is_contiguous() and out.numel() >= N
+    check(lib.isc_colsum(x.data_ptr(), x.stride(0), M, N, out.data_ptr(), int(accumulate), stream()),
+          'isc_colsum')
+
+
+def relu_mask_bwd(dy, y, dz, keep_mask=None, scale=1.0):
+    """dz = dy * (y > 0) [* mask * scale]; y=None skips the ReLU test (pure dropout backward)."""
+    lib = _lib.load()
+    assert dy.is_contiguous() and dz.is_contiguous() and (y is None or y.is_contiguous())
+    check(lib.isc_relu_mask_bwd(dy.data_ptr(), ptr(y), ptr(keep_mask), scale, dy.numel(), dz.data_ptr(),
+                                stream()), 'isc_relu_mask_bwd')
+
+
+def xe_loss_bwd(target, lengths_i32, gout, sum_count, dlogp):
+    lib = _lib.load()
+    B, T, V = dlogp.shape
+    check(lib.isc_xe_loss_bwd(target.data_ptr(), lengths_i32.data_ptr(), B, T, V, gout.data_ptr(),
+                              sum_count.data_ptr(), dlogp.data_ptr(), stream()), 'isc_xe_loss_bwd')
+
+
+def clamp_adam(params, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, clip, step):
+    lib = _lib.load()
+    n = len(params)
+    mk = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])
+    for t in list(params) + list(grads) + list(exp_avg) + list(exp_avg_sq):
+        assert t.is_contiguous() and t.dtype == torch.float32 and t.is_cuda
+    numel = (C.c_int64 * n)(*[t.numel() for t in params])
+    check(lib.isc_clamp_adam(mk(params), mk(grads), mk(exp_avg), mk(exp_avg_sq), numel, n, lr, beta1, beta2,
+                             eps, weight_decay, clip, step, stream()), 'isc_clamp_adam')

@@ -1,0 +1,208 @@
+"""Backward / training parity of the HIP path vs the reference's autograd results (golden vectors)
+and vs fp64 for the individual kernels. Run on the MI355X box: pytest -m gpu."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import assert_digest_close, case_setup, digest
+from insenticap_model_amd import Captioner, XECriterion, clip_gradient, ops, synth
+
+pytestmark = pytest.mark.gpu
+GRAD_RTOL = 1e-4   # gradients within 1e-4 relative to the tensor's max
+
+
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device('cuda:0')
+
+
+def T(d, k):
+    return torch.from_numpy(np.asarray(d[k])).to(dev())
+
+
+def make_captioner(name, train=False):
+    c, st, w, d, s2s = case_setup(name)
+    cap = Captioner(synth.make_idx2word(c['V']), synth.SENTIMENT_CATEGORIES, st)
+    cap.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()})
+    cap.to(dev())
+    cap.train(train)
+    return cap, c, st, w, d, s2s
+
+
+@pytest.mark.parametrize('M,N,K', [(6, 32, 128), (128, 512, 2048), (300, 1024, 2048), (2560, 512, 10000),
+                                   (77, 64, 9487)])
+def test_gemm_nn_vs_fp64(M, N, K):
+    g = torch.Generator().manual_seed(M + N)
+    Kp = (K + 31) // 32 * 32
+    a = torch.zeros(M, Kp)
+    a[:, :K] = torch.randn(M, K, generator=g)
+    w = torch.randn(K, N, generator=g) / K ** 0.5
+    ref = a[:, :K].double() @ w.double()
+    out = torch.empty(M, N, device=dev())
+    ops.gemm_bwd([ops.gemm_problem([(a.to(dev()), w.to(dev()))], out, ops.NN)], ops.NN)
+    np.testing.assert_allclose(out.cpu().numpy(), ref.float().numpy(), atol=3e-5, rtol=1e-5)
+    # accumulate
+    ops.gemm_bwd([ops.gemm_problem([(a.to(dev()), w.to(dev()))], out, ops.NN, accumulate=True)], ops.NN)
+    np.testing.assert_allclose(out.cpu().numpy(), 2 * ref.float().numpy(), atol=6e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize('rows,M,N', [(48, 128, 32), (2560, 2048, 1536), (1000, 10000, 512), (6, 2048, 512),
+                                      (333, 512, 512)])
+def test_gemm_tn_vs_fp64(rows, M, N):
+    g = torch.Generator().manual_seed(rows + M)
+    a = torch.randn(rows, M, generator=g)
+    x = torch.randn(rows, N, generator=g)
+    ref = a.double().t() @ x.double()
+    big = torch.zeros(M, N + 64, device=dev())
+    out = big[:, 32:32 + N]            # column slice of a wider gradient tensor
+    ops.gemm_bwd([ops.gemm_problem([(a.to(dev()), x.to(dev()))], out, ops.TN)], ops.TN)
+    np.testing.assert_allclose(out.cpu().numpy(), ref.float().numpy(), atol=2e-4 * max(1.0, rows ** 0.5 / 8), rtol=1e-5)
+    assert float(big[:, :32].abs().max()) == 0.0 and float(big[:, 32 + N:].abs().max()) == 0.0
+
+
+def test_clamp_adam_vs_torch():
+    g = torch.Generator().manual_seed(3)
+    shapes = [(1000, 37), (5,), (64, 64), (1,)]
+    ps = [torch.randn(s, generator=g) for s in shapes]
+    gs = [torch.randn(s, generator=g) * 0.3 for s in shapes]
+    ref_p = [torch.nn.Parameter(p.clone()) for p in ps]
+    opt = torch.optim.Adam(ref_p, lr=4e-4)
+    mine = [torch.nn.Parameter(p.clone().to(dev())) for p in ps]
+    from insenticap_model_amd import FusedClampAdam
+    mopt = FusedClampAdam(mine, lr=4e-4)
+    for it in range(3):
+        for q, gg in zip(ref_p, gs):
+            q.grad = (gg * (it + 1)).clone().clamp_(-0.1, 0.1)
+        opt.step()
+        for q, gg in zip(mine, gs):
+            q.grad = (gg * (it + 1)).clone().to(dev())
+        clip_gradient(mopt, 0.1)
+        mopt.step()
+    for a, b in zip(ref_p, mine):
+        np.testing.assert_allclose(b.detach().cpu().numpy(), a.detach().numpy(), atol=2e-6)
+    assert set(mopt.state_dict()['state'][0].keys()) == set(opt.state_dict()['state'][0].keys())
+
+
+def run_iteration(cap, d, s2s):
+    xe_crit, da_crit = XECriterion(), torch.nn.MSELoss()
+    cap.zero_grad()
+    pred = cap(T(d, 'fc_feats'), T(d, 'att_feats'), T(d, 'cpt_words'), T(d, 'captions'), T(d, 'senti_labels'),
+               0.0, mode='xe')
+    xe = xe_crit(pred, T(d, 'captions')[:, 1:], d['lengths'])
+    da = da_crit(cap.cpt_feats, cap.fc_feats.detach())
+    pred2 = cap(T(s2s, 'captions'), T(s2s, 'cpt_words'), T(s2s, 'senti_words'), T(s2s, 'senti_labels'), 0.0,
+                mode='seq2seq')
+    l2 = xe_crit(pred2, T(s2s, 'captions')[:, 1:], s2s['lengths'])
+    (xe + da + l2).backward()
+    return pred, pred2, (float(xe.detach()), float(da.detach()), float(l2.detach()))
+
+
+def test_tiny_train_iteration_full_grads_and_adam(golden):
+    """train_xe.py inner step (xe + domain-align + seq2seq losses, backward, clamp, Adam): every
+    gradient tensor and every post-step parameter vs the reference's."""
+    g = golden('tiny')
+    cap, c, st, w, d, s2s = make_captioner('tiny')
+    optim, _, _ = cap.get_optim_criterion(4e-4)
+    pred, pred2, losses = run_iteration(cap, d, s2s)
+    np.testing.assert_allclose(pred.detach().cpu().numpy(), g['it/xe_logp'], atol=1e-4)
+    np.testing.assert_allclose(pred2.detach().cpu().numpy(), g['it/s2s_logp'], atol=1e-4)
+    np.testing.assert_allclose(losses, g['it/losses'], rtol=2e-5)
+    grads = {}
+    n = 0
+    for k, q in cap.named_parameters():
+        key = 'it/grad/' + k
+        if key not in g.files:
+            assert q.grad is None, k
+            continue
+        ref = g[key]
+        grads[k] = q.grad.cpu().numpy().copy()
+        np.testing.assert_allclose(grads[k], ref, atol=GRAD_RTOL * np.abs(ref).max() + 1e-7, err_msg=k)
+        n += 1
+    assert n == 32
+    clip_gradient(optim, 0.1)
+    optim.step()
+    for k, q in cap.named_parameters():
+        got, ref = q.detach().cpu().numpy(), g['it/adam/' + k]
+        if k not in grads:
+            np.testing.assert_array_equal(got, ref, err_msg=k)
+            continue
+        big = np.abs(g['it/grad/' + k]) > 1e-4      # Adam's first step amplifies noise on ~eps-sized grads
+        np.testing.assert_allclose(got[big], ref[big], atol=3e-6, err_msg=k)
+        np.testing.assert_allclose(got[~big], ref[~big], atol=4.1e-4, err_msg=k)
+
+
+def test_tiny_dropout_train_mode_grads(golden):
+    g = golden('tiny')
+    cap, c, st, w, d, s2s = make_captioner('tiny', train=True)
+    masks = {k: torch.from_numpy(g['drop/mask_' + k]) for k in ('fc', 'att', 'label')}
+    for i in range(c['T']):
+        masks['out%d' % i] = torch.from_numpy(g['drop/mask_out%d' % i])
+    cap.zero_grad()
+    pred = cap.forward_xe(T(d, 'fc_feats'), T(d, 'att_feats'), T(d, 'cpt_words'), T(d, 'captions'),
+                          T(d, 'senti_labels'), 0.0, _masks=masks)
+    np.testing.assert_allclose(pred.detach().cpu().numpy(), g['drop/xe_logp'], atol=2e-4)
+    loss = XECriterion()(pred, T(d, 'captions')[:, 1:], d['lengths'])
+    np.testing.assert_allclose(float(loss.detach()), g["drop/loss"][0], rtol=2e-5)
+    loss.backward()
+    for k, q in cap.named_parameters():
+        key = 'drop/grad/' + k
+        if key in g.files:
+            ref = g[key]
+            np.testing.assert_allclose(q.grad.cpu().numpy(), ref, atol=GRAD_RTOL * np.abs(ref).max() + 1e-7,
+                                       err_msg=k)
+
+
+def test_tiny_sampled_rollout_reinforce_grads(golden):
+    """forward_rl(sample_max=0) with grad: replay the reference's draws, RewardCriterion, backward."""
+    g = golden('tiny')
+    cap, c, st, w, d, _ = make_captioner('tiny')
+    a = (T(d, 'fc_feats'), T(d, 'att_feats'), T(d, 'cpt_words'), T(d, 'senti_words'), T(d, 'senti_labels'))
+    cap.zero_grad()
+    seq, lp, mk = cap.forward_rl(*a, c['T'], 0, _replay=torch.from_numpy(g['rl/sample_draws']).to(dev()))
+    assert lp.requires_grad
+    assert (seq.cpu().numpy() == g['rl/sample_seq']).all()
+    np.testing.assert_allclose(lp.detach().cpu().numpy(), g['rl/sample_logprobs'], atol=1e-4)
+    reward = torch.from_numpy(g['rl/sample_reward']).to(dev())
+    loss = (-lp * mk * reward).sum() / mk.sum()       # RewardCriterion, self_critical/utils.py:173-177
+    np.testing.assert_allclose(float(loss.detach()), g["rl/sample_rl_loss"][0], rtol=5e-5)
+    loss.backward()
+    n = 0
+    for k, q in cap.named_parameters():
+        key = 'rl/grad/' + k
+        if key in g.files:
+            ref = g[key]
+            np.testing.assert_allclose(q.grad.cpu().numpy(), ref, atol=GRAD_RTOL * np.abs(ref).max() + 1e-7,
+                                       err_msg=k)
+            n += 1
+    assert n >= 36
+
+
+@pytest.mark.parametrize('name', ['cfg1', 'b128'])
+def test_fullsize_train_iteration_digests(golden, name):
+    """BASELINE.json configs[1] (B=128 XE forward+backward, 36x2048 feats, V=10k, T=20) and the B=4
+    plumbing config: losses, gradient fingerprints of all 32 trained tensors, post-Adam parameters."""
+    g = golden(name)
+    cap, c, st, w, d, s2s = make_captioner(name)
+    optim, _, _ = cap.get_optim_criterion(4e-4)
+    pred, pred2, losses = run_iteration(cap, d, s2s)
+    np.testing.assert_allclose(losses, g['it/losses'], rtol=3e-5)
+    tgt = pred.detach().gather(2, T(d, 'captions')[:, 1:].unsqueeze(2)).squeeze(2).cpu().numpy()
+    np.testing.assert_allclose(tgt, g['it/xe_logp_tgt'], atol=1e-4)
+    n = 0
+    for k, q in cap.named_parameters():
+        key = 'it/gdig/' + k
+        if key in g.files:
+            assert_digest_close(digest(q.grad.cpu().numpy()), g[key], k, rel=2e-4)
+            n += 1
+    assert n == 32
+    clip_gradient(optim, 0.1)
+    optim.step()
+    for k, q in cap.named_parameters():
+        got, ref = digest(q.detach().cpu().numpy()), g['it/adig/' + k]
+        # parameters move by at most lr=4e-4 per element; the fingerprint must agree to that scale.
+        # Tensors whose true gradient is 0 (the alpha biases: softmax shift invariance) carry only
+        # ~1e-9 rounding noise in the reference, which Adam's first step amplifies to ~lr.
+        gkey = 'it/gdig/' + k
+        if gkey in g.files and g[gkey][2] > 1e-6:
+            assert abs(got[2] - ref[2]) <= 1e-5 * ref[2] + 1e-6, k
+        np.testing.assert_allclose(got[3:], ref[3:], atol=4.1e-4, err_msg=k)
