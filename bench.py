@@ -43,6 +43,7 @@ def parse():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--batch', type=int, default=2048, help='captions per GPU per step')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extras', action='store_true', help='skip the XE-train / beam side measurements')
     ap.add_argument('--cpu-seconds', type=float, default=15.0)
     return ap.parse_args()
 
@@ -89,6 +90,63 @@ def cpu_baseline(weights, seconds):
     return dict(value=round(n * Bc / el, 2), unit='captions/s', cores=cores, kind='port',
                 sample='%d greedy roll-outs of B=%d (T=%d, R=%d, V=%d) by oracle/captioner_oracle.py, '
                        'torch CPU fp32, %d threads, %.1f s' % (n, Bc, T, R, V, cores, el))
+
+
+def bench_xe_train(cap, dev, rank, world, iters=6, B=128):
+    """BASELINE.json configs[1]/[3]: XE forward+backward+clamp+Adam, B=128 captions per GPU (plus the
+    80-row seq2seq batch of train_xe.py:132-134), train-mode dropout, DP gradient all-reduce if N>1."""
+    from insenticap_model_amd import dp
+    from insenticap_model_amd.train import xe_train_step
+    cap.train()
+    optim, xe_crit, da_crit = cap.get_optim_criterion(4e-4)
+    arena = dp.GradArena(cap.parameters()) if world > 1 else None
+    d = synth.make_inputs(B, V, synth.DEFAULT_SETTINGS, regions=R, seq_len=T, seed=500 + rank)
+    s = synth.make_inputs(80, V, synth.DEFAULT_SETTINGS, regions=R, seq_len=T, seed=600 + rank)
+    tt = lambda x: torch.from_numpy(x).to(dev)
+    fact = (None, tt(d['fc_feats']), tt(d['att_feats']), (tt(d['captions']), d['lengths']), tt(d['cpt_words']))
+    labels = tt(d['senti_labels'])
+    scs = ((tt(s['captions']), s['lengths']), tt(s['cpt_words']), tt(s['senti_words']), tt(s['senti_labels']))
+    for _ in range(2):
+        xe_train_step(cap, optim, xe_crit, da_crit, fact, labels, scs, 0.0, 0.1, arena=arena)
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        xe_train_step(cap, optim, xe_crit, da_crit, fact, labels, scs, 0.0, 0.1, arena=arena)
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    cap.eval()
+    return dict(iters=iters, batch_per_gpu=B, seq2seq_rows=80, ms_per_iter=round(el / iters * 1e3, 2),
+                captions_per_s=round(world * B * iters / el, 1),
+                grad_allreduce_mb=round(arena.nbytes / 1e6, 2) if arena else 0.0)
+
+
+def bench_beam(cap, inputs, n_img=64, beam=5):
+    """BASELINE.json configs[2]: beam 5, sentiment attention on. Reference API (one image per call)
+    latency and the batched path's throughput."""
+    fc, att, _, sw, lab = [x[:n_img] for x in inputs]
+    lat = []
+    with torch.no_grad():
+        cap.sample(fc[0], att[0], sw[0], lab[0:1], beam, 1, T)
+        for i in range(16):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            cap.sample(fc[i], att[i], sw[i], lab[i:i + 1], beam, 1, T)
+            torch.cuda.synchronize()
+            lat.append(time.perf_counter() - t0)
+        cap.sample_batch(fc, att, sw, lab, beam, 1, T)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        cap.sample_batch(fc, att, sw, lab, beam, 1, T)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+    lat.sort()
+    return dict(beam=beam, per_image_p50_ms=round(lat[len(lat) // 2] * 1e3, 2),
+                per_image_p95_ms=round(lat[int(len(lat) * 0.95) - 1] * 1e3, 2),
+                batched_images=n_img, batched_images_per_s=round(n_img / el, 1))
 
 
 def roofline_entry(name, rec):
@@ -144,7 +202,21 @@ def main():
         tt = torch.tensor([el], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         el = float(tt)
+    extra = {}
+    if not args.no_extras:
+        # secondary measurements (never part of `value`); failures are reported, not fatal
+        try:
+            extra['xe_train'] = bench_xe_train(cap, dev, rank, world)
+        except Exception as e:  # noqa: BLE001
+            extra['xe_train'] = {'error': repr(e)[:200]}
+        if world == 1:
+            try:
+                extra['beam5'] = bench_beam(cap, inputs)
+            except Exception as e:  # noqa: BLE001
+                extra['beam5'] = {'error': repr(e)[:200]}
     if rank != 0:
+        if world > 1:
+            torch.distributed.destroy_process_group()
         return
 
     total = world * B * args.steps
@@ -170,10 +242,13 @@ def main():
                    'batch_per_gpu': B, 'parallelism': 'dp%d (batch shard, no collective)' % world},
         'roofline': entries[0] if entries else None,
         'roofline_kernels': entries[1:],
+        'extra': extra,
     }
     if not args.no_cpu_baseline and world == 1:
         out['cpu_baseline'] = cpu_baseline(weights, args.cpu_seconds)
     print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == '__main__':

@@ -51,5 +51,31 @@ def build(force=False, verbose=False):
     return LIB_PATH
 
 
+def resource_report():
+    """Per-kernel register / scratch / LDS usage from hipcc's -Rpass-analysis (compile only).
+    Returns {kernel: {'vgprs', 'agprs', 'scratch', 'vgpr_spill', 'occupancy'}}."""
+    import re
+    hipcc = _hipcc()
+    rep = {}
+    for s in SOURCES:
+        src = os.path.join(CSRC, s)
+        out = subprocess.run([hipcc] + FLAGS + ['-Rpass-analysis=kernel-resource-usage', '-c', src, '-o',
+                                                 os.devnull], capture_output=True, text=True, check=True).stderr
+        cur = None
+        for line in out.splitlines():
+            m = re.search(r'remark: (.*?)\s*\[-Rpass', line)
+            if not m:
+                continue
+            txt = m.group(1).strip()
+            if txt.startswith('Function Name:'):
+                cur = rep.setdefault(txt.split(':', 1)[1].strip(), {})
+            elif cur is not None:
+                for key, name in (('VGPRs:', 'vgprs'), ('AGPRs:', 'agprs'), ('ScratchSize [bytes/lane]:', 'scratch'),
+                                  ('VGPRs Spill:', 'vgpr_spill'), ('Occupancy [waves/SIMD]:', 'occupancy')):
+                    if txt.startswith(key):
+                        cur[name] = int(txt.split(':')[-1])
+    return rep
+
+
 if __name__ == '__main__':
     print(build(force='--force' in sys.argv, verbose=True))

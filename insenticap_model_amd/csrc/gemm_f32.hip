@@ -142,18 +142,17 @@ __global__ __launch_bounds__(256) void gemm_kernel(const DevLaunch L) {
     int nchunks = 0;
     for (int s = 0; s < P.nseg; ++s) nchunks += (P.seg[s].K + BK - 1) / BK;
 
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 ra[A_LD], rb[B_LD];
     int cs = 0, ck = 0;  // segment / k-offset of the chunk being loaded
     auto gload = [&]() {
         const DevSeg sg = P.seg[cs];
-        if (AKM) {
+        if constexpr (AKM) {
 #pragma unroll
             for (int i = 0; i < A_LD; ++i) {
                 const int k = ck + akr + (1024 / BM) * i;
                 ra[i] = (a_col_ok && k < sg.K)
                             ? *reinterpret_cast<const float4 *>(sg.A + (long long)k * sg.lda + row0 + akc)
-                            : zero4;
+                            : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         } else {
             const float *Ab = sg.A + (long long)(row0 + lr) * sg.lda + ck + lc;
@@ -161,29 +160,29 @@ __global__ __launch_bounds__(256) void gemm_kernel(const DevLaunch L) {
 #pragma unroll
             for (int i = 0; i < A_LD; ++i)
                 ra[i] = (aok[i] && kok) ? *reinterpret_cast<const float4 *>(Ab + (long long)(32 * i) * sg.lda)
-                                        : zero4;
+                                        : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        if (BKM) {
+        if constexpr (BKM) {
 #pragma unroll
             for (int i = 0; i < B_LD; ++i) {
                 const int k = ck + bkr + (1024 / BN) * i;
                 rb[i] = (b_col_ok && k < sg.K)
                             ? *reinterpret_cast<const float4 *>(sg.W + (long long)k * sg.ldw + col0 + bkc)
-                            : zero4;
+                            : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         } else {
             const bool kok = (ck + lc) < sg.K;
 #pragma unroll
             for (int i = 0; i < B_LD; ++i)
                 rb[i] = (wok[i] && kok) ? *reinterpret_cast<const float4 *>(sg.W + wrow[i] * sg.ldw + ck + lc)
-                                        : zero4;
+                                        : make_float4(0.f, 0.f, 0.f, 0.f);
         }
         ck += BK;
         if (ck >= sg.K) { ck = 0; ++cs; }
     };
     auto sstore = [&](int buf) {
         float *a = As + buf * TA::SIZE;
-        if (AKM) {
+        if constexpr (AKM) {
 #pragma unroll
             for (int i = 0; i < A_LD; ++i)
                 *reinterpret_cast<float4 *>(a + (akr + (1024 / BM) * i) * (BM + 4) + akc) = ra[i];
@@ -193,7 +192,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const DevLaunch L) {
                 *reinterpret_cast<float4 *>(a + (lr + 32 * i) * LDT + lc) = ra[i];
         }
         float *b = Bs + buf * TB::SIZE;
-        if (BKM) {
+        if constexpr (BKM) {
 #pragma unroll
             for (int i = 0; i < B_LD; ++i)
                 *reinterpret_cast<float4 *>(b + (bkr + (1024 / BN) * i) * (BN + 4) + bkc) = rb[i];
@@ -220,7 +219,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const DevLaunch L) {
 #pragma unroll
         for (int kb = 0; kb < BK / 8; ++kb) {
             float a[4], b[TN][4];
-            if (AKM) {
+            if constexpr (AKM) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) a[e] = at[(kb * 8 + fk + e) * (BM + 4) + wm * 32 + frow];
             } else {
@@ -229,7 +228,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const DevLaunch L) {
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                if (BKM) {
+                if constexpr (BKM) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
                         b[j][e] = bt[(kb * 8 + fk + e) * (BN + 4) + (wn * TN + j) * 32 + frow];

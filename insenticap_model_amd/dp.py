@@ -1,0 +1,114 @@
+"""Data-parallel training of the captioner over the GPUs of one node (one process per GPU,
+torch.distributed; backend "nccl" is RCCL over xGMI on ROCm, "gloo" on CPU for tests).
+
+The reference is single-device (opts.py:98-99); DP is a capability of this build
+(SURVEY 8(e)).  Design for xGMI (point-to-point links, no switch):
+  * ONE collective per iteration: all 40 gradient tensors live in one flat fp32 arena
+    (22,063,379 elements = 88.25 MB at V=10k), `p.grad` are views into it, so autograd
+    accumulates in place and the all-reduce needs no flatten / unflatten copies.
+    Weights are shared across time steps, so no gradient is final before BPTT ends - there is
+    nothing to overlap with except the optimiser, hence no bucketing.
+  * the reduction is a SUM; each rank pre-scales its loss by local_tokens / global_tokens so the
+    result equals the single-process loss exactly even when ranks hold different token counts
+    (XECriterion / RewardCriterion divide by the *global* mask sum: captioner.py:438, utils.py:175).
+  * the elementwise clamp (train_xe.py:19-23) is nonlinear, so it runs after the reduction, fused
+    into the Adam launch (optim.FusedClampAdam).
+Inference (greedy / beam) shards images across ranks with no collective at all.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Initialise the default process group from torchrun's environment. Returns (rank, world, local)."""
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        kw = {}
+        if backend == 'nccl':
+            torch.cuda.set_device(local)
+            kw['device_id'] = torch.device('cuda', local)
+        dist.init_process_group(backend, **kw)
+    return rank, world, local
+
+
+def world_size(group=None):
+    return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+
+
+class GradArena:
+    """Flat gradient storage: `p.grad` of every parameter is a view into one contiguous buffer."""
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+        n = sum(p.numel() for p in self.params)
+        ref = self.params[0]
+        self.flat = torch.zeros(n, dtype=ref.dtype, device=ref.device)
+        off = 0
+        for p in self.params:
+            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+
+    def zero_(self):
+        """Replaces optimizer.zero_grad(): keeps the views alive (set_to_none would detach them)."""
+        self.flat.zero_()
+        for p in self.params:
+            if p.grad is None or p.grad.data_ptr() < self.flat.data_ptr() or \
+                    p.grad.data_ptr() >= self.flat.data_ptr() + self.flat.numel() * self.flat.element_size():
+                raise RuntimeError('a .grad was replaced; call zero_() instead of zero_grad(set_to_none=True)')
+
+    def all_reduce(self, group=None):
+        """Sum the gradients of all ranks: one collective over the whole arena."""
+        if world_size(group) > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+        return self.flat
+
+    @property
+    def nbytes(self):
+        return self.flat.numel() * self.flat.element_size()
+
+
+def global_count(local_count, group=None):
+    """All-reduce a token count (python number or 0-dim tensor) -> tensor on the same device."""
+    t = local_count.detach().clone().float() if torch.is_tensor(local_count) else torch.tensor(float(local_count))
+    if world_size(group) > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t
+
+
+def dp_token_mean(local_mean_loss, local_tokens, group=None):
+    """Rescales a per-rank token-mean loss so that SUM-reduced gradients equal those of the global
+    token mean: loss_r * n_r / sum_r n_r.  Returns (scaled loss for backward, global token count)."""
+    n = global_count(local_tokens, group)
+    lt = local_tokens if torch.is_tensor(local_tokens) else float(local_tokens)
+    return local_mean_loss * (lt / n.to(local_mean_loss.device)), n
+
+
+def dp_batch_mean(local_mean_loss, group=None):
+    """Same for a plain batch mean with equal per-rank batch sizes (the domain-align MSE)."""
+    return local_mean_loss / world_size(group)
+
+
+def broadcast_parameters(module, src=0, group=None):
+    """Make every rank start from rank `src`'s weights (one flat broadcast)."""
+    if world_size(group) == 1:
+        return
+    ps = [p.data for p in module.parameters()]
+    flat = torch.cat([p.reshape(-1) for p in ps])
+    dist.broadcast(flat, src=src, group=group)
+    off = 0
+    for p in ps:
+        p.copy_(flat[off:off + p.numel()].view_as(p))
+        off += p.numel()
+
+
+def shard(n_items, rank, world):
+    """Contiguous shard [lo, hi) of n_items for this rank (inference: images are independent)."""
+    per = (n_items + world - 1) // world
+    lo = min(rank * per, n_items)
+    return lo, min(lo + per, n_items)

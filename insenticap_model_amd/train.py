@@ -1,0 +1,61 @@
+"""The inner XE training step of the reference (train_xe.py:149-192) on the HIP path, optionally
+data-parallel.  Batch tuple layouts are the reference collate functions' (dataloader.py:11-58):
+  fact batch: (fns, fc_feats [B,F], att_feats [B,...,F], (caps [B,L], lengths), cpts [B,C])
+  scs  batch: ((caps [80,L], lengths), cpts [80,C], sentis [80,10], senti_labels [80])
+The sentence-sentiment classifier that labels the factual captions (train_xe.py:155-158) is a
+frozen helper outside this path: the caller passes its arg-max as `xe_senti_labels`.
+"""
+import torch
+
+from . import dp
+from .optim import clip_gradient
+
+
+def xe_train_step(captioner, optim, xe_crit, da_crit, fact_batch, xe_senti_labels, scs_batch=None,
+                  ss_prob=0.0, grad_clip=0.1, arena=None, group=None, device=None):
+    """One iteration. Returns dict(xe_loss, da_loss, cap_loss, seq2seq_loss, all_loss) of 0-dim
+    tensors (global values under DP).  `arena`: dp.GradArena when gradients are all-reduced."""
+    device = device or next(captioner.parameters()).device
+    _, fc_feats, att_feats, (caps_tensor, lengths), cpts_tensor = fact_batch[:5]
+    fc_feats, att_feats = fc_feats.to(device), att_feats.to(device)
+    caps_tensor, cpts_tensor = caps_tensor.to(device), cpts_tensor.to(device)
+    xe_senti_labels = xe_senti_labels.to(device)
+    world = dp.world_size(group)
+
+    pred = captioner(fc_feats, att_feats, cpts_tensor, caps_tensor, xe_senti_labels, ss_prob, mode='xe')
+    xe_loss = xe_crit(pred, caps_tensor[:, 1:], lengths)
+    da_loss = da_crit(captioner.cpt_feats, captioner.fc_feats.detach())
+    if world > 1:
+        xe_bwd, _ = dp.dp_token_mean(xe_loss, float(sum(lengths)), group)
+        da_bwd = dp.dp_batch_mean(da_loss, group)
+    else:
+        xe_bwd, da_bwd = xe_loss, da_loss
+    total = xe_bwd + da_bwd
+    out = {'xe_loss': xe_bwd.detach(), 'da_loss': da_bwd.detach()}
+    out['cap_loss'] = out['xe_loss'] + out['da_loss']
+    out['seq2seq_loss'] = torch.zeros((), device=device)
+    if scs_batch is not None:
+        (s_caps, s_lengths), s_cpts, s_sentis, s_labels = scs_batch
+        s_caps, s_cpts = s_caps.to(device), s_cpts.to(device)
+        s_sentis, s_labels = s_sentis.to(device), s_labels.to(device)
+        pred2 = captioner(s_caps, s_cpts, s_sentis, s_labels, ss_prob, mode='seq2seq')
+        s2s = xe_crit(pred2, s_caps[:, 1:], s_lengths)
+        if world > 1:
+            s2s, _ = dp.dp_token_mean(s2s, float(sum(s_lengths)), group)
+        total = total + s2s
+        out['seq2seq_loss'] = s2s.detach()
+    out['all_loss'] = out['cap_loss'] + out['seq2seq_loss']
+
+    if arena is not None:
+        arena.zero_()
+    else:
+        optim.zero_grad()
+    total.backward()
+    if arena is not None:
+        arena.all_reduce(group)          # one 88 MB sum over xGMI; clamp must see reduced grads
+    if world > 1:
+        for k in out:                    # report global losses (sum of the pre-scaled locals)
+            torch.distributed.all_reduce(out[k], group=group)
+    clip_gradient(optim, grad_clip)      # fused into the Adam launch
+    optim.step()
+    return out

@@ -1,0 +1,168 @@
+"""CPU-only checks: the C-ABI library loads and exports every symbol include/insenticap_hip.h
+declares (no compute calls without a GPU), the ctypes structs match the C layout, the host
+mirror keeps the reference's API surface, and the product fails loudly without a device."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+from insenticap_model_amd import Captioner, XECriterion, _build, _lib, synth
+
+HEADER = os.path.join(ROOT, 'include', 'insenticap_hip.h')
+
+
+def declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(isc_[a-z0-9_]+)\s*\(', src)))
+
+
+def test_library_builds_and_exports_every_declared_symbol():
+    path = _build.build()
+    assert os.path.exists(path)
+    lib = ctypes.CDLL(path)
+    names = declared_functions()
+    assert len(names) >= 24
+    for n in names:
+        assert hasattr(lib, n), 'missing export: ' + n
+    # the binding table covers exactly the declared entry points
+    assert sorted(_lib.SIGNATURES) == names
+    lib2 = _lib.load()
+    assert lib2.isc_target_arch() == b'gfx950'
+    assert lib2.isc_abi_version() >= 1
+
+
+def test_no_kernel_spills_or_uses_scratch():
+    """A runtime-indexed register array silently moves to scratch memory and halves GEMM speed
+    (seen once in this repo): every kernel must keep its arrays in registers."""
+    rep = _build.resource_report()
+    assert len(rep) >= 25
+    for k, r in rep.items():
+        assert r.get('scratch', 0) == 0, (k, r)
+        assert r.get('vgpr_spill', 0) == 0, (k, r)
+    gemm = [r for k, r in rep.items() if 'gemm_kernel' in k]
+    assert gemm and all(r['occupancy'] >= 3 for r in gemm)
+
+
+def test_ctypes_struct_layout_matches_c():
+    """Compile a tiny C program against the header and compare sizeof/offsetof with ctypes."""
+    prog = r'''
+#include <stdio.h>
+#include <stddef.h>
+#include "insenticap_hip.h"
+int main(void) {
+  printf("%zu %zu %zu %zu %zu\n", sizeof(isc_seg), sizeof(isc_linear_problem), sizeof(isc_lstm_problem),
+         sizeof(isc_scan_problem), sizeof(isc_rollout_step));
+  printf("%zu %zu %zu %zu\n", offsetof(isc_linear_problem, bias0), offsetof(isc_linear_problem, C),
+         offsetof(isc_linear_problem, accumulate), sizeof(isc_scan_bwd_problem));
+  printf("%zu %zu %zu\n", offsetof(isc_lstm_problem, c_prev), offsetof(isc_scan_problem, out),
+         offsetof(isc_rollout_step, xt_next));
+  return 0;
+}
+'''
+    tmp = os.path.join(ROOT, 'gpurun_out')
+    os.makedirs(tmp, exist_ok=True)
+    cfile, exe = os.path.join(tmp, 'layout.c'), os.path.join(tmp, 'layout')
+    open(cfile, 'w').write(prog)
+    subprocess.check_call(['gcc', '-I', os.path.join(ROOT, 'include'), cfile, '-o', exe])
+    out = subprocess.check_output([exe]).decode().split()
+    got = [int(x) for x in out]
+    L = _lib
+    exp = [ctypes.sizeof(L.Seg), ctypes.sizeof(L.LinearProblem), ctypes.sizeof(L.LstmProblem),
+           ctypes.sizeof(L.ScanProblem), ctypes.sizeof(L.RolloutStep),
+           L.LinearProblem.bias0.offset, L.LinearProblem.C.offset, L.LinearProblem.accumulate.offset,
+           ctypes.sizeof(L.ScanBwdProblem),
+           L.LstmProblem.c_prev.offset, L.ScanProblem.out.offset, L.RolloutStep.xt_next.offset]
+    assert got == exp
+
+
+def test_argument_validation_without_a_gpu():
+    """Bad arguments are rejected on the host before anything touches the device."""
+    lib = _lib.load()
+    assert lib.isc_linear_fwd(None, 1, None) == -1
+    p = _lib.LinearProblem()
+    assert lib.isc_linear_fwd(ctypes.byref(p), 0, None) == -2
+    assert lib.isc_linear_fwd(ctypes.byref(p), 1, None) == -2         # nseg == 0
+    p.nseg = 1
+    assert lib.isc_linear_fwd(ctypes.byref(p), 1, None) == -1         # null segment pointers
+    assert lib.isc_attn_scan_fwd(None, 1, 4, None) == -1
+    assert lib.isc_vocab_fwd(None, 0, None, 0, None, 1, 1, 32, None, 0, None, None, None, None) == -1
+    assert lib.isc_gemm_bwd(ctypes.byref(p), 1, 7, None) == -2        # unknown layout
+    assert lib.isc_colsum(None, 0, 1, 1, None, 0, None) == -1
+
+
+def make(V=64, st=synth.TINY_SETTINGS):
+    return Captioner(synth.make_idx2word(V), synth.SENTIMENT_CATEGORIES, st)
+
+
+def test_state_dict_matches_reference_layout():
+    cap = make()
+    shapes = synth.param_shapes(64, synth.TINY_SETTINGS)
+    sd = cap.state_dict()
+    assert list(sd.keys()) == list(shapes.keys())          # names AND registration order
+    for k, v in sd.items():
+        assert tuple(v.shape) == shapes[k], k
+    assert len(sd) == 40
+    # full-size model: 22,063,379 parameters
+    full = synth.param_shapes(10000, synth.DEFAULT_SETTINGS)
+    assert sum(int(np.prod(s)) for s in full.values()) == 22063379
+
+
+def test_special_ids_and_api_surface():
+    cap = make()
+    assert (cap.pad_id, cap.sos_id, cap.eos_id, cap.unk_id, cap.neu_idx) == (0, 1, 2, 3, 2)
+    assert cap.vocab_size == 64
+    for name in ('forward_xe', 'forward_seq2seq', 'forward_rl', 'sample', 'sample_batch', 'init_hidden',
+                 'get_optim_criterion'):
+        assert callable(getattr(cap, name))
+    # vocabulary without <SOS>: sos/eos fall back to <PAD> exactly like the reference (captioner.py:127-128)
+    cap2 = Captioner(['<PAD>', '<UNK>', 'a', 'b'] + ['w%d' % i for i in range(28)], ['positive', 'negative', 'neutral'],
+                     synth.TINY_SETTINGS)
+    assert cap2.sos_id == cap2.pad_id == cap2.eos_id == 0
+    optim, xe, mse = cap.get_optim_criterion(4e-4)
+    assert isinstance(optim, torch.optim.Adam) and isinstance(xe, XECriterion) and isinstance(mse, torch.nn.MSELoss)
+    assert optim.param_groups[0]['lr'] == 4e-4 and optim.param_groups[0]['betas'] == (0.9, 0.999)
+
+
+def test_unsupported_dims_are_rejected():
+    st = dict(synth.TINY_SETTINGS, rnn_hid_dim=48)
+    with pytest.raises(ValueError):
+        make(st=st)
+    st = dict(synth.TINY_SETTINGS, word_emb_dim=64)
+    with pytest.raises(ValueError):
+        make(st=st)
+
+
+def test_product_fails_loudly_on_cpu():
+    """No CPU fallback: calling the model with CPU parameters raises instead of computing."""
+    cap = make().eval()
+    d = synth.make_inputs(2, 64, synth.TINY_SETTINGS, regions=6, seq_len=4, seed=0)
+    t = lambda k: torch.from_numpy(d[k])
+    with torch.no_grad():
+        with pytest.raises(_lib.HipLibraryError):
+            cap(t('fc_feats'), t('att_feats'), t('cpt_words'), t('senti_words'), t('senti_labels'), 4, 1, mode='rl')
+        with pytest.raises(_lib.HipLibraryError):
+            cap(t('fc_feats'), t('att_feats'), t('cpt_words'), t('captions'), t('senti_labels'), mode='xe')
+        with pytest.raises(_lib.HipLibraryError):
+            cap.sample(t('fc_feats')[0], t('att_feats')[0])
+
+
+def test_missing_library_is_an_error(monkeypatch):
+    monkeypatch.setattr(_lib, '_lib', None)
+    monkeypatch.setattr(_lib, 'LIB_PATH', '/nonexistent/libinsenticap_hip.so')
+    with pytest.raises(_lib.HipLibraryError):
+        _lib.load()
+
+
+def test_product_never_imports_the_oracle():
+    """oracle/ is test infrastructure: nothing under insenticap_model_amd/ may reference it."""
+    pkg = os.path.join(ROOT, 'insenticap_model_amd')
+    for fn in os.listdir(pkg):
+        if fn.endswith('.py'):
+            src = open(os.path.join(pkg, fn)).read()
+            assert not re.search(r'^\s*(from|import)\s+oracle\b', src, flags=re.M), fn
