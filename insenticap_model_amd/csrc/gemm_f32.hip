@@ -248,6 +248,96 @@ __global__ __launch_bounds__(256) void gemm_kernel(const DevLaunch L) {
         __syncthreads();
     }
 
+    if constexpr (EPI == EPI_VOCAB) {
+        // ---- vocabulary epilogue straight from the accumulator registers (no LDS round trip):
+        // C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5), so one
+        // register index r is one output row per half-wave and the row's 32*TN columns of this wave
+        // sit on the 32 lanes of that half.  Per row: max / arg-max / sum exp(x - max) by 5-step
+        // butterflies inside the half-wave (xor 1..16 never crosses lane 32).
+        float bv[TN];
+        bool cok[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int gn = col0 + (wn * TN + j) * 32 + (lane & 31);
+            cok[j] = gn < N;
+            bv[j] = cok[j] ? P.bias0[gn] : 0.f;
+        }
+        float *smx = smem;                    // [WN][BM] cross-wave combine (WN > 1 only)
+        float *ssm = smem + WN * BM;
+        int *six = reinterpret_cast<int *>(smem + 2 * WN * BM);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const int gm = row0 + row;
+            float x[TN];
+            float mx = -INFINITY;
+            int ix = 0x7fffffff;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                x[j] = cok[j] ? acc[j][r] + bv[j] : -INFINITY;
+                const int gn = col0 + (wn * TN + j) * 32 + (lane & 31);
+                if (x[j] > mx) { mx = x[j]; ix = gn; }       // j ascending => smaller column wins ties
+            }
+            if (P.C && gm < M) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    if (cok[j])
+                        P.C[(long long)gm * P.ld_logits + col0 + (wn * TN + j) * 32 + (lane & 31)] = x[j];
+            }
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) {
+                const float ov = __shfl_xor(mx, o, 64);
+                const int oi = __shfl_xor(ix, o, 64);
+                if (ov > mx || (ov == mx && oi < ix)) { mx = ov; ix = oi; }
+            }
+            float sm = 0.f;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) sm += cok[j] ? __expf(x[j] - mx) : 0.f;   // padded columns add 0
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) sm += __shfl_xor(sm, o, 64);
+            if ((lane & 31) == 0) {
+                if constexpr (WN == 1) {
+                    if (gm < M) {
+                        const long long o = (long long)gm * P.ntile_total + tn;
+                        P.pmax[o] = mx;
+                        P.psum[o] = sm;
+                        P.pidx[o] = ix;
+                    }
+                } else {
+                    smx[wn * BM + row] = mx;
+                    ssm[wn * BM + row] = sm;
+                    six[wn * BM + row] = ix;
+                }
+            }
+        }
+        if constexpr (WN > 1) {
+            __syncthreads();
+            for (int row = tid; row < BM; row += 256) {
+                const int gm = row0 + row;
+                if (gm >= M) continue;
+                float mx = smx[row];
+                int ix = six[row];
+#pragma unroll
+                for (int w = 1; w < WN; ++w) {
+                    const float ov = smx[w * BM + row];
+                    const int oi = six[w * BM + row];
+                    if (ov > mx || (ov == mx && oi < ix)) { mx = ov; ix = oi; }
+                }
+                float sm = 0.f;
+#pragma unroll
+                for (int w = 0; w < WN; ++w) {
+                    const float wm_ = smx[w * BM + row];          // -inf: that wave had no valid column
+                    if (wm_ > -INFINITY) sm += ssm[w * BM + row] * __expf(wm_ - mx);
+                }
+                const long long o = (long long)gm * P.ntile_total + tn;
+                P.pmax[o] = mx;
+                P.psum[o] = sm;
+                P.pidx[o] = ix;
+            }
+        }
+        return;
+    }
+
     // stage the tile: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll
     for (int j = 0; j < TN; ++j)
@@ -317,38 +407,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(const DevLaunch L) {
             if (P.gates_out) {
                 float *g = P.gates_out + (long long)gm * 4 * H + unit;
                 g[0] = gi; g[H] = gf; g[2 * H] = gg; g[3 * H] = go;
-            }
-        }
-    } else {  // EPI_VOCAB
-        const bool vec = P.C && (P.ld_logits & 3) == 0;
-        // bias add (+ optional logits store), -inf beyond the vocabulary
-        for (int idx = tid; idx < BM * (BN / 4); idx += 256) {
-            const int row = idx / (BN / 4), c4 = (idx % (BN / 4)) * 4;
-            const int gm = row0 + row, gn = col0 + c4;
-            float *cp = Cs + row * LDC + c4;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) cp[e] = (gn + e < N) ? cp[e] + P.bias0[gn + e] : -INFINITY;
-            if (P.C && gm < M && gn < N) {
-                float *dst = P.C + (long long)gm * P.ld_logits + gn;
-                if (vec && gn + 3 < N) *reinterpret_cast<float4 *>(dst) = *reinterpret_cast<float4 *>(cp);
-                else for (int e = 0; e < 4 && gn + e < N; ++e) dst[e] = cp[e];
-            }
-        }
-        __syncthreads();
-        // per-row tile statistics: each wave owns BM/4 rows, a lane owns columns lane, lane+64
-        for (int rr = 0; rr < BM / 4; ++rr) {
-            const int row = wave * (BM / 4) + rr, gm = row0 + row;
-            if (gm >= M) break;  // wave-uniform
-            const float v0 = Cs[row * LDC + lane], v1 = Cs[row * LDC + 64 + lane];
-            float mx = v0; int ix = lane;
-            if (v1 > mx) { mx = v1; ix = lane + 64; }
-            wave_argmax(mx, ix);
-            const float s = wave_sum(expf(v0 - mx) + expf(v1 - mx));
-            if (lane == 0) {
-                const long long o = (long long)gm * P.ntile_total + tn;
-                P.pmax[o] = mx;
-                P.psum[o] = s;
-                P.pidx[o] = col0 + ix;
             }
         }
     }
