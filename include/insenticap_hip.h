@@ -94,6 +94,14 @@ typedef struct {
     const uint8_t *h_keep_mask; /* [M,H] or null */
     float mask_scale;
     float *hdrop_out;         /* [M,H], required iff h_keep_mask */
+    /* Hoisted step-invariant inputs (optional): gates += pre[m,:] + tab[tab_ids[m*tab_ids_stride],:].
+     * `pre` [M,4H] holds fc W_fc^T + label W_x^T + b_ih + b_hh computed once per call (b_ih/b_hh may
+     * then be null); `tab` [V,4H] = relu(Emb) W_x^T replaces the word-embedding K-segment when the
+     * weights are frozen (inference). */
+    const float *pre;
+    const float *tab;
+    const int64_t *tab_ids;
+    int64_t tab_ids_stride;
 } isc_lstm_problem;
 
 int isc_lstm_fwd(const isc_lstm_problem *prob_host, void *stream);

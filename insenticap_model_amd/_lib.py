@@ -32,7 +32,8 @@ class LstmProblem(C.Structure):
                 ('_pad', C.c_int32), ('b_ih', C.c_void_p), ('b_hh', C.c_void_p),
                 ('c_prev', C.c_void_p), ('h_out', C.c_void_p), ('c_out', C.c_void_p),
                 ('gates_out', C.c_void_p), ('h_keep_mask', C.c_void_p), ('mask_scale', C.c_float),
-                ('hdrop_out', C.c_void_p)]
+                ('hdrop_out', C.c_void_p), ('pre', C.c_void_p), ('tab', C.c_void_p),
+                ('tab_ids', C.c_void_p), ('tab_ids_stride', C.c_int64)]
 
 
 class ScanProblem(C.Structure):

@@ -62,7 +62,7 @@ def _train_forward(cap, mode, fc, att, cpt_words, senti_words, tokens_in, senti_
                 drawn = torch.multinomial(out[:, t - 1].detach().exp(), 1).view(-1)
                 it = torch.where(sample_mask, drawn, it)
         S.tok[t] = it
-        ops.embed_relu_fwd(emb, S.tok[t], S.xt[t], add=P.label_e)
+        ops.embed_relu_fwd(emb, S.tok[t], S.xt[t])        # plain relu(Emb[tok]); label term is in P.pre1
         om, osc = mask_for('out%d' % t, B, H)
         save = {'g1': S.g1[t], 'g2': S.g2[t]}
         if om is not None:
@@ -202,9 +202,13 @@ def _backward(cap, S, dlogp, d_fc_feats, d_cpt_feats):
     h2_prev = S.h2[:T].reshape(TB, H)
     feat_tb = (S.f if gate else (S.v if has_c else S.s)).view(TB, E)
     gW1 = new(4 * H, H + E + Wd)
+    # xt = relu(Emb[tok]) + label_e: the per-step part contracts over T*B rows, the label part over B
+    wx_segs = [(dG1f, S.xt.view(TB, Wd))]
+    if P.label_e is not None:
+        wx_segs.append((dG1_sum, P.label_e))
     ops.gemm_bwd([ops.gemm_problem([(dG1f, h2_prev)], gW1[:, 0:H], TN),
                   ops.gemm_problem([(dG1_sum, P.fc_e)], gW1[:, H:H + E], TN),
-                  ops.gemm_problem([(dG1f, S.xt.view(TB, Wd))], gW1[:, H + E:], TN)], TN)
+                  ops.gemm_problem(wx_segs, gW1[:, H + E:], TN)], TN)
     G['att_lstm.weight_ih'] = gW1
     gW2, gwhh1 = new(4 * H, E + H), new(4 * H, H)
     ops.gemm_bwd([ops.gemm_problem([(dG1f, h1_prev)], gwhh1, TN),

@@ -16,7 +16,7 @@ def beam_search_batch(cap, fc_feats, att_feats, senti_words, senti_labels, beam,
     p = cap._p()
     n_img = fc_feats.shape[0]
     P = cap._prologue(p, 'beam', fc_feats, att_feats, None, senti_words,
-                      senti_labels if senti_words is not None else None)
+                      senti_labels if senti_words is not None else None, want_table='cached')
     dev = cap._dev
     H, Wd, V = cap.att_lstm.hidden_size, cap.settings['word_emb_dim'], cap.vocab_size
     rows = n_img * beam
@@ -27,8 +27,9 @@ def beam_search_batch(cap, fc_feats, att_feats, senti_words, senti_labels, beam,
         return None if x is None else x.index_select(0, rep).contiguous()
     Pb = type(P)()
     Pb.B, Pb.R, Pb.Mw = rows, P.R, P.Mw
-    for name in ('fc_e', 'att_e3', 'att_p3', 'words_e3', 'words_p3', 'label_e', 'label_w'):
+    for name in ('fc_e', 'att_e3', 'att_p3', 'words_e3', 'words_p3', 'label_e', 'label_w', 'pre1'):
         setattr(Pb, name, expand(getattr(P, name)))
+    Pb.tab = P.tab
     ws = cap._alloc_step_ws(rows, Pb)
     h_cur, c_cur = cap._zeros(2, rows, H), cap._zeros(2, rows, H)
     h_nxt, c_nxt = cap._new(2, rows, H), cap._new(2, rows, H)
@@ -45,8 +46,9 @@ def beam_search_batch(cap, fc_feats, att_feats, senti_words, senti_labels, beam,
     last = [cap.sos_id] * rows
     for t in range(T):
         last_d = torch.tensor(last, dtype=torch.int64, device=dev)
-        ops.embed_relu_fwd(emb, last_d, xt, add=Pb.label_e)
-        cap._step(p, Pb, ws, xt, h_cur, c_cur, h_nxt, c_nxt, logits=logits)
+        if Pb.tab is None:
+            ops.embed_relu_fwd(emb, last_d, xt)
+        cap._step(p, Pb, ws, xt, h_cur, c_cur, h_nxt, c_nxt, logits=logits, tok=last_d)
         ops.beam_topk(logits, ws['pmax'], ws['psum'], last_d, beam, cap.pad_id, cap.sos_id, cap.unk_id,
                       mask_special, decoding_constraint, top_val, top_idx)
         tv = top_val.cpu().tolist()       # the single host read of this step

@@ -45,6 +45,9 @@ struct DevProb {
     const float *c_prev;
     float *h_out, *c_out, *gates_out, *hdrop;
     const uint8_t *hmask;
+    const float *pre, *tab;
+    const int64_t *tab_ids;
+    long long tab_ids_stride;
     int H, m_fastest;
     // vocab
     float *pmax, *psum;
@@ -390,10 +393,21 @@ __global__ __launch_bounds__(256) void gemm_kernel(const DevLaunch L) {
             const int gm = row0 + row, unit = tn * 32 + u;
             if (gm >= M) continue;
             const float *cr = Cs + row * LDC + u;
-            float gi = cr[0] + P.bias0[unit] + P.bias1[unit];
-            float gf = cr[32] + P.bias0[H + unit] + P.bias1[H + unit];
-            float gg = cr[64] + P.bias0[2 * H + unit] + P.bias1[2 * H + unit];
-            float go = cr[96] + P.bias0[3 * H + unit] + P.bias1[3 * H + unit];
+            float gi = cr[0], gf = cr[32], gg = cr[64], go = cr[96];
+            if (P.bias0) {
+                gi += P.bias0[unit] + P.bias1[unit];
+                gf += P.bias0[H + unit] + P.bias1[H + unit];
+                gg += P.bias0[2 * H + unit] + P.bias1[2 * H + unit];
+                go += P.bias0[3 * H + unit] + P.bias1[3 * H + unit];
+            }
+            if (P.pre) {
+                const float *q = P.pre + (long long)gm * 4 * H + unit;
+                gi += q[0]; gf += q[H]; gg += q[2 * H]; go += q[3 * H];
+            }
+            if (P.tab) {
+                const float *q = P.tab + P.tab_ids[(long long)gm * P.tab_ids_stride] * 4 * H + unit;
+                gi += q[0]; gf += q[H]; gg += q[2 * H]; go += q[3 * H];
+            }
             gi = isc_sigmoid(gi);
             gf = isc_sigmoid(gf);
             gg = tanhf(gg);
@@ -544,7 +558,10 @@ extern "C" int isc_lstm_fwd(const isc_lstm_problem *q, void *stream) {
     if (!q) return ISC_E_NULL;
     int rc = check_segs(q->seg, q->nseg);
     if (rc) return rc;
-    if (!q->b_ih || !q->b_hh || !q->c_prev || !q->h_out || !q->c_out) return ISC_E_NULL;
+    if (!q->c_prev || !q->h_out || !q->c_out) return ISC_E_NULL;
+    if ((!q->b_ih || !q->b_hh) && !q->pre) return ISC_E_NULL;       // biases may only be folded into `pre`
+    if ((q->b_ih == nullptr) != (q->b_hh == nullptr)) return ISC_E_NULL;
+    if (q->tab && !q->tab_ids) return ISC_E_NULL;
     if (q->M <= 0 || q->H <= 0 || (q->H % 32) != 0) return ISC_E_SHAPE;
     if (q->h_keep_mask && !q->hdrop_out) return ISC_E_NULL;
     DevLaunch L = {};
@@ -555,6 +572,7 @@ extern "C" int isc_lstm_fwd(const isc_lstm_problem *q, void *stream) {
     d.bias0 = q->b_ih; d.bias1 = q->b_hh;
     d.c_prev = q->c_prev; d.h_out = q->h_out; d.c_out = q->c_out; d.gates_out = q->gates_out;
     d.hmask = q->h_keep_mask; d.mask_scale = q->mask_scale; d.hdrop = q->hdrop_out;
+    d.pre = q->pre; d.tab = q->tab; d.tab_ids = q->tab_ids; d.tab_ids_stride = q->tab_ids_stride;
     const long long tiles_large = (long long)((q->M + 127) / 128) * (q->H / 32);
     const bool small = use_small_tile(tiles_large, q->M);
     finish_tiling(L, small);

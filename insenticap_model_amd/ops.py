@@ -80,7 +80,7 @@ def _fill_segs(dst, segs):
 
 
 def linear_problem(segs, out, bias0=None, bias1=None, bias2=None, relu=False, keep_mask=None, mask_scale=1.0,
-                   out_pre=None):
+                   out_pre=None, accumulate=False):
     """out[M,N] = act(sum_s A_s W_s^T + bias0 + bias1) [* keep_mask * mask_scale]."""
     p = LinearProblem()
     _fill_segs(p.seg, segs)
@@ -95,6 +95,7 @@ def linear_problem(segs, out, bias0=None, bias1=None, bias2=None, relu=False, ke
     p.ldc = out.stride(0)
     p.C = out.data_ptr()
     p.C_pre = ptr(out_pre)
+    p.accumulate = int(accumulate)
     if out_pre is not None:
         assert out_pre.stride(0) == out.stride(0)
     return p
@@ -112,14 +113,20 @@ def linear_fwd(problems):
 
 
 def lstm_fwd(segs, b_ih, b_hh, c_prev, h_out, c_out, gates_out=None, h_keep_mask=None,
-             mask_scale=1.0, hdrop_out=None):
+             mask_scale=1.0, hdrop_out=None, pre=None, tab=None, tab_ids=None):
     lib = _lib.load()
     p = LstmProblem()
     _fill_segs(p.seg, segs)
     p.nseg = len(segs)
     p.M, p.H = c_prev.shape
     assert c_prev.is_contiguous() and h_out.is_contiguous() and c_out.is_contiguous()
-    p.b_ih, p.b_hh = b_ih.data_ptr(), b_hh.data_ptr()
+    p.b_ih, p.b_hh = ptr(b_ih), ptr(b_hh)
+    if pre is not None:
+        assert pre.is_contiguous() and pre.shape == (p.M, 4 * p.H)
+        p.pre = pre.data_ptr()
+    if tab is not None:
+        assert tab.is_contiguous() and tab.shape[1] == 4 * p.H and tab_ids.dtype == torch.int64
+        p.tab, p.tab_ids, p.tab_ids_stride = tab.data_ptr(), tab_ids.data_ptr(), tab_ids.stride(0)
     p.c_prev, p.h_out, p.c_out = c_prev.data_ptr(), h_out.data_ptr(), c_out.data_ptr()
     p.gates_out = ptr(gates_out)
     p.h_keep_mask = ptr(h_keep_mask)
@@ -375,7 +382,12 @@ def xe_loss_bwd(target, lengths_i32, gout, sum_count, dlogp):
                               sum_count.data_ptr(), dlogp.data_ptr(), stream()), 'isc_xe_loss_bwd')
 
 
+WEIGHT_EPOCH = 0   # bumped by every in-place parameter update done behind torch's back (version counters)
+
+
 def clamp_adam(params, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, clip, step):
+    global WEIGHT_EPOCH
+    WEIGHT_EPOCH += 1
     lib = _lib.load()
     n = len(params)
     mk = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])

@@ -128,7 +128,7 @@ def test_tiny_train_iteration_full_grads_and_adam(golden):
             continue
         big = np.abs(g['it/grad/' + k]) > 1e-4      # Adam's first step amplifies noise on ~eps-sized grads
         np.testing.assert_allclose(got[big], ref[big], atol=3e-6, err_msg=k)
-        np.testing.assert_allclose(got[~big], ref[~big], atol=4.1e-4, err_msg=k)
+        np.testing.assert_allclose(got[~big], ref[~big], atol=8.2e-4, err_msg=k)   # sign flips: up to 2*lr
 
 
 def test_tiny_dropout_train_mode_grads(golden):

@@ -66,7 +66,7 @@ def test_tiny_iteration_full_tensors(golden):
             continue
         big = gref > 1e-4
         np.testing.assert_allclose(got[big], ref[big], atol=2e-6, err_msg=k)
-        np.testing.assert_allclose(got[~big], ref[~big], atol=4.1e-4, err_msg=k)
+        np.testing.assert_allclose(got[~big], ref[~big], atol=8.2e-4, err_msg=k)   # sign flips: up to 2*lr
 
 
 @pytest.mark.parametrize('prefix', ['rl/', 'early/'])
