@@ -41,7 +41,7 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--batch', type=int, default=2048, help='captions per GPU per step')
+    ap.add_argument('--batch', type=int, default=4096, help='captions per GPU per step')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip the XE-train / beam side measurements')
     ap.add_argument('--cpu-seconds', type=float, default=15.0)

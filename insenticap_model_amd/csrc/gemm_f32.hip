@@ -18,6 +18,8 @@
 // to 36 floats so that the ds_read_b128 fragment reads are bank-conflict free), one
 // barrier per chunk.  The finished tile is staged through LDS once so that every epilogue
 // sees (row, col) coordinates and writes full, coalesced rows.
+#include <type_traits>
+
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -145,45 +147,64 @@ __global__ __launch_bounds__(256) void gemm_kernel(const DevLaunch L) {
     int nchunks = 0;
     for (int s = 0; s < P.nseg; ++s) nchunks += (P.seg[s].K + BK - 1) / BK;
 
+    // Per-thread source pointers of the current K-segment, advanced by one chunk per load (keeps the
+    // 64-bit address arithmetic out of the loop); `fast` tiles (interior, K % 32 == 0) load unpredicated.
     float4 ra[A_LD], rb[B_LD];
-    int cs = 0, ck = 0;  // segment / k-offset of the chunk being loaded
-    auto gload = [&]() {
-        const DevSeg sg = P.seg[cs];
+    const float *pa[A_LD], *pb[B_LD];
+    long long stepA = BK, stepB = BK;
+    int cs = 0, ck = 0, segK = 0;  // segment / k-offset of the chunk being loaded
+    auto set_seg = [&](int si) __attribute__((always_inline)) {
+        const DevSeg sg = P.seg[si];
+        segK = sg.K;
         if constexpr (AKM) {
-#pragma unroll
-            for (int i = 0; i < A_LD; ++i) {
-                const int k = ck + akr + (1024 / BM) * i;
-                ra[i] = (a_col_ok && k < sg.K)
-                            ? *reinterpret_cast<const float4 *>(sg.A + (long long)k * sg.lda + row0 + akc)
-                            : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-        } else {
-            const float *Ab = sg.A + (long long)(row0 + lr) * sg.lda + ck + lc;
-            const bool kok = (ck + lc) < sg.K;
+            stepA = (long long)BK * sg.lda;
 #pragma unroll
             for (int i = 0; i < A_LD; ++i)
-                ra[i] = (aok[i] && kok) ? *reinterpret_cast<const float4 *>(Ab + (long long)(32 * i) * sg.lda)
-                                        : make_float4(0.f, 0.f, 0.f, 0.f);
+                pa[i] = sg.A + (long long)(akr + (1024 / BM) * i) * sg.lda + row0 + akc;
+        } else {
+#pragma unroll
+            for (int i = 0; i < A_LD; ++i)
+                pa[i] = sg.A + (long long)(row0 + lr + 32 * i) * sg.lda + lc;
         }
         if constexpr (BKM) {
-#pragma unroll
-            for (int i = 0; i < B_LD; ++i) {
-                const int k = ck + bkr + (1024 / BN) * i;
-                rb[i] = (b_col_ok && k < sg.K)
-                            ? *reinterpret_cast<const float4 *>(sg.W + (long long)k * sg.ldw + col0 + bkc)
-                            : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-        } else {
-            const bool kok = (ck + lc) < sg.K;
+            stepB = (long long)BK * sg.ldw;
 #pragma unroll
             for (int i = 0; i < B_LD; ++i)
-                rb[i] = (wok[i] && kok) ? *reinterpret_cast<const float4 *>(sg.W + wrow[i] * sg.ldw + ck + lc)
-                                        : make_float4(0.f, 0.f, 0.f, 0.f);
+                pb[i] = sg.W + (long long)(bkr + (1024 / BN) * i) * sg.ldw + col0 + bkc;
+        } else {
+#pragma unroll
+            for (int i = 0; i < B_LD; ++i) pb[i] = sg.W + wrow[i] * sg.ldw + lc;
+        }
+    };
+    auto gload = [&](auto fastc) __attribute__((always_inline)) {
+        constexpr bool FAST = decltype(fastc)::value;
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i) {
+            bool ok = true;
+            if constexpr (!FAST) {
+                if constexpr (AKM) ok = a_col_ok && (ck + akr + (1024 / BM) * i) < segK;
+                else ok = aok[i] && (ck + lc) < segK;
+            }
+            ra[i] = ok ? *reinterpret_cast<const float4 *>(pa[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
+            pa[i] += stepA;
+        }
+#pragma unroll
+        for (int i = 0; i < B_LD; ++i) {
+            bool ok = true;
+            if constexpr (!FAST) {
+                if constexpr (BKM) ok = b_col_ok && (ck + bkr + (1024 / BN) * i) < segK;
+                else ok = wok[i] && (ck + lc) < segK;
+            }
+            rb[i] = ok ? *reinterpret_cast<const float4 *>(pb[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
+            pb[i] += stepB;
         }
         ck += BK;
-        if (ck >= sg.K) { ck = 0; ++cs; }
+        if (ck >= segK) {
+            ck = 0;
+            if (++cs < P.nseg) set_seg(cs);
+        }
     };
-    auto sstore = [&](int buf) {
+    auto sstore = [&](int buf) __attribute__((always_inline)) {
         float *a = As + buf * TA::SIZE;
         if constexpr (AKM) {
 #pragma unroll
@@ -206,50 +227,56 @@ __global__ __launch_bounds__(256) void gemm_kernel(const DevLaunch L) {
         }
     };
 
-    gload();
-    sstore(0);
-    __syncthreads();
-
     // MFMA 32x32x2 operand maps: lane l supplies A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31].
     // Per 8-deep k-block a lane holds 4 consecutive k (k0 + 4*(l>>5) + t) of its row for both
     // operands; MFMA t consumes element t, so every k is covered exactly once.
     const int frow = lane & 31, fk = (lane >> 5) * 4;
-    for (int c = 0; c < nchunks; ++c) {
-        const int buf = c & 1;
-        if (c + 1 < nchunks) gload();
-        const float *at = As + buf * TA::SIZE;
-        const float *bt = Bs + buf * TB::SIZE;
+    auto k_loop = [&](auto fastc) __attribute__((always_inline)) {
+        set_seg(0);
+        gload(fastc);
+        sstore(0);
+        __syncthreads();
+        for (int c = 0; c < nchunks; ++c) {
+            const int buf = c & 1;
+            if (c + 1 < nchunks) gload(fastc);
+            const float *at = As + buf * TA::SIZE;
+            const float *bt = Bs + buf * TB::SIZE;
 #pragma unroll
-        for (int kb = 0; kb < BK / 8; ++kb) {
-            float a[4], b[TN][4];
-            if constexpr (AKM) {
+            for (int kb = 0; kb < BK / 8; ++kb) {
+                float a[4], b[TN][4];
+                if constexpr (AKM) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) a[e] = at[(kb * 8 + fk + e) * (BM + 4) + wm * 32 + frow];
-            } else {
-                const float4 v = *reinterpret_cast<const float4 *>(at + (wm * 32 + frow) * LDT + kb * 8 + fk);
-                a[0] = v.x; a[1] = v.y; a[2] = v.z; a[3] = v.w;
-            }
+                    for (int e = 0; e < 4; ++e) a[e] = at[(kb * 8 + fk + e) * (BM + 4) + wm * 32 + frow];
+                } else {
+                    const float4 v = *reinterpret_cast<const float4 *>(at + (wm * 32 + frow) * LDT + kb * 8 + fk);
+                    a[0] = v.x; a[1] = v.y; a[2] = v.z; a[3] = v.w;
+                }
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                if constexpr (BKM) {
+                for (int j = 0; j < TN; ++j) {
+                    if constexpr (BKM) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            b[j][e] = bt[(kb * 8 + fk + e) * (BN + 4) + (wn * TN + j) * 32 + frow];
+                    } else {
+                        const float4 v = *reinterpret_cast<const float4 *>(
+                            bt + ((wn * TN + j) * 32 + frow) * LDT + kb * 8 + fk);
+                        b[j][0] = v.x; b[j][1] = v.y; b[j][2] = v.z; b[j][3] = v.w;
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        b[j][e] = bt[(kb * 8 + fk + e) * (BN + 4) + (wn * TN + j) * 32 + frow];
-                } else {
-                    const float4 v = *reinterpret_cast<const float4 *>(
-                        bt + ((wn * TN + j) * 32 + frow) * LDT + kb * 8 + fk);
-                    b[j][0] = v.x; b[j][1] = v.y; b[j][2] = v.z; b[j][3] = v.w;
-                }
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[j][e], acc[j], 0, 0, 0);
             }
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[j][e], acc[j], 0, 0, 0);
+            if (c + 1 < nchunks) sstore(buf ^ 1);
+            __syncthreads();
         }
-        if (c + 1 < nchunks) sstore(buf ^ 1);
-        __syncthreads();
-    }
+    };
+    bool fast = (row0 + BM <= M) && (EPI == EPI_LSTM || col0 + BN <= N);
+    for (int si = 0; si < P.nseg; ++si) fast = fast && (P.seg[si].K % BK) == 0;
+    if (fast) k_loop(std::true_type{});
+    else k_loop(std::false_type{});
 
     if constexpr (EPI == EPI_VOCAB) {
         // ---- vocabulary epilogue straight from the accumulator registers (no LDS round trip):
@@ -465,19 +492,39 @@ static int launch_cfg(const DevLaunch &L, hipStream_t st) {
     return ISC_OK;
 }
 
+// Tile shapes: 0 = L 128x128 (4 waves stacked in M), 1 = M 64x128 (2x2 waves), 2 = S 32x128 (4 waves in N)
+static const int kTileBM[3] = {128, 64, 32};
+
 template <int EPI, bool AKM, bool BKM>
-static int launch_any(const DevLaunch &L, bool small, hipStream_t st) {
-    return small ? launch_cfg<1, 4, 1, EPI, AKM, BKM>(L, st) : launch_cfg<4, 1, 4, EPI, AKM, BKM>(L, st);
+static int launch_any(const DevLaunch &L, int tile, hipStream_t st) {
+    if (tile == 0) return launch_cfg<4, 1, 4, EPI, AKM, BKM>(L, st);
+    if (tile == 1) return launch_cfg<2, 2, 2, EPI, AKM, BKM>(L, st);
+    return launch_cfg<1, 4, 1, EPI, AKM, BKM>(L, st);
 }
 
-// Tile shape choice: the 128x128 tile needs >= ~1 tile per CU to pay; below that the
-// 32-row tile quadruples the number of workgroups.
-static bool use_small_tile(long long tiles_large, int max_m) {
-    return max_m <= 64 || tiles_large < 160;
+// Tile shape choice by a small cost model.  A launch runs in ceil(blocks / (256 CUs * resident blocks per
+// CU)) rounds; a round costs BM / efficiency, where the efficiency reflects MFMAs per wave between
+// barriers (64 / 32 / 16 per 32-deep chunk for L / M / S).  This picks e.g. 64x128 tiles for a
+// [2048 x 2048] LSTM problem (512 blocks = 2 per CU) instead of 256 tiles of 128x128 (1 per CU).
+static int pick_tile(const DevLaunch &L) {
+    static const double eff[3] = {1.0, 0.9, 0.62};
+    static const int resident[3] = {2, 2, 3};
+    int best = 0;
+    double best_cost = 1e30;
+    for (int t = 0; t < 3; ++t) {
+        long long blocks = 0;
+        for (int i = 0; i < L.nprob; ++i)
+            blocks += (long long)((L.p[i].M + kTileBM[t] - 1) / kTileBM[t]) * ((L.p[i].N + 127) / 128);
+        const long long slots = 256LL * resident[t];
+        const double rounds = (double)((blocks + slots - 1) / slots);
+        const double cost = rounds * kTileBM[t] / eff[t];
+        if (cost < best_cost * 0.97) { best_cost = cost; best = t; }   // prefer the larger tile on near-ties
+    }
+    return best;
 }
 
-static void finish_tiling(DevLaunch &L, bool small) {
-    const int BM = small ? 32 : 128, BN = 128;
+static void finish_tiling(DevLaunch &L, int tile) {
+    const int BM = kTileBM[tile], BN = 128;
     int start = 0;
     for (int i = 0; i < L.nprob; ++i) {
         DevProb &p = L.p[i];
@@ -497,8 +544,6 @@ extern "C" int isc_linear_fwd(const isc_linear_problem *pr, int n_prob, void *st
     if (n_prob < 1 || n_prob > 3) return ISC_E_SHAPE;
     DevLaunch L = {};
     L.nprob = n_prob;
-    long long tiles_large = 0;
-    int max_m = 0;
     for (int i = 0; i < n_prob; ++i) {
         const isc_linear_problem &q = pr[i];
         int rc = check_segs(q.seg, q.nseg);
@@ -512,12 +557,10 @@ extern "C" int isc_linear_fwd(const isc_linear_problem *pr, int n_prob, void *st
         d.bias0 = q.bias0; d.bias1 = q.bias1; d.bias2 = q.bias2;
         d.mask = q.keep_mask; d.mask_scale = q.mask_scale;
         d.ldc = q.ldc; d.C = q.C; d.C_pre = q.C_pre; d.accumulate = q.accumulate;
-        tiles_large += (long long)((q.M + 127) / 128) * ((q.N + 127) / 128);
-        if (q.M > max_m) max_m = q.M;
     }
-    const bool small = use_small_tile(tiles_large, max_m);
-    finish_tiling(L, small);
-    return launch_any<EPI_LINEAR, false, false>(L, small, (hipStream_t)stream);
+    const int tile = pick_tile(L);
+    finish_tiling(L, tile);
+    return launch_any<EPI_LINEAR, false, false>(L, tile, (hipStream_t)stream);
 }
 
 // Backward-pass contractions on the same kernel (include/insenticap_hip.h: isc_gemm_bwd).
@@ -526,8 +569,6 @@ extern "C" int isc_gemm_bwd(const isc_linear_problem *pr, int n_prob, int layout
     if (n_prob < 1 || n_prob > 3 || (layout != ISC_LAYOUT_NN && layout != ISC_LAYOUT_TN)) return ISC_E_SHAPE;
     DevLaunch L = {};
     L.nprob = n_prob;
-    long long tiles_large = 0;
-    int max_m = 0;
     for (int i = 0; i < n_prob; ++i) {
         const isc_linear_problem &q = pr[i];
         if (q.nseg < 1 || q.nseg > ISC_MAX_SEG || !q.C) return q.C ? ISC_E_SHAPE : ISC_E_NULL;
@@ -545,13 +586,11 @@ extern "C" int isc_gemm_bwd(const isc_linear_problem *pr, int n_prob, int layout
         d.M = q.M; d.N = q.N; d.relu = 0;
         d.bias0 = q.bias0; d.bias1 = q.bias1; d.bias2 = q.bias2;
         d.ldc = q.ldc; d.C = q.C; d.accumulate = q.accumulate;
-        tiles_large += (long long)((q.M + 127) / 128) * ((q.N + 127) / 128);
-        if (q.M > max_m) max_m = q.M;
     }
-    const bool small = use_small_tile(tiles_large, max_m);
-    finish_tiling(L, small);
-    return layout == ISC_LAYOUT_NN ? launch_any<EPI_LINEAR, false, true>(L, small, (hipStream_t)stream)
-                                   : launch_any<EPI_LINEAR, true, true>(L, small, (hipStream_t)stream);
+    const int tile = pick_tile(L);
+    finish_tiling(L, tile);
+    return layout == ISC_LAYOUT_NN ? launch_any<EPI_LINEAR, false, true>(L, tile, (hipStream_t)stream)
+                                   : launch_any<EPI_LINEAR, true, true>(L, tile, (hipStream_t)stream);
 }
 
 extern "C" int isc_lstm_fwd(const isc_lstm_problem *q, void *stream) {
@@ -573,10 +612,9 @@ extern "C" int isc_lstm_fwd(const isc_lstm_problem *q, void *stream) {
     d.c_prev = q->c_prev; d.h_out = q->h_out; d.c_out = q->c_out; d.gates_out = q->gates_out;
     d.hmask = q->h_keep_mask; d.mask_scale = q->mask_scale; d.hdrop = q->hdrop_out;
     d.pre = q->pre; d.tab = q->tab; d.tab_ids = q->tab_ids; d.tab_ids_stride = q->tab_ids_stride;
-    const long long tiles_large = (long long)((q->M + 127) / 128) * (q->H / 32);
-    const bool small = use_small_tile(tiles_large, q->M);
-    finish_tiling(L, small);
-    return launch_any<EPI_LSTM, false, false>(L, small, (hipStream_t)stream);
+    const int tile = pick_tile(L);
+    finish_tiling(L, tile);
+    return launch_any<EPI_LSTM, false, false>(L, tile, (hipStream_t)stream);
 }
 
 extern "C" int isc_vocab_fwd(const float *h, int ldh, const float *W, int ldw, const float *bias,
@@ -595,8 +633,7 @@ extern "C" int isc_vocab_fwd(const float *h, int ldh, const float *W, int ldw, c
     d.C = logits; d.ld_logits = ld_logits;
     d.pmax = part_max; d.psum = part_sum; d.pidx = part_idx;
     d.ntile_total = (V + 127) / 128;
-    const long long tiles_large = (long long)((M + 127) / 128) * d.ntile_total;
-    const bool small = use_small_tile(tiles_large, M);
-    finish_tiling(L, small);
-    return launch_any<EPI_VOCAB, false, false>(L, small, (hipStream_t)stream);
+    const int tile = pick_tile(L);
+    finish_tiling(L, tile);
+    return launch_any<EPI_VOCAB, false, false>(L, tile, (hipStream_t)stream);
 }

@@ -125,13 +125,11 @@ struct DevRollout {
     float *xt_next;
 };
 
-__global__ __launch_bounds__(256) void rollout_finalize_kernel(const DevRollout R) {
-    const int lane = threadIdx.x & 63;
-    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (b >= R.B) return;
-    // the reference `break`s once no row is unfinished (captioner.py:343-344): later steps
-    // leave seq / seq_logprobs / seq_masks at their zero initialisation
-    if (R.alive[R.t] == 0) return;
+#define ISC_FIN_ROWS_PER_WAVE 4
+// One wavefront per row, 4 rows per wave, 16 rows per workgroup; the count of still-unfinished rows
+// is reduced inside the workgroup so that the `alive` counter sees one atomic per 16 rows (4096
+// same-address atomics used to dominate this kernel).
+__device__ __forceinline__ int rollout_finalize_row(const DevRollout &R, int b, int lane) {
     float gmax, S;
     int gidx;
     fold_row_stats(R.part_max + (long long)b * R.n_tile, R.part_sum + (long long)b * R.n_tile,
@@ -178,7 +176,6 @@ __global__ __launch_bounds__(256) void rollout_finalize_kernel(const DevRollout 
         R.seq_logprobs[o] = lp;
         if (R.raw_tokens) R.raw_tokens[o] = it;
         R.unfinished[b] = u2;
-        if (u2) atomicAdd(&R.alive[R.t + 1], 1);
     }
     if (R.xt_next) {
         const float4 *src = reinterpret_cast<const float4 *>(R.emb + itm * R.W);
@@ -190,6 +187,26 @@ __global__ __launch_bounds__(256) void rollout_finalize_kernel(const DevRollout 
             if (ad) { const float4 a = ad[i]; v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w; }
             dst[i] = v;
         }
+    }
+    return u2;
+}
+
+__global__ __launch_bounds__(256) void rollout_finalize_kernel(const DevRollout R) {
+    __shared__ int cnt[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // the reference `break`s once no row is unfinished (captioner.py:343-344): later steps
+    // leave seq / seq_logprobs / seq_masks at their zero initialisation
+    if (R.alive[R.t] == 0) return;          // block-uniform
+    int alive = 0;
+    for (int i = 0; i < ISC_FIN_ROWS_PER_WAVE; ++i) {
+        const int b = (blockIdx.x * 4 + wave) * ISC_FIN_ROWS_PER_WAVE + i;
+        if (b < R.B) alive += rollout_finalize_row(R, b, lane);
+    }
+    if (lane == 0) cnt[wave] = alive;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int tot = cnt[0] + cnt[1] + cnt[2] + cnt[3];
+        if (tot) atomicAdd(&R.alive[R.t + 1], tot);
     }
 }
 
@@ -207,7 +224,8 @@ extern "C" int isc_rollout_finalize(const isc_rollout_step *s, void *stream) {
     R.eos_id = s->eos_id; R.seq = s->seq; R.seq_logprobs = s->seq_logprobs; R.seq_masks = s->seq_masks;
     R.unfinished = s->unfinished; R.alive = s->alive; R.raw_tokens = s->raw_tokens;
     R.emb = s->emb; R.xt_add = s->xt_add; R.xt_next = s->xt_next;
-    hipLaunchKernelGGL(rollout_finalize_kernel, dim3((s->B + 3) / 4), dim3(256), 0, (hipStream_t)stream, R);
+    hipLaunchKernelGGL(rollout_finalize_kernel, dim3((s->B + 4 * ISC_FIN_ROWS_PER_WAVE - 1) / (4 * ISC_FIN_ROWS_PER_WAVE)),
+                       dim3(256), 0, (hipStream_t)stream, R);
     ISC_LAUNCH_CHECK();
     return ISC_OK;
 }
