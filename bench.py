@@ -149,6 +149,27 @@ def bench_beam(cap, inputs, n_img=64, beam=5):
                 batched_images=n_img, batched_images_per_s=round(n_img / el, 1))
 
 
+PMC_SUMMARY = os.path.join(ROOT, 'profiles', 'r01_c_pmc_summary_B4096.json')
+KERNEL_SYMBOL = {'vocab[': 'void gemm_kernel<4, 1, 4, 2, false, false>', 'lstm[': 'void gemm_kernel<4, 1, 4, 1, false, false>',
+                 'attn_scan[': 'void attn_scan_kernel<2>', 'gate_mix[': 'gate_mix_kernel',
+                 'rollout_finalize[': 'rollout_finalize_kernel'}
+
+
+def pmc_traffic(name, batch):
+    """HBM-side bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 gfx950
+    correction + WRITE_SIZE); only valid for the batch size the counters were collected at."""
+    try:
+        d = json.load(open(PMC_SUMMARY))
+    except (OSError, ValueError):
+        return None
+    if d.get('batch_per_gpu') != batch:
+        return None
+    for prefix, sym in KERNEL_SYMBOL.items():
+        if name.startswith(prefix) and sym in d['kernels']:
+            return d['kernels'][sym]['traffic_bytes']
+    return None
+
+
 def roofline_entry(name, rec):
     ms = rec['avg_ms']
     if rec['flops'] > 0:
@@ -225,6 +246,8 @@ def main():
     entries = []
     for name, rec in summ.items():
         e = roofline_entry(name, rec)
+        e['traffic'] = pmc_traffic(name, B)
+        e['algorithmic'] = rec['flops'] if rec['flops'] > 0 else rec['bytes']
         e['phase'] = rec['phase']
         e['per_rollout_ms'] = round(rec['avg_ms'] * (1 if rec['phase'] == 'prologue' else T), 3)
         entries.append(e)

@@ -55,7 +55,7 @@ struct DevProb {
     float *pmax, *psum;
     int *pidx;
     long long ld_logits;
-    int tiles_m, tiles_n, tile_start, ntile_total;
+    int tiles_m, tiles_n, tile_start, ntile_total, grp_n;
 };
 
 struct DevLaunch {
@@ -107,8 +107,20 @@ __global__ __launch_bounds__(256) void gemm_kernel(const DevLaunch L) {
     const DevProb &P = L.p[pi];
     const int t = logical - P.tile_start;
     int tm, tn;
-    if (P.m_fastest) { tm = t % P.tiles_m; tn = t / P.tiles_m; }
-    else             { tm = t / P.tiles_n; tn = t % P.tiles_n; }
+    if (P.m_fastest) {
+        // weights are the larger operand: split the N tiles into 8 groups (one per XCD run) so that a
+        // group's weight slice stays resident in that XCD's 4 MB L2 while the activations stream
+        // through once: inside a group tm is the outer index and tn the inner one.
+        const int per_grp = P.grp_n * P.tiles_m;
+        const int g = t / per_grp, r = t - g * per_grp;
+        const int rest = P.tiles_n - g * P.grp_n;
+        const int gn = rest < P.grp_n ? rest : P.grp_n;
+        tm = r / gn;
+        tn = g * P.grp_n + (r - tm * gn);
+    } else {
+        tm = t / P.tiles_n;
+        tn = t % P.tiles_n;
+    }
     const int M = P.M, N = P.N;
     const int row0 = tm * BM, col0 = tn * BN;
 
@@ -534,6 +546,7 @@ static void finish_tiling(DevLaunch &L, int tile) {
         long long wbytes = 0, abytes = 0;
         for (int s = 0; s < p.nseg; ++s) { wbytes += (long long)p.N * p.seg[s].K; abytes += (long long)p.M * p.seg[s].K; }
         p.m_fastest = wbytes > abytes;  // partition the larger operand across XCDs
+        p.grp_n = (p.tiles_n + 7) / 8;
         start += p.tiles_m * p.tiles_n;
     }
     L.total_tiles = start;
