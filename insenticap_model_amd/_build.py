@@ -48,7 +48,24 @@ def build(force=False, verbose=False):
         if verbose:
             print(' '.join(cmd))
         subprocess.check_call(cmd)
+    build_cider(force, verbose)
     return LIB_PATH
+
+
+CIDER_LIB_PATH = os.path.join(LIB_DIR, 'libinsenticap_cider.so')
+
+
+def build_cider(force=False, verbose=False):
+    """Host-side CIDEr-D reward library (plain C++, g++)."""
+    os.makedirs(LIB_DIR, exist_ok=True)
+    src = os.path.join(CSRC, 'cider.cpp')
+    hdr = os.path.join(os.path.dirname(HERE), 'include', 'insenticap_cider.h')
+    if force or _stale(CIDER_LIB_PATH, [src, hdr]):
+        cmd = ['g++', '-O2', '-std=c++17', '-fPIC', '-shared', '-pthread', '-Wall', src, '-o', CIDER_LIB_PATH]
+        if verbose:
+            print(' '.join(cmd))
+        subprocess.check_call(cmd)
+    return CIDER_LIB_PATH
 
 
 def resource_report():

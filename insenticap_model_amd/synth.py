@@ -159,3 +159,38 @@ def make_inputs(batch, vocab_size, settings, regions=36, n_cpt=5, n_senti_words=
     d['captions'] = caps
     d['lengths'] = [int(x) for x in lengths]
     return d
+
+
+def make_cider_data(n_images, vocab_size, batch, seq_len=20, n_refs=5, seed=7):
+    """Synthetic RL-reward inputs: per image `n_refs` ground-truth captions
+    [<SOS>, 8..18 Zipf-distributed ids, <EOS>]; a batch of sampled / greedy roll-out rows built by
+    perturbing references (so that n-gram overlap - and the reward - is non-trivial), <EOS> at a
+    random position and <PAD> after it.  Returns (split_captions, fns, ground_truth, sample, greedy)."""
+    rng = np.random.default_rng(seed)
+    ranks = np.arange(4, vocab_size)
+    prob = 1.0 / (ranks - 3.0)
+    prob /= prob.sum()
+    captions = {}
+    for i in range(n_images):
+        caps = []
+        for _ in range(n_refs):
+            L = int(rng.integers(8, 19))
+            caps.append([1] + [int(x) for x in rng.choice(ranks, size=L, p=prob)] + [2])
+        captions['img%05d' % i] = caps
+    fns = ['img%05d' % int(i) for i in rng.choice(n_images, size=batch, replace=False)]
+
+    def rollout_rows():
+        rows = np.zeros((batch, seq_len), dtype=np.int64)
+        for b, fn in enumerate(fns):
+            ref = captions[fn][int(rng.integers(0, n_refs))][1:-1]
+            words = [w if rng.random() < 0.7 else int(rng.choice(ranks, p=prob)) for w in ref]
+            words = words[:int(rng.integers(3, seq_len))]
+            if len(words) < seq_len and rng.random() < 0.9:
+                words = words + [2]                 # most rows end with <EOS>, some run to the limit
+            rows[b, :len(words)] = words[:seq_len]
+        return rows
+    sample, greedy = rollout_rows(), rollout_rows()
+    split = {'train': {k: v for k, v in list(captions.items())[:n_images // 2]},
+             'val': {k: v for k, v in list(captions.items())[n_images // 2:]}}
+    ground_truth = {fn: captions[fn] for fn in fns}
+    return split, fns, ground_truth, sample, greedy

@@ -373,7 +373,39 @@ def case_b128():
     print('b128: %d arrays' % len(out))
 
 
-CASES = {'tiny': case_tiny, 'cfg1': case_cfg1, 'b128': case_b128}
+def case_cider():
+    """CIDEr-D self-critical reward (self_critical/utils.py:38-83) on synthetic captions."""
+    from self_critical.utils import get_ciderd_scorer, get_self_critical_reward
+    out = {}
+    for name, (n_img, V, B, Tn, seed) in {'small': (40, 60, 16, 12, 7), 'cfg5': (600, 10000, 256, 20, 8)}.items():
+        split, fns, gt, sample, greedy = synth.make_cider_data(n_img, V, B, seq_len=Tn, seed=seed)
+        scorer = get_ciderd_scorer(split, 1, 2)
+        rew = get_self_critical_reward(torch.from_numpy(sample), torch.from_numpy(greedy), fns, gt, 1, 2, scorer)
+        assert rew.dtype == np.float64 and rew.shape == (B, Tn)
+        out[name + '/reward'] = rew[:, 0].copy()
+        # raw scores of the 2B hypotheses, through the scorer's own entry point
+        res = [{'image_id': fn, 'caption': [' '.join(str(w) for w in _words(row))]}
+               for rows in (sample, greedy) for fn, row in zip(fns, rows)]
+        gts = {fn: [' '.join(str(w) for w in _words(c)) for c in gt[fn]] for fn in fns}
+        _, scores = scorer.compute_score(gts, res)
+        out[name + '/scores'] = np.asarray(scores, dtype=np.float64)
+    np.savez_compressed(os.path.join(HERE, 'cider.npz'), **out)
+    print('cider: %d arrays' % len(out))
+
+
+def _words(arr, sos=1, eos=2):
+    arr = [int(x) for x in arr]
+    if arr[0] == sos:
+        arr = arr[1:]
+    o = []
+    for w in arr:
+        if w == eos:
+            break
+        o.append(w)
+    return o + [eos]
+
+
+CASES = {'tiny': case_tiny, 'cfg1': case_cfg1, 'b128': case_b128, 'cider': case_cider}
 
 if __name__ == '__main__':
     which = sys.argv[1:] or list(CASES)
