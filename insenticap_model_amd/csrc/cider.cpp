@@ -6,6 +6,7 @@
 // reference order, then mean over n, / #refs, * 10.
 #include <cmath>
 #include <cstdint>
+#include <algorithm>
 #include <cstring>
 #include <thread>
 #include <unordered_map>
@@ -36,10 +37,38 @@ struct NGramHash {
     }
 };
 
+// Small open-addressing index over the n-grams of ONE caption (<= a few hundred entries); buffers
+// are reused across captions so the scoring loop performs no heap allocation.
+struct LocalIndex {
+    std::vector<int> slot;   // -1 = empty, else index into keys
+    size_t mask = 0;
+    void reset(size_t n_items) {
+        size_t cap = 64;
+        while (cap < 4 * n_items) cap <<= 1;
+        if (slot.size() != cap) slot.assign(cap, -1);
+        else std::fill(slot.begin(), slot.end(), -1);
+        mask = cap - 1;
+    }
+    // returns the position of g in keys, or -1 (and, if `insert_as` >= 0, records it)
+    int find(const std::vector<NGram> &keys, const NGram &g, int insert_as) {
+        size_t h = NGramHash()(g) & mask;
+        for (;;) {
+            const int s = slot[h];
+            if (s < 0) {
+                if (insert_as >= 0) slot[h] = insert_as;
+                return -1;
+            }
+            if (keys[s] == g) return s;
+            h = (h + 1) & mask;
+        }
+    }
+};
+
 // counts in first-occurrence order (precook, ciderD_scorer.py:13-28)
 struct Cooked {
     std::vector<NGram> keys;
     std::vector<double> tf;
+    LocalIndex index;
 };
 
 // _array_to_str (self_critical/utils.py:11-21): drop a leading <SOS>, stop at the first <EOS>, append <EOS>
@@ -57,30 +86,33 @@ static void normalise(const int64_t *arr, int64_t len, int64_t sos, int64_t eos,
 static void precook(const std::vector<int64_t> &words, int n, Cooked &c) {
     c.keys.clear();
     c.tf.clear();
-    std::unordered_map<NGram, int, NGramHash> index;
     const int64_t L = (int64_t)words.size();
+    c.index.reset((size_t)(n * L));
     for (int k = 1; k <= n; ++k)
         for (int64_t i = 0; i + k <= L; ++i) {
             NGram g;
             g.n = k;
             for (int j = 0; j < 4; ++j) g.w[j] = j < k ? words[i + j] : 0;
-            auto it = index.find(g);
-            if (it == index.end()) {
-                index.emplace(g, (int)c.keys.size());
+            const int at = c.index.find(c.keys, g, (int)c.keys.size());
+            if (at < 0) {
                 c.keys.push_back(g);
                 c.tf.push_back(1.0);
             } else {
-                c.tf[it->second] += 1.0;
+                c.tf[at] += 1.0;
             }
         }
 }
 
-struct Vec {  // counts2vec result
-    std::vector<NGram> keys;
+struct Vec {  // counts2vec result; keys / index live in the Cooked it was built from
     std::vector<double> val;
-    std::unordered_map<NGram, double, NGramHash> map;  // for reference lookups
     double norm[4];
     double length;
+};
+
+struct Scratch {  // per-thread buffers
+    std::vector<int64_t> words;
+    Cooked hyp, ref;
+    Vec vh, vr;
 };
 
 }  // namespace
@@ -92,10 +124,8 @@ struct isc_cider {
     int n;
     double sigma;
 
-    void counts2vec(const Cooked &c, Vec &v, bool want_map) const {
-        v.keys = c.keys;
+    void counts2vec(const Cooked &c, Vec &v) const {
         v.val.resize(c.keys.size());
-        v.map.clear();
         for (int i = 0; i < 4; ++i) v.norm[i] = 0.0;
         v.length = 0.0;
         for (size_t i = 0; i < c.keys.size(); ++i) {
@@ -105,37 +135,33 @@ struct isc_cider {
             const int o = g.n - 1;
             const double x = c.tf[i] * (ref_len - d);
             v.val[i] = x;
-            if (want_map) v.map.emplace(g, x);
             v.norm[o] += std::pow(x, 2);
             if (o == 1) v.length += c.tf[i];  // "length" counts bigrams (ciderD_scorer.py:142-143)
         }
         for (int i = 0; i < 4; ++i) v.norm[i] = std::sqrt(v.norm[i]);
     }
 
-    double score_one(const int64_t *hyp, int64_t T, const int64_t *rtok, const int64_t *rcap, int64_t c0,
-                     int64_t c1) const {
-        std::vector<int64_t> words;
-        Cooked ck;
-        Vec vh, vr;
-        normalise(hyp, T, sos, eos, words);
-        precook(words, n, ck);
-        counts2vec(ck, vh, false);
+    double score_one(Scratch &S, const int64_t *hyp, int64_t T, const int64_t *rtok, const int64_t *rcap,
+                     int64_t c0, int64_t c1) const {
+        normalise(hyp, T, sos, eos, S.words);
+        precook(S.words, n, S.hyp);
+        counts2vec(S.hyp, S.vh);
         double score[4] = {0, 0, 0, 0};
         for (int64_t c = c0; c < c1; ++c) {
-            normalise(rtok + rcap[c], rcap[c + 1] - rcap[c], sos, eos, words);
-            precook(words, n, ck);
-            counts2vec(ck, vr, true);
-            const double delta = vh.length - vr.length;
+            normalise(rtok + rcap[c], rcap[c + 1] - rcap[c], sos, eos, S.words);
+            precook(S.words, n, S.ref);
+            counts2vec(S.ref, S.vr);
+            const double delta = S.vh.length - S.vr.length;
             double val[4] = {0, 0, 0, 0};
-            for (size_t i = 0; i < vh.keys.size(); ++i) {
-                const int o = vh.keys[i].n - 1;
-                auto it = vr.map.find(vh.keys[i]);
-                const double r = it == vr.map.end() ? 0.0 : it->second;
-                val[o] += std::fmin(vh.val[i], r) * r;  // clipped (ciderD_scorer.py:164)
+            for (size_t i = 0; i < S.hyp.keys.size(); ++i) {
+                const int o = S.hyp.keys[i].n - 1;
+                const int at = S.ref.index.find(S.ref.keys, S.hyp.keys[i], -1);
+                const double r = at < 0 ? 0.0 : S.vr.val[at];
+                val[o] += std::fmin(S.vh.val[i], r) * r;  // clipped (ciderD_scorer.py:164)
             }
             const double pen = std::pow(M_E, -(delta * delta) / (2 * sigma * sigma));
             for (int o = 0; o < n; ++o) {
-                if (vh.norm[o] != 0 && vr.norm[o] != 0) val[o] /= (vh.norm[o] * vr.norm[o]);
+                if (S.vh.norm[o] != 0 && S.vr.norm[o] != 0) val[o] /= (S.vh.norm[o] * S.vr.norm[o]);
                 val[o] *= pen;
                 score[o] += val[o];
             }
@@ -182,8 +208,9 @@ extern "C" int isc_cider_score(const isc_cider *h, const int64_t *hyp, int64_t n
     if (n_threads < 1) n_threads = 1;
     if ((int64_t)n_threads > n_hyp) n_threads = (int)n_hyp;
     auto work = [&](int tid) {
+        Scratch S;
         for (int64_t i = tid; i < n_hyp; i += n_threads)
-            scores_out[i] = h->score_one(hyp + i * hyp_stride, T, ref_tokens, ref_cap_off, ref_img_off[i],
+            scores_out[i] = h->score_one(S, hyp + i * hyp_stride, T, ref_tokens, ref_cap_off, ref_img_off[i],
                                          ref_img_off[i + 1]);
     };
     if (n_threads == 1) {

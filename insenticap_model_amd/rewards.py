@@ -99,10 +99,30 @@ class CiderD:
     def num_ngrams(self):
         return self._lib.isc_cider_num_ngrams(self._h)
 
-    def score_arrays(self, hyps, ref_caption_lists):
-        """hyps: int64 [N,T] raw roll-out rows; ref_caption_lists[i]: list of id lists. -> float64 [N]."""
+    def flatten_refs(self, ref_caption_lists, keys=None):
+        """Flattened (tokens, cap_off, img_off) of a batch of reference lists; with `keys` (image ids)
+        the per-image conversion is cached across calls (the ground truth of an image never changes)."""
+        if keys is None:
+            return _flatten(ref_caption_lists)
+        toks, lens, counts = [], [], []
+        for k, caps in zip(keys, ref_caption_lists):
+            c = self._gt_cache.get(k)
+            if c is None:
+                c = (np.asarray([int(x) for cap in caps for x in cap], dtype=np.int64),
+                     np.asarray([len(cap) for cap in caps], dtype=np.int64))
+                self._gt_cache[k] = c
+            toks.append(c[0])
+            lens.append(c[1])
+            counts.append(len(c[1]))
+        cap_off = np.concatenate([[0], np.cumsum(np.concatenate(lens))]).astype(np.int64)
+        img_off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+        return np.concatenate(toks), cap_off, img_off
+
+    def score_arrays(self, hyps, ref_caption_lists, flat=None):
+        """hyps: int64 [N,T] raw roll-out rows; ref_caption_lists[i]: list of id lists (or `flat` = a
+        flatten_refs() result). -> float64 [N]."""
         hyps = np.ascontiguousarray(hyps, dtype=np.int64)
-        toks, cap_off, img_off = _flatten(ref_caption_lists)
+        toks, cap_off, img_off = flat if flat is not None else _flatten(ref_caption_lists)
         out = np.empty(hyps.shape[0], dtype=np.float64)
         rc = self._lib.isc_cider_score(self._h, _p(hyps), hyps.shape[0], hyps.shape[1], hyps.shape[1], _p(toks),
                                        _p(cap_off), _p(img_off), out.ctypes.data_as(C.POINTER(C.c_double)),
@@ -130,9 +150,8 @@ def get_self_critical_reward(sample_captions, greedy_captions, fns, ground_truth
     assert sample_captions.shape[0] == greedy_captions.shape[0] == batch_size
     if not isinstance(scorer, CiderD):
         raise Exception('do not support this scorer: %s' % type(scorer))
-    refs = [ground_truth[fn] for fn in fns]
-    scores = scorer.score_arrays(np.concatenate([sample_captions, greedy_captions], axis=0), refs + refs)
-    scores = scores[:batch_size] - scores[batch_size:]
+    flat = scorer.flatten_refs([ground_truth[fn] for fn in fns], keys=list(fns))
+    scores = scorer.score_arrays(sample_captions, None, flat) - scorer.score_arrays(greedy_captions, None, flat)
     return np.repeat(scores[:, np.newaxis], sample_captions.shape[1], 1)
 
 
