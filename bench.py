@@ -124,6 +124,51 @@ def bench_xe_train(cap, dev, rank, world, iters=6, B=128):
                 grad_allreduce_mb=round(arena.nbytes / 1e6, 2) if arena else 0.0)
 
 
+def bench_rl(dev, iters=3, B=512):
+    """BASELINE.json configs[4]: self-critical RL iteration (Detector.forward, training=True): sampled +
+    greedy roll-out per image, CIDEr-D + classifier rewards, XE (ss 0.5) + seq2seq (ss 0.25) passes,
+    backward, clamp, Adam; B=512, T=20, 6x6x2048 grid for the sentiment detector, 5 GT captions/image."""
+    from insenticap_model_amd import Detector, rewards
+    st = dict(synth.DEFAULT_SETTINGS, **synth.HELPER_SETTINGS)
+    det = Detector(synth.make_idx2word(V), T, synth.SENTIMENT_CATEGORIES, {'cap_lr': 4e-5}, st)
+    det.captioner.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_weights(V, st, seed=0).items()})
+    det.to(dev)
+    batches, split = synth.make_rl_batches(1, B, V, st, grid=(6, 6), seq_len=T, seed=90)
+    det.set_ciderd_scorer(split)
+    tt = torch.from_numpy
+    b = batches[0]
+    fact = [(b[0], tt(b[1]).to(dev), tt(b[2]).to(dev), (tt(b[3][0]).to(dev), b[3][1]), tt(b[4]).to(dev),
+             tt(b[5]).to(dev), b[6])]
+    s = synth.make_inputs(80, V, st, regions=R, seq_len=T, seed=91)
+    scs = [((tt(s['captions']).to(dev), s['lengths']), tt(s['cpt_words']).to(dev), tt(s['senti_words']).to(dev),
+            tt(s['senti_labels']).to(dev))]
+    cider_t = [0.0]
+    orig = rewards.get_self_critical_reward
+
+    def timed(*a, **k):
+        t0 = time.perf_counter()
+        r = orig(*a, **k)
+        cider_t[0] += time.perf_counter() - t0
+        return r
+    import insenticap_model_amd.detector as dmod
+    dmod.get_self_critical_reward = timed
+    try:
+        det((fact, scs), 'fact', True)            # warm-up
+        torch.cuda.synchronize()
+        cider_t[0] = 0.0
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            losses = det((fact, scs), 'fact', True)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+    finally:
+        dmod.get_self_critical_reward = orig
+    return dict(iters=iters, batch=B, ms_per_iter=round(el / iters * 1e3, 1),
+                images_per_s=round(B * iters / el, 1),
+                cider_ms_per_iter=round(cider_t[0] / iters * 1e3, 1), cider_threads=det.ciderd_scorer.n_threads,
+                losses={k: round(float(v), 4) for k, v in losses.items()})
+
+
 def bench_beam(cap, inputs, n_img=64, beam=5):
     """BASELINE.json configs[2]: beam 5, sentiment attention on. Reference API (one image per call)
     latency and the batched path's throughput."""
@@ -235,6 +280,10 @@ def main():
                 extra['beam5'] = bench_beam(cap, inputs)
             except Exception as e:  # noqa: BLE001
                 extra['beam5'] = {'error': repr(e)[:200]}
+            try:
+                extra['rl_iteration'] = bench_rl(dev)
+            except Exception as e:  # noqa: BLE001
+                extra['rl_iteration'] = {'error': repr(e)[:300]}
     if rank != 0:
         if world > 1:
             torch.distributed.destroy_process_group()

@@ -1,0 +1,148 @@
+"""`Detector`: the RL-stage trainer wrapper of the reference (/root/reference/models/decoder.py:21-192)
+on the MI355X path - same constructor, setters, `forward(data, data_type, training)` loss dictionary
+and `sample(...)`.
+
+One RL iteration = sampled roll-out (with REINFORCE gradients) + greedy roll-out (baseline) +
+CIDEr-D and classifier rewards + XE pass (ss_prob 0.5) + seq2seq pass (ss_prob 0.25) + backward +
+clamp(0.1) + Adam (decoder.py:65-167).  The decoder work runs on the HIP kernels through
+`Captioner`; CIDEr-D runs in the native host library; the two frozen helper nets are stock
+PyTorch-ROCm modules (helper_nets.py).
+"""
+from collections import defaultdict
+
+import torch
+import torch.nn as nn
+
+from .captioner import Captioner
+from .helper_nets import SentenceSentimentClassifier, SentimentDetector
+from .optim import clip_gradient
+from .rewards import RewardCriterion, get_ciderd_scorer, get_cls_reward, get_self_critical_reward
+
+
+class Detector(nn.Module):
+    MAX_BATCHES_PER_CALL = 500      # decoder.py:65
+
+    def __init__(self, idx2word, max_seq_len, sentiment_categories, lrs, settings):
+        super().__init__()
+        self.idx2word = idx2word
+        self.pad_id = idx2word.index('<PAD>')
+        self.max_seq_len = max_seq_len
+        self.captioner = Captioner(idx2word, sentiment_categories, settings)
+        self.senti_detector = SentimentDetector(sentiment_categories, settings)
+        self.sent_senti_cls = SentenceSentimentClassifier(idx2word, sentiment_categories, settings)
+        self.senti_detector.eval()
+        self.sent_senti_cls.eval()
+        self.cap_optim, self.cap_xe_crit, self.cap_da_crit = self.captioner.get_optim_criterion(lrs['cap_lr'])
+        self.cap_rl_crit = RewardCriterion()
+        self.cls_flag = 0.4
+        self.seq_flag = 1.0
+        self.senti_threshold = 0.7
+
+    def set_ciderd_scorer(self, captions):
+        self.ciderd_scorer = get_ciderd_scorer(captions, self.captioner.sos_id, self.captioner.eos_id)
+
+    def set_sentiment_words(self, sentiment_words):
+        self.sentiment_words = sentiment_words
+
+    def set_lms(self, lms):
+        self.lms = lms
+
+    def forward(self, data, data_type, training):
+        """data = (caption loader[, seq2seq loader]); data_type 'fact' | 'senti'. Returns the dict of
+        loss sums divided by len(data) - the tuple length, as the reference does (decoder.py:178-179)."""
+        if data_type not in ('fact', 'senti'):
+            raise Exception('data_type(%s) is wrong!' % data_type)
+        cap = self.captioner
+        cap.train(training)
+        sums = defaultdict(float)
+        device = next(self.parameters()).device
+        seq2seq_iter = iter(data[1]) if training else None
+        caption_iter = iter(data[0])
+        for _ in range(min(self.MAX_BATCHES_PER_CALL, len(data[0]))):
+            item = next(caption_iter)
+            if data_type == 'fact':
+                fns, fc_feats, att_feats, (caps_tensor, lengths), cpts_tensor, sentis_tensor, ground_truth = item
+                caps_tensor = caps_tensor.to(device)
+            else:
+                fns, fc_feats, att_feats, cpts_tensor, sentis_tensor, senti_labels = item
+                senti_labels = senti_labels.to(device)
+            fc_feats, att_feats = fc_feats.to(device), att_feats.to(device)
+            cpts_tensor, sentis_tensor = cpts_tensor.to(device), sentis_tensor.to(device)
+            del item
+
+            if data_type == 'fact' or not training:      # labels from the image sentiment detector
+                senti_labels = self.senti_detector.sample(att_feats, self.senti_threshold)[0].detach()
+
+            # sampled roll-out (graph kept in train mode) and the domain-alignment loss on its prologue
+            sample_captions, sample_logprobs, seq_masks = cap(
+                fc_feats, att_feats, cpts_tensor, sentis_tensor, senti_labels, self.max_seq_len,
+                sample_max=0, mode='rl')
+            da_loss = self.cap_da_crit(cap.cpt_feats, cap.fc_feats.detach())
+            sums['da_loss'] += float(da_loss.detach())
+
+            cap.eval()                                   # greedy baseline
+            with torch.no_grad():
+                greedy_captions, _, greedy_masks = cap(
+                    fc_feats, att_feats, cpts_tensor, sentis_tensor, senti_labels, self.max_seq_len,
+                    sample_max=1, mode='rl')
+            cap.train(training)
+
+            if data_type == 'fact':
+                fact_reward = get_self_critical_reward(
+                    sample_captions, greedy_captions, fns, ground_truth, cap.sos_id, cap.eos_id,
+                    self.ciderd_scorer)
+                fact_reward = torch.from_numpy(fact_reward).float().to(device)
+                sums['fact_reward'] += float(fact_reward[:, 0].mean())
+            else:
+                fact_reward = 0
+
+            cls_reward = get_cls_reward(sample_captions, seq_masks, greedy_captions, greedy_masks, senti_labels,
+                                        self.sent_senti_cls)
+            cls_reward = torch.from_numpy(cls_reward).float().to(device)
+            sums['cls_reward'] += float(cls_reward.mean(-1).mean(-1))
+
+            rewards = fact_reward + self.cls_flag * cls_reward
+            sums['all_rewards'] += float(rewards.mean(-1).mean(-1))
+            cap_loss = self.cap_rl_crit(sample_logprobs, seq_masks, rewards)
+            sums['cap_loss'] += float(cap_loss.detach())
+
+            xe_loss = 0.0
+            if data_type == 'fact':                      # XE on the ground truth, labelled by the classifier
+                with torch.no_grad():
+                    xe_senti_labels = self.sent_senti_cls(caps_tensor[:, 1:], lengths)[0]
+                    xe_senti_labels = xe_senti_labels.softmax(dim=-1).argmax(dim=-1).detach()
+                pred = cap(fc_feats, att_feats, cpts_tensor, caps_tensor, xe_senti_labels, ss_prob=0.5, mode='xe')
+                xe_loss = self.cap_xe_crit(pred, caps_tensor[:, 1:], lengths)
+                sums['xe_loss'] += float(xe_loss.detach())
+
+            seq2seq_loss = 0.0
+            if training:
+                try:
+                    batch = next(seq2seq_iter)
+                except StopIteration:
+                    seq2seq_iter = iter(data[1])
+                    batch = next(seq2seq_iter)
+                (s_caps, s_lengths), s_cpts, s_sentis, s_labels = batch
+                s_caps, s_cpts = s_caps.to(device), s_cpts.to(device)
+                s_sentis, s_labels = s_sentis.to(device), s_labels.to(device)
+                pred = cap(s_caps, s_cpts, s_sentis, s_labels, ss_prob=0.25, mode='seq2seq')
+                seq2seq_loss = self.seq_flag * self.cap_xe_crit(pred, s_caps[:, 1:], s_lengths)
+                sums['seq2seq_loss'] += float(seq2seq_loss.detach())
+
+            total = cap_loss + xe_loss + da_loss + seq2seq_loss
+            if training:
+                self.cap_optim.zero_grad()
+                total.backward()
+                clip_gradient(self.cap_optim)            # 0.1, fused into the Adam launch
+                self.cap_optim.step()
+
+        return {k: v / len(data) for k, v in sums.items()}
+
+    def sample(self, fc_feats, att_feats, sentis_tensor, beam_size=3, decoding_constraint=1):
+        """One image: detect its sentiment, then beam search (decoder.py:182-192)."""
+        self.eval()
+        att_feats = att_feats.unsqueeze(0)
+        senti_label, _, det_img_sentis, _ = self.senti_detector.sample(att_feats, self.senti_threshold)
+        captions, _ = self.captioner.sample(fc_feats, att_feats, sentis_tensor, senti_label, beam_size,
+                                            decoding_constraint, self.max_seq_len)
+        return captions, det_img_sentis

@@ -194,3 +194,45 @@ def make_cider_data(n_images, vocab_size, batch, seq_len=20, n_refs=5, seed=7):
              'val': {k: v for k, v in list(captions.items())[n_images // 2:]}}
     ground_truth = {fn: captions[fn] for fn in fns}
     return split, fns, ground_truth, sample, greedy
+
+
+# settings keys only the helper nets read (opts.py:89-92)
+HELPER_SETTINGS = dict(sentiment_convs_num=2, sentiment_fcs_num=2)
+
+
+def make_module_weights(shapes, seed, gain=2.0):
+    """Deterministic weights for an arbitrary module given {name: shape} (its state_dict layout):
+    U(-1,1) * gain / sqrt(fan_in), embeddings U(-1,1) with a zero <PAD> row; one PCG64 stream per name."""
+    out = {}
+    for name, shape in shapes.items():
+        shape = tuple(int(x) for x in shape)
+        rng = np.random.default_rng([seed, zlib.crc32(name.encode())])
+        if 'embed' in name:
+            w = rng.uniform(-1.0, 1.0, size=shape)
+            w[0] = 0.0
+        else:
+            fan_in = int(np.prod(shape[1:])) if len(shape) > 1 else max(shape[0], 1)
+            w = rng.uniform(-1.0, 1.0, size=shape) * gain / np.sqrt(fan_in)
+        out[name] = w.astype(np.float32)
+    return out
+
+
+def make_rl_batches(n_batches, batch, vocab_size, settings, grid=(2, 3), seq_len=8, seed=40):
+    """Fact batches in the reference's rl_fact collate layout (dataloader.py:60-91):
+    (fns, fc [B,F], att [B,h,w,F], (caps [B,L], lengths), cpts [B,5], sentis [B,10], ground_truth)
+    plus the caption dictionary for the CIDEr-D document frequencies."""
+    n_img = n_batches * batch
+    split, _, _, _, _ = make_cider_data(n_img, vocab_size, min(batch, n_img), seq_len=seq_len, seed=seed)
+    captions = {}
+    for v in split.values():
+        captions.update(v)
+    fns_all = sorted(captions)
+    batches = []
+    for i in range(n_batches):
+        d = make_inputs(batch, vocab_size, settings, regions=grid[0] * grid[1], seq_len=seq_len,
+                        seed=seed + 1 + i, grid=grid)
+        fns = fns_all[i * batch:(i + 1) * batch]
+        gt = {fn: [c[:seq_len + 1] for c in captions[fn]] for fn in fns}
+        batches.append((fns, d['fc_feats'], d['att_feats'], (d['captions'], d['lengths']), d['cpt_words'],
+                        d['senti_words'], gt))
+    return batches, split

@@ -405,7 +405,65 @@ def _words(arr, sos=1, eos=2):
     return o + [eos]
 
 
-CASES = {'tiny': case_tiny, 'cfg1': case_cfg1, 'b128': case_b128, 'cider': case_cider}
+def case_detector():
+    """Helper nets and Detector.forward (models/decoder.py:52-180) in eval mode on tiny dims: the loss
+    dictionary of two 'fact' batches, with the multinomial draws of the sampled roll-outs recorded."""
+    from models.decoder import Detector
+    V, Tn, B = 64, 8, 4
+    st = dict(synth.TINY_SETTINGS, **synth.HELPER_SETTINGS)
+    idx2word = synth.make_idx2word(V)
+    det = Detector(idx2word, Tn, synth.SENTIMENT_CATEGORIES, {'cap_lr': 4e-5}, st)
+    det.captioner.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_weights(V, st, seed=1).items()})
+    for name, mod, seed in (('senti_detector', det.senti_detector, 51), ('sent_senti_cls', det.sent_senti_cls, 52)):
+        shapes = {k: tuple(v.shape) for k, v in mod.state_dict().items()}
+        mod.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_module_weights(shapes, seed).items()})
+    batches, split = synth.make_rl_batches(2, B, V, st, seq_len=Tn)
+    det.set_ciderd_scorer(split)
+    tens = lambda b: (b[0], torch.from_numpy(b[1]), torch.from_numpy(b[2]), (torch.from_numpy(b[3][0]), b[3][1]),
+                      torch.from_numpy(b[4]), torch.from_numpy(b[5]), b[6])
+    out = {}
+    # helper nets alone
+    for i, b in enumerate(batches):
+        labels, maps, _, scores = det.senti_detector.sample(torch.from_numpy(b[2]), 0.7)
+        out['senti_det/labels%d' % i] = labels.numpy()
+        out['senti_det/scores%d' % i] = scores.detach().numpy()
+        out['senti_det/maps%d' % i] = maps.detach().numpy()
+        logits0, _ = det.senti_detector(torch.from_numpy(b[2]))
+        out['senti_det/logits%d' % i] = logits0.detach().numpy()
+        det.sent_senti_cls.eval()
+        with torch.no_grad():
+            pred, w = det.sent_senti_cls(torch.from_numpy(b[3][0])[:, 1:], b[3][1])
+        out['sent_cls/pred%d' % i] = pred.numpy()
+        out['sent_cls/weights%d' % i] = w.numpy()
+    # Detector.forward, eval mode
+    ms = MultinomialSpy()
+    bounds = []
+    orig = det.captioner.forward_rl
+
+    def spy_rl(*a, **k):
+        n0 = len(ms.draws)
+        r = orig(*a, **k)
+        if not k.get('sample_max', a[-1] if len(a) >= 7 else 1):
+            bounds.append((n0, len(ms.draws)))
+        return r
+    det.captioner.forward_rl = spy_rl
+    torch.manual_seed(2024)
+    losses = det(([tens(b) for b in batches],), 'fact', False)
+    ms.close()
+    det.captioner.forward_rl = orig
+    for i, (a, b) in enumerate(bounds):
+        dr = torch.stack(ms.draws[a:b], dim=1).numpy()
+        out['det/draws%d' % i] = np.pad(dr, ((0, 0), (0, Tn - dr.shape[1])))
+        out['det/steps%d' % i] = np.array([dr.shape[1]])
+    assert len(bounds) == 2, bounds
+    for k, v in losses.items():
+        out['det/loss_' + k] = np.array([v], dtype=np.float64)
+    print({k: round(v, 5) for k, v in losses.items()})
+    np.savez_compressed(os.path.join(HERE, 'detector.npz'), **out)
+    print('detector: %d arrays' % len(out))
+
+
+CASES = {'tiny': case_tiny, 'cfg1': case_cfg1, 'b128': case_b128, 'cider': case_cider, 'detector': case_detector}
 
 if __name__ == '__main__':
     which = sys.argv[1:] or list(CASES)
