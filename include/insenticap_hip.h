@@ -198,6 +198,81 @@ int isc_beam_topk(const float *logits, int64_t ld_logits, const float *part_max,
 int isc_xe_loss_fwd(const float *logp, const int64_t *target, const int32_t *lengths, int B,
                     int T, int V, float *out2, void *stream);
 
+/* ------------------------------------------------------------------ whole decode step */
+
+/* One forward_step (captioner.py:168-186) as ONE host call: enqueues the att-LSTM, the attention
+ * projections (+ the h-term of the gate), the attention scan(s), the gate contraction + mix, the
+ * lang-LSTM, the vocabulary projection and (optionally) the in-place log-softmax on `stream`.
+ * It exists to take ~10 descriptor-building FFI calls per step off the host: at B <= 128 the step
+ * is launch-bound.  Every pointer is a device pointer; nn.Linear weights are contiguous [out,in].
+ * Branch selection like captioner.py:96-118: att_e == NULL -> sentiment words only (seq2seq),
+ * words_e == NULL -> regions only (xe), both -> both + gate. */
+typedef struct {
+    int32_t rows, H, E, A, W, V, R, Mw;
+    /* weights */
+    const float *Wih1, *Whh1;           /* att_lstm.weight_ih [4H, H+E+W] (ld = H+E+W), weight_hh [4H,H] */
+    const float *Wih2, *Whh2;           /* lang_lstm.weight_ih [4H, E+H], weight_hh */
+    const float *b_ih2, *b_hh2;
+    const float *W_h2att, *b_h2att, *w_alpha_c, *b_alpha_c;      /* attention.cont_att.* */
+    const float *W_h2word, *b_h2word, *w_alpha_s, *b_alpha_s;    /* attention.senti_att.* */
+    const float *W_gh, *b_gh, *W_gc, *b_gc, *W_gs, *b_gs, *w_gate, *b_gate; /* attention.{h2att,cont2att,senti2att,att_alpha} */
+    const float *W_cls, *b_cls;
+    /* step-invariant activations */
+    const float *pre1;                  /* [rows,4H] hoisted fc/label/bias term of the att-LSTM */
+    const float *tab;                   /* [V,4H] relu(Emb) W_x^T or NULL */
+    const float *att_p, *att_e;         /* [rows,R,A], [rows,R,E] or NULL */
+    const float *words_p, *words_e;     /* [rows,Mw,A], [rows,Mw,W] or NULL */
+    const float *label_w;               /* [rows,A] or NULL */
+    /* per step */
+    const float *xt;                    /* [rows,W] relu(Emb[token]) (ignored when tab) */
+    const int64_t *tok;                 /* token ids (row stride tok_stride), required iff tab */
+    int64_t tok_stride;
+    const float *h1_prev, *c1_prev, *h2_prev, *c2_prev;   /* [rows,H] */
+    float *h1, *c1, *h2, *c2;
+    float *g1, *g2;                     /* optional activated gates [rows,4H] (training) */
+    float *qa, *v, *qw, *s, *z, *f;     /* [rows,A] / [rows,E] workspaces (branch-dependent) */
+    float *alpha_c, *alpha_s, *beta;    /* optional attention-weight outputs */
+    int64_t alpha_c_ld, alpha_s_ld, beta_ld;
+    const uint8_t *out_mask;            /* dropout keep-mask on h_lang or NULL */
+    float out_scale;
+    int32_t apply_logsoftmax;           /* normalise `logits` in place after the projection */
+    float *hdrop;                       /* [rows,H], required iff out_mask */
+    float *logits;                      /* [rows,V] (row stride ld_logits) or NULL */
+    int64_t ld_logits;
+    float *pmax, *psum;                 /* [rows, ceil(V/128)] */
+    int32_t *pidx;
+} isc_step_plan;
+
+int isc_step_fwd(const isc_step_plan *plan_host, void *stream);
+
+/* Reverse-sweep counterpart (one BPTT step, see autograd.py): lang-LSTM cell backward, input-gradient
+ * contractions, gate / scan backward, att-LSTM cell backward, recurrent gradients for step t-1.
+ * `first` = last time step (no incoming recurrent gradients), `last` = step 0 (no outgoing ones). */
+typedef struct {
+    int32_t rows, H, E, A, W, R, Mw, first, last, _pad;
+    const float *Wih1, *Whh1, *Wih2, *Whh2;
+    const float *W_h2att, *w_alpha_c, *W_h2word, *w_alpha_s, *W_gh, *W_gc, *W_gs, *w_gate;
+    const float *att_p, *att_e, *words_p, *words_e, *label_w;
+    /* saved activations of this step */
+    const float *g1, *c1_prev, *c1, *g2, *c2_prev, *c2;
+    const float *qa, *qw, *v, *s, *z;
+    const float *alpha_c, *alpha_s, *beta;
+    int64_t alpha_c_ld, alpha_s_ld, beta_ld;
+    /* gradients */
+    const float *dhd;                   /* [rows,H] d loss / d h_lang of this step (classifier path) */
+    float *dG1, *dG2;                   /* [rows,4H] this step's slices of the time-stacked buffers */
+    float *dG1_sum;                     /* [rows,4H] running sum over time */
+    float *d_feat, *dh1, *dv, *ds;      /* [rows,E] / [rows,H] scratch */
+    float *dh2_rec, *dh1_rec;           /* recurrent gradients (in: from t+1, out: for t-1) */
+    const float *dc1_in, *dc2_in;       /* cell-state gradients from t+1 (ignored when first) */
+    float *dc1_out, *dc2_out;
+    float *dqa, *dqw, *dz;              /* [rows,A] this step's slices */
+    float *dP_att, *dV_att, *dP_w, *dV_w;       /* accumulated over time */
+    float *dwc_rows, *dws_rows, *dwg_rows, *dbg_rows;
+} isc_step_bwd_plan;
+
+int isc_step_bwd(const isc_step_bwd_plan *plan_host, void *stream);
+
 /* ------------------------------------------------------------------ backward (BPTT) */
 
 /* d logits = d logp - softmax * rowsum(d logp)  (autograd of F.log_softmax, captioner.py:183).

@@ -50,6 +50,36 @@ class ScanBwdProblem(C.Structure):
                 ('dP', C.c_void_p), ('dV', C.c_void_p), ('dq', C.c_void_p), ('dw_rows', C.c_void_p)]
 
 
+def _f(names, ctype):
+    return [(n, ctype) for n in names.split()]
+
+
+class StepPlan(C.Structure):
+    """isc_step_plan: field order mirrors include/insenticap_hip.h exactly (checked by the layout test)."""
+    _fields_ = (_f('rows H E A W V R Mw', C.c_int32) +
+                _f('Wih1 Whh1 Wih2 Whh2 b_ih2 b_hh2 W_h2att b_h2att w_alpha_c b_alpha_c W_h2word b_h2word '
+                   'w_alpha_s b_alpha_s W_gh b_gh W_gc b_gc W_gs b_gs w_gate b_gate W_cls b_cls '
+                   'pre1 tab att_p att_e words_p words_e label_w xt tok', C.c_void_p) +
+                [('tok_stride', C.c_int64)] +
+                _f('h1_prev c1_prev h2_prev c2_prev h1 c1 h2 c2 g1 g2 qa v qw s z f alpha_c alpha_s beta',
+                   C.c_void_p) +
+                _f('alpha_c_ld alpha_s_ld beta_ld', C.c_int64) +
+                [('out_mask', C.c_void_p), ('out_scale', C.c_float), ('apply_logsoftmax', C.c_int32),
+                 ('hdrop', C.c_void_p), ('logits', C.c_void_p), ('ld_logits', C.c_int64),
+                 ('pmax', C.c_void_p), ('psum', C.c_void_p), ('pidx', C.c_void_p)])
+
+
+class StepBwdPlan(C.Structure):
+    """isc_step_bwd_plan."""
+    _fields_ = (_f('rows H E A W R Mw first last _pad', C.c_int32) +
+                _f('Wih1 Whh1 Wih2 Whh2 W_h2att w_alpha_c W_h2word w_alpha_s W_gh W_gc W_gs w_gate '
+                   'att_p att_e words_p words_e label_w g1 c1_prev c1 g2 c2_prev c2 qa qw v s z '
+                   'alpha_c alpha_s beta', C.c_void_p) +
+                _f('alpha_c_ld alpha_s_ld beta_ld', C.c_int64) +
+                _f('dhd dG1 dG2 dG1_sum d_feat dh1 dv ds dh2_rec dh1_rec dc1_in dc2_in dc1_out dc2_out '
+                   'dqa dqw dz dP_att dV_att dP_w dV_w dwc_rows dws_rows dwg_rows dbg_rows', C.c_void_p))
+
+
 class RolloutStep(C.Structure):
     _fields_ = [('B', C.c_int32), ('V', C.c_int32), ('T', C.c_int32), ('t', C.c_int32),
                 ('n_tile', C.c_int32), ('W', C.c_int32),
@@ -68,6 +98,8 @@ SIGNATURES = {
     'isc_linear_fwd': (C.c_int, [C.POINTER(LinearProblem), C.c_int, C.c_void_p]),
     'isc_gemm_bwd': (C.c_int, [C.POINTER(LinearProblem), C.c_int, C.c_int, C.c_void_p]),
     'isc_lstm_fwd': (C.c_int, [C.POINTER(LstmProblem), C.c_void_p]),
+    'isc_step_fwd': (C.c_int, [C.POINTER(StepPlan), C.c_void_p]),
+    'isc_step_bwd': (C.c_int, [C.POINTER(StepBwdPlan), C.c_void_p]),
     'isc_vocab_fwd': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int,
                                 C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                 C.c_void_p]),

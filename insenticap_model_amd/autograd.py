@@ -54,6 +54,7 @@ def _train_forward(cap, mode, fc, att, cpt_words, senti_words, tokens_in, senti_
     pi = new(B, n_tile, dtype=torch.int32)
     out = new(B, T, V)
     emb = p['word_embed.0.weight']
+    plan = cap._make_plan(p, P, B)
     for t in range(T):
         it = tokens_in[:, t]
         if cap.training and t >= 1 and ss_prob > 0.0:           # scheduled sampling, captioner.py:219-228
@@ -71,7 +72,7 @@ def _train_forward(cap, mode, fc, att, cpt_words, senti_words, tokens_in, senti_
             save['hdrop'] = S.hdrop[t]
             S.out_scale = osc
         S.out_masks.append(om)
-        ws = {'pmax': pm, 'psum': ps, 'pidx': pi}
+        ws = {'pmax': pm, 'psum': ps, 'pidx': pi, '_plan': plan}
         if has_c:
             ws['qa'], ws['v'] = S.qa[t], S.v[t]
         if has_s:
@@ -82,8 +83,7 @@ def _train_forward(cap, mode, fc, att, cpt_words, senti_words, tokens_in, senti_
         cap._step(p, P, ws, S.xt[t], (S.h1[t], S.h2[t]), (S.c1[t], S.c2[t]),
                   (S.h1[t + 1], S.h2[t + 1]), (S.c1[t + 1], S.c2[t + 1]),
                   S.aC[:, t] if has_c else None, S.aS[:, t] if has_s else None,
-                  S.bG[:, t:t + 1] if (has_c and has_s) else None, logits, om, osc, save=save)
-        ops.logsoftmax_apply(logits, pm, ps)
+                  S.bG[:, t:t + 1] if (has_c and has_s) else None, logits, om, osc, save=save, normalize=True)
     cap._set_weights(S.aC if has_c else None, S.aS if has_s else None,
                      S.bG if (has_c and has_s) else None, T)
     S.logp = out
@@ -158,43 +158,52 @@ def _backward(cap, S, dlogp, d_fc_feats, d_cpt_feats):
     if gate:
         dz = new(T, B, A)
         dwg_rows, dbg_rows = new(B, A), new(B)
+    # reverse sweep: one library call per time step (isc_step_bwd enqueues the ~9 kernels of the step)
+    from . import _lib
+    bp = _lib.StepBwdPlan()
+    bp.rows, bp.H, bp.E, bp.A, bp.W, bp.R, bp.Mw = B, H, E, A, Wd, P.R, P.Mw
+    for field, key in (('Wih1', 'att_lstm.weight_ih'), ('Whh1', 'att_lstm.weight_hh'),
+                       ('Wih2', 'lang_lstm.weight_ih'), ('Whh2', 'lang_lstm.weight_hh'),
+                       ('W_h2att', 'attention.cont_att.h2att.weight'),
+                       ('w_alpha_c', 'attention.cont_att.att_alpha.weight'),
+                       ('W_h2word', 'attention.senti_att.h2word.weight'),
+                       ('w_alpha_s', 'attention.senti_att.word_alpha.weight'),
+                       ('W_gh', 'attention.h2att.weight'), ('W_gc', 'attention.cont2att.weight'),
+                       ('W_gs', 'attention.senti2att.weight'), ('w_gate', 'attention.att_alpha.weight')):
+        setattr(bp, field, p[key].data_ptr())
+    ptr = ops.ptr
+    for field, t_ in (('att_p', P.att_p3), ('att_e', P.att_e3), ('words_p', P.words_p3), ('words_e', P.words_e3),
+                      ('label_w', P.label_w)):
+        setattr(bp, field, ptr(t_))
+    bp.dG1_sum, bp.d_feat, bp.dh1 = dG1_sum.data_ptr(), d_feat.data_ptr(), dh1.data_ptr()
+    bp.dh2_rec, bp.dh1_rec = dh2_rec.data_ptr(), dh1_rec.data_ptr()
+    if has_c:
+        bp.dP_att, bp.dV_att, bp.dwc_rows = dP_att.data_ptr(), dV_att.data_ptr(), dwc_rows.data_ptr()
+        bp.alpha_c_ld = S.aC.stride(0)
+    if has_s:
+        bp.dP_w, bp.dV_w, bp.dws_rows = dP_w.data_ptr(), dV_w.data_ptr(), dws_rows.data_ptr()
+        bp.alpha_s_ld = S.aS.stride(0)
+    if gate:
+        bp.dv, bp.ds = dv.data_ptr(), ds.data_ptr()
+        bp.dwg_rows, bp.dbg_rows = dwg_rows.data_ptr(), dbg_rows.data_ptr()
+        bp.beta_ld = S.bG.stride(0)
     for t in range(T - 1, -1, -1):
-        first = (t == T - 1)
         cur, nxt = t & 1, (t + 1) & 1
-        # lang-LSTM cell
-        ops.lstm_bwd(dhd[t], None if first else dh2_rec, None if first else dc2_rec[nxt], S.g2[t], S.c2[t],
-                     S.c2[t + 1], dG2[t], dc2_rec[cur])
-        ops.gemm_bwd([nn([(dG2[t], Wih2[:, 0:E])], d_feat), nn([(dG2[t], Wih2[:, E:E + H])], dh1),
-                      nn([(dG2[t], Whh2)], dh2_rec)], NN)
-        # attention
-        scans = []
+        bp.first, bp.last = int(t == T - 1), int(t == 0)
+        bp.g1, bp.c1_prev, bp.c1 = S.g1[t].data_ptr(), S.c1[t].data_ptr(), S.c1[t + 1].data_ptr()
+        bp.g2, bp.c2_prev, bp.c2 = S.g2[t].data_ptr(), S.c2[t].data_ptr(), S.c2[t + 1].data_ptr()
+        bp.dhd, bp.dG1, bp.dG2 = dhd[t].data_ptr(), dG1[t].data_ptr(), dG2[t].data_ptr()
+        bp.dc1_in, bp.dc1_out = dc1_rec[nxt].data_ptr(), dc1_rec[cur].data_ptr()
+        bp.dc2_in, bp.dc2_out = dc2_rec[nxt].data_ptr(), dc2_rec[cur].data_ptr()
+        if has_c:
+            bp.qa, bp.v, bp.alpha_c, bp.dqa = S.qa[t].data_ptr(), S.v[t].data_ptr(), S.aC[:, t].data_ptr(), \
+                dqa[t].data_ptr()
+        if has_s:
+            bp.qw, bp.s, bp.alpha_s, bp.dqw = S.qw[t].data_ptr(), S.s[t].data_ptr(), S.aS[:, t].data_ptr(), \
+                dqw[t].data_ptr()
         if gate:
-            ops.gate_mix_bwd(S.z[t], p['attention.att_alpha.weight'], S.v[t], S.s[t], S.bG[:, t:t + 1], d_feat,
-                             dv, ds, dz[t], dwg_rows, dbg_rows, not first)
-            ops.gemm_bwd([nn([(dz[t], p['attention.cont2att.weight'])], dv, True),
-                          nn([(dz[t], p['attention.senti2att.weight'])], ds, True),
-                          nn([(dz[t], p['attention.h2att.weight'])], dh1, True)], NN)
-        if has_c:
-            scans.append(ops.scan_bwd_problem(P.att_p3, P.att_e3, S.qa[t], p['attention.cont_att.att_alpha.weight'],
-                                              S.aC[:, t], dv if gate else d_feat, dP_att, dV_att, dqa[t],
-                                              dwc_rows, not first))
-        if has_s:
-            scans.append(ops.scan_bwd_problem(P.words_p3, P.words_e3, S.qw[t],
-                                              p['attention.senti_att.word_alpha.weight'], S.aS[:, t],
-                                              ds if gate else d_feat, dP_w, dV_w, dqw[t], dws_rows, not first,
-                                              q2=P.label_w))
-        ops.attn_scan_bwd(scans, B)
-        segs = []
-        if has_c:
-            segs.append((dqa[t], p['attention.cont_att.h2att.weight']))
-        if has_s:
-            segs.append((dqw[t], p['attention.senti_att.h2word.weight']))
-        ops.gemm_bwd([nn(segs, dh1, True)], NN)
-        # att-LSTM cell
-        ops.lstm_bwd(dh1, None if first else dh1_rec, None if first else dc1_rec[nxt], S.g1[t], S.c1[t],
-                     S.c1[t + 1], dG1[t], dc1_rec[cur], dG1_sum)
-        if t > 0:
-            ops.gemm_bwd([nn([(dG1[t], Wih1[:, 0:H])], dh2_rec, True), nn([(dG1[t], Whh1)], dh1_rec)], NN)
+            bp.z, bp.beta, bp.dz = S.z[t].data_ptr(), S.bG[:, t:t + 1].data_ptr(), dz[t].data_ptr()
+        ops.step_bwd(bp)
 
     # ---- weight gradients: one contraction over all T*B rows each
     dG1f, dG2f = dG1.view(TB, 4 * H), dG2.view(TB, 4 * H)

@@ -1,0 +1,170 @@
+// Whole-step host drivers: isc_step_fwd / isc_step_bwd enqueue every kernel of one decode step (or
+// one BPTT step) from C++, so the host language pays one FFI call per step instead of ~10
+// descriptor-building calls (include/insenticap_hip.h, "whole decode step").  Pure host code: it
+// only fills the per-kernel descriptors and calls the library's own entry points.
+#include "common.h"
+
+static inline isc_seg seg(const float *A, int lda, const float *W, int ldw, int K) {
+    isc_seg s = {A, W, lda, ldw, K, 0};
+    return s;
+}
+
+#define RET(x)            \
+    do {                  \
+        int rc__ = (x);   \
+        if (rc__) return rc__; \
+    } while (0)
+
+extern "C" int isc_step_fwd(const isc_step_plan *p, void *stream) {
+    if (!p) return ISC_E_NULL;
+    const int rows = p->rows, H = p->H, E = p->E, A = p->A, W = p->W, V = p->V;
+    if (rows <= 0 || H <= 0) return ISC_E_SHAPE;
+    const bool has_c = p->att_e != nullptr, has_s = p->words_e != nullptr, gate = has_c && has_s;
+    if (!has_c && !has_s) return ISC_E_NULL;
+    const int ld1 = H + E + W, ld2 = E + H;
+
+    // att-LSTM over cat[h_lang_prev, fc, xt] (captioner.py:174-175); fc/label/bias are in pre1
+    {
+        isc_lstm_problem l = {};
+        int n = 0;
+        l.seg[n++] = seg(p->h2_prev, H, p->Wih1, ld1, H);
+        if (!p->tab) l.seg[n++] = seg(p->xt, W, p->Wih1 + H + E, ld1, W);
+        l.seg[n++] = seg(p->h1_prev, H, p->Whh1, H, H);
+        l.nseg = n; l.M = rows; l.H = H;
+        l.c_prev = p->c1_prev; l.h_out = p->h1; l.c_out = p->c1; l.gates_out = p->g1;
+        l.pre = p->pre1; l.tab = p->tab; l.tab_ids = p->tok; l.tab_ids_stride = p->tok_stride;
+        RET(isc_lstm_fwd(&l, stream));
+    }
+    // projections of h_att: h2att (content), h2word (sentiment), h2att of the gate - one launch
+    {
+        isc_linear_problem q[3] = {};
+        int n = 0;
+        auto lin = [&](const float *Wm, const float *b, float *out) {
+            isc_linear_problem &x = q[n++];
+            x.seg[0] = seg(p->h1, H, Wm, H, H);
+            x.nseg = 1; x.M = rows; x.N = A; x.bias0 = b; x.ldc = A; x.C = out;
+        };
+        if (has_c) lin(p->W_h2att, p->b_h2att, p->qa);
+        if (has_s) lin(p->W_h2word, p->b_h2word, p->qw);
+        if (gate) lin(p->W_gh, p->b_gh, p->z);
+        RET(isc_linear_fwd(q, n, stream));
+    }
+    // attention scans (captioner.py:23-35, 50-62)
+    {
+        isc_scan_problem sc[2] = {};
+        int n = 0;
+        if (has_c) {
+            isc_scan_problem &x = sc[n++];
+            x.P = p->att_p; x.V = p->att_e; x.q = p->qa; x.w = p->w_alpha_c; x.w_bias = p->b_alpha_c;
+            x.R = p->R; x.A = A; x.D = E; x.out = p->v; x.alpha_out = p->alpha_c; x.alpha_ld = p->alpha_c_ld;
+        }
+        if (has_s) {
+            isc_scan_problem &x = sc[n++];
+            x.P = p->words_p; x.V = p->words_e; x.q = p->qw; x.q2 = p->label_w; x.w = p->w_alpha_s;
+            x.w_bias = p->b_alpha_s; x.R = p->Mw; x.A = A; x.D = W; x.out = p->s; x.alpha_out = p->alpha_s;
+            x.alpha_ld = p->alpha_s_ld;
+        }
+        RET(isc_attn_scan_fwd(sc, n, rows, stream));
+    }
+    const float *feat = has_c ? p->v : p->s;
+    if (gate) {  // z += cont2att(v) + senti2att(s); beta, mix (captioner.py:107-117)
+        isc_linear_problem x = {};
+        x.seg[0] = seg(p->v, E, p->W_gc, E, E);
+        x.seg[1] = seg(p->s, W, p->W_gs, W, W);
+        x.nseg = 2; x.M = rows; x.N = A; x.bias0 = p->b_gc; x.bias1 = p->b_gs; x.ldc = A; x.C = p->z;
+        x.accumulate = 1;
+        RET(isc_linear_fwd(&x, 1, stream));
+        RET(isc_gate_mix_fwd(p->z, p->w_gate, p->b_gate, p->v, p->s, rows, A, E, p->f, p->beta, p->beta_ld, stream));
+        feat = p->f;
+    }
+    // lang-LSTM over cat[feat, h_att] (captioner.py:180-181) (+ dropout on h_lang, :182)
+    {
+        isc_lstm_problem l = {};
+        l.seg[0] = seg(feat, E, p->Wih2, ld2, E);
+        l.seg[1] = seg(p->h1, H, p->Wih2 + E, ld2, H);
+        l.seg[2] = seg(p->h2_prev, H, p->Whh2, H, H);
+        l.nseg = 3; l.M = rows; l.H = H; l.b_ih = p->b_ih2; l.b_hh = p->b_hh2;
+        l.c_prev = p->c2_prev; l.h_out = p->h2; l.c_out = p->c2; l.gates_out = p->g2;
+        l.h_keep_mask = p->out_mask; l.mask_scale = p->out_scale; l.hdrop_out = p->hdrop;
+        RET(isc_lstm_fwd(&l, stream));
+    }
+    // classifier + log-softmax statistics (captioner.py:183)
+    RET(isc_vocab_fwd(p->out_mask ? p->hdrop : p->h2, H, p->W_cls, H, p->b_cls, rows, V, H, p->logits,
+                      p->ld_logits, p->pmax, p->psum, p->pidx, stream));
+    if (p->apply_logsoftmax) {
+        if (!p->logits) return ISC_E_NULL;
+        RET(isc_logsoftmax_apply(p->logits, p->ld_logits, rows, V, p->pmax, p->psum, nullptr, stream));
+    }
+    return ISC_OK;
+}
+
+static inline isc_linear_problem nn_problem(const float *A, int lda, const float *Wm, int ldw, int K, int M,
+                                            int N, float *C, int accumulate) {
+    isc_linear_problem x = {};
+    x.seg[0] = seg(A, lda, Wm, ldw, K);
+    x.nseg = 1; x.M = M; x.N = N; x.ldc = N; x.C = C; x.accumulate = accumulate;
+    return x;
+}
+
+extern "C" int isc_step_bwd(const isc_step_bwd_plan *p, void *stream) {
+    if (!p) return ISC_E_NULL;
+    const int rows = p->rows, H = p->H, E = p->E, A = p->A, W = p->W;
+    const bool has_c = p->att_e != nullptr, has_s = p->words_e != nullptr, gate = has_c && has_s;
+    const int ld1 = H + E + W, ld2 = E + H, G = 4 * H;
+    const int acc = p->first ? 0 : 1;      // time-accumulated buffers: the first processed step writes
+
+    // lang-LSTM cell
+    RET(isc_lstm_bwd(p->dhd, p->first ? nullptr : p->dh2_rec, p->first ? nullptr : p->dc2_in, p->g2,
+                     p->c2_prev, p->c2, rows, H, p->dG2, p->dc2_out, nullptr, stream));
+    {   // d feat, d h_att (lang-LSTM input part), d h_lang_prev (recurrent part)
+        isc_linear_problem q[3] = {nn_problem(p->dG2, G, p->Wih2, ld2, G, rows, E, p->d_feat, 0),
+                                   nn_problem(p->dG2, G, p->Wih2 + E, ld2, G, rows, H, p->dh1, 0),
+                                   nn_problem(p->dG2, G, p->Whh2, H, G, rows, H, p->dh2_rec, 0)};
+        RET(isc_gemm_bwd(q, 3, ISC_LAYOUT_NN, stream));
+    }
+    const float *dv = p->d_feat, *dsw = p->d_feat;
+    if (gate) {
+        RET(isc_gate_mix_bwd(p->z, p->w_gate, p->v, p->s, p->beta, p->beta_ld, p->d_feat, rows, A, E, p->dv,
+                             p->ds, p->dz, p->dwg_rows, p->dbg_rows, acc, stream));
+        isc_linear_problem q[3] = {nn_problem(p->dz, A, p->W_gc, E, A, rows, E, p->dv, 1),
+                                   nn_problem(p->dz, A, p->W_gs, W, A, rows, W, p->ds, 1),
+                                   nn_problem(p->dz, A, p->W_gh, H, A, rows, H, p->dh1, 1)};
+        RET(isc_gemm_bwd(q, 3, ISC_LAYOUT_NN, stream));
+        dv = p->dv;
+        dsw = p->ds;
+    }
+    {
+        isc_scan_bwd_problem sc[2] = {};
+        int n = 0;
+        if (has_c) {
+            isc_scan_bwd_problem &x = sc[n++];
+            x.P = p->att_p; x.V = p->att_e; x.q = p->qa; x.w = p->w_alpha_c; x.alpha = p->alpha_c;
+            x.alpha_ld = p->alpha_c_ld; x.dout = dv; x.R = p->R; x.A = A; x.D = E; x.accumulate = acc;
+            x.dP = p->dP_att; x.dV = p->dV_att; x.dq = p->dqa; x.dw_rows = p->dwc_rows;
+        }
+        if (has_s) {
+            isc_scan_bwd_problem &x = sc[n++];
+            x.P = p->words_p; x.V = p->words_e; x.q = p->qw; x.q2 = p->label_w; x.w = p->w_alpha_s;
+            x.alpha = p->alpha_s; x.alpha_ld = p->alpha_s_ld; x.dout = dsw; x.R = p->Mw; x.A = A; x.D = W;
+            x.accumulate = acc; x.dP = p->dP_w; x.dV = p->dV_w; x.dq = p->dqw; x.dw_rows = p->dws_rows;
+        }
+        RET(isc_attn_scan_bwd(sc, n, rows, stream));
+    }
+    {   // d h_att += dqa W_h2att + dqw W_h2word
+        isc_linear_problem x = {};
+        int n = 0;
+        if (has_c) x.seg[n++] = seg(p->dqa, A, p->W_h2att, H, A);
+        if (has_s) x.seg[n++] = seg(p->dqw, A, p->W_h2word, H, A);
+        x.nseg = n; x.M = rows; x.N = H; x.ldc = H; x.C = p->dh1; x.accumulate = 1;
+        RET(isc_gemm_bwd(&x, 1, ISC_LAYOUT_NN, stream));
+    }
+    // att-LSTM cell
+    RET(isc_lstm_bwd(p->dh1, p->first ? nullptr : p->dh1_rec, p->first ? nullptr : p->dc1_in, p->g1,
+                     p->c1_prev, p->c1, rows, H, p->dG1, p->dc1_out, p->dG1_sum, stream));
+    if (!p->last) {  // recurrent gradients for step t-1
+        isc_linear_problem q[2] = {nn_problem(p->dG1, G, p->Wih1, ld1, G, rows, H, p->dh2_rec, 1),
+                                   nn_problem(p->dG1, G, p->Whh1, H, G, rows, H, p->dh1_rec, 0)};
+        RET(isc_gemm_bwd(q, 2, ISC_LAYOUT_NN, stream));
+    }
+    return ISC_OK;
+}

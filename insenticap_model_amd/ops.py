@@ -139,6 +139,15 @@ def lstm_fwd(segs, b_ih, b_hh, c_prev, h_out, c_out, gates_out=None, h_keep_mask
         TIMER.end(e0, 'lstm[%dx%dx%d]' % (p.M, 4 * p.H, k), 2.0 * p.M * 4 * p.H * k)
 
 
+def step_fwd(plan):
+    """One decode step from a prepared isc_step_plan (all kernels enqueued by the library)."""
+    check(_lib.load().isc_step_fwd(C.byref(plan), stream()), 'isc_step_fwd')
+
+
+def step_bwd(plan):
+    check(_lib.load().isc_step_bwd(C.byref(plan), stream()), 'isc_step_bwd')
+
+
 def vocab_fwd(h, W, bias, part_max, part_sum, part_idx, logits=None):
     lib = _lib.load()
     M, K = h.shape

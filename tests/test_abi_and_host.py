@@ -62,6 +62,9 @@ int main(void) {
          offsetof(isc_linear_problem, accumulate), sizeof(isc_scan_bwd_problem));
   printf("%zu %zu %zu\n", offsetof(isc_lstm_problem, c_prev), offsetof(isc_scan_problem, out),
          offsetof(isc_rollout_step, xt_next));
+  printf("%zu %zu %zu %zu %zu %zu\n", sizeof(isc_step_plan), offsetof(isc_step_plan, tok_stride),
+         offsetof(isc_step_plan, out_scale), offsetof(isc_step_plan, pidx), sizeof(isc_step_bwd_plan),
+         offsetof(isc_step_bwd_plan, dbg_rows));
   return 0;
 }
 '''
@@ -77,7 +80,9 @@ int main(void) {
            ctypes.sizeof(L.ScanProblem), ctypes.sizeof(L.RolloutStep),
            L.LinearProblem.bias0.offset, L.LinearProblem.C.offset, L.LinearProblem.accumulate.offset,
            ctypes.sizeof(L.ScanBwdProblem),
-           L.LstmProblem.c_prev.offset, L.ScanProblem.out.offset, L.RolloutStep.xt_next.offset]
+           L.LstmProblem.c_prev.offset, L.ScanProblem.out.offset, L.RolloutStep.xt_next.offset,
+           ctypes.sizeof(L.StepPlan), L.StepPlan.tok_stride.offset, L.StepPlan.out_scale.offset,
+           L.StepPlan.pidx.offset, ctypes.sizeof(L.StepBwdPlan), L.StepBwdPlan.dbg_rows.offset]
     assert got == exp
 
 
