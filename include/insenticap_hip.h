@@ -63,6 +63,12 @@ typedef struct {
     float *C_pre;               /* optional: activation before the mask (captioner.fc_feats attr) */
     int32_t accumulate;         /* C += result (gradient accumulation) */
     int32_t _pad;
+    /* Optional split-K workspace (of the FIRST problem of a launch): when a launch has too few tiles to
+     * occupy the chip (small M), the contraction is split over ksplit workgroups per tile, partial tiles go
+     * to [ksplit, M, N] slabs in this buffer and a second kernel reduces them in fixed order and applies
+     * the epilogue (bitwise reproducible). NULL disables it. */
+    float *splitk_ws;
+    int64_t splitk_ws_floats;
 } isc_linear_problem;
 
 int isc_linear_fwd(const isc_linear_problem *probs_host, int n_prob, void *stream);
@@ -102,6 +108,8 @@ typedef struct {
     const float *tab;
     const int64_t *tab_ids;
     int64_t tab_ids_stride;
+    float *splitk_ws;           /* optional split-K workspace, see isc_linear_problem */
+    int64_t splitk_ws_floats;
 } isc_lstm_problem;
 
 int isc_lstm_fwd(const isc_lstm_problem *prob_host, void *stream);
@@ -241,6 +249,8 @@ typedef struct {
     int64_t ld_logits;
     float *pmax, *psum;                 /* [rows, ceil(V/128)] */
     int32_t *pidx;
+    float *splitk_ws;                   /* optional split-K workspace shared by the step's launches */
+    int64_t splitk_ws_floats;
 } isc_step_plan;
 
 int isc_step_fwd(const isc_step_plan *plan_host, void *stream);
@@ -269,6 +279,8 @@ typedef struct {
     float *dqa, *dqw, *dz;              /* [rows,A] this step's slices */
     float *dP_att, *dV_att, *dP_w, *dV_w;       /* accumulated over time */
     float *dwc_rows, *dws_rows, *dwg_rows, *dbg_rows;
+    float *splitk_ws;                   /* optional split-K workspace */
+    int64_t splitk_ws_floats;
 } isc_step_bwd_plan;
 
 int isc_step_bwd(const isc_step_bwd_plan *plan_host, void *stream);

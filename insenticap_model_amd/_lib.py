@@ -24,7 +24,8 @@ class LinearProblem(C.Structure):
     _fields_ = [('seg', Seg * ISC_MAX_SEG), ('nseg', C.c_int32), ('M', C.c_int32), ('N', C.c_int32),
                 ('relu', C.c_int32), ('bias0', C.c_void_p), ('bias1', C.c_void_p), ('bias2', C.c_void_p),
                 ('keep_mask', C.c_void_p), ('mask_scale', C.c_float), ('ldc', C.c_int32),
-                ('C', C.c_void_p), ('C_pre', C.c_void_p), ('accumulate', C.c_int32), ('_pad', C.c_int32)]
+                ('C', C.c_void_p), ('C_pre', C.c_void_p), ('accumulate', C.c_int32), ('_pad', C.c_int32),
+                ('splitk_ws', C.c_void_p), ('splitk_ws_floats', C.c_int64)]
 
 
 class LstmProblem(C.Structure):
@@ -33,7 +34,8 @@ class LstmProblem(C.Structure):
                 ('c_prev', C.c_void_p), ('h_out', C.c_void_p), ('c_out', C.c_void_p),
                 ('gates_out', C.c_void_p), ('h_keep_mask', C.c_void_p), ('mask_scale', C.c_float),
                 ('hdrop_out', C.c_void_p), ('pre', C.c_void_p), ('tab', C.c_void_p),
-                ('tab_ids', C.c_void_p), ('tab_ids_stride', C.c_int64)]
+                ('tab_ids', C.c_void_p), ('tab_ids_stride', C.c_int64),
+                ('splitk_ws', C.c_void_p), ('splitk_ws_floats', C.c_int64)]
 
 
 class ScanProblem(C.Structure):
@@ -66,7 +68,8 @@ class StepPlan(C.Structure):
                 _f('alpha_c_ld alpha_s_ld beta_ld', C.c_int64) +
                 [('out_mask', C.c_void_p), ('out_scale', C.c_float), ('apply_logsoftmax', C.c_int32),
                  ('hdrop', C.c_void_p), ('logits', C.c_void_p), ('ld_logits', C.c_int64),
-                 ('pmax', C.c_void_p), ('psum', C.c_void_p), ('pidx', C.c_void_p)])
+                 ('pmax', C.c_void_p), ('psum', C.c_void_p), ('pidx', C.c_void_p),
+                 ('splitk_ws', C.c_void_p), ('splitk_ws_floats', C.c_int64)])
 
 
 class StepBwdPlan(C.Structure):
@@ -77,7 +80,8 @@ class StepBwdPlan(C.Structure):
                    'alpha_c alpha_s beta', C.c_void_p) +
                 _f('alpha_c_ld alpha_s_ld beta_ld', C.c_int64) +
                 _f('dhd dG1 dG2 dG1_sum d_feat dh1 dv ds dh2_rec dh1_rec dc1_in dc2_in dc1_out dc2_out '
-                   'dqa dqw dz dP_att dV_att dP_w dV_w dwc_rows dws_rows dwg_rows dbg_rows', C.c_void_p))
+                   'dqa dqw dz dP_att dV_att dP_w dV_w dwc_rows dws_rows dwg_rows dbg_rows splitk_ws',
+                   C.c_void_p) + [('splitk_ws_floats', C.c_int64)])
 
 
 class RolloutStep(C.Structure):

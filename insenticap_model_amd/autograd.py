@@ -175,6 +175,8 @@ def _backward(cap, S, dlogp, d_fc_feats, d_cpt_feats):
     for field, t_ in (('att_p', P.att_p3), ('att_e', P.att_e3), ('words_p', P.words_p3), ('words_e', P.words_e3),
                       ('label_w', P.label_w)):
         setattr(bp, field, ptr(t_))
+    skws = ops.splitk_ws(cap._dev)
+    bp.splitk_ws, bp.splitk_ws_floats = skws.data_ptr(), skws.numel()
     bp.dG1_sum, bp.d_feat, bp.dh1 = dG1_sum.data_ptr(), d_feat.data_ptr(), dh1.data_ptr()
     bp.dh2_rec, bp.dh1_rec = dh2_rec.data_ptr(), dh1_rec.data_ptr()
     if has_c:

@@ -301,6 +301,8 @@ class Captioner(nn.Module):
             if t is not None:
                 assert t.is_contiguous()
                 setattr(pl, field, t.data_ptr())
+        ws = ops.splitk_ws(self._dev)
+        pl.splitk_ws, pl.splitk_ws_floats = ws.data_ptr(), ws.numel()
         return pl
 
     def _step(self, p, P, ws, xt, h_cur, c_cur, h_nxt, c_nxt, alpha_c=None, alpha_s=None, beta=None,

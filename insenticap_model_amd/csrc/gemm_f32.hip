@@ -56,6 +56,11 @@ struct DevProb {
     int *pidx;
     long long ld_logits;
     int tiles_m, tiles_n, tile_start, ntile_total, grp_n;
+    // split-K (small-M problems): workgroup (tile, ks) contracts chunk range ks and writes its raw
+    // partial tile to slab[ks]; a second kernel sums the slabs in order and applies the epilogue
+    int ksplit;
+    float *slab;
+    long long slab_stride;
 };
 
 struct DevLaunch {
@@ -105,7 +110,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(const DevLaunch L) {
     if (L.nprob > 1 && logical >= L.p[1].tile_start) pi = 1;
     if (L.nprob > 2 && logical >= L.p[2].tile_start) pi = 2;
     const DevProb &P = L.p[pi];
-    const int t = logical - P.tile_start;
+    int t = logical - P.tile_start;
+    const int ksplit = P.ksplit > 1 ? P.ksplit : 1;
+    const int ks = t % ksplit;
+    t /= ksplit;
     int tm, tn;
     if (P.m_fastest) {
         // weights are the larger operand: split the N tiles into 8 groups (one per XCD run) so that a
@@ -161,7 +169,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const DevLaunch L) {
 
     // Per-thread source pointers of the current K-segment, advanced by one chunk per load (keeps the
     // 64-bit address arithmetic out of the loop); `fast` tiles (interior, K % 32 == 0) load unpredicated.
-    float4 ra[A_LD], rb[B_LD];
+    // two register stages: chunk c+1 waits in one while chunk c+2 is being fetched into the other,
+    // so a global load has two compute phases (not one) to land before its LDS store needs it
+    float4 ra[2][A_LD], rb[2][B_LD];
     const float *pa[A_LD], *pb[B_LD];
     long long stepA = BK, stepB = BK;
     int cs = 0, ck = 0, segK = 0;  // segment / k-offset of the chunk being loaded
@@ -188,8 +198,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const DevLaunch L) {
             for (int i = 0; i < B_LD; ++i) pb[i] = sg.W + wrow[i] * sg.ldw + lc;
         }
     };
-    auto gload = [&](auto fastc) __attribute__((always_inline)) {
+    auto gload = [&](auto fastc, auto stagec) __attribute__((always_inline)) {
         constexpr bool FAST = decltype(fastc)::value;
+        constexpr int ST = decltype(stagec)::value;
 #pragma unroll
         for (int i = 0; i < A_LD; ++i) {
             bool ok = true;
@@ -197,7 +208,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const DevLaunch L) {
                 if constexpr (AKM) ok = a_col_ok && (ck + akr + (1024 / BM) * i) < segK;
                 else ok = aok[i] && (ck + lc) < segK;
             }
-            ra[i] = ok ? *reinterpret_cast<const float4 *>(pa[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
+            ra[ST][i] = ok ? *reinterpret_cast<const float4 *>(pa[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
             pa[i] += stepA;
         }
 #pragma unroll
@@ -207,7 +218,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const DevLaunch L) {
                 if constexpr (BKM) ok = b_col_ok && (ck + bkr + (1024 / BN) * i) < segK;
                 else ok = wok[i] && (ck + lc) < segK;
             }
-            rb[i] = ok ? *reinterpret_cast<const float4 *>(pb[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
+            rb[ST][i] = ok ? *reinterpret_cast<const float4 *>(pb[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
             pb[i] += stepB;
         }
         ck += BK;
@@ -216,26 +227,27 @@ __global__ __launch_bounds__(256) void gemm_kernel(const DevLaunch L) {
             if (++cs < P.nseg) set_seg(cs);
         }
     };
-    auto sstore = [&](int buf) __attribute__((always_inline)) {
-        float *a = As + buf * TA::SIZE;
+    auto sstore = [&](auto stagec) __attribute__((always_inline)) {
+        constexpr int ST = decltype(stagec)::value;   // register stage ST feeds LDS buffer ST
+        float *a = As + ST * TA::SIZE;
         if constexpr (AKM) {
 #pragma unroll
             for (int i = 0; i < A_LD; ++i)
-                *reinterpret_cast<float4 *>(a + (akr + (1024 / BM) * i) * (BM + 4) + akc) = ra[i];
+                *reinterpret_cast<float4 *>(a + (akr + (1024 / BM) * i) * (BM + 4) + akc) = ra[ST][i];
         } else {
 #pragma unroll
             for (int i = 0; i < A_LD; ++i)
-                *reinterpret_cast<float4 *>(a + (lr + 32 * i) * LDT + lc) = ra[i];
+                *reinterpret_cast<float4 *>(a + (lr + 32 * i) * LDT + lc) = ra[ST][i];
         }
-        float *b = Bs + buf * TB::SIZE;
+        float *b = Bs + ST * TB::SIZE;
         if constexpr (BKM) {
 #pragma unroll
             for (int i = 0; i < B_LD; ++i)
-                *reinterpret_cast<float4 *>(b + (bkr + (1024 / BN) * i) * (BN + 4) + bkc) = rb[i];
+                *reinterpret_cast<float4 *>(b + (bkr + (1024 / BN) * i) * (BN + 4) + bkc) = rb[ST][i];
         } else {
 #pragma unroll
             for (int i = 0; i < B_LD; ++i)
-                *reinterpret_cast<float4 *>(b + (lr + 32 * i) * LDT + lc) = rb[i];
+                *reinterpret_cast<float4 *>(b + (lr + 32 * i) * LDT + lc) = rb[ST][i];
         }
     };
 
@@ -243,45 +255,83 @@ __global__ __launch_bounds__(256) void gemm_kernel(const DevLaunch L) {
     // Per 8-deep k-block a lane holds 4 consecutive k (k0 + 4*(l>>5) + t) of its row for both
     // operands; MFMA t consumes element t, so every k is covered exactly once.
     const int frow = lane & 31, fk = (lane >> 5) * 4;
-    auto k_loop = [&](auto fastc) __attribute__((always_inline)) {
-        set_seg(0);
-        gload(fastc);
-        sstore(0);
-        __syncthreads();
-        for (int c = 0; c < nchunks; ++c) {
-            const int buf = c & 1;
-            if (c + 1 < nchunks) gload(fastc);
-            const float *at = As + buf * TA::SIZE;
-            const float *bt = Bs + buf * TB::SIZE;
+    auto compute = [&](int buf) __attribute__((always_inline)) {
+        const float *at = As + buf * TA::SIZE;
+        const float *bt = Bs + buf * TB::SIZE;
 #pragma unroll
-            for (int kb = 0; kb < BK / 8; ++kb) {
-                float a[4], b[TN][4];
-                if constexpr (AKM) {
+        for (int kb = 0; kb < BK / 8; ++kb) {
+            float a[4], b[TN][4];
+            if constexpr (AKM) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) a[e] = at[(kb * 8 + fk + e) * (BM + 4) + wm * 32 + frow];
-                } else {
-                    const float4 v = *reinterpret_cast<const float4 *>(at + (wm * 32 + frow) * LDT + kb * 8 + fk);
-                    a[0] = v.x; a[1] = v.y; a[2] = v.z; a[3] = v.w;
-                }
+                for (int e = 0; e < 4; ++e) a[e] = at[(kb * 8 + fk + e) * (BM + 4) + wm * 32 + frow];
+            } else {
+                const float4 v = *reinterpret_cast<const float4 *>(at + (wm * 32 + frow) * LDT + kb * 8 + fk);
+                a[0] = v.x; a[1] = v.y; a[2] = v.z; a[3] = v.w;
+            }
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    if constexpr (BKM) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            b[j][e] = bt[(kb * 8 + fk + e) * (BN + 4) + (wn * TN + j) * 32 + frow];
-                    } else {
-                        const float4 v = *reinterpret_cast<const float4 *>(
-                            bt + ((wn * TN + j) * 32 + frow) * LDT + kb * 8 + fk);
-                        b[j][0] = v.x; b[j][1] = v.y; b[j][2] = v.z; b[j][3] = v.w;
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
+            for (int j = 0; j < TN; ++j) {
+                if constexpr (BKM) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[j][e], acc[j], 0, 0, 0);
+                        b[j][e] = bt[(kb * 8 + fk + e) * (BN + 4) + (wn * TN + j) * 32 + frow];
+                } else {
+                    const float4 v = *reinterpret_cast<const float4 *>(
+                        bt + ((wn * TN + j) * 32 + frow) * LDT + kb * 8 + fk);
+                    b[j][0] = v.x; b[j][1] = v.y; b[j][2] = v.z; b[j][3] = v.w;
+                }
             }
-            if (c + 1 < nchunks) sstore(buf ^ 1);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[j][e], acc[j], 0, 0, 0);
+        }
+    };
+    // split-K: this workgroup's chunk range [c_lo, c_lo + nchunks) of the problem's chunk sequence
+    int c_lo = 0;
+    if (ksplit > 1) {
+        const int cps = (nchunks + ksplit - 1) / ksplit;
+        c_lo = ks * cps;
+        int mine = nchunks - c_lo;
+        nchunks = mine < 0 ? 0 : (mine < cps ? mine : cps);
+    }
+    auto k_loop = [&](auto fastc) __attribute__((always_inline)) {
+        using S0 = std::integral_constant<int, 0>;
+        using S1 = std::integral_constant<int, 1>;
+        if (nchunks == 0) return;
+        {   // position the loader on chunk c_lo
+            int skip = c_lo, si = 0;
+            for (; si < P.nseg; ++si) {
+                const int sc = (P.seg[si].K + BK - 1) / BK;
+                if (skip < sc) break;
+                skip -= sc;
+            }
+            set_seg(si);
+            cs = si;
+            ck = skip * BK;
+#pragma unroll
+            for (int i = 0; i < A_LD; ++i) pa[i] += stepA * skip;
+#pragma unroll
+            for (int i = 0; i < B_LD; ++i) pb[i] += stepB * skip;
+        }
+        gload(fastc, S0{});                       // chunk 0 -> stage 0
+        if (nchunks > 1) gload(fastc, S1{});      // chunk 1 -> stage 1
+        sstore(S0{});
+        __syncthreads();
+        for (int c = 0; c + 1 < nchunks; c += 2) {
+            // LDS[0] holds chunk c, stage 1 holds chunk c+1, stage 0 is free
+            if (c + 2 < nchunks) gload(fastc, S0{});
+            compute(0);
+            sstore(S1{});
+            __syncthreads();
+            // LDS[1] holds chunk c+1, stage 0 holds chunk c+2, stage 1 is free
+            if (c + 3 < nchunks) gload(fastc, S1{});
+            compute(1);
+            if (c + 2 < nchunks) sstore(S0{});
+            __syncthreads();
+        }
+        if (nchunks & 1) {   // odd chunk count: the last chunk sits in LDS[0]
+            compute(0);
             __syncthreads();
         }
     };
@@ -391,6 +441,17 @@ __global__ __launch_bounds__(256) void gemm_kernel(const DevLaunch L) {
         }
     __syncthreads();
 
+    if (EPI == EPI_LINEAR && ksplit > 1) {      // raw partial tile -> slab[ks] ([M,N], ld = N, N % 4 == 0)
+        float *slab = P.slab + (long long)ks * P.slab_stride;
+        for (int idx = tid; idx < BM * (BN / 4); idx += 256) {
+            const int row = idx / (BN / 4), c4 = (idx % (BN / 4)) * 4;
+            const int gm = row0 + row, gn = col0 + c4;
+            if (gm < M && gn < N)
+                *reinterpret_cast<float4 *>(slab + (long long)gm * N + gn) =
+                    *reinterpret_cast<const float4 *>(Cs + row * LDC + c4);
+        }
+        return;
+    }
     if (EPI == EPI_LINEAR) {
         const bool vec = (P.ldc & 3) == 0;
         for (int idx = tid; idx < BM * (BN / 4); idx += 256) {
@@ -462,6 +523,75 @@ __global__ __launch_bounds__(256) void gemm_kernel(const DevLaunch L) {
                 g[0] = gi; g[H] = gf; g[2 * H] = gg; g[3 * H] = go;
             }
         }
+    }
+}
+
+// ---------------------------------------------------------------- split-K reduction + epilogue
+// Sums the ksplit partial slabs in a fixed order (deterministic) and applies the epilogue the
+// single-pass kernel would have applied.  blockIdx.y = problem.
+__global__ __launch_bounds__(256) void splitk_linear_kernel(const DevLaunch L) {
+    const DevProb &P = L.p[blockIdx.y];
+    const long long n4 = (long long)P.M * (P.N >> 2);
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const int N = P.N, gm = (int)(i / (N >> 2)), gn = (int)(i % (N >> 2)) * 4;
+    const float *sl = P.slab + (long long)gm * N + gn;
+    float4 v = *reinterpret_cast<const float4 *>(sl);
+    for (int s = 1; s < P.ksplit; ++s) {
+        const float4 w = *reinterpret_cast<const float4 *>(sl + (long long)s * P.slab_stride);
+        v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+    }
+    float o[4] = {v.x, v.y, v.z, v.w}, pre[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int n = gn + e;
+        if (P.bias0) o[e] += P.bias0[n];
+        if (P.bias1) o[e] += P.bias1[n];
+        if (P.bias2) o[e] += P.bias2[n];
+        if (P.accumulate) o[e] += P.C[(long long)gm * P.ldc + n];
+        if (P.relu) o[e] = fmaxf(o[e], 0.f);
+        pre[e] = o[e];
+        if (P.mask) o[e] = o[e] * (float)P.mask[(long long)gm * N + n] * P.mask_scale;
+    }
+    float *dst = P.C + (long long)gm * P.ldc + gn;
+    if ((P.ldc & 3) == 0) {
+        *reinterpret_cast<float4 *>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+        if (P.C_pre)
+            *reinterpret_cast<float4 *>(P.C_pre + (long long)gm * P.ldc + gn) = make_float4(pre[0], pre[1], pre[2], pre[3]);
+    } else {
+        for (int e = 0; e < 4; ++e) {
+            dst[e] = o[e];
+            if (P.C_pre) P.C_pre[(long long)gm * P.ldc + gn + e] = pre[e];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void splitk_lstm_kernel(const DevLaunch L) {
+    const DevProb &P = L.p[0];
+    const int H = P.H;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)P.M * H) return;
+    const int gm = (int)(i / H), unit = (int)(i % H);
+    float g[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float *sl = P.slab + (long long)gm * 4 * H + k * H + unit;
+        float a = sl[0];
+        for (int s = 1; s < P.ksplit; ++s) a += sl[(long long)s * P.slab_stride];
+        if (P.bias0) a += P.bias0[k * H + unit] + P.bias1[k * H + unit];
+        if (P.pre) a += P.pre[(long long)gm * 4 * H + k * H + unit];
+        if (P.tab) a += P.tab[P.tab_ids[(long long)gm * P.tab_ids_stride] * 4 * H + k * H + unit];
+        g[k] = a;
+    }
+    const float gi = isc_sigmoid(g[0]), gf = isc_sigmoid(g[1]), gg = tanhf(g[2]), go = isc_sigmoid(g[3]);
+    const float c2 = gf * P.c_prev[i] + gi * gg;
+    const float h2 = go * tanhf(c2);
+    P.c_out[i] = c2;
+    P.h_out[i] = h2;
+    if (P.hmask) P.hdrop[i] = h2 * (float)P.hmask[i] * P.mask_scale;
+    if (P.gates_out) {
+        float *q = P.gates_out + (long long)gm * 4 * H + unit;
+        q[0] = gi; q[H] = gf; q[2 * H] = gg; q[3 * H] = go;
     }
 }
 
@@ -547,9 +677,53 @@ static void finish_tiling(DevLaunch &L, int tile) {
         for (int s = 0; s < p.nseg; ++s) { wbytes += (long long)p.N * p.seg[s].K; abytes += (long long)p.M * p.seg[s].K; }
         p.m_fastest = wbytes > abytes;  // partition the larger operand across XCDs
         p.grp_n = (p.tiles_n + 7) / 8;
-        start += p.tiles_m * p.tiles_n;
+        start += p.tiles_m * p.tiles_n * (p.ksplit > 1 ? p.ksplit : 1);
     }
     L.total_tiles = start;
+}
+
+// Split-K plan for launches with too few tiles to occupy the chip (small M): every workgroup would
+// otherwise walk the whole contraction serially (~0.8 us per 32-deep chunk).  Returns the split count
+// (1 = no split) and carves one [S, M, N] slab region per problem out of the caller's workspace.
+static int plan_splitk(DevLaunch &L, float *ws, long long ws_floats) {
+    if (!ws || ws_floats <= 0) return 1;
+    long long blocks = 0, need1 = 0;
+    int min_chunks = 1 << 30;
+    for (int i = 0; i < L.nprob; ++i) {
+        const DevProb &p = L.p[i];
+        if (p.N & 3) return 1;
+        blocks += (long long)((p.M + 31) / 32) * ((p.N + 127) / 128);
+        need1 += (long long)p.M * p.N;
+        int ch = 0;
+        for (int s = 0; s < p.nseg; ++s) ch += (p.seg[s].K + BK - 1) / BK;
+        if (ch < min_chunks) min_chunks = ch;
+    }
+    if (blocks >= 384) return 1;
+    long long S = 768 / blocks;
+    if (S > 16) S = 16;
+    if (S > min_chunks / 4) S = min_chunks / 4;      // keep >= 4 chunks per split
+    if (S > ws_floats / need1) S = ws_floats / need1;
+    if (S < 2) return 1;
+    float *at = ws;
+    for (int i = 0; i < L.nprob; ++i) {
+        DevProb &p = L.p[i];
+        p.ksplit = (int)S;
+        p.slab = at;
+        p.slab_stride = (long long)p.M * p.N;
+        at += S * p.slab_stride;
+    }
+    return (int)S;
+}
+
+static int launch_splitk_linear_reduce(const DevLaunch &L, hipStream_t st) {
+    long long mx = 0;
+    for (int i = 0; i < L.nprob; ++i) {
+        const long long n4 = (long long)L.p[i].M * (L.p[i].N >> 2);
+        if (n4 > mx) mx = n4;
+    }
+    hipLaunchKernelGGL(splitk_linear_kernel, dim3((unsigned)((mx + 255) / 256), L.nprob), dim3(256), 0, st, L);
+    ISC_LAUNCH_CHECK();
+    return ISC_OK;
 }
 
 extern "C" int isc_linear_fwd(const isc_linear_problem *pr, int n_prob, void *stream) {
@@ -571,9 +745,12 @@ extern "C" int isc_linear_fwd(const isc_linear_problem *pr, int n_prob, void *st
         d.mask = q.keep_mask; d.mask_scale = q.mask_scale;
         d.ldc = q.ldc; d.C = q.C; d.C_pre = q.C_pre; d.accumulate = q.accumulate;
     }
-    const int tile = pick_tile(L);
+    const int S = plan_splitk(L, pr[0].splitk_ws, pr[0].splitk_ws_floats);
+    const int tile = S > 1 ? 2 : pick_tile(L);
     finish_tiling(L, tile);
-    return launch_any<EPI_LINEAR, false, false>(L, tile, (hipStream_t)stream);
+    int rc = launch_any<EPI_LINEAR, false, false>(L, tile, (hipStream_t)stream);
+    if (rc || S == 1) return rc;
+    return launch_splitk_linear_reduce(L, (hipStream_t)stream);
 }
 
 // Backward-pass contractions on the same kernel (include/insenticap_hip.h: isc_gemm_bwd).
@@ -600,10 +777,13 @@ extern "C" int isc_gemm_bwd(const isc_linear_problem *pr, int n_prob, int layout
         d.bias0 = q.bias0; d.bias1 = q.bias1; d.bias2 = q.bias2;
         d.ldc = q.ldc; d.C = q.C; d.accumulate = q.accumulate;
     }
-    const int tile = pick_tile(L);
+    const int S = plan_splitk(L, pr[0].splitk_ws, pr[0].splitk_ws_floats);
+    const int tile = S > 1 ? 2 : pick_tile(L);
     finish_tiling(L, tile);
-    return layout == ISC_LAYOUT_NN ? launch_any<EPI_LINEAR, false, true>(L, tile, (hipStream_t)stream)
-                                   : launch_any<EPI_LINEAR, true, true>(L, tile, (hipStream_t)stream);
+    int rc = layout == ISC_LAYOUT_NN ? launch_any<EPI_LINEAR, false, true>(L, tile, (hipStream_t)stream)
+                                     : launch_any<EPI_LINEAR, true, true>(L, tile, (hipStream_t)stream);
+    if (rc || S == 1) return rc;
+    return launch_splitk_linear_reduce(L, (hipStream_t)stream);
 }
 
 extern "C" int isc_lstm_fwd(const isc_lstm_problem *q, void *stream) {
@@ -625,6 +805,17 @@ extern "C" int isc_lstm_fwd(const isc_lstm_problem *q, void *stream) {
     d.c_prev = q->c_prev; d.h_out = q->h_out; d.c_out = q->c_out; d.gates_out = q->gates_out;
     d.hmask = q->h_keep_mask; d.mask_scale = q->mask_scale; d.hdrop = q->hdrop_out;
     d.pre = q->pre; d.tab = q->tab; d.tab_ids = q->tab_ids; d.tab_ids_stride = q->tab_ids_stride;
+    const int S = plan_splitk(L, q->splitk_ws, q->splitk_ws_floats);
+    if (S > 1) {   // plain [M,4H] pre-activation slabs, then the cell update in the reduce kernel
+        finish_tiling(L, 2);
+        int rc2 = launch_any<EPI_LINEAR, false, false>(L, 2, (hipStream_t)stream);
+        if (rc2) return rc2;
+        const long long n = (long long)q->M * q->H;
+        hipLaunchKernelGGL(splitk_lstm_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                           (hipStream_t)stream, L);
+        ISC_LAUNCH_CHECK();
+        return ISC_OK;
+    }
     const int tile = pick_tile(L);
     finish_tiling(L, tile);
     return launch_any<EPI_LSTM, false, false>(L, tile, (hipStream_t)stream);

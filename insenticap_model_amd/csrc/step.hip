@@ -33,6 +33,7 @@ extern "C" int isc_step_fwd(const isc_step_plan *p, void *stream) {
         l.nseg = n; l.M = rows; l.H = H;
         l.c_prev = p->c1_prev; l.h_out = p->h1; l.c_out = p->c1; l.gates_out = p->g1;
         l.pre = p->pre1; l.tab = p->tab; l.tab_ids = p->tok; l.tab_ids_stride = p->tok_stride;
+        l.splitk_ws = p->splitk_ws; l.splitk_ws_floats = p->splitk_ws_floats;
         RET(isc_lstm_fwd(&l, stream));
     }
     // projections of h_att: h2att (content), h2word (sentiment), h2att of the gate - one launch
@@ -47,6 +48,7 @@ extern "C" int isc_step_fwd(const isc_step_plan *p, void *stream) {
         if (has_c) lin(p->W_h2att, p->b_h2att, p->qa);
         if (has_s) lin(p->W_h2word, p->b_h2word, p->qw);
         if (gate) lin(p->W_gh, p->b_gh, p->z);
+        q[0].splitk_ws = p->splitk_ws; q[0].splitk_ws_floats = p->splitk_ws_floats;
         RET(isc_linear_fwd(q, n, stream));
     }
     // attention scans (captioner.py:23-35, 50-62)
@@ -73,6 +75,7 @@ extern "C" int isc_step_fwd(const isc_step_plan *p, void *stream) {
         x.seg[1] = seg(p->s, W, p->W_gs, W, W);
         x.nseg = 2; x.M = rows; x.N = A; x.bias0 = p->b_gc; x.bias1 = p->b_gs; x.ldc = A; x.C = p->z;
         x.accumulate = 1;
+        x.splitk_ws = p->splitk_ws; x.splitk_ws_floats = p->splitk_ws_floats;
         RET(isc_linear_fwd(&x, 1, stream));
         RET(isc_gate_mix_fwd(p->z, p->w_gate, p->b_gate, p->v, p->s, rows, A, E, p->f, p->beta, p->beta_ld, stream));
         feat = p->f;
@@ -86,6 +89,7 @@ extern "C" int isc_step_fwd(const isc_step_plan *p, void *stream) {
         l.nseg = 3; l.M = rows; l.H = H; l.b_ih = p->b_ih2; l.b_hh = p->b_hh2;
         l.c_prev = p->c2_prev; l.h_out = p->h2; l.c_out = p->c2; l.gates_out = p->g2;
         l.h_keep_mask = p->out_mask; l.mask_scale = p->out_scale; l.hdrop_out = p->hdrop;
+        l.splitk_ws = p->splitk_ws; l.splitk_ws_floats = p->splitk_ws_floats;
         RET(isc_lstm_fwd(&l, stream));
     }
     // classifier + log-softmax statistics (captioner.py:183)
@@ -120,6 +124,7 @@ extern "C" int isc_step_bwd(const isc_step_bwd_plan *p, void *stream) {
         isc_linear_problem q[3] = {nn_problem(p->dG2, G, p->Wih2, ld2, G, rows, E, p->d_feat, 0),
                                    nn_problem(p->dG2, G, p->Wih2 + E, ld2, G, rows, H, p->dh1, 0),
                                    nn_problem(p->dG2, G, p->Whh2, H, G, rows, H, p->dh2_rec, 0)};
+        q[0].splitk_ws = p->splitk_ws; q[0].splitk_ws_floats = p->splitk_ws_floats;
         RET(isc_gemm_bwd(q, 3, ISC_LAYOUT_NN, stream));
     }
     const float *dv = p->d_feat, *dsw = p->d_feat;
@@ -129,6 +134,7 @@ extern "C" int isc_step_bwd(const isc_step_bwd_plan *p, void *stream) {
         isc_linear_problem q[3] = {nn_problem(p->dz, A, p->W_gc, E, A, rows, E, p->dv, 1),
                                    nn_problem(p->dz, A, p->W_gs, W, A, rows, W, p->ds, 1),
                                    nn_problem(p->dz, A, p->W_gh, H, A, rows, H, p->dh1, 1)};
+        q[0].splitk_ws = p->splitk_ws; q[0].splitk_ws_floats = p->splitk_ws_floats;
         RET(isc_gemm_bwd(q, 3, ISC_LAYOUT_NN, stream));
         dv = p->dv;
         dsw = p->ds;
@@ -156,6 +162,7 @@ extern "C" int isc_step_bwd(const isc_step_bwd_plan *p, void *stream) {
         if (has_c) x.seg[n++] = seg(p->dqa, A, p->W_h2att, H, A);
         if (has_s) x.seg[n++] = seg(p->dqw, A, p->W_h2word, H, A);
         x.nseg = n; x.M = rows; x.N = H; x.ldc = H; x.C = p->dh1; x.accumulate = 1;
+        x.splitk_ws = p->splitk_ws; x.splitk_ws_floats = p->splitk_ws_floats;
         RET(isc_gemm_bwd(&x, 1, ISC_LAYOUT_NN, stream));
     }
     // att-LSTM cell
@@ -164,6 +171,7 @@ extern "C" int isc_step_bwd(const isc_step_bwd_plan *p, void *stream) {
     if (!p->last) {  // recurrent gradients for step t-1
         isc_linear_problem q[2] = {nn_problem(p->dG1, G, p->Wih1, ld1, G, rows, H, p->dh2_rec, 1),
                                    nn_problem(p->dG1, G, p->Whh1, H, G, rows, H, p->dh1_rec, 0)};
+        q[0].splitk_ws = p->splitk_ws; q[0].splitk_ws_floats = p->splitk_ws_floats;
         RET(isc_gemm_bwd(q, 2, ISC_LAYOUT_NN, stream));
     }
     return ISC_OK;

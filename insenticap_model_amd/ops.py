@@ -56,6 +56,26 @@ def _seg_k(segs):
     return sum(a.shape[1] for a, _ in segs)
 
 
+_SPLITK_WS = {}
+SPLITK_WS_FLOATS = 16 * 1024 * 1024     # 64 MB per device: [ksplit, M, N] partial slabs of small-M GEMMs
+
+
+def splitk_ws(device=None):
+    """Per-device split-K workspace (allocated once; kernels on one stream use it one after another)."""
+    device = torch.device(device if device is not None else torch.cuda.current_device())
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    ws = _SPLITK_WS.get(key)
+    if ws is None:
+        ws = _SPLITK_WS[key] = torch.empty(SPLITK_WS_FLOATS, dtype=torch.float32, device=device)
+    return ws
+
+
+def _attach_ws(problem, like_ptr_device):
+    if not problem.splitk_ws:
+        ws = splitk_ws(like_ptr_device)
+        problem.splitk_ws, problem.splitk_ws_floats = ws.data_ptr(), ws.numel()
+
+
 def ptr(t):
     return None if t is None else t.data_ptr()
 
@@ -103,6 +123,7 @@ def linear_problem(segs, out, bias0=None, bias1=None, bias2=None, relu=False, ke
 
 def linear_fwd(problems):
     lib = _lib.load()
+    _attach_ws(problems[0], torch.cuda.current_device())
     arr = (LinearProblem * len(problems))(*problems)
     e0 = TIMER.begin()
     check(lib.isc_linear_fwd(arr, len(problems), stream()), 'isc_linear_fwd')
@@ -132,6 +153,7 @@ def lstm_fwd(segs, b_ih, b_hh, c_prev, h_out, c_out, gates_out=None, h_keep_mask
     p.h_keep_mask = ptr(h_keep_mask)
     p.mask_scale = mask_scale
     p.hdrop_out = ptr(hdrop_out)
+    _attach_ws(p, c_prev.device)
     e0 = TIMER.begin()
     check(lib.isc_lstm_fwd(C.byref(p), stream()), 'isc_lstm_fwd')
     if e0 is not None:
@@ -296,6 +318,7 @@ def gemm_problem(segs, out, layout, accumulate=False, bias0=None):
 
 def gemm_bwd(problems, layout):
     lib = _lib.load()
+    _attach_ws(problems[0], torch.cuda.current_device())
     arr = (LinearProblem * len(problems))(*problems)
     e0 = TIMER.begin()
     check(lib.isc_gemm_bwd(arr, len(problems), layout, stream()), 'isc_gemm_bwd')
