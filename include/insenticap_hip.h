@@ -326,8 +326,10 @@ int isc_embed_relu_bwd(const float *emb, int V, int W, const int64_t *ids, int64
                        float scale, const uint8_t *keep_mask, float mask_scale, float *demb,
                        void *stream);
 
-/* out[n] (+)= sum_m x[m,n]  (bias gradients) */
-int isc_colsum(const float *x, int64_t ld, int M, int N, float *out, int accumulate, void *stream);
+/* out[n] (+)= sum_m x[m,n]  (bias gradients). With a workspace of >= 64*N floats tall matrices are
+ * summed in two deterministic stages (row chunks in parallel, then the chunks in order). */
+int isc_colsum(const float *x, int64_t ld, int M, int N, float *out, int accumulate, float *workspace,
+               int64_t workspace_floats, void *stream);
 
 /* dz = dy * (y > 0) [* mask * scale]  (ReLU + Dropout backward of the prologue layers);
  * y == NULL skips the ReLU test (pure nn.Dropout backward, captioner.py:182). */

@@ -90,10 +90,13 @@ struct DevScanBwdLaunch {
 };
 
 // One workgroup per (row, problem).  LDS: da[R] (d alpha -> d e), red[ngrp][A] x2 for dq / dw.
-__global__ __launch_bounds__(256) void attn_scan_bwd_kernel(const DevScanBwdLaunch L) {
+// Launched with 1024 threads (16 wavefronts): at B=128 there are only 128 rows, so the parallelism has
+// to come from inside the row.
+__global__ __launch_bounds__(1024) void attn_scan_bwd_kernel(const DevScanBwdLaunch L) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const DevScanBwd &S = L.p[blockIdx.y];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int NT = blockDim.x, NW = NT >> 6;
     const int R = S.R, A = S.A, D = S.D;
     float *de = smem;                         // [R]
     float *red = smem + ((R + 3) & ~3);       // [2][ngrp][A]
@@ -103,7 +106,7 @@ __global__ __launch_bounds__(256) void attn_scan_bwd_kernel(const DevScanBwdLaun
     const float *alpha = S.alpha + (long long)b * S.alpha_ld;
 
     // d alpha_r = dout . V[r]
-    for (int r = wave; r < R; r += 4) {
+    for (int r = wave; r < R; r += NW) {
         float acc = 0.f;
         for (int d = lane; d < D; d += 64) acc += dout[d] * Vb[(long long)r * D + d];
         acc = wave_sum(acc);
@@ -113,21 +116,27 @@ __global__ __launch_bounds__(256) void attn_scan_bwd_kernel(const DevScanBwdLaun
     float s = 0.f;
     for (int r = 0; r < R; ++r) s += alpha[r] * de[r];
     __syncthreads();
-    for (int r = tid; r < R; r += 256) de[r] = alpha[r] * (de[r] - s);   // d e_r (softmax backward)
+    for (int r = tid; r < R; r += NT) de[r] = alpha[r] * (de[r] - s);   // d e_r (softmax backward)
     __syncthreads();
 
     // dV[r,:] (+)= alpha_r * dout
     float *dVb = S.dV + (long long)b * R * D;
-    for (int i = tid; i < R * D; i += 256) {
-        const int r = i / D, d = i % D;
-        const float v = alpha[r] * dout[d];
-        dVb[i] = S.accumulate ? dVb[i] + v : v;
+    {
+        const int dgrp = NT / D > 0 ? NT / D : 1;       // row groups working in parallel (D <= NT)
+        for (int d = tid % D; d < D; d += NT) {          // D > NT: strided columns
+            const float g = dout[d];
+            for (int r = (D <= NT ? tid / D : 0); r < R; r += dgrp) {
+                const long long o = (long long)r * D + d;
+                const float v = alpha[r] * g;
+                dVb[o] = S.accumulate ? dVb[o] + v : v;
+            }
+        }
     }
     // dP[r,a] (+)= de_r * w[a] * (1 - tanh^2);  dq[a] = sum_r (...);  dw_rows[b,a] += sum_r de_r * tanh
     float *dPb = S.dP + (long long)b * R * A;
-    const int ngrp = (A <= 256) ? 256 / A : 1;   // region groups working in parallel
-    const int a0 = (A <= 256) ? tid % A : tid, grp = (A <= 256) ? tid / A : 0;
-    for (int a = a0; a < A; a += (A <= 256 ? A : 256)) {
+    const int ngrp = (A <= NT) ? NT / A : 1;   // region groups working in parallel
+    const int a0 = (A <= NT) ? tid % A : tid, grp = (A <= NT) ? tid / A : 0;
+    for (int a = a0; a < A; a += (A <= NT ? A : NT)) {
         const float qa = S.q[(long long)b * A + a] + (S.q2 ? S.q2[(long long)b * A + a] : 0.f);
         const float wa = S.w[a];
         float dq = 0.f, dw = 0.f;
@@ -145,7 +154,7 @@ __global__ __launch_bounds__(256) void attn_scan_bwd_kernel(const DevScanBwdLaun
         }
     }
     __syncthreads();
-    for (int a = tid; a < A; a += 256) {
+    for (int a = tid; a < A; a += NT) {
         float dq = 0.f, dw = 0.f;
         for (int g = 0; g < ngrp; ++g) { dq += red[g * A + a]; dw += red[(ngrp + g) * A + a]; }
         S.dq[(long long)b * A + a] = dq;
@@ -164,19 +173,19 @@ extern "C" int isc_attn_scan_bwd(const isc_scan_bwd_problem *pr, int n_prob, int
         if (!q.P || !q.V || !q.q || !q.w || !q.alpha || !q.dout || !q.dP || !q.dV || !q.dq || !q.dw_rows)
             return ISC_E_NULL;
         if (q.R <= 0 || q.A <= 0 || q.D <= 0 || q.A > 1024) return ISC_E_SHAPE;
-        if (q.A > 256 && (q.A % 256) != 0) return ISC_E_SHAPE;
-        if (q.A <= 256 && (256 % q.A) != 0) return ISC_E_SHAPE;
+        if (q.A > 1024 || (1024 % q.A) != 0) return ISC_E_SHAPE;
+        if (q.D > 1024 || (1024 % q.D) != 0) return ISC_E_SHAPE;
         DevScanBwd &d = L.p[i];
         d.P = q.P; d.V = q.V; d.q = q.q; d.q2 = q.q2; d.w = q.w; d.alpha = q.alpha; d.dout = q.dout;
         d.alpha_ld = q.alpha_ld; d.R = q.R; d.A = q.A; d.D = q.D; d.accumulate = q.accumulate;
         d.dP = q.dP; d.dV = q.dV; d.dq = q.dq; d.dw_rows = q.dw_rows;
-        const int ngrp = q.A <= 256 ? 256 / q.A : 1;
+        const int ngrp = 1024 / q.A;
         const size_t need = (((size_t)q.R + 3) & ~(size_t)3) + (size_t)2 * ngrp * q.A;
         if (need > lds) lds = need;
     }
     lds *= sizeof(float);
     if (lds > 60000) return ISC_E_SHAPE;
-    hipLaunchKernelGGL(attn_scan_bwd_kernel, dim3(B, n_prob), dim3(256), lds, (hipStream_t)stream, L);
+    hipLaunchKernelGGL(attn_scan_bwd_kernel, dim3(B, n_prob), dim3(1024), lds, (hipStream_t)stream, L);
     ISC_LAUNCH_CHECK();
     return ISC_OK;
 }
@@ -283,12 +292,44 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float *x, long long l
     }
 }
 
+// Tall matrices: stage 1 sums row chunks in parallel into part[chunk][N], stage 2 (the kernel above on the
+// [chunks, N] partials) finishes in chunk order - deterministic, and no workgroup walks thousands of rows.
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float *x, long long ld, int M, int N,
+                                                             int rows_per_chunk, float *part) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + lane;
+    const int m0 = blockIdx.y * rows_per_chunk;
+    int m1 = m0 + rows_per_chunk;
+    if (m1 > M) m1 = M;
+    float s = 0.f;
+    if (n < N)
+        for (int m = m0 + grp; m < m1; m += 4) s += x[(long long)m * ld + n];
+    red[grp][lane] = s;
+    __syncthreads();
+    if (grp == 0 && n < N)
+        part[(long long)blockIdx.y * N + n] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+}
+
 extern "C" int isc_colsum(const float *x, int64_t ld, int M, int N, float *out, int accumulate,
-                          void *stream) {
+                          float *workspace, int64_t workspace_floats, void *stream) {
     if (!x || !out) return ISC_E_NULL;
     if (M <= 0 || N <= 0) return ISC_E_SHAPE;
-    hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64), dim3(256), 0, (hipStream_t)stream, x,
-                       (long long)ld, M, N, out, accumulate);
+    hipStream_t st = (hipStream_t)stream;
+    int chunks = (M + 63) / 64;
+    if (chunks > 64) chunks = 64;
+    if (workspace && M >= 256 && (int64_t)chunks * N <= workspace_floats) {
+        const int rpc = (M + chunks - 1) / chunks;
+        chunks = (M + rpc - 1) / rpc;
+        hipLaunchKernelGGL(colsum_partial_kernel, dim3((N + 63) / 64, chunks), dim3(256), 0, st, x, (long long)ld, M,
+                           N, rpc, workspace);
+        ISC_LAUNCH_CHECK();
+        hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64), dim3(256), 0, st, workspace, (long long)N, chunks, N,
+                           out, accumulate);
+    } else {
+        hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64), dim3(256), 0, st, x, (long long)ld, M, N, out,
+                           accumulate);
+    }
     ISC_LAUNCH_CHECK();
     return ISC_OK;
 }

@@ -395,8 +395,9 @@ def colsum(x, out, accumulate=False):
     lib = _lib.load()
     M, N = x.shape
     assert x.stride(1) == 1 and out.is_contiguous() and out.numel() >= N
-    check(lib.isc_colsum(x.data_ptr(), x.stride(0), M, N, out.data_ptr(), int(accumulate), stream()),
-          'isc_colsum')
+    ws = splitk_ws(x.device)
+    check(lib.isc_colsum(x.data_ptr(), x.stride(0), M, N, out.data_ptr(), int(accumulate), ws.data_ptr(),
+                         ws.numel(), stream()), 'isc_colsum')
 
 
 def relu_mask_bwd(dy, y, dz, keep_mask=None, scale=1.0):
