@@ -230,14 +230,31 @@ def roofline_entry(name, rec):
 
 def main():
     args = parse()
+    # stdout must carry exactly ONE JSON line: send everything libraries print (RCCL's version banner,
+    # MIOpen notices ...) to stderr until the result is ready
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        line = run(args)
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        os.close(saved_stdout)
+    if line is not None:
+        print(line, flush=True)
+
+
+def run(args):
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
-    if world > 1:
+    under_launcher = 'RANK' in os.environ and 'MASTER_ADDR' in os.environ
+    if world > 1 or under_launcher:      # torchrun (also with one rank: exercises the RCCL path)
         import torch.distributed as dist
         torch.cuda.set_device(local)
         dist.init_process_group('nccl', device_id=torch.device('cuda', local))
-    dev = torch.device('cuda', local if world > 1 else 0)
+    dev = torch.device('cuda', local if (world > 1 or under_launcher) else 0)
     torch.cuda.set_device(dev)
     B = args.batch
 
@@ -248,7 +265,7 @@ def main():
     inputs, _ = device_inputs(B, 100 + rank, dev)
 
     def barrier():
-        if world > 1:
+        if world > 1 or under_launcher:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -264,7 +281,7 @@ def main():
         barrier()
         el = time.perf_counter() - t0
     ops.TIMER.arm_step = None
-    if world > 1:
+    if world > 1 or under_launcher:
         tt = torch.tensor([el], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         el = float(tt)
@@ -285,9 +302,8 @@ def main():
             except Exception as e:  # noqa: BLE001
                 extra['rl_iteration'] = {'error': repr(e)[:300]}
     if rank != 0:
-        if world > 1:
-            torch.distributed.destroy_process_group()
-        return
+        torch.distributed.destroy_process_group()
+        return None
 
     total = world * B * args.steps
     summ = ops.TIMER.summary()
@@ -318,9 +334,9 @@ def main():
     }
     if not args.no_cpu_baseline and world == 1:
         out['cpu_baseline'] = cpu_baseline(weights, args.cpu_seconds)
-    print(json.dumps(out))
-    if world > 1:
+    if world > 1 or under_launcher:
         torch.distributed.destroy_process_group()
+    return json.dumps(out)
 
 
 if __name__ == '__main__':
