@@ -463,7 +463,47 @@ def case_detector():
     print('detector: %d arrays' % len(out))
 
 
-CASES = {'tiny': case_tiny, 'cfg1': case_cfg1, 'b128': case_b128, 'cider': case_cider, 'detector': case_detector}
+def case_checkpoint():
+    """A checkpoint file exactly as train_xe.py:241-254 writes it (tiny model, after one training step with
+    the reference's Adam), plus the parameters the reference reaches after a SECOND step from that state:
+    the build must load the file (model + optimizer) and reproduce step two."""
+    V, st, seed = 64, synth.TINY_SETTINGS, 1
+    d = synth.make_inputs(6, V, st, regions=6, seq_len=8, seed=11)
+    s2s = synth.make_inputs(4, V, st, regions=6, seq_len=8, seed=12)
+    cap = build_reference(V, st, seed)
+    cap.eval()
+    optim, xe_crit, da_crit = cap.get_optim_criterion(4e-4)
+
+    def step():
+        fc, att, cpt, caps, lab = T(d, 'fc_feats', 'att_feats', 'cpt_words', 'captions', 'senti_labels')
+        pred = cap(fc, att, cpt, caps, lab, 0.0, mode='xe')
+        loss = xe_crit(pred, caps[:, 1:], d['lengths']) + da_crit(cap.cpt_feats, cap.fc_feats.detach())
+        scaps, scpt, ssw, slab = T(s2s, 'captions', 'cpt_words', 'senti_words', 'senti_labels')
+        pred2 = cap(scaps, scpt, ssw, slab, 0.0, mode='seq2seq')
+        loss = loss + xe_crit(pred2, scaps[:, 1:], s2s['lengths'])
+        optim.zero_grad()
+        loss.backward()
+        for group in optim.param_groups:
+            for prm in group['params']:
+                if prm.grad is not None:
+                    prm.grad.data.clamp_(-0.1, 0.1)
+        optim.step()
+        return float(loss.detach())
+    l1 = step()
+    chk = {'epoch': 7, 'model': cap.state_dict(), 'optimizer': optim.state_dict(), 'settings': dict(st),
+           'idx2word': synth.make_idx2word(V), 'sentiment_categories': list(synth.SENTIMENT_CATEGORIES),
+           'dataset_name': 'coco', 'corpus_type': 'part'}
+    torch.save(chk, os.path.join(HERE, 'ref_xe_checkpoint_tiny.pth'))
+    l2 = step()
+    out = {'loss1': np.array([l1]), 'loss2': np.array([l2])}
+    for k, v in cap.state_dict().items():
+        out['after2/' + k] = v.detach().numpy().copy()
+    np.savez_compressed(os.path.join(HERE, 'checkpoint.npz'), **out)
+    print('checkpoint: %d arrays' % len(out))
+
+
+CASES = {'tiny': case_tiny, 'cfg1': case_cfg1, 'b128': case_b128, 'cider': case_cider, 'detector': case_detector,
+         'checkpoint': case_checkpoint}
 
 if __name__ == '__main__':
     which = sys.argv[1:] or list(CASES)
