@@ -169,9 +169,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(const DevLaunch L) {
 
     // Per-thread source pointers of the current K-segment, advanced by one chunk per load (keeps the
     // 64-bit address arithmetic out of the loop); `fast` tiles (interior, K % 32 == 0) load unpredicated.
-    // two register stages: chunk c+1 waits in one while chunk c+2 is being fetched into the other,
-    // so a global load has two compute phases (not one) to land before its LDS store needs it
-    float4 ra[2][A_LD], rb[2][B_LD];
+    // One register stage: chunk c+1 waits in it while chunk c is being contracted, is written to the
+    // other LDS buffer in the middle of that contraction, and the stage is re-armed with chunk c+2 at
+    // once - so a global load has a whole chunk of MFMAs (~4k cycles) to land.
+    float4 ra[A_LD], rb[B_LD];
     const float *pa[A_LD], *pb[B_LD];
     long long stepA = BK, stepB = BK;
     int cs = 0, ck = 0, segK = 0;  // segment / k-offset of the chunk being loaded
@@ -198,9 +199,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const DevLaunch L) {
             for (int i = 0; i < B_LD; ++i) pb[i] = sg.W + wrow[i] * sg.ldw + lc;
         }
     };
-    auto gload = [&](auto fastc, auto stagec) __attribute__((always_inline)) {
+    auto gload = [&](auto fastc) __attribute__((always_inline)) {
         constexpr bool FAST = decltype(fastc)::value;
-        constexpr int ST = decltype(stagec)::value;
 #pragma unroll
         for (int i = 0; i < A_LD; ++i) {
             bool ok = true;
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const DevLaunch L) {
                 if constexpr (AKM) ok = a_col_ok && (ck + akr + (1024 / BM) * i) < segK;
                 else ok = aok[i] && (ck + lc) < segK;
             }
-            ra[ST][i] = ok ? *reinterpret_cast<const float4 *>(pa[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
+            ra[i] = ok ? *reinterpret_cast<const float4 *>(pa[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
             pa[i] += stepA;
         }
 #pragma unroll
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const DevLaunch L) {
                 if constexpr (BKM) ok = b_col_ok && (ck + bkr + (1024 / BN) * i) < segK;
                 else ok = wok[i] && (ck + lc) < segK;
             }
-            rb[ST][i] = ok ? *reinterpret_cast<const float4 *>(pb[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
+            rb[i] = ok ? *reinterpret_cast<const float4 *>(pb[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
             pb[i] += stepB;
         }
         ck += BK;
@@ -227,65 +227,70 @@ __global__ __launch_bounds__(256) void gemm_kernel(const DevLaunch L) {
             if (++cs < P.nseg) set_seg(cs);
         }
     };
-    auto sstore = [&](auto stagec) __attribute__((always_inline)) {
-        constexpr int ST = decltype(stagec)::value;   // register stage ST feeds LDS buffer ST
-        float *a = As + ST * TA::SIZE;
+    auto sstore = [&](auto bufc) __attribute__((always_inline)) {
+        constexpr int BUF = decltype(bufc)::value;
+        float *a = As + BUF * TA::SIZE;
         if constexpr (AKM) {
 #pragma unroll
             for (int i = 0; i < A_LD; ++i)
-                *reinterpret_cast<float4 *>(a + (akr + (1024 / BM) * i) * (BM + 4) + akc) = ra[ST][i];
+                *reinterpret_cast<float4 *>(a + (akr + (1024 / BM) * i) * (BM + 4) + akc) = ra[i];
         } else {
 #pragma unroll
             for (int i = 0; i < A_LD; ++i)
-                *reinterpret_cast<float4 *>(a + (lr + 32 * i) * LDT + lc) = ra[ST][i];
+                *reinterpret_cast<float4 *>(a + (lr + 32 * i) * LDT + lc) = ra[i];
         }
-        float *b = Bs + ST * TB::SIZE;
+        float *b = Bs + BUF * TB::SIZE;
         if constexpr (BKM) {
 #pragma unroll
             for (int i = 0; i < B_LD; ++i)
-                *reinterpret_cast<float4 *>(b + (bkr + (1024 / BN) * i) * (BN + 4) + bkc) = rb[ST][i];
+                *reinterpret_cast<float4 *>(b + (bkr + (1024 / BN) * i) * (BN + 4) + bkc) = rb[i];
         } else {
 #pragma unroll
             for (int i = 0; i < B_LD; ++i)
-                *reinterpret_cast<float4 *>(b + (lr + 32 * i) * LDT + lc) = rb[ST][i];
+                *reinterpret_cast<float4 *>(b + (lr + 32 * i) * LDT + lc) = rb[i];
         }
     };
 
     // MFMA 32x32x2 operand maps: lane l supplies A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31].
     // Per 8-deep k-block a lane holds 4 consecutive k (k0 + 4*(l>>5) + t) of its row for both
     // operands; MFMA t consumes element t, so every k is covered exactly once.
+    // Two fragment register sets: while the MFMAs of k-block kb run from one set, the fragments of
+    // kb+1 (or of the next chunk's first k-block, after the barrier) are read into the other, so the
+    // matrix pipe never waits for an LDS round trip - not even across a chunk boundary.
+    static_assert(BK == 32, "the chunk body below is written for 4 k-blocks of 8");
     const int frow = lane & 31, fk = (lane >> 5) * 4;
-    auto compute = [&](int buf) __attribute__((always_inline)) {
-        const float *at = As + buf * TA::SIZE;
-        const float *bt = Bs + buf * TB::SIZE;
+    float fa[2][4], fb[2][TN][4];
+    auto lfrag = [&](auto bufc, auto kbc, auto setc) __attribute__((always_inline)) {
+        constexpr int BUF = decltype(bufc)::value, kb = decltype(kbc)::value, ST = decltype(setc)::value;
+        const float *at = As + BUF * TA::SIZE;
+        const float *bt = Bs + BUF * TB::SIZE;
+        if constexpr (AKM) {
 #pragma unroll
-        for (int kb = 0; kb < BK / 8; ++kb) {
-            float a[4], b[TN][4];
-            if constexpr (AKM) {
+            for (int e = 0; e < 4; ++e) fa[ST][e] = at[(kb * 8 + fk + e) * (BM + 4) + wm * 32 + frow];
+        } else {
+            const float4 v = *reinterpret_cast<const float4 *>(at + (wm * 32 + frow) * LDT + kb * 8 + fk);
+            fa[ST][0] = v.x; fa[ST][1] = v.y; fa[ST][2] = v.z; fa[ST][3] = v.w;
+        }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) a[e] = at[(kb * 8 + fk + e) * (BM + 4) + wm * 32 + frow];
-            } else {
-                const float4 v = *reinterpret_cast<const float4 *>(at + (wm * 32 + frow) * LDT + kb * 8 + fk);
-                a[0] = v.x; a[1] = v.y; a[2] = v.z; a[3] = v.w;
-            }
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                if constexpr (BKM) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        b[j][e] = bt[(kb * 8 + fk + e) * (BN + 4) + (wn * TN + j) * 32 + frow];
-                } else {
-                    const float4 v = *reinterpret_cast<const float4 *>(
-                        bt + ((wn * TN + j) * 32 + frow) * LDT + kb * 8 + fk);
-                    b[j][0] = v.x; b[j][1] = v.y; b[j][2] = v.z; b[j][3] = v.w;
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
+        for (int j = 0; j < TN; ++j) {
+            if constexpr (BKM) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[j][e], acc[j], 0, 0, 0);
+                    fb[ST][j][e] = bt[(kb * 8 + fk + e) * (BN + 4) + (wn * TN + j) * 32 + frow];
+            } else {
+                const float4 v = *reinterpret_cast<const float4 *>(
+                    bt + ((wn * TN + j) * 32 + frow) * LDT + kb * 8 + fk);
+                fb[ST][j][0] = v.x; fb[ST][j][1] = v.y; fb[ST][j][2] = v.z; fb[ST][j][3] = v.w;
+            }
         }
+    };
+    auto mma = [&](auto setc) __attribute__((always_inline)) {
+        constexpr int ST = decltype(setc)::value;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[ST][e], fb[ST][j][e], acc[j], 0, 0, 0);
     };
     // split-K: this workgroup's chunk range [c_lo, c_lo + nchunks) of the problem's chunk sequence
     int c_lo = 0;
@@ -295,9 +300,30 @@ __global__ __launch_bounds__(256) void gemm_kernel(const DevLaunch L) {
         int mine = nchunks - c_lo;
         nchunks = mine < 0 ? 0 : (mine < cps ? mine : cps);
     }
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>;
+    // One chunk: LDS[CUR] holds it and fragment set 0 its first k-block; the register stage holds
+    // chunk c+1 (if any).  Exactly one barrier per chunk, placed in front of the last k-block's MFMAs.
+    auto chunk_body = [&](auto curc, auto nxtc, auto fastc, bool has1, bool has2) __attribute__((always_inline)) {
+        lfrag(curc, I1{}, I1{});
+        mma(I0{});
+        if (has1) {
+            sstore(nxtc);                 // LDS[NXT] was last read before the previous chunk's barrier
+            if (has2) gload(fastc);
+        }
+        lfrag(curc, I2{}, I0{});
+        mma(I1{});
+        lfrag(curc, I3{}, I1{});
+        mma(I0{});
+        if (has1) {
+            __syncthreads();              // every wave's stores of chunk c+1 have landed
+            lfrag(nxtc, I0{}, I0{});
+        }
+        mma(I1{});
+    };
     auto k_loop = [&](auto fastc) __attribute__((always_inline)) {
-        using S0 = std::integral_constant<int, 0>;
-        using S1 = std::integral_constant<int, 1>;
         if (nchunks == 0) return;
         {   // position the loader on chunk c_lo
             int skip = c_lo, si = 0;
@@ -314,26 +340,16 @@ __global__ __launch_bounds__(256) void gemm_kernel(const DevLaunch L) {
 #pragma unroll
             for (int i = 0; i < B_LD; ++i) pb[i] += stepB * skip;
         }
-        gload(fastc, S0{});                       // chunk 0 -> stage 0
-        if (nchunks > 1) gload(fastc, S1{});      // chunk 1 -> stage 1
-        sstore(S0{});
+        gload(fastc);                             // chunk 0
+        sstore(I0{});
+        if (nchunks > 1) gload(fastc);            // chunk 1 -> register stage
         __syncthreads();
-        for (int c = 0; c + 1 < nchunks; c += 2) {
-            // LDS[0] holds chunk c, stage 1 holds chunk c+1, stage 0 is free
-            if (c + 2 < nchunks) gload(fastc, S0{});
-            compute(0);
-            sstore(S1{});
-            __syncthreads();
-            // LDS[1] holds chunk c+1, stage 0 holds chunk c+2, stage 1 is free
-            if (c + 3 < nchunks) gload(fastc, S1{});
-            compute(1);
-            if (c + 2 < nchunks) sstore(S0{});
-            __syncthreads();
+        lfrag(I0{}, I0{}, I0{});
+        for (int c = 0; c < nchunks; c += 2) {
+            chunk_body(I0{}, I1{}, fastc, c + 1 < nchunks, c + 2 < nchunks);
+            if (c + 1 < nchunks) chunk_body(I1{}, I0{}, fastc, c + 2 < nchunks, c + 3 < nchunks);
         }
-        if (nchunks & 1) {   // odd chunk count: the last chunk sits in LDS[0]
-            compute(0);
-            __syncthreads();
-        }
+        __syncthreads();                          // the epilogue re-uses the operand buffers
     };
     bool fast = (row0 + BM <= M) && (EPI == EPI_LSTM || col0 + BN <= N);
     for (int si = 0; si < P.nseg; ++si) fast = fast && (P.seg[si].K % BK) == 0;
