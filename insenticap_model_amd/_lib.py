@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libinsenticap_hip.so')
+LIB_PATH = os.environ.get('ISC_HIP_LIB') or os.path.join(_HERE, 'lib', 'libinsenticap_hip.so')
 
 ISC_MAX_SEG = 4
 
@@ -99,6 +99,7 @@ class RolloutStep(C.Structure):
 SIGNATURES = {
     'isc_abi_version': (C.c_int, []),
     'isc_target_arch': (C.c_char_p, []),
+    'isc_set_tile_override': (C.c_int, [C.c_int]),
     'isc_linear_fwd': (C.c_int, [C.POINTER(LinearProblem), C.c_int, C.c_void_p]),
     'isc_gemm_bwd': (C.c_int, [C.POINTER(LinearProblem), C.c_int, C.c_int, C.c_void_p]),
     'isc_lstm_fwd': (C.c_int, [C.POINTER(LstmProblem), C.c_void_p]),

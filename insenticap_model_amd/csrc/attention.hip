@@ -60,10 +60,10 @@ __global__ __launch_bounds__(256) void attn_scan_kernel(const DevScanLaunch L) {
             const int a4 = lane + 64 * i;
             if (a4 < na4) {
                 const float4 p = Pb[(long long)r * na4 + a4];
-                acc += wv[i].x * tanhf(p.x + qv[i].x);
-                acc += wv[i].y * tanhf(p.y + qv[i].y);
-                acc += wv[i].z * tanhf(p.z + qv[i].z);
-                acc += wv[i].w * tanhf(p.w + qv[i].w);
+                acc += wv[i].x * isc_tanh(p.x + qv[i].x);
+                acc += wv[i].y * isc_tanh(p.y + qv[i].y);
+                acc += wv[i].z * isc_tanh(p.z + qv[i].z);
+                acc += wv[i].w * isc_tanh(p.w + qv[i].w);
             }
         }
         acc = wave_sum(acc);
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256) void gate_mix_kernel(const float *z, const flo
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= B) return;
     float acc = 0.f;
-    for (int a = lane; a < A; a += 64) acc += w[a] * tanhf(z[(long long)b * A + a]);
+    for (int a = lane; a < A; a += 64) acc += w[a] * isc_tanh(z[(long long)b * A + a]);
     acc = wave_sum(acc);
     const float beta = isc_sigmoid(acc + (w_bias ? w_bias[0] : 0.f));
     if (lane == 0 && beta_out) beta_out[(long long)b * beta_ld] = beta;

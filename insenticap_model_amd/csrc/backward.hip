@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float *dh, const fl
     const float gi = g[0], gf = g[H], gg = g[2 * H], go = g[3 * H];
     float d_h = dh[idx];
     if (dh2) d_h += dh2[idx];
-    const float tc = tanhf(c[idx]);
+    const float tc = isc_tanh(c[idx]);
     float d_c = d_h * go * (1.f - tc * tc);
     if (dc_next) d_c += dc_next[idx];
     const float di = d_c * gg * gi * (1.f - gi);
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(1024) void attn_scan_bwd_kernel(const DevScanBwdLau
         float dq = 0.f, dw = 0.f;
         if (grp < ngrp) {
             for (int r = grp; r < R; r += ngrp) {
-                const float t = tanhf(Pb[(long long)r * A + a] + qa);
+                const float t = isc_tanh(Pb[(long long)r * A + a] + qa);
                 const float gr = de[r] * wa * (1.f - t * t);
                 const long long o = (long long)r * A + a;
                 dPb[o] = S.accumulate ? dPb[o] + gr : gr;
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void gate_mix_bwd_kernel(const float *z, const
     const float du = dot * bt * (1.f - bt);
     for (int a = lane; a < A; a += 64) {
         const long long o = (long long)b * A + a;
-        const float t = tanhf(z[o]);
+        const float t = isc_tanh(z[o]);
         dz[o] = du * w[a] * (1.f - t * t);
         dw_rows[o] = accumulate ? dw_rows[o] + du * t : du * t;
     }

@@ -15,7 +15,57 @@ static inline int isc_aligned16(const void *p) { return (((uintptr_t)p) & 15u) =
         if (e__ != hipSuccess) return (int)e__;    \
     } while (0)
 
-__device__ __forceinline__ float isc_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+// Activations on the hardware transcendentals (v_exp_f32 / v_rcp_f32, ~1 ulp each): 5-6 VALU
+// instructions instead of libm's ~25 (sigmoid) / ~40 (tanhf).  The attention scan evaluates 24k tanh
+// per caption and step - with tanhf the "HBM-bound" kernel was in fact VALU-limited.  Absolute error
+// <= ~2e-7 (tanh near 0 is accurate to ~1.2e-7 absolute, not relative), far inside the 1e-4 log-prob
+// bound; +-inf saturate correctly and NaN propagates.
+__device__ __forceinline__ float isc_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float isc_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
+
+// DPP lane exchanges inside a 16-lane row (VALU rate, no LDS crossbar): xor 1, xor 2, mirror inside each
+// 8-lane half, mirror inside the row.  Applied in this order with a commutative combine they leave every
+// lane of a row holding the row's reduction.
+template <int CTRL>
+__device__ __forceinline__ float isc_dpp(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+template <int CTRL>
+__device__ __forceinline__ int isc_dpp(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false);
+}
+#define ISC_DPP_XOR1 0xB1         // quad_perm [1,0,3,2]
+#define ISC_DPP_XOR2 0x4E         // quad_perm [2,3,0,1]
+#define ISC_DPP_HALF_MIRROR 0x141 // row_half_mirror
+#define ISC_DPP_MIRROR 0x140      // row_mirror
+// lane l <-> l ^ 16 inside each 32-lane half (ds_swizzle bit mode: and 0x1f, or 0, xor 0x10)
+__device__ __forceinline__ float isc_swz16(float v) {
+    return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x401F));
+}
+__device__ __forceinline__ int isc_swz16(int v) { return __builtin_amdgcn_ds_swizzle(v, 0x401F); }
+// all-reduce over each 32-lane half of the wavefront
+__device__ __forceinline__ float half_sum(float v) {
+    v += isc_dpp<ISC_DPP_XOR1>(v);
+    v += isc_dpp<ISC_DPP_XOR2>(v);
+    v += isc_dpp<ISC_DPP_HALF_MIRROR>(v);
+    v += isc_dpp<ISC_DPP_MIRROR>(v);
+    return v + isc_swz16(v);
+}
+// (value, index) arg-max over each 32-lane half; ties resolve to the smaller index
+__device__ __forceinline__ void half_argmax(float &v, int &i) {
+#define ISC_ARGMAX_STEP(OV, OI)                                        \
+    {                                                                  \
+        const float ov = (OV);                                         \
+        const int oi = (OI);                                           \
+        if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }         \
+    }
+    ISC_ARGMAX_STEP(isc_dpp<ISC_DPP_XOR1>(v), isc_dpp<ISC_DPP_XOR1>(i))
+    ISC_ARGMAX_STEP(isc_dpp<ISC_DPP_XOR2>(v), isc_dpp<ISC_DPP_XOR2>(i))
+    ISC_ARGMAX_STEP(isc_dpp<ISC_DPP_HALF_MIRROR>(v), isc_dpp<ISC_DPP_HALF_MIRROR>(i))
+    ISC_ARGMAX_STEP(isc_dpp<ISC_DPP_MIRROR>(v), isc_dpp<ISC_DPP_MIRROR>(i))
+    ISC_ARGMAX_STEP(isc_swz16(v), isc_swz16(i))
+#undef ISC_ARGMAX_STEP
+}
 
 // 64-lane butterfly reductions (wavefront = 64 on CDNA4).
 __device__ __forceinline__ float wave_sum(float v) {

@@ -80,6 +80,322 @@ struct Tile {
     static constexpr int NLD = ROWS / 32;  // float4 loads per thread per chunk
 };
 
+// Logical tile -> (problem, tm, tn, k-split slice).  XCD-aware order: blocks with equal blockIdx%8 share
+// an XCD (and its L2); give each XCD one contiguous run of logical tiles so that neighbours re-use
+// A / W panels from L2.
+__device__ __forceinline__ void map_tile(const DevLaunch &L, int &pi, int &tm, int &tn, int &ks, int &ksplit) {
+    int logical;
+    {
+        const int nt = L.total_tiles, bid = blockIdx.x;
+        const int q = nt >> 3, r = nt & 7, xcd = bid & 7, j = bid >> 3;
+        logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    }
+    pi = 0;
+    if (L.nprob > 1 && logical >= L.p[1].tile_start) pi = 1;
+    if (L.nprob > 2 && logical >= L.p[2].tile_start) pi = 2;
+    const DevProb &P = L.p[pi];
+    int t = logical - P.tile_start;
+    ksplit = P.ksplit > 1 ? P.ksplit : 1;
+    ks = t % ksplit;
+    t /= ksplit;
+    if (P.m_fastest) {
+        // weights are the larger operand: split the N tiles into 8 groups (one per XCD run) so that a
+        // group's weight slice stays resident in that XCD's 4 MB L2 while the activations stream
+        // through once: inside a group tm is the outer index and tn the inner one.
+        const int per_grp = P.grp_n * P.tiles_m;
+        const int g = t / per_grp, r = t - g * per_grp;
+        const int rest = P.tiles_n - g * P.grp_n;
+        const int gn = rest < P.grp_n ? rest : P.grp_n;
+        tm = r / gn;
+        tn = g * P.grp_n + (r - tm * gn);
+    } else {
+        tm = t / P.tiles_n;
+        tn = t % P.tiles_n;
+    }
+}
+
+// ---- epilogues, shared by the tile shapes ---------------------------------------------------------
+// Vocabulary epilogue of one 32 x (32*TN) accumulator fragment, straight from the registers (no LDS
+// round trip).  C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5), so
+// one register index r is one output row per half-wave and the row's 32*TN columns of this wave sit
+// on the 32 lanes of that half.  Per row: max / arg-max / sum exp(x - max) by 5-step butterflies
+// inside the half-wave (4 DPP steps inside the 16-lane rows + one swizzle across them).  frow0 = tile-relative first row of the
+// fragment, fcol0 = tile-relative first column.  WN == 1 writes the tile statistics directly,
+// otherwise they go to smx/ssm/six[wn][BM] for the cross-wave combine.
+template <int TN, int WN, int BM>
+__device__ __forceinline__ void epi_vocab_frag(const DevProb &P, f32x16 (&acc)[TN], int frow0, int fcol0, int wn,
+                                               int lane, int row0, int col0, int tn, float *smem) {
+    const int M = P.M, N = P.N;
+    float bv[TN];
+    bool cok[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int gn = col0 + fcol0 + j * 32 + (lane & 31);
+        cok[j] = gn < N;
+        bv[j] = cok[j] ? P.bias0[gn] : 0.f;
+    }
+    float *smx = smem;                    // [WN][BM] cross-wave combine (WN > 1 only)
+    float *ssm = smem + WN * BM;
+    int *six = reinterpret_cast<int *>(smem + 2 * WN * BM);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = frow0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int gm = row0 + row;
+        float x[TN];
+        float mx = -INFINITY;
+        int ix = 0x7fffffff;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            x[j] = cok[j] ? acc[j][r] + bv[j] : -INFINITY;
+            const int gn = col0 + fcol0 + j * 32 + (lane & 31);
+            if (x[j] > mx) { mx = x[j]; ix = gn; }       // j ascending => smaller column wins ties
+        }
+        if (P.C && gm < M) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                if (cok[j])
+                    P.C[(long long)gm * P.ld_logits + col0 + fcol0 + j * 32 + (lane & 31)] = x[j];
+        }
+        half_argmax(mx, ix);
+        float sm = 0.f;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) sm += cok[j] ? __expf(x[j] - mx) : 0.f;   // padded columns add 0
+        sm = half_sum(sm);
+        if ((lane & 31) == 0) {
+            if constexpr (WN == 1) {
+                if (gm < M) {
+                    const long long o = (long long)gm * P.ntile_total + tn;
+                    P.pmax[o] = mx;
+                    P.psum[o] = sm;
+                    P.pidx[o] = ix;
+                }
+            } else {
+                smx[wn * BM + row] = mx;
+                ssm[wn * BM + row] = sm;
+                six[wn * BM + row] = ix;
+            }
+        }
+    }
+}
+
+// accumulator fragment -> Cs[BM][LDC] (row-major tile image in LDS)
+template <int TN>
+__device__ __forceinline__ void epi_stage_frag(float *Cs, int LDC, f32x16 (&acc)[TN], int frow0, int fcol0, int lane) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = frow0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const int col = fcol0 + j * 32 + (lane & 31);
+            Cs[row * LDC + col] = acc[j][r];
+        }
+}
+
+template <int BM, int BN>
+__device__ __forceinline__ void epi_linear_tile(const DevProb &P, const float *Cs, int row0, int col0, int tid,
+                                                int ks, int ksplit) {
+    constexpr int LDC = BN + 4;
+    const int M = P.M, N = P.N;
+    if (ksplit > 1) {      // raw partial tile -> slab[ks] ([M,N], ld = N, N % 4 == 0)
+        float *slab = P.slab + (long long)ks * P.slab_stride;
+        for (int idx = tid; idx < BM * (BN / 4); idx += 256) {
+            const int row = idx / (BN / 4), c4 = (idx % (BN / 4)) * 4;
+            const int gm = row0 + row, gn = col0 + c4;
+            if (gm < M && gn < N)
+                *reinterpret_cast<float4 *>(slab + (long long)gm * N + gn) =
+                    *reinterpret_cast<const float4 *>(Cs + row * LDC + c4);
+        }
+        return;
+    }
+    const bool vec = (P.ldc & 3) == 0;
+    for (int idx = tid; idx < BM * (BN / 4); idx += 256) {
+        const int row = idx / (BN / 4), c4 = (idx % (BN / 4)) * 4;
+        const int gm = row0 + row, gn = col0 + c4;
+        if (gm >= M || gn >= N) continue;
+        float4 v = *reinterpret_cast<const float4 *>(Cs + row * LDC + c4);
+        float o[4] = {v.x, v.y, v.z, v.w}, pre[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int n = gn + e;
+            if (n < N) {
+                if (P.bias0) o[e] += P.bias0[n];
+                if (P.bias1) o[e] += P.bias1[n];
+                if (P.bias2) o[e] += P.bias2[n];
+                if (P.accumulate) o[e] += P.C[(long long)gm * P.ldc + n];
+                if (P.relu) o[e] = fmaxf(o[e], 0.f);
+                pre[e] = o[e];
+                if (P.mask) o[e] = o[e] * (float)P.mask[(long long)gm * N + n] * P.mask_scale;
+            }
+        }
+        float *dst = P.C + (long long)gm * P.ldc + gn;
+        if (vec && gn + 3 < N) {
+            *reinterpret_cast<float4 *>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+            if (P.C_pre)
+                *reinterpret_cast<float4 *>(P.C_pre + (long long)gm * P.ldc + gn) =
+                    make_float4(pre[0], pre[1], pre[2], pre[3]);
+        } else {
+            for (int e = 0; e < 4 && gn + e < N; ++e) {
+                dst[e] = o[e];
+                if (P.C_pre) P.C_pre[(long long)gm * P.ldc + gn + e] = pre[e];
+            }
+        }
+    }
+}
+
+// LSTM cell update of one (row, unit) from its four gate pre-activations (W x products only; biases,
+// the hoisted `pre` term and the embedding-table row are added here), gate order i, f, g, o.
+__device__ __forceinline__ void lstm_cell_store(const DevProb &P, int gm, int unit, float gi, float gf, float gg, float go) {
+    const int H = P.H;
+    if (P.bias0) {
+        gi += P.bias0[unit] + P.bias1[unit];
+        gf += P.bias0[H + unit] + P.bias1[H + unit];
+        gg += P.bias0[2 * H + unit] + P.bias1[2 * H + unit];
+        go += P.bias0[3 * H + unit] + P.bias1[3 * H + unit];
+    }
+    if (P.pre) {
+        const float *q = P.pre + (long long)gm * 4 * H + unit;
+        gi += q[0]; gf += q[H]; gg += q[2 * H]; go += q[3 * H];
+    }
+    if (P.tab) {
+        const float *q = P.tab + P.tab_ids[(long long)gm * P.tab_ids_stride] * 4 * H + unit;
+        gi += q[0]; gf += q[H]; gg += q[2 * H]; go += q[3 * H];
+    }
+    gi = isc_sigmoid(gi);
+    gf = isc_sigmoid(gf);
+    gg = isc_tanh(gg);
+    go = isc_sigmoid(go);
+    const long long o = (long long)gm * H + unit;
+    const float c2 = gf * P.c_prev[o] + gi * gg;
+    const float h2 = go * isc_tanh(c2);
+    P.c_out[o] = c2;
+    P.h_out[o] = h2;
+    if (P.hmask) P.hdrop[o] = h2 * (float)P.hmask[o] * P.mask_scale;
+    if (P.gates_out) {
+        float *g = P.gates_out + (long long)gm * 4 * H + unit;
+        g[0] = gi; g[H] = gf; g[2 * H] = gg; g[3 * H] = go;
+    }
+}
+
+// gate-interleaved tile (columns = 4 gates x 32 units) -> LSTM cell update of units tn*32 .. +32
+template <int BM, int BN>
+__device__ __forceinline__ void epi_lstm_tile(const DevProb &P, const float *Cs, int row0, int tn, int tid) {
+    constexpr int LDC = BN + 4;
+    const int M = P.M;
+    for (int idx = tid; idx < BM * 32; idx += 256) {
+        const int row = idx >> 5, u = idx & 31;
+        const int gm = row0 + row;
+        if (gm >= M) continue;
+        const float *cr = Cs + row * LDC + u;
+        lstm_cell_store(P, gm, tn * 32 + u, cr[0], cr[32], cr[64], cr[96]);
+    }
+}
+
+// The same two epilogues straight from a 32 x 128 accumulator fragment (C/D layout: col = lane&31 of
+// sub-tile j, row = (r&3) + 8*(r>>2) + 4*(lane>>5)): every store instruction writes two full 128-byte
+// row segments.  Used by the XL tile, whose lone workgroup per CU has nobody to hide an LDS round
+// trip and a branchy tile loop behind.  Same per-element arithmetic (and order) as the staged forms.
+// Interior tiles (no edge predicate) run branch-free per element; the feature flags are uniform and
+// tested once per fragment.
+template <bool EDGE>
+__device__ __forceinline__ void epi_lstm_frag_impl(const DevProb &P, f32x16 (&acc)[4], int frow0, int lane, int row0, int tn) {
+    const int H = P.H, unit = tn * 32 + (lane & 31);
+    float bi = 0.f, bf = 0.f, bg = 0.f, bo = 0.f;
+    if (P.bias0) {
+        bi = P.bias0[unit] + P.bias1[unit];
+        bf = P.bias0[H + unit] + P.bias1[H + unit];
+        bg = P.bias0[2 * H + unit] + P.bias1[2 * H + unit];
+        bo = P.bias0[3 * H + unit] + P.bias1[3 * H + unit];
+    }
+    const bool has_b = P.bias0 != nullptr, has_pre = P.pre != nullptr, has_tab = P.tab != nullptr;
+    const bool has_drop = P.hmask != nullptr, has_gates = P.gates_out != nullptr;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int gm = row0 + frow0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (EDGE && gm >= P.M) continue;
+        float gi = acc[0][r], gf = acc[1][r], gg = acc[2][r], go = acc[3][r];
+        if (has_b) { gi += bi; gf += bf; gg += bg; go += bo; }
+        if (has_pre) {
+            const float *q = P.pre + (long long)gm * 4 * H + unit;
+            gi += q[0]; gf += q[H]; gg += q[2 * H]; go += q[3 * H];
+        }
+        if (has_tab) {
+            const float *q = P.tab + P.tab_ids[(long long)gm * P.tab_ids_stride] * 4 * H + unit;
+            gi += q[0]; gf += q[H]; gg += q[2 * H]; go += q[3 * H];
+        }
+        gi = isc_sigmoid(gi);
+        gf = isc_sigmoid(gf);
+        gg = isc_tanh(gg);
+        go = isc_sigmoid(go);
+        const long long o = (long long)gm * H + unit;
+        const float c2 = gf * P.c_prev[o] + gi * gg;
+        const float h2 = go * isc_tanh(c2);
+        P.c_out[o] = c2;
+        P.h_out[o] = h2;
+        if (has_drop) P.hdrop[o] = h2 * (float)P.hmask[o] * P.mask_scale;
+        if (has_gates) {
+            float *g = P.gates_out + (long long)gm * 4 * H + unit;
+            g[0] = gi; g[H] = gf; g[2 * H] = gg; g[3 * H] = go;
+        }
+    }
+}
+
+__device__ __forceinline__ void epi_lstm_frag(const DevProb &P, f32x16 (&acc)[4], int frow0, int lane, int row0, int tn) {
+    if (row0 + frow0 + 32 <= P.M) epi_lstm_frag_impl<false>(P, acc, frow0, lane, row0, tn);
+    else epi_lstm_frag_impl<true>(P, acc, frow0, lane, row0, tn);
+}
+
+// FAST: interior fragment without accumulate / pre-activation copy / keep-mask
+template <bool FAST, bool RELU>
+__device__ __forceinline__ void epi_linear_frag_impl(const DevProb &P, f32x16 (&acc)[4], int frow0, int lane, int row0, int col0) {
+    const int M = P.M, N = P.N;
+    float b0[4], b1[4], b2[4];
+    bool cok[4];
+    const bool h0 = P.bias0 != nullptr, h1 = P.bias1 != nullptr, h2 = P.bias2 != nullptr;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int gn = col0 + j * 32 + (lane & 31);
+        cok[j] = FAST || gn < N;
+        b0[j] = (h0 && cok[j]) ? P.bias0[gn] : 0.f;
+        b1[j] = (h1 && cok[j]) ? P.bias1[gn] : 0.f;
+        b2[j] = (h2 && cok[j]) ? P.bias2[gn] : 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int gm = row0 + frow0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (!FAST && gm >= M) continue;
+        float *crow = P.C + (long long)gm * P.ldc + col0 + (lane & 31);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (!FAST && !cok[j]) continue;
+            float o = acc[j][r];
+            if (h0) o += b0[j];
+            if (h1) o += b1[j];
+            if (h2) o += b2[j];
+            if constexpr (!FAST) {
+                if (P.accumulate) o += crow[j * 32];
+            }
+            if (RELU) o = fmaxf(o, 0.f);
+            if constexpr (!FAST) {
+                const int gn = col0 + j * 32 + (lane & 31);
+                if (P.C_pre) P.C_pre[(long long)gm * P.ldc + gn] = o;
+                if (P.mask) o = o * (float)P.mask[(long long)gm * N + gn] * P.mask_scale;
+            }
+            crow[j * 32] = o;
+        }
+    }
+}
+
+__device__ __forceinline__ void epi_linear_frag(const DevProb &P, f32x16 (&acc)[4], int frow0, int lane, int row0, int col0) {
+    const bool fast = !(P.accumulate || P.C_pre || P.mask) && row0 + frow0 + 32 <= P.M && col0 + 128 <= P.N;
+    if (fast) {
+        if (P.relu) epi_linear_frag_impl<true, true>(P, acc, frow0, lane, row0, col0);
+        else epi_linear_frag_impl<true, false>(P, acc, frow0, lane, row0, col0);
+    } else {
+        if (P.relu) epi_linear_frag_impl<false, true>(P, acc, frow0, lane, row0, col0);
+        else epi_linear_frag_impl<false, false>(P, acc, frow0, lane, row0, col0);
+    }
+}
+
 template <int WM, int WN, int TN, int EPI, bool AKM, bool BKM>
 __global__ __launch_bounds__(256) void gemm_kernel(const DevLaunch L) {
     constexpr int BM = 32 * WM;
@@ -98,37 +414,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const DevLaunch L) {
     const int wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
 
-    // XCD-aware tile order: blocks with equal blockIdx%8 share an XCD (and its L2); give each
-    // XCD one contiguous run of logical tiles so that neighbours re-use A / W panels from L2.
-    int logical;
-    {
-        const int nt = L.total_tiles, bid = blockIdx.x;
-        const int q = nt >> 3, r = nt & 7, xcd = bid & 7, j = bid >> 3;
-        logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
-    }
-    int pi = 0;
-    if (L.nprob > 1 && logical >= L.p[1].tile_start) pi = 1;
-    if (L.nprob > 2 && logical >= L.p[2].tile_start) pi = 2;
+    int pi, tm, tn, ks, ksplit;
+    map_tile(L, pi, tm, tn, ks, ksplit);
     const DevProb &P = L.p[pi];
-    int t = logical - P.tile_start;
-    const int ksplit = P.ksplit > 1 ? P.ksplit : 1;
-    const int ks = t % ksplit;
-    t /= ksplit;
-    int tm, tn;
-    if (P.m_fastest) {
-        // weights are the larger operand: split the N tiles into 8 groups (one per XCD run) so that a
-        // group's weight slice stays resident in that XCD's 4 MB L2 while the activations stream
-        // through once: inside a group tm is the outer index and tn the inner one.
-        const int per_grp = P.grp_n * P.tiles_m;
-        const int g = t / per_grp, r = t - g * per_grp;
-        const int rest = P.tiles_n - g * P.grp_n;
-        const int gn = rest < P.grp_n ? rest : P.grp_n;
-        tm = r / gn;
-        tn = g * P.grp_n + (r - tm * gn);
-    } else {
-        tm = t / P.tiles_n;
-        tn = t % P.tiles_n;
-    }
     const int M = P.M, N = P.N;
     const int row0 = tm * BM, col0 = tn * BN;
 
@@ -357,68 +645,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(const DevLaunch L) {
     else k_loop(std::false_type{});
 
     if constexpr (EPI == EPI_VOCAB) {
-        // ---- vocabulary epilogue straight from the accumulator registers (no LDS round trip):
-        // C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5), so one
-        // register index r is one output row per half-wave and the row's 32*TN columns of this wave
-        // sit on the 32 lanes of that half.  Per row: max / arg-max / sum exp(x - max) by 5-step
-        // butterflies inside the half-wave (xor 1..16 never crosses lane 32).
-        float bv[TN];
-        bool cok[TN];
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int gn = col0 + (wn * TN + j) * 32 + (lane & 31);
-            cok[j] = gn < N;
-            bv[j] = cok[j] ? P.bias0[gn] : 0.f;
-        }
-        float *smx = smem;                    // [WN][BM] cross-wave combine (WN > 1 only)
-        float *ssm = smem + WN * BM;
-        int *six = reinterpret_cast<int *>(smem + 2 * WN * BM);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            const int gm = row0 + row;
-            float x[TN];
-            float mx = -INFINITY;
-            int ix = 0x7fffffff;
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                x[j] = cok[j] ? acc[j][r] + bv[j] : -INFINITY;
-                const int gn = col0 + (wn * TN + j) * 32 + (lane & 31);
-                if (x[j] > mx) { mx = x[j]; ix = gn; }       // j ascending => smaller column wins ties
-            }
-            if (P.C && gm < M) {
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    if (cok[j])
-                        P.C[(long long)gm * P.ld_logits + col0 + (wn * TN + j) * 32 + (lane & 31)] = x[j];
-            }
-#pragma unroll
-            for (int o = 16; o > 0; o >>= 1) {
-                const float ov = __shfl_xor(mx, o, 64);
-                const int oi = __shfl_xor(ix, o, 64);
-                if (ov > mx || (ov == mx && oi < ix)) { mx = ov; ix = oi; }
-            }
-            float sm = 0.f;
-#pragma unroll
-            for (int j = 0; j < TN; ++j) sm += cok[j] ? __expf(x[j] - mx) : 0.f;   // padded columns add 0
-#pragma unroll
-            for (int o = 16; o > 0; o >>= 1) sm += __shfl_xor(sm, o, 64);
-            if ((lane & 31) == 0) {
-                if constexpr (WN == 1) {
-                    if (gm < M) {
-                        const long long o = (long long)gm * P.ntile_total + tn;
-                        P.pmax[o] = mx;
-                        P.psum[o] = sm;
-                        P.pidx[o] = ix;
-                    }
-                } else {
-                    smx[wn * BM + row] = mx;
-                    ssm[wn * BM + row] = sm;
-                    six[wn * BM + row] = ix;
-                }
-            }
-        }
+        epi_vocab_frag<TN, WN, BM>(P, acc, wm * 32, wn * TN * 32, wn, lane, row0, col0, tn, smem);
         if constexpr (WN > 1) {
+            float *smx = smem;
+            float *ssm = smem + WN * BM;
+            int *six = reinterpret_cast<int *>(smem + 2 * WN * BM);
             __syncthreads();
             for (int row = tid; row < BM; row += 256) {
                 const int gm = row0 + row;
@@ -446,99 +677,191 @@ __global__ __launch_bounds__(256) void gemm_kernel(const DevLaunch L) {
         return;
     }
 
-    // stage the tile: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            const int col = (wn * TN + j) * 32 + (lane & 31);
-            Cs[row * LDC + col] = acc[j][r];
-        }
+    epi_stage_frag<TN>(Cs, LDC, acc, wm * 32, wn * TN * 32, lane);
     __syncthreads();
+    if (EPI == EPI_LINEAR) epi_linear_tile<BM, BN>(P, Cs, row0, col0, tid, ks, ksplit);
+    else if (EPI == EPI_LSTM) epi_lstm_tile<BM, BN>(P, Cs, row0, tn, tid);
+}
 
-    if (EPI == EPI_LINEAR && ksplit > 1) {      // raw partial tile -> slab[ks] ([M,N], ld = N, N % 4 == 0)
-        float *slab = P.slab + (long long)ks * P.slab_stride;
-        for (int idx = tid; idx < BM * (BN / 4); idx += 256) {
-            const int row = idx / (BN / 4), c4 = (idx % (BN / 4)) * 4;
-            const int gm = row0 + row, gn = col0 + c4;
-            if (gm < M && gn < N)
-                *reinterpret_cast<float4 *>(slab + (long long)gm * N + gn) =
-                    *reinterpret_cast<const float4 *>(Cs + row * LDC + c4);
-        }
-        return;
-    }
-    if (EPI == EPI_LINEAR) {
-        const bool vec = (P.ldc & 3) == 0;
-        for (int idx = tid; idx < BM * (BN / 4); idx += 256) {
-            const int row = idx / (BN / 4), c4 = (idx % (BN / 4)) * 4;
-            const int gm = row0 + row, gn = col0 + c4;
-            if (gm >= M || gn >= N) continue;
-            float4 v = *reinterpret_cast<const float4 *>(Cs + row * LDC + c4);
-            float o[4] = {v.x, v.y, v.z, v.w}, pre[4];
+// ---------------------------------------------------------------- XL tile: 256 x 128, one workgroup per CU
+// For batch-sized NT problems.  4 waves stacked in M, each owning a 64 x 128 accumulator (2 x 4 MFMA
+// fragments, 128 AGPRs): twice the MFMAs per staged byte of the 128 x 128 tile.  Operand chunks go
+// global -> LDS by LDS-DMA (global_load_lds_dwordx4: no staging VGPRs, no ds_write pass) into a
+// 3-deep ring (144 KB), so the DMA of chunk c+2 is in flight while chunk c is contracted and only a
+// counted vmcnt (never 0 in steady state) precedes the one barrier per chunk.  The 12 DMA
+// instructions of a chunk are issued one by one in the shadow of 8-MFMA groups.  An LDS-DMA writes
+// lane-linear (wave-uniform base + 16 B * lane), which rules out padded rows: the tile image is
+// [rows][8 slots of 16 B] with slot = k-quad ^ ((row >> 1) & 7), applied to the per-lane SOURCE address
+// when staging and to the ds_read_b128 address when reading fragments (conflict-free for the
+// instruction's four 16-lane groups).  The DMA is issued from inline asm (M0 = LDS address): the
+// compiler would otherwise drain every DMA (vmcnt(0)) in front of the next ds_read.
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_xl_kernel(const DevLaunch L) {
+    constexpr int BM = 256, BN = 128, TN = 4;
+    constexpr int TSA = BM * BK, TSB = BN * BK;         // floats per ring slot
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *As = smem;                     // [3][TSA]
+    float *Bs = smem + 3 * TSA;           // [3][TSB]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wm = tid >> 6;
+    int pi, tm, tn, ks, ksplit;
+    map_tile(L, pi, tm, tn, ks, ksplit);
+    const DevProb &P = L.p[pi];
+    const int M = P.M, N = P.N;
+    const int row0 = tm * BM, col0 = tn * BN;
+
+    // staging pieces (8 rows x 128 B each): A piece i of wave w = tile rows 64w + 8i .. +8, B piece i =
+    // tile columns 32w + 8i .. +8; lane -> (row = lane>>3, slot = lane&7).  Rows past the edge re-read
+    // the last valid row (their results are never stored).
+    int arow[8];
+    long long wrow[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int n = gn + e;
-                if (n < N) {
-                    if (P.bias0) o[e] += P.bias0[n];
-                    if (P.bias1) o[e] += P.bias1[n];
-                    if (P.bias2) o[e] += P.bias2[n];
-                    if (P.accumulate) o[e] += P.C[(long long)gm * P.ldc + n];
-                    if (P.relu) o[e] = fmaxf(o[e], 0.f);
-                    pre[e] = o[e];
-                    if (P.mask) o[e] = o[e] * (float)P.mask[(long long)gm * N + n] * P.mask_scale;
-                }
-            }
-            float *dst = P.C + (long long)gm * P.ldc + gn;
-            if (vec && gn + 3 < N) {
-                *reinterpret_cast<float4 *>(dst) = make_float4(o[0], o[1], o[2], o[3]);
-                if (P.C_pre)
-                    *reinterpret_cast<float4 *>(P.C_pre + (long long)gm * P.ldc + gn) =
-                        make_float4(pre[0], pre[1], pre[2], pre[3]);
-            } else {
-                for (int e = 0; e < 4 && gn + e < N; ++e) {
-                    dst[e] = o[e];
-                    if (P.C_pre) P.C_pre[(long long)gm * P.ldc + gn + e] = pre[e];
-                }
+    for (int i = 0; i < 8; ++i) {
+        const int r = row0 + 64 * wm + 8 * i + (lane >> 3);
+        arow[i] = r < M ? r : M - 1;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (EPI == EPI_LSTM) {
+            wrow[i] = (long long)wm * P.H + tn * 32 + 8 * i + (lane >> 3);   // gate wm, unit tn*32 + ..
+        } else {
+            const int c = col0 + 32 * wm + 8 * i + (lane >> 3);
+            wrow[i] = c < N ? c : N - 1;
+        }
+    }
+    const int lq = lane & 7, lh = lane >> 4;   // (tile row >> 1) & 7 == (4*(i&1) + lh) for both operands
+    const float *pa[8], *pb[4];
+    int cs = 0, ck = 0, segK = 0;
+    auto set_seg = [&](int si) __attribute__((always_inline)) {
+        const DevSeg sg = P.seg[si];
+        segK = sg.K;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) pa[i] = sg.A + (long long)arow[i] * sg.lda + (lq ^ (4 * (i & 1) + lh)) * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pb[i] = sg.W + wrow[i] * sg.ldw + (lq ^ (4 * (i & 1) + lh)) * 4;
+    };
+    const unsigned a_lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)As + wm * 64 * BK * 4);
+    const unsigned b_lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)Bs + wm * 32 * BK * 4);
+    auto dma = [&](auto bufc, auto idxc) __attribute__((always_inline)) {
+        constexpr int BUF = decltype(bufc)::value, IDX = decltype(idxc)::value;
+        if constexpr (IDX < 8) {
+            asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off"
+                         :: "s"(a_lds0 + (BUF * TSA + 8 * IDX * BK) * 4), "v"(pa[IDX]) : "memory");
+            pa[IDX] += BK;
+        } else {
+            asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off"
+                         :: "s"(b_lds0 + (BUF * TSB + 8 * (IDX - 8) * BK) * 4), "v"(pb[IDX - 8]) : "memory");
+            pb[IDX - 8] += BK;
+        }
+        if constexpr (IDX == 11) {         // the chunk is fully issued: move the loader on
+            ck += BK;
+            if (ck >= segK) {
+                ck = 0;
+                if (++cs < P.nseg) set_seg(cs);
             }
         }
-    } else if (EPI == EPI_LSTM) {
-        const int H = P.H;
-        for (int idx = tid; idx < BM * 32; idx += 256) {
-            const int row = idx >> 5, u = idx & 31;
-            const int gm = row0 + row, unit = tn * 32 + u;
-            if (gm >= M) continue;
-            const float *cr = Cs + row * LDC + u;
-            float gi = cr[0], gf = cr[32], gg = cr[64], go = cr[96];
-            if (P.bias0) {
-                gi += P.bias0[unit] + P.bias1[unit];
-                gf += P.bias0[H + unit] + P.bias1[H + unit];
-                gg += P.bias0[2 * H + unit] + P.bias1[2 * H + unit];
-                go += P.bias0[3 * H + unit] + P.bias1[3 * H + unit];
-            }
-            if (P.pre) {
-                const float *q = P.pre + (long long)gm * 4 * H + unit;
-                gi += q[0]; gf += q[H]; gg += q[2 * H]; go += q[3 * H];
-            }
-            if (P.tab) {
-                const float *q = P.tab + P.tab_ids[(long long)gm * P.tab_ids_stride] * 4 * H + unit;
-                gi += q[0]; gf += q[H]; gg += q[2 * H]; go += q[3 * H];
-            }
-            gi = isc_sigmoid(gi);
-            gf = isc_sigmoid(gf);
-            gg = tanhf(gg);
-            go = isc_sigmoid(go);
-            const long long o = (long long)gm * H + unit;
-            const float c2 = gf * P.c_prev[o] + gi * gg;
-            const float h2 = go * tanhf(c2);
-            P.c_out[o] = c2;
-            P.h_out[o] = h2;
-            if (P.hmask) P.hdrop[o] = h2 * (float)P.hmask[o] * P.mask_scale;
-            if (P.gates_out) {
-                float *g = P.gates_out + (long long)gm * 4 * H + unit;
-                g[0] = gi; g[H] = gf; g[2 * H] = gg; g[3 * H] = go;
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>;
+    auto dma_all = [&](auto bufc) __attribute__((always_inline)) {
+        dma(bufc, I0{}); dma(bufc, I1{}); dma(bufc, I2{}); dma(bufc, I3{});
+        dma(bufc, std::integral_constant<int, 4>{}); dma(bufc, std::integral_constant<int, 5>{});
+        dma(bufc, std::integral_constant<int, 6>{}); dma(bufc, std::integral_constant<int, 7>{});
+        dma(bufc, std::integral_constant<int, 8>{}); dma(bufc, std::integral_constant<int, 9>{});
+        dma(bufc, std::integral_constant<int, 10>{}); dma(bufc, std::integral_constant<int, 11>{});
+    };
+
+    f32x16 acc[2][TN];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    static_assert(BK == 32, "chunk body written for 4 k-blocks of 8");
+    const int frow = lane & 31, khalf = lane >> 5;
+    const int fsw = (frow >> 1) & 7;       // identical for rows frow + 32*j
+    float4 fa[2][2], fb[2][TN];
+    auto lfrag = [&](auto bufc, auto kbc, auto setc) __attribute__((always_inline)) {
+        constexpr int BUF = decltype(bufc)::value, kb = decltype(kbc)::value, ST = decltype(setc)::value;
+        const int slot = ((2 * kb + khalf) ^ fsw) * 4;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            fa[ST][i] = *reinterpret_cast<const float4 *>(As + BUF * TSA + (wm * 64 + i * 32 + frow) * BK + slot);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+            fb[ST][j] = *reinterpret_cast<const float4 *>(Bs + BUF * TSB + (j * 32 + frow) * BK + slot);
+    };
+    auto mma_e = [&](auto setc, auto ec) __attribute__((always_inline)) {
+        constexpr int ST = decltype(setc)::value, e = decltype(ec)::value;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float a[4] = {fa[ST][i].x, fa[ST][i].y, fa[ST][i].z, fa[ST][i].w};
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const float b[4] = {fb[ST][j].x, fb[ST][j].y, fb[ST][j].z, fb[ST][j].w};
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], acc[i][j], 0, 0, 0);
             }
         }
+    };
+    // one k-block (32 MFMAs) with up to 4 DMA pieces of chunk c+2 issued between its 8-MFMA groups
+    auto mma_dma = [&](auto setc, auto bufc, auto basec, bool on) __attribute__((always_inline)) {
+        constexpr int B0 = decltype(basec)::value;
+        mma_e(setc, I0{}); if (on) dma(bufc, std::integral_constant<int, B0 + 0>{});
+        mma_e(setc, I1{}); if (on) dma(bufc, std::integral_constant<int, B0 + 1>{});
+        mma_e(setc, I2{}); if (on) dma(bufc, std::integral_constant<int, B0 + 2>{});
+        mma_e(setc, I3{}); if (on) dma(bufc, std::integral_constant<int, B0 + 3>{});
+    };
+    int nchunks = 0;
+    for (int s = 0; s < P.nseg; ++s) nchunks += P.seg[s].K / BK;
+    // chunk c lives in ring slot c % 3.  Slot (c+2) % 3 was last read in chunk c-1, whose reads all
+    // retired (lgkmcnt(0)) in front of that chunk's barrier - so its DMA may start right away.
+    auto chunk_body = [&](auto curc, auto nxtc, auto nnc, bool has1, bool has2) __attribute__((always_inline)) {
+        lfrag(curc, I1{}, I1{});
+        mma_dma(I0{}, nnc, I0{}, has2);
+        lfrag(curc, I2{}, I0{});
+        mma_dma(I1{}, nnc, std::integral_constant<int, 4>{}, has2);
+        lfrag(curc, I3{}, I1{});
+        mma_dma(I0{}, nnc, std::integral_constant<int, 8>{}, has2);
+        if (has1) {
+            // chunk c+1 (issued one chunk ago) must have landed; chunk c+2's 12 pieces stay in flight
+            if (has2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            lfrag(nxtc, I0{}, I0{});
+        }
+        mma_e(I1{}, I0{}); mma_e(I1{}, I1{}); mma_e(I1{}, I2{}); mma_e(I1{}, I3{});
+    };
+    set_seg(0);
+    dma_all(I0{});
+    if (nchunks > 1) {
+        dma_all(I1{});
+        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    lfrag(I0{}, I0{}, I0{});
+    for (int c = 0; c < nchunks; c += 3) {
+        chunk_body(I0{}, I1{}, I2{}, c + 1 < nchunks, c + 2 < nchunks);
+        if (c + 1 < nchunks) chunk_body(I1{}, I2{}, I0{}, c + 2 < nchunks, c + 3 < nchunks);
+        if (c + 2 < nchunks) chunk_body(I2{}, I0{}, I1{}, c + 3 < nchunks, c + 4 < nchunks);
+    }
+
+    if constexpr (EPI == EPI_VOCAB) {
+        epi_vocab_frag<TN, 1, BM>(P, acc[0], wm * 64, 0, 0, lane, row0, col0, tn, smem);
+        epi_vocab_frag<TN, 1, BM>(P, acc[1], wm * 64 + 32, 0, 0, lane, row0, col0, tn, smem);
+    } else if constexpr (EPI == EPI_LSTM) {
+        epi_lstm_frag(P, acc[0], wm * 64, lane, row0, tn);
+        epi_lstm_frag(P, acc[1], wm * 64 + 32, lane, row0, tn);
+    } else {
+        epi_linear_frag(P, acc[0], wm * 64, lane, row0, col0);
+        epi_linear_frag(P, acc[1], wm * 64 + 32, lane, row0, col0);
     }
 }
 
@@ -599,9 +922,9 @@ __global__ __launch_bounds__(256) void splitk_lstm_kernel(const DevLaunch L) {
         if (P.tab) a += P.tab[P.tab_ids[(long long)gm * P.tab_ids_stride] * 4 * H + k * H + unit];
         g[k] = a;
     }
-    const float gi = isc_sigmoid(g[0]), gf = isc_sigmoid(g[1]), gg = tanhf(g[2]), go = isc_sigmoid(g[3]);
+    const float gi = isc_sigmoid(g[0]), gf = isc_sigmoid(g[1]), gg = isc_tanh(g[2]), go = isc_sigmoid(g[3]);
     const float c2 = gf * P.c_prev[i] + gi * gg;
-    const float h2 = go * tanhf(c2);
+    const float h2 = go * isc_tanh(c2);
     P.c_out[i] = c2;
     P.h_out[i] = h2;
     if (P.hmask) P.hdrop[i] = h2 * (float)P.hmask[i] * P.mask_scale;
@@ -650,33 +973,65 @@ static int launch_cfg(const DevLaunch &L, hipStream_t st) {
     return ISC_OK;
 }
 
-// Tile shapes: 0 = L 128x128 (4 waves stacked in M), 1 = M 64x128 (2x2 waves), 2 = S 32x128 (4 waves in N)
-static const int kTileBM[3] = {128, 64, 32};
+template <int EPI>
+static int launch_xl(const DevLaunch &L, hipStream_t st) {
+    constexpr size_t lds = (size_t)3 * (256 + 128) * BK * sizeof(float);   // 147456 >= Cs 256 x 132 floats
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_xl_kernel<EPI>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_xl_kernel<EPI>), dim3(L.total_tiles), dim3(256), lds, st, L);
+    ISC_LAUNCH_CHECK();
+    return ISC_OK;
+}
+
+// Tile shapes: 0 = L 128x128 (4 waves stacked in M), 1 = M 64x128 (2x2 waves), 2 = S 32x128 (4 waves in N),
+// 3 = XL 256x128 (LDS-DMA ring, NT layout only)
+static const int kTileBM[4] = {128, 64, 32, 256};
 
 template <int EPI, bool AKM, bool BKM>
 static int launch_any(const DevLaunch &L, int tile, hipStream_t st) {
+    if constexpr (!AKM && !BKM) {
+        if (tile == 3) return launch_xl<EPI>(L, st);
+    }
     if (tile == 0) return launch_cfg<4, 1, 4, EPI, AKM, BKM>(L, st);
     if (tile == 1) return launch_cfg<2, 2, 2, EPI, AKM, BKM>(L, st);
     return launch_cfg<1, 4, 1, EPI, AKM, BKM>(L, st);
 }
 
-// Tile shape choice by a small cost model.  A launch runs in ceil(blocks / (256 CUs * resident blocks per
-// CU)) rounds; a round costs BM / efficiency, where the efficiency reflects MFMAs per wave between
-// barriers (64 / 32 / 16 per 32-deep chunk for L / M / S).  This picks e.g. 64x128 tiles for a
-// [2048 x 2048] LSTM problem (512 blocks = 2 per CU) instead of 256 tiles of 128x128 (1 per CU).
-static int pick_tile(const DevLaunch &L) {
-    static const double eff[3] = {1.0, 0.9, 0.62};
-    static const int resident[3] = {2, 2, 3};
+// Tile shape choice by a small cost model.  The most loaded CU works through n = ceil(blocks / 256)
+// workgroups; its time is n * BM / efficiency, where the efficiency depends on the tile (MFMAs per
+// staged byte and per barrier) and on how many workgroups share the CU (the 128/64/32-row tiles rely
+// on a co-resident workgroup to cover their chunk-boundary stalls, the XL tile is pipelined to run
+// alone).  Calibrated on tools/gemm_big.py / gemm_bench.py.
+static int g_tile_override = -1;
+extern "C" int isc_set_tile_override(int tile) {
+    const int prev = g_tile_override;
+    g_tile_override = (tile >= 0 && tile <= 3) ? tile : -1;
+    return prev;
+}
+
+static int pick_tile(const DevLaunch &L, bool allow_xl) {
+    if (g_tile_override >= 0) return (g_tile_override == 3 && !allow_xl) ? 0 : g_tile_override;
+    static const double eff[4][3] = {{0.80, 1.00, 1.00},    // L : 1, 2, >=3 workgroups on the busiest CU
+                                     {0.55, 0.80, 0.90},    // M
+                                     {0.35, 0.50, 0.62},    // S
+                                     {1.10, 1.10, 1.10}};   // XL
     int best = 0;
     double best_cost = 1e30;
-    for (int t = 0; t < 3; ++t) {
+    static const int order[4] = {3, 0, 1, 2};               // larger tiles first: they win near-ties
+    for (int k = 0; k < 4; ++k) {
+        const int t = order[k];
+        if (t == 3 && !allow_xl) continue;
         long long blocks = 0;
         for (int i = 0; i < L.nprob; ++i)
             blocks += (long long)((L.p[i].M + kTileBM[t] - 1) / kTileBM[t]) * ((L.p[i].N + 127) / 128);
-        const long long slots = 256LL * resident[t];
-        const double rounds = (double)((blocks + slots - 1) / slots);
-        const double cost = rounds * kTileBM[t] / eff[t];
-        if (cost < best_cost * 0.97) { best_cost = cost; best = t; }   // prefer the larger tile on near-ties
+        const long long n = (blocks + 255) / 256;
+        const double cost = (double)n * kTileBM[t] / eff[t][n >= 3 ? 2 : (int)n - 1];
+        if (cost < best_cost * 0.97) { best_cost = cost; best = t; }
     }
     return best;
 }
@@ -762,7 +1117,7 @@ extern "C" int isc_linear_fwd(const isc_linear_problem *pr, int n_prob, void *st
         d.ldc = q.ldc; d.C = q.C; d.C_pre = q.C_pre; d.accumulate = q.accumulate;
     }
     const int S = plan_splitk(L, pr[0].splitk_ws, pr[0].splitk_ws_floats);
-    const int tile = S > 1 ? 2 : pick_tile(L);
+    const int tile = S > 1 ? 2 : pick_tile(L, true);
     finish_tiling(L, tile);
     int rc = launch_any<EPI_LINEAR, false, false>(L, tile, (hipStream_t)stream);
     if (rc || S == 1) return rc;
@@ -794,7 +1149,7 @@ extern "C" int isc_gemm_bwd(const isc_linear_problem *pr, int n_prob, int layout
         d.ldc = q.ldc; d.C = q.C; d.accumulate = q.accumulate;
     }
     const int S = plan_splitk(L, pr[0].splitk_ws, pr[0].splitk_ws_floats);
-    const int tile = S > 1 ? 2 : pick_tile(L);
+    const int tile = S > 1 ? 2 : pick_tile(L, false);
     finish_tiling(L, tile);
     int rc = layout == ISC_LAYOUT_NN ? launch_any<EPI_LINEAR, false, true>(L, tile, (hipStream_t)stream)
                                      : launch_any<EPI_LINEAR, true, true>(L, tile, (hipStream_t)stream);
@@ -832,7 +1187,7 @@ extern "C" int isc_lstm_fwd(const isc_lstm_problem *q, void *stream) {
         ISC_LAUNCH_CHECK();
         return ISC_OK;
     }
-    const int tile = pick_tile(L);
+    const int tile = pick_tile(L, true);
     finish_tiling(L, tile);
     return launch_any<EPI_LSTM, false, false>(L, tile, (hipStream_t)stream);
 }
@@ -853,7 +1208,8 @@ extern "C" int isc_vocab_fwd(const float *h, int ldh, const float *W, int ldw, c
     d.C = logits; d.ld_logits = ld_logits;
     d.pmax = part_max; d.psum = part_sum; d.pidx = part_idx;
     d.ntile_total = (V + 127) / 128;
-    const int tile = pick_tile(L);
+    // no XL here: its lone workgroup per CU cannot hide the per-row softmax statistics of the epilogue
+    const int tile = pick_tile(L, false);
     finish_tiling(L, tile);
     return launch_any<EPI_VOCAB, false, false>(L, tile, (hipStream_t)stream);
 }

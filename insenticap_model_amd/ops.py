@@ -99,6 +99,11 @@ def _fill_segs(dst, segs):
         s.lda, s.ldw, s.K = A.stride(0), W.stride(0), A.shape[1]
 
 
+def set_tile_override(tile):
+    """Force the GEMM tile shape (0..3, see include/insenticap_hip.h) or -1 for the cost model; returns the previous value."""
+    return _lib.load().isc_set_tile_override(int(tile))
+
+
 def linear_problem(segs, out, bias0=None, bias1=None, bias2=None, relu=False, keep_mask=None, mask_scale=1.0,
                    out_pre=None, accumulate=False):
     """out[M,N] = act(sum_s A_s W_s^T + bias0 + bias1) [* keep_mask * mask_scale]."""
