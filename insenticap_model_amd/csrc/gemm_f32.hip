@@ -137,42 +137,59 @@ __device__ __forceinline__ void epi_vocab_frag(const DevProb &P, f32x16 (&acc)[T
     float *smx = smem;                    // [WN][BM] cross-wave combine (WN > 1 only)
     float *ssm = smem + WN * BM;
     int *six = reinterpret_cast<int *>(smem + 2 * WN * BM);
+    // Phased over the fragment's 16 rows, every phase straight-line code: the 16 dependent reduction
+    // chains interleave instead of running one after the other between per-row branches.
+    float mx[16], sm[16];
+    int ix[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const int row = frow0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        const int gm = row0 + row;
-        float x[TN];
-        float mx = -INFINITY;
-        int ix = 0x7fffffff;
+        mx[r] = -INFINITY;
+        ix[r] = 0x7fffffff;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            x[j] = cok[j] ? acc[j][r] + bv[j] : -INFINITY;
+            acc[j][r] = cok[j] ? acc[j][r] + bv[j] : -INFINITY;      // acc now holds the logits
             const int gn = col0 + fcol0 + j * 32 + (lane & 31);
-            if (x[j] > mx) { mx = x[j]; ix = gn; }       // j ascending => smaller column wins ties
+            if (acc[j][r] > mx[r]) { mx[r] = acc[j][r]; ix[r] = gn; }   // j ascending => smaller column wins ties
         }
-        if (P.C && gm < M) {
+    }
+    if (P.C) {
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
-                if (cok[j])
-                    P.C[(long long)gm * P.ld_logits + col0 + fcol0 + j * 32 + (lane & 31)] = x[j];
+        for (int r = 0; r < 16; ++r) {
+            const int gm = row0 + frow0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (gm < M) {
+                float *crow = P.C + (long long)gm * P.ld_logits + col0 + fcol0 + (lane & 31);
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    if (cok[j]) crow[j * 32] = acc[j][r];
+            }
         }
-        half_argmax(mx, ix);
-        float sm = 0.f;
+    }
 #pragma unroll
-        for (int j = 0; j < TN; ++j) sm += cok[j] ? __expf(x[j] - mx) : 0.f;   // padded columns add 0
-        sm = half_sum(sm);
-        if ((lane & 31) == 0) {
+    for (int r = 0; r < 16; ++r) half_argmax(mx[r], ix[r]);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        sm[r] = 0.f;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) sm[r] += cok[j] ? __expf(acc[j][r] - mx[r]) : 0.f;   // padded columns add 0
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sm[r] = half_sum(sm[r]);
+    if ((lane & 31) == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = frow0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const int gm = row0 + row;
             if constexpr (WN == 1) {
                 if (gm < M) {
                     const long long o = (long long)gm * P.ntile_total + tn;
-                    P.pmax[o] = mx;
-                    P.psum[o] = sm;
-                    P.pidx[o] = ix;
+                    P.pmax[o] = mx[r];
+                    P.psum[o] = sm[r];
+                    P.pidx[o] = ix[r];
                 }
             } else {
-                smx[wn * BM + row] = mx;
-                ssm[wn * BM + row] = sm;
-                six[wn * BM + row] = ix;
+                smx[wn * BM + row] = mx[r];
+                ssm[wn * BM + row] = sm[r];
+                six[wn * BM + row] = ix[r];
             }
         }
     }
@@ -1008,6 +1025,10 @@ static int launch_any(const DevLaunch &L, int tile, hipStream_t st) {
 // on a co-resident workgroup to cover their chunk-boundary stalls, the XL tile is pipelined to run
 // alone).  Calibrated on tools/gemm_big.py / gemm_bench.py.
 static int g_tile_override = -1;
+// The vocabulary projection stays on the 128x128 tile: measured at [4096 x 10000 x 512] it runs at 116 TFLOP/s
+// there and 108 on the XL tile, whose lone workgroup per CU has nothing to hide the per-row softmax
+// statistics of the epilogue behind (3k VALU instructions per wave at the end of a 16-chunk tile).
+static int g_vocab_xl = 0;
 extern "C" int isc_set_tile_override(int tile) {
     const int prev = g_tile_override;
     g_tile_override = (tile >= 0 && tile <= 3) ? tile : -1;
@@ -1208,8 +1229,7 @@ extern "C" int isc_vocab_fwd(const float *h, int ldh, const float *W, int ldw, c
     d.C = logits; d.ld_logits = ld_logits;
     d.pmax = part_max; d.psum = part_sum; d.pidx = part_idx;
     d.ntile_total = (V + 127) / 128;
-    // no XL here: its lone workgroup per CU cannot hide the per-row softmax statistics of the epilogue
-    const int tile = pick_tile(L, false);
+    const int tile = pick_tile(L, g_vocab_xl != 0);
     finish_tiling(L, tile);
     return launch_any<EPI_VOCAB, false, false>(L, tile, (hipStream_t)stream);
 }
