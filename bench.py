@@ -194,10 +194,13 @@ def bench_beam(cap, inputs, n_img=64, beam=5):
                 batched_images=n_img, batched_images_per_s=round(n_img / el, 1))
 
 
-PMC_SUMMARY = os.path.join(ROOT, 'profiles', 'r01_c_pmc_summary_B4096.json')
-KERNEL_SYMBOL = {'vocab[': 'void gemm_kernel<4, 1, 4, 2, false, false>', 'lstm[': 'void gemm_kernel<4, 1, 4, 1, false, false>',
-                 'attn_scan[': 'void attn_scan_kernel<2>', 'gate_mix[': 'gate_mix_kernel',
-                 'rollout_finalize[': 'rollout_finalize_kernel'}
+PMC_SUMMARY = os.path.join(ROOT, 'profiles', 'r01_d_pmc_summary_B4096.json')
+# bench kernel label -> device symbols it may run as (first one present in the PMC summary wins)
+KERNEL_SYMBOL = {'vocab[': ['void gemm_kernel<4, 1, 4, 2, false, false>'],
+                 'lstm[4096x2048x1536': ['void gemm_xl_kernel<1>'],      # lang-LSTM (bias-only cell)
+                 'lstm[': ['void gemm_kernel<4, 1, 4, 1, false, false>', 'void gemm_xl_kernel<1>'],
+                 'attn_scan[': ['void attn_scan_kernel<2>'], 'gate_mix[': ['gate_mix_kernel'],
+                 'rollout_finalize[': ['rollout_finalize_kernel']}
 
 
 def pmc_traffic(name, batch):
@@ -209,9 +212,11 @@ def pmc_traffic(name, batch):
         return None
     if d.get('batch_per_gpu') != batch:
         return None
-    for prefix, sym in KERNEL_SYMBOL.items():
-        if name.startswith(prefix) and sym in d['kernels']:
-            return d['kernels'][sym]['traffic_bytes']
+    for prefix, syms in KERNEL_SYMBOL.items():
+        if name.startswith(prefix):
+            for sym in syms:
+                if sym in d['kernels']:
+                    return d['kernels'][sym]['traffic_bytes']
     return None
 
 

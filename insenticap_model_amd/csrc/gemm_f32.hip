@@ -1208,7 +1208,10 @@ extern "C" int isc_lstm_fwd(const isc_lstm_problem *q, void *stream) {
         ISC_LAUNCH_CHECK();
         return ISC_OK;
     }
-    const int tile = pick_tile(L, true);
+    // XL only for the bias-only cell: a hoisted `pre` term or an embedding-table gather adds 8-16 B of
+    // epilogue reads per output, which the XL tile's lone workgroup per CU cannot overlap with MFMA work
+    // (in the roll-out: att-LSTM 168 us on the 128x128 tile vs 178 us on XL; lang-LSTM 223 vs 206)
+    const int tile = pick_tile(L, !q->pre && !q->tab);
     finish_tiling(L, tile);
     return launch_any<EPI_LSTM, false, false>(L, tile, (hipStream_t)stream);
 }
