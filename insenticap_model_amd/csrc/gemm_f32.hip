@@ -259,106 +259,105 @@ __device__ __forceinline__ void epi_linear_tile(const DevProb &P, const float *C
     }
 }
 
-// LSTM cell update of one (row, unit) from its four gate pre-activations (W x products only; biases,
-// the hoisted `pre` term and the embedding-table row are added here), gate order i, f, g, o.
-__device__ __forceinline__ void lstm_cell_store(const DevProb &P, int gm, int unit, float gi, float gf, float gg, float go) {
+// LSTM cell update from the four gate pre-activations of NE (row, unit) elements, gate order i, f, g, o.
+// The epilogue's global operands - hoisted `pre` term, embedding-table row (behind its token id),
+// c_prev - are fetched for all NE elements BEFORE any arithmetic: issued element by element inside the
+// compute loop they formed NE serial dependent round trips (att-LSTM at B=4096: +24 us per launch).
+// Per element:  g += (b_ih + b_hh);  g += pre;  g += table row   (same order in every kernel).
+template <int NE>
+__device__ __forceinline__ void lstm_cells(const DevProb &P, const int (&gm)[NE], int unit, const bool (&ok)[NE],
+                                           float (&g)[NE][4]) {
     const int H = P.H;
-    if (P.bias0) {
-        gi += P.bias0[unit] + P.bias1[unit];
-        gf += P.bias0[H + unit] + P.bias1[H + unit];
-        gg += P.bias0[2 * H + unit] + P.bias1[2 * H + unit];
-        go += P.bias0[3 * H + unit] + P.bias1[3 * H + unit];
+    const bool has_b = P.bias0 != nullptr, has_pre = P.pre != nullptr, has_tab = P.tab != nullptr;
+    float q[NE][4], t[NE][4], b[4], cp[NE];
+    long long tok[NE];
+    if (has_tab) {
+#pragma unroll
+        for (int e = 0; e < NE; ++e) tok[e] = ok[e] ? P.tab_ids[(long long)gm[e] * P.tab_ids_stride] : 0;
     }
-    if (P.pre) {
-        const float *q = P.pre + (long long)gm * 4 * H + unit;
-        gi += q[0]; gf += q[H]; gg += q[2 * H]; go += q[3 * H];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) cp[e] = ok[e] ? P.c_prev[(long long)gm[e] * H + unit] : 0.f;
+    if (has_pre) {
+#pragma unroll
+        for (int e = 0; e < NE; ++e)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) q[e][k] = ok[e] ? P.pre[(long long)gm[e] * 4 * H + k * H + unit] : 0.f;
     }
-    if (P.tab) {
-        const float *q = P.tab + P.tab_ids[(long long)gm * P.tab_ids_stride] * 4 * H + unit;
-        gi += q[0]; gf += q[H]; gg += q[2 * H]; go += q[3 * H];
+    if (has_tab) {
+#pragma unroll
+        for (int e = 0; e < NE; ++e)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) t[e][k] = ok[e] ? P.tab[tok[e] * 4 * H + k * H + unit] : 0.f;
     }
-    gi = isc_sigmoid(gi);
-    gf = isc_sigmoid(gf);
-    gg = isc_tanh(gg);
-    go = isc_sigmoid(go);
-    const long long o = (long long)gm * H + unit;
-    const float c2 = gf * P.c_prev[o] + gi * gg;
-    const float h2 = go * isc_tanh(c2);
-    P.c_out[o] = c2;
-    P.h_out[o] = h2;
-    if (P.hmask) P.hdrop[o] = h2 * (float)P.hmask[o] * P.mask_scale;
-    if (P.gates_out) {
-        float *g = P.gates_out + (long long)gm * 4 * H + unit;
-        g[0] = gi; g[H] = gf; g[2 * H] = gg; g[3 * H] = go;
+    if (has_b) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) b[k] = P.bias0[k * H + unit] + P.bias1[k * H + unit];
+    }
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (has_b) g[e][k] += b[k];
+            if (has_pre) g[e][k] += q[e][k];
+            if (has_tab) g[e][k] += t[e][k];
+        }
+        const float gi = isc_sigmoid(g[e][0]), gf = isc_sigmoid(g[e][1]), gg = isc_tanh(g[e][2]), go = isc_sigmoid(g[e][3]);
+        const float c2 = gf * cp[e] + gi * gg;
+        const float h2 = go * isc_tanh(c2);
+        if (ok[e]) {
+            const long long o = (long long)gm[e] * H + unit;
+            P.c_out[o] = c2;
+            P.h_out[o] = h2;
+            if (P.hmask) P.hdrop[o] = h2 * (float)P.hmask[o] * P.mask_scale;
+            if (P.gates_out) {
+                float *go_ = P.gates_out + (long long)gm[e] * 4 * H + unit;
+                go_[0] = gi; go_[H] = gf; go_[2 * H] = gg; go_[3 * H] = go;
+            }
+        }
     }
 }
 
-// gate-interleaved tile (columns = 4 gates x 32 units) -> LSTM cell update of units tn*32 .. +32
+// gate-interleaved tile (columns = 4 gates x 32 units) in LDS -> cells of units tn*32 .. +32.  A thread's
+// elements are rows tid/32 + 8*i of ONE unit (tid % 32).
 template <int BM, int BN>
 __device__ __forceinline__ void epi_lstm_tile(const DevProb &P, const float *Cs, int row0, int tn, int tid) {
-    constexpr int LDC = BN + 4;
-    const int M = P.M;
-    for (int idx = tid; idx < BM * 32; idx += 256) {
-        const int row = idx >> 5, u = idx & 31;
-        const int gm = row0 + row;
-        if (gm >= M) continue;
-        const float *cr = Cs + row * LDC + u;
-        lstm_cell_store(P, gm, tn * 32 + u, cr[0], cr[32], cr[64], cr[96]);
-    }
-}
-
-// The same two epilogues straight from a 32 x 128 accumulator fragment (C/D layout: col = lane&31 of
-// sub-tile j, row = (r&3) + 8*(r>>2) + 4*(lane>>5)): every store instruction writes two full 128-byte
-// row segments.  Used by the XL tile, whose lone workgroup per CU has nobody to hide an LDS round
-// trip and a branchy tile loop behind.  Same per-element arithmetic (and order) as the staged forms.
-// Interior tiles (no edge predicate) run branch-free per element; the feature flags are uniform and
-// tested once per fragment.
-template <bool EDGE>
-__device__ __forceinline__ void epi_lstm_frag_impl(const DevProb &P, f32x16 (&acc)[4], int frow0, int lane, int row0, int tn) {
-    const int H = P.H, unit = tn * 32 + (lane & 31);
-    float bi = 0.f, bf = 0.f, bg = 0.f, bo = 0.f;
-    if (P.bias0) {
-        bi = P.bias0[unit] + P.bias1[unit];
-        bf = P.bias0[H + unit] + P.bias1[H + unit];
-        bg = P.bias0[2 * H + unit] + P.bias1[2 * H + unit];
-        bo = P.bias0[3 * H + unit] + P.bias1[3 * H + unit];
-    }
-    const bool has_b = P.bias0 != nullptr, has_pre = P.pre != nullptr, has_tab = P.tab != nullptr;
-    const bool has_drop = P.hmask != nullptr, has_gates = P.gates_out != nullptr;
+    constexpr int LDC = BN + 4, NE = 4;
+    static_assert(BM * 32 % (256 * NE) == 0, "tile rows per thread must be a multiple of the batch");
+    const int u = tid & 31;
+    for (int base = tid; base < BM * 32; base += 256 * NE) {
+        int gm[NE];
+        bool ok[NE];
+        float g[NE][4];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int gm = row0 + frow0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (EDGE && gm >= P.M) continue;
-        float gi = acc[0][r], gf = acc[1][r], gg = acc[2][r], go = acc[3][r];
-        if (has_b) { gi += bi; gf += bf; gg += bg; go += bo; }
-        if (has_pre) {
-            const float *q = P.pre + (long long)gm * 4 * H + unit;
-            gi += q[0]; gf += q[H]; gg += q[2 * H]; go += q[3 * H];
+        for (int e = 0; e < NE; ++e) {
+            const int row = (base + 256 * e) >> 5;
+            gm[e] = row0 + row;
+            ok[e] = gm[e] < P.M;
+            const float *cr = Cs + row * LDC + u;
+            g[e][0] = cr[0]; g[e][1] = cr[32]; g[e][2] = cr[64]; g[e][3] = cr[96];
         }
-        if (has_tab) {
-            const float *q = P.tab + P.tab_ids[(long long)gm * P.tab_ids_stride] * 4 * H + unit;
-            gi += q[0]; gf += q[H]; gg += q[2 * H]; go += q[3 * H];
-        }
-        gi = isc_sigmoid(gi);
-        gf = isc_sigmoid(gf);
-        gg = isc_tanh(gg);
-        go = isc_sigmoid(go);
-        const long long o = (long long)gm * H + unit;
-        const float c2 = gf * P.c_prev[o] + gi * gg;
-        const float h2 = go * isc_tanh(c2);
-        P.c_out[o] = c2;
-        P.h_out[o] = h2;
-        if (has_drop) P.hdrop[o] = h2 * (float)P.hmask[o] * P.mask_scale;
-        if (has_gates) {
-            float *g = P.gates_out + (long long)gm * 4 * H + unit;
-            g[0] = gi; g[H] = gf; g[2 * H] = gg; g[3 * H] = go;
-        }
+        lstm_cells<NE>(P, gm, tn * 32 + u, ok, g);
     }
 }
 
+// The same from a 32 x 128 accumulator fragment (fragment j = gate j, lane&31 = unit; C/D row map): used by
+// the XL tile, whose lone workgroup per CU has nobody to hide an LDS round trip behind.
 __device__ __forceinline__ void epi_lstm_frag(const DevProb &P, f32x16 (&acc)[4], int frow0, int lane, int row0, int tn) {
-    if (row0 + frow0 + 32 <= P.M) epi_lstm_frag_impl<false>(P, acc, frow0, lane, row0, tn);
-    else epi_lstm_frag_impl<true>(P, acc, frow0, lane, row0, tn);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        int gm[8];
+        bool ok[8];
+        float g[8][4];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int r = half * 8 + e;
+            gm[e] = row0 + frow0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            ok[e] = gm[e] < P.M;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) g[e][k] = acc[k][r];
+        }
+        lstm_cells<8>(P, gm, tn * 32 + (lane & 31), ok, g);
+    }
 }
 
 // FAST: interior fragment without accumulate / pre-activation copy / keep-mask
@@ -468,7 +467,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(const DevLaunch L) {
     for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-
     int nchunks = 0;
     for (int s = 0; s < P.nseg; ++s) nchunks += (P.seg[s].K + BK - 1) / BK;
 
@@ -1210,7 +1208,8 @@ extern "C" int isc_lstm_fwd(const isc_lstm_problem *q, void *stream) {
     }
     // XL only for the bias-only cell: a hoisted `pre` term or an embedding-table gather adds 8-16 B of
     // epilogue reads per output, which the XL tile's lone workgroup per CU cannot overlap with MFMA work
-    // (in the roll-out: att-LSTM 168 us on the 128x128 tile vs 178 us on XL; lang-LSTM 223 vs 206)
+    // (in the roll-out: att-LSTM 168 us on the 128x128 tile vs 178 us on XL; lang-LSTM 223 vs 206; with the
+    // batched epilogue loads of lstm_cells the two are within 2 % of each other on either cell)
     const int tile = pick_tile(L, !q->pre && !q->tab);
     finish_tiling(L, tile);
     return launch_any<EPI_LSTM, false, false>(L, tile, (hipStream_t)stream);
