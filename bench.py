@@ -189,8 +189,10 @@ def bench_beam(cap, inputs, n_img=64, beam=5):
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
     lat.sort()
+    # latency is bimodal with random-init weights: captions either end after ~9 steps or run all T=20
     return dict(beam=beam, per_image_p50_ms=round(lat[len(lat) // 2] * 1e3, 2),
                 per_image_p95_ms=round(lat[int(len(lat) * 0.95) - 1] * 1e3, 2),
+                per_image_min_ms=round(lat[0] * 1e3, 2), per_image_max_ms=round(lat[-1] * 1e3, 2),
                 batched_images=n_img, batched_images_per_s=round(n_img / el, 1))
 
 

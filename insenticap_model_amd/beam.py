@@ -7,6 +7,7 @@ step over I*beam rows + one device top-k per time step and ONE host read of the 
 scores are Python floats (fp64 sums of fp32 log-probs, :404-406) and the per-step selection is
 a stable descending sort over candidates in insertion order (:409), which fixes tie order.
 """
+import numpy as np
 import torch
 
 from . import ops
@@ -31,12 +32,17 @@ def beam_search_batch(cap, fc_feats, att_feats, senti_words, senti_labels, beam,
         setattr(Pb, name, expand(getattr(P, name)))
     Pb.tab = P.tab
     ws = cap._alloc_step_ws(rows, Pb)
-    h_cur, c_cur = cap._zeros(2, rows, H), cap._zeros(2, rows, H)
-    h_nxt, c_nxt = cap._new(2, rows, H), cap._new(2, rows, H)
+    # recurrent state as ONE tensor [h|c, layer, row, H] per buffer: the per-step beam re-ordering is then a
+    # single gather over [next ; current] rows instead of four index_selects and two wheres
+    st_cur = cap._zeros(2, 2, rows, H)
+    st_nxt = cap._new(2, 2, rows, H)
     logits = cap._new(rows, V)
     xt = cap._new(rows, Wd)
-    top_val = cap._new(rows, beam)
-    top_idx = cap._new(rows, beam, dtype=torch.int64)
+    # top-k ids and values share one byte buffer: ONE device->host copy per step (ids first: 8-byte aligned)
+    nk = rows * beam
+    top_buf = torch.empty(nk * 12, dtype=torch.uint8, device=dev)
+    top_idx = top_buf[:nk * 8].view(torch.int64).view(rows, beam)
+    top_val = top_buf[nk * 8:].view(torch.float32).view(rows, beam)
     emb = p['word_embed.0.weight']
     mask_special = cap.pad_id != cap.eos_id
 
@@ -44,15 +50,21 @@ def beam_search_batch(cap, fc_feats, att_feats, senti_words, senti_labels, beam,
     cands = [[(0.0, cap.sos_id, [])] for _ in range(n_img)]
     done = [False] * n_img
     last = [cap.sos_id] * rows
+    ctrl_h = torch.empty(2, rows, dtype=torch.int64).pin_memory()     # [last word ; gather index], one upload per step
+    ctrl_np = ctrl_h.numpy()
+    ctrl_np[0, :] = last
+    ctrl_d = ctrl_h.to(dev, non_blocking=True)
     for t in range(T):
-        last_d = torch.tensor(last, dtype=torch.int64, device=dev)
+        last_d = ctrl_d[0]
+        h_cur, c_cur, h_nxt, c_nxt = st_cur[0], st_cur[1], st_nxt[0], st_nxt[1]
         if Pb.tab is None:
             ops.embed_relu_fwd(emb, last_d, xt)
         cap._step(p, Pb, ws, xt, h_cur, c_cur, h_nxt, c_nxt, logits=logits, tok=last_d)
         ops.beam_topk(logits, ws['pmax'], ws['psum'], last_d, beam, cap.pad_id, cap.sos_id, cap.unk_id,
                       mask_special, decoding_constraint, top_val, top_idx)
-        tv = top_val.cpu().tolist()       # the single host read of this step
-        ti = top_idx.cpu().tolist()
+        hb = top_buf.cpu().numpy()        # the single host read of this step
+        ti = hb[:nk * 8].view(np.int64).reshape(rows, beam).tolist()
+        tv = hb[nk * 8:].view(np.float32).reshape(rows, beam).tolist()
         parent = list(range(rows))        # source row of every new row (state gather)
         stepped = [True] * rows           # False: carried candidate keeps its old state
         any_live = False
@@ -86,12 +98,11 @@ def beam_search_batch(cap, fc_feats, att_feats, senti_words, senti_labels, beam,
                 any_live = True
         if not any_live:
             break
-        # new state of row r = stepped ? nxt[parent] : cur[parent]
-        par = torch.tensor(parent, dtype=torch.int64, device=dev)
-        stp = torch.tensor(stepped, dtype=torch.bool, device=dev).view(1, rows, 1)
-        h_new = torch.where(stp, h_nxt.index_select(1, par), h_cur.index_select(1, par))
-        c_new = torch.where(stp, c_nxt.index_select(1, par), c_cur.index_select(1, par))
-        h_cur, c_cur = h_new.contiguous(), c_new.contiguous()
+        # new state of row r = stepped ? nxt[parent] : cur[parent]  ==  [nxt ; cur][parent + (stepped ? 0 : rows)]
+        ctrl_np[0, :] = last
+        ctrl_np[1, :] = [pr if st else pr + rows for pr, st in zip(parent, stepped)]
+        ctrl_d = ctrl_h.to(dev, non_blocking=True)
+        st_cur = torch.cat([st_nxt, st_cur], dim=2).index_select(2, ctrl_d[1])
     cap.cont_weights, cap.senti_weights, cap.cont_senti_weights = [], [], []
     captions, scores, ids = [], [], []
     for i in range(n_img):
