@@ -446,5 +446,5 @@ class XELossFn(torch.autograd.Function):
 
 def xe_criterion_with_grad(pred, target, lengths):
     ops.require_device(pred, target)
-    ln = torch.tensor(lengths, dtype=torch.int32, device=pred.device)
+    ln = ops.upload(lengths, torch.int32, pred.device)
     return XELossFn.apply(pred.contiguous(), target.long().contiguous(), ln)

@@ -595,6 +595,6 @@ class XECriterion(nn.Module):
             return xe_criterion_with_grad(pred, target, lengths)
         ops.require_device(pred, target)
         out2 = torch.empty(2, dtype=torch.float32, device=pred.device)
-        ln = torch.tensor(lengths, dtype=torch.int32, device=pred.device)
+        ln = ops.upload(lengths, torch.int32, pred.device)
         ops.xe_loss_fwd(pred.contiguous(), target.long().contiguous(), ln, out2)
         return out2[0] / out2[1]

@@ -141,23 +141,50 @@ __device__ __forceinline__ int rollout_finalize_row(const DevRollout &R, int b, 
         it = R.forced[(long long)b * R.T + R.t];
         lp = (R.logits[(long long)b * R.ld_logits + it] - gmax) - logS;
     } else if (R.sample_u) {
-        // inverse-CDF sampling from softmax(logits) with a caller-supplied uniform
+        // inverse-CDF sampling from softmax(logits) with a caller-supplied uniform, in vocabulary order.
+        // Two levels: the vocabulary kernel already left sum exp(x - tile max) per 128-column tile, so the
+        // tile holding the target is found by a prefix over n_tile values and only its 128 columns are
+        // exponentiated (4 wave-prefix rounds per row instead of V/64 = 157: 300 us -> ~15 us at B=512).
         const float target = R.sample_u[(long long)b * R.T + R.t] * S;
         const float *x = R.logits + (long long)b * R.ld_logits;
-        float run = 0.f;
-        int pick = -1;
-        for (int base = 0; base < R.V && pick < 0; base += 64) {
-            const int i = base + lane;
-            const float e = (i < R.V) ? expf(x[i] - gmax) : 0.f;
-            float incl = e;  // inclusive prefix sum over the wave
+        const float *pm = R.part_max + (long long)b * R.n_tile, *ps = R.part_sum + (long long)b * R.n_tile;
+        auto wave_incl = [&](float v) __attribute__((always_inline)) {
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) {
-                const float n = __shfl_up(incl, o, 64);
-                if (lane >= o) incl += n;
+                const float n = __shfl_up(v, o, 64);
+                if (lane >= o) v += n;
             }
-            const unsigned long long hit = __ballot((run + incl > target) && i < R.V);
-            if (hit) pick = base + __ffsll((long long)hit) - 1;
-            run += __shfl(incl, 63, 64);
+            return v;
+        };
+        float run = 0.f;
+        int tile = -1;
+        for (int base = 0; base < R.n_tile && tile < 0; base += 64) {
+            const int j = base + lane;
+            const float w = (j < R.n_tile) ? ps[j] * expf(pm[j] - gmax) : 0.f;
+            const float incl = wave_incl(w);
+            const unsigned long long hit = __ballot((run + incl > target) && j < R.n_tile);
+            if (hit) {
+                const int l = __ffsll((long long)hit) - 1;
+                tile = base + l;
+                run += __shfl(incl - w, l, 64);       // mass in front of the tile
+            } else {
+                run += __shfl(incl, 63, 64);
+            }
+        }
+        int pick = -1;
+        if (tile >= 0) {
+            for (int c = 0; c < 2 && pick < 0; ++c) {
+                const int i = tile * 128 + c * 64 + lane;
+                const float e = (i < R.V) ? expf(x[i] - gmax) : 0.f;
+                const float incl = wave_incl(e);
+                const unsigned long long hit = __ballot((run + incl > target) && i < R.V);
+                if (hit) pick = tile * 128 + c * 64 + __ffsll((long long)hit) - 1;
+                run += __shfl(incl, 63, 64);
+            }
+            if (pick < 0) {                           // the tile's own sum rounded differently: its last column
+                pick = tile * 128 + 127;
+                if (pick > R.V - 1) pick = R.V - 1;
+            }
         }
         if (pick < 0) pick = gidx;  // target == S after rounding
         it = pick;

@@ -13,6 +13,7 @@ from collections import defaultdict
 import torch
 import torch.nn as nn
 
+from . import ops
 from .captioner import Captioner
 from .helper_nets import SentenceSentimentClassifier, SentimentDetector
 from .optim import clip_gradient
@@ -151,7 +152,7 @@ class Detector(nn.Module):
             self._senti_cache, self._senti_cache_key = {}, key
         cache = self._senti_cache
         if all(fn in cache for fn in fns):
-            return torch.tensor([cache[fn] for fn in fns], dtype=torch.int64, device=att_feats.device)
+            return ops.upload([cache[fn] for fn in fns], torch.int64, att_feats.device)
         labels = self.senti_detector.sample(att_feats, self.senti_threshold)[0].detach()
         for fn, lab in zip(fns, labels.tolist()):
             cache[fn] = lab

@@ -80,6 +80,13 @@ def ptr(t):
     return None if t is None else t.data_ptr()
 
 
+def upload(values, dtype, device):
+    """Small host list -> device tensor through pinned memory, asynchronously.  A pageable
+    `torch.tensor(values, device=...)` is a stream-ordered blocking copy: the host would stall behind every
+    kernel already queued (1.2 ms per criterion call in the XE training step)."""
+    return torch.tensor(values, dtype=dtype).pin_memory().to(device, non_blocking=True)
+
+
 def require_device(*tensors):
     for t in tensors:
         if t is not None and not t.is_cuda:
