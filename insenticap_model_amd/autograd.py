@@ -395,7 +395,7 @@ def rollout_with_grad(cap, fc, att, cpt_words, senti_words, senti_labels, T, rep
     with torch.no_grad():
         if masks is None and cap.training and cap.drop.p > 0:
             masks = _draw_masks(cap, fc, att, senti_words, T)
-        seq, _, seq_masks, raw, steps = cap._rollout(fc, att, cpt_words, senti_words, senti_labels, T, 0,
+        seq, _, seq_masks, raw, alive = cap._rollout(fc, att, cpt_words, senti_words, senti_labels, T, 0,
                                                      replay, masks)
     B = seq.shape[0]
     sos = torch.full((B, 1), cap.sos_id, dtype=torch.int64, device=seq.device)
@@ -409,7 +409,7 @@ def rollout_with_grad(cap, fc, att, cpt_words, senti_words, senti_labels, T, rep
     logp = outs[0]
     cap.cpt_feats, cap.fc_feats = outs[1], outs[2]
     lp = logp.gather(2, raw.unsqueeze(2)).squeeze(2)
-    live = (torch.arange(T, device=seq.device) < steps).to(lp.dtype)      # zero after the early break
+    live = (alive[:T] > 0).to(lp.dtype)      # step t ran iff some row was unfinished before it: zero after the early break
     return seq, lp * live, seq_masks
 
 

@@ -408,11 +408,40 @@ class Captioner(nn.Module):
             ops.logsoftmax_apply(logits, ws['pmax'], ws['psum'])
 
     def _set_weights(self, aC, aS, bG, steps):
-        """attention._get_weights (captioner.py:83-94): per-step weights concatenated along dim 1."""
+        """attention._get_weights (captioner.py:83-94): per-step weights concatenated along dim 1.
+        `steps` may be the roll-out's device-side `alive` counter vector instead of an int: the number of
+        executed steps (the reference's early `break`, captioner.py:343-344) is then read from the device
+        only if somebody looks at the weights - the roll-out itself stays free of host syncs."""
+        self._weights_pending = (aC, aS, bG, steps)
+
+    def _resolve_weights(self):
+        pend = self.__dict__.get('_weights_pending')
+        if pend is None:
+            return
+        aC, aS, bG, steps = pend
+        self._weights_pending = None
+        if torch.is_tensor(steps):                       # alive[t+1] == 0: no row unfinished after step t
+            alive_h = steps.cpu().tolist()
+            T = len(alive_h) - 1
+            steps = next((t + 1 for t in range(T) if alive_h[t + 1] == 0), T)
         B = (aC if aC is not None else aS).shape[0]
-        self.cont_weights = aC[:, :steps].reshape(B, -1) if aC is not None else []
-        self.senti_weights = aS[:, :steps].reshape(B, -1) if aS is not None else []
-        self.cont_senti_weights = bG[:, :steps] if bG is not None else []
+        self._weights = (aC[:, :steps].reshape(B, -1) if aC is not None else [],
+                         aS[:, :steps].reshape(B, -1) if aS is not None else [],
+                         bG[:, :steps] if bG is not None else [])
+
+    def _weight_get(self, i):
+        self._resolve_weights()
+        return self.__dict__.get('_weights', ([], [], []))[i]
+
+    def _weight_set(self, i, value):
+        self._resolve_weights()
+        w = list(self.__dict__.get('_weights', ([], [], [])))
+        w[i] = value
+        self._weights = tuple(w)
+
+    cont_weights = property(lambda self: self._weight_get(0), lambda self, v: self._weight_set(0, v))
+    senti_weights = property(lambda self: self._weight_get(1), lambda self, v: self._weight_set(1, v))
+    cont_senti_weights = property(lambda self: self._weight_get(2), lambda self, v: self._weight_set(2, v))
 
     # ------------------------------------------------------------------ modes
     def forward(self, *args, **kwargs):
@@ -544,15 +573,9 @@ class Captioner(nn.Module):
             rs.xt_next = None if use_tab else xt[nxt].data_ptr()
             ops.rollout_finalize(rs)
         ops.TIMER.armed = False
-        # one host read per roll-out: number of steps the reference would have executed
-        alive_h = alive.cpu()
-        steps = T
-        for t in range(T):
-            if int(alive_h[t + 1]) == 0:
-                steps = t + 1
-                break
-        self._set_weights(aC, aS, bG, steps)
-        return seq, seq_logprobs, seq_masks, raw, steps
+        # no host read: the executed-step count stays on the device (`alive`) until someone needs it
+        self._set_weights(aC, aS, bG, alive)
+        return seq, seq_logprobs, seq_masks, raw, alive
 
     # ------------------------------------------------------------------ beam search
     def sample(self, fc_feat, att_feat, senti_words=None, senti_label=None,

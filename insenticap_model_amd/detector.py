@@ -60,7 +60,13 @@ class Detector(nn.Module):
             raise Exception('data_type(%s) is wrong!' % data_type)
         cap = self.captioner
         cap.train(training)
+        # statistics stay on the device until the end of the call: every float(tensor) would stall the host
+        # behind the whole queue (the reference reads them one by one, decoder.py:90-163)
         sums = defaultdict(float)
+
+        def add(key, value):
+            sums[key] = sums[key] + (value.detach() if torch.is_tensor(value) else value)
+
         device = next(self.parameters()).device
         seq2seq_iter = iter(data[1]) if training else None
         caption_iter = iter(data[0])
@@ -84,7 +90,7 @@ class Detector(nn.Module):
                 fc_feats, att_feats, cpts_tensor, sentis_tensor, senti_labels, self.max_seq_len,
                 sample_max=0, mode='rl')
             da_loss = self.cap_da_crit(cap.cpt_feats, cap.fc_feats.detach())
-            sums['da_loss'] += float(da_loss.detach())
+            add('da_loss', da_loss)
 
             cap.eval()                                   # greedy baseline
             with torch.no_grad():
@@ -93,24 +99,18 @@ class Detector(nn.Module):
                     sample_max=1, mode='rl')
             cap.train(training)
 
-            if data_type == 'fact':
-                fact_reward = get_self_critical_reward(
-                    sample_captions, greedy_captions, fns, ground_truth, cap.sos_id, cap.eos_id,
-                    self.ciderd_scorer)
-                fact_reward = torch.from_numpy(fact_reward).float().to(device)
-                sums['fact_reward'] += float(fact_reward[:, 0].mean())
-            else:
-                fact_reward = 0
-
-            cls_reward = get_cls_reward(sample_captions, seq_masks, greedy_captions, greedy_masks, senti_labels,
-                                        self.sent_senti_cls)
-            cls_reward = torch.from_numpy(cls_reward).float().to(device)
-            sums['cls_reward'] += float(cls_reward.mean(-1).mean(-1))
-
-            rewards = fact_reward + self.cls_flag * cls_reward
-            sums['all_rewards'] += float(rewards.mean(-1).mean(-1))
-            cap_loss = self.cap_rl_crit(sample_logprobs, seq_masks, rewards)
-            sums['cap_loss'] += float(cap_loss.detach())
+            # The rewards need the token matrices on the host (CIDEr-D is host code).  Start their copies
+            # now, enqueue the XE / seq2seq forward passes, and only then wait: the host scores the captions
+            # while the device works through the two unrolls.  The order of the captioner calls - hence of
+            # every random draw - is the reference's; only host-side waiting moved.
+            host_sample = torch.empty(sample_captions.shape, dtype=sample_captions.dtype).pin_memory()
+            host_greedy = torch.empty(greedy_captions.shape, dtype=greedy_captions.dtype).pin_memory()
+            host_lens = torch.empty(seq_masks.shape[0], dtype=torch.int32).pin_memory()
+            host_sample.copy_(sample_captions, non_blocking=True)
+            host_greedy.copy_(greedy_captions, non_blocking=True)
+            host_lens.copy_(seq_masks.sum(dim=-1).type(torch.int32), non_blocking=True)
+            copied = torch.cuda.Event()
+            copied.record()
 
             xe_loss = 0.0
             if data_type == 'fact':                      # XE on the ground truth, labelled by the classifier
@@ -119,7 +119,7 @@ class Detector(nn.Module):
                     xe_senti_labels = xe_senti_labels.softmax(dim=-1).argmax(dim=-1).detach()
                 pred = cap(fc_feats, att_feats, cpts_tensor, caps_tensor, xe_senti_labels, ss_prob=0.5, mode='xe')
                 xe_loss = self.cap_xe_crit(pred, caps_tensor[:, 1:], lengths)
-                sums['xe_loss'] += float(xe_loss.detach())
+                add('xe_loss', xe_loss)
 
             seq2seq_loss = 0.0
             if training:
@@ -133,7 +133,25 @@ class Detector(nn.Module):
                 s_sentis, s_labels = s_sentis.to(device), s_labels.to(device)
                 pred = cap(s_caps, s_cpts, s_sentis, s_labels, ss_prob=0.25, mode='seq2seq')
                 seq2seq_loss = self.seq_flag * self.cap_xe_crit(pred, s_caps[:, 1:], s_lengths)
-                sums['seq2seq_loss'] += float(seq2seq_loss.detach())
+                add('seq2seq_loss', seq2seq_loss)
+
+            copied.synchronize()
+            cls_reward = get_cls_reward(sample_captions, seq_masks, greedy_captions, greedy_masks, senti_labels,
+                                        self.sent_senti_cls, sample_lens=host_lens.tolist(), on_device=True)
+            if data_type == 'fact':
+                fact_reward = get_self_critical_reward(
+                    host_sample.numpy(), host_greedy.numpy(), fns, ground_truth, cap.sos_id, cap.eos_id,
+                    self.ciderd_scorer)
+                fact_reward = ops.upload(fact_reward.astype('float32'), torch.float32, device)
+                add('fact_reward', fact_reward[:, 0].mean())
+            else:
+                fact_reward = 0
+            add('cls_reward', cls_reward.mean(-1).mean(-1))
+
+            rewards = fact_reward + self.cls_flag * cls_reward
+            add('all_rewards', rewards.mean(-1).mean(-1))
+            cap_loss = self.cap_rl_crit(sample_logprobs, seq_masks, rewards)
+            add('cap_loss', cap_loss)
 
             total = cap_loss + xe_loss + da_loss + seq2seq_loss
             if training:
@@ -142,7 +160,7 @@ class Detector(nn.Module):
                 clip_gradient(self.cap_optim)            # 0.1, fused into the Adam launch
                 self.cap_optim.step()
 
-        return {k: v / len(data) for k, v in sums.items()}
+        return {k: float(v) / len(data) for k, v in sums.items()}
 
     def _image_sentiments(self, fns, att_feats):
         if not self.cache_image_sentiments:

@@ -155,17 +155,24 @@ def get_self_critical_reward(sample_captions, greedy_captions, fns, ground_truth
     return np.repeat(scores[:, np.newaxis], sample_captions.shape[1], 1)
 
 
-def get_cls_reward(sample_captions, sample_masks, greedy_captions, greedy_masks, senti_labels, sent_senti_cls):
+def get_cls_reward(sample_captions, sample_masks, greedy_captions, greedy_masks, senti_labels, sent_senti_cls,
+                   sample_lens=None, on_device=False):
     """utils.py:120-151: 1[classifier(sample) == label] x per-token squeeze-excite weights, zero-padded
-    to T. `sent_senti_cls` is the frozen helper net (helper_nets.SentenceSentimentClassifier)."""
+    to T. `sent_senti_cls` is the frozen helper net (helper_nets.SentenceSentimentClassifier).
+    `sample_lens` (host ints) skips the device->host read of the mask sums; `on_device=True` returns the
+    [B,T] float tensor without a host round trip (the trainer adds it to the CIDEr reward on the device)."""
     training = sent_senti_cls.training
-    sample_lens = list(sample_masks.sum(dim=-1).type(torch.int).cpu().numpy())
+    if sample_lens is None:
+        sample_lens = list(sample_masks.sum(dim=-1).type(torch.int).cpu().numpy())
     sent_senti_cls.eval()
     with torch.no_grad():
         sample_preds, sample_att_weights = sent_senti_cls(sample_captions, sample_lens)
         sample_preds = sample_preds.softmax(dim=-1).argmax(dim=-1)
         sample_preds = (sample_preds == senti_labels).type_as(sample_att_weights).unsqueeze(1)
-        sample_scores = (sample_preds * sample_att_weights).detach().cpu().numpy()
+        sample_scores = (sample_preds * sample_att_weights).detach()
     sent_senti_cls.train(training)
     max_len = sample_captions.shape[1]
+    if on_device:
+        return torch.nn.functional.pad(sample_scores, (0, max_len - sample_scores.shape[1]))
+    sample_scores = sample_scores.cpu().numpy()
     return np.pad(sample_scores, ((0, 0), (0, max_len - sample_scores.shape[1])))
