@@ -326,11 +326,14 @@ int isc_gate_mix_bwd(const float *z, const float *w, const float *v, const float
                      float *dz, float *dw_rows, float *db_rows, int accumulate, void *stream);
 
 /* Embedding + ReLU backward: demb[id(r),:] += scale * dout[r / rows_per_grad,:] * (emb[id(r),:] > 0)
- * [* mask]. pad_first = n_words+1 selects the sentiment-word layout (row 0 of every image = <PAD>). */
+ * [* mask]. pad_first = n_words+1 selects the sentiment-word layout (row 0 of every image = <PAD>).
+ * Deterministic (no floating-point atomics): the positions of one id are summed in ascending order by the
+ * workgroup of its first occurrence.  Rows with id == skip_id are left untouched (nn.Embedding's
+ * padding_idx row, whose gradient the caller discards; -1 = none).  W <= 1024. */
 int isc_embed_relu_bwd(const float *emb, int V, int W, const int64_t *ids, int64_t ids_stride,
                        int n_rows, int rows_per_grad, int pad_first, int64_t pad_id, const float *dout,
                        float scale, const uint8_t *keep_mask, float mask_scale, float *demb,
-                       void *stream);
+                       int64_t skip_id, void *stream);
 
 /* out[n] (+)= sum_m x[m,n]  (bias gradients). With a workspace of >= 64*N floats tall matrices are
  * summed in two deterministic stages (row chunks in parallel, then the chunks in order). */

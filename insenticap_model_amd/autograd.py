@@ -242,7 +242,7 @@ def _backward(cap, S, dlogp, d_fc_feats, d_cpt_feats):
     ops.gemm_bwd(probs, NN)
     emb = p['word_embed.0.weight']
     dEmb = zeros(V, Wd)
-    ops.embed_relu_bwd(emb, S.tok.view(-1), dxt, dEmb, TB)
+    ops.embed_relu_bwd(emb, S.tok.view(-1), dxt, dEmb, TB, skip_id=cap.pad_id)    # the <PAD> row is zeroed below
 
     zero1 = lambda: zeros(1)
     if has_c:
@@ -304,7 +304,7 @@ def _backward(cap, S, dlogp, d_fc_feats, d_cpt_feats):
         dVw = dV_w.view(BM, Wd)
         ops.gemm_bwd([nn([(dzp, p['senti2att.0.weight'])], dVw, True)], NN)
         ops.embed_relu_bwd(emb, P.sw_ids, dVw, dEmb, BM, pad_first=P.Mw, pad_id=cap.pad_id,
-                           keep_mask=P.m_words, mask_scale=P.sc)
+                           keep_mask=P.m_words, mask_scale=P.sc, skip_id=cap.pad_id)
     # fc_embed (xe / rl) and cpt2fc
     d_cpt = None
     if S.mode != 'seq2seq':
@@ -332,7 +332,8 @@ def _backward(cap, S, dlogp, d_fc_feats, d_cpt_feats):
         dcm = new(B, Wd)
         ops.gemm_bwd([nn([(d_cpt, p['cpt2fc.0.weight'])], dcm)], NN)
         C = P.cpt_ids.shape[1]
-        ops.embed_relu_bwd(emb, P.cpt_ids.view(-1), dcm, dEmb, B * C, rows_per_grad=C, scale=1.0 / C)
+        ops.embed_relu_bwd(emb, P.cpt_ids.view(-1), dcm, dEmb, B * C, rows_per_grad=C, scale=1.0 / C,
+                           skip_id=cap.pad_id)
     dEmb[cap.pad_id].zero_()     # nn.Embedding(padding_idx=pad_id): the <PAD> row never gets a gradient
     G['word_embed.0.weight'] = dEmb
     return G

@@ -232,45 +232,125 @@ extern "C" int isc_gate_mix_bwd(const float *z, const float *w, const float *v, 
     return ISC_OK;
 }
 
-// ------------------------------------------------------------------ embedding backward (scatter-add)
+// ------------------------------------------------------------------ embedding backward (deterministic scatter-add)
 // demb[ids[r], :] += scale * dout[r / rows_per_grad, :] * (emb[ids[r], :] > 0) [* mask[r,:]*mask_scale]
-__global__ __launch_bounds__(256) void embed_relu_bwd_kernel(const float *emb, int W, const int64_t *ids,
-                                                             long long ids_stride, int n_rows,
-                                                             int rows_per_grad, int pad_first,
-                                                             long long pad_id, const float *dout,
+// No floating-point atomics: one workgroup per input position r; it works only if r is the FIRST position
+// holding its id, then sums every position with that id in ascending order and adds the total to the row it
+// alone owns in this launch.  The id array (<= 80 KB) stays in L2, so the "am I first" test over the
+// earlier positions and the match scan over the later ones cost ~N/256 cached reads per thread.
+struct EmbIds {
+    const int64_t *ids;
+    long long ids_stride, pad_id, skip_id;
+    int pad_first;
+    __device__ __forceinline__ long long at(int r) const {
+        if (pad_first) {            // senti-word layout: row = b*(n+1)+m, m==0 is the <PAD> prefix
+            const int Mw = pad_first, b = r / Mw, m = r % Mw;
+            return (m == 0) ? pad_id : ids[(long long)b * (Mw - 1) + (m - 1)];
+        }
+        return ids[(long long)r * ids_stride];
+    }
+};
+
+#define ISC_EMB_ROUND 2048   // positions compacted per round (LDS list)
+template <bool MASK>
+__global__ __launch_bounds__(256) void embed_relu_bwd_kernel(const float *emb, int W, EmbIds I, int n_rows,
+                                                             int rows_per_grad, const float *dout,
                                                              float scale, const uint8_t *mask,
                                                              float mask_scale, float *demb) {
-    const int lane = threadIdx.x & 63;
-    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r >= n_rows) return;
-    long long id;
-    if (pad_first) {            // senti-word layout: row = b*(n+1)+m, m==0 is the <PAD> prefix
-        const int Mw = pad_first, b = r / Mw, m = r % Mw;
-        id = (m == 0) ? pad_id : ids[(long long)b * (Mw - 1) + (m - 1)];
-    } else {
-        id = ids[(long long)r * ids_stride];
+    __shared__ int list[ISC_EMB_ROUND];
+    __shared__ int cnt[256];
+    __shared__ int flag;
+    const int tid = threadIdx.x, r = blockIdx.x;
+    const long long id = I.at(r);
+    if (tid == 0) flag = 0;
+    __syncthreads();
+    int seen = 0;
+    for (int q = tid; q < r; q += 256) seen |= (I.at(q) == id);
+    if (seen) flag = 1;                       // benign race: every writer stores 1
+    __syncthreads();
+    if (flag || id == I.skip_id) return;     // an earlier position owns this id / the caller discards this row
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};      // columns tid, tid+256, ... (W <= 1024)
+    for (int base = r; base < n_rows; base += ISC_EMB_ROUND) {
+        // ordered compaction of the matches in [base, base + ROUND): thread t scans a contiguous slice
+        const int per = ISC_EMB_ROUND / 256, q0 = base + tid * per;
+        int mine[ISC_EMB_ROUND / 256], n = 0;
+#pragma unroll
+        for (int k = 0; k < per; ++k) {
+            const int q = q0 + k;
+            const bool hit = q < n_rows && I.at(q) == id;
+            mine[k] = hit ? q : -1;
+            n += hit;
+        }
+        cnt[tid] = n;
+        __syncthreads();
+        int off = 0, total = 0;
+        for (int t = 0; t < 256; ++t) {       // 256 LDS broadcasts; the launch is tiny next to the GEMMs
+            const int c = cnt[t];
+            off += (t < tid) ? c : 0;
+            total += c;
+        }
+#pragma unroll
+        for (int k = 0; k < per; ++k)
+            if (mine[k] >= 0) list[off++] = mine[k];
+        __syncthreads();
+        // ascending position order = a fixed summation order; 8 rows' loads in flight at a time (a frequent
+        // token is ONE workgroup walking hundreds of rows: without this the walk is a chain of L2 round
+        // trips).  Loads are unconditional - out-of-range slots re-read a valid element with weight 0 -
+        // because a predicated load is a branch, and branches serialise the 16 loads of a group again.
+        int ci[4];
+        float cw[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = tid + 256 * k;
+            ci[k] = i < W ? i : 0;
+            cw[k] = i < W ? 1.f : 0.f;
+        }
+        for (int m0 = 0; m0 < total; m0 += 8) {
+            float v[8][4];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const bool live = m0 + u < total;
+                const int q = list[live ? m0 + u : total - 1];
+                const float wq = live ? scale : 0.f;
+                const float *g = dout + (long long)(q / rows_per_grad) * W;
+                if (MASK) {
+                    const uint8_t *mk = mask + (long long)q * W;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[u][k] = g[ci[k]] * (wq * cw[k]) * ((float)mk[ci[k]] * mask_scale);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[u][k] = g[ci[k]] * (wq * cw[k]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc[k] += v[u][k];      // weight-0 slots add 0
+        }
+        __syncthreads();
     }
     const float *e = emb + id * W;
-    const float *g = dout + (long long)(r / rows_per_grad) * W;
     float *o = demb + id * W;
-    for (int i = lane; i < W; i += 64) {
-        if (e[i] > 0.f) {
-            float v = g[i] * scale;
-            if (mask) v *= (float)mask[(long long)r * W + i] * mask_scale;
-            atomicAdd(o + i, v);
-        }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = tid + 256 * k;
+        if (i < W && e[i] > 0.f) o[i] += acc[k];
     }
 }
 
 extern "C" int isc_embed_relu_bwd(const float *emb, int V, int W, const int64_t *ids, int64_t ids_stride,
                                   int n_rows, int rows_per_grad, int pad_first, int64_t pad_id,
                                   const float *dout, float scale, const uint8_t *keep_mask,
-                                  float mask_scale, float *demb, void *stream) {
+                                  float mask_scale, float *demb, int64_t skip_id, void *stream) {
     if (!emb || !ids || !dout || !demb) return ISC_E_NULL;
-    if (n_rows <= 0 || W <= 0 || V <= 0 || rows_per_grad <= 0) return ISC_E_SHAPE;
-    hipLaunchKernelGGL(embed_relu_bwd_kernel, dim3((n_rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, emb,
-                       W, ids, (long long)ids_stride, n_rows, rows_per_grad, pad_first, (long long)pad_id,
-                       dout, scale, keep_mask, mask_scale, demb);
+    if (n_rows <= 0 || W <= 0 || W > 1024 || V <= 0 || rows_per_grad <= 0) return ISC_E_SHAPE;
+    EmbIds I = {ids, (long long)ids_stride, (long long)pad_id, (long long)skip_id, pad_first};
+    if (keep_mask)
+        hipLaunchKernelGGL(embed_relu_bwd_kernel<true>, dim3(n_rows), dim3(256), 0, (hipStream_t)stream, emb, W, I,
+                           n_rows, rows_per_grad, dout, scale, keep_mask, mask_scale, demb);
+    else
+        hipLaunchKernelGGL(embed_relu_bwd_kernel<false>, dim3(n_rows), dim3(256), 0, (hipStream_t)stream, emb, W, I,
+                           n_rows, rows_per_grad, dout, scale, keep_mask, mask_scale, demb);
     ISC_LAUNCH_CHECK();
     return ISC_OK;
 }

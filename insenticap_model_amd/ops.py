@@ -394,13 +394,13 @@ def gate_mix_bwd(z, w, v, s, beta, dfeat, dv, ds, dz, dw_rows, db_rows, accumula
 
 
 def embed_relu_bwd(emb, ids, dout, demb, n_rows, rows_per_grad=1, scale=1.0, ids_stride=1, pad_first=0,
-                   pad_id=0, keep_mask=None, mask_scale=1.0):
+                   pad_id=0, keep_mask=None, mask_scale=1.0, skip_id=-1):
     lib = _lib.load()
     V, W = emb.shape
     assert dout.is_contiguous() and demb.is_contiguous() and ids.dtype == torch.int64
     check(lib.isc_embed_relu_bwd(emb.data_ptr(), V, W, ids.data_ptr(), ids_stride, n_rows, rows_per_grad,
                                  pad_first, pad_id, dout.data_ptr(), scale, ptr(keep_mask), mask_scale,
-                                 demb.data_ptr(), stream()), 'isc_embed_relu_bwd')
+                                 demb.data_ptr(), skip_id, stream()), 'isc_embed_relu_bwd')
 
 
 def colsum(x, out, accumulate=False):
