@@ -1023,10 +1023,6 @@ static int launch_any(const DevLaunch &L, int tile, hipStream_t st) {
 // on a co-resident workgroup to cover their chunk-boundary stalls, the XL tile is pipelined to run
 // alone).  Calibrated on tools/gemm_big.py / gemm_bench.py.
 static int g_tile_override = -1;
-// The vocabulary projection stays on the 128x128 tile: measured at [4096 x 10000 x 512] it runs at 116 TFLOP/s
-// there and 108 on the XL tile, whose lone workgroup per CU has nothing to hide the per-row softmax
-// statistics of the epilogue behind (3k VALU instructions per wave at the end of a 16-chunk tile).
-static int g_vocab_xl = 0;
 extern "C" int isc_set_tile_override(int tile) {
     const int prev = g_tile_override;
     g_tile_override = (tile >= 0 && tile <= 3) ? tile : -1;
@@ -1231,7 +1227,10 @@ extern "C" int isc_vocab_fwd(const float *h, int ldh, const float *W, int ldw, c
     d.C = logits; d.ld_logits = ld_logits;
     d.pmax = part_max; d.psum = part_sum; d.pidx = part_idx;
     d.ntile_total = (V + 127) / 128;
-    const int tile = pick_tile(L, g_vocab_xl != 0);
+    // The vocabulary projection stays on the 128x128 tile: at [4096 x 10000 x 512] it runs at 116 TFLOP/s there
+    // and 108 on the XL tile, whose lone workgroup per CU has nothing to hide the per-row softmax statistics
+    // of the epilogue behind (3k VALU instructions per wave at the end of a 16-chunk tile).
+    const int tile = pick_tile(L, false);
     finish_tiling(L, tile);
     return launch_any<EPI_VOCAB, false, false>(L, tile, (hipStream_t)stream);
 }
