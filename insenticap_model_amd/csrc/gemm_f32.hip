@@ -890,11 +890,15 @@ __global__ __launch_bounds__(256) void splitk_linear_kernel(const DevLaunch L) {
     if (i >= n4) return;
     const int N = P.N, gm = (int)(i / (N >> 2)), gn = (int)(i % (N >> 2)) * 4;
     const float *sl = P.slab + (long long)gm * N + gn;
-    float4 v = *reinterpret_cast<const float4 *>(sl);
-    for (int s = 1; s < P.ksplit; ++s) {
-        const float4 w = *reinterpret_cast<const float4 *>(sl + (long long)s * P.slab_stride);
-        v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
-    }
+    float4 part[16];                            // every slab's float4 in flight before the first add
+    const int S = P.ksplit;
+#pragma unroll
+    for (int s = 0; s < 16; ++s)
+        part[s] = s < S ? *reinterpret_cast<const float4 *>(sl + (long long)s * P.slab_stride)
+                        : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 v = part[0];
+#pragma unroll
+    for (int s = 1; s < 16; ++s) { v.x += part[s].x; v.y += part[s].y; v.z += part[s].z; v.w += part[s].w; }
     float o[4] = {v.x, v.y, v.z, v.w}, pre[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -926,12 +930,22 @@ __global__ __launch_bounds__(256) void splitk_lstm_kernel(const DevLaunch L) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= (long long)P.M * H) return;
     const int gm = (int)(i / H), unit = (int)(i % H);
-    float g[4];
+    // all 4 x ksplit slab values are requested before the first add: summed one by one behind a runtime
+    // trip count they were 16 dependent L2 round trips (15 us for a [4 x 2048] cell update)
+    float part[4][16];
+    const int S = P.ksplit;                   // <= 16 (plan_splitk)
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const float *sl = P.slab + (long long)gm * 4 * H + k * H + unit;
-        float a = sl[0];
-        for (int s = 1; s < P.ksplit; ++s) a += sl[(long long)s * P.slab_stride];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) part[k][s] = s < S ? sl[(long long)s * P.slab_stride] : 0.f;
+    }
+    float g[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float a = part[k][0];
+#pragma unroll
+        for (int s = 1; s < 16; ++s) a += part[k][s];      // fixed order; the unused slots add 0
         if (P.bias0) a += P.bias0[k * H + unit] + P.bias1[k * H + unit];
         if (P.pre) a += P.pre[(long long)gm * 4 * H + k * H + unit];
         if (P.tab) a += P.tab[P.tab_ids[(long long)gm * P.tab_ids_stride] * 4 * H + k * H + unit];
