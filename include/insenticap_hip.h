@@ -123,10 +123,13 @@ int isc_lstm_fwd(const isc_lstm_problem *prob_host, void *stream);
 /* Vocabulary projection with fused log-softmax statistics (captioner.py:183):
  * logits = h W^T + b.  Per 128-column tile the kernel emits (max, argmax, sum exp(x-max));
  * the [M,V] logits are only stored when `logits` is non-null (XE / beam / sampling).
- * n_tile = ceil(V/128); part_* are [M, n_tile]. */
+ * n_tile = ceil(V/128); part_* are [M, n_tile].  With a split-K workspace (optional, see
+ * isc_linear_problem) launches of few rows contract K in parallel slices and a reduce kernel forms the
+ * same outputs (V % 4 == 0 required for that route; otherwise the single-pass kernel runs). */
 int isc_vocab_fwd(const float *h, int ldh, const float *W, int ldw, const float *bias,
                   int M, int V, int K, float *logits, int64_t ld_logits,
-                  float *part_max, float *part_sum, int32_t *part_idx, void *stream);
+                  float *part_max, float *part_sum, int32_t *part_idx,
+                  float *splitk_ws, int64_t splitk_ws_floats, void *stream);
 
 /* logp[m, :] = logits[m, :] - logsumexp(row) in place, using the tile statistics.
  * (F.log_softmax of captioner.py:183 when the full [B,V] row is an API output.) */

@@ -107,7 +107,7 @@ SIGNATURES = {
     'isc_step_bwd': (C.c_int, [C.POINTER(StepBwdPlan), C.c_void_p]),
     'isc_vocab_fwd': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int,
                                 C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
-                                C.c_void_p]),
+                                C.c_void_p, C.c_int64, C.c_void_p]),
     'isc_logsoftmax_apply': (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_void_p]),
     'isc_attn_scan_fwd': (C.c_int, [C.POINTER(ScanProblem), C.c_int, C.c_int, C.c_void_p]),

@@ -963,6 +963,47 @@ __global__ __launch_bounds__(256) void splitk_lstm_kernel(const DevLaunch L) {
     }
 }
 
+// Vocabulary projection by split-K (few rows): sums the slabs in fixed order, adds the bias, optionally
+// writes the logits, and emits the per-128-column (max, arg-max, sum exp) the single-pass kernel's epilogue
+// would have produced.  One wavefront per (row, column tile): lane l holds columns l and l + 64 of the tile.
+__global__ __launch_bounds__(256) void splitk_vocab_kernel(const DevLaunch L) {
+    const DevProb &P = L.p[0];
+    const int lane = threadIdx.x & 63;
+    const long long w = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int n_tile = P.ntile_total;
+    if (w >= (long long)P.M * n_tile) return;
+    const int gm = (int)(w / n_tile), tn = (int)(w % n_tile);
+    const int N = P.N, S = P.ksplit;
+    float x[2];
+    int col[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        col[h] = tn * 128 + lane + 64 * h;
+        const bool ok = col[h] < N;
+        const float *sl = P.slab + (long long)gm * N + (ok ? col[h] : 0);
+        float part[16];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) part[s] = (ok && s < S) ? sl[(long long)s * P.slab_stride] : 0.f;
+        float a = part[0];
+#pragma unroll
+        for (int s = 1; s < 16; ++s) a += part[s];
+        x[h] = ok ? a + P.bias0[col[h]] : -INFINITY;
+        if (ok && P.C) P.C[(long long)gm * P.ld_logits + col[h]] = x[h];
+    }
+    float mx = x[0];
+    int ix = col[0];
+    if (x[1] > mx) { mx = x[1]; ix = col[1]; }             // equal: the lower column (h = 0) stays
+    wave_argmax(mx, ix);
+    float sm = (x[0] > -INFINITY ? __expf(x[0] - mx) : 0.f) + (x[1] > -INFINITY ? __expf(x[1] - mx) : 0.f);
+    sm = wave_sum(sm);
+    if (lane == 0) {
+        const long long o = (long long)gm * n_tile + tn;
+        P.pmax[o] = mx;
+        P.psum[o] = sm;
+        P.pidx[o] = ix;
+    }
+}
+
 // ---------------------------------------------------------------- host side
 static int check_segs(const isc_seg *seg, int nseg) {
     if (nseg < 1 || nseg > ISC_MAX_SEG) return ISC_E_SHAPE;
@@ -1227,7 +1268,8 @@ extern "C" int isc_lstm_fwd(const isc_lstm_problem *q, void *stream) {
 
 extern "C" int isc_vocab_fwd(const float *h, int ldh, const float *W, int ldw, const float *bias,
                              int M, int V, int K, float *logits, int64_t ld_logits,
-                             float *part_max, float *part_sum, int32_t *part_idx, void *stream) {
+                             float *part_max, float *part_sum, int32_t *part_idx,
+                             float *splitk_ws, int64_t splitk_ws_floats, void *stream) {
     if (!h || !W || !bias || !part_max || !part_sum || !part_idx) return ISC_E_NULL;
     isc_seg sg = {h, W, ldh, ldw, K, 0};
     int rc = check_segs(&sg, 1);
@@ -1241,6 +1283,18 @@ extern "C" int isc_vocab_fwd(const float *h, int ldh, const float *W, int ldw, c
     d.C = logits; d.ld_logits = ld_logits;
     d.pmax = part_max; d.psum = part_sum; d.pidx = part_idx;
     d.ntile_total = (V + 127) / 128;
+    // few rows (beam search, small batches): the 16-chunk contraction of a 32-row tile is a serial walk
+    // of ~27 us; split it over K into raw [S,M,V] slabs and let the reduce kernel form the statistics
+    const int S = plan_splitk(L, splitk_ws, splitk_ws_floats);
+    if (S > 1) {
+        finish_tiling(L, 2);
+        rc = launch_any<EPI_LINEAR, false, false>(L, 2, (hipStream_t)stream);
+        if (rc) return rc;
+        const long long waves = (long long)M * d.ntile_total;
+        hipLaunchKernelGGL(splitk_vocab_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, L);
+        ISC_LAUNCH_CHECK();
+        return ISC_OK;
+    }
     // The vocabulary projection stays on the 128x128 tile: at [4096 x 10000 x 512] it runs at 116 TFLOP/s there
     // and 108 on the XL tile, whose lone workgroup per CU has nothing to hide the per-row softmax statistics
     // of the epilogue behind (3k VALU instructions per wave at the end of a 16-chunk tile).

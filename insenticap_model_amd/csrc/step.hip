@@ -94,7 +94,7 @@ extern "C" int isc_step_fwd(const isc_step_plan *p, void *stream) {
     }
     // classifier + log-softmax statistics (captioner.py:183)
     RET(isc_vocab_fwd(p->out_mask ? p->hdrop : p->h2, H, p->W_cls, H, p->b_cls, rows, V, H, p->logits,
-                      p->ld_logits, p->pmax, p->psum, p->pidx, stream));
+                      p->ld_logits, p->pmax, p->psum, p->pidx, p->splitk_ws, p->splitk_ws_floats, stream));
     if (p->apply_logsoftmax) {
         if (!p->logits) return ISC_E_NULL;
         RET(isc_logsoftmax_apply(p->logits, p->ld_logits, rows, V, p->pmax, p->psum, nullptr, stream));

@@ -189,9 +189,10 @@ def vocab_fwd(h, W, bias, part_max, part_sum, part_idx, logits=None):
     assert h.stride(1) == 1 and W.stride(1) == 1
     ld = logits.stride(0) if logits is not None else 0
     e0 = TIMER.begin()
+    ws = splitk_ws(h.device)
     check(lib.isc_vocab_fwd(h.data_ptr(), h.stride(0), W.data_ptr(), W.stride(0), bias.data_ptr(), M, V, K,
                             ptr(logits), ld, part_max.data_ptr(), part_sum.data_ptr(),
-                            part_idx.data_ptr(), stream()), 'isc_vocab_fwd')
+                            part_idx.data_ptr(), ws.data_ptr(), ws.numel(), stream()), 'isc_vocab_fwd')
     TIMER.end(e0, 'vocab[%dx%dx%d]' % (M, V, K), 2.0 * M * V * K)
 
 
