@@ -27,12 +27,20 @@ def _pad32(v):
 
 # ------------------------------------------------------------------------------ forward
 def _train_forward(cap, mode, fc, att, cpt_words, senti_words, tokens_in, senti_labels, ss_prob, masks):
-    """Returns (logp [B,T,V], S). tokens_in [B,T]: ground-truth inputs (column 0 = <SOS>)."""
+    """Returns (logp [B,T,V], S). tokens_in [B,T]: ground-truth inputs (column 0 = <SOS>) - or, for the sampled
+    roll-out with gradients, a dict {'T', 'u' (uniforms [B,T]) or 'forced' (raw draws [B,T])}: every step then
+    draws its own next token on the device (isc_rollout_finalize) while the activations the backward pass
+    needs are kept, so sampling and the differentiable forward are ONE unroll (captioner.py:290-349 does the
+    same inside autograd).  The draws land in S.sample = (seq, masks, raw, alive)."""
     p = cap._p()
     P = cap._prologue(p, mode, fc, att, cpt_words, senti_words, senti_labels, masks)
     st = cap.settings
     E, A, H, Wd, V = st['feat_emb_dim'], st['att_hid_dim'], st['rnn_hid_dim'], st['word_emb_dim'], cap.vocab_size
-    B, T = tokens_in.shape
+    sampling = isinstance(tokens_in, dict)
+    if sampling:
+        B, T = P.B, tokens_in['T']
+    else:
+        B, T = tokens_in.shape
     has_c, has_s = P.att_e3 is not None, P.words_e3 is not None
     S = _Saved()
     S.p, S.P, S.mode, S.B, S.T = p, P, mode, B, T
@@ -55,15 +63,37 @@ def _train_forward(cap, mode, fc, att, cpt_words, senti_words, tokens_in, senti_
     out = new(B, T, V)
     emb = p['word_embed.0.weight']
     plan = cap._make_plan(p, P, B)
+    if sampling:
+        from ._lib import RolloutStep
+        seq = zeros(B, T, dtype=torch.int64)
+        seq_lp, seq_masks, raw = zeros(B, T), zeros(B, T), zeros(B, T, dtype=torch.int64)
+        unfinished = torch.ones(B, dtype=torch.int32, device=cap._dev)
+        alive = zeros(T + 1, dtype=torch.int32)
+        alive[0] = B
+        forced, sample_u = tokens_in.get('forced'), tokens_in.get('u')
+        rs = RolloutStep()
+        rs.B, rs.V, rs.T, rs.n_tile, rs.W = B, V, T, n_tile, Wd
+        rs.part_max, rs.part_sum, rs.part_idx = pm.data_ptr(), ps.data_ptr(), pi.data_ptr()
+        rs.ld_logits = out.stride(0)
+        rs.forced, rs.sample_u, rs.eos_id = ops.ptr(forced), ops.ptr(sample_u), cap.eos_id
+        rs.seq, rs.seq_logprobs, rs.seq_masks = seq.data_ptr(), seq_lp.data_ptr(), seq_masks.data_ptr()
+        rs.unfinished, rs.alive, rs.raw_tokens = unfinished.data_ptr(), alive.data_ptr(), raw.data_ptr()
+        rs.emb, rs.xt_add = emb.data_ptr(), None
+        S.tok[0] = cap.sos_id
+        ops.embed_relu_fwd(emb, S.tok[0], S.xt[0])
     for t in range(T):
-        it = tokens_in[:, t]
-        if cap.training and t >= 1 and ss_prob > 0.0:           # scheduled sampling, captioner.py:219-228
-            sample_mask = torch.rand(B, device=cap._dev) < ss_prob
-            if bool(sample_mask.any()):
-                drawn = torch.multinomial(out[:, t - 1].detach().exp(), 1).view(-1)
-                it = torch.where(sample_mask, drawn, it)
-        S.tok[t] = it
-        ops.embed_relu_fwd(emb, S.tok[t], S.xt[t])        # plain relu(Emb[tok]); label term is in P.pre1
+        if sampling:
+            if t >= 1:
+                S.tok[t].copy_(seq[:, t - 1])             # it * unfinished, written by the previous finalize
+        else:
+            it = tokens_in[:, t]
+            if cap.training and t >= 1 and ss_prob > 0.0:           # scheduled sampling, captioner.py:219-228
+                sample_mask = torch.rand(B, device=cap._dev) < ss_prob
+                if bool(sample_mask.any()):
+                    drawn = torch.multinomial(out[:, t - 1].detach().exp(), 1).view(-1)
+                    it = torch.where(sample_mask, drawn, it)
+            S.tok[t] = it
+            ops.embed_relu_fwd(emb, S.tok[t], S.xt[t])        # plain relu(Emb[tok]); label term is in P.pre1
         om, osc = mask_for('out%d' % t, B, H)
         save = {'g1': S.g1[t], 'g2': S.g2[t]}
         if om is not None:
@@ -83,7 +113,15 @@ def _train_forward(cap, mode, fc, att, cpt_words, senti_words, tokens_in, senti_
         cap._step(p, P, ws, S.xt[t], (S.h1[t], S.h2[t]), (S.c1[t], S.c2[t]),
                   (S.h1[t + 1], S.h2[t + 1]), (S.c1[t + 1], S.c2[t + 1]),
                   S.aC[:, t] if has_c else None, S.aS[:, t] if has_s else None,
-                  S.bG[:, t:t + 1] if (has_c and has_s) else None, logits, om, osc, save=save, normalize=True)
+                  S.bG[:, t:t + 1] if (has_c and has_s) else None, logits, om, osc, save=save,
+                  normalize=not sampling)
+        if sampling:                                      # draw on the raw logits, then turn them into log-probs
+            rs.t, rs.logits = t, logits.data_ptr()
+            rs.xt_next = S.xt[t + 1].data_ptr() if t + 1 < T else None
+            ops.rollout_finalize(rs)
+            ops.logsoftmax_apply(logits, pm, ps)
+    if sampling:
+        S.sample = (seq, seq_masks, raw, alive)
     cap._set_weights(S.aC if has_c else None, S.aS if has_s else None,
                      S.bG if (has_c and has_s) else None, T)
     S.logp = out
@@ -356,6 +394,7 @@ class DecodeFn(torch.autograd.Function):
                                      ss_prob, masks)
         S.P.fc_pre = cap.fc_feats if mode != 'seq2seq' else None
         S.P.cpt_pre = cap.cpt_feats
+        cap._last_sample = getattr(S, 'sample', None)
         ctx.cap, ctx.S, ctx.names = cap, S, names
         ctx.set_materialize_grads(False)
         outs = [logp, cap.cpt_feats]
@@ -390,42 +429,28 @@ def xe_with_grad(cap, mode, fc, att, cpt_words, senti_words, captions, senti_lab
 
 
 def rollout_with_grad(cap, fc, att, cpt_words, senti_words, senti_labels, T, replay, masks):
-    """Sampled roll-out with REINFORCE gradients (captioner.py:290-349, sample_max=0, train mode):
-    (1) sample on device without a graph, (2) replay the fed tokens through the differentiable
-    unroll and gather log p(token).  Same result as differentiating the sampling loop itself."""
-    with torch.no_grad():
-        if masks is None and cap.training and cap.drop.p > 0:
-            masks = _draw_masks(cap, fc, att, senti_words, T)
-        seq, _, seq_masks, raw, alive = cap._rollout(fc, att, cpt_words, senti_words, senti_labels, T, 0,
-                                                     replay, masks)
-    B = seq.shape[0]
-    sos = torch.full((B, 1), cap.sos_id, dtype=torch.int64, device=seq.device)
-    fed = torch.cat([sos, seq], dim=1)          # forward feeds captions[:, :-1] = [SOS, seq[:, :T-1]]
+    """Sampled roll-out with REINFORCE gradients (captioner.py:290-349, sample_max=0, train mode): one unroll
+    that samples each next token on the device and keeps the activations for the backward pass; the returned
+    log-probs are log p(drawn token), zero after the reference's early `break`."""
     names = [n for n, q in cap.named_parameters() if q.requires_grad]
     params = [q for _, q in cap.named_parameters() if q.requires_grad]
+    B = fc.shape[0]
+    draws = {'T': T}
+    if replay is not None:
+        draws['forced'] = cap._ids(replay)
+    else:
+        draws['u'] = torch.rand(B, T, device=cap._dev)
     was = cap.training
-    outs = DecodeFn.apply(cap, 'rl', fc, att, cpt_words, senti_words, fed[:, :-1].contiguous(), senti_labels,
-                          0.0, masks if masks is not None else {}, names, *params)
+    outs = DecodeFn.apply(cap, 'rl', fc, att, cpt_words, senti_words, draws, senti_labels, 0.0,
+                          masks, names, *params)
     cap.train(was)
     logp = outs[0]
     cap.cpt_feats, cap.fc_feats = outs[1], outs[2]
+    seq, seq_masks, raw, alive = cap._last_sample
+    cap._last_sample = None
     lp = logp.gather(2, raw.unsqueeze(2)).squeeze(2)
     live = (alive[:T] > 0).to(lp.dtype)      # step t ran iff some row was unfinished before it: zero after the early break
     return seq, lp * live, seq_masks
-
-
-def _draw_masks(cap, fc, att, senti_words, T):
-    """One set of dropout keep-masks shared by the sampling pass and its differentiable replay."""
-    st = cap.settings
-    E, Wd, H = st['feat_emb_dim'], st['word_emb_dim'], st['rnn_hid_dim']
-    B = fc.shape[0]
-    R = att.reshape(B, -1, att.shape[-1]).shape[1]
-    keep = lambda *s: (torch.rand(s, device=cap._dev) >= cap.drop.p).to(torch.uint8)
-    m = {'fc': keep(B, E), 'att': keep(B * R, E), 'label': keep(B, Wd),
-         'words': keep(B * (senti_words.shape[1] + 1), Wd)}
-    for t in range(T):
-        m['out%d' % t] = keep(B, H)
-    return m
 
 
 class XELossFn(torch.autograd.Function):
