@@ -200,6 +200,14 @@ typedef struct {
 
 int isc_rollout_finalize(const isc_rollout_step *s_host, void *stream);
 
+/* Scheduled sampling of the teacher-forced unrolls (captioner.py:219-228): out_ids[b] = u_select[b] < ss_prob
+ * ? a draw from exp(logp[b,:]) (inverse CDF with uniform u_draw[b], vocabulary order) : base_ids[b*stride].
+ * logp = the previous step's normalised output, part_* = that step's tile statistics from isc_vocab_fwd. */
+int isc_sched_sample(const float *logp, int64_t ld, int M, int V, const float *part_max,
+                     const float *part_sum, const int32_t *part_idx, const float *u_select,
+                     const float *u_draw, float ss_prob, const int64_t *base_ids, int64_t base_stride,
+                     int64_t *out_ids, void *stream);
+
 /* Beam step (sample(), captioner.py:390-409), batched over images: for every live beam row
  * apply the -inf masks (PAD,SOS,UNK, last word), take its top-`beam` (value, id) pairs
  * from logp = logits - lse.  Candidate merge + stable ordering is done by the host mirror

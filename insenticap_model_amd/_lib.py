@@ -108,6 +108,9 @@ SIGNATURES = {
     'isc_vocab_fwd': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int,
                                 C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                 C.c_void_p, C.c_int64, C.c_void_p]),
+    'isc_sched_sample': (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int64, C.c_void_p,
+                                   C.c_void_p]),
     'isc_logsoftmax_apply': (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_void_p]),
     'isc_attn_scan_fwd': (C.c_int, [C.POINTER(ScanProblem), C.c_int, C.c_int, C.c_void_p]),

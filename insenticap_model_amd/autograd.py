@@ -86,13 +86,11 @@ def _train_forward(cap, mode, fc, att, cpt_words, senti_words, tokens_in, senti_
             if t >= 1:
                 S.tok[t].copy_(seq[:, t - 1])             # it * unfinished, written by the previous finalize
         else:
-            it = tokens_in[:, t]
-            if cap.training and t >= 1 and ss_prob > 0.0:           # scheduled sampling, captioner.py:219-228
-                sample_mask = torch.rand(B, device=cap._dev) < ss_prob
-                if bool(sample_mask.any()):
-                    drawn = torch.multinomial(out[:, t - 1].detach().exp(), 1).view(-1)
-                    it = torch.where(sample_mask, drawn, it)
-            S.tok[t] = it
+            if cap.training and t >= 1 and ss_prob > 0.0:           # scheduled sampling, captioner.py:219-228:
+                u = torch.rand(2, B, device=cap._dev)              # select + draw on the device, no host test
+                ops.sched_sample(out[:, t - 1], pm, ps, pi, u[0], u[1], ss_prob, tokens_in[:, t], S.tok[t])
+            else:
+                S.tok[t] = tokens_in[:, t]
             ops.embed_relu_fwd(emb, S.tok[t], S.xt[t])        # plain relu(Emb[tok]); label term is in P.pre1
         om, osc = mask_for('out%d' % t, B, H)
         save = {'g1': S.g1[t], 'g2': S.g2[t]}

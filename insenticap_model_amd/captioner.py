@@ -469,11 +469,11 @@ class Captioner(nn.Module):
         emb = p['word_embed.0.weight']
         for i in range(T):
             it = tokens_in[:, i]
-            if self.training and i >= 1 and ss_prob > 0.0:
-                sample_mask = torch.rand(B, device=self._dev) < ss_prob
-                if bool(sample_mask.any()):
-                    drawn = torch.multinomial(out[:, i - 1].detach().exp(), 1).view(-1)
-                    it = torch.where(sample_mask, drawn, it)
+            if self.training and i >= 1 and ss_prob > 0.0:       # scheduled sampling, on the device (no host test)
+                u = torch.rand(2, B, device=self._dev)
+                drawn = torch.empty(B, dtype=torch.int64, device=self._dev)
+                ops.sched_sample(out[:, i - 1], ws['pmax'], ws['psum'], ws['pidx'], u[0], u[1], ss_prob, it, drawn)
+                it = drawn
             ops.embed_relu_fwd(emb, it.contiguous(), xt)
             om, osc = mask_for('out%d' % i, B, self.att_lstm.hidden_size)
             cur, nxt = i & 1, (i + 1) & 1

@@ -125,6 +125,56 @@ struct DevRollout {
     float *xt_next;
 };
 
+// Inverse-CDF sampling from softmax over one row, in vocabulary order, by one wavefront.  Two levels: the
+// vocabulary kernel already left sum exp(x - tile max) per 128-column tile, so the tile holding the target
+// mass is found by a prefix over n_tile values and only its 128 columns are exponentiated (4 wave-prefix
+// rounds per row instead of V/64 = 157: 300 us -> ~12 us per roll-out step at B=512).
+// Element mass = exp(x[i] - shift) * scale: (gmax, 1) for raw logits, (0, S) for log-probabilities, so that
+// both agree with the tile masses psum[j] * exp(pmax[j] - gmax) and with target = u * S.
+// Returns the drawn id, or -1 when rounding put the target past the total mass.
+__device__ __forceinline__ int sample_two_level(const float *x, float shift, float scale, const float *pm,
+                                                const float *ps, int n_tile, int V, float gmax, float target,
+                                                int lane) {
+    auto wave_incl = [&](float v) __attribute__((always_inline)) {
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const float n = __shfl_up(v, o, 64);
+            if (lane >= o) v += n;
+        }
+        return v;
+    };
+    float run = 0.f;
+    int tile = -1;
+    for (int base = 0; base < n_tile && tile < 0; base += 64) {
+        const int j = base + lane;
+        const float w = (j < n_tile) ? ps[j] * expf(pm[j] - gmax) : 0.f;
+        const float incl = wave_incl(w);
+        const unsigned long long hit = __ballot((run + incl > target) && j < n_tile);
+        if (hit) {
+            const int l = __ffsll((long long)hit) - 1;
+            tile = base + l;
+            run += __shfl(incl - w, l, 64);       // mass in front of the tile
+        } else {
+            run += __shfl(incl, 63, 64);
+        }
+    }
+    if (tile < 0) return -1;
+    int pick = -1;
+    for (int c = 0; c < 2 && pick < 0; ++c) {
+        const int i = tile * 128 + c * 64 + lane;
+        const float e = (i < V) ? expf(x[i] - shift) * scale : 0.f;
+        const float incl = wave_incl(e);
+        const unsigned long long hit = __ballot((run + incl > target) && i < V);
+        if (hit) pick = tile * 128 + c * 64 + __ffsll((long long)hit) - 1;
+        run += __shfl(incl, 63, 64);
+    }
+    if (pick < 0) {                               // the tile's own sum rounded differently: its last column
+        pick = tile * 128 + 127;
+        if (pick > V - 1) pick = V - 1;
+    }
+    return pick;
+}
+
 #define ISC_FIN_ROWS_PER_WAVE 4
 // One wavefront per row, 4 rows per wave, 16 rows per workgroup; the count of still-unfinished rows
 // is reduced inside the workgroup so that the `alive` counter sees one atomic per 16 rows (4096
@@ -141,51 +191,10 @@ __device__ __forceinline__ int rollout_finalize_row(const DevRollout &R, int b, 
         it = R.forced[(long long)b * R.T + R.t];
         lp = (R.logits[(long long)b * R.ld_logits + it] - gmax) - logS;
     } else if (R.sample_u) {
-        // inverse-CDF sampling from softmax(logits) with a caller-supplied uniform, in vocabulary order.
-        // Two levels: the vocabulary kernel already left sum exp(x - tile max) per 128-column tile, so the
-        // tile holding the target is found by a prefix over n_tile values and only its 128 columns are
-        // exponentiated (4 wave-prefix rounds per row instead of V/64 = 157: 300 us -> ~15 us at B=512).
-        const float target = R.sample_u[(long long)b * R.T + R.t] * S;
         const float *x = R.logits + (long long)b * R.ld_logits;
-        const float *pm = R.part_max + (long long)b * R.n_tile, *ps = R.part_sum + (long long)b * R.n_tile;
-        auto wave_incl = [&](float v) __attribute__((always_inline)) {
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const float n = __shfl_up(v, o, 64);
-                if (lane >= o) v += n;
-            }
-            return v;
-        };
-        float run = 0.f;
-        int tile = -1;
-        for (int base = 0; base < R.n_tile && tile < 0; base += 64) {
-            const int j = base + lane;
-            const float w = (j < R.n_tile) ? ps[j] * expf(pm[j] - gmax) : 0.f;
-            const float incl = wave_incl(w);
-            const unsigned long long hit = __ballot((run + incl > target) && j < R.n_tile);
-            if (hit) {
-                const int l = __ffsll((long long)hit) - 1;
-                tile = base + l;
-                run += __shfl(incl - w, l, 64);       // mass in front of the tile
-            } else {
-                run += __shfl(incl, 63, 64);
-            }
-        }
-        int pick = -1;
-        if (tile >= 0) {
-            for (int c = 0; c < 2 && pick < 0; ++c) {
-                const int i = tile * 128 + c * 64 + lane;
-                const float e = (i < R.V) ? expf(x[i] - gmax) : 0.f;
-                const float incl = wave_incl(e);
-                const unsigned long long hit = __ballot((run + incl > target) && i < R.V);
-                if (hit) pick = tile * 128 + c * 64 + __ffsll((long long)hit) - 1;
-                run += __shfl(incl, 63, 64);
-            }
-            if (pick < 0) {                           // the tile's own sum rounded differently: its last column
-                pick = tile * 128 + 127;
-                if (pick > R.V - 1) pick = R.V - 1;
-            }
-        }
+        int pick = sample_two_level(x, gmax, 1.0f, R.part_max + (long long)b * R.n_tile,
+                                    R.part_sum + (long long)b * R.n_tile, R.n_tile, R.V, gmax,
+                                    R.sample_u[(long long)b * R.T + R.t] * S, lane);
         if (pick < 0) pick = gidx;  // target == S after rounding
         it = pick;
         lp = (x[it] - gmax) - logS;
@@ -253,6 +262,45 @@ extern "C" int isc_rollout_finalize(const isc_rollout_step *s, void *stream) {
     R.emb = s->emb; R.xt_add = s->xt_add; R.xt_next = s->xt_next;
     hipLaunchKernelGGL(rollout_finalize_kernel, dim3((s->B + 4 * ISC_FIN_ROWS_PER_WAVE - 1) / (4 * ISC_FIN_ROWS_PER_WAVE)),
                        dim3(256), 0, (hipStream_t)stream, R);
+    ISC_LAUNCH_CHECK();
+    return ISC_OK;
+}
+
+// ------------------------------------------------------------------ scheduled sampling (captioner.py:219-228)
+// out[b] = (u_select[b] < ss_prob) ? draw from exp(logp[b, :]) with uniform u_draw[b] : base[b].
+// One launch and no host decision in place of rand / `if mask.sum() == 0` / multinomial / index_copy_:
+// the reference's host test costs a device->host sync at every step.
+__global__ __launch_bounds__(256) void sched_sample_kernel(const float *logp, long long ld, int M, int V,
+                                                           const float *pmax, const float *psum, const int *pidx,
+                                                           int n_tile, const float *u_select, const float *u_draw,
+                                                           float ss_prob, const int64_t *base, long long base_stride,
+                                                           int64_t *out) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= M) return;
+    long long it = base[(long long)b * base_stride];
+    if (u_select[b] < ss_prob) {                  // wave-uniform
+        float gmax, S;
+        int gidx;
+        fold_row_stats(pmax + (long long)b * n_tile, psum + (long long)b * n_tile, pidx + (long long)b * n_tile,
+                       n_tile, lane, gmax, gidx, S);
+        const int pick = sample_two_level(logp + (long long)b * ld, 0.f, S, pmax + (long long)b * n_tile,
+                                          psum + (long long)b * n_tile, n_tile, V, gmax, u_draw[b] * S, lane);
+        it = pick < 0 ? gidx : pick;
+    }
+    if (lane == 0) out[b] = it;
+}
+
+extern "C" int isc_sched_sample(const float *logp, int64_t ld, int M, int V, const float *part_max,
+                                const float *part_sum, const int32_t *part_idx, const float *u_select,
+                                const float *u_draw, float ss_prob, const int64_t *base_ids, int64_t base_stride,
+                                int64_t *out_ids, void *stream) {
+    if (!logp || !part_max || !part_sum || !part_idx || !u_select || !u_draw || !base_ids || !out_ids)
+        return ISC_E_NULL;
+    if (M <= 0 || V <= 0) return ISC_E_SHAPE;
+    hipLaunchKernelGGL(sched_sample_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, logp,
+                       (long long)ld, M, V, part_max, part_sum, part_idx, (V + 127) / 128, u_select, u_draw, ss_prob,
+                       base_ids, (long long)base_stride, out_ids);
     ISC_LAUNCH_CHECK();
     return ISC_OK;
 }

@@ -81,3 +81,31 @@ def test_sampling_frequencies_follow_softmax():
     n = counts.sum()
     z = (counts - n * p) / np.sqrt(n * p * (1 - p) + 1e-12)
     assert np.abs(z).max() < 5.5 and np.abs(z[p * n > 20]).mean() < 1.2
+
+
+def test_scheduled_sampling_kernel():
+    """isc_sched_sample: unselected rows keep the ground-truth token, selected rows get the inverse-CDF draw of
+    exp(logp) for their uniform; the selection itself is u_select < ss_prob."""
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(11)
+    B, V, K = 300, 1000, 64
+    h, W, bias = (torch.randn(B, K, generator=g)).to(dev), (torch.randn(V, K, generator=g) * 0.4).to(dev), torch.zeros(V, device=dev)
+    nt = (V + 127) // 128
+    pm, ps = torch.empty(B, nt, device=dev), torch.empty(B, nt, device=dev)
+    pi = torch.empty(B, nt, device=dev, dtype=torch.int32)
+    logits = torch.empty(B, V, device=dev)
+    ops.vocab_fwd(h, W, bias, pm, ps, pi, logits)
+    ops.logsoftmax_apply(logits, pm, ps)                       # now log-probs, tile statistics unchanged
+    caps = torch.randint(4, V, (B, 7), generator=g).to(dev)    # base ids = a strided column
+    u_sel, u_draw = torch.rand(B, generator=g).to(dev), torch.rand(B, generator=g).to(dev)
+    out = torch.empty(B, dtype=torch.int64, device=dev)
+    ops.sched_sample(logits, pm, ps, pi, u_sel, u_draw, 0.4, caps[:, 3], out)
+    torch.cuda.synchronize()
+    sel = (u_sel < 0.4).cpu().numpy()
+    got, base = out.cpu().numpy(), caps[:, 3].cpu().numpy()
+    assert (got[~sel] == base[~sel]).all() and 0.25 < sel.mean() < 0.55
+    cdf = torch.cumsum(logits.double().exp(), 1).cpu().numpy()
+    un = u_draw.double().cpu().numpy()
+    lo = np.where(got > 0, cdf[np.arange(B), np.maximum(got - 1, 0)], 0.0)
+    hi = cdf[np.arange(B), got]
+    assert ((un >= lo - 2e-6) & (un <= hi + 2e-6))[sel].all()
