@@ -54,7 +54,9 @@ def beam_search_batch(cap, fc_feats, att_feats, senti_words, senti_labels, beam,
     ctrl_np = ctrl_h.numpy()
     ctrl_np[0, :] = last
     ctrl_d = ctrl_h.to(dev, non_blocking=True)
+    cap.last_beam_steps = 0                    # decode steps executed (bench.py: latency per step)
     for t in range(T):
+        cap.last_beam_steps = t + 1
         last_d = ctrl_d[0]
         h_cur, c_cur, h_nxt, c_nxt = st_cur[0], st_cur[1], st_nxt[0], st_nxt[1]
         if Pb.tab is None:
