@@ -17,6 +17,7 @@ from . import ops
 from .captioner import Captioner
 from .helper_nets import SentenceSentimentClassifier, SentimentDetector
 from .optim import clip_gradient
+from .train import run_on_side_stream
 from .rewards import RewardCriterion, get_ciderd_scorer, get_cls_reward, get_self_critical_reward
 
 
@@ -131,8 +132,13 @@ class Detector(nn.Module):
                 (s_caps, s_lengths), s_cpts, s_sentis, s_labels = batch
                 s_caps, s_cpts = s_caps.to(device), s_cpts.to(device)
                 s_sentis, s_labels = s_sentis.to(device), s_labels.to(device)
-                pred = cap(s_caps, s_cpts, s_sentis, s_labels, ss_prob=0.25, mode='seq2seq')
-                seq2seq_loss = self.seq_flag * self.cap_xe_crit(pred, s_caps[:, 1:], s_lengths)
+                def seq2seq_unroll():                     # 80 text-only rows: a chain of small launches that
+                    pred = cap(s_caps, s_cpts, s_sentis, s_labels, ss_prob=0.25, mode='seq2seq')
+                    return self.seq_flag * self.cap_xe_crit(pred, s_caps[:, 1:], s_lengths)
+                # ... overlaps with the XE unroll queued above when it runs on the side stream (forward and,
+                # through autograd, backward); same numbers either way
+                seq2seq_loss = run_on_side_stream(device, seq2seq_unroll) if device.type == 'cuda' \
+                    else seq2seq_unroll()
                 add('seq2seq_loss', seq2seq_loss)
 
             copied.synchronize()

@@ -61,9 +61,11 @@ SPLITK_WS_FLOATS = 16 * 1024 * 1024     # 64 MB per device: [ksplit, M, N] parti
 
 
 def splitk_ws(device=None):
-    """Per-device split-K workspace (allocated once; kernels on one stream use it one after another)."""
+    """Split-K workspace of the CURRENT stream on `device` (allocated once per (device, stream)): kernels on one
+    stream use it one after another; two streams never share one - their split-K launches may overlap."""
     device = torch.device(device if device is not None else torch.cuda.current_device())
-    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    index = device.index if device.index is not None else torch.cuda.current_device()
+    key = (index, torch.cuda.current_stream(index).cuda_stream)
     ws = _SPLITK_WS.get(key)
     if ws is None:
         ws = _SPLITK_WS[key] = torch.empty(SPLITK_WS_FLOATS, dtype=torch.float32, device=device)

@@ -11,10 +11,40 @@ from . import dp
 from .optim import clip_gradient
 
 
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device):
+    key = (device.type, device.index)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+        # gradients of one parameter arrive from two streams by design
+        warn_off = getattr(torch.autograd.graph, 'set_warn_on_accumulate_grad_stream_mismatch', None)
+        if warn_off is not None:
+            warn_off(False)
+    return _SIDE_STREAMS[key]
+
+
+def run_on_side_stream(device, fn):
+    """fn() with its launches on the device's side stream, ordered after everything queued so far on the current
+    stream; the current stream then waits for it.  Returns fn()'s tensor result (recorded on the current stream)."""
+    main, side = torch.cuda.current_stream(device), _side_stream(device)
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        out = fn()
+    main.wait_stream(side)
+    out.record_stream(main)
+    return out
+
+
 def xe_train_step(captioner, optim, xe_crit, da_crit, fact_batch, xe_senti_labels, scs_batch=None,
-                  ss_prob=0.0, grad_clip=0.1, arena=None, group=None, device=None):
+                  ss_prob=0.0, grad_clip=0.1, arena=None, group=None, device=None, overlap_unrolls=True):
     """One iteration. Returns dict(xe_loss, da_loss, cap_loss, seq2seq_loss, all_loss) of 0-dim
-    tensors (global values under DP).  `arena`: dp.GradArena when gradients are all-reduced."""
+    tensors (global values under DP).  `arena`: dp.GradArena when gradients are all-reduced.
+    `overlap_unrolls`: the seq2seq unroll (80 text-only rows) runs on a side HIP stream.  It shares nothing
+    with the XE unroll but the weights, and at these batch sizes both are chains of small launches that leave
+    most of the chip idle; autograd replays each unroll's backward on the stream its forward ran on, so the
+    two backward sweeps overlap as well.  Same numbers either way (two-operand gradient sums commute)."""
     device = device or next(captioner.parameters()).device
     _, fc_feats, att_feats, (caps_tensor, lengths), cpts_tensor = fact_batch[:5]
     fc_feats, att_feats = fc_feats.to(device), att_feats.to(device)
@@ -38,8 +68,13 @@ def xe_train_step(captioner, optim, xe_crit, da_crit, fact_batch, xe_senti_label
         (s_caps, s_lengths), s_cpts, s_sentis, s_labels = scs_batch
         s_caps, s_cpts = s_caps.to(device), s_cpts.to(device)
         s_sentis, s_labels = s_sentis.to(device), s_labels.to(device)
-        pred2 = captioner(s_caps, s_cpts, s_sentis, s_labels, ss_prob, mode='seq2seq')
-        s2s = xe_crit(pred2, s_caps[:, 1:], s_lengths)
+        def seq2seq_unroll():
+            pred2 = captioner(s_caps, s_cpts, s_sentis, s_labels, ss_prob, mode='seq2seq')
+            return xe_crit(pred2, s_caps[:, 1:], s_lengths)
+        if overlap_unrolls and torch.device(device).type == 'cuda':
+            s2s = run_on_side_stream(torch.device(device), seq2seq_unroll)
+        else:
+            s2s = seq2seq_unroll()
         if world > 1:
             s2s, _ = dp.dp_token_mean(s2s, float(sum(s_lengths)), group)
         total = total + s2s

@@ -109,3 +109,31 @@ def test_step_plan_equals_per_kernel_path():
             ops.TIMER.records.clear()
     for o in outs:
         assert all(torch.equal(x, y) for x, y in zip(a, o))
+
+
+def test_side_stream_unroll_gives_identical_step():
+    """train.xe_train_step with the seq2seq unroll on a side stream == everything on one stream, bit for bit
+    (losses, parameters after clamp + Adam)."""
+    from insenticap_model_amd.train import xe_train_step
+    V = 1000
+    d = synth.make_inputs(24, V, synth.DEFAULT_SETTINGS, regions=36, seq_len=10, seed=21)
+    s = synth.make_inputs(16, V, synth.DEFAULT_SETTINGS, regions=36, seq_len=10, seed=22)
+    tt = lambda x: torch.from_numpy(np.asarray(x)).to(dev())
+    fact = (None, tt(d['fc_feats']), tt(d['att_feats']), (tt(d['captions']), d['lengths']), tt(d['cpt_words']))
+    scs = ((tt(s['captions']), s['lengths']), tt(s['cpt_words']), tt(s['senti_words']), tt(s['senti_labels']))
+    res = []
+    for overlap in (False, True, True):
+        cap = _cap(V).train()
+        optim, xe_crit, da_crit = cap.get_optim_criterion(4e-4)
+        torch.manual_seed(5)
+        outs = []
+        for it in range(3):
+            o = xe_train_step(cap, optim, xe_crit, da_crit, fact, tt(d['senti_labels']), scs, 0.0, 0.1,
+                              overlap_unrolls=overlap)
+            outs.append({k: float(v) for k, v in o.items()})
+        torch.cuda.synchronize()
+        res.append((outs, {k: v.clone() for k, v in cap.state_dict().items()}))
+    for other in res[1:]:
+        assert other[0] == res[0][0]
+        for k in res[0][1]:
+            assert torch.equal(res[0][1][k], other[1][k]), k
