@@ -123,12 +123,12 @@ def bench_xe_train(cap, dev, rank, world, iters=6, B=128):
     fact = (None, tt(d['fc_feats']), tt(d['att_feats']), (tt(d['captions']), d['lengths']), tt(d['cpt_words']))
     labels = tt(d['senti_labels'])
     scs = ((tt(s['captions']), s['lengths']), tt(s['cpt_words']), tt(s['senti_words']), tt(s['senti_labels']))
-    for _ in range(2):
-        xe_train_step(cap, optim, xe_crit, da_crit, fact, labels, scs, 0.0, 0.1, arena=arena)
-    if world > 1:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
     with no_gc():
+        for _ in range(2):
+            xe_train_step(cap, optim, xe_crit, da_crit, fact, labels, scs, 0.0, 0.1, arena=arena)
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(iters):
             xe_train_step(cap, optim, xe_crit, da_crit, fact, labels, scs, 0.0, 0.1, arena=arena)
@@ -221,9 +221,9 @@ def bench_beam(cap, inputs, n_img=64, beam=5):
 
 PMC_SUMMARY = os.path.join(ROOT, 'profiles', 'r01_e_pmc_summary_B4096.json')
 # bench kernel label -> device symbols it may run as (first one present in the PMC summary wins)
-KERNEL_SYMBOL = {'vocab[': ['void gemm_kernel<4, 1, 4, 2, false, false>'],
+KERNEL_SYMBOL = {'vocab[': ['void gemm_ld_kernel<2>', 'void gemm_kernel<4, 1, 4, 2, false, false>'],
                  'lstm[4096x2048x1536': ['void gemm_xl_kernel<1>'],      # lang-LSTM (bias-only cell)
-                 'lstm[': ['void gemm_kernel<4, 1, 4, 1, false, false>', 'void gemm_xl_kernel<1>'],
+                 'lstm[': ['void gemm_ld_kernel<1>', 'void gemm_kernel<4, 1, 4, 1, false, false>', 'void gemm_xl_kernel<1>'],
                  'attn_scan[': ['void attn_scan_kernel<2>'], 'gate_mix[': ['gate_mix_kernel'],
                  'rollout_finalize[': ['rollout_finalize_kernel']}
 
@@ -299,26 +299,24 @@ def run(args):
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    with torch.no_grad():
+    # The cyclic collector is off for warm-up AND timing (collected first): a full collection of a process with
+    # torch imported costs 35-40 ms - inside the window it made the headline bimodal (173k vs 147k captions/s), and
+    # right in front of it the GPU would start the timed region from idle clocks.
+    with torch.no_grad(), no_gc():
         for w in range(args.warmup):
-            # warm the per-kernel (event-timed) code paths too: their first use allocates fresh blocks and loads
-            # kernels that the one-call step plan never touches - ~4 ms per roll-out if that lands in the timed loop
+            # warm the per-kernel (event-timed) code paths too: the one-call step plan never touches them
             ops.TIMER.arm_step = None if args.no_kernel_timing else (w % 3) - 1
             cap(*inputs, T, 1, mode='rl')
         ops.TIMER.arm_step = None
         ops.TIMER.records.clear()
         barrier()
-        # a full (generation-2) collection of a process that has torch imported walks ~1M objects: 35-40 ms.
-        # Whether one fires inside a 10-roll-out window is luck (it moved with unrelated code edits and made the
-        # headline bimodal, 173k vs 147k captions/s), so collect now and keep the collector off while timing.
-        with no_gc():
-            t0 = time.perf_counter()
-            for k in range(args.steps):
-                # HIP events around every kernel of ONE decode step of this roll-out (-1 = prologue)
-                ops.TIMER.arm_step = None if args.no_kernel_timing else (k % (T + 1)) - 1
-                seq, lp, mk = cap(*inputs, T, 1, mode='rl')
-            barrier()
-            el = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            # HIP events around every kernel of ONE decode step of this roll-out (-1 = prologue)
+            ops.TIMER.arm_step = None if args.no_kernel_timing else (k % (T + 1)) - 1
+            seq, lp, mk = cap(*inputs, T, 1, mode='rl')
+        barrier()
+        el = time.perf_counter() - t0
     ops.TIMER.arm_step = None
     if world > 1 or under_launcher:
         tt = torch.tensor([el], device=dev, dtype=torch.float64)

@@ -39,8 +39,8 @@ extern "C" {
 int isc_abi_version(void);
 const char *isc_target_arch(void);
 /* Tuning / test hook: force the GEMM tile shape of isc_linear_fwd / isc_lstm_fwd / isc_vocab_fwd /
- * isc_gemm_bwd (0 = 128x128, 1 = 64x128, 2 = 32x128, 3 = 256x128 LDS-DMA ring [NT layout only; other
- * layouts fall back to 0]); -1 (default) = the cost model picks.  Results are identical up to fp32
+ * isc_gemm_bwd (0 = 128x128, 1 = 64x128, 2 = 32x128, 3 = 256x128 LDS-DMA ring, 4 = 128x128 LDS-DMA [3 and 4: NT
+ * layout only; other layouts fall back to 0]); -1 (default) = the cost model picks.  Results are identical up to fp32
  * summation order for every shape; process-wide, not meant to be flipped while launches are in flight
  * on other threads.  Returns the previous value. */
 int isc_set_tile_override(int tile);

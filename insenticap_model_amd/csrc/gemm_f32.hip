@@ -880,6 +880,157 @@ __global__ __launch_bounds__(256) void gemm_xl_kernel(const DevLaunch L) {
     }
 }
 
+// ---------------------------------------------------------------- LD tile: 128 x 128 by LDS-DMA, two workgroups per CU
+// The L tile's geometry (4 waves stacked in M, 32 x 128 accumulator each) fed like the XL tile: operands by
+// global_load_lds_dwordx4 into two XOR-swizzled 32 KB buffers, no register stage and no ds_write pass (the
+// register-staged loop spends ~9 % of its time moving the staged chunk VGPR -> LDS).  64 KB of LDS keep two
+// workgroups on a CU, so an epilogue-heavy kernel - the vocabulary projection: 16 chunks of MFMAs, then per-row
+// softmax statistics - still has a neighbour to hide its epilogue behind, which the XL tile does not.
+// Chunk c+1's eight DMAs per wave are issued inside k-block 0 of chunk c (its buffer was last read before the
+// previous barrier) and retired with vmcnt(0) in front of the one barrier per chunk.
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_ld_kernel(const DevLaunch L) {
+    constexpr int BM = 128, BN = 128, TN = 4;
+    constexpr int TS = 128 * BK;                        // floats per operand buffer
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *As = smem;                     // [2][TS]
+    float *Bs = smem + 2 * TS;            // [2][TS]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wm = tid >> 6;
+    int pi, tm, tn, ks, ksplit;
+    map_tile(L, pi, tm, tn, ks, ksplit);
+    const DevProb &P = L.p[pi];
+    const int M = P.M, N = P.N;
+    const int row0 = tm * BM, col0 = tn * BN;
+
+    // staging pieces (8 rows x 128 B): piece i of wave w = tile rows / columns 32w + 8i .. +8
+    int arow[4];
+    long long wrow[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = row0 + 32 * wm + 8 * i + (lane >> 3);
+        arow[i] = r < M ? r : M - 1;
+        if (EPI == EPI_LSTM) {
+            wrow[i] = (long long)wm * P.H + tn * 32 + 8 * i + (lane >> 3);
+        } else {
+            const int c = col0 + 32 * wm + 8 * i + (lane >> 3);
+            wrow[i] = c < N ? c : N - 1;
+        }
+    }
+    const int lq = lane & 7, lh = lane >> 4;
+    const float *pa[4], *pb[4];
+    int cs = 0, ck = 0, segK = 0;
+    auto set_seg = [&](int si) __attribute__((always_inline)) {
+        const DevSeg sg = P.seg[si];
+        segK = sg.K;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            pa[i] = sg.A + (long long)arow[i] * sg.lda + (lq ^ (4 * (i & 1) + lh)) * 4;
+            pb[i] = sg.W + wrow[i] * sg.ldw + (lq ^ (4 * (i & 1) + lh)) * 4;
+        }
+    };
+    const unsigned a_lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)As + wm * 32 * BK * 4);
+    const unsigned b_lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)Bs + wm * 32 * BK * 4);
+    auto dma = [&](auto bufc, auto idxc) __attribute__((always_inline)) {
+        constexpr int BUF = decltype(bufc)::value, IDX = decltype(idxc)::value;
+        if constexpr (IDX < 4) {
+            asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off"
+                         :: "s"(a_lds0 + (BUF * TS + 8 * IDX * BK) * 4), "v"(pa[IDX]) : "memory");
+            pa[IDX] += BK;
+        } else {
+            asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off"
+                         :: "s"(b_lds0 + (BUF * TS + 8 * (IDX - 4) * BK) * 4), "v"(pb[IDX - 4]) : "memory");
+            pb[IDX - 4] += BK;
+        }
+        if constexpr (IDX == 7) {
+            ck += BK;
+            if (ck >= segK) {
+                ck = 0;
+                if (++cs < P.nseg) set_seg(cs);
+            }
+        }
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>;
+    using I4 = std::integral_constant<int, 4>;
+    using I5 = std::integral_constant<int, 5>;
+    using I6 = std::integral_constant<int, 6>;
+    using I7 = std::integral_constant<int, 7>;
+
+    f32x16 acc[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    static_assert(BK == 32, "chunk body written for 4 k-blocks of 8");
+    const int frow = lane & 31, khalf = lane >> 5;
+    const int fsw = (frow >> 1) & 7;
+    float4 fa[2], fb[2][TN];
+    auto lfrag = [&](auto bufc, auto kbc, auto setc) __attribute__((always_inline)) {
+        constexpr int BUF = decltype(bufc)::value, kb = decltype(kbc)::value, ST = decltype(setc)::value;
+        const int slot = ((2 * kb + khalf) ^ fsw) * 4;
+        fa[ST] = *reinterpret_cast<const float4 *>(As + BUF * TS + (wm * 32 + frow) * BK + slot);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+            fb[ST][j] = *reinterpret_cast<const float4 *>(Bs + BUF * TS + (j * 32 + frow) * BK + slot);
+    };
+    auto mma_e = [&](auto setc, auto ec) __attribute__((always_inline)) {
+        constexpr int ST = decltype(setc)::value, e = decltype(ec)::value;
+        const float a[4] = {fa[ST].x, fa[ST].y, fa[ST].z, fa[ST].w};
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const float b[4] = {fb[ST][j].x, fb[ST][j].y, fb[ST][j].z, fb[ST][j].w};
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], acc[j], 0, 0, 0);
+        }
+    };
+    auto mma = [&](auto setc) __attribute__((always_inline)) {
+        mma_e(setc, I0{}); mma_e(setc, I1{}); mma_e(setc, I2{}); mma_e(setc, I3{});
+    };
+    int nchunks = 0;
+    for (int s = 0; s < P.nseg; ++s) nchunks += P.seg[s].K / BK;
+    auto chunk_body = [&](auto curc, auto nxtc, bool has1) __attribute__((always_inline)) {
+        lfrag(curc, I1{}, I1{});
+        // k-block 0: 4 MFMAs, then two DMA pieces of the next chunk, four times over
+        mma_e(I0{}, I0{}); if (has1) { dma(nxtc, I0{}); dma(nxtc, I1{}); }
+        mma_e(I0{}, I1{}); if (has1) { dma(nxtc, I2{}); dma(nxtc, I3{}); }
+        mma_e(I0{}, I2{}); if (has1) { dma(nxtc, I4{}); dma(nxtc, I5{}); }
+        mma_e(I0{}, I3{}); if (has1) { dma(nxtc, I6{}); dma(nxtc, I7{}); }
+        lfrag(curc, I2{}, I0{});
+        mma(I1{});
+        lfrag(curc, I3{}, I1{});
+        mma(I0{});
+        if (has1) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            lfrag(nxtc, I0{}, I0{});
+        }
+        mma(I1{});
+    };
+    set_seg(0);
+    dma(I0{}, I0{}); dma(I0{}, I1{}); dma(I0{}, I2{}); dma(I0{}, I3{});
+    dma(I0{}, I4{}); dma(I0{}, I5{}); dma(I0{}, I6{}); dma(I0{}, I7{});
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    lfrag(I0{}, I0{}, I0{});
+    for (int c = 0; c < nchunks; c += 2) {
+        chunk_body(I0{}, I1{}, c + 1 < nchunks);
+        if (c + 1 < nchunks) chunk_body(I1{}, I0{}, c + 2 < nchunks);
+    }
+
+    if constexpr (EPI == EPI_VOCAB) {
+        epi_vocab_frag<TN, 1, BM>(P, acc, wm * 32, 0, 0, lane, row0, col0, tn, smem);
+    } else if constexpr (EPI == EPI_LSTM) {
+        epi_lstm_frag(P, acc, wm * 32, lane, row0, tn);
+    } else {
+        epi_linear_frag(P, acc, wm * 32, lane, row0, col0);
+    }
+}
+
 // ---------------------------------------------------------------- split-K reduction + epilogue
 // Sums the ksplit partial slabs in a fixed order (deterministic) and applies the epilogue the
 // single-pass kernel would have applied.  blockIdx.y = problem.
@@ -1058,14 +1209,23 @@ static int launch_xl(const DevLaunch &L, hipStream_t st) {
     return ISC_OK;
 }
 
+template <int EPI>
+static int launch_ld(const DevLaunch &L, hipStream_t st) {
+    constexpr size_t lds = (size_t)4 * 128 * BK * sizeof(float);           // 65536: two workgroups per CU
+    hipLaunchKernelGGL((gemm_ld_kernel<EPI>), dim3(L.total_tiles), dim3(256), lds, st, L);
+    ISC_LAUNCH_CHECK();
+    return ISC_OK;
+}
+
 // Tile shapes: 0 = L 128x128 (4 waves stacked in M), 1 = M 64x128 (2x2 waves), 2 = S 32x128 (4 waves in N),
-// 3 = XL 256x128 (LDS-DMA ring, NT layout only)
-static const int kTileBM[4] = {128, 64, 32, 256};
+// 3 = XL 256x128 (LDS-DMA ring, NT layout only), 4 = LD 128x128 by LDS-DMA (NT layout only)
+static const int kTileBM[5] = {128, 64, 32, 256, 128};
 
 template <int EPI, bool AKM, bool BKM>
 static int launch_any(const DevLaunch &L, int tile, hipStream_t st) {
     if constexpr (!AKM && !BKM) {
         if (tile == 3) return launch_xl<EPI>(L, st);
+        if (tile == 4) return launch_ld<EPI>(L, st);
     }
     if (tile == 0) return launch_cfg<4, 1, 4, EPI, AKM, BKM>(L, st);
     if (tile == 1) return launch_cfg<2, 2, 2, EPI, AKM, BKM>(L, st);
@@ -1080,22 +1240,28 @@ static int launch_any(const DevLaunch &L, int tile, hipStream_t st) {
 static int g_tile_override = -1;
 extern "C" int isc_set_tile_override(int tile) {
     const int prev = g_tile_override;
-    g_tile_override = (tile >= 0 && tile <= 3) ? tile : -1;
+    g_tile_override = (tile >= 0 && tile <= 4) ? tile : -1;
     return prev;
 }
 
-static int pick_tile(const DevLaunch &L, bool allow_xl) {
+// nt: the launch is in the NT layout (the two LDS-DMA tiles exist for it); use_ld: let the cost model consider
+// the LD tile (only the vocabulary projection does: in the roll-out the prologue GEMMs measured slower on LD
+// than on XL - 2.76 vs 2.22 ms for att_embed - although the isolated kernels tie)
+static int pick_tile(const DevLaunch &L, bool allow_xl, bool nt = true, bool use_ld = false) {
+    if (g_tile_override == 4) return nt ? 4 : 0;
     if (g_tile_override >= 0) return (g_tile_override == 3 && !allow_xl) ? 0 : g_tile_override;
-    static const double eff[4][3] = {{0.80, 1.00, 1.00},    // L : 1, 2, >=3 workgroups on the busiest CU
+    static const double eff[5][3] = {{0.80, 1.00, 1.00},    // L : 1, 2, >=3 workgroups on the busiest CU
                                      {0.55, 0.80, 0.90},    // M
                                      {0.35, 0.50, 0.62},    // S
-                                     {1.10, 1.10, 1.10}};   // XL
+                                     {1.10, 1.10, 1.10},    // XL
+                                     {0.85, 1.06, 1.12}};   // LD
     int best = 0;
     double best_cost = 1e30;
-    static const int order[4] = {3, 0, 1, 2};               // larger tiles first: they win near-ties
-    for (int k = 0; k < 4; ++k) {
+    static const int order[5] = {3, 4, 0, 1, 2};            // larger / DMA tiles first: they win near-ties
+    for (int k = 0; k < 5; ++k) {
         const int t = order[k];
         if (t == 3 && !allow_xl) continue;
+        if (t == 4 && !(nt && use_ld)) continue;
         long long blocks = 0;
         for (int i = 0; i < L.nprob; ++i)
             blocks += (long long)((L.p[i].M + kTileBM[t] - 1) / kTileBM[t]) * ((L.p[i].N + 127) / 128);
@@ -1219,7 +1385,7 @@ extern "C" int isc_gemm_bwd(const isc_linear_problem *pr, int n_prob, int layout
         d.ldc = q.ldc; d.C = q.C; d.accumulate = q.accumulate;
     }
     const int S = plan_splitk(L, pr[0].splitk_ws, pr[0].splitk_ws_floats);
-    const int tile = S > 1 ? 2 : pick_tile(L, false);
+    const int tile = S > 1 ? 2 : pick_tile(L, false, false);
     finish_tiling(L, tile);
     int rc = layout == ISC_LAYOUT_NN ? launch_any<EPI_LINEAR, false, true>(L, tile, (hipStream_t)stream)
                                      : launch_any<EPI_LINEAR, true, true>(L, tile, (hipStream_t)stream);
@@ -1295,10 +1461,10 @@ extern "C" int isc_vocab_fwd(const float *h, int ldh, const float *W, int ldw, c
         ISC_LAUNCH_CHECK();
         return ISC_OK;
     }
-    // The vocabulary projection stays on the 128x128 tile: at [4096 x 10000 x 512] it runs at 116 TFLOP/s there
-    // and 108 on the XL tile, whose lone workgroup per CU has nothing to hide the per-row softmax statistics
-    // of the epilogue behind (3k VALU instructions per wave at the end of a 16-chunk tile).
-    const int tile = pick_tile(L, false);
+    // The vocabulary projection runs on the 128x128 LDS-DMA tile: at [4096 x 10000 x 512] 121 TFLOP/s there, 115 on
+    // the register-staged 128x128 tile and 108 on XL, whose lone workgroup per CU has nothing to hide the per-row
+    // softmax statistics of the epilogue behind (3k VALU instructions per wave at the end of a 16-chunk tile).
+    const int tile = pick_tile(L, false, true, true);
     finish_tiling(L, tile);
     return launch_any<EPI_VOCAB, false, false>(L, tile, (hipStream_t)stream);
 }

@@ -1,4 +1,4 @@
-"""Every GEMM tile shape (128x128, 64x128, 32x128 register-staged; 256x128 LDS-DMA ring) behind the same
+"""Every GEMM tile shape (128x128, 64x128, 32x128 register-staged; 256x128 and 128x128 by LDS-DMA) behind the same
 entry points: each must match an fp64 reference and - because every shape accumulates an output element
 over k in the same order - must agree bit for bit with the others."""
 import numpy as np
@@ -8,7 +8,7 @@ import torch
 from insenticap_model_amd import ops
 
 pytestmark = pytest.mark.gpu
-TILES = (0, 1, 2, 3)
+TILES = (0, 1, 2, 3, 4)
 
 
 @pytest.fixture(autouse=True)
