@@ -69,7 +69,7 @@ def _train_forward(cap, mode, fc, att, cpt_words, senti_words, tokens_in, senti_
         seq_lp, seq_masks, raw = zeros(B, T), zeros(B, T), zeros(B, T, dtype=torch.int64)
         unfinished = torch.ones(B, dtype=torch.int32, device=cap._dev)
         alive = zeros(T + 1, dtype=torch.int32)
-        alive[0] = B
+        alive[0:1].fill_(B)                     # a fill kernel (a scalar assignment would be a pageable H2D copy)
         forced, sample_u = tokens_in.get('forced'), tokens_in.get('u')
         rs = RolloutStep()
         rs.B, rs.V, rs.T, rs.n_tile, rs.W = B, V, T, n_tile, Wd

@@ -60,9 +60,14 @@ _SPLITK_WS = {}
 SPLITK_WS_FLOATS = 16 * 1024 * 1024     # 64 MB per device: [ksplit, M, N] partial slabs of small-M GEMMs
 
 
+WS_OVERRIDE = None      # set while a HIP graph is being captured: the graph owns its workspace
+
+
 def splitk_ws(device=None):
     """Split-K workspace of the CURRENT stream on `device` (allocated once per (device, stream)): kernels on one
     stream use it one after another; two streams never share one - their split-K launches may overlap."""
+    if WS_OVERRIDE is not None:
+        return WS_OVERRIDE
     device = torch.device(device if device is not None else torch.cuda.current_device())
     index = device.index if device.index is not None else torch.cuda.current_device()
     key = (index, torch.cuda.current_stream(index).cuda_stream)

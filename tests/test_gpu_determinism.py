@@ -137,3 +137,28 @@ def test_side_stream_unroll_gives_identical_step():
         assert other[0] == res[0][0]
         for k in res[0][1]:
             assert torch.equal(res[0][1][k], other[1][k]), k
+
+
+@pytest.mark.parametrize('B', [5, 130])
+def test_graph_replay_equals_eager_rollout(B):
+    """enable_rollout_graphs(): the captured T-step roll-out returns the eager path's bits for new inputs of the
+    same geometry, and follows in-place weight changes."""
+    cap = _cap().eval()
+    ref = _cap().eval()
+    cap.enable_rollout_graphs(True)
+    outs = []
+    with torch.no_grad():
+        for seed in (3, 4, 5, 6):                              # call 1 eager, call 2 captures, calls 3-4 replay
+            d, t = _inputs(B, 1000, seed=seed)
+            args = (t('fc_feats'), t('att_feats'), t('cpt_words'), t('senti_words'), t('senti_labels'), 12)
+            got = cap(*args, sample_max=1, mode='rl')
+            exp = ref(*args, sample_max=1, mode='rl')
+            assert all(torch.equal(a, b) for a, b in zip(got, exp)), seed
+            assert torch.equal(cap.cont_weights, ref.cont_weights)
+        assert any(isinstance(v, tuple) for v in cap._rollout_graphs.values())
+        # in-place weight update (classifier bias): the graph reads weights by pointer
+        for m in (cap, ref):
+            m.classifier.bias.add_(torch.linspace(-1, 1, m.classifier.bias.numel(), device=dev()))
+        got = cap(*args, sample_max=1, mode='rl')
+        exp = ref(*args, sample_max=1, mode='rl')
+        assert all(torch.equal(a, b) for a, b in zip(got, exp))
