@@ -116,10 +116,22 @@ __global__ __launch_bounds__(256) void attn_scan_kernel(const DevScanLaunch L) {
         const int d4 = tid % nd4, grp = tid / nd4;
         float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
         if (grp < ngrp) {
-            for (int r = grp; r < R; r += ngrp) {
-                const float a = sc[r];
-                const float4 v = Vb[(long long)r * nd4 + d4];
-                o.x += a * v.x; o.y += a * v.y; o.z += a * v.z; o.w += a * v.w;
+            // six regions' loads in flight per thread (24 KB per workgroup, like phase 1): one at a time the
+            // weighted sum was a chain of HBM round trips.  Rows past R re-read row R-1 with weight 0.
+            for (int r0 = grp; r0 < R; r0 += 6 * ngrp) {
+                float4 v[6];
+                float a[6];
+#pragma unroll
+                for (int u = 0; u < 6; ++u) {
+                    const int r = r0 + u * ngrp;
+                    const int rc = r < R ? r : R - 1;
+                    v[u] = Vb[(long long)rc * nd4 + d4];
+                    a[u] = r < R ? sc[rc] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 6; ++u) {       // ascending region order, as before
+                    o.x += a[u] * v[u].x; o.y += a[u] * v[u].y; o.z += a[u] * v[u].z; o.w += a[u] * v[u].w;
+                }
             }
             reinterpret_cast<float4 *>(part)[grp * nd4 + d4] = o;
         }
