@@ -171,3 +171,23 @@ def test_product_never_imports_the_oracle():
         if fn.endswith('.py'):
             src = open(os.path.join(pkg, fn)).read()
             assert not re.search(r'^\s*(from|import)\s+oracle\b', src, flags=re.M), fn
+
+
+def test_attention_weight_attributes_resolve_lazily():
+    """cont_weights / senti_weights / cont_senti_weights: set per call without a host read; the executed-step
+    count of a roll-out (the reference's early `break`) is taken from the `alive` counters only on access."""
+    import torch
+    from insenticap_model_amd import Captioner, synth
+    cap = Captioner(synth.make_idx2word(64), synth.SENTIMENT_CATEGORIES, synth.TINY_SETTINGS)
+    assert cap.cont_weights == [] and cap.senti_weights == [] and cap.cont_senti_weights == []
+    B, T, R, M = 3, 5, 4, 2
+    aC, aS, bG = torch.rand(B, T, R), torch.rand(B, T, M), torch.rand(B, T)
+    cap._set_weights(aC, aS, bG, T)                                  # teacher-forced unrolls: all T steps
+    assert cap.cont_weights.shape == (B, T * R) and cap.senti_weights.shape == (B, T * M)
+    assert torch.equal(cap.cont_senti_weights, bG)
+    alive = torch.tensor([3, 2, 1, 0, 0, 0], dtype=torch.int32)      # no row unfinished after step 2 -> 3 steps ran
+    cap._set_weights(aC, None, None, alive)
+    assert cap.cont_weights.shape == (B, 3 * R) and torch.equal(cap.cont_weights, aC[:, :3].reshape(B, -1))
+    assert cap.senti_weights == [] and cap.cont_senti_weights == []
+    cap.cont_weights = []                                            # plain assignment still works (beam search)
+    assert cap.cont_weights == []
