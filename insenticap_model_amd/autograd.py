@@ -81,13 +81,18 @@ def _train_forward(cap, mode, fc, att, cpt_words, senti_words, tokens_in, senti_
         rs.emb, rs.xt_add = emb.data_ptr(), None
         S.tok[0] = cap.sos_id
         ops.embed_relu_fwd(emb, S.tok[0], S.xt[0])
+    mask_for.predraw('out', T, B, H)
+    fed_known = not sampling and not (cap.training and ss_prob > 0.0)
+    if fed_known:                                         # every fed token is known up front: one copy, one gather
+        S.tok.copy_(tokens_in.t())
+        ops.embed_relu_fwd(emb, S.tok.view(-1), S.xt.view(T * B, Wd))
     for t in range(T):
         if sampling:
             if t >= 1:
                 S.tok[t].copy_(seq[:, t - 1])             # it * unfinished, written by the previous finalize
-        else:
-            if cap.training and t >= 1 and ss_prob > 0.0:           # scheduled sampling, captioner.py:219-228:
-                u = torch.rand(2, B, device=cap._dev)              # select + draw on the device, no host test
+        elif not fed_known:
+            if t >= 1:                                    # scheduled sampling, captioner.py:219-228:
+                u = torch.rand(2, B, device=cap._dev)     # select + draw on the device, no host test
                 ops.sched_sample(out[:, t - 1], pm, ps, pi, u[0], u[1], ss_prob, tokens_in[:, t], S.tok[t])
             else:
                 S.tok[t] = tokens_in[:, t]
