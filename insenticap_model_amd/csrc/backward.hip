@@ -91,24 +91,29 @@ struct DevScanBwdLaunch {
 
 // One workgroup per (row, problem).  LDS: da[R] (d alpha -> d e), red[ngrp][A] x2 for dq / dw.
 // Launched with 1024 threads (16 wavefronts): at B=128 there are only 128 rows, so the parallelism has
-// to come from inside the row.
+// to come from inside the row.  All row traffic is 16 bytes per lane: a thread owns 4 consecutive columns
+// (A/4 resp. D/4 threads span a row, 1024 / (A/4) region groups work in parallel).
 __global__ __launch_bounds__(1024) void attn_scan_bwd_kernel(const DevScanBwdLaunch L) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const DevScanBwd &S = L.p[blockIdx.y];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int NT = blockDim.x, NW = NT >> 6;
     const int R = S.R, A = S.A, D = S.D;
+    const int A4 = A >> 2, D4 = D >> 2;
     float *de = smem;                         // [R]
     float *red = smem + ((R + 3) & ~3);       // [2][ngrp][A]
-    const float *Vb = S.V + (long long)b * R * D;
-    const float *Pb = S.P + (long long)b * R * A;
-    const float *dout = S.dout + (long long)b * D;
+    const float4 *Vb = reinterpret_cast<const float4 *>(S.V + (long long)b * R * D);
+    const float4 *Pb = reinterpret_cast<const float4 *>(S.P + (long long)b * R * A);
+    const float4 *dout4 = reinterpret_cast<const float4 *>(S.dout + (long long)b * D);
     const float *alpha = S.alpha + (long long)b * S.alpha_ld;
 
     // d alpha_r = dout . V[r]
     for (int r = wave; r < R; r += NW) {
         float acc = 0.f;
-        for (int d = lane; d < D; d += 64) acc += dout[d] * Vb[(long long)r * D + d];
+        for (int d = lane; d < D4; d += 64) {
+            const float4 g = dout4[d], v = Vb[(long long)r * D4 + d];
+            acc += g.x * v.x + g.y * v.y + g.z * v.z + g.w * v.w;
+        }
         acc = wave_sum(acc);
         if (lane == 0) de[r] = acc;
     }
@@ -120,38 +125,48 @@ __global__ __launch_bounds__(1024) void attn_scan_bwd_kernel(const DevScanBwdLau
     __syncthreads();
 
     // dV[r,:] (+)= alpha_r * dout
-    float *dVb = S.dV + (long long)b * R * D;
+    float4 *dVb = reinterpret_cast<float4 *>(S.dV + (long long)b * R * D);
     {
-        const int dgrp = NT / D > 0 ? NT / D : 1;       // row groups working in parallel (D <= NT)
-        for (int d = tid % D; d < D; d += NT) {          // D > NT: strided columns
-            const float g = dout[d];
-            for (int r = (D <= NT ? tid / D : 0); r < R; r += dgrp) {
-                const long long o = (long long)r * D + d;
-                const float v = alpha[r] * g;
-                dVb[o] = S.accumulate ? dVb[o] + v : v;
+        const int dgrp = NT / D4;                         // row groups working in parallel
+        const int d = tid % D4, g0 = tid / D4;
+        if (g0 < dgrp) {
+            const float4 g = dout4[d];
+            for (int r = g0; r < R; r += dgrp) {
+                const long long o = (long long)r * D4 + d;
+                const float al = alpha[r];
+                float4 v = make_float4(al * g.x, al * g.y, al * g.z, al * g.w);
+                if (S.accumulate) { const float4 c = dVb[o]; v.x += c.x; v.y += c.y; v.z += c.z; v.w += c.w; }
+                dVb[o] = v;
             }
         }
     }
     // dP[r,a] (+)= de_r * w[a] * (1 - tanh^2);  dq[a] = sum_r (...);  dw_rows[b,a] += sum_r de_r * tanh
-    float *dPb = S.dP + (long long)b * R * A;
-    const int ngrp = (A <= NT) ? NT / A : 1;   // region groups working in parallel
-    const int a0 = (A <= NT) ? tid % A : tid, grp = (A <= NT) ? tid / A : 0;
-    for (int a = a0; a < A; a += (A <= NT ? A : NT)) {
-        const float qa = S.q[(long long)b * A + a] + (S.q2 ? S.q2[(long long)b * A + a] : 0.f);
-        const float wa = S.w[a];
-        float dq = 0.f, dw = 0.f;
-        if (grp < ngrp) {
-            for (int r = grp; r < R; r += ngrp) {
-                const float t = isc_tanh(Pb[(long long)r * A + a] + qa);
-                const float gr = de[r] * wa * (1.f - t * t);
-                const long long o = (long long)r * A + a;
-                dPb[o] = S.accumulate ? dPb[o] + gr : gr;
-                dq += gr;
-                dw += de[r] * t;
-            }
-            red[grp * A + a] = dq;
-            red[(ngrp + grp) * A + a] = dw;
+    float4 *dPb = reinterpret_cast<float4 *>(S.dP + (long long)b * R * A);
+    const int ngrp = NT / A4;                             // region groups working in parallel
+    const int a4 = tid % A4, grp = tid / A4;
+    if (grp < ngrp) {
+        float4 qa = reinterpret_cast<const float4 *>(S.q + (long long)b * A)[a4];
+        if (S.q2) {
+            const float4 t = reinterpret_cast<const float4 *>(S.q2 + (long long)b * A)[a4];
+            qa.x += t.x; qa.y += t.y; qa.z += t.z; qa.w += t.w;
         }
+        const float4 wa = reinterpret_cast<const float4 *>(S.w)[a4];
+        float4 dq = make_float4(0.f, 0.f, 0.f, 0.f), dw = dq;
+        for (int r = grp; r < R; r += ngrp) {
+            const long long o = (long long)r * A4 + a4;
+            const float4 pv = Pb[o];
+            const float der = de[r];
+            const float tx = isc_tanh(pv.x + qa.x), ty = isc_tanh(pv.y + qa.y);
+            const float tz = isc_tanh(pv.z + qa.z), tw = isc_tanh(pv.w + qa.w);
+            float4 gr = make_float4(der * wa.x * (1.f - tx * tx), der * wa.y * (1.f - ty * ty),
+                                    der * wa.z * (1.f - tz * tz), der * wa.w * (1.f - tw * tw));
+            dq.x += gr.x; dq.y += gr.y; dq.z += gr.z; dq.w += gr.w;
+            dw.x += der * tx; dw.y += der * ty; dw.z += der * tz; dw.w += der * tw;
+            if (S.accumulate) { const float4 c = dPb[o]; gr.x += c.x; gr.y += c.y; gr.z += c.z; gr.w += c.w; }
+            dPb[o] = gr;
+        }
+        reinterpret_cast<float4 *>(red + grp * A)[a4] = dq;
+        reinterpret_cast<float4 *>(red + (ngrp + grp) * A)[a4] = dw;
     }
     __syncthreads();
     for (int a = tid; a < A; a += NT) {
@@ -173,13 +188,15 @@ extern "C" int isc_attn_scan_bwd(const isc_scan_bwd_problem *pr, int n_prob, int
         if (!q.P || !q.V || !q.q || !q.w || !q.alpha || !q.dout || !q.dP || !q.dV || !q.dq || !q.dw_rows)
             return ISC_E_NULL;
         if (q.R <= 0 || q.A <= 0 || q.D <= 0 || q.A > 1024) return ISC_E_SHAPE;
-        if (q.A > 1024 || (1024 % q.A) != 0) return ISC_E_SHAPE;
-        if (q.D > 1024 || (1024 % q.D) != 0) return ISC_E_SHAPE;
+        if ((q.A & 3) || (q.D & 3) || (1024 % (q.A / 4)) != 0 || (1024 % (q.D / 4)) != 0) return ISC_E_SHAPE;
+        if (!isc_aligned16(q.P) || !isc_aligned16(q.V) || !isc_aligned16(q.dP) || !isc_aligned16(q.dV) ||
+            !isc_aligned16(q.q) || !isc_aligned16(q.w) || !isc_aligned16(q.dout) || (q.q2 && !isc_aligned16(q.q2)))
+            return ISC_E_ALIGN;
         DevScanBwd &d = L.p[i];
         d.P = q.P; d.V = q.V; d.q = q.q; d.q2 = q.q2; d.w = q.w; d.alpha = q.alpha; d.dout = q.dout;
         d.alpha_ld = q.alpha_ld; d.R = q.R; d.A = q.A; d.D = q.D; d.accumulate = q.accumulate;
         d.dP = q.dP; d.dV = q.dV; d.dq = q.dq; d.dw_rows = q.dw_rows;
-        const int ngrp = 1024 / q.A;
+        const int ngrp = 1024 / (q.A / 4);
         const size_t need = (((size_t)q.R + 3) & ~(size_t)3) + (size_t)2 * ngrp * q.A;
         if (need > lds) lds = need;
     }
