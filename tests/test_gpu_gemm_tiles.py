@@ -133,3 +133,36 @@ def test_vocab_all_tiles(M, V, K):
             base = (logits.cpu(), pm.cpu(), pi.cpu())
         else:
             assert torch.equal(base[0], logits.cpu()) and torch.equal(base[1], pm.cpu()) and torch.equal(base[2], pi.cpu()), t
+
+
+def test_large_shapes_bit_identical_across_big_tiles():
+    """The roll-out's own shapes at B=4096 (full grids, every CU busy, operands streaming from HBM): the
+    LDS-DMA tiles must reproduce the register-staged 128x128 tile bit for bit."""
+    g = torch.Generator().manual_seed(77)
+    B = 4096
+    x = _rand(g, B, 1536).to(dev())
+    w = _rand(g, 2048, 1536, scale=1536 ** -0.5).to(dev())
+    b = _rand(g, 2048).to(dev())
+    c0 = _rand(g, B, 512).to(dev())
+    hW = _rand(g, 10000, 512, scale=4 * 512 ** -0.5).to(dev())
+    hb = _rand(g, 10000).to(dev())
+    base = {}
+    for t in (0, 3, 4):
+        ops.set_tile_override(t)
+        out = torch.empty(B, 2048, device=dev())
+        ops.linear_fwd([ops.linear_problem([(x[:, :1024], w[:, :1024]), (x[:, 1024:], w[:, 1024:])], out, b, relu=True)])
+        h, c = torch.empty(B, 512, device=dev()), torch.empty(B, 512, device=dev())
+        ops.lstm_fwd([(x, w)], b, b, c0, h, c)
+        nt = 79
+        pm, ps = torch.empty(B, nt, device=dev()), torch.empty(B, nt, device=dev())
+        pi = torch.empty(B, nt, device=dev(), dtype=torch.int32)
+        ops.vocab_fwd(h, hW, hb, pm, ps, pi)
+        torch.cuda.synchronize()
+        cur = dict(lin=out.cpu(), h=h.cpu(), c=c.cpu(), pm=pm.cpu(), pi=pi.cpu())
+        if not base:
+            base = cur
+            ref = torch.relu(x.double() @ w.double().t() + b.double()).float().cpu()
+            np.testing.assert_allclose(cur['lin'].numpy(), ref.numpy(), atol=3e-5, rtol=1e-5)
+        else:
+            for k in base:
+                assert torch.equal(base[k], cur[k]), (t, k)
