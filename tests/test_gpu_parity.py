@@ -298,3 +298,33 @@ def test_large_batch_properties():
     eos_pos = (sq == cap.eos_id) & (mkc == 1)
     assert (eos_pos.sum(1) <= 1).all()
     assert np.isfinite(lp.cpu().numpy()).all()
+
+
+def test_beam5_batch64_matches_per_image_and_oracle(golden):
+    """BASELINE config 2: beam 5 over 64 images with sentiment words.  The batched search must return, image by
+    image, the captions the one-image API returns (images are independent; scores agree to fp32 summation order -
+    320 rows and 5 rows take different split-K routes), and agree with the CPU oracle's beam search on a sample of
+    them (captions where the oracle's own beams are not near-ties, scores to 1e-3)."""
+    cap, c, st, w, _, _ = make_captioner('cfg1')
+    n, Tn = 64, 20
+    d = synth.make_inputs(n, c['V'], st, regions=36, seq_len=Tn, seed=321)
+    fc, att, sw, lab = T(d, 'fc_feats'), T(d, 'att_feats'), T(d, 'senti_words'), T(d, 'senti_labels')
+    caps, scores, ids = cap.sample_batch(fc, att, sw, lab, 5, 1, Tn)
+    assert len(caps) == n and all(len(x) == 5 for x in caps)
+    for i in (0, 7, 31, 63):
+        cp, sc = cap.sample(fc[i], att[i], sw[i], lab[i:i + 1], 5, 1, Tn)
+        assert cp == caps[i], i
+        np.testing.assert_allclose(sc, scores[i], atol=1e-4)
+    O = oracle()
+    p = O.to_params(w)
+    oid = O.Ids(synth.make_idx2word(c['V']), synth.SENTIMENT_CATEGORIES)
+    for i in (3, 40):
+        ocaps, oscores, _ = O.beam_search(p, oid, synth.make_idx2word(c['V']), torch.from_numpy(d['fc_feats'][i]),
+                                          torch.from_numpy(d['att_feats'][i]), torch.from_numpy(d['senti_words'][i]),
+                                          torch.from_numpy(d['senti_labels'][i:i + 1]), 5, 1, Tn)
+        np.testing.assert_allclose(scores[i], oscores, atol=1e-3)
+        gaps = np.abs(np.diff(np.asarray(oscores)))
+        if (gaps > 2e-3).all():                    # well separated beams: order and words must match exactly
+            assert caps[i] == list(ocaps), i
+        else:
+            assert caps[i][0] == ocaps[0] or abs(oscores[0] - oscores[1]) <= 2e-3
