@@ -142,6 +142,33 @@ def bench_xe_train(cap, dev, rank, world, iters=6, B=128):
                 grad_allreduce_mb=round(arena.nbytes / 1e6, 2) if arena else 0.0)
 
 
+def bench_scan_sweep(dev, batches=(128, 512, 1024, 2048, 4096)):
+    """the attention scan's algorithmic GB/s at the config batch sizes as well as where its rows
+    (B x 192 512 B for content + sentiment) exceed the 256 MB last-level cache.  Isolated kernel, HIP events."""
+    out = {}
+    for B in batches:
+        g = torch.Generator(device='cpu').manual_seed(B)
+        mk = lambda *s: torch.rand(*s, generator=g).to(dev)
+        Pc, Vc, Pw, Vw = mk(B, R, 512), mk(B, R, 512), mk(B, 11, 512), mk(B, 11, 512)
+        q, q2, w, wb = mk(B, 512), mk(B, 512), mk(512), mk(1)
+        oc, ow = torch.empty(B, 512, device=dev), torch.empty(B, 512, device=dev)
+        pr = [ops.scan_problem(Pc, Vc, q, w, wb, oc), ops.scan_problem(Pw, Vw, q, w, wb, ow, q2=q2)]
+        for _ in range(3):
+            ops.attn_scan_fwd(pr, B)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 20
+        e0.record()
+        for _ in range(reps):
+            ops.attn_scan_fwd(pr, B)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / reps * 1e3
+        out[str(B)] = dict(us=round(us, 1), gb_per_s=round(B * 192512.0 / us / 1e3, 1),
+                           row_bytes_mb=round(B * 192512.0 / 1e6, 1))
+    return out
+
+
 def bench_rl(dev, iters=3, B=512):
     """BASELINE.json configs[4]: self-critical RL iteration (Detector.forward, training=True): sampled +
     greedy roll-out per image, CIDEr-D + classifier rewards, XE (ss 0.5) + seq2seq (ss 0.25) passes,
@@ -334,6 +361,10 @@ def run(args):
                 extra['beam5'] = bench_beam(cap, inputs)
             except Exception as e:  # noqa: BLE001
                 extra['beam5'] = {'error': repr(e)[:200]}
+            try:
+                extra['scan_sweep'] = bench_scan_sweep(dev)
+            except Exception as e:      # noqa: BLE001 - side measurement only
+                extra['scan_sweep'] = {'error': repr(e)}
             try:
                 extra['rl_iteration'] = bench_rl(dev)
             except Exception as e:  # noqa: BLE001
