@@ -360,17 +360,21 @@ __device__ __forceinline__ void epi_lstm_frag(const DevProb &P, f32x16 (&acc)[4]
     }
 }
 
-// FAST: interior fragment without accumulate / pre-activation copy / keep-mask
-template <bool FAST, bool RELU>
-__device__ __forceinline__ void epi_linear_frag_impl(const DevProb &P, f32x16 (&acc)[4], int frow0, int lane, int row0, int col0) {
+// Linear epilogue of TN sub-tiles of 32 columns starting at tile column fcol0.  EDGE: the fragment touches the
+// matrix border (per-element predicates); FEAT: accumulate / pre-activation copy / keep-mask in play.  Interior
+// fragments run without per-element branches whatever the features.
+template <int TN, bool EDGE, bool FEAT, bool RELU>
+__device__ __forceinline__ void epi_linear_frag_impl(const DevProb &P, f32x16 (&acc)[TN], int frow0, int fcol0, int lane,
+                                                     int row0, int col0) {
     const int M = P.M, N = P.N;
-    float b0[4], b1[4], b2[4];
-    bool cok[4];
+    float b0[TN], b1[TN], b2[TN];
+    bool cok[TN];
     const bool h0 = P.bias0 != nullptr, h1 = P.bias1 != nullptr, h2 = P.bias2 != nullptr;
+    const bool f_acc = FEAT && P.accumulate, f_pre = FEAT && P.C_pre != nullptr, f_mask = FEAT && P.mask != nullptr;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int gn = col0 + j * 32 + (lane & 31);
-        cok[j] = FAST || gn < N;
+    for (int j = 0; j < TN; ++j) {
+        const int gn = col0 + fcol0 + j * 32 + (lane & 31);
+        cok[j] = !EDGE || gn < N;
         b0[j] = (h0 && cok[j]) ? P.bias0[gn] : 0.f;
         b1[j] = (h1 && cok[j]) ? P.bias1[gn] : 0.f;
         b2[j] = (h2 && cok[j]) ? P.bias2[gn] : 0.f;
@@ -378,38 +382,47 @@ __device__ __forceinline__ void epi_linear_frag_impl(const DevProb &P, f32x16 (&
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int gm = row0 + frow0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (!FAST && gm >= M) continue;
-        float *crow = P.C + (long long)gm * P.ldc + col0 + (lane & 31);
+        if (EDGE && gm >= M) continue;
+        float *crow = P.C + (long long)gm * P.ldc + col0 + fcol0 + (lane & 31);
+        float prev[TN];
+        if (f_acc) {                                   // all TN loads of the row before any arithmetic
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (!FAST && !cok[j]) continue;
+            for (int j = 0; j < TN; ++j) prev[j] = (!EDGE || cok[j]) ? crow[j * 32] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            if (EDGE && !cok[j]) continue;
             float o = acc[j][r];
             if (h0) o += b0[j];
             if (h1) o += b1[j];
             if (h2) o += b2[j];
-            if constexpr (!FAST) {
-                if (P.accumulate) o += crow[j * 32];
-            }
+            if (f_acc) o += prev[j];
             if (RELU) o = fmaxf(o, 0.f);
-            if constexpr (!FAST) {
-                const int gn = col0 + j * 32 + (lane & 31);
-                if (P.C_pre) P.C_pre[(long long)gm * P.ldc + gn] = o;
-                if (P.mask) o = o * (float)P.mask[(long long)gm * N + gn] * P.mask_scale;
+            if constexpr (FEAT) {
+                const int gn = col0 + fcol0 + j * 32 + (lane & 31);
+                if (f_pre) P.C_pre[(long long)gm * P.ldc + gn] = o;
+                if (f_mask) o = o * (float)P.mask[(long long)gm * N + gn] * P.mask_scale;
             }
             crow[j * 32] = o;
         }
     }
 }
 
-__device__ __forceinline__ void epi_linear_frag(const DevProb &P, f32x16 (&acc)[4], int frow0, int lane, int row0, int col0) {
-    const bool fast = !(P.accumulate || P.C_pre || P.mask) && row0 + frow0 + 32 <= P.M && col0 + 128 <= P.N;
-    if (fast) {
-        if (P.relu) epi_linear_frag_impl<true, true>(P, acc, frow0, lane, row0, col0);
-        else epi_linear_frag_impl<true, false>(P, acc, frow0, lane, row0, col0);
+template <int TN>
+__device__ __forceinline__ void epi_linear_frag(const DevProb &P, f32x16 (&acc)[TN], int frow0, int fcol0, int lane,
+                                                int row0, int col0) {
+    const bool feat = P.accumulate || P.C_pre || P.mask;
+    const bool edge = !(row0 + frow0 + 32 <= P.M && col0 + fcol0 + 32 * TN <= P.N);
+    const bool relu = P.relu != 0;
+#define ISC_EPI_CASE(E, F, R) epi_linear_frag_impl<TN, E, F, R>(P, acc, frow0, fcol0, lane, row0, col0)
+    if (edge) {
+        if (relu) ISC_EPI_CASE(true, true, true); else ISC_EPI_CASE(true, true, false);
+    } else if (feat) {
+        if (relu) ISC_EPI_CASE(false, true, true); else ISC_EPI_CASE(false, true, false);
     } else {
-        if (P.relu) epi_linear_frag_impl<false, true>(P, acc, frow0, lane, row0, col0);
-        else epi_linear_frag_impl<false, false>(P, acc, frow0, lane, row0, col0);
+        if (relu) ISC_EPI_CASE(false, false, true); else ISC_EPI_CASE(false, false, false);
     }
+#undef ISC_EPI_CASE
 }
 
 template <int WM, int WN, int TN, int EPI, bool AKM, bool BKM>
@@ -875,8 +888,8 @@ __global__ __launch_bounds__(256) void gemm_xl_kernel(const DevLaunch L) {
         epi_lstm_frag(P, acc[0], wm * 64, lane, row0, tn);
         epi_lstm_frag(P, acc[1], wm * 64 + 32, lane, row0, tn);
     } else {
-        epi_linear_frag(P, acc[0], wm * 64, lane, row0, col0);
-        epi_linear_frag(P, acc[1], wm * 64 + 32, lane, row0, col0);
+        epi_linear_frag<4>(P, acc[0], wm * 64, 0, lane, row0, col0);
+        epi_linear_frag<4>(P, acc[1], wm * 64 + 32, 0, lane, row0, col0);
     }
 }
 
@@ -1027,8 +1040,137 @@ __global__ __launch_bounds__(256) void gemm_ld_kernel(const DevLaunch L) {
     } else if constexpr (EPI == EPI_LSTM) {
         epi_lstm_frag(P, acc, wm * 32, lane, row0, tn);
     } else {
-        epi_linear_frag(P, acc, wm * 32, lane, row0, col0);
+        epi_linear_frag<4>(P, acc, wm * 32, 0, lane, row0, col0);
     }
+}
+
+// ---------------------------------------------------------------- MD tile: 64 x 128 by LDS-DMA (linear epilogue)
+// The LD scheme on the M geometry (2 x 2 waves, 32 x 64 accumulator each) for the per-step projections with
+// N = 512: their 64-row tiles are what balances 4096 x 512 outputs over 256 CUs, and at one to three workgroups
+// per CU the register-staged form of that tile leaves the matrix pipe idle over its chunk-boundary round trips.
+__global__ __launch_bounds__(256) void gemm_md_kernel(const DevLaunch L) {
+    constexpr int TN = 2;
+    constexpr int TSA = 64 * BK, TSB = 128 * BK;      // floats per operand buffer
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *As = smem;                     // [2][TSA]
+    float *Bs = smem + 2 * TSA;           // [2][TSB]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = tid >> 6, wm = w >> 1, wn = w & 1;
+    int pi, tm, tn, ks, ksplit;
+    map_tile(L, pi, tm, tn, ks, ksplit);
+    const DevProb &P = L.p[pi];
+    const int M = P.M, N = P.N;
+    const int row0 = tm * 64, col0 = tn * 128;
+
+    // staging pieces (8 rows x 128 B): A pieces 2w, 2w+1 = tile rows 16w + 8i; B pieces 4w .. 4w+3 = columns 32w + 8i
+    int arow[2];
+    long long wrow[4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = row0 + 16 * w + 8 * i + (lane >> 3);
+        arow[i] = r < M ? r : M - 1;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = col0 + 32 * w + 8 * i + (lane >> 3);
+        wrow[i] = c < N ? c : N - 1;
+    }
+    const int lq = lane & 7, lh = lane >> 4;
+    const float *pa[2], *pb[4];
+    int cs = 0, ck = 0, segK = 0;
+    auto set_seg = [&](int si) __attribute__((always_inline)) {
+        const DevSeg sg = P.seg[si];
+        segK = sg.K;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) pa[i] = sg.A + (long long)arow[i] * sg.lda + (lq ^ (4 * (i & 1) + lh)) * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pb[i] = sg.W + wrow[i] * sg.ldw + (lq ^ (4 * (i & 1) + lh)) * 4;
+    };
+    const unsigned a_lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)As + w * 16 * BK * 4);
+    const unsigned b_lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)Bs + w * 32 * BK * 4);
+    auto dma = [&](auto bufc, auto idxc) __attribute__((always_inline)) {
+        constexpr int BUF = decltype(bufc)::value, IDX = decltype(idxc)::value;
+        if constexpr (IDX < 2) {
+            asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off"
+                         :: "s"(a_lds0 + (BUF * TSA + 8 * IDX * BK) * 4), "v"(pa[IDX]) : "memory");
+            pa[IDX] += BK;
+        } else {
+            asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off"
+                         :: "s"(b_lds0 + (BUF * TSB + 8 * (IDX - 2) * BK) * 4), "v"(pb[IDX - 2]) : "memory");
+            pb[IDX - 2] += BK;
+        }
+        if constexpr (IDX == 5) {
+            ck += BK;
+            if (ck >= segK) {
+                ck = 0;
+                if (++cs < P.nseg) set_seg(cs);
+            }
+        }
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>;
+    using I4 = std::integral_constant<int, 4>;
+    using I5 = std::integral_constant<int, 5>;
+
+    f32x16 acc[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    const int frow = lane & 31, khalf = lane >> 5;
+    const int fsw = (frow >> 1) & 7;
+    float4 fa[2], fb[2][TN];
+    auto lfrag = [&](auto bufc, auto kbc, auto setc) __attribute__((always_inline)) {
+        constexpr int BUF = decltype(bufc)::value, kb = decltype(kbc)::value, ST = decltype(setc)::value;
+        const int slot = ((2 * kb + khalf) ^ fsw) * 4;
+        fa[ST] = *reinterpret_cast<const float4 *>(As + BUF * TSA + (wm * 32 + frow) * BK + slot);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+            fb[ST][j] = *reinterpret_cast<const float4 *>(Bs + BUF * TSB + ((wn * TN + j) * 32 + frow) * BK + slot);
+    };
+    auto mma_e = [&](auto setc, auto ec) __attribute__((always_inline)) {
+        constexpr int ST = decltype(setc)::value, e = decltype(ec)::value;
+        const float a[4] = {fa[ST].x, fa[ST].y, fa[ST].z, fa[ST].w};
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const float b[4] = {fb[ST][j].x, fb[ST][j].y, fb[ST][j].z, fb[ST][j].w};
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], acc[j], 0, 0, 0);
+        }
+    };
+    auto mma = [&](auto setc) __attribute__((always_inline)) {
+        mma_e(setc, I0{}); mma_e(setc, I1{}); mma_e(setc, I2{}); mma_e(setc, I3{});
+    };
+    int nchunks = 0;
+    for (int s = 0; s < P.nseg; ++s) nchunks += P.seg[s].K / BK;
+    auto chunk_body = [&](auto curc, auto nxtc, bool has1) __attribute__((always_inline)) {
+        lfrag(curc, I1{}, I1{});
+        mma_e(I0{}, I0{}); if (has1) { dma(nxtc, I0{}); dma(nxtc, I1{}); }
+        mma_e(I0{}, I1{}); if (has1) { dma(nxtc, I2{}); dma(nxtc, I3{}); }
+        mma_e(I0{}, I2{}); if (has1) { dma(nxtc, I4{}); dma(nxtc, I5{}); }
+        mma_e(I0{}, I3{});
+        lfrag(curc, I2{}, I0{});
+        mma(I1{});
+        lfrag(curc, I3{}, I1{});
+        mma(I0{});
+        if (has1) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            lfrag(nxtc, I0{}, I0{});
+        }
+        mma(I1{});
+    };
+    set_seg(0);
+    dma(I0{}, I0{}); dma(I0{}, I1{}); dma(I0{}, I2{}); dma(I0{}, I3{}); dma(I0{}, I4{}); dma(I0{}, I5{});
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    lfrag(I0{}, I0{}, I0{});
+    for (int c = 0; c < nchunks; c += 2) {
+        chunk_body(I0{}, I1{}, c + 1 < nchunks);
+        if (c + 1 < nchunks) chunk_body(I1{}, I0{}, c + 2 < nchunks);
+    }
+    epi_linear_frag<TN>(P, acc, wm * 32, wn * 64, lane, row0, col0);
 }
 
 // ---------------------------------------------------------------- split-K reduction + epilogue
@@ -1221,8 +1363,24 @@ static int launch_ld(const DevLaunch &L, hipStream_t st) {
 // 3 = XL 256x128 (LDS-DMA ring, NT layout only), 4 = LD 128x128 by LDS-DMA (NT layout only)
 static const int kTileBM[5] = {128, 64, 32, 256, 128};
 
+static int launch_md(const DevLaunch &L, hipStream_t st) {
+    constexpr size_t lds = (size_t)2 * (64 + 128) * BK * sizeof(float);    // 49152: three workgroups per CU
+    hipLaunchKernelGGL(gemm_md_kernel, dim3(L.total_tiles), dim3(256), lds, st, L);
+    ISC_LAUNCH_CHECK();
+    return ISC_OK;
+}
+
+static int g_md_enabled = 1;   // isc_set_tile_override(102 / 103): MD path off / on (A/B measurements)
+
 template <int EPI, bool AKM, bool BKM>
 static int launch_any(const DevLaunch &L, int tile, hipStream_t st) {
+    if constexpr (EPI == EPI_LINEAR && !AKM && !BKM) {
+        if (tile == 1 && g_md_enabled) {
+            bool plain = true;
+            for (int i = 0; i < L.nprob; ++i) plain = plain && L.p[i].ksplit <= 1;
+            if (plain) return launch_md(L, st);
+        }
+    }
     if constexpr (!AKM && !BKM) {
         if (tile == 3) return launch_xl<EPI>(L, st);
         if (tile == 4) return launch_ld<EPI>(L, st);
@@ -1239,6 +1397,10 @@ static int launch_any(const DevLaunch &L, int tile, hipStream_t st) {
 // alone).  Calibrated on tools/gemm_big.py / gemm_bench.py.
 static int g_tile_override = -1;
 extern "C" int isc_set_tile_override(int tile) {
+    if (tile == 102 || tile == 103) {          // measurement switch for the MD path, leaves the tile choice alone
+        g_md_enabled = tile == 103;
+        return g_tile_override;
+    }
     const int prev = g_tile_override;
     g_tile_override = (tile >= 0 && tile <= 4) ? tile : -1;
     return prev;
