@@ -1589,7 +1589,7 @@ extern "C" int isc_lstm_fwd(const isc_lstm_problem *q, void *stream) {
     // epilogue reads per output, which the XL tile's lone workgroup per CU cannot overlap with MFMA work
     // (in the roll-out: att-LSTM 168 us on the 128x128 tile vs 178 us on XL; lang-LSTM 223 vs 206; with the
     // batched epilogue loads of lstm_cells the two are within 2 % of each other on either cell)
-    const int tile = pick_tile(L, !q->pre && !q->tab);
+    const int tile = pick_tile(L, !q->pre && !q->tab, true, true);
     finish_tiling(L, tile);
     return launch_any<EPI_LSTM, false, false>(L, tile, (hipStream_t)stream);
 }
