@@ -1406,10 +1406,9 @@ extern "C" int isc_set_tile_override(int tile) {
     return prev;
 }
 
-// nt: the launch is in the NT layout (the two LDS-DMA tiles exist for it); use_ld: let the cost model consider
-// the LD tile (only the vocabulary projection does: in the roll-out the prologue GEMMs measured slower on LD
-// than on XL - 2.76 vs 2.22 ms for att_embed - although the isolated kernels tie)
-static int pick_tile(const DevLaunch &L, bool allow_xl, bool nt = true, bool use_ld = false) {
+// nt: the launch is in the NT layout (the LDS-DMA tiles XL / LD exist for it; MD replaces M for the linear epilogue
+// inside launch_any); use_ld: let the cost model consider the LD tile
+static int pick_tile(const DevLaunch &L, bool allow_xl, bool nt = true, bool use_ld = true) {
     if (g_tile_override == 4) return nt ? 4 : 0;
     if (g_tile_override >= 0) return (g_tile_override == 3 && !allow_xl) ? 0 : g_tile_override;
     static const double eff[5][3] = {{0.80, 1.00, 1.00},    // L : 1, 2, >=3 workgroups on the busiest CU
