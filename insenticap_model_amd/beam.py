@@ -13,6 +13,121 @@ import torch
 from . import ops
 
 
+class _ListMerge:
+    """Candidate bookkeeping of captioner.py:378-411, image by image in plain Python (fastest for one or two
+    images).  step() fills `last_out` [rows] and `gather_out` [rows] (source row of every new row: parent, or
+    parent + rows when the candidate is carried and keeps its old state) and returns False when every image is done."""
+
+    def __init__(self, n_img, beam, sos_id, eos_id):
+        self.n_img, self.beam, self.eos = n_img, beam, eos_id
+        self.cands = [[(0.0, sos_id, [])] for _ in range(n_img)]
+        self.done = [False] * n_img
+
+    def step(self, t, ti, tv, last_out, gather_out):
+        beam, rows = self.beam, self.n_img * self.beam
+        ti, tv = ti.tolist(), tv.tolist()
+        any_live = False
+        for i in range(self.n_img):
+            base = i * beam
+            if self.done[i]:
+                for k in range(beam):
+                    gather_out[base + k] = base + k + rows
+                continue
+            tmp = []                      # (score, last, words, src_row, was_stepped)
+            all_ended = True
+            for k, (score, lw, words) in enumerate(self.cands[i]):
+                row = base + k
+                if t > 0 and lw == self.eos:
+                    tmp.append((score, lw, words, row, False))
+                    continue
+                all_ended = False
+                for j in range(beam):
+                    w = ti[row][j]
+                    tmp.append((score + tv[row][j], w, words + [w], row, True))
+            tmp = sorted(tmp, key=lambda x: x[0], reverse=True)[:beam]   # stable, as the reference
+            self.cands[i] = [(s, lw, words) for (s, lw, words, _, _) in tmp]
+            for k, (_, lw, _, src, st) in enumerate(tmp):
+                gather_out[base + k] = src if st else src + rows
+                last_out[base + k] = lw
+            for k in range(len(tmp), beam):          # t == 0 with beam > candidates never happens
+                gather_out[base + k] = base + k + rows
+            if all_ended:
+                self.done[i] = True
+            else:
+                any_live = True
+        return any_live
+
+    def result(self):
+        return [[(s, words) for (s, _, words) in c] for c in self.cands]
+
+
+class _VectorMerge:
+    """The same bookkeeping for many images at once in numpy: fp64 score sums, candidates laid out in insertion
+    order (parents in rank order, children by rank) and a STABLE descending sort, so ties resolve exactly as the
+    reference's `sorted(..., reverse=True)`.  64 images cost one set of array operations instead of 64 Python loops."""
+
+    def __init__(self, n_img, beam, T, sos_id, eos_id):
+        self.n, self.beam, self.eos = n_img, beam, eos_id
+        self.scores = np.full((n_img, beam), -np.inf)
+        self.scores[:, 0] = 0.0
+        self.ncand = 1                                      # candidates per image: 1 at t = 0, then `beam`
+        self.last = np.full((n_img, beam), sos_id, dtype=np.int64)
+        self.words = np.zeros((n_img, beam, T), dtype=np.int64)
+        self.length = np.zeros((n_img, beam), dtype=np.int64)
+        self.done = np.zeros(n_img, dtype=bool)
+        self.img = np.arange(n_img)[:, None]
+
+    def step(self, t, ti, tv, last_out, gather_out):
+        n, beam = self.n, self.beam
+        rows = n * beam
+        valid = np.arange(beam)[None, :] < self.ncand                      # [1,beam]
+        ended = (self.last == self.eos) & (t > 0) & valid                  # carried candidates
+        live = valid & ~ended
+        all_ended = ~live.any(axis=1)
+        newly_done = all_ended & ~self.done
+        active = ~self.done & ~all_ended
+        # candidate table [n, beam(parent), beam(child)] in insertion order
+        cand = np.full((n, beam, beam), -np.inf)
+        child = self.scores[:, :, None] + tv.reshape(n, beam, beam).astype(np.float64)
+        cand[live] = child[live]
+        cand[ended, 0] = self.scores[ended]
+        flat = cand.reshape(n, beam * beam)
+        order = np.argsort(-flat, axis=1, kind='stable')[:, :beam]
+        pk, cj = order // beam, order % beam
+        new_scores = np.take_along_axis(flat, order, axis=1)
+        carried = ended[self.img, pk]
+        tok = ti.reshape(n, beam, beam)[self.img, pk, cj]
+        new_last = np.where(carried, self.last[self.img, pk], tok)
+        new_words = self.words[self.img, pk]
+        new_len = self.length[self.img, pk]
+        add = ~carried
+        ii, kk = np.nonzero(add & active[:, None])
+        new_words[ii, kk, new_len[ii, kk]] = tok[ii, kk]
+        new_len = new_len + add
+        upd = active                                                        # frozen images keep everything
+        self.scores[upd] = new_scores[upd]
+        self.last[upd] = new_last[upd]
+        self.words[upd] = new_words[upd]
+        self.length[upd] = new_len[upd]
+        self.done |= newly_done
+        base = (np.arange(n) * beam)[:, None]
+        src = base + pk
+        gat = np.where(carried, src + rows, src)
+        ident = base + np.arange(beam)[None, :] + rows
+        gather_out[:] = np.where(upd[:, None], gat, ident).reshape(rows)
+        last_out[:] = self.last.reshape(rows)
+        if t == 0:
+            self.ncand = beam
+        return bool(active.any())
+
+    def result(self):
+        out = []
+        for i in range(self.n):
+            k = self.ncand
+            out.append([(float(self.scores[i, j]), self.words[i, j, :self.length[i, j]].tolist()) for j in range(k)])
+        return out
+
+
 def beam_search_batch(cap, fc_feats, att_feats, senti_words, senti_labels, beam, decoding_constraint, T):
     p = cap._p()
     n_img = fc_feats.shape[0]
@@ -46,15 +161,13 @@ def beam_search_batch(cap, fc_feats, att_feats, senti_words, senti_labels, beam,
     emb = p['word_embed.0.weight']
     mask_special = cap.pad_id != cap.eos_id
 
-    # host-side candidates per image: (score, last_word, words, ended_state_row)
-    cands = [[(0.0, cap.sos_id, [])] for _ in range(n_img)]
-    done = [False] * n_img
-    last = [cap.sos_id] * rows
+    cap.last_beam_steps = 0                    # decode steps executed (bench.py: latency per step)
+    merge = _VectorMerge(n_img, beam, T, cap.sos_id, cap.eos_id) if n_img >= 4 else \
+        _ListMerge(n_img, beam, cap.sos_id, cap.eos_id)
     ctrl_h = torch.empty(2, rows, dtype=torch.int64).pin_memory()     # [last word ; gather index], one upload per step
     ctrl_np = ctrl_h.numpy()
-    ctrl_np[0, :] = last
+    ctrl_np[0, :] = cap.sos_id
     ctrl_d = ctrl_h.to(dev, non_blocking=True)
-    cap.last_beam_steps = 0                    # decode steps executed (bench.py: latency per step)
     for t in range(T):
         cap.last_beam_steps = t + 1
         last_d = ctrl_d[0]
@@ -65,51 +178,18 @@ def beam_search_batch(cap, fc_feats, att_feats, senti_words, senti_labels, beam,
         ops.beam_topk(logits, ws['pmax'], ws['psum'], last_d, beam, cap.pad_id, cap.sos_id, cap.unk_id,
                       mask_special, decoding_constraint, top_val, top_idx)
         hb = top_buf.cpu().numpy()        # the single host read of this step
-        ti = hb[:nk * 8].view(np.int64).reshape(rows, beam).tolist()
-        tv = hb[nk * 8:].view(np.float32).reshape(rows, beam).tolist()
-        parent = list(range(rows))        # source row of every new row (state gather)
-        stepped = [True] * rows           # False: carried candidate keeps its old state
-        any_live = False
-        for i in range(n_img):
-            if done[i]:
-                for k in range(beam):
-                    stepped[i * beam + k] = False
-                continue
-            tmp = []                      # (score, last, words, src_row, was_stepped)
-            all_ended = True
-            for k, (score, lw, words) in enumerate(cands[i]):
-                row = i * beam + k
-                if t > 0 and lw == cap.eos_id:
-                    tmp.append((score, lw, words, row, False))
-                    continue
-                all_ended = False
-                for j in range(beam):
-                    w = ti[row][j]
-                    tmp.append((score + tv[row][j], w, words + [w], row, True))
-            tmp = sorted(tmp, key=lambda x: x[0], reverse=True)[:beam]   # stable, as the reference
-            cands[i] = [(s, lw, words) for (s, lw, words, _, _) in tmp]
-            for k, (_, lw, _, src, st) in enumerate(tmp):
-                parent[i * beam + k] = src
-                stepped[i * beam + k] = st
-                last[i * beam + k] = lw
-            for k in range(len(tmp), beam):          # t == 0 with beam > candidates never happens
-                stepped[i * beam + k] = False
-            if all_ended:
-                done[i] = True
-            else:
-                any_live = True
+        ti = hb[:nk * 8].view(np.int64).reshape(rows, beam)
+        tv = hb[nk * 8:].view(np.float32).reshape(rows, beam)
+        # new state of row r = stepped ? nxt[parent] : cur[parent]  ==  [nxt ; cur][parent + (stepped ? 0 : rows)]
+        any_live = merge.step(t, ti, tv, ctrl_np[0], ctrl_np[1])
         if not any_live:
             break
-        # new state of row r = stepped ? nxt[parent] : cur[parent]  ==  [nxt ; cur][parent + (stepped ? 0 : rows)]
-        ctrl_np[0, :] = last
-        ctrl_np[1, :] = [pr if st else pr + rows for pr, st in zip(parent, stepped)]
         ctrl_d = ctrl_h.to(dev, non_blocking=True)
         st_cur = torch.cat([st_nxt, st_cur], dim=2).index_select(2, ctrl_d[1])
     cap.cont_weights, cap.senti_weights, cap.cont_senti_weights = [], [], []
     captions, scores, ids = [], [], []
-    for i in range(n_img):
-        captions.append([' '.join(cap.idx2word[w] for w in words if w != cap.eos_id)
-                         for (_, _, words) in cands[i]])
-        scores.append([s for (s, _, _) in cands[i]])
-        ids.append([list(words) for (_, _, words) in cands[i]])
+    for i, cands in enumerate(merge.result()):
+        captions.append([' '.join(cap.idx2word[w] for w in words if w != cap.eos_id) for (_, words) in cands])
+        scores.append([s for (s, _) in cands])
+        ids.append([list(words) for (_, words) in cands])
     return captions, scores, ids
