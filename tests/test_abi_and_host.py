@@ -191,3 +191,33 @@ def test_attention_weight_attributes_resolve_lazily():
     assert cap.senti_weights == [] and cap.cont_senti_weights == []
     cap.cont_weights = []                                            # plain assignment still works (beam search)
     assert cap.cont_weights == []
+
+
+def test_beam_merge_vectorised_equals_list_version():
+    """beam.py: the numpy candidate merge (many images) must reproduce the reference-style Python merge step by step -
+    gather indices, fed tokens, final ids and fp64 scores - including ties, early <EOS> and images that finish."""
+    import numpy as np
+    from insenticap_model_amd.beam import _ListMerge, _VectorMerge
+    rng = np.random.default_rng(5)
+    n_img, beam, T, sos, eos = 7, 3, 9, 1, 2
+    rows = n_img * beam
+    a, b = _ListMerge(n_img, beam, sos, eos), _VectorMerge(n_img, beam, T, sos, eos)
+    for t in range(T):
+        ti = rng.integers(2, 7, size=(rows, beam)).astype(np.int64)           # small vocabulary: <EOS> (2) is frequent
+        tv = -rng.integers(1, 4, size=(rows, beam)).astype(np.float32) * 0.5     # few distinct values: many ties
+        tv.sort(axis=1)
+        tv = tv[:, ::-1].copy()                                                # top-k comes sorted, best first
+        la, ga = np.full(rows, sos, dtype=np.int64), np.zeros(rows, dtype=np.int64)
+        lb, gb = la.copy(), ga.copy()
+        if t > 0:
+            la[:] = last_prev
+            lb[:] = last_prev
+        live_a = a.step(t, ti, tv, la, ga)
+        live_b = b.step(t, ti, tv, lb, gb)
+        assert live_a == live_b, t
+        assert (ga == gb).all() and (la == lb).all(), t
+        last_prev = la.copy()
+        if not live_a:
+            break
+    ra, rb = a.result(), b.result()
+    assert ra == rb
