@@ -123,6 +123,7 @@ struct DevRollout {
     int64_t *raw_tokens;
     const float *emb, *xt_add;
     float *xt_next;
+    int rows_per_wave;
 };
 
 // Inverse-CDF sampling from softmax over one row, in vocabulary order, by one wavefront.  Two levels: the
@@ -234,8 +235,8 @@ __global__ __launch_bounds__(256) void rollout_finalize_kernel(const DevRollout 
     // leave seq / seq_logprobs / seq_masks at their zero initialisation
     if (R.alive[R.t] == 0) return;          // block-uniform
     int alive = 0;
-    for (int i = 0; i < ISC_FIN_ROWS_PER_WAVE; ++i) {
-        const int b = (blockIdx.x * 4 + wave) * ISC_FIN_ROWS_PER_WAVE + i;
+    for (int i = 0; i < R.rows_per_wave; ++i) {
+        const int b = (blockIdx.x * 4 + wave) * R.rows_per_wave + i;
         if (b < R.B) alive += rollout_finalize_row(R, b, lane);
     }
     if (lane == 0) cnt[wave] = alive;
@@ -260,7 +261,10 @@ extern "C" int isc_rollout_finalize(const isc_rollout_step *s, void *stream) {
     R.eos_id = s->eos_id; R.seq = s->seq; R.seq_logprobs = s->seq_logprobs; R.seq_masks = s->seq_masks;
     R.unfinished = s->unfinished; R.alive = s->alive; R.raw_tokens = s->raw_tokens;
     R.emb = s->emb; R.xt_add = s->xt_add; R.xt_next = s->xt_next;
-    hipLaunchKernelGGL(rollout_finalize_kernel, dim3((s->B + 4 * ISC_FIN_ROWS_PER_WAVE - 1) / (4 * ISC_FIN_ROWS_PER_WAVE)),
+    // few rows: one per wavefront (a wave walking 4 rows in turn is 12 us at B=4); many rows: 4 per wave, so that the
+    // `alive` counter sees one atomic per 16 rows
+    R.rows_per_wave = s->B <= 1024 ? 1 : ISC_FIN_ROWS_PER_WAVE;
+    hipLaunchKernelGGL(rollout_finalize_kernel, dim3((s->B + 4 * R.rows_per_wave - 1) / (4 * R.rows_per_wave)),
                        dim3(256), 0, (hipStream_t)stream, R);
     ISC_LAUNCH_CHECK();
     return ISC_OK;
