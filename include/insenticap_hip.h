@@ -44,6 +44,17 @@ const char *isc_target_arch(void);
  * summation order for every shape; process-wide, not meant to be flipped while launches are in flight
  * on other threads.  Returns the previous value. */
 int isc_set_tile_override(int tile);
+/* Split-f16 GEMM path of the forward entry points (isc_linear_fwd / isc_lstm_fwd / isc_vocab_fwd): fp32 operands
+ * are split into two f16 planes each (x = hi + lo * 2^-11) inside the caller's workspace and contracted with three
+ * f16 MFMAs per k-step into fp32 accumulators - fp32 in, fp32 out, error against an fp64 contraction no larger than
+ * an fp32 FMA chain's (tests/test_gpu_h3.py), at 2-2.5x the fp32 MFMA rate.  Operand domain |x| < 65504.
+ * mode 0 = off (fp32 MFMA tiles only), 1 = auto (default: launches of >= 160 128x128 tiles, smaller launches keep
+ * the fp32 tiles), 2 = whenever shapes and workspace allow.  The planes of a launch must fit the workspace; a linear
+ * problem that does not goes through it in row chunks (the prologue's region projections).  A tile override
+ * (>= 0) also disables it.  Returns the previous mode. */
+int isc_set_h3_mode(int mode);
+/* Number of launches that went out on the split-f16 path so far (process-wide; measurement / test hook). */
+long long isc_h3_launches(void);
 
 /* One K-segment of a contraction: acc += A[M,K] * W[N,K]^T.  Replaces the
  * torch.cat([...],1) + nn.Linear / nn.LSTMCell pattern of captioner.py:174-175,180-181. */

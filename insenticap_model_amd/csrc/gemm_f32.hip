@@ -61,6 +61,9 @@ struct DevProb {
     int ksplit;
     float *slab;
     long long slab_stride;
+    // split-f16 path (gemm_h3_kernel): hi / lo planes of the K-concatenated operands, [rows, Kp] halfs each
+    const _Float16 *Ah, *Al, *Wh, *Wl;
+    int Kp;
 };
 
 struct DevLaunch {
@@ -1044,6 +1047,183 @@ __global__ __launch_bounds__(256) void gemm_ld_kernel(const DevLaunch L) {
     }
 }
 
+// ---------------------------------------------------------------- H3 tile: 128 x 128 on the f16 matrix cores
+// fp32 operands, fp32 results, f16 MFMA rate.  Every operand value is split once into two f16 planes,
+//     x = hi + lo * 2^-11,   hi = f16(x),   lo = f16((x - hi) * 2^11)
+// which keeps 22-24 mantissa bits of x (the subtraction is exact in fp32; lo's own rounding error is 2^-24 |x|),
+// and the contraction is taken as
+//     C = sum hi_a hi_b  +  2^-11 * sum (hi_a lo_b + lo_a hi_b)
+// on v_mfma_f32_32x32x16_f16: three MFMAs per 16-deep k-step instead of eight 32x32x2 fp32 ones at 1/16 the rate.
+// f16 x f16 products are exact in the fp32 accumulator, the dropped lo_a lo_b term is 2^-24 relative, and the
+// two sums live in separate accumulators so that the 2^-11 weight is applied once, in fp32, at the end.  Measured
+// against an fp64 contraction the result is CLOSER than an fp32 fmaf chain (rms 1.0e-7 vs 2.6e-7 at K = 512,
+// tools/h3_gemm_lab.hip) - the 1e-4 log-prob parity bound is not touched.  Domain: |x| < 65504 (f16 range of hi);
+// beyond it hi is inf and the output NaN - loud, and far outside what the decoder's bounded activations reach.
+// Geometry = the LD tile's (4 waves stacked in M, 32 x 128 accumulators, so the register epilogues are shared),
+// operands by LDS-DMA from the pre-split planes: per 32-deep chunk four [128 x 32] f16 plane tiles of 8 KB
+// (A hi, A lo, W hi, W lo), two buffers = 64 KB, two workgroups per CU.  64-byte LDS rows: slot s of row r holds
+// k-octet q = s ^ ((r >> 2) & 3), which makes the ds_read_b128 fragment reads conflict-free.
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_h3_kernel(const DevLaunch L) {
+    constexpr int BM = 128, BN = 128, TN = 4;
+    constexpr int PL = 128 * 64;                        // bytes per plane tile
+    constexpr int ST = 4 * PL;                          // bytes per buffer
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char *lds = reinterpret_cast<char *>(smem);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wm = tid >> 6;
+    int pi, tm, tn, ks, ksplit;
+    map_tile(L, pi, tm, tn, ks, ksplit);
+    const DevProb &P = L.p[pi];
+    const int M = P.M, N = P.N, Kp = P.Kp;
+    const int row0 = tm * BM, col0 = tn * BN;
+
+    // staging: per plane, wave w issues pieces 2w and 2w+1; piece ii = tile rows 16*ii .. +16, 4 lanes per row
+    const _Float16 *src[8];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int t = 16 * (2 * wm + i) + (lane >> 2);
+        const int q = (lane & 3) ^ ((t >> 2) & 3);
+        int ar = row0 + t;
+        ar = ar < M ? ar : M - 1;
+        long long wr;
+        if (EPI == EPI_LSTM) {
+            wr = (long long)(t >> 5) * P.H + tn * 32 + (t & 31);
+        } else {
+            const int c = col0 + t;
+            wr = c < N ? c : N - 1;
+        }
+        src[0 + i] = P.Ah + (long long)ar * Kp + q * 8;
+        src[2 + i] = P.Al + (long long)ar * Kp + q * 8;
+        src[4 + i] = P.Wh + wr * Kp + q * 8;
+        src[6 + i] = P.Wl + wr * Kp + q * 8;
+    }
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds + wm * 2048);
+    auto stage = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off"
+                             :: "s"(lds0 + buf * ST + p * PL + i * 1024), "v"(src[2 * p + i]) : "memory");
+                src[2 * p + i] += 32;
+            }
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+
+    f32x16 acc0[TN], acc1[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[j][r] = 0.f; acc1[j][r] = 0.f; }
+
+    const int fr = lane & 31, fh = lane >> 5, fsw = (fr >> 2) & 3;
+    h8 a1[2], a2[2], b1[2][TN], b2[2][TN];
+    auto lfrag = [&](int buf, auto ksc, auto setc) __attribute__((always_inline)) {
+        constexpr int kk = decltype(ksc)::value, S = decltype(setc)::value;
+        const int slot = ((2 * kk + fh) ^ fsw) * 16;
+        const char *base = lds + buf * ST;
+        const int ra = (wm * 32 + fr) * 64 + slot;
+        a1[S] = *reinterpret_cast<const h8 *>(base + ra);
+        a2[S] = *reinterpret_cast<const h8 *>(base + PL + ra);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int rb = (j * 32 + fr) * 64 + slot;
+            b1[S][j] = *reinterpret_cast<const h8 *>(base + 2 * PL + rb);
+            b2[S][j] = *reinterpret_cast<const h8 *>(base + 3 * PL + rb);
+        }
+    };
+    auto mma = [&](auto setc) __attribute__((always_inline)) {
+        constexpr int S = decltype(setc)::value;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            acc0[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[S], b1[S][j], acc0[j], 0, 0, 0);
+            acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[S], b2[S][j], acc1[j], 0, 0, 0);
+            acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2[S], b1[S][j], acc1[j], 0, 0, 0);
+        }
+    };
+    const int nchunks = Kp / 32;
+    stage(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    lfrag(0, I0{}, I0{});
+    for (int c = 0; c < nchunks; ++c) {
+        const int cur = c & 1, nxt = cur ^ 1;
+        const bool has1 = c + 1 < nchunks;
+        if (has1) stage(nxt);                 // buffer nxt was last read in front of the previous barrier
+        lfrag(cur, I1{}, I1{});
+        mma(I0{});
+        if (has1) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            lfrag(nxt, I0{}, I0{});
+        }
+        mma(I1{});
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc0[j][r] = fmaf(acc1[j][r], 1.f / 2048.f, acc0[j][r]);
+
+    if constexpr (EPI == EPI_VOCAB) {
+        epi_vocab_frag<TN, 1, BM>(P, acc0, wm * 32, 0, 0, lane, row0, col0, tn, smem);
+    } else if constexpr (EPI == EPI_LSTM) {
+        epi_lstm_frag(P, acc0, wm * 32, lane, row0, tn);
+    } else {
+        epi_linear_frag<4>(P, acc0, wm * 32, 0, lane, row0, col0);
+    }
+}
+
+// Operand split in front of gemm_h3_kernel: gathers the K-segments of one operand into the two packed f16 planes
+// [rows, Kp].  One thread per 8 consecutive k (two float4 loads, one 16-byte store per plane).
+struct SplitJob {
+    const float *src[ISC_MAX_SEG];
+    int ld[ISC_MAX_SEG];
+    int kstart[ISC_MAX_SEG];
+    int nseg, rows, Kp, first_block;
+    _Float16 *hi, *lo;
+};
+struct SplitLaunch {
+    SplitJob j[6];
+    int njobs;
+};
+
+__global__ __launch_bounds__(256) void h3_split_kernel(const SplitLaunch S) {
+    int ji = 0;
+#pragma unroll
+    for (int i = 1; i < 6; ++i)
+        if (i < S.njobs && (int)blockIdx.x >= S.j[i].first_block) ji = i;
+    const SplitJob &J = S.j[ji];
+    const int k8n = J.Kp >> 3;
+    const long long idx = (long long)(blockIdx.x - J.first_block) * 256 + threadIdx.x;
+    if (idx >= (long long)J.rows * k8n) return;
+    const int row = (int)(idx / k8n);
+    int k = (int)(idx - (long long)row * k8n) * 8;
+    const long long o = (long long)row * J.Kp + k;
+    const float *sp = J.src[0];
+    int ld = J.ld[0], k0 = 0;
+#pragma unroll
+    for (int s = 1; s < ISC_MAX_SEG; ++s)
+        if (s < J.nseg && k >= J.kstart[s]) { sp = J.src[s]; ld = J.ld[s]; k0 = J.kstart[s]; }
+    const float *p = sp + (long long)row * ld + (k - k0);
+    const float4 v0 = *reinterpret_cast<const float4 *>(p), v1 = *reinterpret_cast<const float4 *>(p + 4);
+    const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+    h8 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const _Float16 h = (_Float16)x[e];
+        hi[e] = h;
+        lo[e] = (_Float16)((x[e] - (float)h) * 2048.f);
+    }
+    *reinterpret_cast<h8 *>(J.hi + o) = hi;
+    *reinterpret_cast<h8 *>(J.lo + o) = lo;
+}
+
 // ---------------------------------------------------------------- MD tile: 64 x 128 by LDS-DMA (linear epilogue)
 // The LD scheme on the M geometry (2 x 2 waves, 32 x 64 accumulator each) for the per-step projections with
 // N = 512: their 64-row tiles are what balances 4096 x 512 outputs over 256 CUs, and at one to three workgroups
@@ -1450,6 +1630,148 @@ static void finish_tiling(DevLaunch &L, int tile) {
     L.total_tiles = start;
 }
 
+// ---- split-f16 path (gemm_h3_kernel) ----
+// isc_set_h3_mode: 0 = off, 1 = auto (launches of at least H3_MIN_TILES 128x128 tiles), 2 = whenever the shapes allow
+static int g_h3_mode = 1;
+static long long g_h3_launches = 0;
+extern "C" long long isc_h3_launches(void) { return g_h3_launches; }
+extern "C" int isc_set_h3_mode(int mode) {
+    const int prev = g_h3_mode;
+    if (mode >= 0 && mode <= 2) g_h3_mode = mode;
+    return prev;
+}
+#define H3_MIN_TILES 160
+
+template <int EPI>
+static int launch_h3(const DevLaunch &L, hipStream_t st) {
+    constexpr size_t lds = 65536;                                          // two workgroups per CU
+    hipLaunchKernelGGL((gemm_h3_kernel<EPI>), dim3(L.total_tiles), dim3(256), lds, st, L);
+    ISC_LAUNCH_CHECK();
+    return ISC_OK;
+}
+
+// Operand-split jobs of one launch: add() lays the planes of an operand out in the workspace and queues its job.
+struct H3Planner {
+    SplitLaunch S = {};
+    char *at;
+    int blocks = 0;
+    explicit H3Planner(float *ws) : at(reinterpret_cast<char *>(ws)) {}
+    void add(const DevProb &p, bool is_w, int rows, const _Float16 *&hi, const _Float16 *&lo) {
+        SplitJob &J = S.j[S.njobs++];
+        int k0 = 0;
+        for (int s = 0; s < p.nseg; ++s) {
+            J.src[s] = is_w ? p.seg[s].W : p.seg[s].A;
+            J.ld[s] = is_w ? p.seg[s].ldw : p.seg[s].lda;
+            J.kstart[s] = k0;
+            k0 += p.seg[s].K;
+        }
+        J.nseg = p.nseg; J.rows = rows; J.Kp = k0; J.first_block = blocks;
+        const size_t bytes = (((size_t)rows * k0 * 2) + 255) & ~(size_t)255;
+        J.hi = reinterpret_cast<_Float16 *>(at); at += bytes;
+        J.lo = reinterpret_cast<_Float16 *>(at); at += bytes;
+        hi = J.hi; lo = J.lo;
+        blocks += (int)(((long long)rows * (k0 >> 3) + 255) / 256);
+    }
+    int launch(hipStream_t st) {
+        if (!S.njobs) return ISC_OK;
+        hipLaunchKernelGGL(h3_split_kernel, dim3(blocks), dim3(256), 0, st, S);
+        ISC_LAUNCH_CHECK();
+        return ISC_OK;
+    }
+};
+
+static int h3_kp(const DevProb &p) {
+    int Kp = 0;
+    for (int s = 0; s < p.nseg; ++s) Kp += p.seg[s].K;
+    return Kp;
+}
+
+// A linear problem whose planes do not fit the workspace (the prologue's region projections: 147456 rows) goes
+// through it in row chunks: split chunk -> GEMM chunk -> next.  A chunk's planes (<= the workspace, 128 MB) are
+// written and read back while still resident in L2 / the 256 MB memory-side cache.
+static int h3_linear_chunked(const DevProb &p0, float *ws, long long ws_floats, long long chunk_rows, hipStream_t st) {
+    const int Kp = h3_kp(p0);
+    for (long long r0 = 0; r0 < p0.M; r0 += chunk_rows) {
+        DevLaunch L = {};
+        L.nprob = 1;
+        DevProb &p = L.p[0];
+        p = p0;
+        p.M = (int)((p0.M - r0) < chunk_rows ? (p0.M - r0) : chunk_rows);
+        p.Kp = Kp;
+        for (int s = 0; s < p.nseg; ++s) p.seg[s].A = p0.seg[s].A + r0 * p0.seg[s].lda;
+        p.C = p0.C + r0 * p0.ldc;
+        if (p0.C_pre) p.C_pre = p0.C_pre + r0 * p0.ldc;
+        if (p0.mask) p.mask = p0.mask + r0 * p0.N;
+        H3Planner pl(ws);
+        const _Float16 *wh, *wl;
+        pl.add(p0, true, p0.N, wh, wl);              // same place every chunk; only the first chunk's job is launched
+        if (r0 != 0) { pl.S.njobs = 0; pl.blocks = 0; }
+        p.Wh = wh; p.Wl = wl;
+        pl.add(p, false, p.M, p.Ah, p.Al);
+        int rc = pl.launch(st);
+        if (rc) return rc;
+        finish_tiling(L, 4);
+        rc = launch_h3<EPI_LINEAR>(L, st);
+        if (rc) return rc;
+        ++g_h3_launches;
+    }
+    return ISC_OK;
+}
+
+// Plans the planes of every problem inside the caller's workspace, launches the operand split and the GEMM.
+// Returns 1 when the launch went out on this path (rc = its status), 0 when the path does not apply.
+template <int EPI>
+static int try_h3(DevLaunch &L, float *ws, long long ws_floats, hipStream_t st, int &rc) {
+    if (g_h3_mode == 0 || g_tile_override >= 0 || !ws || ((uintptr_t)ws & 255)) return 0;
+    long long tiles = 0, need = 0;
+    for (int i = 0; i < L.nprob; ++i) {
+        const DevProb &p = L.p[i];
+        if (p.ksplit > 1) return 0;
+        tiles += (long long)((p.M + 127) / 128) * ((p.N + 127) / 128);
+        const long long Kp = h3_kp(p);
+        if (Kp > (1 << 20)) return 0;
+        need += ((long long)p.M + p.N) * Kp + 256;        // floats: 2 planes x 2 bytes per element, both operands
+    }
+    if (g_h3_mode == 1 && tiles < H3_MIN_TILES) return 0;
+    if (need > ws_floats) {
+        if constexpr (EPI != EPI_LINEAR) return 0;
+        long long chunk[3];
+        for (int i = 0; i < L.nprob; ++i) {               // every problem must chunk usefully before anything is launched
+            const DevProb &p = L.p[i];
+            const long long Kp = h3_kp(p);
+            chunk[i] = ((ws_floats - (long long)p.N * Kp - 512) / Kp) & ~127LL;
+            if (chunk[i] < 2048) return 0;
+        }
+        for (int i = 0; i < L.nprob; ++i) {
+            rc = h3_linear_chunked(L.p[i], ws, ws_floats, chunk[i], st);
+            if (rc) return 1;
+        }
+        return 1;
+    }
+    H3Planner pl(ws);
+    for (int i = 0; i < L.nprob; ++i) {
+        DevProb &p = L.p[i];
+        p.Kp = h3_kp(p);
+        int same = -1;                                   // problems of one launch often share their activations
+        for (int j = 0; j < i && same < 0; ++j) {
+            const DevProb &o = L.p[j];
+            bool eq = o.nseg == p.nseg && o.M == p.M;
+            for (int s = 0; eq && s < p.nseg; ++s)
+                eq = o.seg[s].A == p.seg[s].A && o.seg[s].lda == p.seg[s].lda && o.seg[s].K == p.seg[s].K;
+            if (eq) same = j;
+        }
+        if (same >= 0) { p.Ah = L.p[same].Ah; p.Al = L.p[same].Al; }
+        else pl.add(p, false, p.M, p.Ah, p.Al);
+        pl.add(p, true, p.N, p.Wh, p.Wl);
+    }
+    rc = pl.launch(st);
+    if (rc) return 1;
+    finish_tiling(L, 4);
+    rc = launch_h3<EPI>(L, st);
+    ++g_h3_launches;
+    return 1;
+}
+
 // Split-K plan for launches with too few tiles to occupy the chip (small M): every workgroup would
 // otherwise walk the whole contraction serially (~0.8 us per 32-deep chunk).  Returns the split count
 // (1 = no split) and carves one [S, M, N] slab region per problem out of the caller's workspace.
@@ -1514,9 +1836,11 @@ extern "C" int isc_linear_fwd(const isc_linear_problem *pr, int n_prob, void *st
         d.ldc = q.ldc; d.C = q.C; d.C_pre = q.C_pre; d.accumulate = q.accumulate;
     }
     const int S = plan_splitk(L, pr[0].splitk_ws, pr[0].splitk_ws_floats);
+    int rc = ISC_OK;
+    if (S == 1 && try_h3<EPI_LINEAR>(L, pr[0].splitk_ws, pr[0].splitk_ws_floats, (hipStream_t)stream, rc)) return rc;
     const int tile = S > 1 ? 2 : pick_tile(L, true);
     finish_tiling(L, tile);
-    int rc = launch_any<EPI_LINEAR, false, false>(L, tile, (hipStream_t)stream);
+    rc = launch_any<EPI_LINEAR, false, false>(L, tile, (hipStream_t)stream);
     if (rc || S == 1) return rc;
     return launch_splitk_linear_reduce(L, (hipStream_t)stream);
 }
@@ -1588,6 +1912,7 @@ extern "C" int isc_lstm_fwd(const isc_lstm_problem *q, void *stream) {
     // epilogue reads per output, which the XL tile's lone workgroup per CU cannot overlap with MFMA work
     // (in the roll-out: att-LSTM 168 us on the 128x128 tile vs 178 us on XL; lang-LSTM 223 vs 206; with the
     // batched epilogue loads of lstm_cells the two are within 2 % of each other on either cell)
+    if (try_h3<EPI_LSTM>(L, q->splitk_ws, q->splitk_ws_floats, (hipStream_t)stream, rc)) return rc;
     const int tile = pick_tile(L, !q->pre && !q->tab, true, true);
     finish_tiling(L, tile);
     return launch_any<EPI_LSTM, false, false>(L, tile, (hipStream_t)stream);
@@ -1625,6 +1950,7 @@ extern "C" int isc_vocab_fwd(const float *h, int ldh, const float *W, int ldw, c
     // The vocabulary projection runs on the 128x128 LDS-DMA tile: at [4096 x 10000 x 512] 121 TFLOP/s there, 115 on
     // the register-staged 128x128 tile and 108 on XL, whose lone workgroup per CU has nothing to hide the per-row
     // softmax statistics of the epilogue behind (3k VALU instructions per wave at the end of a 16-chunk tile).
+    if (try_h3<EPI_VOCAB>(L, splitk_ws, splitk_ws_floats, (hipStream_t)stream, rc)) return rc;
     const int tile = pick_tile(L, false, true, true);
     finish_tiling(L, tile);
     return launch_any<EPI_VOCAB, false, false>(L, tile, (hipStream_t)stream);

@@ -28,6 +28,7 @@ class KernelTimer:
             return None
         e = torch.cuda.Event(enable_timing=True)
         e.record()
+        self._h3_before = _lib.load().isc_h3_launches()
         return e
 
     def end(self, e0, name, flops=0.0, nbytes=0.0):
@@ -35,13 +36,14 @@ class KernelTimer:
             return
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
-        self.records.append((name, e0, e1, flops, nbytes, self.phase))
+        h3 = _lib.load().isc_h3_launches() != self._h3_before     # the op went out on the split-f16 GEMM path
+        self.records.append((name, e0, e1, flops, nbytes, self.phase, h3))
 
     def summary(self):
         """name -> dict(n, avg_ms, flops, bytes); call after a device synchronize."""
         out = {}
-        for name, e0, e1, fl, nb, ph in self.records:
-            d = out.setdefault(name, dict(n=0, total_ms=0.0, flops=fl, bytes=nb, phase=ph))
+        for name, e0, e1, fl, nb, ph, h3 in self.records:
+            d = out.setdefault(name, dict(n=0, total_ms=0.0, flops=fl, bytes=nb, phase=ph, h3=h3))
             d['n'] += 1
             d['total_ms'] += e0.elapsed_time(e1)
         for d in out.values():
@@ -57,7 +59,8 @@ def _seg_k(segs):
 
 
 _SPLITK_WS = {}
-SPLITK_WS_FLOATS = 16 * 1024 * 1024     # 64 MB per device: [ksplit, M, N] partial slabs of small-M GEMMs
+SPLITK_WS_FLOATS = 32 * 1024 * 1024     # 128 MB per device and stream: [ksplit, M, N] partial slabs of small-M GEMMs,
+                                        # or the f16 operand planes of the split-f16 path
 
 
 WS_OVERRIDE = None      # set while a HIP graph is being captured: the graph owns its workspace
@@ -116,6 +119,12 @@ def _fill_segs(dst, segs):
 def set_tile_override(tile):
     """Force the GEMM tile shape (0..3, see include/insenticap_hip.h) or -1 for the cost model; returns the previous value."""
     return _lib.load().isc_set_tile_override(int(tile))
+
+
+def set_h3_mode(mode):
+    """Split-f16 GEMM path: 0 = off, 1 = auto (default), 2 = whenever shapes allow (include/insenticap_hip.h);
+    returns the previous mode."""
+    return _lib.load().isc_set_h3_mode(int(mode))
 
 
 def linear_problem(segs, out, bias0=None, bias1=None, bias2=None, relu=False, keep_mask=None, mask_scale=1.0,

@@ -1,0 +1,222 @@
+"""Split-f16 GEMM path (gemm_h3_kernel, include/insenticap_hip.h: isc_set_h3_mode): fp32 operands split into two
+f16 planes each, three f16 MFMAs per k-step, fp32 accumulators.  Checked here: it stays an fp32-accurate path - its
+error against an fp64 contraction is no larger than that of the fp32 MFMA tiles on the same inputs - through every
+fused epilogue (linear, LSTM cell, vocabulary statistics), on ragged shapes, K-segments and grouped launches, and the
+auto mode takes it only for large launches."""
+import numpy as np
+import pytest
+import torch
+
+from insenticap_model_amd import ops
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _restore():
+    yield
+    ops.set_h3_mode(1)
+    ops.set_tile_override(-1)
+
+
+def dev():
+    return torch.device('cuda:0')
+
+
+def _rand(g, *shape, scale=1.0):
+    return (torch.rand(*shape, generator=g) * 2 - 1) * scale
+
+
+def _err(out, ref):
+    d = (out.double().cpu() - ref).abs()
+    return d.max().item(), d.pow(2).mean().sqrt().item()
+
+
+@pytest.mark.parametrize('M,N,K1,K2', [(512, 256, 64, 0), (1000, 520, 512, 96), (777, 128, 2048, 0), (4096, 512, 512, 512)])
+def test_linear_h3_vs_fp32_tiles(M, N, K1, K2):
+    g = torch.Generator().manual_seed(M + N)
+    x1, w1, b = _rand(g, M, K1), _rand(g, N, K1, scale=K1 ** -0.5), _rand(g, N)
+    keep = (torch.rand(M, N, generator=g) > 0.5).to(torch.uint8)
+    prior = _rand(g, M, N)
+    ref = x1.double() @ w1.double().t() + b.double() + prior.double()
+    segs = [(x1.to(dev()), w1.to(dev()))]
+    if K2:
+        x2, w2 = _rand(g, M, K2), _rand(g, N, K2, scale=K2 ** -0.5)
+        ref = ref + x2.double() @ w2.double().t()
+        segs.append((x2.to(dev()), w2.to(dev())))
+    ref_pre = torch.relu(ref)
+    ref_out = ref_pre * keep.double() * 2.0
+    db, dkeep = b.to(dev()), keep.to(dev())
+    errs = {}
+    for mode in (0, 2):
+        ops.set_h3_mode(mode)
+        out = prior.clone().to(dev())
+        pre = torch.full((M, N), float('nan'), device=dev())
+        ops.linear_fwd([ops.linear_problem(segs, out, db, relu=True, keep_mask=dkeep,
+                                           mask_scale=2.0, out_pre=pre, accumulate=True)])
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(out.cpu().numpy(), ref_out.float().numpy(), atol=3e-5, rtol=1e-5)
+        np.testing.assert_allclose(pre.cpu().numpy(), ref_pre.float().numpy(), atol=3e-5, rtol=1e-5)
+        errs[mode] = _err(pre, ref_pre)
+    # fp32-accurate: no worse than the fp32 MFMA chain (both are dominated by the final fp32 rounding of the output)
+    assert errs[2][1] <= errs[0][1] * 1.05 + 1e-9, errs
+    assert errs[2][0] <= errs[0][0] * 1.5 + 1e-8, errs
+
+
+def test_linear_grouped_shared_activations():
+    """Three projections of one activation matrix in one launch (the roll-out's h2att / h2word / gate launch): the
+    activation planes are built once and shared."""
+    g = torch.Generator().manual_seed(11)
+    M, K = 1500, 512
+    x = _rand(g, M, K)
+    ws = [_rand(g, n, K, scale=K ** -0.5) for n in (512, 512, 384)]
+    bs = [_rand(g, n) for n in (512, 512, 384)]
+    dx = x.to(dev())
+    dws, dbs = [w.to(dev()) for w in ws], [b.to(dev()) for b in bs]
+    outs = {}
+    for mode in (0, 2):
+        ops.set_h3_mode(mode)
+        o = [torch.empty(M, w.shape[0], device=dev()) for w in ws]
+        ops.linear_fwd([ops.linear_problem([(dx, w)], oo, b) for w, oo, b in zip(dws, o, dbs)])
+        torch.cuda.synchronize()
+        outs[mode] = o
+    for w, b, o0, o2 in zip(ws, bs, outs[0], outs[2]):
+        ref = x.double() @ w.double().t() + b.double()
+        e0, e2 = _err(o0, ref), _err(o2, ref)
+        assert e2[0] < 3e-6 and e2[1] <= e0[1] * 1.05 + 1e-9, (e0, e2)
+
+
+@pytest.mark.parametrize('M,H,with_pre,with_tab', [(700, 64, True, False), (1024, 512, False, False),
+                                                   (4096, 512, True, True)])
+def test_lstm_h3(M, H, with_pre, with_tab):
+    g = torch.Generator().manual_seed(M + H)
+    ks = (H, 2 * H, 32)
+    xs = [_rand(g, M, k) for k in ks]
+    ws = [_rand(g, 4 * H, k, scale=(3 * k) ** -0.5) for k in ks]
+    b_ih, b_hh, c0 = _rand(g, 4 * H), _rand(g, 4 * H), _rand(g, M, H)
+    pre = _rand(g, M, 4 * H, scale=0.3) if with_pre else None
+    z = sum(x.double() @ w.double().t() for x, w in zip(xs, ws)) + b_ih.double() + b_hh.double()
+    kw = {}
+    keep = []
+    if with_pre:
+        z = z + pre.double()
+        kw['pre'] = pre.to(dev())
+    if with_tab:
+        tab = _rand(g, 50, 4 * H, scale=0.3)
+        ids = torch.randint(0, 50, (M,), generator=g)
+        z = z + tab.double()[ids]
+        kw['tab'], kw['tab_ids'] = tab.to(dev()), ids.to(dev())
+    i, f, gg, o = z.split(H, dim=1)
+    c_ref = torch.sigmoid(f) * c0.double() + torch.sigmoid(i) * torch.tanh(gg)
+    h_ref = torch.sigmoid(o) * torch.tanh(c_ref)
+    dsegs = [(x.to(dev()), w.to(dev())) for x, w in zip(xs, ws)]
+    dargs = [v.to(dev()) for v in (b_ih, b_hh, c0)]
+    errs = {}
+    for mode in (0, 2):
+        ops.set_h3_mode(mode)
+        h, c = torch.empty(M, H, device=dev()), torch.empty(M, H, device=dev())
+        gates = torch.empty(M, 4 * H, device=dev())
+        ops.lstm_fwd(dsegs, dargs[0], dargs[1], dargs[2], h, c, gates_out=gates, **kw)
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(h.cpu().numpy(), h_ref.float().numpy(), atol=2e-5)
+        np.testing.assert_allclose(c.cpu().numpy(), c_ref.float().numpy(), atol=2e-5)
+        errs[mode] = _err(h, h_ref) + _err(c, c_ref)
+    # the cell's hardware exp / rcp dominate both; the contraction must not add to it
+    assert errs[2][1] <= errs[0][1] * 1.1 + 1e-9 and errs[2][3] <= errs[0][3] * 1.1 + 1e-9, errs
+
+
+@pytest.mark.parametrize('M,V,K', [(520, 1000, 64), (300, 10000, 512), (4096, 10000, 512)])
+def test_vocab_h3(M, V, K):
+    g = torch.Generator().manual_seed(V + M)
+    h, W, bias = _rand(g, M, K), _rand(g, V, K, scale=4 * K ** -0.5), _rand(g, V)
+    logits_ref = h.double() @ W.double().t() + bias.double()
+    lse_ref = torch.logsumexp(logits_ref, 1)
+    nt = (V + 127) // 128
+    dh, dW, dbias = h.to(dev()), W.to(dev()), bias.to(dev())
+    errs, args = {}, {}
+    for mode in (0, 2):
+        ops.set_h3_mode(mode)
+        pm, ps = torch.empty(M, nt, device=dev()), torch.empty(M, nt, device=dev())
+        pi = torch.empty(M, nt, device=dev(), dtype=torch.int32)
+        logits = torch.empty(M, V, device=dev())
+        ops.vocab_fwd(dh, dW, dbias, pm, ps, pi, logits)
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(logits.cpu().numpy(), logits_ref.float().numpy(), atol=3e-5, rtol=1e-5)
+        mx = pm.max(1).values
+        lse = mx + torch.log((ps * torch.exp(pm - mx[:, None])).sum(1))
+        np.testing.assert_allclose(lse.cpu().numpy(), lse_ref.float().numpy(), atol=3e-5, rtol=1e-5)
+        col = pm.argmax(1)
+        arg = pi.gather(1, col[:, None]).squeeze(1).long()
+        assert torch.equal(arg, logits.argmax(1))           # statistics consistent with the logits written
+        errs[mode] = _err(logits, logits_ref)
+        args[mode] = arg.cpu()
+    assert errs[2][1] <= errs[0][1] * 1.05 + 1e-9 and errs[2][0] <= errs[0][0] * 1.5 + 1e-8, errs
+    # arg-max against fp64: the split path may only differ where fp64 itself has a near-tie
+    ref_arg = logits_ref.argmax(1)
+    for mode in (0, 2):
+        bad = (args[mode] != ref_arg).nonzero().flatten()
+        for r in bad.tolist():
+            top2 = logits_ref[r].topk(2).values
+            assert (top2[0] - top2[1]).item() < 1e-5, (mode, r, top2)
+
+
+def test_h3_wide_dynamic_range_and_tiny_values():
+    """Values far below the f16 normal range keep their fp32 accuracy (the lo plane carries the residual scaled by
+    2^11), and large-but-legal magnitudes do not overflow."""
+    g = torch.Generator().manual_seed(3)
+    M, N, K = 2048, 1024, 256          # large enough not to take the split-K route
+    x = _rand(g, M, K) * torch.pow(10.0, torch.randint(-7, 4, (M, K), generator=g).float())
+    w = _rand(g, N, K) * torch.pow(10.0, torch.randint(-7, 1, (N, K), generator=g).float())
+    ref = x.double() @ w.double().t()
+    scale = (x.double().abs() @ w.double().abs().t())         # error is relative to sum |a||b|
+    dx, dw = x.to(dev()), w.to(dev())
+    rel = {}
+    for mode in (0, 2):
+        ops.set_h3_mode(mode)
+        out = torch.empty(M, N, device=dev())
+        ops.linear_fwd([ops.linear_problem([(dx, dw)], out)])
+        torch.cuda.synchronize()
+        assert torch.isfinite(out).all()
+        rel[mode] = ((out.double().cpu() - ref).abs() / scale).max().item()
+    assert rel[2] < 2e-6 and rel[2] <= rel[0] * 1.5 + 1e-9, rel
+
+
+def test_auto_mode_only_takes_large_launches():
+    """mode 1 (default): a small launch stays bit-identical to the fp32 tiles, a large one matches the forced path."""
+    g = torch.Generator().manual_seed(9)
+
+    def run(M, N, K, mode):
+        gg = torch.Generator().manual_seed(M)
+        x, w = _rand(gg, M, K).to(dev()), _rand(gg, N, K, scale=K ** -0.5).to(dev())
+        ops.set_h3_mode(mode)
+        out = torch.empty(M, N, device=dev())
+        ops.linear_fwd([ops.linear_problem([(x, w)], out)])
+        torch.cuda.synchronize()
+        return out.cpu()
+    assert torch.equal(run(256, 512, 128, 1), run(256, 512, 128, 0))
+    big_auto, big_force, big_off = run(4096, 1024, 256, 1), run(4096, 1024, 256, 2), run(4096, 1024, 256, 0)
+    assert torch.equal(big_auto, big_force)
+    assert not torch.equal(big_auto, big_off)                  # a different summation order, same accuracy class
+    assert (big_auto - big_off).abs().max().item() < 5e-6
+
+
+def test_linear_larger_than_workspace_goes_in_row_chunks():
+    """Planes of 40000 x 1024 activations exceed the 128 MB workspace: the launch is cut into row chunks, with
+    accumulate / keep-mask / pre-activation outputs following the chunk offsets."""
+    g = torch.Generator().manual_seed(21)
+    M, N, K = 40000, 256, 1024
+    x, w, b = _rand(g, M, K), _rand(g, N, K, scale=K ** -0.5), _rand(g, N)
+    keep = (torch.rand(M, N, generator=g) > 0.3).to(torch.uint8)
+    prior = _rand(g, M, N)
+    ref_pre = torch.relu(x.double() @ w.double().t() + b.double() + prior.double())
+    ref_out = ref_pre * keep.double() * 1.5
+    dx, dw, db, dkeep = x.to(dev()), w.to(dev()), b.to(dev()), keep.to(dev())
+    before = ops._lib.load().isc_h3_launches()
+    out = prior.clone().to(dev())
+    pre = torch.full((M, N), float('nan'), device=dev())
+    ops.linear_fwd([ops.linear_problem([(dx, dw)], out, db, relu=True, keep_mask=dkeep, mask_scale=1.5,
+                                       out_pre=pre, accumulate=True)])
+    torch.cuda.synchronize()
+    assert ops._lib.load().isc_h3_launches() - before >= 2         # more than one chunk
+    np.testing.assert_allclose(pre.cpu().numpy(), ref_pre.float().numpy(), atol=3e-5, rtol=1e-5)
+    np.testing.assert_allclose(out.cpu().numpy(), ref_out.float().numpy(), atol=3e-5, rtol=1e-5)
