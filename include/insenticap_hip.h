@@ -55,6 +55,14 @@ int isc_set_tile_override(int tile);
 int isc_set_h3_mode(int mode);
 /* Number of launches that went out on the split-f16 path so far (process-wide; measurement / test hook). */
 long long isc_h3_launches(void);
+/* Weights scope of the split-f16 path.  Between _begin and _end the caller guarantees that no weight matrix passed
+ * to the forward entry points changes (a roll-out's decode loop): each weight operand is then split into its planes
+ * once, into `buf` (device memory, 256-byte aligned; 64 MB holds the decoder's matrices), and later launches with
+ * the same weight segments reuse them instead of re-splitting per step.  Launches inside the scope must be issued in
+ * one stream order.  Without a scope, or when `buf` is full, every launch splits its weights into the workspace.
+ * _begin discards earlier entries; _end closes the scope (`buf` may then be reused). */
+int isc_h3_weights_begin(void *buf, long long bytes);
+int isc_h3_weights_end(void);
 
 /* One K-segment of a contraction: acc += A[M,K] * W[N,K]^T.  Replaces the
  * torch.cat([...],1) + nn.Linear / nn.LSTMCell pattern of captioner.py:174-175,180-181. */

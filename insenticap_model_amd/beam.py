@@ -168,24 +168,25 @@ def beam_search_batch(cap, fc_feats, att_feats, senti_words, senti_labels, beam,
     ctrl_np = ctrl_h.numpy()
     ctrl_np[0, :] = cap.sos_id
     ctrl_d = ctrl_h.to(dev, non_blocking=True)
-    for t in range(T):
-        cap.last_beam_steps = t + 1
-        last_d = ctrl_d[0]
-        h_cur, c_cur, h_nxt, c_nxt = st_cur[0], st_cur[1], st_nxt[0], st_nxt[1]
-        if Pb.tab is None:
-            ops.embed_relu_fwd(emb, last_d, xt)
-        cap._step(p, Pb, ws, xt, h_cur, c_cur, h_nxt, c_nxt, logits=logits, tok=last_d)
-        ops.beam_topk(logits, ws['pmax'], ws['psum'], last_d, beam, cap.pad_id, cap.sos_id, cap.unk_id,
-                      mask_special, decoding_constraint, top_val, top_idx)
-        hb = top_buf.cpu().numpy()        # the single host read of this step
-        ti = hb[:nk * 8].view(np.int64).reshape(rows, beam)
-        tv = hb[nk * 8:].view(np.float32).reshape(rows, beam)
-        # new state of row r = stepped ? nxt[parent] : cur[parent]  ==  [nxt ; cur][parent + (stepped ? 0 : rows)]
-        any_live = merge.step(t, ti, tv, ctrl_np[0], ctrl_np[1])
-        if not any_live:
-            break
-        ctrl_d = ctrl_h.to(dev, non_blocking=True)
-        st_cur = torch.cat([st_nxt, st_cur], dim=2).index_select(2, ctrl_d[1])
+    with ops.h3_weights_scope(dev):               # frozen weights: their f16 planes are built once per search
+        for t in range(T):
+            cap.last_beam_steps = t + 1
+            last_d = ctrl_d[0]
+            h_cur, c_cur, h_nxt, c_nxt = st_cur[0], st_cur[1], st_nxt[0], st_nxt[1]
+            if Pb.tab is None:
+                ops.embed_relu_fwd(emb, last_d, xt)
+            cap._step(p, Pb, ws, xt, h_cur, c_cur, h_nxt, c_nxt, logits=logits, tok=last_d)
+            ops.beam_topk(logits, ws['pmax'], ws['psum'], last_d, beam, cap.pad_id, cap.sos_id, cap.unk_id,
+                          mask_special, decoding_constraint, top_val, top_idx)
+            hb = top_buf.cpu().numpy()        # the single host read of this step
+            ti = hb[:nk * 8].view(np.int64).reshape(rows, beam)
+            tv = hb[nk * 8:].view(np.float32).reshape(rows, beam)
+            # new state of row r = stepped ? nxt[parent] : cur[parent]  ==  [nxt ; cur][parent + (stepped ? 0 : rows)]
+            any_live = merge.step(t, ti, tv, ctrl_np[0], ctrl_np[1])
+            if not any_live:
+                break
+            ctrl_d = ctrl_h.to(dev, non_blocking=True)
+            st_cur = torch.cat([st_nxt, st_cur], dim=2).index_select(2, ctrl_d[1])
     cap.cont_weights, cap.senti_weights, cap.cont_senti_weights = [], [], []
     captions, scores, ids = [], [], []
     for i, cands in enumerate(merge.result()):

@@ -623,16 +623,17 @@ class Captioner(nn.Module):
         rs.seq, rs.seq_logprobs, rs.seq_masks = seq.data_ptr(), seq_logprobs.data_ptr(), seq_masks.data_ptr()
         rs.unfinished, rs.alive, rs.raw_tokens = unfinished.data_ptr(), alive.data_ptr(), raw.data_ptr()
         rs.emb, rs.xt_add = emb.data_ptr(), None      # the label term lives in P.pre1
-        for t in range(T):
-            cur, nxt = t & 1, (t + 1) & 1
-            om, osc = mask_for('out%d' % t, B, H)
-            ops.TIMER.armed = (arm == t)
-            # token fed at step t: <SOS>, then seq[:, t-1] (= it * unfinished, written by finalize)
-            self._step(p, P, ws, xt[cur], h[cur], c[cur], h[nxt], c[nxt], aC[:, t], aS[:, t], bG[:, t:t + 1],
-                       logits, om, osc, tok=(sos if t == 0 else seq[:, t - 1]) if use_tab else None)
-            rs.t = t
-            rs.xt_next = None if use_tab else xt[nxt].data_ptr()
-            ops.rollout_finalize(rs)
+        with ops.h3_weights_scope(self._dev):      # frozen weights for the whole loop: split them once, not per step
+            for t in range(T):
+                cur, nxt = t & 1, (t + 1) & 1
+                om, osc = mask_for('out%d' % t, B, H)
+                ops.TIMER.armed = (arm == t)
+                # token fed at step t: <SOS>, then seq[:, t-1] (= it * unfinished, written by finalize)
+                self._step(p, P, ws, xt[cur], h[cur], c[cur], h[nxt], c[nxt], aC[:, t], aS[:, t], bG[:, t:t + 1],
+                           logits, om, osc, tok=(sos if t == 0 else seq[:, t - 1]) if use_tab else None)
+                rs.t = t
+                rs.xt_next = None if use_tab else xt[nxt].data_ptr()
+                ops.rollout_finalize(rs)
         ops.TIMER.armed = False
         # no host read: the executed-step count stays on the device (`alive`) until someone needs it
         self._set_weights(aC, aS, bG, alive)

@@ -1179,6 +1179,128 @@ __global__ __launch_bounds__(256, 2) void gemm_h3_kernel(const DevLaunch L) {
     }
 }
 
+// H3 on the 64 x 128 geometry (2 x 2 waves, 32 x 64 accumulators each; linear epilogue): launches whose 128-row
+// tiling would leave CUs idle - the per-step projections with N = 512 at 4096 rows are 256 tiles of 64 x 128.
+// Per chunk: A planes 2 x 4 KB, W planes 2 x 8 KB; four buffers = 96 KB, one workgroup per CU.
+__global__ __launch_bounds__(256) void gemm_h3m_kernel(const DevLaunch L) {
+    constexpr int TN = 2;
+    constexpr int PA = 64 * 64, PB = 128 * 64;          // bytes per A / W plane tile
+    constexpr int ST = 2 * PA + 2 * PB;                 // bytes per buffer
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char *lds = reinterpret_cast<char *>(smem);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = tid >> 6, wm = w >> 1, wn = w & 1;
+    int pi, tm, tn, ks, ksplit;
+    map_tile(L, pi, tm, tn, ks, ksplit);
+    const DevProb &P = L.p[pi];
+    const int M = P.M, N = P.N, Kp = P.Kp;
+    const int row0 = tm * 64, col0 = tn * 128;
+
+    // staging pieces of 16 rows x 64 B: A planes one piece per wave, W planes two
+    const _Float16 *src[6];
+    {
+        const int t = 16 * w + (lane >> 2);
+        const int q = (lane & 3) ^ ((t >> 2) & 3);
+        int ar = row0 + t;
+        ar = ar < M ? ar : M - 1;
+        src[0] = P.Ah + (long long)ar * Kp + q * 8;
+        src[1] = P.Al + (long long)ar * Kp + q * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int t = 16 * (2 * w + i) + (lane >> 2);
+        const int q = (lane & 3) ^ ((t >> 2) & 3);
+        int c = col0 + t;
+        c = c < N ? c : N - 1;
+        src[2 + i] = P.Wh + (long long)c * Kp + q * 8;
+        src[4 + i] = P.Wl + (long long)c * Kp + q * 8;
+    }
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds);
+    const unsigned wv = __builtin_amdgcn_readfirstlane((unsigned)w);
+    auto dma1 = [&](unsigned dst, const _Float16 *&p) __attribute__((always_inline)) {
+        asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(dst), "v"(p) : "memory");
+        p += 32;
+    };
+    auto stage = [&](int buf) __attribute__((always_inline)) {
+        const unsigned b = lds0 + buf * ST;
+        dma1(b + wv * 1024, src[0]);
+        dma1(b + PA + wv * 1024, src[1]);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            dma1(b + 2 * PA + (2 * wv + i) * 1024, src[2 + i]);
+            dma1(b + 2 * PA + PB + (2 * wv + i) * 1024, src[4 + i]);
+        }
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+
+    f32x16 acc0[TN], acc1[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[j][r] = 0.f; acc1[j][r] = 0.f; }
+
+    const int fr = lane & 31, fh = lane >> 5, fsw = (fr >> 2) & 3;
+    h8 a1[2], a2[2], b1[2][TN], b2[2][TN];
+    auto lfrag = [&](int buf, auto ksc, auto setc) __attribute__((always_inline)) {
+        constexpr int kk = decltype(ksc)::value, S = decltype(setc)::value;
+        const int slot = ((2 * kk + fh) ^ fsw) * 16;
+        const char *base = lds + buf * ST;
+        const int ra = (wm * 32 + fr) * 64 + slot;
+        a1[S] = *reinterpret_cast<const h8 *>(base + ra);
+        a2[S] = *reinterpret_cast<const h8 *>(base + PA + ra);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int rb = (wn * 64 + j * 32 + fr) * 64 + slot;
+            b1[S][j] = *reinterpret_cast<const h8 *>(base + 2 * PA + rb);
+            b2[S][j] = *reinterpret_cast<const h8 *>(base + 2 * PA + PB + rb);
+        }
+    };
+    auto mma = [&](auto setc) __attribute__((always_inline)) {
+        constexpr int S = decltype(setc)::value;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            acc0[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[S], b1[S][j], acc0[j], 0, 0, 0);
+            acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[S], b2[S][j], acc1[j], 0, 0, 0);
+            acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2[S], b1[S][j], acc1[j], 0, 0, 0);
+        }
+    };
+    // four buffers, three chunks in flight: these launches run one workgroup per CU, so the DMA round trip
+    // (~1 us) has to be covered by the workgroup's own prefetch depth, not by a neighbour
+    const int nchunks = Kp / 32;
+    auto wait_for = [&](int in_flight) __attribute__((always_inline)) {   // stages that may still be outstanding
+        if (in_flight >= 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else if (in_flight == 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    stage(0);
+    if (nchunks > 1) stage(1);
+    if (nchunks > 2) stage(2);
+    wait_for((nchunks < 3 ? nchunks : 3) - 1);
+    __syncthreads();
+    lfrag(0, I0{}, I0{});
+    for (int c = 0; c < nchunks; ++c) {
+        const int cur = c & 3, nxt = (c + 1) & 3;
+        if (c + 3 < nchunks) stage((c + 3) & 3);      // that buffer was last read in front of the previous barrier
+        lfrag(cur, I1{}, I1{});
+        mma(I0{});
+        if (c + 1 < nchunks) {
+            const int last = nchunks - 1 < c + 3 ? nchunks - 1 : c + 3;
+            wait_for(last - (c + 1));
+            __syncthreads();
+            lfrag(nxt, I0{}, I0{});
+        }
+        mma(I1{});
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc0[j][r] = fmaf(acc1[j][r], 1.f / 2048.f, acc0[j][r]);
+    epi_linear_frag<TN>(P, acc0, wm * 32, wn * 64, lane, row0, col0);
+}
+
 // Operand split in front of gemm_h3_kernel: gathers the K-segments of one operand into the two packed f16 planes
 // [rows, Kp].  One thread per 8 consecutive k (two float4 loads, one 16-byte store per plane).
 struct SplitJob {
@@ -1650,6 +1772,66 @@ static int launch_h3(const DevLaunch &L, hipStream_t st) {
     return ISC_OK;
 }
 
+static int h3_kp(const DevProb &p) {
+    int Kp = 0;
+    for (int s = 0; s < p.nseg; ++s) Kp += p.seg[s].K;
+    return Kp;
+}
+
+// Weight planes kept across launches while the caller guarantees the weights do not change
+// (isc_h3_weights_begin / _end, include/insenticap_hip.h): a roll-out splits each weight matrix once, not once
+// per step.  Host-side table, valid on the stream order of the launches that filled it.
+struct H3WEntry {
+    const float *W[ISC_MAX_SEG];
+    int ldw[ISC_MAX_SEG], K[ISC_MAX_SEG], nseg, rows;
+    const _Float16 *hi, *lo;
+};
+static struct {
+    char *buf = nullptr;
+    size_t bytes = 0, used = 0;
+    H3WEntry e[24];
+    int n = 0;
+    bool active = false;
+} g_h3w;
+
+extern "C" int isc_h3_weights_begin(void *buf, long long bytes) {
+    if (!buf || bytes <= 0) return ISC_E_NULL;
+    if ((uintptr_t)buf & 255) return ISC_E_ALIGN;
+    g_h3w.buf = static_cast<char *>(buf); g_h3w.bytes = (size_t)bytes; g_h3w.used = 0; g_h3w.n = 0;
+    g_h3w.active = true;
+    return ISC_OK;
+}
+extern "C" int isc_h3_weights_end(void) {
+    g_h3w.active = false; g_h3w.n = 0; g_h3w.used = 0; g_h3w.buf = nullptr;
+    return ISC_OK;
+}
+
+static const H3WEntry *h3w_find(const DevProb &p) {
+    if (!g_h3w.active) return nullptr;
+    for (int i = 0; i < g_h3w.n; ++i) {
+        const H3WEntry &e = g_h3w.e[i];
+        bool eq = e.nseg == p.nseg && e.rows == p.N;
+        for (int s = 0; eq && s < p.nseg; ++s)
+            eq = e.W[s] == p.seg[s].W && e.ldw[s] == p.seg[s].ldw && e.K[s] == p.seg[s].K;
+        if (eq) return &e;
+    }
+    return nullptr;
+}
+
+static int launch_h3m(const DevLaunch &L, hipStream_t st) {
+    constexpr size_t lds = 4 * (2 * 64 * 64 + 2 * 128 * 64);             // 98304: one workgroup per CU
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_h3m_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(gemm_h3m_kernel, dim3(L.total_tiles), dim3(256), lds, st, L);
+    ISC_LAUNCH_CHECK();
+    return ISC_OK;
+}
+
 // Operand-split jobs of one launch: add() lays the planes of an operand out in the workspace and queues its job.
 struct H3Planner {
     SplitLaunch S = {};
@@ -1672,6 +1854,23 @@ struct H3Planner {
         hi = J.hi; lo = J.lo;
         blocks += (int)(((long long)rows * (k0 >> 3) + 255) / 256);
     }
+    // weight operand: cached planes if the caller opened a weights scope, else planes in the workspace
+    void add_w(const DevProb &p, const _Float16 *&hi, const _Float16 *&lo) {
+        if (const H3WEntry *e = h3w_find(p)) { hi = e->hi; lo = e->lo; return; }
+        const size_t bytes = (((size_t)p.N * h3_kp(p) * 2) + 255) & ~(size_t)255;
+        if (g_h3w.active && g_h3w.n < 24 && g_h3w.used + 2 * bytes <= g_h3w.bytes) {
+            char *keep = at;
+            at = g_h3w.buf + g_h3w.used;
+            add(p, true, p.N, hi, lo);
+            at = keep;
+            g_h3w.used += 2 * bytes;
+            H3WEntry &e = g_h3w.e[g_h3w.n++];
+            e.nseg = p.nseg; e.rows = p.N; e.hi = hi; e.lo = lo;
+            for (int s = 0; s < p.nseg; ++s) { e.W[s] = p.seg[s].W; e.ldw[s] = p.seg[s].ldw; e.K[s] = p.seg[s].K; }
+            return;
+        }
+        add(p, true, p.N, hi, lo);
+    }
     int launch(hipStream_t st) {
         if (!S.njobs) return ISC_OK;
         hipLaunchKernelGGL(h3_split_kernel, dim3(blocks), dim3(256), 0, st, S);
@@ -1679,12 +1878,6 @@ struct H3Planner {
         return ISC_OK;
     }
 };
-
-static int h3_kp(const DevProb &p) {
-    int Kp = 0;
-    for (int s = 0; s < p.nseg; ++s) Kp += p.seg[s].K;
-    return Kp;
-}
 
 // A linear problem whose planes do not fit the workspace (the prologue's region projections: 147456 rows) goes
 // through it in row chunks: split chunk -> GEMM chunk -> next.  A chunk's planes (<= the workspace, 128 MB) are
@@ -1706,7 +1899,7 @@ static int h3_linear_chunked(const DevProb &p0, float *ws, long long ws_floats, 
         const _Float16 *wh, *wl;
         pl.add(p0, true, p0.N, wh, wl);              // same place every chunk; only the first chunk's job is launched
         if (r0 != 0) { pl.S.njobs = 0; pl.blocks = 0; }
-        p.Wh = wh; p.Wl = wl;
+        p.Wh = wh; p.Wl = wl;                        // (in the workspace, not the weights scope: used once per call)
         pl.add(p, false, p.M, p.Ah, p.Al);
         int rc = pl.launch(st);
         if (rc) return rc;
@@ -1732,7 +1925,9 @@ static int try_h3(DevLaunch &L, float *ws, long long ws_floats, hipStream_t st, 
         if (Kp > (1 << 20)) return 0;
         need += ((long long)p.M + p.N) * Kp + 256;        // floats: 2 planes x 2 bytes per element, both operands
     }
-    if (g_h3_mode == 1 && tiles < H3_MIN_TILES) return 0;
+    // linear launches that fill less than 1.5 rounds of CUs with 128-row tiles go out on the 64-row H3 tile
+    const bool half_tile = EPI == EPI_LINEAR && tiles < 384;
+    if (g_h3_mode == 1 && tiles < (half_tile ? H3_MIN_TILES / 2 : H3_MIN_TILES)) return 0;
     if (need > ws_floats) {
         if constexpr (EPI != EPI_LINEAR) return 0;
         long long chunk[3];
@@ -1762,12 +1957,17 @@ static int try_h3(DevLaunch &L, float *ws, long long ws_floats, hipStream_t st, 
         }
         if (same >= 0) { p.Ah = L.p[same].Ah; p.Al = L.p[same].Al; }
         else pl.add(p, false, p.M, p.Ah, p.Al);
-        pl.add(p, true, p.N, p.Wh, p.Wl);
+        pl.add_w(p, p.Wh, p.Wl);
     }
     rc = pl.launch(st);
     if (rc) return 1;
-    finish_tiling(L, 4);
-    rc = launch_h3<EPI>(L, st);
+    if (half_tile) {
+        finish_tiling(L, 1);
+        rc = launch_h3m(L, st);
+    } else {
+        finish_tiling(L, 4);
+        rc = launch_h3<EPI>(L, st);
+    }
     ++g_h3_launches;
     return 1;
 }

@@ -127,6 +127,42 @@ def set_h3_mode(mode):
     return _lib.load().isc_set_h3_mode(int(mode))
 
 
+_H3W_BUF = {}
+H3W_BYTES = 64 * 1024 * 1024
+
+
+class h3_weights_scope:
+    """`with ops.h3_weights_scope(device):` - the weights passed to the forward GEMMs do not change inside the block
+    (include/insenticap_hip.h: isc_h3_weights_begin), so their f16 planes are built once per block, not per launch.
+    Launches inside must stay on one stream; nested scopes are ignored (the outer one stays in force)."""
+    _depth = 0
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+
+    def __enter__(self):
+        cls = h3_weights_scope
+        cls._depth += 1
+        if cls._depth == 1 and WS_OVERRIDE is None:       # not while a HIP graph is being captured
+            index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+            key = (index, torch.cuda.current_stream(index).cuda_stream)     # one buffer per stream, as splitk_ws
+            buf = _H3W_BUF.get(key)
+            if buf is None:
+                buf = _H3W_BUF[key] = torch.empty(H3W_BYTES, dtype=torch.uint8, device=self.device)
+            _lib.check(_lib.load().isc_h3_weights_begin(buf.data_ptr(), buf.numel()), 'isc_h3_weights_begin')
+            self.opened = True
+        else:
+            self.opened = False
+        return self
+
+    def __exit__(self, *exc):
+        cls = h3_weights_scope
+        cls._depth -= 1
+        if self.opened:
+            _lib.load().isc_h3_weights_end()
+        return False
+
+
 def linear_problem(segs, out, bias0=None, bias1=None, bias2=None, relu=False, keep_mask=None, mask_scale=1.0,
                    out_pre=None, accumulate=False):
     """out[M,N] = act(sum_s A_s W_s^T + bias0 + bias1) [* keep_mask * mask_scale]."""

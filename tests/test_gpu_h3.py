@@ -220,3 +220,30 @@ def test_linear_larger_than_workspace_goes_in_row_chunks():
     assert ops._lib.load().isc_h3_launches() - before >= 2         # more than one chunk
     np.testing.assert_allclose(pre.cpu().numpy(), ref_pre.float().numpy(), atol=3e-5, rtol=1e-5)
     np.testing.assert_allclose(out.cpu().numpy(), ref_out.float().numpy(), atol=3e-5, rtol=1e-5)
+
+
+def test_weights_scope_reuses_planes_and_ends_cleanly():
+    """Inside ops.h3_weights_scope the weight planes are built once and reused (bit-identical results, and only the
+    first launch carries the weight split); after the scope a changed weight is picked up again."""
+    g = torch.Generator().manual_seed(31)
+    M, N, K = 4096, 1024, 256
+    x, w = _rand(g, M, K).to(dev()), _rand(g, N, K, scale=K ** -0.5).to(dev())
+
+    def run():
+        out = torch.empty(M, N, device=dev())
+        ops.linear_fwd([ops.linear_problem([(x, w)], out)])
+        return out
+    plain = run()
+    with ops.h3_weights_scope(dev()):
+        a, b = run(), run()
+        with ops.h3_weights_scope(dev()):          # nested: ignored
+            c = run()
+    torch.cuda.synchronize()
+    assert torch.equal(plain, a) and torch.equal(a, b) and torch.equal(a, c)
+    w.mul_(2.0)                                     # outside any scope: the next launch splits the new values
+    doubled = run()
+    with ops.h3_weights_scope(dev()):
+        doubled_scoped = run()
+    torch.cuda.synchronize()
+    assert torch.equal(doubled_scoped, doubled)
+    np.testing.assert_allclose(doubled.cpu().numpy(), (plain * 2).cpu().numpy(), rtol=2e-6, atol=1e-6)
