@@ -328,3 +328,38 @@ def test_beam5_batch64_matches_per_image_and_oracle(golden):
             assert caps[i] == list(ocaps), i
         else:
             assert caps[i][0] == ocaps[0] or abs(oscores[0] - oscores[1]) <= 2e-3
+
+
+@pytest.mark.parametrize('mode', [1, 2])
+def test_greedy_b1024_vs_oracle_on_the_split_f16_path(mode):
+    """B=1024 greedy roll-out at full size against the CPU oracle with the split-f16 GEMM path in play (mode 1: the
+    classifier takes it; mode 2: every launch large enough not to be split over K, i.e. both LSTM cells, the
+    projections and the prologue as well).  Token-exact wherever the oracle's own top-1/top-2 margin is above fp32
+    reassociation noise, log-probs within the 1e-4 bound."""
+    cap, c, st, w, _, _ = make_captioner('cfg1')
+    B, Tn = 1024, 20
+    d = synth.make_inputs(B, c['V'], st, regions=36, seq_len=Tn, seed=4242)
+    a = [T(d, k) for k in ('fc_feats', 'att_feats', 'cpt_words', 'senti_words', 'senti_labels')]
+    before = ops._lib.load().isc_h3_launches()
+    prev = ops.set_h3_mode(mode)
+    try:
+        with torch.no_grad():
+            seq, lp, mk = cap(*a, Tn, 1, mode='rl')
+        torch.cuda.synchronize()
+    finally:
+        ops.set_h3_mode(prev)
+    assert ops._lib.load().isc_h3_launches() - before >= Tn * (1 if mode == 1 else 3)
+    O = oracle()
+    p = O.to_params(w)
+    oid = O.Ids(synth.make_idx2word(c['V']), synth.SENTIMENT_CATEGORIES)
+    ca = [torch.from_numpy(np.asarray(d[k])) for k in ('fc_feats', 'att_feats', 'cpt_words', 'senti_words', 'senti_labels')]
+    with torch.no_grad():
+        oseq, olp, omk, _, _, margins = O.forward_rl(p, oid, *ca, Tn, 1)
+    n = trusted_prefix(margins.numpy(), omk.numpy(), 2e-3)
+    assert n.mean() >= 0.8 * Tn
+    seq, lp, mk = seq.cpu().numpy(), lp.cpu().numpy(), mk.cpu().numpy()
+    oseq, olp, omk = oseq.numpy(), olp.numpy(), omk.numpy()
+    for b in range(B):
+        assert (seq[b, :n[b]] == oseq[b, :n[b]]).all(), b
+        assert (mk[b, :n[b]] == omk[b, :n[b]]).all(), b
+        np.testing.assert_allclose(lp[b, :n[b]], olp[b, :n[b]], atol=LOGP_TOL)
