@@ -70,6 +70,11 @@ typedef struct {
     const float *A; /* [M, K] activations, leading dim lda */
     const float *W; /* [N, K] weight slice (row-major, K contiguous), leading dim ldw */
     int32_t lda, ldw, K, _pad;
+    /* Optional (forward entry points, split-f16 path): the f16 planes of A, [M, K] contiguous each, as a producer
+     * wrote them (isc_lstm_problem.h_hi / h_lo): hi = f16(x), lo = f16((x - hi) * 2048).  When present and the launch
+     * takes the split-f16 path, A is read from the planes instead of being split again; `A` must still be valid (the
+     * fp32 tiles read it).  Null = split on the fly. */
+    const void *A_hi, *A_lo;
 } isc_seg;
 
 /* y = act(sum_seg A_s W_s^T + bias0 + bias1) [* keep_mask * mask_scale]
@@ -125,6 +130,7 @@ typedef struct {
     const uint8_t *h_keep_mask; /* [M,H] or null */
     float mask_scale;
     float *hdrop_out;         /* [M,H], required iff h_keep_mask */
+    void *h_hi, *h_lo;        /* optional: f16 planes of h_out ([M,H] each) for consumers' isc_seg.A_hi / A_lo */
     /* Hoisted step-invariant inputs (optional): gates += pre[m,:] + tab[tab_ids[m*tab_ids_stride],:].
      * `pre` [M,4H] holds fc W_fc^T + label W_x^T + b_ih + b_hh computed once per call (b_ih/b_hh may
      * then be null); `tab` [V,4H] = relu(Emb) W_x^T replaces the word-embedding K-segment when the
@@ -144,10 +150,12 @@ int isc_lstm_fwd(const isc_lstm_problem *prob_host, void *stream);
  * the [M,V] logits are only stored when `logits` is non-null (XE / beam / sampling).
  * n_tile = ceil(V/128); part_* are [M, n_tile].  With a split-K workspace (optional, see
  * isc_linear_problem) launches of few rows contract K in parallel slices and a reduce kernel forms the
- * same outputs (V % 4 == 0 required for that route; otherwise the single-pass kernel runs). */
+ * same outputs (V % 4 == 0 required for that route; otherwise the single-pass kernel runs).
+ * h_hi / h_lo (optional): f16 planes of h ([M,K] contiguous, see isc_seg.A_hi). */
 int isc_vocab_fwd(const float *h, int ldh, const float *W, int ldw, const float *bias,
                   int M, int V, int K, float *logits, int64_t ld_logits,
                   float *part_max, float *part_sum, int32_t *part_idx,
+                  const void *h_hi, const void *h_lo,
                   float *splitk_ws, int64_t splitk_ws_floats, void *stream);
 
 /* logp[m, :] = logits[m, :] - logsumexp(row) in place, using the tile statistics.
@@ -287,6 +295,12 @@ typedef struct {
     int32_t *pidx;
     float *splitk_ws;                   /* optional split-K workspace shared by the step's launches */
     int64_t splitk_ws_floats;
+    /* Optional f16 planes of the recurrent state (split-f16 path, see isc_seg.A_hi): [rows,H] each.  The *_prev
+     * planes must hold the split of h1_prev / h2_prev (zeros for a zero state); the step writes the planes of h1 / h2
+     * from the LSTM epilogues, so a roll-out that swaps (prev, next) every step never splits its state again.  All
+     * eight or none. */
+    const void *h1_prev_hi, *h1_prev_lo, *h2_prev_hi, *h2_prev_lo;
+    void *h1_hi, *h1_lo, *h2_hi, *h2_lo;
 } isc_step_plan;
 
 int isc_step_fwd(const isc_step_plan *plan_host, void *stream);

@@ -17,7 +17,7 @@ c_f32p = C.c_void_p  # device pointers travel as integers
 
 class Seg(C.Structure):
     _fields_ = [('A', C.c_void_p), ('W', C.c_void_p), ('lda', C.c_int32), ('ldw', C.c_int32),
-                ('K', C.c_int32), ('_pad', C.c_int32)]
+                ('K', C.c_int32), ('_pad', C.c_int32), ('A_hi', C.c_void_p), ('A_lo', C.c_void_p)]
 
 
 class LinearProblem(C.Structure):
@@ -33,7 +33,8 @@ class LstmProblem(C.Structure):
                 ('_pad', C.c_int32), ('b_ih', C.c_void_p), ('b_hh', C.c_void_p),
                 ('c_prev', C.c_void_p), ('h_out', C.c_void_p), ('c_out', C.c_void_p),
                 ('gates_out', C.c_void_p), ('h_keep_mask', C.c_void_p), ('mask_scale', C.c_float),
-                ('hdrop_out', C.c_void_p), ('pre', C.c_void_p), ('tab', C.c_void_p),
+                ('hdrop_out', C.c_void_p), ('h_hi', C.c_void_p), ('h_lo', C.c_void_p),
+                ('pre', C.c_void_p), ('tab', C.c_void_p),
                 ('tab_ids', C.c_void_p), ('tab_ids_stride', C.c_int64),
                 ('splitk_ws', C.c_void_p), ('splitk_ws_floats', C.c_int64)]
 
@@ -69,7 +70,8 @@ class StepPlan(C.Structure):
                 [('out_mask', C.c_void_p), ('out_scale', C.c_float), ('apply_logsoftmax', C.c_int32),
                  ('hdrop', C.c_void_p), ('logits', C.c_void_p), ('ld_logits', C.c_int64),
                  ('pmax', C.c_void_p), ('psum', C.c_void_p), ('pidx', C.c_void_p),
-                 ('splitk_ws', C.c_void_p), ('splitk_ws_floats', C.c_int64)])
+                 ('splitk_ws', C.c_void_p), ('splitk_ws_floats', C.c_int64)] +
+                _f('h1_prev_hi h1_prev_lo h2_prev_hi h2_prev_lo h1_hi h1_lo h2_hi h2_lo', C.c_void_p))
 
 
 class StepBwdPlan(C.Structure):
@@ -111,7 +113,7 @@ SIGNATURES = {
     'isc_step_bwd': (C.c_int, [C.POINTER(StepBwdPlan), C.c_void_p]),
     'isc_vocab_fwd': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int,
                                 C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
-                                C.c_void_p, C.c_int64, C.c_void_p]),
+                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     'isc_sched_sample': (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int64, C.c_void_p,
                                    C.c_void_p]),

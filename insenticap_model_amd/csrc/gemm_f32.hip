@@ -33,6 +33,12 @@ struct DevSeg {
     const float *A;
     const float *W;
     int lda, ldw, K, pad;
+    const _Float16 *A_hi, *A_lo;      // caller-provided planes of A ([M,K] contiguous) or null
+};
+
+struct DevASeg {                      // one K-segment of the split-f16 A operand
+    const _Float16 *hi, *lo;
+    int ld, K;
 };
 
 struct DevProb {
@@ -61,9 +67,12 @@ struct DevProb {
     int ksplit;
     float *slab;
     long long slab_stride;
-    // split-f16 path (gemm_h3_kernel): hi / lo planes of the K-concatenated operands, [rows, Kp] halfs each
-    const _Float16 *Ah, *Al, *Wh, *Wl;
-    int Kp;
+    // split-f16 path (gemm_h3_kernel): W planes of the K-concatenated weights [N, Kp]; A planes by segment (either one
+    // packed segment built by the split kernel, or the caller's per-tensor planes)
+    const _Float16 *Wh, *Wl;
+    DevASeg ap[ISC_MAX_SEG];
+    int nap, Kp;
+    _Float16 *h_hi, *h_lo;            // LSTM epilogue: planes of h_out for the consumers
 };
 
 struct DevLaunch {
@@ -311,6 +320,11 @@ __device__ __forceinline__ void lstm_cells(const DevProb &P, const int (&gm)[NE]
             const long long o = (long long)gm[e] * H + unit;
             P.c_out[o] = c2;
             P.h_out[o] = h2;
+            if (P.h_hi) {
+                const _Float16 hh = (_Float16)h2;
+                P.h_hi[o] = hh;
+                P.h_lo[o] = (_Float16)((h2 - (float)hh) * 2048.f);
+            }
             if (P.hmask) P.hdrop[o] = h2 * (float)P.hmask[o] * P.mask_scale;
             if (P.gates_out) {
                 float *go_ = P.gates_out + (long long)gm[e] * 4 * H + unit;
@@ -1082,14 +1096,18 @@ __global__ __launch_bounds__(256, 2) void gemm_h3_kernel(const DevLaunch L) {
     const int M = P.M, N = P.N, Kp = P.Kp;
     const int row0 = tm * BM, col0 = tn * BN;
 
-    // staging: per plane, wave w issues pieces 2w and 2w+1; piece ii = tile rows 16*ii .. +16, 4 lanes per row
+    // staging: per plane, wave w issues pieces 2w and 2w+1; piece ii = tile rows 16*ii .. +16, 4 lanes per row.
+    // W planes are K-packed [N, Kp]; A planes come by K-segment (P.ap: the split kernel's packed planes as one
+    // segment, or the producers' per-tensor planes), switched at chunk boundaries.
     const _Float16 *src[8];
+    int arow[2], aq[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int t = 16 * (2 * wm + i) + (lane >> 2);
         const int q = (lane & 3) ^ ((t >> 2) & 3);
         int ar = row0 + t;
-        ar = ar < M ? ar : M - 1;
+        arow[i] = ar < M ? ar : M - 1;
+        aq[i] = q * 8;
         long long wr;
         if (EPI == EPI_LSTM) {
             wr = (long long)(t >> 5) * P.H + tn * 32 + (t & 31);
@@ -1097,11 +1115,20 @@ __global__ __launch_bounds__(256, 2) void gemm_h3_kernel(const DevLaunch L) {
             const int c = col0 + t;
             wr = c < N ? c : N - 1;
         }
-        src[0 + i] = P.Ah + (long long)ar * Kp + q * 8;
-        src[2 + i] = P.Al + (long long)ar * Kp + q * 8;
         src[4 + i] = P.Wh + wr * Kp + q * 8;
         src[6 + i] = P.Wl + wr * Kp + q * 8;
     }
+    int cs = 0, ck = 0, segK = 0;
+    auto set_aseg = [&](int si) __attribute__((always_inline)) {
+        const DevASeg a = P.ap[si];
+        segK = a.K;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            src[0 + i] = a.hi + (long long)arow[i] * a.ld + aq[i];
+            src[2 + i] = a.lo + (long long)arow[i] * a.ld + aq[i];
+        }
+    };
+    set_aseg(0);
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds + wm * 2048);
     auto stage = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
@@ -1112,6 +1139,11 @@ __global__ __launch_bounds__(256, 2) void gemm_h3_kernel(const DevLaunch L) {
                              :: "s"(lds0 + buf * ST + p * PL + i * 1024), "v"(src[2 * p + i]) : "memory");
                 src[2 * p + i] += 32;
             }
+        ck += 32;
+        if (ck >= segK) {
+            ck = 0;
+            if (++cs < P.nap) set_aseg(cs);
+        }
     };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
@@ -1198,15 +1230,15 @@ __global__ __launch_bounds__(256) void gemm_h3m_kernel(const DevLaunch L) {
     const int M = P.M, N = P.N, Kp = P.Kp;
     const int row0 = tm * 64, col0 = tn * 128;
 
-    // staging pieces of 16 rows x 64 B: A planes one piece per wave, W planes two
+    // staging pieces of 16 rows x 64 B: A planes one piece per wave (by K-segment, as in gemm_h3_kernel), W planes two
     const _Float16 *src[6];
+    int arow, aq;
     {
         const int t = 16 * w + (lane >> 2);
         const int q = (lane & 3) ^ ((t >> 2) & 3);
         int ar = row0 + t;
-        ar = ar < M ? ar : M - 1;
-        src[0] = P.Ah + (long long)ar * Kp + q * 8;
-        src[1] = P.Al + (long long)ar * Kp + q * 8;
+        arow = ar < M ? ar : M - 1;
+        aq = q * 8;
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -1217,6 +1249,14 @@ __global__ __launch_bounds__(256) void gemm_h3m_kernel(const DevLaunch L) {
         src[2 + i] = P.Wh + (long long)c * Kp + q * 8;
         src[4 + i] = P.Wl + (long long)c * Kp + q * 8;
     }
+    int cs = 0, ck = 0, segK = 0;
+    auto set_aseg = [&](int si) __attribute__((always_inline)) {
+        const DevASeg a = P.ap[si];
+        segK = a.K;
+        src[0] = a.hi + (long long)arow * a.ld + aq;
+        src[1] = a.lo + (long long)arow * a.ld + aq;
+    };
+    set_aseg(0);
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds);
     const unsigned wv = __builtin_amdgcn_readfirstlane((unsigned)w);
     auto dma1 = [&](unsigned dst, const _Float16 *&p) __attribute__((always_inline)) {
@@ -1231,6 +1271,11 @@ __global__ __launch_bounds__(256) void gemm_h3m_kernel(const DevLaunch L) {
         for (int i = 0; i < 2; ++i) {
             dma1(b + 2 * PA + (2 * wv + i) * 1024, src[2 + i]);
             dma1(b + 2 * PA + PB + (2 * wv + i) * 1024, src[4 + i]);
+        }
+        ck += 32;
+        if (ck >= segK) {
+            ck = 0;
+            if (++cs < P.nap) set_aseg(cs);
         }
     };
     using I0 = std::integral_constant<int, 0>;
@@ -1310,15 +1355,16 @@ struct SplitJob {
     int nseg, rows, Kp, first_block;
     _Float16 *hi, *lo;
 };
+#define H3_MAX_JOBS 12
 struct SplitLaunch {
-    SplitJob j[6];
+    SplitJob j[H3_MAX_JOBS];
     int njobs;
 };
 
 __global__ __launch_bounds__(256) void h3_split_kernel(const SplitLaunch S) {
     int ji = 0;
 #pragma unroll
-    for (int i = 1; i < 6; ++i)
+    for (int i = 1; i < H3_MAX_JOBS; ++i)
         if (i < S.njobs && (int)blockIdx.x >= S.j[i].first_block) ji = i;
     const SplitJob &J = S.j[ji];
     const int k8n = J.Kp >> 3;
@@ -1551,6 +1597,11 @@ __global__ __launch_bounds__(256) void splitk_lstm_kernel(const DevLaunch L) {
     const float h2 = go * isc_tanh(c2);
     P.c_out[i] = c2;
     P.h_out[i] = h2;
+    if (P.h_hi) {
+        const _Float16 hh = (_Float16)h2;
+        P.h_hi[i] = hh;
+        P.h_lo[i] = (_Float16)((h2 - (float)hh) * 2048.f);
+    }
     if (P.hmask) P.hdrop[i] = h2 * (float)P.hmask[i] * P.mask_scale;
     if (P.gates_out) {
         float *q = P.gates_out + (long long)gm * 4 * H + unit;
@@ -1616,6 +1667,8 @@ static void copy_segs(DevProb &d, const isc_seg *seg, int nseg) {
     for (int s = 0; s < nseg; ++s) {
         d.seg[s].A = seg[s].A; d.seg[s].W = seg[s].W;
         d.seg[s].lda = seg[s].lda; d.seg[s].ldw = seg[s].ldw; d.seg[s].K = seg[s].K; d.seg[s].pad = 0;
+        d.seg[s].A_hi = static_cast<const _Float16 *>(seg[s].A_hi);
+        d.seg[s].A_lo = static_cast<const _Float16 *>(seg[s].A_lo);
     }
 }
 
@@ -1838,21 +1891,46 @@ struct H3Planner {
     char *at;
     int blocks = 0;
     explicit H3Planner(float *ws) : at(reinterpret_cast<char *>(ws)) {}
-    void add(const DevProb &p, bool is_w, int rows, const _Float16 *&hi, const _Float16 *&lo) {
+    // planes of segments [s0, s1) of an operand, K-packed
+    void add(const DevProb &p, bool is_w, int rows, const _Float16 *&hi, const _Float16 *&lo, int s0 = 0, int s1 = -1) {
+        if (s1 < 0) s1 = p.nseg;
         SplitJob &J = S.j[S.njobs++];
         int k0 = 0;
-        for (int s = 0; s < p.nseg; ++s) {
-            J.src[s] = is_w ? p.seg[s].W : p.seg[s].A;
-            J.ld[s] = is_w ? p.seg[s].ldw : p.seg[s].lda;
-            J.kstart[s] = k0;
+        for (int s = s0; s < s1; ++s) {
+            J.src[s - s0] = is_w ? p.seg[s].W : p.seg[s].A;
+            J.ld[s - s0] = is_w ? p.seg[s].ldw : p.seg[s].lda;
+            J.kstart[s - s0] = k0;
             k0 += p.seg[s].K;
         }
-        J.nseg = p.nseg; J.rows = rows; J.Kp = k0; J.first_block = blocks;
+        J.nseg = s1 - s0; J.rows = rows; J.Kp = k0; J.first_block = blocks;
         const size_t bytes = (((size_t)rows * k0 * 2) + 255) & ~(size_t)255;
         J.hi = reinterpret_cast<_Float16 *>(at); at += bytes;
         J.lo = reinterpret_cast<_Float16 *>(at); at += bytes;
         hi = J.hi; lo = J.lo;
         blocks += (int)(((long long)rows * (k0 >> 3) + 255) / 256);
+    }
+    // activation operand: the caller's per-tensor planes where given, split jobs for the rest
+    void add_a(DevProb &p) {
+        bool any = false;
+        for (int s = 0; s < p.nseg; ++s) any = any || (p.seg[s].A_hi && p.seg[s].A_lo);
+        if (!any) {
+            const _Float16 *hi, *lo;
+            add(p, false, p.M, hi, lo);
+            p.nap = 1;
+            p.ap[0] = DevASeg{hi, lo, p.Kp, p.Kp};
+            return;
+        }
+        p.nap = p.nseg;
+        for (int s = 0; s < p.nseg; ++s) {
+            const int K = p.seg[s].K;
+            if (p.seg[s].A_hi && p.seg[s].A_lo) {
+                p.ap[s] = DevASeg{p.seg[s].A_hi, p.seg[s].A_lo, K, K};
+            } else {
+                const _Float16 *hi, *lo;
+                add(p, false, p.M, hi, lo, s, s + 1);
+                p.ap[s] = DevASeg{hi, lo, K, K};
+            }
+        }
     }
     // weight operand: cached planes if the caller opened a weights scope, else planes in the workspace
     void add_w(const DevProb &p, const _Float16 *&hi, const _Float16 *&lo) {
@@ -1900,7 +1978,8 @@ static int h3_linear_chunked(const DevProb &p0, float *ws, long long ws_floats, 
         pl.add(p0, true, p0.N, wh, wl);              // same place every chunk; only the first chunk's job is launched
         if (r0 != 0) { pl.S.njobs = 0; pl.blocks = 0; }
         p.Wh = wh; p.Wl = wl;                        // (in the workspace, not the weights scope: used once per call)
-        pl.add(p, false, p.M, p.Ah, p.Al);
+        for (int s = 0; s < p.nseg; ++s) p.seg[s].A_hi = p.seg[s].A_lo = nullptr;   // planes are per chunk
+        pl.add_a(p);
         int rc = pl.launch(st);
         if (rc) return rc;
         finish_tiling(L, 4);
@@ -1943,6 +2022,11 @@ static int try_h3(DevLaunch &L, float *ws, long long ws_floats, hipStream_t st, 
         }
         return 1;
     }
+    {
+        int jobs = 0;
+        for (int i = 0; i < L.nprob; ++i) jobs += L.p[i].nseg + 1;
+        if (jobs > H3_MAX_JOBS) return 0;
+    }
     H3Planner pl(ws);
     for (int i = 0; i < L.nprob; ++i) {
         DevProb &p = L.p[i];
@@ -1952,11 +2036,16 @@ static int try_h3(DevLaunch &L, float *ws, long long ws_floats, hipStream_t st, 
             const DevProb &o = L.p[j];
             bool eq = o.nseg == p.nseg && o.M == p.M;
             for (int s = 0; eq && s < p.nseg; ++s)
-                eq = o.seg[s].A == p.seg[s].A && o.seg[s].lda == p.seg[s].lda && o.seg[s].K == p.seg[s].K;
+                eq = o.seg[s].A == p.seg[s].A && o.seg[s].lda == p.seg[s].lda && o.seg[s].K == p.seg[s].K &&
+                     o.seg[s].A_hi == p.seg[s].A_hi && o.seg[s].A_lo == p.seg[s].A_lo;
             if (eq) same = j;
         }
-        if (same >= 0) { p.Ah = L.p[same].Ah; p.Al = L.p[same].Al; }
-        else pl.add(p, false, p.M, p.Ah, p.Al);
+        if (same >= 0) {
+            p.nap = L.p[same].nap;
+            for (int s = 0; s < p.nap; ++s) p.ap[s] = L.p[same].ap[s];
+        } else {
+            pl.add_a(p);
+        }
         pl.add_w(p, p.Wh, p.Wl);
     }
     rc = pl.launch(st);
@@ -2096,6 +2185,8 @@ extern "C" int isc_lstm_fwd(const isc_lstm_problem *q, void *stream) {
     d.bias0 = q->b_ih; d.bias1 = q->b_hh;
     d.c_prev = q->c_prev; d.h_out = q->h_out; d.c_out = q->c_out; d.gates_out = q->gates_out;
     d.hmask = q->h_keep_mask; d.mask_scale = q->mask_scale; d.hdrop = q->hdrop_out;
+    if ((q->h_hi == nullptr) != (q->h_lo == nullptr)) return ISC_E_NULL;
+    d.h_hi = static_cast<_Float16 *>(q->h_hi); d.h_lo = static_cast<_Float16 *>(q->h_lo);
     d.pre = q->pre; d.tab = q->tab; d.tab_ids = q->tab_ids; d.tab_ids_stride = q->tab_ids_stride;
     const int S = plan_splitk(L, q->splitk_ws, q->splitk_ws_floats);
     if (S > 1) {   // plain [M,4H] pre-activation slabs, then the cell update in the reduce kernel
@@ -2121,9 +2212,10 @@ extern "C" int isc_lstm_fwd(const isc_lstm_problem *q, void *stream) {
 extern "C" int isc_vocab_fwd(const float *h, int ldh, const float *W, int ldw, const float *bias,
                              int M, int V, int K, float *logits, int64_t ld_logits,
                              float *part_max, float *part_sum, int32_t *part_idx,
+                             const void *h_hi, const void *h_lo,
                              float *splitk_ws, int64_t splitk_ws_floats, void *stream) {
     if (!h || !W || !bias || !part_max || !part_sum || !part_idx) return ISC_E_NULL;
-    isc_seg sg = {h, W, ldh, ldw, K, 0};
+    isc_seg sg = {h, W, ldh, ldw, K, 0, h_hi, h_lo};
     int rc = check_segs(&sg, 1);
     if (rc) return rc;
     if (M <= 0 || V <= 0) return ISC_E_SHAPE;

@@ -4,8 +4,9 @@
 // only fills the per-kernel descriptors and calls the library's own entry points.
 #include "common.h"
 
-static inline isc_seg seg(const float *A, int lda, const float *W, int ldw, int K) {
-    isc_seg s = {A, W, lda, ldw, K, 0};
+static inline isc_seg seg(const float *A, int lda, const float *W, int ldw, int K, const void *hi = nullptr,
+                          const void *lo = nullptr) {
+    isc_seg s = {A, W, lda, ldw, K, 0, hi, lo};
     return s;
 }
 
@@ -22,15 +23,23 @@ extern "C" int isc_step_fwd(const isc_step_plan *p, void *stream) {
     const bool has_c = p->att_e != nullptr, has_s = p->words_e != nullptr, gate = has_c && has_s;
     if (!has_c && !has_s) return ISC_E_NULL;
     const int ld1 = H + E + W, ld2 = E + H;
+    // f16 planes of the recurrent state (split-f16 path): all eight or none
+    const bool planes = p->h1_prev_hi && p->h1_prev_lo && p->h2_prev_hi && p->h2_prev_lo && p->h1_hi && p->h1_lo &&
+                        p->h2_hi && p->h2_lo;
+    if (!planes && (p->h1_prev_hi || p->h1_prev_lo || p->h2_prev_hi || p->h2_prev_lo || p->h1_hi || p->h1_lo ||
+                    p->h2_hi || p->h2_lo))
+        return ISC_E_NULL;
+#define PL(x) (planes ? (x) : nullptr)
 
     // att-LSTM over cat[h_lang_prev, fc, xt] (captioner.py:174-175); fc/label/bias are in pre1
     {
         isc_lstm_problem l = {};
         int n = 0;
-        l.seg[n++] = seg(p->h2_prev, H, p->Wih1, ld1, H);
+        l.seg[n++] = seg(p->h2_prev, H, p->Wih1, ld1, H, PL(p->h2_prev_hi), PL(p->h2_prev_lo));
         if (!p->tab) l.seg[n++] = seg(p->xt, W, p->Wih1 + H + E, ld1, W);
-        l.seg[n++] = seg(p->h1_prev, H, p->Whh1, H, H);
+        l.seg[n++] = seg(p->h1_prev, H, p->Whh1, H, H, PL(p->h1_prev_hi), PL(p->h1_prev_lo));
         l.nseg = n; l.M = rows; l.H = H;
+        l.h_hi = PL(p->h1_hi); l.h_lo = PL(p->h1_lo);
         l.c_prev = p->c1_prev; l.h_out = p->h1; l.c_out = p->c1; l.gates_out = p->g1;
         l.pre = p->pre1; l.tab = p->tab; l.tab_ids = p->tok; l.tab_ids_stride = p->tok_stride;
         l.splitk_ws = p->splitk_ws; l.splitk_ws_floats = p->splitk_ws_floats;
@@ -42,7 +51,7 @@ extern "C" int isc_step_fwd(const isc_step_plan *p, void *stream) {
         int n = 0;
         auto lin = [&](const float *Wm, const float *b, float *out) {
             isc_linear_problem &x = q[n++];
-            x.seg[0] = seg(p->h1, H, Wm, H, H);
+            x.seg[0] = seg(p->h1, H, Wm, H, H, PL(p->h1_hi), PL(p->h1_lo));
             x.nseg = 1; x.M = rows; x.N = A; x.bias0 = b; x.ldc = A; x.C = out;
         };
         if (has_c) lin(p->W_h2att, p->b_h2att, p->qa);
@@ -84,9 +93,10 @@ extern "C" int isc_step_fwd(const isc_step_plan *p, void *stream) {
     {
         isc_lstm_problem l = {};
         l.seg[0] = seg(feat, E, p->Wih2, ld2, E);
-        l.seg[1] = seg(p->h1, H, p->Wih2 + E, ld2, H);
-        l.seg[2] = seg(p->h2_prev, H, p->Whh2, H, H);
+        l.seg[1] = seg(p->h1, H, p->Wih2 + E, ld2, H, PL(p->h1_hi), PL(p->h1_lo));
+        l.seg[2] = seg(p->h2_prev, H, p->Whh2, H, H, PL(p->h2_prev_hi), PL(p->h2_prev_lo));
         l.nseg = 3; l.M = rows; l.H = H; l.b_ih = p->b_ih2; l.b_hh = p->b_hh2;
+        l.h_hi = PL(p->h2_hi); l.h_lo = PL(p->h2_lo);
         l.c_prev = p->c2_prev; l.h_out = p->h2; l.c_out = p->c2; l.gates_out = p->g2;
         l.h_keep_mask = p->out_mask; l.mask_scale = p->out_scale; l.hdrop_out = p->hdrop;
         l.splitk_ws = p->splitk_ws; l.splitk_ws_floats = p->splitk_ws_floats;
@@ -94,7 +104,9 @@ extern "C" int isc_step_fwd(const isc_step_plan *p, void *stream) {
     }
     // classifier + log-softmax statistics (captioner.py:183)
     RET(isc_vocab_fwd(p->out_mask ? p->hdrop : p->h2, H, p->W_cls, H, p->b_cls, rows, V, H, p->logits,
-                      p->ld_logits, p->pmax, p->psum, p->pidx, p->splitk_ws, p->splitk_ws_floats, stream));
+                      p->ld_logits, p->pmax, p->psum, p->pidx, p->out_mask ? nullptr : PL(p->h2_hi),
+                      p->out_mask ? nullptr : PL(p->h2_lo), p->splitk_ws, p->splitk_ws_floats, stream));
+#undef PL
     if (p->apply_logsoftmax) {
         if (!p->logits) return ISC_E_NULL;
         RET(isc_logsoftmax_apply(p->logits, p->ld_logits, rows, V, p->pmax, p->psum, nullptr, stream));

@@ -55,7 +55,7 @@ TIMER = KernelTimer()
 
 
 def _seg_k(segs):
-    return sum(a.shape[1] for a, _ in segs)
+    return sum(sg[0].shape[1] for sg in segs)
 
 
 _SPLITK_WS = {}
@@ -107,13 +107,20 @@ def require_device(*tensors):
 def _fill_segs(dst, segs):
     if not 1 <= len(segs) <= _lib.ISC_MAX_SEG:
         raise ValueError('1..4 K-segments supported')
-    for i, (A, W) in enumerate(segs):
+    for i, sg in enumerate(segs):
+        A, W = sg[0], sg[1]
         assert A.dim() == 2 and W.dim() == 2 and A.stride(1) == 1 and W.stride(1) == 1
         assert A.shape[1] == W.shape[1], (A.shape, W.shape)
         assert A.dtype == torch.float32 and W.dtype == torch.float32
         s = dst[i]
         s.A, s.W = A.data_ptr(), W.data_ptr()
         s.lda, s.ldw, s.K = A.stride(0), W.stride(0), A.shape[1]
+        planes = sg[2] if len(sg) > 2 else None      # optional [2, M, K] f16 planes of A (isc_seg.A_hi / A_lo)
+        if planes is not None:
+            assert planes.dtype == torch.float16 and planes.is_contiguous() and planes.shape == (2,) + tuple(A.shape)
+            s.A_hi, s.A_lo = planes[0].data_ptr(), planes[1].data_ptr()
+        else:
+            s.A_hi = s.A_lo = None
 
 
 def set_tile_override(tile):
@@ -198,7 +205,8 @@ def linear_fwd(problems):
 
 
 def lstm_fwd(segs, b_ih, b_hh, c_prev, h_out, c_out, gates_out=None, h_keep_mask=None,
-             mask_scale=1.0, hdrop_out=None, pre=None, tab=None, tab_ids=None):
+             mask_scale=1.0, hdrop_out=None, pre=None, tab=None, tab_ids=None, h_planes=None):
+    """h_planes: optional [2, M, H] f16 tensor receiving the split-f16 planes of h_out (for consumers' segments)."""
     lib = _lib.load()
     p = LstmProblem()
     _fill_segs(p.seg, segs)
@@ -217,6 +225,9 @@ def lstm_fwd(segs, b_ih, b_hh, c_prev, h_out, c_out, gates_out=None, h_keep_mask
     p.h_keep_mask = ptr(h_keep_mask)
     p.mask_scale = mask_scale
     p.hdrop_out = ptr(hdrop_out)
+    if h_planes is not None:
+        assert h_planes.dtype == torch.float16 and h_planes.is_contiguous() and h_planes.shape == (2, p.M, p.H)
+        p.h_hi, p.h_lo = h_planes[0].data_ptr(), h_planes[1].data_ptr()
     _attach_ws(p, c_prev.device)
     e0 = TIMER.begin()
     check(lib.isc_lstm_fwd(C.byref(p), stream()), 'isc_lstm_fwd')
@@ -234,8 +245,12 @@ def step_bwd(plan):
     check(_lib.load().isc_step_bwd(C.byref(plan), stream()), 'isc_step_bwd')
 
 
-def vocab_fwd(h, W, bias, part_max, part_sum, part_idx, logits=None):
+def vocab_fwd(h, W, bias, part_max, part_sum, part_idx, logits=None, h_planes=None):
     lib = _lib.load()
+    hi = lo = None
+    if h_planes is not None:
+        assert h_planes.dtype == torch.float16 and h_planes.is_contiguous() and h_planes.shape == (2,) + tuple(h.shape)
+        hi, lo = h_planes[0].data_ptr(), h_planes[1].data_ptr()
     M, K = h.shape
     V = W.shape[0]
     assert h.stride(1) == 1 and W.stride(1) == 1
@@ -244,7 +259,7 @@ def vocab_fwd(h, W, bias, part_max, part_sum, part_idx, logits=None):
     ws = splitk_ws(h.device)
     check(lib.isc_vocab_fwd(h.data_ptr(), h.stride(0), W.data_ptr(), W.stride(0), bias.data_ptr(), M, V, K,
                             ptr(logits), ld, part_max.data_ptr(), part_sum.data_ptr(),
-                            part_idx.data_ptr(), ws.data_ptr(), ws.numel(), stream()), 'isc_vocab_fwd')
+                            part_idx.data_ptr(), hi, lo, ws.data_ptr(), ws.numel(), stream()), 'isc_vocab_fwd')
     TIMER.end(e0, 'vocab[%dx%dx%d]' % (M, V, K), 2.0 * M * V * K)
 
 

@@ -96,7 +96,7 @@ def test_argument_validation_without_a_gpu():
     p.nseg = 1
     assert lib.isc_linear_fwd(ctypes.byref(p), 1, None) == -1         # null segment pointers
     assert lib.isc_attn_scan_fwd(None, 1, 4, None) == -1
-    assert lib.isc_vocab_fwd(None, 0, None, 0, None, 1, 1, 32, None, 0, None, None, None, None, 0, None) == -1
+    assert lib.isc_vocab_fwd(None, 0, None, 0, None, 1, 1, 32, None, 0, None, None, None, None, None, None, 0, None) == -1
     assert lib.isc_gemm_bwd(ctypes.byref(p), 1, 7, None) == -2        # unknown layout
     assert lib.isc_colsum(None, 0, 1, 1, None, 0, None, 0, None) == -1
 

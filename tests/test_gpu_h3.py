@@ -247,3 +247,37 @@ def test_weights_scope_reuses_planes_and_ends_cleanly():
     torch.cuda.synchronize()
     assert torch.equal(doubled_scoped, doubled)
     np.testing.assert_allclose(doubled.cpu().numpy(), (plain * 2).cpu().numpy(), rtol=2e-6, atol=1e-6)
+
+
+def test_rollout_state_planes_are_bit_identical_to_resplitting():
+    """The roll-out lets the LSTM epilogues write the f16 planes of h next to h (isc_step_plan.h1_hi ...); consumers
+    then read those instead of splitting h again.  Same values by construction -> identical tokens and log-probs,
+    on the whole-step entry point and on the per-op path (bench.py's kernel timer), with fewer split launches."""
+    import numpy as np
+    from conftest import case_setup
+    from insenticap_model_amd import Captioner, synth
+    c, st, w, _, _ = case_setup('cfg1')
+    cap = Captioner(synth.make_idx2word(c['V']), synth.SENTIMENT_CATEGORIES, st)
+    cap.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()})
+    cap.to(dev()).eval()
+    B, Tn = 1024, 12
+    d = synth.make_inputs(B, c['V'], st, regions=36, seq_len=Tn, seed=99)
+    a = [torch.from_numpy(np.asarray(d[k])).to(dev()) for k in ('fc_feats', 'att_feats', 'cpt_words', 'senti_words', 'senti_labels')]
+    ops.set_h3_mode(2)
+    outs = {}
+    for planes in (True, False):
+        cap.state_planes = planes
+        with torch.no_grad():
+            seq, lp, mk = cap(*a, Tn, 1, mode='rl')
+        outs[planes] = (seq.cpu(), lp.cpu())
+    cap.state_planes = True
+    assert torch.equal(outs[True][0], outs[False][0]) and torch.equal(outs[True][1], outs[False][1])
+    # per-op path with the timer armed on a middle step: the planes stay consistent across the two paths
+    ops.TIMER.arm_step = 5
+    try:
+        with torch.no_grad():
+            seq, lp, mk = cap(*a, Tn, 1, mode='rl')
+    finally:
+        ops.TIMER.arm_step = None
+        ops.TIMER.records.clear()
+    assert torch.equal(seq.cpu(), outs[True][0]) and torch.equal(lp.cpu(), outs[True][1])
