@@ -178,6 +178,7 @@ typedef struct {
     float *out;       /* [B,D] */
     float *alpha_out; /* [B,*] row stride alpha_ld, R values written per row */
     int64_t alpha_ld;
+    void *out_hi, *out_lo; /* optional: f16 planes of `out` ([B,D] each, see isc_seg.A_hi) */
 } isc_scan_problem;
 
 int isc_attn_scan_fwd(const isc_scan_problem *probs_host, int n_prob, int B, void *stream);
@@ -186,7 +187,7 @@ int isc_attn_scan_fwd(const isc_scan_problem *probs_host, int n_prob, int B, voi
  * out = beta*v + (1-beta)*s.  z = cont2att(v)+senti2att(s)+h2att(h) from isc_linear_fwd. */
 int isc_gate_mix_fwd(const float *z, const float *w, const float *w_bias, const float *v,
                      const float *s, int B, int A, int D, float *out, float *beta_out,
-                     int64_t beta_ld, void *stream);
+                     int64_t beta_ld, void *out_hi, void *out_lo, void *stream);   /* out_hi/lo: optional planes of out */
 
 /* xt[b,:] = relu(Emb[ids[b]]) (+ add[b,:])   (captioner.py:170-172), ids int64. */
 int isc_embed_relu_fwd(const float *emb, int V, int W, const int64_t *ids, int64_t ids_stride,
@@ -301,6 +302,9 @@ typedef struct {
      * eight or none. */
     const void *h1_prev_hi, *h1_prev_lo, *h2_prev_hi, *h2_prev_lo;
     void *h1_hi, *h1_lo, *h2_hi, *h2_lo;
+    /* Optional plane workspace of the step's own intermediates v, s, f ([rows,E] f16 each; used with the state
+     * planes): the scans and the gate write them, the gate sum and the lang-LSTM read them. */
+    void *v_hi, *v_lo, *s_hi, *s_lo, *f_hi, *f_lo;
 } isc_step_plan;
 
 int isc_step_fwd(const isc_step_plan *plan_host, void *stream);

@@ -349,8 +349,13 @@ class Captioner(nn.Module):
             pl.h2_prev_hi, pl.h2_prev_lo = hp_cur[1, 0].data_ptr(), hp_cur[1, 1].data_ptr()
             pl.h1_hi, pl.h1_lo = hp_nxt[0, 0].data_ptr(), hp_nxt[0, 1].data_ptr()
             pl.h2_hi, pl.h2_lo = hp_nxt[1, 0].data_ptr(), hp_nxt[1, 1].data_ptr()
+            for k in ('v', 's', 'f'):                 # plane workspace of the step's own intermediates
+                pp = ws.get(k + 'p')
+                setattr(pl, k + '_hi', None if pp is None else pp[0].data_ptr())
+                setattr(pl, k + '_lo', None if pp is None else pp[1].data_ptr())
         else:
-            for k in ('h1_prev_hi', 'h1_prev_lo', 'h2_prev_hi', 'h2_prev_lo', 'h1_hi', 'h1_lo', 'h2_hi', 'h2_lo'):
+            for k in ('h1_prev_hi', 'h1_prev_lo', 'h2_prev_hi', 'h2_prev_lo', 'h1_hi', 'h1_lo', 'h2_hi', 'h2_lo',
+                      'v_hi', 'v_lo', 's_hi', 's_lo', 'f_hi', 'f_lo'):
                 setattr(pl, k, None)
         pl.g1, pl.g2 = ptr(save.get('g1')), ptr(save.get('g2'))
         for k in ('qa', 'v', 'qw', 's', 'z', 'f'):
@@ -385,6 +390,7 @@ class Captioner(nn.Module):
         # fc / label / bias terms come pre-summed (P.pre1), the word term from the table when present
         pc = (lambda l: None) if hp_cur is None else (lambda l: hp_cur[l])      # planes of h_cur[l] / h_nxt[l]
         pn = (lambda l: None) if hp_nxt is None else (lambda l: hp_nxt[l])
+        wp = (lambda k: None) if hp_cur is None else (lambda k: ws.get(k + 'p'))   # planes of v / s / f
         segs = [(h_cur[1], Wih[:, 0:H], pc(1)), (h_cur[0], Whh, pc(0))]
         if P.tab is None:
             segs.insert(1, (xt, Wih[:, H + E:]))
@@ -398,14 +404,15 @@ class Captioner(nn.Module):
                                             p['attention.cont_att.h2att.bias']))
             scans.append(ops.scan_problem(P.att_p3, P.att_e3, ws['qa'],
                                           p['attention.cont_att.att_alpha.weight'],
-                                          p['attention.cont_att.att_alpha.bias'], ws['v'], alpha_c))
+                                          p['attention.cont_att.att_alpha.bias'], ws['v'], alpha_c,
+                                          out_planes=wp('v')))
         if has_senti:
             probs.append(ops.linear_problem([(h1, p['attention.senti_att.h2word.weight'], pn(0))], ws['qw'],
                                             p['attention.senti_att.h2word.bias']))
             scans.append(ops.scan_problem(P.words_p3, P.words_e3, ws['qw'],
                                           p['attention.senti_att.word_alpha.weight'],
                                           p['attention.senti_att.word_alpha.bias'], ws['s'], alpha_s,
-                                          q2=P.label_w))
+                                          q2=P.label_w, out_planes=wp('s')))
         gate = has_cont and has_senti
         if gate:   # the h2att(h1) term of the gate rides in the same launch as the two projections
             probs.append(ops.linear_problem([(h1, p['attention.h2att.weight'], pn(0))], ws['z'],
@@ -415,18 +422,19 @@ class Captioner(nn.Module):
         if gate:
             # z = cont2att(v) + senti2att(s) + h2att(h1) (captioner.py:107-110): add the v / s terms
             ops.linear_fwd([ops.linear_problem(
-                [(ws['v'], p['attention.cont2att.weight']), (ws['s'], p['attention.senti2att.weight'])],
+                [(ws['v'], p['attention.cont2att.weight'], wp('v')),
+                 (ws['s'], p['attention.senti2att.weight'], wp('s'))],
                 ws['z'], p['attention.cont2att.bias'], p['attention.senti2att.bias'], accumulate=True)])
             ops.gate_mix_fwd(ws['z'], p['attention.att_alpha.weight'], p['attention.att_alpha.bias'],
-                             ws['v'], ws['s'], ws['f'], beta)
-            feat = ws['f']
+                             ws['v'], ws['s'], ws['f'], beta, out_planes=wp('f'))
+            feat, featp = ws['f'], wp('f')
         else:
-            feat = ws['v'] if has_cont else ws['s']
+            feat, featp = (ws['v'], wp('v')) if has_cont else (ws['s'], wp('s'))
         Wih2, Whh2 = p['lang_lstm.weight_ih'], p['lang_lstm.weight_hh']
         hdrop = None
         if out_mask is not None:
             hdrop = save['hdrop'] if 'hdrop' in save else self._new(rows, H)
-        ops.lstm_fwd([(feat, Wih2[:, 0:E]), (h1, Wih2[:, E:E + H], pn(0)), (h_cur[1], Whh2, pc(1))],
+        ops.lstm_fwd([(feat, Wih2[:, 0:E], featp), (h1, Wih2[:, E:E + H], pn(0)), (h_cur[1], Whh2, pc(1))],
                      p['lang_lstm.bias_ih'], p['lang_lstm.bias_hh'], c_cur[1], h_nxt[1], c_nxt[1],
                      gates_out=save.get('g2'), h_keep_mask=out_mask, mask_scale=out_scale, hdrop_out=hdrop,
                      h_planes=pn(1))
@@ -612,6 +620,10 @@ class Captioner(nn.Module):
         hp = [torch.zeros(2, 2, B, H, dtype=torch.float16, device=self._dev) if getattr(self, 'state_planes', True)
               else None for _ in range(2)]
         ws = self._alloc_step_ws(B, P)
+        if hp[0] is not None:
+            for k in ('v', 's', 'f'):
+                if k in ws:
+                    ws[k + 'p'] = torch.empty((2,) + tuple(ws[k].shape), dtype=torch.float16, device=self._dev)
         seq = self._zeros(B, T, dtype=torch.int64)
         seq_logprobs, seq_masks = self._zeros(B, T), self._zeros(B, T)
         raw = self._zeros(B, T, dtype=torch.int64)

@@ -22,10 +22,25 @@ struct DevScan {
     int R, A, D;
     float *out, *alpha_out;
     long long alpha_ld;
+    _Float16 *out_hi, *out_lo;
 };
 struct DevScanLaunch {
     DevScan p[2];
 };
+
+// f16 planes of four consecutive outputs (split-f16 GEMM operands: hi = f16(x), lo = f16((x - hi) * 2048))
+__device__ __forceinline__ void store_planes4(_Float16 *hi, _Float16 *lo, long long o, const float4 &x) {
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    const float v[4] = {x.x, x.y, x.z, x.w};
+    h4 a, b;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        a[e] = (_Float16)v[e];
+        b[e] = (_Float16)((v[e] - (float)a[e]) * 2048.f);
+    }
+    *reinterpret_cast<h4 *>(hi + o) = a;
+    *reinterpret_cast<h4 *>(lo + o) = b;
+}
 
 template <int NA>  // float4 per lane along A: A <= 256*NA
 __global__ __launch_bounds__(256) void attn_scan_kernel(const DevScanLaunch L) {
@@ -143,6 +158,7 @@ __global__ __launch_bounds__(256) void attn_scan_kernel(const DevScanLaunch L) {
                 s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
             }
             reinterpret_cast<float4 *>(S.out + (long long)b * D)[tid] = s;
+            if (S.out_hi) store_planes4(S.out_hi, S.out_lo, (long long)b * D + 4 * tid, s);
         }
     } else {
         for (int d4 = tid; d4 < nd4; d4 += 256) {
@@ -153,6 +169,7 @@ __global__ __launch_bounds__(256) void attn_scan_kernel(const DevScanLaunch L) {
                 o.x += a * v.x; o.y += a * v.y; o.z += a * v.z; o.w += a * v.w;
             }
             reinterpret_cast<float4 *>(S.out + (long long)b * D)[d4] = o;
+            if (S.out_hi) store_planes4(S.out_hi, S.out_lo, (long long)b * D + 4 * d4, o);
         }
     }
 }
@@ -173,6 +190,8 @@ extern "C" int isc_attn_scan_fwd(const isc_scan_problem *pr, int n_prob, int B, 
         DevScan &d = L.p[i];
         d.P = q.P; d.V = q.V; d.q = q.q; d.q2 = q.q2; d.w = q.w; d.w_bias = q.w_bias;
         d.R = q.R; d.A = q.A; d.D = q.D; d.out = q.out; d.alpha_out = q.alpha_out; d.alpha_ld = q.alpha_ld;
+        if ((q.out_hi == nullptr) != (q.out_lo == nullptr)) return ISC_E_NULL;
+        d.out_hi = static_cast<_Float16 *>(q.out_hi); d.out_lo = static_cast<_Float16 *>(q.out_lo);
         if (q.A > maxA) maxA = q.A;
         const int nd4 = q.D / 4;
         const size_t part = nd4 <= 256 ? (size_t)(256 / nd4) * q.D : 0;
@@ -194,7 +213,7 @@ extern "C" int isc_attn_scan_fwd(const isc_scan_problem *pr, int n_prob, int B, 
 __global__ __launch_bounds__(256) void gate_mix_kernel(const float *z, const float *w, const float *w_bias,
                                                        const float *v, const float *s, int B, int A,
                                                        int D, float *out, float *beta_out,
-                                                       long long beta_ld) {
+                                                       long long beta_ld, _Float16 *out_hi, _Float16 *out_lo) {
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= B) return;
@@ -205,17 +224,25 @@ __global__ __launch_bounds__(256) void gate_mix_kernel(const float *z, const flo
     if (lane == 0 && beta_out) beta_out[(long long)b * beta_ld] = beta;
     for (int d = lane; d < D; d += 64) {
         const long long o = (long long)b * D + d;
-        out[o] = beta * v[o] + (1.0f - beta) * s[o];
+        const float f = beta * v[o] + (1.0f - beta) * s[o];
+        out[o] = f;
+        if (out_hi) {
+            const _Float16 fh = (_Float16)f;
+            out_hi[o] = fh;
+            out_lo[o] = (_Float16)((f - (float)fh) * 2048.f);
+        }
     }
 }
 
 extern "C" int isc_gate_mix_fwd(const float *z, const float *w, const float *w_bias, const float *v,
                                 const float *s, int B, int A, int D, float *out, float *beta_out,
-                                int64_t beta_ld, void *stream) {
+                                int64_t beta_ld, void *out_hi, void *out_lo, void *stream) {
     if (!z || !w || !v || !s || !out) return ISC_E_NULL;
+    if ((out_hi == nullptr) != (out_lo == nullptr)) return ISC_E_NULL;
     if (B <= 0 || A <= 0 || D <= 0) return ISC_E_SHAPE;
     hipLaunchKernelGGL(gate_mix_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, z, w,
-                       w_bias, v, s, B, A, D, out, beta_out, (long long)beta_ld);
+                       w_bias, v, s, B, A, D, out, beta_out, (long long)beta_ld, static_cast<_Float16 *>(out_hi),
+                       static_cast<_Float16 *>(out_lo));
     ISC_LAUNCH_CHECK();
     return ISC_OK;
 }

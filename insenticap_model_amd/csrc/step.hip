@@ -30,6 +30,9 @@ extern "C" int isc_step_fwd(const isc_step_plan *p, void *stream) {
                     p->h2_hi || p->h2_lo))
         return ISC_E_NULL;
 #define PL(x) (planes ? (x) : nullptr)
+    const bool wplanes = planes && (!has_c || (p->v_hi && p->v_lo)) && (!has_s || (p->s_hi && p->s_lo)) &&
+                         (!gate || (p->f_hi && p->f_lo));
+#define PW(x) (wplanes ? (x) : nullptr)
 
     // att-LSTM over cat[h_lang_prev, fc, xt] (captioner.py:174-175); fc/label/bias are in pre1
     {
@@ -68,31 +71,35 @@ extern "C" int isc_step_fwd(const isc_step_plan *p, void *stream) {
             isc_scan_problem &x = sc[n++];
             x.P = p->att_p; x.V = p->att_e; x.q = p->qa; x.w = p->w_alpha_c; x.w_bias = p->b_alpha_c;
             x.R = p->R; x.A = A; x.D = E; x.out = p->v; x.alpha_out = p->alpha_c; x.alpha_ld = p->alpha_c_ld;
+            x.out_hi = PW(p->v_hi); x.out_lo = PW(p->v_lo);
         }
         if (has_s) {
             isc_scan_problem &x = sc[n++];
             x.P = p->words_p; x.V = p->words_e; x.q = p->qw; x.q2 = p->label_w; x.w = p->w_alpha_s;
             x.w_bias = p->b_alpha_s; x.R = p->Mw; x.A = A; x.D = W; x.out = p->s; x.alpha_out = p->alpha_s;
             x.alpha_ld = p->alpha_s_ld;
+            x.out_hi = PW(p->s_hi); x.out_lo = PW(p->s_lo);
         }
         RET(isc_attn_scan_fwd(sc, n, rows, stream));
     }
     const float *feat = has_c ? p->v : p->s;
+    const void *feat_hi = has_c ? PW(p->v_hi) : PW(p->s_hi), *feat_lo = has_c ? PW(p->v_lo) : PW(p->s_lo);
     if (gate) {  // z += cont2att(v) + senti2att(s); beta, mix (captioner.py:107-117)
         isc_linear_problem x = {};
-        x.seg[0] = seg(p->v, E, p->W_gc, E, E);
-        x.seg[1] = seg(p->s, W, p->W_gs, W, W);
+        x.seg[0] = seg(p->v, E, p->W_gc, E, E, PW(p->v_hi), PW(p->v_lo));
+        x.seg[1] = seg(p->s, W, p->W_gs, W, W, PW(p->s_hi), PW(p->s_lo));
         x.nseg = 2; x.M = rows; x.N = A; x.bias0 = p->b_gc; x.bias1 = p->b_gs; x.ldc = A; x.C = p->z;
         x.accumulate = 1;
         x.splitk_ws = p->splitk_ws; x.splitk_ws_floats = p->splitk_ws_floats;
         RET(isc_linear_fwd(&x, 1, stream));
-        RET(isc_gate_mix_fwd(p->z, p->w_gate, p->b_gate, p->v, p->s, rows, A, E, p->f, p->beta, p->beta_ld, stream));
-        feat = p->f;
+        RET(isc_gate_mix_fwd(p->z, p->w_gate, p->b_gate, p->v, p->s, rows, A, E, p->f, p->beta, p->beta_ld,
+                             PW(p->f_hi), PW(p->f_lo), stream));
+        feat = p->f; feat_hi = PW(p->f_hi); feat_lo = PW(p->f_lo);
     }
     // lang-LSTM over cat[feat, h_att] (captioner.py:180-181) (+ dropout on h_lang, :182)
     {
         isc_lstm_problem l = {};
-        l.seg[0] = seg(feat, E, p->Wih2, ld2, E);
+        l.seg[0] = seg(feat, E, p->Wih2, ld2, E, feat_hi, feat_lo);
         l.seg[1] = seg(p->h1, H, p->Wih2 + E, ld2, H, PL(p->h1_hi), PL(p->h1_lo));
         l.seg[2] = seg(p->h2_prev, H, p->Whh2, H, H, PL(p->h2_prev_hi), PL(p->h2_prev_lo));
         l.nseg = 3; l.M = rows; l.H = H; l.b_ih = p->b_ih2; l.b_hh = p->b_hh2;
@@ -107,6 +114,7 @@ extern "C" int isc_step_fwd(const isc_step_plan *p, void *stream) {
                       p->ld_logits, p->pmax, p->psum, p->pidx, p->out_mask ? nullptr : PL(p->h2_hi),
                       p->out_mask ? nullptr : PL(p->h2_lo), p->splitk_ws, p->splitk_ws_floats, stream));
 #undef PL
+#undef PW
     if (p->apply_logsoftmax) {
         if (!p->logits) return ISC_E_NULL;
         RET(isc_logsoftmax_apply(p->logits, p->ld_logits, rows, V, p->pmax, p->psum, nullptr, stream));

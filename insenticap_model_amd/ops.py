@@ -271,7 +271,14 @@ def logsoftmax_apply(logits, part_max, part_sum, lse_out=None):
                                    part_sum.data_ptr(), ptr(lse_out), stream()), 'isc_logsoftmax_apply')
 
 
-def scan_problem(P, V, q, w, w_bias, out, alpha_out=None, q2=None):
+def _planes_ptrs(planes, like):
+    if planes is None:
+        return None, None
+    assert planes.dtype == torch.float16 and planes.is_contiguous() and planes.shape == (2,) + tuple(like.shape)
+    return planes[0].data_ptr(), planes[1].data_ptr()
+
+
+def scan_problem(P, V, q, w, w_bias, out, alpha_out=None, q2=None, out_planes=None):
     """P [B,R,A], V [B,R,D] contiguous; q/q2 [B,A]; w [A] (or [1,A]); out [B,D];
     alpha_out: [B,R] view with unit inner stride (row stride arbitrary)."""
     s = ScanProblem()
@@ -280,6 +287,7 @@ def scan_problem(P, V, q, w, w_bias, out, alpha_out=None, q2=None):
     s.w_bias = ptr(w_bias)
     s.R, s.A, s.D = P.shape[1], P.shape[2], V.shape[2]
     s.out = out.data_ptr()
+    s.out_hi, s.out_lo = _planes_ptrs(out_planes, out)
     if alpha_out is not None:
         assert alpha_out.stride(1) == 1
         s.alpha_out, s.alpha_ld = alpha_out.data_ptr(), alpha_out.stride(0)
@@ -297,7 +305,7 @@ def attn_scan_fwd(problems, B):
         TIMER.end(e0, 'attn_scan[' + '+'.join('%dx%dx%d' % (B, q.R, q.A) for q in problems) + ']', 0.0, nb)
 
 
-def gate_mix_fwd(z, w, w_bias, v, s, out, beta_out=None):
+def gate_mix_fwd(z, w, w_bias, v, s, out, beta_out=None, out_planes=None):
     lib = _lib.load()
     B, A = z.shape
     D = v.shape[1]
@@ -305,7 +313,8 @@ def gate_mix_fwd(z, w, w_bias, v, s, out, beta_out=None):
     bl = beta_out.stride(0) if beta_out is not None else 0
     e0 = TIMER.begin()
     check(lib.isc_gate_mix_fwd(z.data_ptr(), w.data_ptr(), ptr(w_bias), v.data_ptr(), s.data_ptr(), B, A, D,
-                               out.data_ptr(), ptr(beta_out), bl, stream()), 'isc_gate_mix_fwd')
+                               out.data_ptr(), ptr(beta_out), bl, *_planes_ptrs(out_planes, out), stream()),
+          'isc_gate_mix_fwd')
     TIMER.end(e0, 'gate_mix[%dx%d]' % (B, A), 0.0, 4.0 * B * (A + 3 * D))
 
 
