@@ -222,6 +222,20 @@ __global__ __launch_bounds__(256) void gate_mix_kernel(const float *z, const flo
     acc = wave_sum(acc);
     const float beta = isc_sigmoid(acc + (w_bias ? w_bias[0] : 0.f));
     if (lane == 0 && beta_out) beta_out[(long long)b * beta_ld] = beta;
+    if ((D & 3) == 0) {      // rows are 16-byte aligned (D % 4 == 0, cudaMalloc'd bases): four outputs per lane and pass
+        const float4 *v4 = reinterpret_cast<const float4 *>(v + (long long)b * D);
+        const float4 *s4 = reinterpret_cast<const float4 *>(s + (long long)b * D);
+        float4 *o4 = reinterpret_cast<float4 *>(out + (long long)b * D);
+        for (int d = lane; d < (D >> 2); d += 64) {
+            const float4 a = v4[d], c = s4[d];
+            float4 f;
+            f.x = beta * a.x + (1.0f - beta) * c.x; f.y = beta * a.y + (1.0f - beta) * c.y;
+            f.z = beta * a.z + (1.0f - beta) * c.z; f.w = beta * a.w + (1.0f - beta) * c.w;
+            o4[d] = f;
+            if (out_hi) store_planes4(out_hi, out_lo, (long long)b * D + 4 * d, f);
+        }
+        return;
+    }
     for (int d = lane; d < D; d += 64) {
         const long long o = (long long)b * D + d;
         const float f = beta * v[o] + (1.0f - beta) * s[o];
@@ -239,6 +253,7 @@ extern "C" int isc_gate_mix_fwd(const float *z, const float *w, const float *w_b
                                 int64_t beta_ld, void *out_hi, void *out_lo, void *stream) {
     if (!z || !w || !v || !s || !out) return ISC_E_NULL;
     if ((out_hi == nullptr) != (out_lo == nullptr)) return ISC_E_NULL;
+    if ((D & 3) == 0 && (!isc_aligned16(v) || !isc_aligned16(s) || !isc_aligned16(out))) return ISC_E_ALIGN;
     if (B <= 0 || A <= 0 || D <= 0) return ISC_E_SHAPE;
     hipLaunchKernelGGL(gate_mix_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, z, w,
                        w_bias, v, s, B, A, D, out, beta_out, (long long)beta_ld, static_cast<_Float16 *>(out_hi),

@@ -1211,6 +1211,153 @@ __global__ __launch_bounds__(256, 2) void gemm_h3_kernel(const DevLaunch L) {
     }
 }
 
+// H3 on a 256 x 128 tile with EIGHT waves (32 x 128 accumulators, the same fragment code) and three 48 KB buffers:
+// one workgroup per CU keeps two chunks of DMA in flight (96 KB against the 64 KB of two 128-row workgroups with one
+// chunk each) - these launches are bound by the DMA round trip, not by the matrix pipe: [4096 x 9984 x 512] 178 -> 137 us,
+// [4096 x 2048 x 1536] 97 -> 76 us (tools/h3_gemm_lab.hip).  Used when the launch has >= 224 such tiles.
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_h3x_kernel(const DevLaunch L) {
+    constexpr int BM = 256, BN = 128, TN = 4;
+    constexpr int PA = 256 * 64, PB = 128 * 64;         // bytes per A / W plane tile
+    constexpr int ST = 2 * PA + 2 * PB;                 // bytes per buffer (48 KB)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char *lds = reinterpret_cast<char *>(smem);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wm = tid >> 6;
+    int pi, tm, tn, ks, ksplit;
+    map_tile(L, pi, tm, tn, ks, ksplit);
+    const DevProb &P = L.p[pi];
+    const int M = P.M, N = P.N, Kp = P.Kp;
+    const int row0 = tm * BM, col0 = tn * BN;
+
+    // staging pieces of 16 rows x 64 B: A planes 16 pieces (two per wave), W planes 8 (one per wave).  A by K-segment.
+    const _Float16 *src[6];
+    int arow[2], aq[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int t = 16 * (2 * wm + i) + (lane >> 2);
+        int ar = row0 + t;
+        arow[i] = ar < M ? ar : M - 1;
+        aq[i] = ((lane & 3) ^ ((t >> 2) & 3)) * 8;
+    }
+    {
+        const int t = 16 * wm + (lane >> 2);
+        const int q = (lane & 3) ^ ((t >> 2) & 3);
+        long long wr;
+        if (EPI == EPI_LSTM) {
+            wr = (long long)(t >> 5) * P.H + tn * 32 + (t & 31);
+        } else {
+            const int c = col0 + t;
+            wr = c < N ? c : N - 1;
+        }
+        src[4] = P.Wh + wr * Kp + q * 8;
+        src[5] = P.Wl + wr * Kp + q * 8;
+    }
+    int cs = 0, ck = 0, segK = 0;
+    auto set_aseg = [&](int si) __attribute__((always_inline)) {
+        const DevASeg a = P.ap[si];
+        segK = a.K;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            src[0 + i] = a.hi + (long long)arow[i] * a.ld + aq[i];
+            src[2 + i] = a.lo + (long long)arow[i] * a.ld + aq[i];
+        }
+    };
+    set_aseg(0);
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds);
+    const unsigned wv = __builtin_amdgcn_readfirstlane((unsigned)wm);
+    auto dma1 = [&](unsigned dst, const _Float16 *&p) __attribute__((always_inline)) {
+        asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(dst), "v"(p) : "memory");
+        p += 32;
+    };
+    auto stage = [&](int buf) __attribute__((always_inline)) {
+        const unsigned b = lds0 + buf * ST;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            dma1(b + (2 * wv + i) * 1024, src[0 + i]);
+            dma1(b + PA + (2 * wv + i) * 1024, src[2 + i]);
+        }
+        dma1(b + 2 * PA + wv * 1024, src[4]);
+        dma1(b + 2 * PA + PB + wv * 1024, src[5]);
+        ck += 32;
+        if (ck >= segK) {
+            ck = 0;
+            if (++cs < P.nap) set_aseg(cs);
+        }
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+
+    f32x16 acc0[TN], acc1[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[j][r] = 0.f; acc1[j][r] = 0.f; }
+
+    const int fr = lane & 31, fh = lane >> 5, fsw = (fr >> 2) & 3;
+    h8 a1[2], a2[2], b1[2][TN], b2[2][TN];
+    auto lfrag = [&](int buf, auto ksc, auto setc) __attribute__((always_inline)) {
+        constexpr int kk = decltype(ksc)::value, S = decltype(setc)::value;
+        const int slot = ((2 * kk + fh) ^ fsw) * 16;
+        const char *base = lds + buf * ST;
+        const int ra = (wm * 32 + fr) * 64 + slot;
+        a1[S] = *reinterpret_cast<const h8 *>(base + ra);
+        a2[S] = *reinterpret_cast<const h8 *>(base + PA + ra);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int rb = (j * 32 + fr) * 64 + slot;
+            b1[S][j] = *reinterpret_cast<const h8 *>(base + 2 * PA + rb);
+            b2[S][j] = *reinterpret_cast<const h8 *>(base + 2 * PA + PB + rb);
+        }
+    };
+    auto mma = [&](auto setc) __attribute__((always_inline)) {
+        constexpr int S = decltype(setc)::value;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            acc0[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[S], b1[S][j], acc0[j], 0, 0, 0);
+            acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[S], b2[S][j], acc1[j], 0, 0, 0);
+            acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2[S], b1[S][j], acc1[j], 0, 0, 0);
+        }
+    };
+    // three buffers, two chunks in flight (6 DMAs per wave and chunk): vmcnt(6) leaves the younger chunk outstanding
+    const int nchunks = Kp / 32;
+    stage(0);
+    if (nchunks > 1) stage(1);
+    if (nchunks > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    lfrag(0, I0{}, I0{});
+    int cur = 0;
+    for (int c = 0; c < nchunks; ++c) {
+        const int nxt = cur == 2 ? 0 : cur + 1, nn = nxt == 2 ? 0 : nxt + 1;
+        if (c + 2 < nchunks) stage(nn);           // buffer nn was last read in front of the previous barrier
+        lfrag(cur, I1{}, I1{});
+        mma(I0{});
+        if (c + 1 < nchunks) {
+            if (c + 2 < nchunks) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            lfrag(nxt, I0{}, I0{});
+        }
+        mma(I1{});
+        cur = nxt;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc0[j][r] = fmaf(acc1[j][r], 1.f / 2048.f, acc0[j][r]);
+
+    if constexpr (EPI == EPI_VOCAB) {
+        epi_vocab_frag<TN, 1, BM>(P, acc0, wm * 32, 0, 0, lane, row0, col0, tn, smem);
+    } else if constexpr (EPI == EPI_LSTM) {
+        epi_lstm_frag(P, acc0, wm * 32, lane, row0, tn);
+    } else {
+        epi_linear_frag<4>(P, acc0, wm * 32, 0, lane, row0, col0);
+    }
+}
+
 // H3 on the 64 x 128 geometry (2 x 2 waves, 32 x 64 accumulators each; linear epilogue): launches whose 128-row
 // tiling would leave CUs idle - the per-step projections with N = 512 at 4096 rows are 256 tiles of 64 x 128.
 // Per chunk: A planes 2 x 4 KB, W planes 2 x 8 KB; four buffers = 96 KB, one workgroup per CU.
@@ -1871,6 +2018,36 @@ static const H3WEntry *h3w_find(const DevProb &p) {
     return nullptr;
 }
 
+template <int EPI>
+static int launch_h3x(const DevLaunch &L, hipStream_t st) {
+    constexpr size_t lds = 3 * (2 * 256 * 64 + 2 * 128 * 64);             // 147456: one workgroup per CU
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_h3x_kernel<EPI>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_h3x_kernel<EPI>), dim3(L.total_tiles), dim3(512), lds, st, L);
+    ISC_LAUNCH_CHECK();
+    return ISC_OK;
+}
+
+// 256-row tiles when they fill the chip, else the 128-row kernel.  The vocabulary projection stays on the 128-row
+// kernel: its epilogue (per-row softmax statistics, ~3k VALU instructions per wave) is as long as its 16-chunk main
+// loop, and only a second, out-of-phase workgroup on the CU overlaps the two (174 us on the 256-row tile vs 162 us).
+template <int EPI>
+static int launch_h3_big(DevLaunch &L, hipStream_t st) {
+    long long t256 = 0;
+    for (int i = 0; i < L.nprob; ++i) t256 += (long long)((L.p[i].M + 255) / 256) * ((L.p[i].N + 127) / 128);
+    if (EPI != EPI_VOCAB && t256 >= 224) {
+        finish_tiling(L, 3);
+        return launch_h3x<EPI>(L, st);
+    }
+    finish_tiling(L, 4);
+    return launch_h3<EPI>(L, st);
+}
+
 static int launch_h3m(const DevLaunch &L, hipStream_t st) {
     constexpr size_t lds = 4 * (2 * 64 * 64 + 2 * 128 * 64);             // 98304: one workgroup per CU
     static bool attr_set = false;
@@ -1982,8 +2159,7 @@ static int h3_linear_chunked(const DevProb &p0, float *ws, long long ws_floats, 
         pl.add_a(p);
         int rc = pl.launch(st);
         if (rc) return rc;
-        finish_tiling(L, 4);
-        rc = launch_h3<EPI_LINEAR>(L, st);
+        rc = launch_h3_big<EPI_LINEAR>(L, st);
         if (rc) return rc;
         ++g_h3_launches;
     }
@@ -2054,8 +2230,7 @@ static int try_h3(DevLaunch &L, float *ws, long long ws_floats, hipStream_t st, 
         finish_tiling(L, 1);
         rc = launch_h3m(L, st);
     } else {
-        finish_tiling(L, 4);
-        rc = launch_h3<EPI>(L, st);
+        rc = launch_h3_big<EPI>(L, st);
     }
     ++g_h3_launches;
     return 1;

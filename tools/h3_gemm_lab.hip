@@ -163,6 +163,207 @@ __global__ __launch_bounds__(256, 2) void gemm_h3(const _Float16 *Ah, const _Flo
             }
 }
 
+// variant X: 256x128 tile, 8 waves (each 32x128), 3 buffers of 48 KB, two chunks in flight, one workgroup per CU
+__global__ __launch_bounds__(512) void gemm_h3x(const _Float16 *Ah, const _Float16 *Al, const _Float16 *Wh,
+                                                const _Float16 *Wl, float *C, int M, int N, int K) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int PA = 256 * 64, PB = 128 * 64, ST = 2 * PA + 2 * PB;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    int tm, tn;
+    tile_coords(M / 256, N / 128, tm, tn);
+    const int row0 = tm * 256, col0 = tn * 128;
+    f32x16 acc0[4], acc1[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[j][r] = 0.f; acc1[j][r] = 0.f; }
+    const _Float16 *src[6];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = 16 * (2 * w + i) + (lane >> 2);
+        const int q = (lane & 3) ^ ((r >> 2) & 3);
+        src[0 + i] = Ah + (long long)(row0 + r) * K + q * 8;
+        src[2 + i] = Al + (long long)(row0 + r) * K + q * 8;
+    }
+    {
+        const int r = 16 * w + (lane >> 2);
+        const int q = (lane & 3) ^ ((r >> 2) & 3);
+        src[4] = Wh + (long long)(col0 + r) * K + q * 8;
+        src[5] = Wl + (long long)(col0 + r) * K + q * 8;
+    }
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)smem);
+    const unsigned wv = __builtin_amdgcn_readfirstlane((unsigned)w);
+    auto dma1 = [&](unsigned dst, const _Float16 *&p) __attribute__((always_inline)) {
+        asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(dst), "v"(p) : "memory");
+        p += 32;
+    };
+    auto stage = [&](int buf) __attribute__((always_inline)) {
+        const unsigned b = lds0 + buf * ST;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            dma1(b + (2 * wv + i) * 1024, src[0 + i]);
+            dma1(b + PA + (2 * wv + i) * 1024, src[2 + i]);
+        }
+        dma1(b + 2 * PA + wv * 1024, src[4]);
+        dma1(b + 2 * PA + PB + wv * 1024, src[5]);
+    };
+    const int fr = lane & 31, fh = lane >> 5, fsw = (fr >> 2) & 3;
+    h8 a1[2], a2[2], b1[2][4], b2[2][4];
+    auto lfrag = [&](int buf, auto ksc, auto setc) __attribute__((always_inline)) {
+        constexpr int ks = decltype(ksc)::value, S = decltype(setc)::value;
+        const int slot = ((2 * ks + fh) ^ fsw) * 16;
+        const char *base = smem + buf * ST;
+        const int ra = (w * 32 + fr) * 64 + slot;
+        a1[S] = *reinterpret_cast<const h8 *>(base + ra);
+        a2[S] = *reinterpret_cast<const h8 *>(base + PA + ra);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int rb = (j * 32 + fr) * 64 + slot;
+            b1[S][j] = *reinterpret_cast<const h8 *>(base + 2 * PA + rb);
+            b2[S][j] = *reinterpret_cast<const h8 *>(base + 2 * PA + PB + rb);
+        }
+    };
+    auto mma = [&](auto setc) __attribute__((always_inline)) {
+        constexpr int S = decltype(setc)::value;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            acc0[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[S], b1[S][j], acc0[j], 0, 0, 0);
+            acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[S], b2[S][j], acc1[j], 0, 0, 0);
+            acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2[S], b1[S][j], acc1[j], 0, 0, 0);
+        }
+    };
+    const int n = K / 32;
+    auto wait_for = [&](int in_flight) __attribute__((always_inline)) {
+        if (in_flight >= 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    stage(0);
+    if (n > 1) stage(1);
+    wait_for(n > 1 ? 1 : 0);
+    __syncthreads();
+    lfrag(0, I0{}, I0{});
+    int cur = 0;
+    for (int c = 0; c < n; ++c) {
+        const int nxt = cur == 2 ? 0 : cur + 1, nn = nxt == 2 ? 0 : nxt + 1;
+        if (c + 2 < n) stage(nn);
+        lfrag(cur, I1{}, I1{});
+        mma(I0{});
+        if (c + 1 < n) {
+            wait_for(c + 2 < n ? 1 : 0);
+            __syncthreads();
+            lfrag(nxt, I0{}, I0{});
+        }
+        mma(I1{});
+        cur = nxt;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = row0 + w * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const int col = col0 + j * 32 + (lane & 31);
+            C[(long long)row * N + col] = acc0[j][r] + acc1[j][r] * (1.f / 2048.f);
+        }
+}
+
+// variant 7: 128x128, 4 waves (32x128), 16-deep sub-chunks of 16 KB, four buffers, three sub-chunks in flight, 2 WG/CU
+__global__ __launch_bounds__(256, 2) void gemm_h3s(const _Float16 *Ah, const _Float16 *Al, const _Float16 *Wh,
+                                                   const _Float16 *Wl, float *C, int M, int N, int K) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int PL = 128 * 32, ST = 4 * PL;      // 4 KB planes, 16 KB per buffer
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    int tm, tn;
+    tile_coords(M / 128, N / 128, tm, tn);
+    const int row0 = tm * 128, col0 = tn * 128;
+    f32x16 acc0[4], acc1[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[j][r] = 0.f; acc1[j][r] = 0.f; }
+    // piece w of each plane: rows 32w + (lane>>1), slot lane&1 holds k-octet (lane&1) ^ ((row>>3)&1)
+    const _Float16 *src[4];
+    {
+        const int r = 32 * w + (lane >> 1);
+        const int q = (lane & 1) ^ ((r >> 3) & 1);
+        src[0] = Ah + (long long)(row0 + r) * K + q * 8;
+        src[1] = Al + (long long)(row0 + r) * K + q * 8;
+        src[2] = Wh + (long long)(col0 + r) * K + q * 8;
+        src[3] = Wl + (long long)(col0 + r) * K + q * 8;
+    }
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)smem + w * 1024);
+    auto stage = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off"
+                         :: "s"(lds0 + buf * ST + p * PL), "v"(src[p]) : "memory");
+            src[p] += 16;
+        }
+    };
+    const int fr = lane & 31, fh = lane >> 5;
+    h8 a1[2], a2[2], b1[2][4], b2[2][4];
+    auto lfrag = [&](int buf, auto setc) __attribute__((always_inline)) {
+        constexpr int S = decltype(setc)::value;
+        const int slot = (fh ^ ((fr >> 3) & 1)) * 16;
+        const char *base = smem + buf * ST;
+        const int ra = (w * 32 + fr) * 32 + slot;
+        a1[S] = *reinterpret_cast<const h8 *>(base + ra);
+        a2[S] = *reinterpret_cast<const h8 *>(base + PL + ra);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int rb = (j * 32 + fr) * 32 + slot;
+            b1[S][j] = *reinterpret_cast<const h8 *>(base + 2 * PL + rb);
+            b2[S][j] = *reinterpret_cast<const h8 *>(base + 3 * PL + rb);
+        }
+    };
+    auto mma = [&](auto setc) __attribute__((always_inline)) {
+        constexpr int S = decltype(setc)::value;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            acc0[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[S], b1[S][j], acc0[j], 0, 0, 0);
+            acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[S], b2[S][j], acc1[j], 0, 0, 0);
+            acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2[S], b1[S][j], acc1[j], 0, 0, 0);
+        }
+    };
+    const int n = K / 16;                           // sub-chunks (n >= 4 and even assumed)
+    auto wait_for = [&](int in_flight) __attribute__((always_inline)) {
+        if (in_flight >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (in_flight == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    stage(0); stage(1); stage(2);
+    wait_for(2);
+    __syncthreads();
+    lfrag(0, I0{});
+    for (int c = 0; c < n; c += 2) {
+        // sub-chunk c (set 0)
+        if (c + 3 < n) stage((c + 3) & 3);
+        {
+            const int last = n - 1 < c + 3 ? n - 1 : c + 3;
+            wait_for(last - (c + 1));
+            __syncthreads();
+            lfrag((c + 1) & 3, I1{});
+        }
+        mma(I0{});
+        // sub-chunk c+1 (set 1)
+        if (c + 4 < n) stage((c + 4) & 3);
+        if (c + 2 < n) {
+            const int last = n - 1 < c + 4 ? n - 1 : c + 4;
+            wait_for(last - (c + 2));
+            __syncthreads();
+            lfrag((c + 2) & 3, I0{});
+        }
+        mma(I1{});
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = row0 + w * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const int col = col0 + j * 32 + (lane & 31);
+            C[(long long)row * N + col] = acc0[j][r] + acc1[j][r] * (1.f / 2048.f);
+        }
+}
+
 // plain fp32 reference GEMM (one thread per output, fmaf chain) for the accuracy comparison
 __global__ void gemm_f32_ref(const float *A, const float *W, float *C, int M, int N, int K, const int *rows, int nrows) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x, ri = blockIdx.y;
@@ -199,8 +400,12 @@ static void run_shape(int M, int N, int K, float wscale, int dist) {
     CK(hipFuncSetAttribute((const void *)gemm_h3<2, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 32768));
     CK(hipFuncSetAttribute((const void *)gemm_h3<3, 1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 32768));
     CK(hipFuncSetAttribute((const void *)gemm_h3<2, 1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 32768));
-    for (int nb = 2; nb <= 5; ++nb) {
+    CK(hipFuncSetAttribute((const void *)gemm_h3x, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 49152));
+    CK(hipFuncSetAttribute((const void *)gemm_h3s, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+    for (int nb = 4; nb <= 7; ++nb) {
         auto launch = [&]() {
+            if (nb == 7) { gemm_h3s<<<grid, 256, 65536>>>(Ah, Al, Wh, Wl, dC, M, N, K); return; }
+            if (nb == 6) { gemm_h3x<<<(M / 256) * (N / 128), 512, 3 * 49152>>>(Ah, Al, Wh, Wl, dC, M, N, K); return; }
             if (nb == 2) gemm_h3<2, 2, 2><<<grid, 256, 2 * 32768>>>(Ah, Al, Wh, Wl, dC, M, N, K);
             else if (nb == 3) gemm_h3<3, 2, 2><<<grid, 256, 3 * 32768>>>(Ah, Al, Wh, Wl, dC, M, N, K);
             else if (nb == 4) gemm_h3<2, 1, 4><<<grid, 256, 2 * 32768>>>(Ah, Al, Wh, Wl, dC, M, N, K);
@@ -215,7 +420,7 @@ static void run_shape(int M, int N, int K, float wscale, int dist) {
         CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         const double us = ms * 1000.0 / it;
-        printf("M=%d N=%d K=%d  h3 v%d (2,3: 2x2 waves nbuf 2,3; 4,5: 4x1 waves): %.1f us  %.1f TF(fp32-equivalent)  %.1f TF(f16 executed)\n", M, N, K, nb, us,
+        printf("M=%d N=%d K=%d  h3 v%d (2,3: 2x2 waves nbuf 2,3; 4,5: 4x1 waves; 6: 256x128 8 waves 3 buf; 7: 128x128 16-deep x4 buf): %.1f us  %.1f TF(fp32-equivalent)  %.1f TF(f16 executed)\n", M, N, K, nb, us,
                2.0 * M * N * K / us * 1e-6, 6.0 * M * N * K / us * 1e-6);
     }
     // split cost
