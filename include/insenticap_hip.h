@@ -179,6 +179,12 @@ typedef struct {
     float *alpha_out; /* [B,*] row stride alpha_ld, R values written per row */
     int64_t alpha_ld;
     void *out_hi, *out_lo; /* optional: f16 planes of `out` ([B,D] each, see isc_seg.A_hi) */
+    /* Optional gather mode: region r of row b is row row_ids[b*row_ids_ld + r] of P / V, which are then tables
+     * [n_rows, A] / [n_rows, D] shared by all rows.  The sentiment words of captioner.py:307-312 in eval mode:
+     * word_embed(id) and senti2att(word_embed(id)) depend on the id alone, so two vocabulary-sized tables
+     * (cache-resident) replace the per-caption [B,M,.] copies that were streamed from HBM every step. */
+    const int64_t *row_ids;
+    int64_t row_ids_ld;
 } isc_scan_problem;
 
 int isc_attn_scan_fwd(const isc_scan_problem *probs_host, int n_prob, int B, void *stream);
@@ -305,6 +311,10 @@ typedef struct {
     /* Optional plane workspace of the step's own intermediates v, s, f ([rows,E] f16 each; used with the state
      * planes): the scans and the gate write them, the gate sum and the lang-LSTM read them. */
     void *v_hi, *v_lo, *s_hi, *s_lo, *f_hi, *f_lo;
+    /* Optional gather mode of the sentiment-word scan (isc_scan_problem.row_ids): words_p / words_e are then the
+     * [V,A] / [V,W] tables and words_ids [rows, Mw] (row stride words_ids_ld) the word ids incl. the leading <PAD>. */
+    const int64_t *words_ids;
+    int64_t words_ids_ld;
 } isc_step_plan;
 
 int isc_step_fwd(const isc_step_plan *plan_host, void *stream);

@@ -43,7 +43,8 @@ class ScanProblem(C.Structure):
     _fields_ = [('P', C.c_void_p), ('V', C.c_void_p), ('q', C.c_void_p), ('q2', C.c_void_p),
                 ('w', C.c_void_p), ('w_bias', C.c_void_p), ('R', C.c_int32), ('A', C.c_int32),
                 ('D', C.c_int32), ('_pad', C.c_int32), ('out', C.c_void_p), ('alpha_out', C.c_void_p),
-                ('alpha_ld', C.c_int64), ('out_hi', C.c_void_p), ('out_lo', C.c_void_p)]
+                ('alpha_ld', C.c_int64), ('out_hi', C.c_void_p), ('out_lo', C.c_void_p),
+                ('row_ids', C.c_void_p), ('row_ids_ld', C.c_int64)]
 
 
 class ScanBwdProblem(C.Structure):
@@ -72,7 +73,7 @@ class StepPlan(C.Structure):
                  ('pmax', C.c_void_p), ('psum', C.c_void_p), ('pidx', C.c_void_p),
                  ('splitk_ws', C.c_void_p), ('splitk_ws_floats', C.c_int64)] +
                 _f('h1_prev_hi h1_prev_lo h2_prev_hi h2_prev_lo h1_hi h1_lo h2_hi h2_lo '
-                   'v_hi v_lo s_hi s_lo f_hi f_lo', C.c_void_p))
+                   'v_hi v_lo s_hi s_lo f_hi f_lo words_ids', C.c_void_p) + [('words_ids_ld', C.c_int64)])
 
 
 class StepBwdPlan(C.Structure):

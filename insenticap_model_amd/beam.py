@@ -132,7 +132,8 @@ def beam_search_batch(cap, fc_feats, att_feats, senti_words, senti_labels, beam,
     p = cap._p()
     n_img = fc_feats.shape[0]
     P = cap._prologue(p, 'beam', fc_feats, att_feats, None, senti_words,
-                      senti_labels if senti_words is not None else None, want_table='cached')
+                      senti_labels if senti_words is not None else None, want_table='cached',
+                      words_table=getattr(cap, 'words_table', True))
     dev = cap._dev
     H, Wd, V = cap.att_lstm.hidden_size, cap.settings['word_emb_dim'], cap.vocab_size
     rows = n_img * beam
@@ -144,7 +145,11 @@ def beam_search_batch(cap, fc_feats, att_feats, senti_words, senti_labels, beam,
     Pb = type(P)()
     Pb.B, Pb.R, Pb.Mw = rows, P.R, P.Mw
     for name in ('fc_e', 'att_e3', 'att_p3', 'words_e3', 'words_p3', 'label_e', 'label_w', 'pre1'):
-        setattr(Pb, name, expand(getattr(P, name)))
+        if P.words_ids is not None and name in ('words_e3', 'words_p3'):
+            setattr(Pb, name, getattr(P, name))           # shared [V,.] tables: only the ids are per row
+        else:
+            setattr(Pb, name, expand(getattr(P, name)))
+    Pb.words_ids = expand(P.words_ids)
     Pb.tab = P.tab
     ws = cap._alloc_step_ws(rows, Pb)
     # recurrent state as ONE tensor [h|c, layer, row, H] per buffer: the per-step beam re-ordering is then a

@@ -46,6 +46,8 @@ class _Pro:
     att_p3 = None    # [B,R,A] att2att projection
     words_e3 = None  # [B,M,W] embedded sentiment words
     words_p3 = None  # [B,M,A]
+    words_ids = None  # gather mode: [B,M] int64 ids (leading <PAD> included); words_e3 / words_p3 are then the
+                      # [V,W] / [V,A] tables relu(Emb) and senti2att(relu(Emb)) shared by all rows
     label_e = None   # [B,W]   sentiment-label embedding (added to every xt)
     label_w = None   # [B,A]   label2word(label_e): step-invariant term of the senti attention
     pre1 = None      # [B,4H]  fc_e W_fc^T + label_e W_x^T + b_ih + b_hh: step-invariant att-LSTM input
@@ -156,8 +158,9 @@ class Captioner(nn.Module):
 
     # ------------------------------------------------------------------ prologue
     def _prologue(self, p, mode, fc=None, att=None, cpt_words=None, senti_words=None, senti_labels=None,
-                  masks=None, want_table=False):
-        """want_table: False | 'cached' (use the embedding table only if already built) | 'build'."""
+                  masks=None, want_table=False, words_table=False):
+        """want_table: False | 'cached' (use the embedding table only if already built) | 'build'.
+        words_table: serve the sentiment words from the vocabulary-sized tables (no dropout on them, no autograd)."""
         P = _Pro()
         st = self.settings
         E, A, Wd = st['feat_emb_dim'], st['att_hid_dim'], st['word_emb_dim']
@@ -227,6 +230,12 @@ class Captioner(nn.Module):
             P.Mw = sw.shape[1] + 1
             m, sc = mask_for('words', B * P.Mw, Wd)
             P.sw_ids, P.m_words, P.sc = sw, m, sc
+        if senti_words is not None and words_table and m is None:
+            # captioner.py:307-312 without dropout: word_embed(id) and senti2att(word_embed(id)) are functions of the
+            # id alone -> two [V,.] tables (41 MB, cache-resident) instead of [B,M,.] copies re-read every step
+            P.words_e3, P.words_p3 = self._senti_tables(p)
+            P.words_ids = torch.cat([sw.new_full((B, 1), self.pad_id), sw], dim=1).contiguous()
+        elif senti_words is not None:
             words_e = self._new(B * P.Mw, Wd)
             ops.embed_senti_words_fwd(p['word_embed.0.weight'], sw, self.pad_id, words_e, m, sc)
             words_p = self._new(B * P.Mw, A)
@@ -247,6 +256,21 @@ class Captioner(nn.Module):
         if want_table:
             P.tab = self._embedding_table(p, build=(want_table == 'build'))
         return P
+
+    def _senti_tables(self, p):
+        """(relu(Emb) [V,W], relu(senti2att(relu(Emb))) [V,A]), cached until the embedding or senti2att change."""
+        emb, W2, b2 = p['word_embed.0.weight'], p['senti2att.0.weight'], p['senti2att.0.bias']
+        key = (emb.data_ptr(), emb._version, W2.data_ptr(), W2._version, b2.data_ptr(), b2._version, ops.WEIGHT_EPOCH)
+        cached = getattr(self, '_senti_tab_cache', None)
+        if cached is not None and cached[0] == key:
+            return cached[1]
+        V, Wd, A = self.vocab_size, self.settings['word_emb_dim'], self.settings['att_hid_dim']
+        act = self._new(V, Wd)
+        ops.embed_relu_fwd(emb, torch.arange(V, dtype=torch.int64, device=self._dev), act)
+        proj = self._new(V, A)
+        ops.linear_fwd([ops.linear_problem([(act, W2)], proj, b2, relu=True)])
+        self._senti_tab_cache = (key, (act, proj))
+        return act, proj
 
     def _embedding_table(self, p, build):
         """relu(Emb) W_x^T [V,4H], cached until the embedding or the att-LSTM weights change
@@ -314,6 +338,8 @@ class Captioner(nn.Module):
             if t is not None:
                 assert t.is_contiguous()
                 setattr(pl, field, t.data_ptr())
+        if P.words_ids is not None:
+            pl.words_ids, pl.words_ids_ld = P.words_ids.data_ptr(), P.words_ids.stride(0)
         ws = ops.splitk_ws(self._dev)
         pl.splitk_ws, pl.splitk_ws_floats = ws.data_ptr(), ws.numel()
         return pl
@@ -412,7 +438,7 @@ class Captioner(nn.Module):
             scans.append(ops.scan_problem(P.words_p3, P.words_e3, ws['qw'],
                                           p['attention.senti_att.word_alpha.weight'],
                                           p['attention.senti_att.word_alpha.bias'], ws['s'], alpha_s,
-                                          q2=P.label_w, out_planes=wp('s')))
+                                          q2=P.label_w, out_planes=wp('s'), row_ids=P.words_ids))
         gate = has_cont and has_senti
         if gate:   # the h2att(h1) term of the gate rides in the same launch as the two projections
             probs.append(ops.linear_problem([(h1, p['attention.h2att.weight'], pn(0))], ws['z'],
@@ -609,7 +635,7 @@ class Captioner(nn.Module):
         if not torch.is_grad_enabled() or not any(q.requires_grad for q in self.parameters()):
             want = 'build' if n_rows * T >= self.vocab_size // 4 else 'cached'
         P = self._prologue(p, 'rl', fc_feats, att_feats, cpt_words, senti_words, senti_labels, masks,
-                           want_table=want)
+                           want_table=want, words_table=bool(want) and getattr(self, 'words_table', True))
         ops.TIMER.armed, ops.TIMER.phase = False, 'step'
         B, V = P.B, self.vocab_size
         H, Wd = self.att_lstm.hidden_size, self.settings['word_emb_dim']

@@ -23,6 +23,9 @@ struct DevScan {
     float *out, *alpha_out;
     long long alpha_ld;
     _Float16 *out_hi, *out_lo;
+    const int64_t *ids;        // gather mode: region r of row b = row ids[b*ids_ld + r] of the P / V tables
+    long long ids_ld;
+    int rid_off;               // float offset of the row-id staging area in dynamic LDS
 };
 struct DevScanLaunch {
     DevScan p[2];
@@ -51,6 +54,14 @@ __global__ __launch_bounds__(256) void attn_scan_kernel(const DevScanLaunch L) {
     const int R = S.R, A = S.A, D = S.D;
     float *sc = smem;                      // [R] scores -> alphas
     float *part = smem + ((R + 3) & ~3);   // [ngrp][D] partial weighted sums
+    // gather mode (sentiment words in eval mode: features are rows of two vocabulary-sized tables that stay
+    // cache-resident, instead of [B,R,.] copies streamed from HBM every step): row ids of this caption in LDS
+    int *rid = reinterpret_cast<int *>(smem + S.rid_off);
+    const bool gather = S.ids != nullptr;
+    if (gather) {
+        for (int r = tid; r < R; r += 256) rid[r] = (int)S.ids[(long long)b * S.ids_ld + r];
+        __syncthreads();
+    }
 
     // ---- phase 1: scores
     const int na4 = A >> 2;
@@ -70,7 +81,7 @@ __global__ __launch_bounds__(256) void attn_scan_kernel(const DevScanLaunch L) {
             wv[i] = qv[i];
         }
     }
-    const float4 *Pb = reinterpret_cast<const float4 *>(S.P + (long long)b * R * A);
+    const float4 *Pb = reinterpret_cast<const float4 *>(gather ? S.P : S.P + (long long)b * R * A);
     const float w_bias = S.w_bias ? S.w_bias[0] : 0.f;
     // three regions per wave-iteration: their 3*NA 16-byte loads are issued back to back (6 KB in flight
     // per wave instead of 2) and the three butterfly reductions interleave
@@ -82,7 +93,8 @@ __global__ __launch_bounds__(256) void attn_scan_kernel(const DevScanLaunch L) {
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
                 const int a4 = lane + 64 * i;
-                p[u][i] = (r < R && a4 < na4) ? Pb[(long long)r * na4 + a4] : make_float4(0.f, 0.f, 0.f, 0.f);
+                const long long pr = (r < R && gather) ? rid[r] : r;
+                p[u][i] = (r < R && a4 < na4) ? Pb[pr * na4 + a4] : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
         float acc[3];
@@ -125,7 +137,7 @@ __global__ __launch_bounds__(256) void attn_scan_kernel(const DevScanLaunch L) {
 
     // ---- phase 3: weighted sum
     const int nd4 = D >> 2;
-    const float4 *Vb = reinterpret_cast<const float4 *>(S.V + (long long)b * R * D);
+    const float4 *Vb = reinterpret_cast<const float4 *>(gather ? S.V : S.V + (long long)b * R * D);
     if (nd4 <= 256) {
         const int ngrp = 256 / nd4;             // region groups working in parallel
         const int d4 = tid % nd4, grp = tid / nd4;
@@ -140,7 +152,7 @@ __global__ __launch_bounds__(256) void attn_scan_kernel(const DevScanLaunch L) {
                 for (int u = 0; u < 6; ++u) {
                     const int r = r0 + u * ngrp;
                     const int rc = r < R ? r : R - 1;
-                    v[u] = Vb[(long long)rc * nd4 + d4];
+                    v[u] = Vb[(long long)(gather ? rid[rc] : rc) * nd4 + d4];
                     a[u] = r < R ? sc[rc] : 0.f;
                 }
 #pragma unroll
@@ -165,7 +177,7 @@ __global__ __launch_bounds__(256) void attn_scan_kernel(const DevScanLaunch L) {
             float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
             for (int r = 0; r < R; ++r) {
                 const float a = sc[r];
-                const float4 v = Vb[(long long)r * nd4 + d4];
+                const float4 v = Vb[(long long)(gather ? rid[r] : r) * nd4 + d4];
                 o.x += a * v.x; o.y += a * v.y; o.z += a * v.z; o.w += a * v.w;
             }
             reinterpret_cast<float4 *>(S.out + (long long)b * D)[d4] = o;
@@ -195,7 +207,9 @@ extern "C" int isc_attn_scan_fwd(const isc_scan_problem *pr, int n_prob, int B, 
         if (q.A > maxA) maxA = q.A;
         const int nd4 = q.D / 4;
         const size_t part = nd4 <= 256 ? (size_t)(256 / nd4) * q.D : 0;
-        const size_t need = (((size_t)q.R + 3) & ~(size_t)3) + part;
+        size_t need = (((size_t)q.R + 3) & ~(size_t)3) + part;
+        d.ids = q.row_ids; d.ids_ld = q.row_ids_ld; d.rid_off = (int)need;
+        if (q.row_ids) need += ((size_t)q.R + 3) & ~(size_t)3;
         if (need > lds) lds = need;
     }
     lds *= sizeof(float);

@@ -79,6 +79,7 @@ extern "C" int isc_step_fwd(const isc_step_plan *p, void *stream) {
             x.w_bias = p->b_alpha_s; x.R = p->Mw; x.A = A; x.D = W; x.out = p->s; x.alpha_out = p->alpha_s;
             x.alpha_ld = p->alpha_s_ld;
             x.out_hi = PW(p->s_hi); x.out_lo = PW(p->s_lo);
+            x.row_ids = p->words_ids; x.row_ids_ld = p->words_ids_ld;
         }
         RET(isc_attn_scan_fwd(sc, n, rows, stream));
     }

@@ -278,14 +278,21 @@ def _planes_ptrs(planes, like):
     return planes[0].data_ptr(), planes[1].data_ptr()
 
 
-def scan_problem(P, V, q, w, w_bias, out, alpha_out=None, q2=None, out_planes=None):
+def scan_problem(P, V, q, w, w_bias, out, alpha_out=None, q2=None, out_planes=None, row_ids=None):
     """P [B,R,A], V [B,R,D] contiguous; q/q2 [B,A]; w [A] (or [1,A]); out [B,D];
-    alpha_out: [B,R] view with unit inner stride (row stride arbitrary)."""
+    alpha_out: [B,R] view with unit inner stride (row stride arbitrary).
+    row_ids (gather mode): int64 [B,R]; P / V are then tables [n,A] / [n,D] and region r of row b is their row
+    row_ids[b,r]."""
     s = ScanProblem()
     assert P.is_contiguous() and V.is_contiguous() and q.is_contiguous() and out.is_contiguous()
     s.P, s.V, s.q, s.q2, s.w = P.data_ptr(), V.data_ptr(), q.data_ptr(), ptr(q2), w.data_ptr()
     s.w_bias = ptr(w_bias)
-    s.R, s.A, s.D = P.shape[1], P.shape[2], V.shape[2]
+    if row_ids is not None:
+        assert row_ids.dtype == torch.int64 and row_ids.dim() == 2 and row_ids.stride(1) == 1 and P.dim() == 2
+        s.row_ids, s.row_ids_ld = row_ids.data_ptr(), row_ids.stride(0)
+        s.R, s.A, s.D = row_ids.shape[1], P.shape[1], V.shape[1]
+    else:
+        s.R, s.A, s.D = P.shape[1], P.shape[2], V.shape[2]
     s.out = out.data_ptr()
     s.out_hi, s.out_lo = _planes_ptrs(out_planes, out)
     if alpha_out is not None:

@@ -281,3 +281,32 @@ def test_rollout_state_planes_are_bit_identical_to_resplitting():
         ops.TIMER.arm_step = None
         ops.TIMER.records.clear()
     assert torch.equal(seq.cpu(), outs[True][0]) and torch.equal(lp.cpu(), outs[True][1])
+
+
+def test_sentiment_word_tables_match_per_caption_features():
+    """Eval-mode roll-out and beam search serve the sentiment words from two vocabulary-sized tables through the
+    scan's gather mode (isc_scan_problem.row_ids); the reference's per-caption [B,M,.] features give the same result."""
+    import numpy as np
+    from conftest import case_setup
+    from insenticap_model_amd import Captioner, synth
+    c, st, w, _, _ = case_setup('cfg1')
+    cap = Captioner(synth.make_idx2word(c['V']), synth.SENTIMENT_CATEGORIES, st)
+    cap.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()})
+    cap.to(dev()).eval()
+    B, Tn = 320, 12
+    d = synth.make_inputs(B, c['V'], st, regions=36, seq_len=Tn, seed=17)
+    a = [torch.from_numpy(np.asarray(d[k])).to(dev()) for k in ('fc_feats', 'att_feats', 'cpt_words', 'senti_words', 'senti_labels')]
+    outs = {}
+    for tables in (True, False):
+        cap.words_table = tables
+        with torch.no_grad():
+            seq, lp, mk = cap(*a, Tn, 1, mode='rl')
+            sw = cap.senti_weights.cpu()
+            caps, scores, _ = cap.sample_batch(a[0][:8], a[1][:8], a[3][:8], a[4][:8], 3, 1, Tn)
+        outs[tables] = (seq.cpu(), lp.cpu(), sw, caps, scores)
+    cap.words_table = True
+    assert torch.equal(outs[True][0], outs[False][0])
+    np.testing.assert_allclose(outs[True][1].numpy(), outs[False][1].numpy(), atol=1e-5)
+    np.testing.assert_allclose(outs[True][2].numpy(), outs[False][2].numpy(), atol=1e-5)
+    assert outs[True][3] == outs[False][3]
+    np.testing.assert_allclose(np.asarray(outs[True][4]), np.asarray(outs[False][4]), atol=1e-4)
