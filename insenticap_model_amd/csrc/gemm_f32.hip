@@ -2135,7 +2135,9 @@ struct H3Planner {
 };
 
 // A linear problem whose planes do not fit the workspace (the prologue's region projections: 147456 rows) goes
-// through it in row chunks: split chunk -> GEMM chunk -> next.  A chunk's planes (<= the workspace, 128 MB) are
+// through it in row chunks: split chunk -> GEMM chunk -> next.  (Tried: two plane buffers with the split of chunk
+// c+1 on a side stream under the GEMM of chunk c - 5-19 % SLOWER: the split's workgroups take CU slots and HBM
+// bandwidth from a GEMM that is bound by its DMA round trips, and the event hand-offs add their own gaps.)  A chunk's planes (<= the workspace, 128 MB) are
 // written and read back while still resident in L2 / the 256 MB memory-side cache.
 static int h3_linear_chunked(const DevProb &p0, float *ws, long long ws_floats, long long chunk_rows, hipStream_t st) {
     const int Kp = h3_kp(p0);
@@ -2180,8 +2182,8 @@ static int try_h3(DevLaunch &L, float *ws, long long ws_floats, hipStream_t st, 
         if (Kp > (1 << 20)) return 0;
         need += ((long long)p.M + p.N) * Kp + 256;        // floats: 2 planes x 2 bytes per element, both operands
     }
-    // linear launches that fill less than 1.5 rounds of CUs with 128-row tiles go out on the 64-row H3 tile
-    const bool half_tile = EPI == EPI_LINEAR && tiles < 384;
+    // linear launches that cannot give every CU a 128-row tile go out on the 64-row H3 tile
+    const bool half_tile = EPI == EPI_LINEAR && tiles < 256;
     if (g_h3_mode == 1 && tiles < (half_tile ? H3_MIN_TILES / 2 : H3_MIN_TILES)) return 0;
     if (need > ws_floats) {
         if constexpr (EPI != EPI_LINEAR) return 0;

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Split-f16 GEMM ops in a rocprofv3 kernel trace: an op is the operand-split kernel (h3_split_kernel) followed by its
-GEMM (gemm_h3_kernel<EPI> / gemm_h3m_kernel).  bench.py times the op with HIP events around the C-ABI call; this script
+GEMM (gemm_h3_kernel<EPI> / gemm_h3x_kernel<EPI> / gemm_h3m_kernel).  bench.py times the op with HIP events around the C-ABI call; this script
 pairs the two dispatches in the trace so that the rocprof durations can be set beside that figure.
 
     python3 tools/h3_op_breakdown.py <dir with *_kernel_trace.csv> > profiles/<round>_h3_op_breakdown.json
