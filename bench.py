@@ -48,6 +48,8 @@ def parse():
     ap.add_argument('--no-kernel-timing', action='store_true', help='do not arm the per-kernel HIP-event timer')
     ap.add_argument('--no-extras', action='store_true', help='skip the XE-train / beam side measurements')
     ap.add_argument('--cpu-seconds', type=float, default=15.0)
+    ap.add_argument('--h3-mode', type=int, default=1, choices=(0, 1, 2),
+                    help='split-f16 GEMM path: 1 auto (default), 0 off = exact-fp32 MFMA tiles only, 2 force')
     return ap.parse_args()
 
 
@@ -326,6 +328,7 @@ def run(args):
     dev = torch.device('cuda', local if (world > 1 or under_launcher) else 0)
     torch.cuda.set_device(dev)
     B = args.batch
+    ops.set_h3_mode(args.h3_mode)
 
     weights = synth.make_weights(V, synth.DEFAULT_SETTINGS, seed=0)
     cap = Captioner(synth.make_idx2word(V), synth.SENTIMENT_CATEGORIES, synth.DEFAULT_SETTINGS)
@@ -407,7 +410,9 @@ def run(args):
         'config': {'workload': 'greedy decode forward_rl(sample_max=1): B=%d captions/GPU/step, R=%d '
                                'regions x 2048, V=%d, T=%d, sentiment-word attention + gate on, '
                                'prologue included, random-init reference-architecture weights' % (B, R, V, T),
-                   'batch_per_gpu': B, 'parallelism': 'dp%d (batch shard, no collective)' % world},
+                   'batch_per_gpu': B, 'parallelism': 'dp%d (batch shard, no collective)' % world,
+                   'gemm_engine': {1: 'split-f16 x3 MFMA for large forward GEMMs (fp32 in/out/accumulate), fp32 MFMA elsewhere',
+                                   0: 'fp32 MFMA only (--h3-mode 0)', 2: 'split-f16 forced'}[args.h3_mode]},
         'roofline': entries[0] if entries else None,
         'roofline_kernels': entries[1:],
         'extra': extra,
