@@ -1,5 +1,7 @@
-// fp32 MFMA (v_mfma_f32_32x32x2_f32) grouped, K-segmented GEMM (NT forward, NN / TN backward)
-// with fused epilogues.
+// Grouped, K-segmented GEMM (NT forward, NN / TN backward) with fused epilogues, on two engines:
+//   * fp32 MFMA (v_mfma_f32_32x32x2_f32): every layout, every size (tile kernels below);
+//   * split-f16 (v_mfma_f32_32x32x16_f16 on hi/lo f16 planes of the fp32 operands, fp32 accumulators): the large
+//     forward launches - gemm_h3_kernel / gemm_h3x_kernel / gemm_h3m_kernel, h3_split_kernel, try_h3 further down.
 //
 //   acc[M,N] = sum_s A_s[M,K_s] * W_s[N,K_s]^T          (s = up to 4 K-segments)
 //
