@@ -70,10 +70,13 @@ typedef struct {
     const float *A; /* [M, K] activations, leading dim lda */
     const float *W; /* [N, K] weight slice (row-major, K contiguous), leading dim ldw */
     int32_t lda, ldw, K, _pad;
-    /* Optional (forward entry points, split-f16 path): the f16 planes of A, [M, K] contiguous each, as a producer
-     * wrote them (isc_lstm_problem.h_hi / h_lo): hi = f16(x), lo = f16((x - hi) * 2048).  When present and the launch
-     * takes the split-f16 path, A is read from the planes instead of being split again; `A` must still be valid (the
-     * fp32 tiles read it).  Null = split on the fly. */
+    /* Optional (forward entry points, split-f16 path): the f16 planes of A as a producer wrote them
+     * (isc_lstm_problem.h_hi / h_lo ...): hi = f16(x), lo = f16((x - hi) * 2048), in ONE buffer of 2*M*K halfs with the
+     * two planes interleaved per 32-wide k-block (so that a chunk consumes whole 128-byte lines):
+     *     hi(m, k) = buf[m*2K + (k/32)*64 + k%32],   lo(m, k) = the same + 32;   A_hi = buf, A_lo = buf + 32 halfs.
+     * Every plane pointer pair of this header uses that layout for its own [rows, width] tensor (K % 32 == 0).
+     * When present and the launch takes the split-f16 path, A is read from the planes instead of being split again;
+     * `A` must still be valid (the fp32 tiles read it).  Null = split on the fly. */
     const void *A_hi, *A_lo;
 } isc_seg;
 

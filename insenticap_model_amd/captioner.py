@@ -371,14 +371,15 @@ class Captioner(nn.Module):
         pl.h1, pl.h2, pl.c1, pl.c2 = (h_nxt[0].data_ptr(), h_nxt[1].data_ptr(), c_nxt[0].data_ptr(),
                                       c_nxt[1].data_ptr())
         if hp_cur is not None:
-            pl.h1_prev_hi, pl.h1_prev_lo = hp_cur[0, 0].data_ptr(), hp_cur[0, 1].data_ptr()
-            pl.h2_prev_hi, pl.h2_prev_lo = hp_cur[1, 0].data_ptr(), hp_cur[1, 1].data_ptr()
-            pl.h1_hi, pl.h1_lo = hp_nxt[0, 0].data_ptr(), hp_nxt[0, 1].data_ptr()
-            pl.h2_hi, pl.h2_lo = hp_nxt[1, 0].data_ptr(), hp_nxt[1, 1].data_ptr()
+            pl.h1_prev_hi, pl.h1_prev_lo = ops.planes_ptrs(hp_cur[0])
+            pl.h2_prev_hi, pl.h2_prev_lo = ops.planes_ptrs(hp_cur[1])
+            pl.h1_hi, pl.h1_lo = ops.planes_ptrs(hp_nxt[0])
+            pl.h2_hi, pl.h2_lo = ops.planes_ptrs(hp_nxt[1])
             for k in ('v', 's', 'f'):                 # plane workspace of the step's own intermediates
                 pp = ws.get(k + 'p')
-                setattr(pl, k + '_hi', None if pp is None else pp[0].data_ptr())
-                setattr(pl, k + '_lo', None if pp is None else pp[1].data_ptr())
+                hi, lo = (None, None) if pp is None else ops.planes_ptrs(pp)
+                setattr(pl, k + '_hi', hi)
+                setattr(pl, k + '_lo', lo)
         else:
             for k in ('h1_prev_hi', 'h1_prev_lo', 'h2_prev_hi', 'h2_prev_lo', 'h1_hi', 'h1_lo', 'h2_hi', 'h2_lo',
                       'v_hi', 'v_lo', 's_hi', 's_lo', 'f_hi', 'f_lo'):

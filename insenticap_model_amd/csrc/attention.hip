@@ -31,8 +31,11 @@ struct DevScanLaunch {
     DevScan p[2];
 };
 
-// f16 planes of four consecutive outputs (split-f16 GEMM operands: hi = f16(x), lo = f16((x - hi) * 2048))
-__device__ __forceinline__ void store_planes4(_Float16 *hi, _Float16 *lo, long long o, const float4 &x) {
+// f16 planes of four consecutive outputs d .. d+3 of row `row` of a [rows, D] tensor (split-f16 GEMM operands:
+// hi = f16(x), lo = f16((x - hi) * 2048); interleaved layout of gemm_f32.hip: per row and 32-wide block 32 hi then
+// 32 lo values, lo pointer = hi pointer + 32)
+__device__ __forceinline__ void store_planes4(_Float16 *hi, _Float16 *lo, long long row, int d, int D, const float4 &x) {
+    const long long o = row * 2 * D + (d >> 5) * 64 + (d & 31);
     typedef _Float16 h4 __attribute__((ext_vector_type(4)));
     const float v[4] = {x.x, x.y, x.z, x.w};
     h4 a, b;
@@ -170,7 +173,7 @@ __global__ __launch_bounds__(256) void attn_scan_kernel(const DevScanLaunch L) {
                 s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
             }
             reinterpret_cast<float4 *>(S.out + (long long)b * D)[tid] = s;
-            if (S.out_hi) store_planes4(S.out_hi, S.out_lo, (long long)b * D + 4 * tid, s);
+            if (S.out_hi) store_planes4(S.out_hi, S.out_lo, b, 4 * tid, D, s);
         }
     } else {
         for (int d4 = tid; d4 < nd4; d4 += 256) {
@@ -181,7 +184,7 @@ __global__ __launch_bounds__(256) void attn_scan_kernel(const DevScanLaunch L) {
                 o.x += a * v.x; o.y += a * v.y; o.z += a * v.z; o.w += a * v.w;
             }
             reinterpret_cast<float4 *>(S.out + (long long)b * D)[d4] = o;
-            if (S.out_hi) store_planes4(S.out_hi, S.out_lo, (long long)b * D + 4 * d4, o);
+            if (S.out_hi) store_planes4(S.out_hi, S.out_lo, b, 4 * d4, D, o);
         }
     }
 }
@@ -246,7 +249,7 @@ __global__ __launch_bounds__(256) void gate_mix_kernel(const float *z, const flo
             f.x = beta * a.x + (1.0f - beta) * c.x; f.y = beta * a.y + (1.0f - beta) * c.y;
             f.z = beta * a.z + (1.0f - beta) * c.z; f.w = beta * a.w + (1.0f - beta) * c.w;
             o4[d] = f;
-            if (out_hi) store_planes4(out_hi, out_lo, (long long)b * D + 4 * d, f);
+            if (out_hi) store_planes4(out_hi, out_lo, b, 4 * d, D, f);
         }
         return;
     }
@@ -256,8 +259,9 @@ __global__ __launch_bounds__(256) void gate_mix_kernel(const float *z, const flo
         out[o] = f;
         if (out_hi) {
             const _Float16 fh = (_Float16)f;
-            out_hi[o] = fh;
-            out_lo[o] = (_Float16)((f - (float)fh) * 2048.f);
+            const long long po = (long long)b * 2 * D + (d >> 5) * 64 + (d & 31);
+            out_hi[po] = fh;
+            out_lo[po] = (_Float16)((f - (float)fh) * 2048.f);
         }
     }
 }

@@ -38,9 +38,16 @@ struct DevSeg {
     const _Float16 *A_hi, *A_lo;      // caller-provided planes of A ([M,K] contiguous) or null
 };
 
+// Plane layout (split-f16 operands): one buffer per [rows, K] tensor, K % 32 == 0; per row and per 32-deep k-block
+// the 32 hi values are followed by the 32 lo values, so the 64 bytes of hi and the 64 bytes of lo that one chunk
+// consumes form one 128-byte line:  hi(row, k) at base[row * 2K + (k >> 5) * 64 + (k & 31)],  lo = the same + 32.
+// The `lo` pointers carried around are `hi + 32`.
+__host__ __device__ __forceinline__ long long plane_index(long long row, int k, int K) {
+    return row * 2 * K + (k >> 5) * 64 + (k & 31);
+}
 struct DevASeg {                      // one K-segment of the split-f16 A operand
     const _Float16 *hi, *lo;
-    int ld, K;
+    int ld, K;                        // ld = row stride in halfs = 2 * K of the tensor the planes belong to
 };
 
 struct DevProb {
@@ -324,8 +331,9 @@ __device__ __forceinline__ void lstm_cells(const DevProb &P, const int (&gm)[NE]
             P.h_out[o] = h2;
             if (P.h_hi) {
                 const _Float16 hh = (_Float16)h2;
-                P.h_hi[o] = hh;
-                P.h_lo[o] = (_Float16)((h2 - (float)hh) * 2048.f);
+                const long long po = plane_index(gm[e], unit, H);
+                P.h_hi[po] = hh;
+                P.h_lo[po] = (_Float16)((h2 - (float)hh) * 2048.f);
             }
             if (P.hmask) P.hdrop[o] = h2 * (float)P.hmask[o] * P.mask_scale;
             if (P.gates_out) {
@@ -1117,8 +1125,8 @@ __global__ __launch_bounds__(256, 2) void gemm_h3_kernel(const DevLaunch L) {
             const int c = col0 + t;
             wr = c < N ? c : N - 1;
         }
-        src[4 + i] = P.Wh + wr * Kp + q * 8;
-        src[6 + i] = P.Wl + wr * Kp + q * 8;
+        src[4 + i] = P.Wh + wr * 2 * Kp + q * 8;
+        src[6 + i] = P.Wl + wr * 2 * Kp + q * 8;
     }
     int cs = 0, ck = 0, segK = 0;
     auto set_aseg = [&](int si) __attribute__((always_inline)) {
@@ -1139,7 +1147,7 @@ __global__ __launch_bounds__(256, 2) void gemm_h3_kernel(const DevLaunch L) {
             for (int i = 0; i < 2; ++i) {
                 asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off"
                              :: "s"(lds0 + buf * ST + p * PL + i * 1024), "v"(src[2 * p + i]) : "memory");
-                src[2 * p + i] += 32;
+                src[2 * p + i] += 64;                     // next 32-k block: 32 hi + 32 lo halfs further
             }
         ck += 32;
         if (ck >= segK) {
@@ -1254,8 +1262,8 @@ __global__ __launch_bounds__(512) void gemm_h3x_kernel(const DevLaunch L) {
             const int c = col0 + t;
             wr = c < N ? c : N - 1;
         }
-        src[4] = P.Wh + wr * Kp + q * 8;
-        src[5] = P.Wl + wr * Kp + q * 8;
+        src[4] = P.Wh + wr * 2 * Kp + q * 8;
+        src[5] = P.Wl + wr * 2 * Kp + q * 8;
     }
     int cs = 0, ck = 0, segK = 0;
     auto set_aseg = [&](int si) __attribute__((always_inline)) {
@@ -1272,7 +1280,7 @@ __global__ __launch_bounds__(512) void gemm_h3x_kernel(const DevLaunch L) {
     const unsigned wv = __builtin_amdgcn_readfirstlane((unsigned)wm);
     auto dma1 = [&](unsigned dst, const _Float16 *&p) __attribute__((always_inline)) {
         asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(dst), "v"(p) : "memory");
-        p += 32;
+        p += 64;
     };
     auto stage = [&](int buf) __attribute__((always_inline)) {
         const unsigned b = lds0 + buf * ST;
@@ -1395,8 +1403,8 @@ __global__ __launch_bounds__(256) void gemm_h3m_kernel(const DevLaunch L) {
         const int q = (lane & 3) ^ ((t >> 2) & 3);
         int c = col0 + t;
         c = c < N ? c : N - 1;
-        src[2 + i] = P.Wh + (long long)c * Kp + q * 8;
-        src[4 + i] = P.Wl + (long long)c * Kp + q * 8;
+        src[2 + i] = P.Wh + (long long)c * 2 * Kp + q * 8;
+        src[4 + i] = P.Wl + (long long)c * 2 * Kp + q * 8;
     }
     int cs = 0, ck = 0, segK = 0;
     auto set_aseg = [&](int si) __attribute__((always_inline)) {
@@ -1410,7 +1418,7 @@ __global__ __launch_bounds__(256) void gemm_h3m_kernel(const DevLaunch L) {
     const unsigned wv = __builtin_amdgcn_readfirstlane((unsigned)w);
     auto dma1 = [&](unsigned dst, const _Float16 *&p) __attribute__((always_inline)) {
         asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(dst), "v"(p) : "memory");
-        p += 32;
+        p += 64;
     };
     auto stage = [&](int buf) __attribute__((always_inline)) {
         const unsigned b = lds0 + buf * ST;
@@ -1521,7 +1529,7 @@ __global__ __launch_bounds__(256) void h3_split_kernel(const SplitLaunch S) {
     if (idx >= (long long)J.rows * k8n) return;
     const int row = (int)(idx / k8n);
     int k = (int)(idx - (long long)row * k8n) * 8;
-    const long long o = (long long)row * J.Kp + k;
+    const long long o = plane_index(row, k, J.Kp);        // 8 consecutive k never leave their 32-block
     const float *sp = J.src[0];
     int ld = J.ld[0], k0 = 0;
 #pragma unroll
@@ -1748,8 +1756,9 @@ __global__ __launch_bounds__(256) void splitk_lstm_kernel(const DevLaunch L) {
     P.h_out[i] = h2;
     if (P.h_hi) {
         const _Float16 hh = (_Float16)h2;
-        P.h_hi[i] = hh;
-        P.h_lo[i] = (_Float16)((h2 - (float)hh) * 2048.f);
+        const long long po = plane_index(gm, unit, H);
+        P.h_hi[po] = hh;
+        P.h_lo[po] = (_Float16)((h2 - (float)hh) * 2048.f);
     }
     if (P.hmask) P.hdrop[i] = h2 * (float)P.hmask[i] * P.mask_scale;
     if (P.gates_out) {
@@ -2082,9 +2091,9 @@ struct H3Planner {
             k0 += p.seg[s].K;
         }
         J.nseg = s1 - s0; J.rows = rows; J.Kp = k0; J.first_block = blocks;
-        const size_t bytes = (((size_t)rows * k0 * 2) + 255) & ~(size_t)255;
+        const size_t bytes = (((size_t)rows * k0 * 4) + 255) & ~(size_t)255;      // hi and lo interleaved
         J.hi = reinterpret_cast<_Float16 *>(at); at += bytes;
-        J.lo = reinterpret_cast<_Float16 *>(at); at += bytes;
+        J.lo = J.hi + 32;
         hi = J.hi; lo = J.lo;
         blocks += (int)(((long long)rows * (k0 >> 3) + 255) / 256);
     }
@@ -2096,31 +2105,31 @@ struct H3Planner {
             const _Float16 *hi, *lo;
             add(p, false, p.M, hi, lo);
             p.nap = 1;
-            p.ap[0] = DevASeg{hi, lo, p.Kp, p.Kp};
+            p.ap[0] = DevASeg{hi, lo, 2 * p.Kp, p.Kp};
             return;
         }
         p.nap = p.nseg;
         for (int s = 0; s < p.nseg; ++s) {
             const int K = p.seg[s].K;
             if (p.seg[s].A_hi && p.seg[s].A_lo) {
-                p.ap[s] = DevASeg{p.seg[s].A_hi, p.seg[s].A_lo, K, K};
+                p.ap[s] = DevASeg{p.seg[s].A_hi, p.seg[s].A_lo, 2 * K, K};
             } else {
                 const _Float16 *hi, *lo;
                 add(p, false, p.M, hi, lo, s, s + 1);
-                p.ap[s] = DevASeg{hi, lo, K, K};
+                p.ap[s] = DevASeg{hi, lo, 2 * K, K};
             }
         }
     }
     // weight operand: cached planes if the caller opened a weights scope, else planes in the workspace
     void add_w(const DevProb &p, const _Float16 *&hi, const _Float16 *&lo) {
         if (const H3WEntry *e = h3w_find(p)) { hi = e->hi; lo = e->lo; return; }
-        const size_t bytes = (((size_t)p.N * h3_kp(p) * 2) + 255) & ~(size_t)255;
-        if (g_h3w.active && g_h3w.n < 24 && g_h3w.used + 2 * bytes <= g_h3w.bytes) {
+        const size_t bytes = (((size_t)p.N * h3_kp(p) * 4) + 255) & ~(size_t)255;
+        if (g_h3w.active && g_h3w.n < 24 && g_h3w.used + bytes <= g_h3w.bytes) {
             char *keep = at;
             at = g_h3w.buf + g_h3w.used;
             add(p, true, p.N, hi, lo);
             at = keep;
-            g_h3w.used += 2 * bytes;
+            g_h3w.used += bytes;
             H3WEntry &e = g_h3w.e[g_h3w.n++];
             e.nseg = p.nseg; e.rows = p.N; e.hi = hi; e.lo = lo;
             for (int s = 0; s < p.nseg; ++s) { e.W[s] = p.seg[s].W; e.ldw[s] = p.seg[s].ldw; e.K[s] = p.seg[s].K; }

@@ -54,6 +54,12 @@ class KernelTimer:
 TIMER = KernelTimer()
 
 
+def planes_ptrs(planes):
+    """(hi, lo) pointers of a split-f16 plane buffer: a [2, rows, K] f16 tensor used as ONE buffer in which the two
+    planes are interleaved per 32-wide k-block (include/insenticap_hip.h, isc_seg.A_hi): lo = hi + 32 halfs."""
+    return planes.data_ptr(), planes.data_ptr() + 64
+
+
 def _seg_k(segs):
     return sum(sg[0].shape[1] for sg in segs)
 
@@ -118,7 +124,7 @@ def _fill_segs(dst, segs):
         planes = sg[2] if len(sg) > 2 else None      # optional [2, M, K] f16 planes of A (isc_seg.A_hi / A_lo)
         if planes is not None:
             assert planes.dtype == torch.float16 and planes.is_contiguous() and planes.shape == (2,) + tuple(A.shape)
-            s.A_hi, s.A_lo = planes[0].data_ptr(), planes[1].data_ptr()
+            s.A_hi, s.A_lo = planes_ptrs(planes)
         else:
             s.A_hi = s.A_lo = None
 
@@ -227,7 +233,7 @@ def lstm_fwd(segs, b_ih, b_hh, c_prev, h_out, c_out, gates_out=None, h_keep_mask
     p.hdrop_out = ptr(hdrop_out)
     if h_planes is not None:
         assert h_planes.dtype == torch.float16 and h_planes.is_contiguous() and h_planes.shape == (2, p.M, p.H)
-        p.h_hi, p.h_lo = h_planes[0].data_ptr(), h_planes[1].data_ptr()
+        p.h_hi, p.h_lo = planes_ptrs(h_planes)
     _attach_ws(p, c_prev.device)
     e0 = TIMER.begin()
     check(lib.isc_lstm_fwd(C.byref(p), stream()), 'isc_lstm_fwd')
@@ -250,7 +256,7 @@ def vocab_fwd(h, W, bias, part_max, part_sum, part_idx, logits=None, h_planes=No
     hi = lo = None
     if h_planes is not None:
         assert h_planes.dtype == torch.float16 and h_planes.is_contiguous() and h_planes.shape == (2,) + tuple(h.shape)
-        hi, lo = h_planes[0].data_ptr(), h_planes[1].data_ptr()
+        hi, lo = planes_ptrs(h_planes)
     M, K = h.shape
     V = W.shape[0]
     assert h.stride(1) == 1 and W.stride(1) == 1
@@ -275,7 +281,7 @@ def _planes_ptrs(planes, like):
     if planes is None:
         return None, None
     assert planes.dtype == torch.float16 and planes.is_contiguous() and planes.shape == (2,) + tuple(like.shape)
-    return planes[0].data_ptr(), planes[1].data_ptr()
+    return planes_ptrs(planes)
 
 
 def scan_problem(P, V, q, w, w_bias, out, alpha_out=None, q2=None, out_planes=None, row_ids=None):
