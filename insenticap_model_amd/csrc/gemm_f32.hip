@@ -2046,7 +2046,9 @@ static int launch_h3x(const DevLaunch &L, hipStream_t st) {
 
 // 256-row tiles when they fill the chip, else the 128-row kernel.  The vocabulary projection stays on the 128-row
 // kernel: its epilogue (per-row softmax statistics, ~3k VALU instructions per wave) is as long as its 16-chunk main
-// loop, and only a second, out-of-phase workgroup on the CU overlaps the two (174 us on the 256-row tile vs 162 us).
+// loop, and only a second, out-of-phase workgroup on the CU overlaps the two (174 us on the 256-row tile vs 162 us;
+// a persistent form of the 256-row kernel that put the next tile's first two chunks in flight before the epilogue
+// measured 173 us: what is exposed is the epilogue's own VALU time, 8-10 us per tile, not the workgroup turnover).
 template <int EPI>
 static int launch_h3_big(DevLaunch &L, hipStream_t st) {
     long long t256 = 0;

@@ -125,7 +125,7 @@ def test_lstm_h3(M, H, with_pre, with_tab):
     assert errs[2][1] <= errs[0][1] * 1.1 + 1e-9 and errs[2][3] <= errs[0][3] * 1.1 + 1e-9, errs
 
 
-@pytest.mark.parametrize('M,V,K', [(520, 1000, 64), (300, 10000, 512), (4096, 10000, 512)])
+@pytest.mark.parametrize('M,V,K', [(520, 1000, 64), (300, 10000, 512), (4096, 10000, 512), (2100, 9487, 512)])
 def test_vocab_h3(M, V, K):
     g = torch.Generator().manual_seed(V + M)
     h, W, bias = _rand(g, M, K), _rand(g, V, K, scale=4 * K ** -0.5), _rand(g, V)
