@@ -1074,11 +1074,12 @@ __global__ __launch_bounds__(256) void gemm_ld_kernel(const DevLaunch L) {
 // ---------------------------------------------------------------- H3 tile: 128 x 128 on the f16 matrix cores
 // fp32 operands, fp32 results, f16 MFMA rate.  Every operand value is split once into two f16 planes,
 //     x = hi + lo * 2^-11,   hi = f16(x),   lo = f16((x - hi) * 2^11)
-// which keeps 22-24 mantissa bits of x (the subtraction is exact in fp32; lo's own rounding error is 2^-24 |x|),
+// which keeps >= 22 significant bits of x for |x| >= 2^-14 and an absolute error <= 2^-35 below (the subtraction is
+// exact in fp32; tests/test_h3_math.py),
 // and the contraction is taken as
 //     C = sum hi_a hi_b  +  2^-11 * sum (hi_a lo_b + lo_a hi_b)
 // on v_mfma_f32_32x32x16_f16: three MFMAs per 16-deep k-step instead of eight 32x32x2 fp32 ones at 1/16 the rate.
-// f16 x f16 products are exact in the fp32 accumulator, the dropped lo_a lo_b term is 2^-24 relative, and the
+// f16 x f16 products are exact in the fp32 accumulator, the dropped lo_a lo_b term is <= 2^-22 relative, and the
 // two sums live in separate accumulators so that the 2^-11 weight is applied once, in fp32, at the end.  Measured
 // against an fp64 contraction the result is CLOSER than an fp32 fmaf chain (rms 1.0e-7 vs 2.6e-7 at K = 512,
 // tools/h3_gemm_lab.hip) - the 1e-4 log-prob parity bound is not touched.  Domain: |x| < 65504 (f16 range of hi);

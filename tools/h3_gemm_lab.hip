@@ -1,6 +1,6 @@
 // Lab: fp32-accurate GEMM on the f16 matrix cores by operand splitting.
-//   x = hi + lo * 2^-11  with hi = f16(x), lo = f16((x - hi) * 2^11)   (22+ mantissa bits)
-//   C = sum hi_a*hi_b  +  2^-11 * sum (hi_a*lo_b + lo_a*hi_b)          (lo*lo dropped: 2^-24 relative)
+//   x = hi + lo * 2^-11  with hi = f16(x), lo = f16((x - hi) * 2^11)   (>= 22 significant bits for |x| >= 2^-14)
+//   C = sum hi_a*hi_b  +  2^-11 * sum (hi_a*lo_b + lo_a*hi_b)          (lo*lo dropped: <= 2^-22 relative)
 // C[M,N] = A[M,K] * W[N,K]^T; 128x128 tile, 4 waves (2x2) of 64x64, BK = 32 halfs, LDS-DMA, 2 buffers.
 #include <hip/hip_runtime.h>
 #include <cstdio>
