@@ -143,8 +143,8 @@ __device__ __forceinline__ void map_tile(const DevLaunch &L, int &pi, int &tm, i
 // inside the half-wave (4 DPP steps inside the 16-lane rows + one swizzle across them).  frow0 = tile-relative first row of the
 // fragment, fcol0 = tile-relative first column.  WN == 1 writes the tile statistics directly,
 // otherwise they go to smx/ssm/six[wn][BM] for the cross-wave combine.
-template <int TN, int WN, int BM, bool EDGE>
-__device__ __forceinline__ void epi_vocab_frag_impl(const DevProb &P, f32x16 (&acc)[TN], int frow0, int fcol0, int wn,
+template <int TN, int WN, int BM>
+__device__ __forceinline__ void epi_vocab_frag(const DevProb &P, f32x16 (&acc)[TN], int frow0, int fcol0, int wn,
                                                int lane, int row0, int col0, int tn, float *smem) {
     const int M = P.M, N = P.N;
     float bv[TN];
@@ -152,7 +152,7 @@ __device__ __forceinline__ void epi_vocab_frag_impl(const DevProb &P, f32x16 (&a
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int gn = col0 + fcol0 + j * 32 + (lane & 31);
-        cok[j] = !EDGE || gn < N;           // interior fragments: a compile-time true, the selects below fold away
+        cok[j] = gn < N;
         bv[j] = cok[j] ? P.bias0[gn] : 0.f;
     }
     float *smx = smem;                    // [WN][BM] cross-wave combine (WN > 1 only)
@@ -214,15 +214,6 @@ __device__ __forceinline__ void epi_vocab_frag_impl(const DevProb &P, f32x16 (&a
             }
         }
     }
-}
-
-// EDGE = the fragment touches the last, partial column tile of the vocabulary: only then are the per-element column
-// predicates (128 selects per lane) compiled in.
-template <int TN, int WN, int BM>
-__device__ __forceinline__ void epi_vocab_frag(const DevProb &P, f32x16 (&acc)[TN], int frow0, int fcol0, int wn,
-                                               int lane, int row0, int col0, int tn, float *smem) {
-    if (col0 + fcol0 + 32 * TN <= P.N) epi_vocab_frag_impl<TN, WN, BM, false>(P, acc, frow0, fcol0, wn, lane, row0, col0, tn, smem);
-    else epi_vocab_frag_impl<TN, WN, BM, true>(P, acc, frow0, fcol0, wn, lane, row0, col0, tn, smem);
 }
 
 // accumulator fragment -> Cs[BM][LDC] (row-major tile image in LDS)
