@@ -2194,7 +2194,8 @@ static int try_h3(DevLaunch &L, float *ws, long long ws_floats, hipStream_t st, 
         tiles += (long long)((p.M + 127) / 128) * ((p.N + 127) / 128);
         const long long Kp = h3_kp(p);
         if (Kp > (1 << 20)) return 0;
-        need += ((long long)p.M + p.N) * Kp + 256;        // floats: 2 planes x 2 bytes per element, both operands
+        need += ((long long)p.M + p.N) * Kp + 1024;       // floats: 2 planes x 2 bytes per element, both operands,
+                                                          // + the 256-byte round-up of up to five plane buffers
     }
     // linear launches that cannot give every CU a 128-row tile go out on the 64-row H3 tile
     const bool half_tile = EPI == EPI_LINEAR && tiles < 256;
