@@ -255,6 +255,33 @@ int isc_beam_topk(const float *logits, int64_t ld_logits, const float *part_max,
                   int mask_special, int decoding_constraint, float *top_val, int64_t *top_idx,
                   void *stream);
 
+/* Candidate merge of a batched beam search on the device (captioner.py:378-411), one step: from the step's top-`beam`
+ * (value, id) pairs per live row, form every image's candidates in the reference's insertion order (an ended
+ * candidate carries itself, a live one contributes its `beam` children), add scores in fp64 (the reference sums
+ * Python floats) and keep the first `beam` of a STABLE descending sort.  State (scores, last words, word lists,
+ * lengths) is double-buffered by the caller; `gather` receives, per new row, its source row inside
+ * [next-state rows ; current-state rows]; `done[i]` latches when every candidate of image i has ended (the image is
+ * then frozen); live[t+1] counts the images still searching.  beam <= 8.  No host read is needed between steps. */
+typedef struct {
+    int32_t n_img, beam, T, t;
+    int64_t eos_id;
+    const float *top_val;     /* [n_img*beam, beam] log-probs of isc_beam_topk */
+    const int64_t *top_idx;   /* [n_img*beam, beam] */
+    const double *score_in;   /* [n_img*beam] */
+    double *score_out;
+    const int64_t *last_in;   /* [n_img*beam] last word of every candidate = the token fed to the next step */
+    int64_t *last_out;
+    const int64_t *words_in;  /* [n_img*beam, T] */
+    int64_t *words_out;
+    const int32_t *len_in;    /* [n_img*beam] */
+    int32_t *len_out;
+    int32_t *done;            /* [n_img] */
+    int64_t *gather;          /* [n_img*beam] */
+    int32_t *live;            /* [T+1] */
+} isc_beam_merge_args;
+
+int isc_beam_merge(const isc_beam_merge_args *args_host, void *stream);
+
 /* Masked NLL (XECriterion, captioner.py:427-440): returns sum and token count in out[0..1].
  * logp [B,T,V] contiguous, target [B,T] int64, lengths [B] int32. */
 int isc_xe_loss_fwd(const float *logp, const int64_t *target, const int32_t *lengths, int B,

@@ -88,6 +88,12 @@ class StepBwdPlan(C.Structure):
                    C.c_void_p) + [('splitk_ws_floats', C.c_int64)])
 
 
+class BeamMergeArgs(C.Structure):
+    _fields_ = ([('n_img', C.c_int32), ('beam', C.c_int32), ('T', C.c_int32), ('t', C.c_int32), ('eos_id', C.c_int64)] +
+                _f('top_val top_idx score_in score_out last_in last_out words_in words_out len_in len_out done gather live',
+                   C.c_void_p))
+
+
 class RolloutStep(C.Structure):
     _fields_ = [('B', C.c_int32), ('V', C.c_int32), ('T', C.c_int32), ('t', C.c_int32),
                 ('n_tile', C.c_int32), ('W', C.c_int32),
@@ -132,6 +138,7 @@ SIGNATURES = {
     'isc_embed_senti_words_fwd': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int64,
                                             C.c_int, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
     'isc_rollout_finalize': (C.c_int, [C.POINTER(RolloutStep), C.c_void_p]),
+    'isc_beam_merge': (C.c_int, [C.POINTER(BeamMergeArgs), C.c_void_p]),
     'isc_beam_topk': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                 C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int,
                                 C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -1,5 +1,11 @@
 """Batched beam search behind `Captioner.sample` (reference: captioner.py:351-420).
 
+Default: the candidate bookkeeping runs on the device too (`isc_beam_merge`, one workgroup per image, fp64 score sums,
+stable descending selection in insertion order), so a step is decode + top-k + merge + state gather with no host read;
+the host looks at the "images still searching" counter every fourth step only.  `cap.beam_device_merge = False`
+selects the host-side merges below (the same rules in Python / numpy; the CPU tests compare the two host forms, the
+GPU tests compare them with the device merge).
+
 The reference decodes one image at a time and runs one batch-1 `forward_step` per live beam
 with 2*beam device->host scalar reads each.  Here all I images advance together: one decode
 step over I*beam rows + one device top-k per time step and ONE host read of the [I*beam, beam]
@@ -167,6 +173,9 @@ def beam_search_batch(cap, fc_feats, att_feats, senti_words, senti_labels, beam,
     mask_special = cap.pad_id != cap.eos_id
 
     cap.last_beam_steps = 0                    # decode steps executed (bench.py: latency per step)
+    if getattr(cap, 'beam_device_merge', True) and beam <= 8:
+        return _search_device_merge(cap, p, Pb, ws, st_cur, st_nxt, logits, xt, emb, top_val, top_idx, n_img, beam, T,
+                                    decoding_constraint, mask_special)
     merge = _VectorMerge(n_img, beam, T, cap.sos_id, cap.eos_id) if n_img >= 4 else \
         _ListMerge(n_img, beam, cap.sos_id, cap.eos_id)
     ctrl_h = torch.empty(2, rows, dtype=torch.int64).pin_memory()     # [last word ; gather index], one upload per step
@@ -198,4 +207,66 @@ def beam_search_batch(cap, fc_feats, att_feats, senti_words, senti_labels, beam,
         captions.append([' '.join(cap.idx2word[w] for w in words if w != cap.eos_id) for (_, words) in cands])
         scores.append([s for (s, _) in cands])
         ids.append([list(words) for (_, words) in cands])
+    return captions, scores, ids
+
+
+def _search_device_merge(cap, p, Pb, ws, st_cur, st_nxt, logits, xt, emb, top_val, top_idx, n_img, beam, T,
+                         decoding_constraint, mask_special):
+    """The search loop with the candidate merge on the device: nothing is read back until the end, except the
+    live-image counter every fourth step (the reference's early exit, captioner.py:379-381)."""
+    from ._lib import BeamMergeArgs
+    dev, rows = cap._dev, n_img * beam
+    score = [torch.zeros(rows, dtype=torch.float64, device=dev) for _ in range(2)]
+    last = [torch.full((rows,), cap.sos_id, dtype=torch.int64, device=dev) for _ in range(2)]
+    words = [torch.zeros(rows, T, dtype=torch.int64, device=dev) for _ in range(2)]
+    length = [torch.zeros(rows, dtype=torch.int32, device=dev) for _ in range(2)]
+    done = torch.zeros(n_img, dtype=torch.int32, device=dev)
+    gather = torch.empty(rows, dtype=torch.int64, device=dev)
+    live = torch.zeros(T + 1, dtype=torch.int32, device=dev)
+    a = BeamMergeArgs()
+    a.n_img, a.beam, a.T, a.eos_id = n_img, beam, T, cap.eos_id
+    a.top_val, a.top_idx = top_val.data_ptr(), top_idx.data_ptr()
+    a.done, a.gather, a.live = done.data_ptr(), gather.data_ptr(), live.data_ptr()
+    cur = 0
+    with ops.h3_weights_scope(dev):
+        for t in range(T):
+            cap.last_beam_steps = t + 1
+            last_d = last[cur]
+            h_cur, c_cur, h_nxt, c_nxt = st_cur[0], st_cur[1], st_nxt[0], st_nxt[1]
+            if Pb.tab is None:
+                ops.embed_relu_fwd(emb, last_d, xt)
+            cap._step(p, Pb, ws, xt, h_cur, c_cur, h_nxt, c_nxt, logits=logits, tok=last_d)
+            ops.beam_topk(logits, ws['pmax'], ws['psum'], last_d, beam, cap.pad_id, cap.sos_id, cap.unk_id,
+                          mask_special, decoding_constraint, top_val, top_idx)
+            nxt = cur ^ 1
+            a.t = t
+            a.score_in, a.score_out = score[cur].data_ptr(), score[nxt].data_ptr()
+            a.last_in, a.last_out = last[cur].data_ptr(), last[nxt].data_ptr()
+            a.words_in, a.words_out = words[cur].data_ptr(), words[nxt].data_ptr()
+            a.len_in, a.len_out = length[cur].data_ptr(), length[nxt].data_ptr()
+            ops.beam_merge(a)
+            cur = nxt
+            if (t & 3) == 3 or t == T - 1:
+                if int(live[t + 1].item()) == 0:          # the one host read: every image has finished
+                    break
+            # new state of row r = stepped ? nxt[parent] : cur[parent]  ==  [nxt ; cur][gather[r]]
+            st_cur = torch.cat([st_nxt, st_cur], dim=2).index_select(2, gather)
+    cap.cont_weights, cap.senti_weights, cap.cont_senti_weights = [], [], []
+    sc = score[cur].view(n_img, beam).cpu().tolist()
+    wd = words[cur].view(n_img, beam, T).cpu().numpy()
+    ln = length[cur].view(n_img, beam).cpu().numpy()
+    # executed steps as the reference counts them: up to and including the step after which nobody was live
+    lv = live.cpu().numpy()
+    steps = cap.last_beam_steps
+    for t in range(steps):
+        if lv[t + 1] == 0:
+            steps = t + 1
+            break
+    cap.last_beam_steps = steps
+    captions, scores, ids = [], [], []
+    for i in range(n_img):
+        cand = [wd[i, k, :ln[i, k]].tolist() for k in range(beam)]
+        captions.append([' '.join(cap.idx2word[w] for w in words_k if w != cap.eos_id) for words_k in cand])
+        scores.append([float(x) for x in sc[i]])
+        ids.append(cand)
     return captions, scores, ids

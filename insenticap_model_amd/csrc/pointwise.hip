@@ -86,6 +86,91 @@ extern "C" int isc_embed_senti_words_fwd(const float *emb, int V, int W, const i
     return ISC_OK;
 }
 
+// ------------------------------------------------------------------ beam search: candidate merge on the device
+// captioner.py:378-411 for every image of a batched search, without the per-step device->host->device round trip:
+// one workgroup per image.  Candidates in the reference's insertion order (parents by rank; an ended parent carries
+// itself, a live one contributes its `beam` children by rank), scores as fp64 sums of the fp32 log-probs (the
+// reference adds Python floats), selection = the first `beam` of a STABLE descending sort:
+//     rank(c) = #{ j : s_j > s_c } + #{ j < c : s_j == s_c }.
+// State is double-buffered by the caller (in -> out).  gather[row] = source row of the new row inside
+// [next-state rows ; current-state rows] (a stepped parent's new state, or a carried candidate's old one).
+#define ISC_BEAM_MAX 8
+__global__ __launch_bounds__(64) void beam_merge_kernel(const isc_beam_merge_args a) {
+    __shared__ double cs[ISC_BEAM_MAX * ISC_BEAM_MAX];
+    __shared__ long long ctok[ISC_BEAM_MAX * ISC_BEAM_MAX];
+    __shared__ int cpar[ISC_BEAM_MAX * ISC_BEAM_MAX], ccar[ISC_BEAM_MAX * ISC_BEAM_MAX], coff[ISC_BEAM_MAX + 1];
+    __shared__ int s_all_ended;
+    const int i = blockIdx.x, tid = threadIdx.x, beam = a.beam, T = a.T, rows = a.n_img * beam, base = i * beam;
+    if (a.done[i]) {                      // frozen image: state carried over unchanged, rows keep their old state
+        for (int k = tid; k < beam; k += 64) {
+            a.gather[base + k] = base + k + rows;
+            a.last_out[base + k] = a.last_in[base + k];
+            a.score_out[base + k] = a.score_in[base + k];
+            a.len_out[base + k] = a.len_in[base + k];
+        }
+        for (int e = tid; e < beam * T; e += 64) a.words_out[(long long)base * T + e] = a.words_in[(long long)base * T + e];
+        return;
+    }
+    const int ncand = a.t == 0 ? 1 : beam;
+    if (tid == 0) {
+        int off = 0, all_ended = 1;
+        for (int k = 0; k < ncand; ++k) {
+            coff[k] = off;
+            const int ended = a.t > 0 && a.last_in[base + k] == a.eos_id;
+            off += ended ? 1 : beam;
+            all_ended &= ended;
+        }
+        coff[ncand] = off;
+        s_all_ended = all_ended;
+    }
+    __syncthreads();
+    const int n = coff[ncand];
+    for (int e = tid; e < ncand * beam; e += 64) {
+        const int k = e / beam, j = e % beam, row = base + k;
+        const int ended = a.t > 0 && a.last_in[row] == a.eos_id;
+        if (ended) {
+            if (j == 0) { const int c = coff[k]; cs[c] = a.score_in[row]; ctok[c] = a.last_in[row]; cpar[c] = k; ccar[c] = 1; }
+        } else {
+            const int c = coff[k] + j;
+            cs[c] = a.score_in[row] + (double)a.top_val[(long long)row * beam + j];
+            ctok[c] = a.top_idx[(long long)row * beam + j];
+            cpar[c] = k; ccar[c] = 0;
+        }
+    }
+    __syncthreads();
+    if (tid < n) {
+        const double sc = cs[tid];
+        int rank = 0;
+        for (int j = 0; j < n; ++j) rank += (cs[j] > sc) || (cs[j] == sc && j < tid);
+        if (rank < beam) {
+            const int par = cpar[tid], car = ccar[tid], dst = base + rank, srow = base + par;
+            a.score_out[dst] = sc;
+            a.last_out[dst] = ctok[tid];
+            a.gather[dst] = car ? srow + rows : srow;
+            const int len = a.len_in[srow];
+            for (int e = 0; e < T; ++e) a.words_out[(long long)dst * T + e] = a.words_in[(long long)srow * T + e];
+            if (!car && len < T) a.words_out[(long long)dst * T + len] = ctok[tid];
+            a.len_out[dst] = len + (car ? 0 : 1);
+        }
+    }
+    if (tid == 0) {
+        if (s_all_ended) a.done[i] = 1;
+        else atomicAdd(&a.live[a.t + 1], 1);
+    }
+}
+
+extern "C" int isc_beam_merge(const isc_beam_merge_args *args, void *stream) {
+    if (!args) return ISC_E_NULL;
+    const isc_beam_merge_args &a = *args;
+    if (!a.top_val || !a.top_idx || !a.score_in || !a.score_out || !a.last_in || !a.last_out || !a.words_in ||
+        !a.words_out || !a.len_in || !a.len_out || !a.done || !a.gather || !a.live)
+        return ISC_E_NULL;
+    if (a.n_img <= 0 || a.beam <= 0 || a.beam > ISC_BEAM_MAX || a.T <= 0 || a.t < 0 || a.t >= a.T) return ISC_E_SHAPE;
+    hipLaunchKernelGGL(beam_merge_kernel, dim3(a.n_img), dim3(64), 0, (hipStream_t)stream, a);
+    ISC_LAUNCH_CHECK();
+    return ISC_OK;
+}
+
 // ------------------------------------------------------------------ row statistics helper
 // Folds the per-tile (max, sumexp, argmax) triples of one row: returns the global max, its
 // vocabulary index (smallest index on ties) and S = sum exp(x - gmax).  All 64 lanes get

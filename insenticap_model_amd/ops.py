@@ -387,6 +387,11 @@ def beam_topk(logits, part_max, part_sum, last_word, beam, pad_id, sos_id, unk_i
                             top_idx.data_ptr(), stream()), 'isc_beam_topk')
 
 
+def beam_merge(args):
+    """One candidate-merge step of a batched beam search on the device (isc_beam_merge)."""
+    check(_lib.load().isc_beam_merge(C.byref(args), stream()), 'isc_beam_merge')
+
+
 def xe_loss_fwd(logp, target, lengths_i32, out2):
     lib = _lib.load()
     B, T, V = logp.shape

@@ -65,6 +65,8 @@ int main(void) {
   printf("%zu %zu %zu %zu %zu %zu\n", sizeof(isc_step_plan), offsetof(isc_step_plan, tok_stride),
          offsetof(isc_step_plan, out_scale), offsetof(isc_step_plan, pidx), sizeof(isc_step_bwd_plan),
          offsetof(isc_step_bwd_plan, dbg_rows));
+  printf("%zu %zu %zu %zu %zu\n", offsetof(isc_step_plan, words_ids_ld), offsetof(isc_lstm_problem, h_lo),
+         offsetof(isc_scan_problem, row_ids_ld), sizeof(isc_beam_merge_args), offsetof(isc_beam_merge_args, live));
   return 0;
 }
 '''
@@ -82,7 +84,9 @@ int main(void) {
            ctypes.sizeof(L.ScanBwdProblem),
            L.LstmProblem.c_prev.offset, L.ScanProblem.out.offset, L.RolloutStep.xt_next.offset,
            ctypes.sizeof(L.StepPlan), L.StepPlan.tok_stride.offset, L.StepPlan.out_scale.offset,
-           L.StepPlan.pidx.offset, ctypes.sizeof(L.StepBwdPlan), L.StepBwdPlan.dbg_rows.offset]
+           L.StepPlan.pidx.offset, ctypes.sizeof(L.StepBwdPlan), L.StepBwdPlan.dbg_rows.offset,
+           L.StepPlan.words_ids_ld.offset, L.LstmProblem.h_lo.offset, L.ScanProblem.row_ids_ld.offset,
+           ctypes.sizeof(L.BeamMergeArgs), L.BeamMergeArgs.live.offset]
     assert got == exp
 
 

@@ -363,3 +363,26 @@ def test_greedy_b1024_vs_oracle_on_the_split_f16_path(mode):
         assert (seq[b, :n[b]] == oseq[b, :n[b]]).all(), b
         assert (mk[b, :n[b]] == omk[b, :n[b]]).all(), b
         np.testing.assert_allclose(lp[b, :n[b]], olp[b, :n[b]], atol=LOGP_TOL)
+
+
+def test_beam_device_merge_equals_host_merge():
+    """The on-device candidate merge (isc_beam_merge: fp64 score sums, stable descending selection in insertion order,
+    carried <EOS> candidates, frozen finished images) returns exactly what the host-side merges return - for a batch
+    (numpy merge), for a pair of images (Python list merge) and with early-finishing images in the batch."""
+    cap, c, st, w, _, _ = make_captioner('cfg1')
+    n, Tn = 48, 20
+    d = synth.make_inputs(n, c['V'], st, regions=36, seq_len=Tn, seed=2024)
+    fc, att, sw, lab = T(d, 'fc_feats'), T(d, 'att_feats'), T(d, 'senti_words'), T(d, 'senti_labels')
+    try:
+        for sl, beam in ((slice(0, n), 5), (slice(0, 2), 3), (slice(5, 6), 5), (slice(0, 16), 8)):
+            cap.beam_device_merge = True
+            dev_out = cap.sample_batch(fc[sl], att[sl], sw[sl], lab[sl], beam, 1, Tn)
+            steps_dev = cap.last_beam_steps
+            cap.beam_device_merge = False
+            host_out = cap.sample_batch(fc[sl], att[sl], sw[sl], lab[sl], beam, 1, Tn)
+            assert dev_out[0] == host_out[0]                      # captions, beam order included
+            assert dev_out[2] == host_out[2]                      # word ids
+            np.testing.assert_array_equal(np.asarray(dev_out[1]), np.asarray(host_out[1]))   # fp64 scores, bit for bit
+            assert steps_dev == cap.last_beam_steps
+    finally:
+        cap.beam_device_merge = True
