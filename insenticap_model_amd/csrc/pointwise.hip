@@ -433,6 +433,87 @@ extern "C" int isc_logsoftmax_apply(float *logits, int64_t ld_logits, int M, int
 }
 
 // ------------------------------------------------------------------ beam top-k
+// Single-pass form for beam <= 8: every thread keeps the best 8 of its ~V/256 entries in registers (one sweep of
+// 16-byte loads instead of `beam` sweeps), then `beam` rounds of a block-wide arg-max over the threads' list heads.
+// Same values, same order as the kernel below (descending value, ties to the smaller word id, masked entries take
+// part as -inf): [5 x 10000] 78 -> 12 us, which was 40 % of a one-image search.
+__global__ __launch_bounds__(256) void beam_topk8_kernel(const float *logits, long long ld,
+                                                         const float *pmax, const float *psum, int n_tile,
+                                                         int V, int beam, const int64_t *last_word,
+                                                         long long pad_id, long long sos_id,
+                                                         long long unk_id, int mask_special, int cons,
+                                                         float *top_val, int64_t *top_idx) {
+    constexpr int K = 8;
+    __shared__ float sv[2][4];
+    __shared__ int si[2][4];
+    __shared__ float sh[2];
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < 64) {
+        float gmax, S;
+        int gi;
+        fold_row_stats(pmax + (long long)row * n_tile, psum + (long long)row * n_tile, nullptr, n_tile,
+                       tid, gmax, gi, S);
+        if (tid == 0) { sh[0] = gmax; sh[1] = logf(S); }
+    }
+    __syncthreads();
+    const float gmax = sh[0], logS = sh[1];
+    const float *x = logits + (long long)row * ld;
+    const long long last = last_word[row];
+    float tv[K];
+    int ti[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) { tv[k] = -INFINITY; ti[k] = 0x7fffffff; }
+    auto offer = [&](float raw, int i) __attribute__((always_inline)) {
+        bool banned = false;
+        if (mask_special && (i == pad_id || i == sos_id || i == unk_id)) banned = true;
+        if (cons && i == last) banned = true;
+        float v = banned ? -INFINITY : (raw - gmax) - logS;
+        int id = i;
+        // insertion into the sorted list (best first); indices arrive in increasing order inside a thread
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const bool better = v > tv[k] || (v == tv[k] && id < ti[k]);
+            const float ov = tv[k];
+            const int oi = ti[k];
+            tv[k] = better ? v : ov;
+            ti[k] = better ? id : oi;
+            v = better ? ov : v;
+            id = better ? oi : id;
+        }
+    };
+    const bool vec = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(logits) & 15) == 0);
+    const int V4 = vec ? (V >> 2) : 0;
+    for (int c = tid; c < V4; c += 256) {
+        const float4 q = reinterpret_cast<const float4 *>(x)[c];
+        offer(q.x, 4 * c); offer(q.y, 4 * c + 1); offer(q.z, 4 * c + 2); offer(q.w, 4 * c + 3);
+    }
+    for (int i = 4 * V4 + tid; i < V; i += 256) offer(x[i], i);
+    for (int k = 0; k < beam; ++k) {
+        float mx = tv[0];
+        int ix = ti[0];
+        wave_argmax(mx, ix);
+        if (lane == 0) { sv[k & 1][wave] = mx; si[k & 1][wave] = ix; }
+        __syncthreads();
+        float bm = sv[k & 1][0];
+        int bi = si[k & 1][0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            const float wv2 = sv[k & 1][w];
+            const int wi = si[k & 1][w];
+            if (wv2 > bm || (wv2 == bm && wi < bi)) { bm = wv2; bi = wi; }
+        }
+        if (ti[0] == bi) {                 // this thread's head won: pop it (word ids are unique)
+#pragma unroll
+            for (int j = 0; j + 1 < K; ++j) { tv[j] = tv[j + 1]; ti[j] = ti[j + 1]; }
+            tv[K - 1] = -INFINITY; ti[K - 1] = 0x7fffffff;
+        }
+        if (tid == 0) {
+            top_val[(long long)row * beam + k] = bm;
+            top_idx[(long long)row * beam + k] = bi;
+        }
+    }
+}
+
 // One workgroup per live beam row; `beam` rounds of a block-wide arg-max over the masked
 // log-probabilities (rows are few: images x beam).  Ties resolve to the smaller word id.
 __global__ __launch_bounds__(256) void beam_topk_kernel(const float *logits, long long ld,
@@ -492,10 +573,16 @@ extern "C" int isc_beam_topk(const float *logits, int64_t ld_logits, const float
                              int64_t *top_idx, void *stream) {
     if (!logits || !part_max || !part_sum || !last_word || !top_val || !top_idx) return ISC_E_NULL;
     if (rows <= 0 || V <= 0 || beam <= 0 || beam > 16 || beam > V) return ISC_E_SHAPE;
-    hipLaunchKernelGGL(beam_topk_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, logits,
-                       (long long)ld_logits, part_max, part_sum, n_tile, V, beam, last_word,
-                       (long long)pad_id, (long long)sos_id, (long long)unk_id, mask_special,
-                       decoding_constraint, top_val, top_idx);
+    if (beam <= 8 && V >= 8)
+        hipLaunchKernelGGL(beam_topk8_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, logits,
+                           (long long)ld_logits, part_max, part_sum, n_tile, V, beam, last_word,
+                           (long long)pad_id, (long long)sos_id, (long long)unk_id, mask_special,
+                           decoding_constraint, top_val, top_idx);
+    else
+        hipLaunchKernelGGL(beam_topk_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, logits,
+                           (long long)ld_logits, part_max, part_sum, n_tile, V, beam, last_word,
+                           (long long)pad_id, (long long)sos_id, (long long)unk_id, mask_special,
+                           decoding_constraint, top_val, top_idx);
     ISC_LAUNCH_CHECK();
     return ISC_OK;
 }

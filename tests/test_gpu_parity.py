@@ -386,3 +386,38 @@ def test_beam_device_merge_equals_host_merge():
             assert steps_dev == cap.last_beam_steps
     finally:
         cap.beam_device_merge = True
+
+
+@pytest.mark.parametrize('rows,V,beam', [(5, 10000, 5), (7, 9487, 3), (3, 130, 8), (2, 10000, 12)])
+def test_beam_topk_kernel_order_ties_and_masks(rows, V, beam):
+    """isc_beam_topk (single-pass kernel for beam <= 8, round-based above): top-`beam` of the masked log-probs in
+    descending order, ties to the smaller word id, <PAD>/<SOS>/<UNK> and the repeated last word masked to -inf."""
+    g = torch.Generator().manual_seed(rows * V)
+    K = 64
+    h = torch.randn(rows, K, generator=g)
+    W = torch.randn(V, K, generator=g) / 8
+    W[17] = W[4000 % V]                           # exact ties between word ids
+    W[V - 1] = W[123 % V]
+    bias = torch.zeros(V)
+    nt = (V + 127) // 128
+    dh, dW, db = h.to(dev()), W.to(dev()), bias.to(dev())
+    pm, ps = torch.empty(rows, nt, device=dev()), torch.empty(rows, nt, device=dev())
+    pi = torch.empty(rows, nt, device=dev(), dtype=torch.int32)
+    logits = torch.empty(rows, V, device=dev())
+    ops.vocab_fwd(dh, dW, db, pm, ps, pi, logits)
+    last = torch.tensor([4000 % V, 17, 5, 123 % V, V - 1, 9, 11][:rows], dtype=torch.int64, device=dev())
+    tv = torch.empty(rows, beam, device=dev())
+    ti = torch.empty(rows, beam, dtype=torch.int64, device=dev())
+    pad_id, sos_id, unk_id = 0, 1, 3
+    ops.beam_topk(logits, pm, ps, last, beam, pad_id, sos_id, unk_id, True, 1, tv, ti)
+    torch.cuda.synchronize()
+    lg = logits.cpu()
+    mx = pm.cpu().max(1).values
+    lse = mx + torch.log((ps.cpu() * torch.exp(pm.cpu() - mx[:, None])).sum(1))
+    for r in range(rows):
+        logp = (lg[r] - mx[r]) - torch.log((ps.cpu()[r] * torch.exp(pm.cpu()[r] - mx[r])).sum())
+        logp[[pad_id, sos_id, unk_id]] = -float('inf')
+        logp[last[r].item()] = -float('inf')
+        order = sorted(range(V), key=lambda i: (-logp[i].item(), i))[:beam]
+        assert ti[r].cpu().tolist() == order, r
+        np.testing.assert_allclose(tv[r].cpu().numpy(), logp[order].numpy(), atol=2e-6)
