@@ -281,6 +281,10 @@ typedef struct {
 } isc_beam_merge_args;
 
 int isc_beam_merge(const isc_beam_merge_args *args_host, void *stream);
+/* State re-ordering of a beam step: out[p, r, :] = (gather[r] < rows ? state_next : state_cur)[p, gather[r] % rows, :]
+ * for the `planes` [rows, H] planes of the recurrent state (h|c x layer), gather as written by isc_beam_merge. */
+int isc_beam_gather(const float *state_next, const float *state_cur, const int64_t *gather, float *out,
+                    int planes, int rows, int H, void *stream);
 
 /* Masked NLL (XECriterion, captioner.py:427-440): returns sum and token count in out[0..1].
  * logp [B,T,V] contiguous, target [B,T] int64, lengths [B] int32. */

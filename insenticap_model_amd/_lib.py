@@ -139,6 +139,7 @@ SIGNATURES = {
                                             C.c_int, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
     'isc_rollout_finalize': (C.c_int, [C.POINTER(RolloutStep), C.c_void_p]),
     'isc_beam_merge': (C.c_int, [C.POINTER(BeamMergeArgs), C.c_void_p]),
+    'isc_beam_gather': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'isc_beam_topk': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                 C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int,
                                 C.c_void_p, C.c_void_p, C.c_void_p]),

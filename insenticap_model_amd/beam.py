@@ -138,7 +138,7 @@ def beam_search_batch(cap, fc_feats, att_feats, senti_words, senti_labels, beam,
     p = cap._p()
     n_img = fc_feats.shape[0]
     P = cap._prologue(p, 'beam', fc_feats, att_feats, None, senti_words,
-                      senti_labels if senti_words is not None else None, want_table='cached',
+                      senti_labels if senti_words is not None else None, want_table='build',
                       words_table=getattr(cap, 'words_table', True))
     dev = cap._dev
     H, Wd, V = cap.att_lstm.hidden_size, cap.settings['word_emb_dim'], cap.vocab_size
@@ -227,6 +227,7 @@ def _search_device_merge(cap, p, Pb, ws, st_cur, st_nxt, logits, xt, emb, top_va
     a.n_img, a.beam, a.T, a.eos_id = n_img, beam, T, cap.eos_id
     a.top_val, a.top_idx = top_val.data_ptr(), top_idx.data_ptr()
     a.done, a.gather, a.live = done.data_ptr(), gather.data_ptr(), live.data_ptr()
+    st_free = torch.empty_like(st_cur)         # third state buffer: target of the per-step re-ordering
     cur = 0
     with ops.h3_weights_scope(dev):
         for t in range(T):
@@ -250,7 +251,8 @@ def _search_device_merge(cap, p, Pb, ws, st_cur, st_nxt, logits, xt, emb, top_va
                 if int(live[t + 1].item()) == 0:          # the one host read: every image has finished
                     break
             # new state of row r = stepped ? nxt[parent] : cur[parent]  ==  [nxt ; cur][gather[r]]
-            st_cur = torch.cat([st_nxt, st_cur], dim=2).index_select(2, gather)
+            ops.beam_gather(st_nxt, st_cur, gather, st_free)
+            st_cur, st_free = st_free, st_cur
     cap.cont_weights, cap.senti_weights, cap.cont_senti_weights = [], [], []
     sc = score[cur].view(n_img, beam).cpu().tolist()
     wd = words[cur].view(n_img, beam, T).cpu().numpy()

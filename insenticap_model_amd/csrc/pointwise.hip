@@ -171,6 +171,29 @@ extern "C" int isc_beam_merge(const isc_beam_merge_args *args, void *stream) {
     return ISC_OK;
 }
 
+// New recurrent state of every beam row: out[p, r, :] = (gather[r] < rows ? next : current)[p, gather[r] % rows, :]
+// for the P = 4 planes (h|c x layer) of a [P, rows, H] state - one launch instead of a concatenation + index_select.
+__global__ __launch_bounds__(256) void beam_gather_kernel(const float *nxt, const float *cur, const int64_t *gather,
+                                                          float *out, int rows, int H) {
+    const int r = blockIdx.x, p = blockIdx.y;
+    const long long g = gather[r];
+    const float *src = (g < rows ? nxt : cur) + ((long long)p * rows + (g < rows ? g : g - rows)) * H;
+    float *dst = out + ((long long)p * rows + r) * H;
+    for (int i = threadIdx.x; i < (H >> 2); i += 256)
+        reinterpret_cast<float4 *>(dst)[i] = reinterpret_cast<const float4 *>(src)[i];
+}
+
+extern "C" int isc_beam_gather(const float *state_next, const float *state_cur, const int64_t *gather, float *out,
+                               int planes, int rows, int H, void *stream) {
+    if (!state_next || !state_cur || !gather || !out) return ISC_E_NULL;
+    if (planes <= 0 || rows <= 0 || H <= 0 || (H & 3)) return ISC_E_SHAPE;
+    if (!isc_aligned16(state_next) || !isc_aligned16(state_cur) || !isc_aligned16(out)) return ISC_E_ALIGN;
+    hipLaunchKernelGGL(beam_gather_kernel, dim3(rows, planes), dim3(256), 0, (hipStream_t)stream, state_next, state_cur,
+                       gather, out, rows, H);
+    ISC_LAUNCH_CHECK();
+    return ISC_OK;
+}
+
 // ------------------------------------------------------------------ row statistics helper
 // Folds the per-tile (max, sumexp, argmax) triples of one row: returns the global max, its
 // vocabulary index (smallest index on ties) and S = sum exp(x - gmax).  All 64 lanes get

@@ -392,6 +392,15 @@ def beam_merge(args):
     check(_lib.load().isc_beam_merge(C.byref(args), stream()), 'isc_beam_merge')
 
 
+def beam_gather(state_next, state_cur, gather, out):
+    """[2,2,rows,H] recurrent states: out = [next ; current][gather] row by row (isc_beam_gather)."""
+    rows, H = state_cur.shape[-2], state_cur.shape[-1]
+    planes = state_cur.numel() // (rows * H)
+    assert state_next.is_contiguous() and state_cur.is_contiguous() and out.is_contiguous()
+    check(_lib.load().isc_beam_gather(state_next.data_ptr(), state_cur.data_ptr(), gather.data_ptr(), out.data_ptr(),
+                                      planes, rows, H, stream()), 'isc_beam_gather')
+
+
 def xe_loss_fwd(logp, target, lengths_i32, out2):
     lib = _lib.load()
     B, T, V = logp.shape
