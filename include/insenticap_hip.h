@@ -247,8 +247,8 @@ int isc_sched_sample(const float *logp, int64_t ld, int M, int V, const float *p
 
 /* Beam step (sample(), captioner.py:390-409), batched over images: for every live beam row
  * apply the -inf masks (PAD,SOS,UNK, last word), take its top-`beam` (value, id) pairs
- * from logp = logits - lse.  Candidate merge + stable ordering is done by the host mirror
- * in fp64 exactly like the reference's Python floats. */
+ * from logp = logits - lse (descending, ties to the smaller word id).  The candidate merge with the reference's
+ * stable ordering and fp64 score sums is isc_beam_merge below (or the host mirror's Python / numpy forms). */
 int isc_beam_topk(const float *logits, int64_t ld_logits, const float *part_max,
                   const float *part_sum, int n_tile, int rows, int V, int beam,
                   const int64_t *last_word, int64_t pad_id, int64_t sos_id, int64_t unk_id,
