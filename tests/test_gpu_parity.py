@@ -421,3 +421,34 @@ def test_beam_topk_kernel_order_ties_and_masks(rows, V, beam):
         order = sorted(range(V), key=lambda i: (-logp[i].item(), i))[:beam]
         assert ti[r].cpu().tolist() == order, r
         np.testing.assert_allclose(tv[r].cpu().numpy(), logp[order].numpy(), atol=2e-6)
+
+
+def test_sampled_rollout_b1024_replayed_by_the_oracle():
+    """Sampled roll-out (sample_max=0) at B=1024 with the split-f16 path forced on: the device draws the tokens
+    (two-level inverse CDF over the materialised log-probs); the oracle replays those raw draws and must assign them
+    the same log-probs (1e-4), masks and <EOS> handling - the logits-writing side of the classifier epilogue."""
+    cap, c, st, w, _, _ = make_captioner('cfg1')
+    B, Tn = 1024, 20
+    d = synth.make_inputs(B, c['V'], st, regions=36, seq_len=Tn, seed=777)
+    a = [T(d, k) for k in ('fc_feats', 'att_feats', 'cpt_words', 'senti_words', 'senti_labels')]
+    prev = ops.set_h3_mode(2)
+    try:
+        torch.manual_seed(5)
+        with torch.no_grad():
+            seq, lp, mk, raw, _ = cap._rollout(*a, Tn, 0, None, None)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_h3_mode(prev)
+    O = oracle()
+    p = O.to_params(w)
+    oid = O.Ids(synth.make_idx2word(c['V']), synth.SENTIMENT_CATEGORIES)
+    ca = [torch.from_numpy(np.asarray(d[k])) for k in ('fc_feats', 'att_feats', 'cpt_words', 'senti_words', 'senti_labels')]
+    with torch.no_grad():
+        oseq, olp, omk, _, _, _ = O.forward_rl(p, oid, *ca, Tn, 0, replay=raw.cpu())
+    steps = int(omk.sum(1).max().item())                     # the oracle stops once every row has ended
+    assert (seq.cpu()[:, :steps] == oseq[:, :steps]).all()
+    assert (mk.cpu()[:, :steps] == omk[:, :steps]).all()
+    live = omk[:, :steps].bool()
+    np.testing.assert_allclose(lp.cpu()[:, :steps][live].numpy(), olp[:, :steps][live].numpy(), atol=LOGP_TOL)
+    # the draws follow the distribution: mean log-prob of the drawn tokens ~ -entropy, far above uniform (-9.2)
+    assert lp.cpu()[:, 0].mean().item() > -9.0
