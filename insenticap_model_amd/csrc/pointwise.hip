@@ -456,10 +456,13 @@ extern "C" int isc_logsoftmax_apply(float *logits, int64_t ld_logits, int M, int
 }
 
 // ------------------------------------------------------------------ beam top-k
-// Single-pass form for beam <= 8: every thread keeps the best 8 of its ~V/256 entries in registers (one sweep of
-// 16-byte loads instead of `beam` sweeps), then `beam` rounds of a block-wide arg-max over the threads' list heads.
-// Same values, same order as the kernel below (descending value, ties to the smaller word id, masked entries take
-// part as -inf): [5 x 10000] 78 -> 12 us, which was 40 % of a one-image search.
+// Form for beam <= 8 over the tile statistics the classifier already produced: the top-`beam` masked log-probs can
+// only sit in column tiles whose maximum is among the (beam + 4) largest tile maxima - at most 4 words are masked
+// (<PAD>, <SOS>, <UNK>, the repeated last word), so at least `beam` unmasked entries reach that threshold and nothing
+// below it can be selected.  Those ~9 of 79 tiles are swept once, every thread keeping its best 8 in registers, then
+// `beam` rounds of a block-wide arg-max over the threads' list heads.  Same values and order as the kernel below
+// (descending value, ties to the smaller word id, masked entries as -inf): [5 x 10000] 78 us -> ~10 us, which was
+// 40 % of a one-image search.
 __global__ __launch_bounds__(256) void beam_topk8_kernel(const float *logits, long long ld,
                                                          const float *pmax, const float *psum, int n_tile,
                                                          int V, int beam, const int64_t *last_word,
@@ -470,7 +473,10 @@ __global__ __launch_bounds__(256) void beam_topk8_kernel(const float *logits, lo
     __shared__ float sv[2][4];
     __shared__ int si[2][4];
     __shared__ float sh[2];
+    __shared__ int sel[256];               // selected tile ids (n_tile <= 256 on this path)
+    __shared__ int nsel;
     const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) nsel = 0;
     if (tid < 64) {
         float gmax, S;
         int gi;
@@ -480,6 +486,18 @@ __global__ __launch_bounds__(256) void beam_topk8_kernel(const float *logits, lo
     }
     __syncthreads();
     const float gmax = sh[0], logS = sh[1];
+    // tile selection: rank of this thread's tile among the tile maxima (ties by tile id); tiles tied with the last
+    // admitted maximum are admitted as well because the comparison below is on values, not ranks
+    const float *pm = pmax + (long long)row * n_tile;
+    const int want = beam + 4;
+    if (tid < n_tile) {
+        const float mine = pm[tid];
+        int larger = 0;
+        for (int j = 0; j < n_tile; ++j) larger += pm[j] > mine;
+        if (larger < want) sel[atomicAdd(&nsel, 1)] = tid;     // order of `sel` is irrelevant: ids break ties later
+    }
+    __syncthreads();
+    const int ns = nsel;
     const float *x = logits + (long long)row * ld;
     const long long last = last_word[row];
     float tv[K];
@@ -492,9 +510,8 @@ __global__ __launch_bounds__(256) void beam_topk8_kernel(const float *logits, lo
         if (cons && i == last) banned = true;
         float v = banned ? -INFINITY : (raw - gmax) - logS;
         int id = i;
-        // insertion into the sorted list (best first); indices arrive in increasing order inside a thread
 #pragma unroll
-        for (int k = 0; k < K; ++k) {
+        for (int k = 0; k < K; ++k) {      // insertion into the sorted list (best first)
             const bool better = v > tv[k] || (v == tv[k] && id < ti[k]);
             const float ov = tv[k];
             const int oi = ti[k];
@@ -504,13 +521,14 @@ __global__ __launch_bounds__(256) void beam_topk8_kernel(const float *logits, lo
             id = better ? oi : id;
         }
     };
-    const bool vec = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(logits) & 15) == 0);
-    const int V4 = vec ? (V >> 2) : 0;
-    for (int c = tid; c < V4; c += 256) {
-        const float4 q = reinterpret_cast<const float4 *>(x)[c];
-        offer(q.x, 4 * c); offer(q.y, 4 * c + 1); offer(q.z, 4 * c + 2); offer(q.w, 4 * c + 3);
+    // two selected tiles per pass: thread t takes column (t & 127) of tile sel[2*pass + (t >> 7)]
+    for (int s0 = 0; s0 < ns; s0 += 2) {
+        const int si2 = s0 + (tid >> 7);
+        if (si2 < ns) {
+            const int i = sel[si2] * 128 + (tid & 127);
+            if (i < V) offer(x[i], i);
+        }
     }
-    for (int i = 4 * V4 + tid; i < V; i += 256) offer(x[i], i);
     for (int k = 0; k < beam; ++k) {
         float mx = tv[0];
         int ix = ti[0];
@@ -596,7 +614,7 @@ extern "C" int isc_beam_topk(const float *logits, int64_t ld_logits, const float
                              int64_t *top_idx, void *stream) {
     if (!logits || !part_max || !part_sum || !last_word || !top_val || !top_idx) return ISC_E_NULL;
     if (rows <= 0 || V <= 0 || beam <= 0 || beam > 16 || beam > V) return ISC_E_SHAPE;
-    if (beam <= 8 && V >= 8)
+    if (beam <= 8 && n_tile <= 256 && V >= (beam + 4) * 128)
         hipLaunchKernelGGL(beam_topk8_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, logits,
                            (long long)ld_logits, part_max, part_sum, n_tile, V, beam, last_word,
                            (long long)pad_id, (long long)sos_id, (long long)unk_id, mask_special,
