@@ -11,8 +11,13 @@
  * Conventions (all entry points):
  *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless the
  *     name ends in _host; tensors are row-major fp32, ids are int64 ("LongTensor");
- *   - no allocation, no ownership transfer, no global mutable state, no device
- *     synchronisation: work is enqueued on `stream` (a hipStream_t passed as void*);
+ *   - no allocation, no ownership transfer, no device synchronisation: work is enqueued on
+ *     `stream` (a hipStream_t passed as void*);
+ *   - no data-carrying global state: entry points may be called from several host threads on
+ *     distinct streams at once (tests/test_gpu_threads.py).  What the library keeps is (a) two
+ *     process-wide tuning words, isc_set_tile_override / isc_set_h3_mode (atomic; they pick a
+ *     kernel, never change a result beyond fp32 summation order), (b) launch counters (atomic),
+ *     and (c) the split-f16 weights scopes, which are keyed by stream (isc_h3_weights_begin);
  *   - return value: 0 ok; <0 bad argument / unsupported shape (ISC_E_*);
  *     >0 a hipError_t from the launch. Never throws, never exits.
  *   - leading dimensions are in elements; every row start must be 16-byte aligned
@@ -53,16 +58,20 @@ int isc_set_tile_override(int tile);
  * problem that does not goes through it in row chunks (the prologue's region projections).  A tile override
  * (>= 0) also disables it.  Returns the previous mode. */
 int isc_set_h3_mode(int mode);
-/* Number of launches that went out on the split-f16 path so far (process-wide; measurement / test hook). */
+/* Number of launches that went out on the split-f16 path so far (process-wide; measurement / test hook);
+ * isc_h3x_launches: those of them that took the 256x128 eight-wave tile (launches of >= 224 such tiles). */
 long long isc_h3_launches(void);
+long long isc_h3x_launches(void);
 /* Weights scope of the split-f16 path.  Between _begin and _end the caller guarantees that no weight matrix passed
  * to the forward entry points changes (a roll-out's decode loop): each weight operand is then split into its planes
  * once, into `buf` (device memory, 256-byte aligned; 64 MB holds the decoder's matrices), and later launches with
- * the same weight segments reuse them instead of re-splitting per step.  Launches inside the scope must be issued in
- * one stream order.  Without a scope, or when `buf` is full, every launch splits its weights into the workspace.
- * _begin discards earlier entries; _end closes the scope (`buf` may then be reused). */
-int isc_h3_weights_begin(void *buf, long long bytes);
-int isc_h3_weights_end(void);
+ * the same weight segments reuse them instead of re-splitting per step.  A scope belongs to ONE stream: only
+ * launches on `stream` see it, and they must be issued in one order (as a stream's launches are anyway); up to 16
+ * streams may hold a scope at once (ISC_E_WORKSPACE beyond that: run without).  Without a scope, or when `buf` is
+ * full, every launch splits its weights into the workspace.  _begin discards the stream's earlier entries; _end
+ * closes its scope (`buf` may then be reused). */
+int isc_h3_weights_begin(void *buf, long long bytes, void *stream);
+int isc_h3_weights_end(void *stream);
 
 /* One K-segment of a contraction: acc += A[M,K] * W[N,K]^T.  Replaces the
  * torch.cat([...],1) + nn.Linear / nn.LSTMCell pattern of captioner.py:174-175,180-181. */

@@ -112,8 +112,9 @@ SIGNATURES = {
     'isc_set_tile_override': (C.c_int, [C.c_int]),
     'isc_set_h3_mode': (C.c_int, [C.c_int]),
     'isc_h3_launches': (C.c_longlong, []),
-    'isc_h3_weights_begin': (C.c_int, [C.c_void_p, C.c_longlong]),
-    'isc_h3_weights_end': (C.c_int, []),
+    'isc_h3x_launches': (C.c_longlong, []),
+    'isc_h3_weights_begin': (C.c_int, [C.c_void_p, C.c_longlong, C.c_void_p]),
+    'isc_h3_weights_end': (C.c_int, [C.c_void_p]),
     'isc_linear_fwd': (C.c_int, [C.POINTER(LinearProblem), C.c_int, C.c_void_p]),
     'isc_gemm_bwd': (C.c_int, [C.POINTER(LinearProblem), C.c_int, C.c_int, C.c_void_p]),
     'isc_lstm_fwd': (C.c_int, [C.POINTER(LstmProblem), C.c_void_p]),

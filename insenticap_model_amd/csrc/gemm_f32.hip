@@ -20,6 +20,8 @@
 // to 36 floats so that the ds_read_b128 fragment reads are bank-conflict free), one
 // barrier per chunk.  The finished tile is staged through LDS once so that every epilogue
 // sees (row, col) coordinates and writes full, coalesced rows.
+#include <atomic>
+#include <mutex>
 #include <type_traits>
 
 #include "common.h"
@@ -1837,13 +1839,13 @@ static int launch_cfg(const DevLaunch &L, hipStream_t st) {
     constexpr size_t k_bytes = (size_t)2 * (Tile<BM, AKM>::SIZE + Tile<BN, BKM>::SIZE) * sizeof(float);
     constexpr size_t c_bytes = (size_t)BM * (BN + 4) * sizeof(float);
     constexpr size_t lds = k_bytes > c_bytes ? k_bytes : c_bytes;
-    static bool attr_set = false;  // idempotent; a benign race only repeats the same call
-    if (!attr_set && lds > 65536) {
+    static std::atomic<bool> attr_set{false};  // idempotent: a race only repeats the same call
+    if (!attr_set.load() && lds > 65536) {
         hipError_t e = hipFuncSetAttribute(
             reinterpret_cast<const void *>(&gemm_kernel<WM, WN, TN, EPI, AKM, BKM>),
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
-        attr_set = true;
+        attr_set.store(true);
     }
     hipLaunchKernelGGL((gemm_kernel<WM, WN, TN, EPI, AKM, BKM>), dim3(L.total_tiles), dim3(256), lds, st, L);
     ISC_LAUNCH_CHECK();
@@ -1853,12 +1855,12 @@ static int launch_cfg(const DevLaunch &L, hipStream_t st) {
 template <int EPI>
 static int launch_xl(const DevLaunch &L, hipStream_t st) {
     constexpr size_t lds = (size_t)3 * (256 + 128) * BK * sizeof(float);   // 147456 >= Cs 256 x 132 floats
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<bool> attr_set{false};
+    if (!attr_set.load()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_xl_kernel<EPI>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
-        attr_set = true;
+        attr_set.store(true);
     }
     hipLaunchKernelGGL((gemm_xl_kernel<EPI>), dim3(L.total_tiles), dim3(256), lds, st, L);
     ISC_LAUNCH_CHECK();
@@ -1884,12 +1886,12 @@ static int launch_md(const DevLaunch &L, hipStream_t st) {
     return ISC_OK;
 }
 
-static int g_md_enabled = 1;   // isc_set_tile_override(102 / 103): MD path off / on (A/B measurements)
+static std::atomic<int> g_md_enabled{1};   // isc_set_tile_override(102 / 103): MD path off / on (A/B measurements)
 
 template <int EPI, bool AKM, bool BKM>
 static int launch_any(const DevLaunch &L, int tile, hipStream_t st) {
     if constexpr (EPI == EPI_LINEAR && !AKM && !BKM) {
-        if (tile == 1 && g_md_enabled) {
+        if (tile == 1 && g_md_enabled.load()) {
             bool plain = true;
             for (int i = 0; i < L.nprob; ++i) plain = plain && L.p[i].ksplit <= 1;
             if (plain) return launch_md(L, st);
@@ -1909,22 +1911,24 @@ static int launch_any(const DevLaunch &L, int tile, hipStream_t st) {
 // staged byte and per barrier) and on how many workgroups share the CU (the 128/64/32-row tiles rely
 // on a co-resident workgroup to cover their chunk-boundary stalls, the XL tile is pipelined to run
 // alone).  Calibrated on tools/gemm_big.py / gemm_bench.py.
-static int g_tile_override = -1;
+// Process-wide tuning knobs (tile override, split-f16 mode): plain configuration words, read once per launch
+// (atomics: flipping them from another thread is a data-race-free, if pointless, thing to do).  They select a
+// kernel; they carry no data between calls.
+static std::atomic<int> g_tile_override{-1};
 extern "C" int isc_set_tile_override(int tile) {
     if (tile == 102 || tile == 103) {          // measurement switch for the MD path, leaves the tile choice alone
-        g_md_enabled = tile == 103;
-        return g_tile_override;
+        g_md_enabled.store(tile == 103);
+        return g_tile_override.load();
     }
-    const int prev = g_tile_override;
-    g_tile_override = (tile >= 0 && tile <= 4) ? tile : -1;
-    return prev;
+    return g_tile_override.exchange((tile >= 0 && tile <= 4) ? tile : -1);
 }
 
 // nt: the launch is in the NT layout (the LDS-DMA tiles XL / LD exist for it; MD replaces M for the linear epilogue
 // inside launch_any); use_ld: let the cost model consider the LD tile
 static int pick_tile(const DevLaunch &L, bool allow_xl, bool nt = true, bool use_ld = true) {
-    if (g_tile_override == 4) return nt ? 4 : 0;
-    if (g_tile_override >= 0) return (g_tile_override == 3 && !allow_xl) ? 0 : g_tile_override;
+    const int ovr = g_tile_override.load();
+    if (ovr == 4) return nt ? 4 : 0;
+    if (ovr >= 0) return (ovr == 3 && !allow_xl) ? 0 : ovr;
     static const double eff[5][3] = {{0.80, 1.00, 1.00},    // L : 1, 2, >=3 workgroups on the busiest CU
                                      {0.55, 0.80, 0.90},    // M
                                      {0.35, 0.50, 0.62},    // S
@@ -1966,13 +1970,13 @@ static void finish_tiling(DevLaunch &L, int tile) {
 
 // ---- split-f16 path (gemm_h3_kernel) ----
 // isc_set_h3_mode: 0 = off, 1 = auto (launches of at least H3_MIN_TILES 128x128 tiles), 2 = whenever the shapes allow
-static int g_h3_mode = 1;
-static long long g_h3_launches = 0;
-extern "C" long long isc_h3_launches(void) { return g_h3_launches; }
+static std::atomic<int> g_h3_mode{1};
+static std::atomic<long long> g_h3_launches{0}, g_h3x_launches{0};
+extern "C" long long isc_h3_launches(void) { return g_h3_launches.load(); }
+extern "C" long long isc_h3x_launches(void) { return g_h3x_launches.load(); }
 extern "C" int isc_set_h3_mode(int mode) {
-    const int prev = g_h3_mode;
-    if (mode >= 0 && mode <= 2) g_h3_mode = mode;
-    return prev;
+    if (mode >= 0 && mode <= 2) return g_h3_mode.exchange(mode);
+    return g_h3_mode.load();
 }
 #define H3_MIN_TILES 160
 
@@ -1998,30 +2002,56 @@ struct H3WEntry {
     int ldw[ISC_MAX_SEG], K[ISC_MAX_SEG], nseg, rows;
     const _Float16 *hi, *lo;
 };
-static struct {
+// One scope per stream (isc_h3_weights_begin(buf, bytes, stream)): the slot table is guarded by a mutex, a slot's
+// entries are only touched by launches on its own stream (which the caller issues in one order, like the launches
+// themselves), so two host threads driving two captioners on two streams never see each other's planes.
+struct H3WScope {
+    hipStream_t stream = nullptr;
     char *buf = nullptr;
     size_t bytes = 0, used = 0;
     H3WEntry e[24];
     int n = 0;
     bool active = false;
-} g_h3w;
+};
+#define H3W_MAX_SCOPES 16
+static H3WScope g_h3w[H3W_MAX_SCOPES];
+static std::mutex g_h3w_mu;
 
-extern "C" int isc_h3_weights_begin(void *buf, long long bytes) {
+static H3WScope *h3w_scope_of(hipStream_t st) {
+    std::lock_guard<std::mutex> lk(g_h3w_mu);
+    for (int i = 0; i < H3W_MAX_SCOPES; ++i)
+        if (g_h3w[i].active && g_h3w[i].stream == st) return &g_h3w[i];
+    return nullptr;
+}
+
+extern "C" int isc_h3_weights_begin(void *buf, long long bytes, void *stream) {
     if (!buf || bytes <= 0) return ISC_E_NULL;
     if ((uintptr_t)buf & 255) return ISC_E_ALIGN;
-    g_h3w.buf = static_cast<char *>(buf); g_h3w.bytes = (size_t)bytes; g_h3w.used = 0; g_h3w.n = 0;
-    g_h3w.active = true;
+    std::lock_guard<std::mutex> lk(g_h3w_mu);
+    H3WScope *slot = nullptr;
+    for (int i = 0; i < H3W_MAX_SCOPES; ++i)
+        if (g_h3w[i].active && g_h3w[i].stream == (hipStream_t)stream) slot = &g_h3w[i];
+    for (int i = 0; !slot && i < H3W_MAX_SCOPES; ++i)
+        if (!g_h3w[i].active) slot = &g_h3w[i];
+    if (!slot) return ISC_E_WORKSPACE;               // more concurrent scopes than slots: the caller runs without one
+    slot->stream = (hipStream_t)stream;
+    slot->buf = static_cast<char *>(buf); slot->bytes = (size_t)bytes; slot->used = 0; slot->n = 0;
+    slot->active = true;
     return ISC_OK;
 }
-extern "C" int isc_h3_weights_end(void) {
-    g_h3w.active = false; g_h3w.n = 0; g_h3w.used = 0; g_h3w.buf = nullptr;
+extern "C" int isc_h3_weights_end(void *stream) {
+    std::lock_guard<std::mutex> lk(g_h3w_mu);
+    for (int i = 0; i < H3W_MAX_SCOPES; ++i)
+        if (g_h3w[i].active && g_h3w[i].stream == (hipStream_t)stream) {
+            g_h3w[i].active = false; g_h3w[i].n = 0; g_h3w[i].used = 0; g_h3w[i].buf = nullptr;
+        }
     return ISC_OK;
 }
 
-static const H3WEntry *h3w_find(const DevProb &p) {
-    if (!g_h3w.active) return nullptr;
-    for (int i = 0; i < g_h3w.n; ++i) {
-        const H3WEntry &e = g_h3w.e[i];
+static const H3WEntry *h3w_find(const H3WScope *sc, const DevProb &p) {
+    if (!sc) return nullptr;
+    for (int i = 0; i < sc->n; ++i) {
+        const H3WEntry &e = sc->e[i];
         bool eq = e.nseg == p.nseg && e.rows == p.N;
         for (int s = 0; eq && s < p.nseg; ++s)
             eq = e.W[s] == p.seg[s].W && e.ldw[s] == p.seg[s].ldw && e.K[s] == p.seg[s].K;
@@ -2033,12 +2063,12 @@ static const H3WEntry *h3w_find(const DevProb &p) {
 template <int EPI>
 static int launch_h3x(const DevLaunch &L, hipStream_t st) {
     constexpr size_t lds = 3 * (2 * 256 * 64 + 2 * 128 * 64);             // 147456: one workgroup per CU
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<bool> attr_set{false};
+    if (!attr_set.load()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_h3x_kernel<EPI>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
-        attr_set = true;
+        attr_set.store(true);
     }
     hipLaunchKernelGGL((gemm_h3x_kernel<EPI>), dim3(L.total_tiles), dim3(512), lds, st, L);
     ISC_LAUNCH_CHECK();
@@ -2055,6 +2085,7 @@ static int launch_h3_big(DevLaunch &L, hipStream_t st) {
     long long t256 = 0;
     for (int i = 0; i < L.nprob; ++i) t256 += (long long)((L.p[i].M + 255) / 256) * ((L.p[i].N + 127) / 128);
     if (EPI != EPI_VOCAB && t256 >= 224) {
+        ++g_h3x_launches;
         finish_tiling(L, 3);
         return launch_h3x<EPI>(L, st);
     }
@@ -2064,12 +2095,12 @@ static int launch_h3_big(DevLaunch &L, hipStream_t st) {
 
 static int launch_h3m(const DevLaunch &L, hipStream_t st) {
     constexpr size_t lds = 4 * (2 * 64 * 64 + 2 * 128 * 64);             // 98304: one workgroup per CU
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<bool> attr_set{false};
+    if (!attr_set.load()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_h3m_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
-        attr_set = true;
+        attr_set.store(true);
     }
     hipLaunchKernelGGL(gemm_h3m_kernel, dim3(L.total_tiles), dim3(256), lds, st, L);
     ISC_LAUNCH_CHECK();
@@ -2081,7 +2112,8 @@ struct H3Planner {
     SplitLaunch S = {};
     char *at;
     int blocks = 0;
-    explicit H3Planner(float *ws) : at(reinterpret_cast<char *>(ws)) {}
+    H3WScope *scope;                                   // the launch stream's weights scope, or null
+    explicit H3Planner(float *ws, H3WScope *sc = nullptr) : at(reinterpret_cast<char *>(ws)), scope(sc) {}
     // planes of segments [s0, s1) of an operand, K-packed
     void add(const DevProb &p, bool is_w, int rows, const _Float16 *&hi, const _Float16 *&lo, int s0 = 0, int s1 = -1) {
         if (s1 < 0) s1 = p.nseg;
@@ -2125,15 +2157,15 @@ struct H3Planner {
     }
     // weight operand: cached planes if the caller opened a weights scope, else planes in the workspace
     void add_w(const DevProb &p, const _Float16 *&hi, const _Float16 *&lo) {
-        if (const H3WEntry *e = h3w_find(p)) { hi = e->hi; lo = e->lo; return; }
+        if (const H3WEntry *e = h3w_find(scope, p)) { hi = e->hi; lo = e->lo; return; }
         const size_t bytes = (((size_t)p.N * h3_kp(p) * 4) + 255) & ~(size_t)255;
-        if (g_h3w.active && g_h3w.n < 24 && g_h3w.used + bytes <= g_h3w.bytes) {
+        if (scope && scope->n < 24 && scope->used + bytes <= scope->bytes) {
             char *keep = at;
-            at = g_h3w.buf + g_h3w.used;
+            at = scope->buf + scope->used;
             add(p, true, p.N, hi, lo);
             at = keep;
-            g_h3w.used += bytes;
-            H3WEntry &e = g_h3w.e[g_h3w.n++];
+            scope->used += bytes;
+            H3WEntry &e = scope->e[scope->n++];
             e.nseg = p.nseg; e.rows = p.N; e.hi = hi; e.lo = lo;
             for (int s = 0; s < p.nseg; ++s) { e.W[s] = p.seg[s].W; e.ldw[s] = p.seg[s].ldw; e.K[s] = p.seg[s].K; }
             return;
@@ -2186,7 +2218,8 @@ static int h3_linear_chunked(const DevProb &p0, float *ws, long long ws_floats, 
 // Returns 1 when the launch went out on this path (rc = its status), 0 when the path does not apply.
 template <int EPI>
 static int try_h3(DevLaunch &L, float *ws, long long ws_floats, hipStream_t st, int &rc) {
-    if (g_h3_mode == 0 || g_tile_override >= 0 || !ws || ((uintptr_t)ws & 255)) return 0;
+    const int h3_mode = g_h3_mode.load();
+    if (h3_mode == 0 || g_tile_override.load() >= 0 || !ws || ((uintptr_t)ws & 255)) return 0;
     long long tiles = 0, need = 0;
     for (int i = 0; i < L.nprob; ++i) {
         const DevProb &p = L.p[i];
@@ -2199,7 +2232,7 @@ static int try_h3(DevLaunch &L, float *ws, long long ws_floats, hipStream_t st, 
     }
     // linear launches that cannot give every CU a 128-row tile go out on the 64-row H3 tile
     const bool half_tile = EPI == EPI_LINEAR && tiles < 256;
-    if (g_h3_mode == 1 && tiles < (half_tile ? H3_MIN_TILES / 2 : H3_MIN_TILES)) return 0;
+    if (h3_mode == 1 && tiles < (half_tile ? H3_MIN_TILES / 2 : H3_MIN_TILES)) return 0;
     if (need > ws_floats) {
         if constexpr (EPI != EPI_LINEAR) return 0;
         long long chunk[3];
@@ -2220,7 +2253,7 @@ static int try_h3(DevLaunch &L, float *ws, long long ws_floats, hipStream_t st, 
         for (int i = 0; i < L.nprob; ++i) jobs += L.p[i].nseg + 1;
         if (jobs > H3_MAX_JOBS) return 0;
     }
-    H3Planner pl(ws);
+    H3Planner pl(ws, h3w_scope_of(st));
     for (int i = 0; i < L.nprob; ++i) {
         DevProb &p = L.p[i];
         p.Kp = h3_kp(p);

@@ -1,11 +1,14 @@
 """Batch-tuple producers in front of the hot path.
 
 * `create_collate_fn(name, ...)` - the four collate layouts the decoder path consumes, with the
-  semantics of /root/reference/dataloader.py:8-109 (`caption`, `scs`, `rl_fact`, `rl_senti`):
-  5-captions-per-image expansion, stable sort by caption length (descending), truncation to
-  `max_seq_len`, <PAD> filling, `lengths - 1`.  Restated from the reference text: its module cannot be
-  imported here (it needs h5py), so these are pinned by hand-checked expectations
-  (tests/test_data_checkpoint.py), not by reference-generated goldens.
+  semantics of /root/reference/dataloader.py:8-109 (`caption`, `senti_corpus_with_sentis` alias `scs`,
+  `rl_fact`, `rl_senti`): 5-captions-per-image expansion, stable sort by caption length (descending),
+  truncation to `max_seq_len`, <PAD> filling, `lengths - 1`.  Pinned by outputs of the reference's own
+  collates (tests/golden/collate.npz, written by tests/golden/make_golden.py::case_collate).
+* `FeatureStore` + `CaptionDataset` / `SCSDataset` / `RLFactDataset` / `RLSentiDataset` and the four
+  `get_*_dataloader` factories (dataloader.py:152-222,267-328): same constructor arguments and item tuples as
+  the reference's classes, but the per-item `h5py.File(...)[fn][:]` (dataloader.py:171-178: two file opens per
+  image) is replaced by one memory-mapped `[N, ...]` fp32 array + a name index, so a batch is a row gather.
 * `DevicePrefetcher` - pinned host staging + asynchronous H2D copies on a side HIP stream, one batch
   ahead of the consumer: at >10k captions/s the 303 KB of fp32 region features per caption
   (~3 GB/s and more) must overlap with decoding instead of serialising in front of it.
@@ -14,6 +17,7 @@ import random
 
 import numpy as np
 import torch
+import torch.utils.data
 
 
 def _pad_rows(seqs, width, pad_index, limit=None):
@@ -63,10 +67,152 @@ def create_collate_fn(name, pad_index=0, max_seq_len=17, num_concepts=5, num_sen
         return fns, _feats(fcs), _feats(atts), _pad_rows(cpts, num_concepts, pad_index), \
             _pad_rows(sentis, num_sentiments, pad_index), torch.from_numpy(np.asarray(labels, dtype=np.int64))
 
-    table = {'caption': caption, 'scs': scs, 'rl_fact': rl_fact, 'rl_senti': rl_senti}
+    table = {'caption': caption, 'scs': scs, 'senti_corpus_with_sentis': scs, 'rl_fact': rl_fact,
+             'rl_senti': rl_senti}
     if name not in table:
         raise KeyError('collate %r is outside the decoder path (have: %s)' % (name, sorted(table)))
     return table[name]
+
+
+class FeatureStore:
+    """fn -> fp32 feature array, backed by ONE `.npy` file opened as a memory map plus `<path>.index.json`
+    ({fn: row}).  Stands where the reference passes an h5 file name (`fc_feats` / `att_feats` arguments of its
+    Dataset classes, dataloader.py:164-178): `store[fn]` returns what `h5py.File(path)[fn][:]` returned there.
+    A plain dict {fn: ndarray} is accepted by the datasets as well."""
+
+    def __init__(self, path):
+        import json
+        self.path = path
+        self.array = np.load(path, mmap_mode='r')
+        with open(path + '.index.json') as f:
+            self.index = json.load(f)
+
+    @staticmethod
+    def write(path, fns, array):
+        import json
+        array = np.ascontiguousarray(array, dtype=np.float32)
+        assert len(fns) == array.shape[0] and len(set(fns)) == len(fns)
+        np.save(path, array)
+        if not path.endswith('.npy'):
+            path = path + '.npy'
+        with open(path + '.index.json', 'w') as f:
+            json.dump({fn: i for i, fn in enumerate(fns)}, f)
+        return path
+
+    def __getitem__(self, fn):
+        return np.array(self.array[self.index[fn]])
+
+    def __contains__(self, fn):
+        return fn in self.index
+
+    def __len__(self):
+        return len(self.index)
+
+
+def _store(x):
+    return FeatureStore(x) if isinstance(x, str) else x
+
+
+class SCSDataset(torch.utils.data.Dataset):
+    """dataloader.py:152-161: rows (caption ids, concept ids, sentiment-word ids, sentiment id)."""
+
+    def __init__(self, senti_corpus_with_sentis):
+        self.senti_corpus_with_sentis = senti_corpus_with_sentis
+
+    def __getitem__(self, index):
+        cap, cpts, sentis, senti_id = self.senti_corpus_with_sentis[index]
+        return cap, cpts, sentis, senti_id
+
+    def __len__(self):
+        return len(self.senti_corpus_with_sentis)
+
+
+class CaptionDataset(torch.utils.data.Dataset):
+    """dataloader.py:164-182: item = (fn, fc [F], att [...,F], captions of the image, detected concepts)."""
+
+    def __init__(self, fc_feats, att_feats, img_captions, img_det_concepts):
+        self.fc_feats, self.att_feats = _store(fc_feats), _store(att_feats)
+        self.captions = list(img_captions.items())
+        self.det_concepts = img_det_concepts
+
+    def __getitem__(self, index):
+        fn, caps = self.captions[index]
+        return fn, np.array(self.fc_feats[fn]), np.array(self.att_feats[fn]), caps, self.det_concepts[fn]
+
+    def __len__(self):
+        return len(self.captions)
+
+
+class RLFactDataset(torch.utils.data.Dataset):
+    """dataloader.py:185-206: item = (fn, captions, fc, att, concepts, sentiment words)."""
+
+    def __init__(self, fc_feats, att_feats, img_captions, img_det_concepts, img_det_sentiments):
+        self.fc_feats, self.att_feats = _store(fc_feats), _store(att_feats)
+        self.captions = list(img_captions.items())
+        self.det_concepts, self.det_sentiments = img_det_concepts, img_det_sentiments
+
+    def __getitem__(self, index):
+        fn, caps = self.captions[index]
+        return fn, caps, np.array(self.fc_feats[fn]), np.array(self.att_feats[fn]), self.det_concepts[fn], \
+            self.det_sentiments[fn]
+
+    def __len__(self):
+        return len(self.captions)
+
+
+class RLSentiDataset(torch.utils.data.Dataset):
+    """dataloader.py:209-230: item = (fn, fc, att, concepts, sentiment words, sentiment label)."""
+
+    def __init__(self, fc_feats, att_feats, img_det_concepts, img_det_sentiments, img_senti_labels):
+        self.fc_feats, self.att_feats = _store(fc_feats), _store(att_feats)
+        self.det_concepts, self.det_sentiments = img_det_concepts, img_det_sentiments
+        self.img_senti_labels = img_senti_labels
+
+    def __getitem__(self, index):
+        fn, senti_label = self.img_senti_labels[index]
+        return fn, np.array(self.fc_feats[fn]), np.array(self.att_feats[fn]), self.det_concepts[fn], \
+            self.det_sentiments[fn], senti_label
+
+    def __len__(self):
+        return len(self.img_senti_labels)
+
+
+def _loader(dataset, batch_size, num_workers, shuffle, collate):
+    return torch.utils.data.DataLoader(dataset, batch_size=batch_size, shuffle=shuffle, num_workers=num_workers,
+                                       collate_fn=collate)
+
+
+def get_caption_dataloader(fc_feats, att_feats, img_captions, img_det_concepts, pad_index, max_seq_len,
+                           num_concepts, batch_size, num_workers=0, shuffle=True):
+    """dataloader.py:267-278 (note max_seq_len + 1: the <SOS> column)."""
+    return _loader(CaptionDataset(fc_feats, att_feats, img_captions, img_det_concepts), batch_size, num_workers,
+                   shuffle, create_collate_fn('caption', pad_index, max_seq_len + 1, num_concepts))
+
+
+def get_senti_corpus_with_sentis_dataloader(senti_corpus_with_sentis, pad_index, max_seq_len, num_concepts,
+                                            num_sentiments, batch_size, num_workers=0, shuffle=True):
+    """dataloader.py:281-294."""
+    return _loader(SCSDataset(senti_corpus_with_sentis), batch_size, num_workers, shuffle,
+                   create_collate_fn('senti_corpus_with_sentis', pad_index, max_seq_len + 1,
+                                     num_concepts=num_concepts, num_sentiments=num_sentiments))
+
+
+def get_rl_fact_dataloader(fc_feats, att_feats, img_captions, img_det_concepts, img_det_sentiments, pad_index,
+                           max_seq_len, num_concepts, num_sentiments, batch_size, num_workers=0, shuffle=True):
+    """dataloader.py:297-312."""
+    return _loader(RLFactDataset(fc_feats, att_feats, img_captions, img_det_concepts, img_det_sentiments),
+                   batch_size, num_workers, shuffle,
+                   create_collate_fn('rl_fact', pad_index=pad_index, max_seq_len=max_seq_len + 1,
+                                     num_concepts=num_concepts, num_sentiments=num_sentiments))
+
+
+def get_rl_senti_dataloader(fc_feats, att_feats, img_det_concepts, img_det_sentiments, img_senti_labels, pad_index,
+                            num_concepts, num_sentiments, batch_size, num_workers=0, shuffle=True):
+    """dataloader.py:315-328."""
+    return _loader(RLSentiDataset(fc_feats, att_feats, img_det_concepts, img_det_sentiments, img_senti_labels),
+                   batch_size, num_workers, shuffle,
+                   create_collate_fn('rl_senti', pad_index=pad_index, num_concepts=num_concepts,
+                                     num_sentiments=num_sentiments))
 
 
 def _map_tensors(obj, fn):

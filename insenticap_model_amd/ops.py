@@ -1,6 +1,7 @@
 """Thin torch-tensor -> C-ABI adapters. PyTorch is plumbing here (device memory + streams);
 all arithmetic happens in libinsenticap_hip.so."""
 import ctypes as C
+import threading
 
 import torch
 
@@ -147,32 +148,40 @@ H3W_BYTES = 64 * 1024 * 1024
 class h3_weights_scope:
     """`with ops.h3_weights_scope(device):` - the weights passed to the forward GEMMs do not change inside the block
     (include/insenticap_hip.h: isc_h3_weights_begin), so their f16 planes are built once per block, not per launch.
-    Launches inside must stay on one stream; nested scopes are ignored (the outer one stays in force)."""
-    _depth = 0
+    The scope belongs to the CURRENT stream (library side: one slot per stream; here: one plane buffer and one
+    nesting depth per (device, stream)), so two host threads running two captioners on two streams are independent.
+    Nested scopes on the same stream are ignored (the outer one stays in force)."""
+    _depth = {}
+    _lock = threading.Lock()
 
     def __init__(self, device):
         self.device = torch.device(device)
 
     def __enter__(self):
         cls = h3_weights_scope
-        cls._depth += 1
-        if cls._depth == 1 and WS_OVERRIDE is None:       # not while a HIP graph is being captured
-            index = self.device.index if self.device.index is not None else torch.cuda.current_device()
-            key = (index, torch.cuda.current_stream(index).cuda_stream)     # one buffer per stream, as splitk_ws
-            buf = _H3W_BUF.get(key)
-            if buf is None:
-                buf = _H3W_BUF[key] = torch.empty(H3W_BYTES, dtype=torch.uint8, device=self.device)
-            _lib.check(_lib.load().isc_h3_weights_begin(buf.data_ptr(), buf.numel()), 'isc_h3_weights_begin')
-            self.opened = True
-        else:
-            self.opened = False
+        index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.key = key = (index, torch.cuda.current_stream(index).cuda_stream)     # one buffer per stream, as splitk_ws
+        with cls._lock:
+            depth = cls._depth[key] = cls._depth.get(key, 0) + 1
+            buf = None
+            if depth == 1 and WS_OVERRIDE is None:        # not while a HIP graph is being captured
+                buf = _H3W_BUF.get(key)
+                if buf is None:
+                    buf = _H3W_BUF[key] = torch.empty(H3W_BYTES, dtype=torch.uint8, device=self.device)
+        self.opened = False
+        if buf is not None:
+            rc = _lib.load().isc_h3_weights_begin(buf.data_ptr(), buf.numel(), C.c_void_p(key[1]))
+            if rc != -4:                                  # ISC_E_WORKSPACE: all scope slots taken - run without one
+                _lib.check(rc, 'isc_h3_weights_begin')
+                self.opened = True
         return self
 
     def __exit__(self, *exc):
         cls = h3_weights_scope
-        cls._depth -= 1
+        with cls._lock:
+            cls._depth[self.key] -= 1
         if self.opened:
-            _lib.load().isc_h3_weights_end()
+            _lib.load().isc_h3_weights_end(C.c_void_p(self.key[1]))
         return False
 
 

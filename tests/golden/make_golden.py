@@ -459,6 +459,16 @@ def case_detector():
     for k, v in losses.items():
         out['det/loss_' + k] = np.array([v], dtype=np.float64)
     print({k: round(v, 5) for k, v in losses.items()})
+    # Detector.sample (models/decoder.py:182-192): beam search + detected sentiment, one image at a time
+    caps_all, sentis_all = [], []
+    for bi, b in enumerate(batches):
+        for i in range(B):
+            caps, det_sentis = det.sample(torch.from_numpy(b[1][i]), torch.from_numpy(b[2][i]),
+                                          torch.from_numpy(b[5][i]), beam_size=3, decoding_constraint=1)
+            caps_all.append(list(caps) + [''] * (3 - len(caps)))
+            sentis_all.append(det_sentis[0])
+    out['det/sample_caps'] = np.array(caps_all)
+    out['det/sample_sentis'] = np.array(sentis_all)
     np.savez_compressed(os.path.join(HERE, 'detector.npz'), **out)
     print('detector: %d arrays' % len(out))
 
@@ -502,8 +512,182 @@ def case_checkpoint():
     print('checkpoint: %d arrays' % len(out))
 
 
+def case_beam64():
+    """BASELINE.json configs[2]: beam 5 over 64 images, sentiment words + label supplied, decoding_constraint=1,
+    T=20 - all 64 images through the reference's one-image `Captioner.sample` (captioner.py:351-420)."""
+    V, st, seed = 10000, synth.DEFAULT_SETTINGS, 0
+    n, R, Tlen = 64, 36, 20
+    d = synth.make_inputs(n, V, st, regions=R, seq_len=Tlen, seed=321)
+    cap = build_reference(V, st, seed)
+    cap.eval()
+    out = {}
+    beam_cases_one(cap, d, Tlen, out, 'beam/', n_images=n, beam=5)
+    np.savez_compressed(os.path.join(HERE, 'beam64.npz'), **out)
+    print('beam64: %d arrays' % len(out))
+
+
+def beam_cases_one(cap, d, Tlen, out, prefix, n_images, beam):
+    fc, att, sw, lab = T(d, 'fc_feats', 'att_feats', 'senti_words', 'senti_labels')
+    caps_all, scores_all = [], []
+    for i in range(n_images):
+        with torch.no_grad():
+            c, s = cap.sample(fc[i], att[i], sw[i], lab[i:i + 1], beam, 1, Tlen)
+        caps_all.append(list(c) + [''] * (beam - len(c)))
+        scores_all.append(list(s) + [np.nan] * (beam - len(s)))
+    out[prefix + 'beam%d_senti1_caps' % beam] = np.array(caps_all)
+    out[prefix + 'beam%d_senti1_scores' % beam] = np.array(scores_all, np.float64)
+
+
+def case_det512():
+    """BASELINE.json configs[4] at full size on ONE batch: Detector.forward(data, 'fact', training=False) of
+    models/decoder.py:52-180 with B=512, V=10k, T=20, 6x6x2048 grid - sampled roll-out (draws recorded), greedy
+    roll-out, CIDEr-D + classifier rewards, RL / XE / domain-align losses.  Also records the per-row quantities the
+    dictionary is made of, so that a mismatch can be traced to its row."""
+    from models.decoder import Detector
+    from self_critical import utils as ref_utils
+    V, Tn, B = 10000, 20, 512
+    st = dict(synth.DEFAULT_SETTINGS, **synth.HELPER_SETTINGS)
+    idx2word = synth.make_idx2word(V)
+    det = Detector(idx2word, Tn, synth.SENTIMENT_CATEGORIES, {'cap_lr': 4e-5}, st)
+    det.captioner.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_weights(V, st, seed=0).items()})
+    for name, mod, seed in (('senti_detector', det.senti_detector, 51), ('sent_senti_cls', det.sent_senti_cls, 52)):
+        shapes = {k: tuple(v.shape) for k, v in mod.state_dict().items()}
+        mod.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_module_weights(shapes, seed).items()})
+    batches, split = synth.make_rl_batches(1, B, V, st, grid=(6, 6), seq_len=Tn, seed=60)
+    det.set_ciderd_scorer(split)
+    b = batches[0]
+    item = (b[0], torch.from_numpy(b[1]), torch.from_numpy(b[2]), (torch.from_numpy(b[3][0]), b[3][1]),
+            torch.from_numpy(b[4]), torch.from_numpy(b[5]), b[6])
+    out = {}
+    ms = MultinomialSpy()
+    spy = StepSpy(det.captioner)
+    rec = {}
+    orig_rl, orig_scr, orig_cls = det.captioner.forward_rl, ref_utils.get_self_critical_reward, ref_utils.get_cls_reward
+    import models.decoder as ref_decoder
+
+    def spy_rl(*a, **k):
+        n0, s0 = len(ms.draws), len(spy.margins)
+        r = orig_rl(*a, **k)
+        greedy = bool(k.get('sample_max', a[-1] if len(a) >= 7 else 1))
+        tag = 'greedy' if greedy else 'sample'
+        rec[tag + '_seq'], rec[tag + '_logprobs'], rec[tag + '_masks'] = [x.detach().numpy().copy() for x in r]
+        m = torch.stack(spy.margins[s0:], dim=1).numpy()
+        rec[tag + '_margins'] = np.pad(m, ((0, 0), (0, Tn - m.shape[1])))
+        if not greedy:
+            dr = torch.stack(ms.draws[n0:], dim=1).numpy()
+            rec['draws'] = np.pad(dr, ((0, 0), (0, Tn - dr.shape[1])))
+        return r
+
+    def spy_scr(*a, **k):
+        r = orig_scr(*a, **k)
+        rec['fact_reward_rows'] = np.asarray(r)[:, 0].copy()
+        return r
+
+    def spy_cls(*a, **k):
+        r = orig_cls(*a, **k)
+        rec['cls_reward'] = np.asarray(r).copy()
+        return r
+    orig_sd = det.senti_detector.sample
+
+    def spy_sd(*a, **k):
+        r = orig_sd(*a, **k)
+        rec['senti_labels'], rec['senti_scores'] = r[0].numpy().copy(), r[3].detach().numpy().copy()
+        return r
+    det.senti_detector.sample = spy_sd
+    det.captioner.forward_rl = spy_rl
+    ref_decoder.get_self_critical_reward = spy_scr
+    ref_decoder.get_cls_reward = spy_cls
+    torch.manual_seed(515)
+    losses = det(([item],), 'fact', False)
+    ms.close()
+    spy.close()
+    det.captioner.forward_rl = orig_rl
+    det.senti_detector.sample = orig_sd
+    ref_decoder.get_self_critical_reward, ref_decoder.get_cls_reward = orig_scr, orig_cls
+    for k, v in rec.items():
+        out['det/' + k] = v
+    for k, v in losses.items():
+        out['det/loss_' + k] = np.array([v], dtype=np.float64)
+    live = rec['greedy_masks'] > 0
+    print({k: round(v, 5) for k, v in losses.items()}, 'min greedy margin on live steps',
+          float(rec['greedy_margins'][live].min()))
+    np.savez_compressed(os.path.join(HERE, 'det512.npz'), **out)
+    print('det512: %d arrays' % len(out))
+
+
+def case_collate():
+    """The four collate functions the decoder path consumes (dataloader.py:11-109: caption, scs, rl_fact, rl_senti).
+    `dataloader.py` imports h5py at module level, which this image does not have; only its Dataset classes
+    (dataloader.py:171-178 ...) ever touch it - the collates are pure list / torch code.  The module is therefore
+    imported with an EMPTY module object registered as `h5py` (no attribute of it is ever read on this path); the
+    h5-backed Dataset classes are NOT exercised and stay unpinned.  Inputs are written next to the outputs so the
+    test needs no generator."""
+    import random
+    import types
+    sys.modules.setdefault('h5py', types.ModuleType('h5py'))
+    import dataloader as ref_dl
+    rng = np.random.default_rng(2718)
+    out = {}
+
+    def ragged(n, lo, hi, V=50):
+        return [[int(x) for x in rng.integers(4, V, size=int(rng.integers(lo, hi + 1)))] for _ in range(n)]
+    n_img, F = 7, 8
+    fns = ['img%02d' % i for i in range(n_img)]
+    fcs = rng.random((n_img, F), dtype=np.float32)
+    atts = rng.random((n_img, 2, 3, F), dtype=np.float32)
+    caps5 = [ragged(5, 3, 14) for _ in range(n_img)]           # lengths straddle max_seq_len=9 -> truncation + ties
+    cpts = ragged(n_img, 2, 8)                                  # shorter and longer than num_concepts=5
+    sentis = ragged(n_img, 3, 13)                               # shorter and longer than num_sentiments=10
+    labels = [int(x) for x in rng.integers(0, 3, size=n_img)]
+    kw = dict(pad_index=0, max_seq_len=9, num_concepts=5, num_sentiments=10)
+
+    def dump_ragged(key, rows):
+        out[key + '/flat'] = np.asarray([x for r in rows for x in r], dtype=np.int64)
+        out[key + '/len'] = np.asarray([len(r) for r in rows], dtype=np.int64)
+    out['in/fns'] = np.array(fns)
+    out['in/fc'], out['in/att'] = fcs, atts
+    dump_ragged('in/caps', [c for img in caps5 for c in img])
+    dump_ragged('in/cpts', cpts)
+    dump_ragged('in/sentis', sentis)
+    out['in/labels'] = np.asarray(labels, dtype=np.int64)
+
+    # caption (dataloader.py:11-34)
+    f = ref_dl.create_collate_fn('caption', **kw)
+    r = f([(fns[i], fcs[i], atts[i], caps5[i], cpts[i]) for i in range(n_img)])
+    out['caption/fns'] = np.array(r[0])
+    out['caption/fc'], out['caption/att'] = r[1].numpy(), r[2].numpy()
+    out['caption/caps'], out['caption/lengths'] = r[3][0].numpy(), np.asarray(r[3][1], dtype=np.int64)
+    out['caption/cpts'] = r[4].numpy()
+    # scs (dataloader.py:36-58): rows of (cap, cpts, sentis, senti_id)
+    f = ref_dl.create_collate_fn('senti_corpus_with_sentis', **kw)
+    scs_rows = [(caps5[i][0], cpts[i], sentis[i], labels[i]) for i in range(n_img)]
+    r = f(list(scs_rows))
+    out['scs/caps'], out['scs/lengths'] = r[0][0].numpy(), np.asarray(r[0][1], dtype=np.int64)
+    out['scs/cpts'], out['scs/sentis'], out['scs/labels'] = r[1].numpy(), r[2].numpy(), r[3].numpy()
+    # rl_fact (dataloader.py:60-91): draws one caption per image with random.sample
+    f = ref_dl.create_collate_fn('rl_fact', **kw)
+    random.seed(31337)
+    r = f([(fns[i], caps5[i], fcs[i], atts[i], cpts[i], sentis[i]) for i in range(n_img)])
+    out['rl_fact/fns'] = np.array(r[0])
+    out['rl_fact/fc'], out['rl_fact/att'] = r[1].numpy(), r[2].numpy()
+    out['rl_fact/caps'], out['rl_fact/lengths'] = r[3][0].numpy(), np.asarray(r[3][1], dtype=np.int64)
+    out['rl_fact/cpts'], out['rl_fact/sentis'] = r[4].numpy(), r[5].numpy()
+    gt_rows = [c for fn in fns for c in r[6][fn]]
+    dump_ragged('rl_fact/gt', gt_rows)
+    out['rl_fact/gt_count'] = np.asarray([len(r[6][fn]) for fn in fns], dtype=np.int64)
+    # rl_senti (dataloader.py:93-109)
+    f = ref_dl.create_collate_fn('rl_senti', **kw)
+    r = f([(fns[i], fcs[i], atts[i], cpts[i], sentis[i], labels[i]) for i in range(n_img)])
+    out['rl_senti/fns'] = np.array(r[0])
+    out['rl_senti/fc'], out['rl_senti/att'] = r[1].numpy(), r[2].numpy()
+    out['rl_senti/cpts'], out['rl_senti/sentis'], out['rl_senti/labels'] = r[3].numpy(), r[4].numpy(), r[5].numpy()
+    np.savez_compressed(os.path.join(HERE, 'collate.npz'), **out)
+    print('collate: %d arrays' % len(out))
+
+
 CASES = {'tiny': case_tiny, 'cfg1': case_cfg1, 'b128': case_b128, 'cider': case_cider, 'detector': case_detector,
-         'checkpoint': case_checkpoint}
+         'checkpoint': case_checkpoint, 'beam64': case_beam64, 'det512': case_det512,
+         'collate': case_collate}
 
 if __name__ == '__main__':
     which = sys.argv[1:] or list(CASES)

@@ -55,6 +55,86 @@ def test_scs_and_rl_collates():
         data.create_collate_fn('concept')                  # outside the decoder path
 
 
+def _ragged(g, key):
+    flat, lens = g[key + '/flat'], g[key + '/len']
+    off = np.concatenate([[0], np.cumsum(lens)])
+    return [[int(x) for x in flat[off[i]:off[i + 1]]] for i in range(len(lens))]
+
+
+def _collate_inputs(g):
+    fns = [str(x) for x in g['in/fns']]
+    caps = _ragged(g, 'in/caps')
+    caps5 = [caps[5 * i:5 * i + 5] for i in range(len(fns))]
+    return fns, g['in/fc'], g['in/att'], caps5, _ragged(g, 'in/cpts'), _ragged(g, 'in/sentis'), \
+        [int(x) for x in g['in/labels']]
+
+
+def test_collates_vs_reference_goldens(golden, tmp_path):
+    """tests/golden/collate.npz holds the outputs of the reference's OWN collate functions (dataloader.py:11-109) on
+    ragged inputs that exercise truncation, <PAD> filling, length ties (stable sort) and the 5-captions expansion;
+    the same inputs through data.py - directly, and through the h5-free datasets + loader factories."""
+    g = golden('collate')
+    fns, fcs, atts, caps5, cpts, sentis, labels = _collate_inputs(g)
+    n = len(fns)
+    kw = dict(pad_index=0, max_seq_len=9, num_concepts=5, num_sentiments=10)
+
+    def same(t, key):
+        assert t.dtype == (torch.int64 if g[key].dtype == np.int64 else torch.float32), key
+        np.testing.assert_array_equal(t.numpy(), g[key], err_msg=key)
+
+    r = data.create_collate_fn('caption', **kw)([(fns[i], fcs[i], atts[i], caps5[i], cpts[i]) for i in range(n)])
+    assert list(r[0]) == [str(x) for x in g['caption/fns']]
+    same(r[1], 'caption/fc'); same(r[2], 'caption/att'); same(r[3][0], 'caption/caps'); same(r[4], 'caption/cpts')
+    assert r[3][1] == g['caption/lengths'].tolist()
+
+    for name in ('senti_corpus_with_sentis', 'scs'):
+        r = data.create_collate_fn(name, **kw)([(caps5[i][0], cpts[i], sentis[i], labels[i]) for i in range(n)])
+        same(r[0][0], 'scs/caps'); same(r[1], 'scs/cpts'); same(r[2], 'scs/sentis'); same(r[3], 'scs/labels')
+        assert r[0][1] == g['scs/lengths'].tolist()
+
+    random.seed(31337)                           # the reference draws the XE caption with random.sample
+    r = data.create_collate_fn('rl_fact', **kw)([(fns[i], caps5[i], fcs[i], atts[i], cpts[i], sentis[i])
+                                                 for i in range(n)])
+    assert list(r[0]) == [str(x) for x in g['rl_fact/fns']]
+    same(r[1], 'rl_fact/fc'); same(r[2], 'rl_fact/att'); same(r[3][0], 'rl_fact/caps')
+    same(r[4], 'rl_fact/cpts'); same(r[5], 'rl_fact/sentis')
+    assert r[3][1] == g['rl_fact/lengths'].tolist()
+    gt_rows, cnt = _ragged(g, 'rl_fact/gt'), g['rl_fact/gt_count']
+    off = np.concatenate([[0], np.cumsum(cnt)])
+    assert r[6] == {fn: gt_rows[off[i]:off[i + 1]] for i, fn in enumerate(fns)}
+
+    r = data.create_collate_fn('rl_senti', **kw)([(fns[i], fcs[i], atts[i], cpts[i], sentis[i], labels[i])
+                                                  for i in range(n)])
+    assert list(r[0]) == [str(x) for x in g['rl_senti/fns']]
+    same(r[1], 'rl_senti/fc'); same(r[2], 'rl_senti/att'); same(r[3], 'rl_senti/cpts')
+    same(r[4], 'rl_senti/sentis'); same(r[5], 'rl_senti/labels')
+
+    # the h5-free datasets (memory-mapped feature stores) + loader factories reproduce the same batches
+    fc_path = data.FeatureStore.write(str(tmp_path / 'fc.npy'), fns, fcs)
+    att_path = data.FeatureStore.write(str(tmp_path / 'att.npy'), fns, atts)
+    captions = {fn: caps5[i] for i, fn in enumerate(fns)}
+    det_c, det_s = dict(zip(fns, cpts)), dict(zip(fns, sentis))
+    (b,) = list(data.get_caption_dataloader(fc_path, att_path, captions, det_c, 0, 8, 5, batch_size=n, shuffle=False))
+    assert list(b[0]) == [str(x) for x in g['caption/fns']]
+    same(b[1], 'caption/fc'); same(b[2], 'caption/att'); same(b[3][0], 'caption/caps'); same(b[4], 'caption/cpts')
+    random.seed(31337)
+    (b,) = list(data.get_rl_fact_dataloader(fc_path, att_path, captions, det_c, det_s, 0, 8, 5, 10, batch_size=n,
+                                            shuffle=False))
+    same(b[2], 'rl_fact/att'); same(b[3][0], 'rl_fact/caps'); same(b[5], 'rl_fact/sentis')
+    (b,) = list(data.get_rl_senti_dataloader(fc_path, att_path, det_c, det_s, list(zip(fns, labels)), 0, 5, 10,
+                                             batch_size=n, shuffle=False))
+    same(b[1], 'rl_senti/fc'); same(b[5], 'rl_senti/labels')
+    (b,) = list(data.get_senti_corpus_with_sentis_dataloader(
+        [(caps5[i][0], cpts[i], sentis[i], labels[i]) for i in range(n)], 0, 8, 5, 10, batch_size=n, shuffle=False))
+    same(b[0][0], 'scs/caps'); same(b[3], 'scs/labels')
+    # two workers, several batches: every image is delivered exactly once
+    seen = []
+    for b in data.get_rl_senti_dataloader(fc_path, att_path, det_c, det_s, list(zip(fns, labels)), 0, 5, 10,
+                                          batch_size=3, num_workers=2, shuffle=True):
+        seen.extend(b[0])
+    assert sorted(seen) == sorted(fns)
+
+
 @pytest.mark.gpu
 def test_device_prefetcher_delivers_identical_batches():
     dev = torch.device('cuda:0')

@@ -91,9 +91,16 @@ def test_detector_forward_eval_vs_reference(golden):
     for k, v in losses.items():
         np.testing.assert_allclose(v, g['det/loss_' + k][0], rtol=2e-4, atol=2e-5, err_msg=k)
     # Detector.sample: one image, beam search + detected sentiment
-    caps, sentis = det.sample(torch.from_numpy(batches[0][1][0]).to(dev), torch.from_numpy(batches[0][2][0]).to(dev),
-                              torch.from_numpy(batches[0][5][0]).to(dev), beam_size=3)
-    assert len(caps) == 3 and sentis[0] in synth.SENTIMENT_CATEGORIES
+    # Detector.sample (models/decoder.py:182-192): every image of both batches - its three beam captions and the
+    # detected sentiment - against what the reference returned
+    k = 0
+    for b in batches:
+        for i in range(B):
+            caps, sentis = det.sample(torch.from_numpy(b[1][i]).to(dev), torch.from_numpy(b[2][i]).to(dev),
+                                      torch.from_numpy(b[5][i]).to(dev), beam_size=3, decoding_constraint=1)
+            assert list(caps) == [str(x) for x in g['det/sample_caps'][k] if str(x)], (k, caps)
+            assert sentis[0] == str(g['det/sample_sentis'][k]), k
+            k += 1
 
 
 @pytest.mark.gpu

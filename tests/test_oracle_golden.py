@@ -214,3 +214,18 @@ def test_cfg1_iteration_digests(golden):
         if key not in g.files:
             continue
         assert_digest_close(digest(p[k].grad.numpy()), g[key], k)
+
+
+def test_beam5_all_64_images_oracle_vs_reference(golden):
+    """BASELINE config 2 (beam 5 x 64 images, sentiment words on): the oracle's beam search against the reference's own
+    `Captioner.sample` on every image (tests/golden/beam64.npz) - the oracle is what bench-size GPU tests lean on."""
+    g = golden('beam64')
+    c, st, w, _, _ = case_setup('cfg1')
+    idx2word = synth.make_idx2word(c['V'])
+    p, ids = O.to_params(w), ids_for(c['V'])
+    d = synth.make_inputs(64, c['V'], st, regions=36, seq_len=20, seed=321)
+    for i in range(0, 64, 3):               # 22 images here keep the CPU suite short; the GPU test covers all 64
+        caps, scores, _ = O.beam_search(p, ids, idx2word, tt(d, 'fc_feats')[i], tt(d, 'att_feats')[i],
+                                        tt(d, 'senti_words')[i], tt(d, 'senti_labels')[i:i + 1], 5, 1, 20)
+        assert list(caps) == [str(x) for x in g['beam/beam5_senti1_caps'][i]], i
+        np.testing.assert_allclose(scores, g['beam/beam5_senti1_scores'][i], atol=1e-4)
