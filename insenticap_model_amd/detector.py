@@ -13,7 +13,7 @@ from collections import defaultdict
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import dp, ops
 from .captioner import Captioner
 from .helper_nets import SentenceSentimentClassifier, SentimentDetector
 from .optim import clip_gradient
@@ -39,11 +39,31 @@ class Detector(nn.Module):
         self.cls_flag = 0.4
         self.seq_flag = 1.0
         self.senti_threshold = 0.7
+        self.xe_ss_prob, self.seq2seq_ss_prob = 0.5, 0.25     # decoder.py:139,155 (hard-coded there)
+        self.dp_arena, self.dp_group = None, None             # data-parallel training: enable_data_parallel()
         # The image sentiment detector is frozen (decoder.py:31,34: only captioner.parameters() are
         # optimised), so its label is a pure function of the image: cache it per file name instead of
         # re-running 1.7-9.2 GFLOP of convolutions per image in every RL iteration.
         self.cache_image_sentiments = True
         self._senti_cache, self._senti_cache_key = {}, None
+
+    def enable_data_parallel(self, group=None, broadcast=True):
+        """Data-parallel RL training over the ranks of `group` (default process group; backend nccl = RCCL over xGMI,
+        gloo in tests).  The reference is single-device; under DP every rank runs `forward` on ITS shard of the fact /
+        seq2seq batches (the caller shards the loaders), and the step becomes:
+          * roll-outs, helper nets, CIDEr-D reward (document frequencies replicated) and classifier reward rank-local;
+          * every loss term pre-scaled by local_count / global_count of ITS normaliser - RewardCriterion by the mask
+            sum (utils.py:175), the two XECriterion terms by their token counts (captioner.py:438), the domain-align
+            MSE by the row count - one 4-float all-reduce per iteration;
+          * ONE sum-all-reduce of the flat 88 MB gradient arena between backward and the elementwise clamp
+            (decoder.py:165-166: the clamp is nonlinear, it must see the reduced gradient), then identical
+            clamp+Adam on every rank;
+          * the returned dictionary holds global values (one all-reduce of the statistics per call)."""
+        self.dp_group = group
+        self.dp_arena = dp.GradArena(self.captioner.parameters())
+        if broadcast:
+            dp.broadcast_parameters(self.captioner, group=group)
+        return self
 
     def set_ciderd_scorer(self, captions):
         self.ciderd_scorer = get_ciderd_scorer(captions, self.captioner.sos_id, self.captioner.eos_id)
@@ -69,10 +89,18 @@ class Detector(nn.Module):
             sums[key] = sums[key] + (value.detach() if torch.is_tensor(value) else value)
 
         device = next(self.parameters()).device
+        world = dp.world_size(self.dp_group) if self.dp_arena is not None else 1
         seq2seq_iter = iter(data[1]) if training else None
         caption_iter = iter(data[0])
         for _ in range(min(self.MAX_BATCHES_PER_CALL, len(data[0]))):
             item = next(caption_iter)
+            s2s_batch = None
+            if training:                                  # fetched here (same loader order) so that its token
+                try:                                      # count can ride in the iteration's one count all-reduce
+                    s2s_batch = next(seq2seq_iter)
+                except StopIteration:
+                    seq2seq_iter = iter(data[1])
+                    s2s_batch = next(seq2seq_iter)
             if data_type == 'fact':
                 fns, fc_feats, att_feats, (caps_tensor, lengths), cpts_tensor, sentis_tensor, ground_truth = item
                 caps_tensor = caps_tensor.to(device)
@@ -91,6 +119,18 @@ class Detector(nn.Module):
                 fc_feats, att_feats, cpts_tensor, sentis_tensor, senti_labels, self.max_seq_len,
                 sample_max=0, mode='rl')
             da_loss = self.cap_da_crit(cap.cpt_feats, cap.fc_feats.detach())
+            # DP: each term's share of the global normaliser (mask sum, XE tokens, seq2seq tokens, rows)
+            w_rl = w_xe = w_s2s = w_rows = None
+            share = (lambda x, w: x * w) if world > 1 else (lambda x, w: x)    # single process: graph untouched
+            if world > 1:
+                n_local = torch.cat([seq_masks.sum().reshape(1), ops.upload(
+                    [float(sum(lengths)) if data_type == 'fact' else 0.0,
+                     float(sum(s2s_batch[0][1])) if s2s_batch is not None else 0.0,
+                     float(fc_feats.shape[0])], torch.float32, device)])
+                n_global = n_local.clone()
+                torch.distributed.all_reduce(n_global, group=self.dp_group)
+                w_rl, w_xe, w_s2s, w_rows = (n_local / n_global.clamp_min(1.0)).unbind(0)
+            da_loss = share(da_loss, w_rows)
             add('da_loss', da_loss)
 
             cap.eval()                                   # greedy baseline
@@ -118,23 +158,19 @@ class Detector(nn.Module):
                 with torch.no_grad():
                     xe_senti_labels = self.sent_senti_cls(caps_tensor[:, 1:], lengths)[0]
                     xe_senti_labels = xe_senti_labels.softmax(dim=-1).argmax(dim=-1).detach()
-                pred = cap(fc_feats, att_feats, cpts_tensor, caps_tensor, xe_senti_labels, ss_prob=0.5, mode='xe')
-                xe_loss = self.cap_xe_crit(pred, caps_tensor[:, 1:], lengths)
+                pred = cap(fc_feats, att_feats, cpts_tensor, caps_tensor, xe_senti_labels, ss_prob=self.xe_ss_prob,
+                           mode='xe')
+                xe_loss = share(self.cap_xe_crit(pred, caps_tensor[:, 1:], lengths), w_xe)
                 add('xe_loss', xe_loss)
 
             seq2seq_loss = 0.0
             if training:
-                try:
-                    batch = next(seq2seq_iter)
-                except StopIteration:
-                    seq2seq_iter = iter(data[1])
-                    batch = next(seq2seq_iter)
-                (s_caps, s_lengths), s_cpts, s_sentis, s_labels = batch
+                (s_caps, s_lengths), s_cpts, s_sentis, s_labels = s2s_batch
                 s_caps, s_cpts = s_caps.to(device), s_cpts.to(device)
                 s_sentis, s_labels = s_sentis.to(device), s_labels.to(device)
                 def seq2seq_unroll():                     # 80 text-only rows: a chain of small launches that
-                    pred = cap(s_caps, s_cpts, s_sentis, s_labels, ss_prob=0.25, mode='seq2seq')
-                    return self.seq_flag * self.cap_xe_crit(pred, s_caps[:, 1:], s_lengths)
+                    pred = cap(s_caps, s_cpts, s_sentis, s_labels, ss_prob=self.seq2seq_ss_prob, mode='seq2seq')
+                    return share(self.seq_flag * self.cap_xe_crit(pred, s_caps[:, 1:], s_lengths), w_s2s)
                 # ... overlaps with the XE unroll queued above when it runs on the side stream (forward and,
                 # through autograd, backward); same numbers either way
                 seq2seq_loss = run_on_side_stream(device, seq2seq_unroll) if device.type == 'cuda' \
@@ -149,23 +185,33 @@ class Detector(nn.Module):
                     host_sample.numpy(), host_greedy.numpy(), fns, ground_truth, cap.sos_id, cap.eos_id,
                     self.ciderd_scorer)
                 fact_reward = ops.upload(fact_reward.astype('float32'), torch.float32, device)
-                add('fact_reward', fact_reward[:, 0].mean())
+                add('fact_reward', share(fact_reward[:, 0].mean(), w_rows))
             else:
                 fact_reward = 0
-            add('cls_reward', cls_reward.mean(-1).mean(-1))
+            add('cls_reward', share(cls_reward.mean(-1).mean(-1), w_rows))
 
             rewards = fact_reward + self.cls_flag * cls_reward
-            add('all_rewards', rewards.mean(-1).mean(-1))
-            cap_loss = self.cap_rl_crit(sample_logprobs, seq_masks, rewards)
+            add('all_rewards', share(rewards.mean(-1).mean(-1), w_rows))
+            cap_loss = share(self.cap_rl_crit(sample_logprobs, seq_masks, rewards), w_rl)
             add('cap_loss', cap_loss)
 
             total = cap_loss + xe_loss + da_loss + seq2seq_loss
             if training:
-                self.cap_optim.zero_grad()
+                if self.dp_arena is not None:
+                    self.dp_arena.zero_()
+                else:
+                    self.cap_optim.zero_grad()
                 total.backward()
+                if self.dp_arena is not None:
+                    self.dp_arena.all_reduce(self.dp_group)      # one 88 MB sum over xGMI, before the clamp
                 clip_gradient(self.cap_optim)            # 0.1, fused into the Adam launch
                 self.cap_optim.step()
 
+        if world > 1 and sums:                           # global statistics: one small all-reduce per call
+            keys = sorted(sums)
+            vec = torch.stack([torch.as_tensor(sums[k], dtype=torch.float32, device=device).reshape(()) for k in keys])
+            torch.distributed.all_reduce(vec, group=self.dp_group)
+            sums = dict(zip(keys, vec.tolist()))
         return {k: float(v) / len(data) for k, v in sums.items()}
 
     def _image_sentiments(self, fns, att_feats):

@@ -49,6 +49,7 @@ class GradArena:
         n = sum(p.numel() for p in self.params)
         ref = self.params[0]
         self.flat = torch.zeros(n, dtype=ref.dtype, device=ref.device)
+        self.collectives = 0
         off = 0
         for p in self.params:
             p.grad = self.flat[off:off + p.numel()].view_as(p)
@@ -63,9 +64,12 @@ class GradArena:
                 raise RuntimeError('a .grad was replaced; call zero_() instead of zero_grad(set_to_none=True)')
 
     def all_reduce(self, group=None):
-        """Sum the gradients of all ranks: one collective over the whole arena."""
-        if world_size(group) > 1:
+        """Sum the gradients of all ranks: one collective over the whole arena.  Issued whenever a process group
+        exists - also a one-rank group, where it is a no-op arithmetically but still goes through the backend
+        (tests/test_gpu_dp.py drives RCCL that way on a one-GPU box)."""
+        if dist.is_available() and dist.is_initialized():
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+            self.collectives += 1
         return self.flat
 
     @property

@@ -1,0 +1,66 @@
+"""Child program of tests/test_gpu_dp.py::test_rccl_all_reduce_in_a_fresh_process - NOT a test module.
+
+Started as a fresh process (nothing has touched the GPU before `init_from_env`), it builds a one-rank process group with
+backend "nccl" (= RCCL on ROCm), runs two `xe_train_step`s of the tiny captioner with a gradient arena, and prints one
+JSON line with what the parent asserts on: the backend, that librccl is mapped into the process, how many collectives
+the arena issued, and that the parameters moved.  NCCL_DEBUG=INFO output (RCCL's own log of the AllReduce calls) goes to
+stdout next to it."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+os.environ.setdefault('MASTER_PORT', sys.argv[1] if len(sys.argv) > 1 else '29533')
+os.environ.update(RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+os.environ.setdefault('NCCL_DEBUG', 'INFO')
+os.environ.setdefault('NCCL_DEBUG_SUBSYS', 'INIT,COLL')
+
+import torch                                            # noqa: E402
+import torch.distributed as dist                        # noqa: E402
+
+from insenticap_model_amd import Captioner, dp, synth   # noqa: E402
+from insenticap_model_amd.train import xe_train_step    # noqa: E402
+
+
+def main():
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    V, st = 64, synth.TINY_SETTINGS
+    cap = Captioner(synth.make_idx2word(V), synth.SENTIMENT_CATEGORIES, st)
+    cap.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_weights(V, st, seed=9).items()})
+    cap.to('cuda:0').eval()
+    dp.broadcast_parameters(cap)                        # world 1: returns at once
+    arena = dp.GradArena(cap.parameters())
+    optim, xe_crit, da_crit = cap.get_optim_criterion(4e-4)
+    d = synth.make_inputs(8, V, st, regions=6, seq_len=8, seed=31)
+    s = synth.make_inputs(4, V, st, regions=6, seq_len=8, seed=32)
+    t = torch.from_numpy
+    fact = (None, t(d['fc_feats']), t(d['att_feats']), (t(d['captions']), d['lengths']), t(d['cpt_words']))
+    scs = ((t(s['captions']), s['lengths']), t(s['cpt_words']), t(s['senti_words']), t(s['senti_labels']))
+    before = {k: v.detach().clone() for k, v in cap.state_dict().items()}
+    losses = []
+    for _ in range(2):
+        out = xe_train_step(cap, optim, xe_crit, da_crit, fact, t(d['senti_labels']), scs, 0.0, 0.1, arena=arena)
+        losses.append(float(out['all_loss']))
+    # a second, explicit collective whose result is checkable: sum over 1 rank == identity, bit for bit
+    probe = torch.arange(arena.flat.numel(), dtype=torch.float32, device='cuda:0') * 0.5
+    arena.flat.copy_(probe)
+    arena.all_reduce()
+    torch.cuda.synchronize()
+    identity = bool(torch.equal(arena.flat, probe))
+    with open('/proc/self/maps') as f:
+        maps = f.read()
+    moved = sum(int(not torch.equal(before[k], v)) for k, v in cap.state_dict().items())
+    print('RCCL_CHILD ' + json.dumps(dict(
+        backend=dist.get_backend(), rccl_mapped=('librccl' in maps), collectives=arena.collectives,
+        arena_bytes=arena.nbytes, losses=losses, identity=identity, moved=moved,
+        nccl_version=list(torch.cuda.nccl.version()))), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -98,3 +98,125 @@ def test_two_rank_training_matches_single_process():
         diff = np.abs(p0[k] - ref[k])
         assert diff.max() <= STEPS * 4e-4 * 1.05, k
     assert arena.nbytes == sum(v.size for v in ref.values()) * 4
+
+
+# ----------------------------------------------------------------------------- RL step under DP (BASELINE configs[4])
+RL_B, RL_S2S = 8, 4
+
+
+def _rl_data(lo, hi, s_lo, s_hi):
+    """Rows [lo, hi) of ONE fact batch (rl_fact layout) and rows [s_lo, s_hi) of one seq2seq batch."""
+    st = dict(ST, **synth.HELPER_SETTINGS)
+    batches, split = synth.make_rl_batches(1, RL_B, V, st, seq_len=TLEN, seed=70)
+    b = batches[0]
+    t = torch.from_numpy
+    fns = b[0][lo:hi]
+    lens = b[3][1][lo:hi]                 # like the collates, a shard's caption tensor ends at ITS longest caption
+    item = (fns, t(b[1][lo:hi]), t(b[2][lo:hi]), (t(b[3][0][lo:hi, :max(lens) + 1].copy()), lens), t(b[4][lo:hi]),
+            t(b[5][lo:hi]), {fn: b[6][fn] for fn in fns})
+    s = synth.make_inputs(RL_S2S, V, ST, regions=R, seq_len=TLEN, seed=72)
+    s_lens = s['lengths'][s_lo:s_hi]
+    scs = ((t(s['captions'][s_lo:s_hi, :max(s_lens) + 1].copy()), s_lens), t(s['cpt_words'][s_lo:s_hi]),
+           t(s['senti_words'][s_lo:s_hi]), t(s['senti_labels'][s_lo:s_hi]))
+    draws = np.random.default_rng(71).integers(2, V, size=(RL_B, TLEN), dtype=np.int64)[lo:hi]
+    return item, scs, split, draws
+
+
+def _make_detector():
+    from insenticap_model_amd.detector import Detector
+    from test_detector import load_helper
+    st = dict(ST, **synth.HELPER_SETTINGS)
+    st['dropout_p'] = 0.0                  # train mode without dropout: deterministic given the replayed draws
+    det = Detector(synth.make_idx2word(V), TLEN, synth.SENTIMENT_CATEGORIES, {'cap_lr': 4e-4}, st)
+    det.captioner.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_weights(V, ST, seed=9).items()})
+    load_helper(det.senti_detector, 51)
+    load_helper(det.sent_senti_cls, 52)
+    det.xe_ss_prob = det.seq2seq_ss_prob = 0.0          # scheduled sampling draws on the device: off for parity
+    return det.to('cuda:0')
+
+
+def _run_rl(det, lo, hi, s_lo, s_hi, steps):
+    item, scs, split, draws = _rl_data(lo, hi, s_lo, s_hi)
+    det.set_ciderd_scorer(split)                        # document frequencies over ALL images, on every rank
+    orig = det.captioner.forward_rl
+
+    def replay_rl(*a, **k):
+        if not k.get('sample_max', 1):
+            k['_replay'] = torch.from_numpy(draws).to('cuda:0')
+        return orig(*a, **k)
+    det.captioner.forward_rl = replay_rl
+    out, first_grad = [], None
+    for i in range(steps):
+        out.append(det(([item], [scs]), 'fact', True))
+        if i == 0:
+            first_grad = det.dp_arena.flat.detach().cpu().numpy().copy()
+    return out, first_grad
+
+
+def _rl_worker(rank, world, port, results):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK='0')
+    dp.init_from_env('gloo')
+    det = _make_detector()
+    det.enable_data_parallel()
+    lo, hi = dp.shard(RL_B, rank, world)
+    s_lo, s_hi = dp.shard(RL_S2S, rank, world)
+    losses, g1 = _run_rl(det, lo, hi, s_lo, s_hi, STEPS)
+    torch.cuda.synchronize()
+    results[rank] = ({k: v.detach().cpu().numpy() for k, v in det.captioner.state_dict().items()}, losses, g1,
+                     det.dp_arena.collectives)
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_rl_step_matches_single_process():
+    """Detector.forward(training=True) under DP: two ranks on half the fact batch and half the seq2seq batch each
+    (different token counts and mask sums per rank), multinomial draws replayed, against ONE process on the whole
+    batches: the loss dictionaries, the all-reduced gradient and the parameters after 3 steps."""
+    mgr = mp.Manager()
+    results = mgr.dict()
+    mp.spawn(_rl_worker, args=(2, _free_port(), results), nprocs=2, join=True)
+    det = _make_detector()
+    det.enable_data_parallel(broadcast=False)           # no process group here: world 1, flat arena for the compare
+    ref_losses, ref_g1 = _run_rl(det, 0, RL_B, 0, RL_S2S, STEPS)
+    ref = {k: v.detach().cpu().numpy() for k, v in det.captioner.state_dict().items()}
+    (p0, l0, g0, c0), (p1, l1, g1, c1) = results[0], results[1]
+    assert c0 == c1 == STEPS                            # one arena all-reduce per iteration
+    for a, b, r in zip(l0, l1, ref_losses):
+        assert set(a) == set(r) == {'da_loss', 'fact_reward', 'cls_reward', 'all_rewards', 'cap_loss', 'xe_loss',
+                                    'seq2seq_loss'}
+        for k in r:
+            np.testing.assert_allclose(a[k], b[k], rtol=1e-6, atol=1e-7, err_msg=k)        # ranks report global values
+            np.testing.assert_allclose(a[k], r[k], rtol=5e-5, atol=2e-6, err_msg=k)
+    np.testing.assert_array_equal(g0, g1)
+    np.testing.assert_allclose(g0, ref_g1, atol=1e-4 * np.abs(ref_g1).max())
+    off = 0
+    for k, v in ref.items():
+        a, b = g0[off:off + v.size], ref_g1[off:off + v.size]
+        np.testing.assert_allclose(a, b, atol=2e-4 * np.abs(b).max() + 1e-7, err_msg=k)
+        off += v.size
+    for k in ref:
+        np.testing.assert_array_equal(p0[k], p1[k], err_msg=k)
+        assert np.abs(p0[k] - ref[k]).max() <= STEPS * 4e-4 * 1.05, k
+
+
+def test_rccl_all_reduce_in_a_fresh_process():
+    """The gradient exchange on the backend the 8-GPU runs use: a fresh child process (nothing touched the GPU before
+    its init_process_group) builds a ONE-rank "nccl" group - RCCL on ROCm - and runs two xe_train_steps whose arena
+    all-reduce goes through it (tests/_rccl_child.py)."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, NCCL_DEBUG='INFO', NCCL_DEBUG_SUBSYS='INIT,COLL', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    child = os.path.join(os.path.dirname(os.path.abspath(__file__)), '_rccl_child.py')
+    r = subprocess.run([sys.executable, child, str(_free_port())], env=env, capture_output=True, text=True, timeout=420)
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-3000:])
+    line = [x for x in r.stdout.splitlines() if x.startswith('RCCL_CHILD ')]
+    assert line, r.stdout[-3000:]
+    info = json.loads(line[-1][len('RCCL_CHILD '):])
+    assert info['backend'] == 'nccl' and info['rccl_mapped']
+    assert info['collectives'] == 3 and info['identity']            # 2 training steps + the probe
+    assert info['arena_bytes'] == 4 * sum(int(np.prod(s)) for s in synth.param_shapes(V, ST).values())
+    assert info['moved'] >= 30 and all(np.isfinite(x) for x in info['losses'])
+    log = r.stdout + r.stderr
+    assert 'NCCL INFO' in log or 'RCCL' in log, log[-2000:]        # the backend's own log saw the communicator
