@@ -37,6 +37,7 @@ extern "C" {
 #define ISC_E_SHAPE (-2)     /* unsupported size (K %32, dims %32, too many segments ...) */
 #define ISC_E_ALIGN (-3)     /* pointer or leading dimension not 16-byte aligned */
 #define ISC_E_WORKSPACE (-4) /* caller-provided workspace too small */
+#define ISC_E_STATE (-5)     /* nothing to resume (isc_h3_weights_resume) */
 
 #define ISC_MAX_SEG 4
 
@@ -53,8 +54,10 @@ int isc_set_tile_override(int tile);
  * are split into two f16 planes each (x = hi + lo * 2^-11) inside the caller's workspace and contracted with three
  * f16 MFMAs per k-step into fp32 accumulators - fp32 in, fp32 out, error against an fp64 contraction no larger than
  * an fp32 FMA chain's (tests/test_gpu_h3.py), at 2-2.5x the fp32 MFMA rate.  Operand domain |x| < 65504.
- * mode 0 = off (fp32 MFMA tiles only), 1 = auto (default: launches of >= 160 128x128 tiles, smaller launches keep
- * the fp32 tiles), 2 = whenever shapes and workspace allow.  The planes of a launch must fit the workspace; a linear
+ * mode 0 = off (fp32 MFMA tiles only), 1 = auto (default: launches of >= 160 128x128 tiles take the large split-f16
+ * kernels; smaller ones take the skinny split-f16 kernel - one launch per GEMM, no split-K slabs - when their stream
+ * holds a weights scope, else the fp32 tiles), 2 = the large kernels whenever shapes and workspace allow, 3 = the
+ * skinny kernel whenever shapes allow (test hook: without a scope its weight planes go to the workspace).  The planes of a launch must fit the workspace; a linear
  * problem that does not goes through it in row chunks (the prologue's region projections).  A tile override
  * (>= 0) also disables it.  Returns the previous mode. */
 int isc_set_h3_mode(int mode);
@@ -62,6 +65,8 @@ int isc_set_h3_mode(int mode);
  * isc_h3x_launches: those of them that took the 256x128 eight-wave tile (launches of >= 224 such tiles). */
 long long isc_h3_launches(void);
 long long isc_h3x_launches(void);
+/* Launches that took the skinny split-f16 kernel (few rows: one launch per GEMM instead of split-K + reduce). */
+long long isc_h3s_launches(void);
 /* Weights scope of the split-f16 path.  Between _begin and _end the caller guarantees that no weight matrix passed
  * to the forward entry points changes (a roll-out's decode loop): each weight operand is then split into its planes
  * once, into `buf` (device memory, 256-byte aligned; 64 MB holds the decoder's matrices), and later launches with
@@ -72,6 +77,12 @@ long long isc_h3x_launches(void);
  * closes its scope (`buf` may then be reused). */
 int isc_h3_weights_begin(void *buf, long long bytes, void *stream);
 int isc_h3_weights_end(void *stream);
+/* _suspend leaves the stream's scope (no launch sees it any more) but keeps its planes; _resume(buf, stream) re-opens
+ * it as it was - the caller vouches that no weight has changed since (Captioner keys it on the parameters' version
+ * counters, so consecutive eval-mode calls split the weights once, not once per call) - or returns ISC_E_STATE when
+ * the slot has meanwhile been recycled (then: _begin).  Between the two, launches on the stream run without a scope. */
+int isc_h3_weights_suspend(void *stream);
+int isc_h3_weights_resume(void *buf, void *stream);
 
 /* One K-segment of a contraction: acc += A[M,K] * W[N,K]^T.  Replaces the
  * torch.cat([...],1) + nn.Linear / nn.LSTMCell pattern of captioner.py:174-175,180-181. */

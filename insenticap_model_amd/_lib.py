@@ -113,8 +113,11 @@ SIGNATURES = {
     'isc_set_h3_mode': (C.c_int, [C.c_int]),
     'isc_h3_launches': (C.c_longlong, []),
     'isc_h3x_launches': (C.c_longlong, []),
+    'isc_h3s_launches': (C.c_longlong, []),
     'isc_h3_weights_begin': (C.c_int, [C.c_void_p, C.c_longlong, C.c_void_p]),
     'isc_h3_weights_end': (C.c_int, [C.c_void_p]),
+    'isc_h3_weights_suspend': (C.c_int, [C.c_void_p]),
+    'isc_h3_weights_resume': (C.c_int, [C.c_void_p, C.c_void_p]),
     'isc_linear_fwd': (C.c_int, [C.POINTER(LinearProblem), C.c_int, C.c_void_p]),
     'isc_gemm_bwd': (C.c_int, [C.POINTER(LinearProblem), C.c_int, C.c_int, C.c_void_p]),
     'isc_lstm_fwd': (C.c_int, [C.POINTER(LstmProblem), C.c_void_p]),
@@ -171,7 +174,7 @@ SIGNATURES = {
 
 _ERRORS = {-1: 'ISC_E_NULL (required pointer is null)', -2: 'ISC_E_SHAPE (unsupported size)',
            -3: 'ISC_E_ALIGN (pointer / leading dimension not 16-byte aligned)',
-           -4: 'ISC_E_WORKSPACE'}
+           -4: 'ISC_E_WORKSPACE', -5: 'ISC_E_STATE'}
 
 _lib = None
 

@@ -86,43 +86,46 @@ def _train_forward(cap, mode, fc, att, cpt_words, senti_words, tokens_in, senti_
     if fed_known:                                         # every fed token is known up front: one copy, one gather
         S.tok.copy_(tokens_in.t())
         ops.embed_relu_fwd(emb, S.tok.view(-1), S.xt.view(T * B, Wd))
-    for t in range(T):
-        if sampling:
-            if t >= 1:
-                S.tok[t].copy_(seq[:, t - 1])             # it * unfinished, written by the previous finalize
-        elif not fed_known:
-            if t >= 1:                                    # scheduled sampling, captioner.py:219-228:
-                u = torch.rand(2, B, device=cap._dev)     # select + draw on the device, no host test
-                ops.sched_sample(out[:, t - 1], pm, ps, pi, u[0], u[1], ss_prob, tokens_in[:, t], S.tok[t])
-            else:
-                S.tok[t] = tokens_in[:, t]
-            ops.embed_relu_fwd(emb, S.tok[t], S.xt[t])        # plain relu(Emb[tok]); label term is in P.pre1
-        om, osc = mask_for('out%d' % t, B, H)
-        save = {'g1': S.g1[t], 'g2': S.g2[t]}
-        if om is not None:
-            if S.hdrop is None:
-                S.hdrop = new(T, B, H)
-            save['hdrop'] = S.hdrop[t]
-            S.out_scale = osc
-        S.out_masks.append(om)
-        ws = {'pmax': pm, 'psum': ps, 'pidx': pi, '_plan': plan}
-        if has_c:
-            ws['qa'], ws['v'] = S.qa[t], S.v[t]
-        if has_s:
-            ws['qw'], ws['s'] = S.qw[t], S.s[t]
-        if has_c and has_s:
-            ws['z'], ws['f'] = S.z[t], S.f[t]
-        logits = out[:, t]
-        cap._step(p, P, ws, S.xt[t], (S.h1[t], S.h2[t]), (S.c1[t], S.c2[t]),
-                  (S.h1[t + 1], S.h2[t + 1]), (S.c1[t + 1], S.c2[t + 1]),
-                  S.aC[:, t] if has_c else None, S.aS[:, t] if has_s else None,
-                  S.bG[:, t:t + 1] if (has_c and has_s) else None, logits, om, osc, save=save,
-                  normalize=not sampling)
-        if sampling:                                      # draw on the raw logits, then turn them into log-probs
-            rs.t, rs.logits = t, logits.data_ptr()
-            rs.xt_next = S.xt[t + 1].data_ptr() if t + 1 < T else None
-            ops.rollout_finalize(rs)
-            ops.logsoftmax_apply(logits, pm, ps)
+    # the weights are fixed for the whole unroll: their f16 planes are built once (few-row launches then take the
+    # one-launch skinny split-f16 kernels instead of split-K + reduce pairs)
+    with ops.h3_weights_scope(cap._dev):
+        for t in range(T):
+            if sampling:
+                if t >= 1:
+                    S.tok[t].copy_(seq[:, t - 1])             # it * unfinished, written by the previous finalize
+            elif not fed_known:
+                if t >= 1:                                    # scheduled sampling, captioner.py:219-228:
+                    u = torch.rand(2, B, device=cap._dev)     # select + draw on the device, no host test
+                    ops.sched_sample(out[:, t - 1], pm, ps, pi, u[0], u[1], ss_prob, tokens_in[:, t], S.tok[t])
+                else:
+                    S.tok[t] = tokens_in[:, t]
+                ops.embed_relu_fwd(emb, S.tok[t], S.xt[t])        # plain relu(Emb[tok]); label term is in P.pre1
+            om, osc = mask_for('out%d' % t, B, H)
+            save = {'g1': S.g1[t], 'g2': S.g2[t]}
+            if om is not None:
+                if S.hdrop is None:
+                    S.hdrop = new(T, B, H)
+                save['hdrop'] = S.hdrop[t]
+                S.out_scale = osc
+            S.out_masks.append(om)
+            ws = {'pmax': pm, 'psum': ps, 'pidx': pi, '_plan': plan}
+            if has_c:
+                ws['qa'], ws['v'] = S.qa[t], S.v[t]
+            if has_s:
+                ws['qw'], ws['s'] = S.qw[t], S.s[t]
+            if has_c and has_s:
+                ws['z'], ws['f'] = S.z[t], S.f[t]
+            logits = out[:, t]
+            cap._step(p, P, ws, S.xt[t], (S.h1[t], S.h2[t]), (S.c1[t], S.c2[t]),
+                      (S.h1[t + 1], S.h2[t + 1]), (S.c1[t + 1], S.c2[t + 1]),
+                      S.aC[:, t] if has_c else None, S.aS[:, t] if has_s else None,
+                      S.bG[:, t:t + 1] if (has_c and has_s) else None, logits, om, osc, save=save,
+                      normalize=not sampling)
+            if sampling:                                      # draw on the raw logits, then turn them into log-probs
+                rs.t, rs.logits = t, logits.data_ptr()
+                rs.xt_next = S.xt[t + 1].data_ptr() if t + 1 < T else None
+                ops.rollout_finalize(rs)
+                ops.logsoftmax_apply(logits, pm, ps)
     if sampling:
         S.sample = (seq, seq_masks, raw, alive)
     cap._set_weights(S.aC if has_c else None, S.aS if has_s else None,

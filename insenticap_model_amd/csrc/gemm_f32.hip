@@ -1681,6 +1681,232 @@ __global__ __launch_bounds__(256) void gemm_md_kernel(const DevLaunch L) {
     epi_linear_frag<TN>(P, acc, wm * 32, wn * 64, lane, row0, col0);
 }
 
+
+// ---------------------------------------------------------------- H3S: skinny split-f16 tiles for few-row launches
+// Launches with few rows (B <= a few hundred captions, beam rows, the 80-row seq2seq unroll) are not contraction-
+// bound: each of their GEMMs streams a weight matrix far larger than its activations, and the step is a chain of
+// such launches.  The fp32 route gave them a 32 x 128 tile per workgroup, split K over up to 16 workgroups, wrote
+// [S, M, N] slabs and ran a second kernel to sum them and apply the epilogue (13 + 6 us per GEMM at M = 128).
+// Here ONE launch does it.  Linear / LSTM: a workgroup owns a 32 x 32 output tile (LSTM: 8 hidden units x 4
+// gates), so a [128 x 2048] launch spreads its weight stream over 256 workgroups, and its four waves take
+// contiguous quarters of K; the four partial tiles meet in LDS, are summed in fixed order (deterministic) and
+// the epilogue runs from the reduced tile.  Vocabulary projection: a 32 x 128 tile (its statistics are per 128
+// columns), wave w owns columns 32w .. 32w+31 over the whole K.  Either way a wave is self-contained: it stages the
+// 32-deep k-blocks of ITS operands - one [32 rows x 128 B] image each for A and W - into a private 4-slot LDS ring
+// by LDS-DMA in pieces of 8 rows x 128 B (whole lines: a row's 32 hi + 32 lo halfs of a block are one line of the
+// interleaved plane layout), three blocks in flight, ordered by its own vmcnt only: no barrier in the loop.
+// LDS image: row r holds global 16-byte chunk c at position c ^ ((r >> 1) & 7) (conflict-free ds_read_b128 fragments).
+// Weights come as f16 planes from the stream's weights scope; an activation segment comes as planes when its
+// producer wrote them, else as fp32 rows (same 128 bytes per row and block) and is split after the fragment read.
+__device__ __forceinline__ void h3s_dma(unsigned lds_addr, const char *src) {
+    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(lds_addr), "v"(src) : "memory");
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_h3s_kernel(const DevLaunch L) {
+    constexpr bool KSPLIT = EPI != EPI_VOCAB;
+    constexpr int BM = 32, BN = KSPLIT ? 32 : 128;
+    // ring depth: 4 slots (three blocks in flight, 128 KB: one workgroup per CU) for the K-split tiles, whose launches
+    // have at most ~256 workgroups; 2 slots (64 KB: two workgroups per CU) for the vocabulary projection, whose 79
+    // column tiles x row tiles do not fit one round of single-workgroup CUs (316 workgroups at M = 128: 32 -> 17 us)
+    constexpr int R = KSPLIT ? 4 : 2, SLOT = 8192, LDR = 33;
+    extern __shared__ __attribute__((aligned(16))) float smem[];     // 4 waves x R slots x (4 KB A + 4 KB W)
+    char *lds = reinterpret_cast<char *>(smem);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    // wave index as a scalar: everything derived from it (k-range, segment cursor) then lives in SGPRs and the
+    // descriptor fields it selects are fetched by scalar loads, not by vector loads that would sit in vmcnt
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int pi, tm, tn, ks, ksplit;
+    map_tile(L, pi, tm, tn, ks, ksplit);
+    const DevProb &P = L.p[pi];
+    const int M = P.M, N = P.N, Kp = P.Kp;
+    const int row0 = tm * BM, col0 = tn * BN;
+    const int fr = lane & 31, fh = lane >> 5;
+    const int cw = KSPLIT ? 0 : wave;                   // this wave's 32-column block inside the tile
+
+    // DMA lanes: piece p covers image rows 8p + (lane >> 3); lane position lane & 7 fetches chunk pos ^ swizzle(row)
+    const int prow = lane >> 3;
+    int a_row[4];
+    const char *w_src[4];
+    int chunk_off[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int r = 8 * p + prow;
+        chunk_off[p] = ((lane & 7) ^ ((r >> 1) & 7)) * 16;
+        const int ar = row0 + r;
+        a_row[p] = ar < M ? ar : M - 1;                 // rows past the edge fetch a valid row, never stored
+        long long wr;
+        if (EPI == EPI_LSTM) {
+            wr = (long long)p * P.H + tn * 8 + prow;    // image row r = gate p, unit tn*8 + prow
+        } else {
+            const int c = col0 + cw * 32 + r;
+            wr = c < N ? c : N - 1;
+        }
+        w_src[p] = reinterpret_cast<const char *>(P.Wh) + wr * 4 * Kp + chunk_off[p];
+    }
+    // this wave's k-blocks, and a cursor over the A segments positioned on its first block
+    const int nblk = Kp >> 5;
+    const int b_lo = KSPLIT ? (nblk * wave) >> 2 : 0, b_hi = KSPLIT ? (nblk * (wave + 1)) >> 2 : nblk;
+    const int n = b_hi - b_lo;
+    int cs = 0, cb = b_lo;
+    while (cs < P.nap - 1 && cb >= (P.ap[cs].K >> 5)) { cb -= P.ap[cs].K >> 5; ++cs; }
+    int seg_blocks = 0;
+    bool seg_f32 = false;
+    const char *a_src[4];
+    auto set_aseg = [&](int si) __attribute__((always_inline)) {
+        const DevASeg a = P.ap[si];
+        seg_blocks = a.K >> 5;
+        seg_f32 = a.hi == nullptr;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            if (seg_f32)
+                a_src[p] = reinterpret_cast<const char *>(P.seg[si].A + (long long)a_row[p] * P.seg[si].lda) + chunk_off[p];
+            else
+                a_src[p] = reinterpret_cast<const char *>(a.hi + (long long)a_row[p] * a.ld) + chunk_off[p];
+        }
+    };
+    set_aseg(cs);
+    const unsigned ring = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds + wave * (R * SLOT));
+    unsigned f32_bits = 0;                               // bit (block % R): that slot's A image holds fp32 rows
+    int lb = b_lo;
+    auto issue = [&](int i) __attribute__((always_inline)) {          // block i of this wave -> slot i % R
+        const unsigned slot = ring + (i & (R - 1)) * SLOT;
+        f32_bits = (f32_bits & ~(1u << (i & (R - 1)))) | ((seg_f32 ? 1u : 0u) << (i & (R - 1)));
+#pragma unroll
+        for (int p = 0; p < 4; ++p) h3s_dma(slot + p * 1024, a_src[p] + (long long)cb * 128);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) h3s_dma(slot + 4096 + p * 1024, w_src[p] + (long long)lb * 128);
+        ++lb;
+        if (++cb >= seg_blocks && cs + 1 < P.nap) { cb = 0; set_aseg(++cs); }
+    };
+
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    const int fsw = (fr >> 1) & 7;
+    for (int i = 0; i < R - 1 && i < n; ++i) issue(i);
+    for (int i = 0; i < n; ++i) {
+        if (i + R - 1 < n) issue(i + R - 1);             // its slot was consumed in iteration i - 1
+        const int younger = n - 1 - i < R - 1 ? n - 1 - i : R - 1;    // blocks issued after block i
+        if (R > 3 && younger == 3) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+        else if (R > 2 && younger == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const char *img = lds + wave * (R * SLOT) + (i & (R - 1)) * SLOT + fr * 128;
+        const bool af32 = (f32_bits >> (i & (R - 1))) & 1u;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            h8 a1, a2;
+            if (af32) {
+                const float4 v0 = *reinterpret_cast<const float4 *>(img + (((4 * kk + 2 * fh) ^ fsw) * 16));
+                const float4 v1 = *reinterpret_cast<const float4 *>(img + (((4 * kk + 2 * fh + 1) ^ fsw) * 16));
+                const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const _Float16 h = (_Float16)x[e];
+                    a1[e] = h;
+                    a2[e] = (_Float16)((x[e] - (float)h) * 2048.f);
+                }
+            } else {
+                a1 = *reinterpret_cast<const h8 *>(img + (((2 * kk + fh) ^ fsw) * 16));
+                a2 = *reinterpret_cast<const h8 *>(img + (((4 + 2 * kk + fh) ^ fsw) * 16));
+            }
+            const h8 b1 = *reinterpret_cast<const h8 *>(img + 4096 + (((2 * kk + fh) ^ fsw) * 16));
+            const h8 b2 = *reinterpret_cast<const h8 *>(img + 4096 + (((4 + 2 * kk + fh) ^ fsw) * 16));
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b2, acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2, b1, acc1, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc0[r] = fmaf(acc1[r], 1.f / 2048.f, acc0[r]);
+    __syncthreads();                                     // every wave is done with its ring: LDS is free
+
+    if constexpr (EPI == EPI_VOCAB) {
+        f32x16 accv[1] = {acc0};
+        epi_vocab_frag<1, 4, BM>(P, accv, 0, wave * 32, wave, lane, row0, col0, tn, smem);
+        float *smx = smem;
+        float *ssm = smem + 4 * BM;
+        int *six = reinterpret_cast<int *>(smem + 2 * 4 * BM);
+        __syncthreads();
+        if (tid < BM && row0 + tid < M) {
+            const int row = tid;
+            float mx = smx[row];
+            int ix = six[row];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) {
+                const float ov = smx[w * BM + row];
+                const int oi = six[w * BM + row];
+                if (ov > mx || (ov == mx && oi < ix)) { mx = ov; ix = oi; }
+            }
+            float sm = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const float wm_ = smx[w * BM + row];          // -inf: that wave had no valid column
+                if (wm_ > -INFINITY) sm += ssm[w * BM + row] * __expf(wm_ - mx);
+            }
+            const long long o = (long long)(row0 + row) * P.ntile_total + tn;
+            P.pmax[o] = mx;
+            P.psum[o] = sm;
+            P.pidx[o] = ix;
+        }
+        return;
+    } else {
+        // partial tile of this wave -> LDS (C/D layout: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5))
+        float *mine = smem + wave * (BM * LDR);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mine[((r & 3) + 8 * (r >> 2) + 4 * fh) * LDR + fr] = acc0[r];
+        __syncthreads();
+        auto red = [&](int row, int col) __attribute__((always_inline)) {
+            const float *q = smem + row * LDR + col;
+            return ((q[0] + q[BM * LDR]) + q[2 * BM * LDR]) + q[3 * BM * LDR];     // fixed order: bit-repeatable
+        };
+        if constexpr (EPI == EPI_LINEAR) {
+            const int row = tid >> 3, c4 = (tid & 7) * 4;
+            const int gm = row0 + row, gn = col0 + c4;
+            if (gm >= M || gn >= N) return;
+            float o[4], pre[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = red(row, c4 + e);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int nn = gn + e;
+                pre[e] = 0.f;
+                if (nn < N) {
+                    if (P.bias0) o[e] += P.bias0[nn];
+                    if (P.bias1) o[e] += P.bias1[nn];
+                    if (P.bias2) o[e] += P.bias2[nn];
+                    if (P.accumulate) o[e] += P.C[(long long)gm * P.ldc + nn];
+                    if (P.relu) o[e] = fmaxf(o[e], 0.f);
+                    pre[e] = o[e];
+                    if (P.mask) o[e] = o[e] * (float)P.mask[(long long)gm * N + nn] * P.mask_scale;
+                }
+            }
+            float *dst = P.C + (long long)gm * P.ldc + gn;
+            if ((P.ldc & 3) == 0 && gn + 3 < N) {
+                *reinterpret_cast<float4 *>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+                if (P.C_pre)
+                    *reinterpret_cast<float4 *>(P.C_pre + (long long)gm * P.ldc + gn) =
+                        make_float4(pre[0], pre[1], pre[2], pre[3]);
+            } else {
+                for (int e = 0; e < 4 && gn + e < N; ++e) {
+                    dst[e] = o[e];
+                    if (P.C_pre) P.C_pre[(long long)gm * P.ldc + gn + e] = pre[e];
+                }
+            }
+        } else {
+            const int row = tid >> 3, u = tid & 7;
+            int gm[1] = {row0 + row};
+            bool ok[1] = {gm[0] < M};
+            float g[1][4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) g[0][k] = red(row, k * 8 + u);
+            lstm_cells<1>(P, gm, tn * 8 + u, ok, g);
+        }
+    }
+}
+
 // ---------------------------------------------------------------- split-K reduction + epilogue
 // Sums the ksplit partial slabs in a fixed order (deterministic) and applies the epilogue the
 // single-pass kernel would have applied.  blockIdx.y = problem.
@@ -1975,7 +2201,7 @@ static std::atomic<long long> g_h3_launches{0}, g_h3x_launches{0};
 extern "C" long long isc_h3_launches(void) { return g_h3_launches.load(); }
 extern "C" long long isc_h3x_launches(void) { return g_h3x_launches.load(); }
 extern "C" int isc_set_h3_mode(int mode) {
-    if (mode >= 0 && mode <= 2) return g_h3_mode.exchange(mode);
+    if (mode >= 0 && mode <= 3) return g_h3_mode.exchange(mode);
     return g_h3_mode.load();
 }
 #define H3_MIN_TILES 160
@@ -2029,9 +2255,11 @@ extern "C" int isc_h3_weights_begin(void *buf, long long bytes, void *stream) {
     if ((uintptr_t)buf & 255) return ISC_E_ALIGN;
     std::lock_guard<std::mutex> lk(g_h3w_mu);
     H3WScope *slot = nullptr;
-    for (int i = 0; i < H3W_MAX_SCOPES; ++i)
-        if (g_h3w[i].active && g_h3w[i].stream == (hipStream_t)stream) slot = &g_h3w[i];
-    for (int i = 0; !slot && i < H3W_MAX_SCOPES; ++i)
+    for (int i = 0; i < H3W_MAX_SCOPES; ++i)                     // the stream's own slot (active or suspended)
+        if (g_h3w[i].buf && g_h3w[i].stream == (hipStream_t)stream) slot = &g_h3w[i];
+    for (int i = 0; !slot && i < H3W_MAX_SCOPES; ++i)            // a free one
+        if (!g_h3w[i].buf) slot = &g_h3w[i];
+    for (int i = 0; !slot && i < H3W_MAX_SCOPES; ++i)            // a suspended one (its owner will rebuild)
         if (!g_h3w[i].active) slot = &g_h3w[i];
     if (!slot) return ISC_E_WORKSPACE;               // more concurrent scopes than slots: the caller runs without one
     slot->stream = (hipStream_t)stream;
@@ -2042,10 +2270,26 @@ extern "C" int isc_h3_weights_begin(void *buf, long long bytes, void *stream) {
 extern "C" int isc_h3_weights_end(void *stream) {
     std::lock_guard<std::mutex> lk(g_h3w_mu);
     for (int i = 0; i < H3W_MAX_SCOPES; ++i)
-        if (g_h3w[i].active && g_h3w[i].stream == (hipStream_t)stream) {
+        if (g_h3w[i].buf && g_h3w[i].stream == (hipStream_t)stream) {
             g_h3w[i].active = false; g_h3w[i].n = 0; g_h3w[i].used = 0; g_h3w[i].buf = nullptr;
         }
     return ISC_OK;
+}
+extern "C" int isc_h3_weights_suspend(void *stream) {
+    std::lock_guard<std::mutex> lk(g_h3w_mu);
+    for (int i = 0; i < H3W_MAX_SCOPES; ++i)
+        if (g_h3w[i].active && g_h3w[i].stream == (hipStream_t)stream) g_h3w[i].active = false;
+    return ISC_OK;
+}
+extern "C" int isc_h3_weights_resume(void *buf, void *stream) {
+    if (!buf) return ISC_E_NULL;
+    std::lock_guard<std::mutex> lk(g_h3w_mu);
+    for (int i = 0; i < H3W_MAX_SCOPES; ++i)
+        if (!g_h3w[i].active && g_h3w[i].buf == static_cast<char *>(buf) && g_h3w[i].stream == (hipStream_t)stream) {
+            g_h3w[i].active = true;
+            return ISC_OK;
+        }
+    return ISC_E_STATE;
 }
 
 static const H3WEntry *h3w_find(const H3WScope *sc, const DevProb &p) {
@@ -2232,7 +2476,7 @@ static int try_h3(DevLaunch &L, float *ws, long long ws_floats, hipStream_t st, 
     }
     // linear launches that cannot give every CU a 128-row tile go out on the 64-row H3 tile
     const bool half_tile = EPI == EPI_LINEAR && tiles < 256;
-    if (h3_mode == 1 && tiles < (half_tile ? H3_MIN_TILES / 2 : H3_MIN_TILES)) return 0;
+    if (h3_mode != 2 && tiles < (half_tile ? H3_MIN_TILES / 2 : H3_MIN_TILES)) return 0;
     if (need > ws_floats) {
         if constexpr (EPI != EPI_LINEAR) return 0;
         long long chunk[3];
@@ -2283,6 +2527,85 @@ static int try_h3(DevLaunch &L, float *ws, long long ws_floats, hipStream_t st, 
         rc = launch_h3_big<EPI>(L, st);
     }
     ++g_h3_launches;
+    return 1;
+}
+
+// ---- skinny split-f16 path (gemm_h3s_kernel): few-row launches inside a weights scope ----
+static std::atomic<long long> g_h3s_launches{0};
+extern "C" long long isc_h3s_launches(void) { return g_h3s_launches.load(); }
+#define H3S_MAX_ROWS 2048
+
+template <int EPI>
+static int launch_h3s(const DevLaunch &L, hipStream_t st) {
+    constexpr size_t lds = (size_t)4 * (EPI == EPI_VOCAB ? 2 : 4) * 8192;      // 4 waves x ring slots x 8 KB
+    static std::atomic<bool> attr_set{false};
+    if (lds > 65536 && !attr_set.load()) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_h3s_kernel<EPI>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set.store(true);
+    }
+    hipLaunchKernelGGL((gemm_h3s_kernel<EPI>), dim3(L.total_tiles), dim3(256), lds, st, L);
+    ISC_LAUNCH_CHECK();
+    return ISC_OK;
+}
+
+// Returns 1 when the launch went out on the skinny path (rc = its status), 0 when it does not apply: mode off / tile
+// override, no weights scope on this stream in auto mode (the weight planes would have to be rebuilt per launch),
+// more rows than H3S_MAX_ROWS, or a launch the large split-f16 kernels take (>= H3_MIN_TILES 128 x 128 tiles).
+// Mode 3 forces it (tests): without a scope the weight planes then go to the workspace.
+template <int EPI>
+static int try_h3s(DevLaunch &L, float *ws, long long ws_floats, hipStream_t st, int &rc) {
+    const int mode = g_h3_mode.load();
+    if ((mode != 1 && mode != 3) || g_tile_override.load() >= 0) return 0;
+    H3WScope *sc = h3w_scope_of(st);
+    if (!sc && mode != 3) return 0;
+    long long tiles = 0, need = 0;
+    for (int i = 0; i < L.nprob; ++i) {
+        const DevProb &p = L.p[i];
+        if (p.M > H3S_MAX_ROWS) return 0;
+        if (EPI == EPI_LSTM && (p.H & 7)) return 0;
+        const long long Kp = h3_kp(p);
+        if (Kp > (1 << 20)) return 0;
+        tiles += (long long)((p.M + 127) / 128) * ((p.N + 127) / 128);
+        need += (long long)p.N * Kp + 256;
+    }
+    if (mode == 1) {
+        const bool half_tile = EPI == EPI_LINEAR && tiles < 256;
+        if (tiles >= (half_tile ? H3_MIN_TILES / 2 : H3_MIN_TILES)) return 0;      // the large kernels' launch
+    }
+    if (!ws || ((uintptr_t)ws & 255) || need > ws_floats) return 0;   // planes that do not fit the scope go here
+    {
+        int jobs = 0;
+        for (int i = 0; i < L.nprob; ++i) jobs += 1;
+        if (jobs > H3_MAX_JOBS) return 0;
+    }
+    H3Planner pl(ws, sc);
+    int start = 0;
+    constexpr int BN = EPI == EPI_VOCAB ? 128 : 32;
+    for (int i = 0; i < L.nprob; ++i) {
+        DevProb &p = L.p[i];
+        p.Kp = h3_kp(p);
+        p.nap = p.nseg;
+        for (int s = 0; s < p.nseg; ++s) {
+            const bool planes = p.seg[s].A_hi && p.seg[s].A_lo;
+            p.ap[s] = DevASeg{planes ? p.seg[s].A_hi : nullptr, planes ? p.seg[s].A_lo : nullptr, 2 * p.seg[s].K,
+                              p.seg[s].K};
+        }
+        pl.add_w(p, p.Wh, p.Wl);
+        p.ksplit = 1;
+        p.tiles_m = (p.M + 31) / 32;
+        p.tiles_n = (p.N + BN - 1) / BN;
+        p.tile_start = start;
+        p.m_fastest = 0;                                  // tn fastest: neighbouring workgroups share their A rows
+        p.grp_n = (p.tiles_n + 7) / 8;
+        start += p.tiles_m * p.tiles_n;
+    }
+    L.total_tiles = start;
+    rc = pl.launch(st);                                   // weight planes not yet in the scope (first use only)
+    if (rc) return 1;
+    rc = launch_h3s<EPI>(L, st);
+    ++g_h3s_launches;
     return 1;
 }
 
@@ -2349,8 +2672,9 @@ extern "C" int isc_linear_fwd(const isc_linear_problem *pr, int n_prob, void *st
         d.mask = q.keep_mask; d.mask_scale = q.mask_scale;
         d.ldc = q.ldc; d.C = q.C; d.C_pre = q.C_pre; d.accumulate = q.accumulate;
     }
-    const int S = plan_splitk(L, pr[0].splitk_ws, pr[0].splitk_ws_floats);
     int rc = ISC_OK;
+    if (try_h3s<EPI_LINEAR>(L, pr[0].splitk_ws, pr[0].splitk_ws_floats, (hipStream_t)stream, rc)) return rc;
+    const int S = plan_splitk(L, pr[0].splitk_ws, pr[0].splitk_ws_floats);
     if (S == 1 && try_h3<EPI_LINEAR>(L, pr[0].splitk_ws, pr[0].splitk_ws_floats, (hipStream_t)stream, rc)) return rc;
     const int tile = S > 1 ? 2 : pick_tile(L, true);
     finish_tiling(L, tile);
@@ -2413,6 +2737,7 @@ extern "C" int isc_lstm_fwd(const isc_lstm_problem *q, void *stream) {
     if ((q->h_hi == nullptr) != (q->h_lo == nullptr)) return ISC_E_NULL;
     d.h_hi = static_cast<_Float16 *>(q->h_hi); d.h_lo = static_cast<_Float16 *>(q->h_lo);
     d.pre = q->pre; d.tab = q->tab; d.tab_ids = q->tab_ids; d.tab_ids_stride = q->tab_ids_stride;
+    if (try_h3s<EPI_LSTM>(L, q->splitk_ws, q->splitk_ws_floats, (hipStream_t)stream, rc)) return rc;
     const int S = plan_splitk(L, q->splitk_ws, q->splitk_ws_floats);
     if (S > 1) {   // plain [M,4H] pre-activation slabs, then the cell update in the reduce kernel
         finish_tiling(L, 2);
@@ -2454,6 +2779,7 @@ extern "C" int isc_vocab_fwd(const float *h, int ldh, const float *W, int ldw, c
     d.ntile_total = (V + 127) / 128;
     // few rows (beam search, small batches): the 16-chunk contraction of a 32-row tile is a serial walk
     // of ~27 us; split it over K into raw [S,M,V] slabs and let the reduce kernel form the statistics
+    if (try_h3s<EPI_VOCAB>(L, splitk_ws, splitk_ws_floats, (hipStream_t)stream, rc)) return rc;
     const int S = plan_splitk(L, splitk_ws, splitk_ws_floats);
     if (S > 1) {
         finish_tiling(L, 2);

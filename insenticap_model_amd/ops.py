@@ -71,6 +71,7 @@ SPLITK_WS_FLOATS = 32 * 1024 * 1024     # 128 MB per device and stream: [ksplit,
 
 
 WS_OVERRIDE = None      # set while a HIP graph is being captured: the graph owns its workspace
+H3W_OVERRIDE = None     # ... and its weight-plane buffer (h3_weights_scope)
 
 
 def splitk_ws(device=None):
@@ -142,7 +143,7 @@ def set_h3_mode(mode):
 
 
 _H3W_BUF = {}
-H3W_BYTES = 64 * 1024 * 1024
+H3W_BYTES = 96 * 1024 * 1024
 
 
 class h3_weights_scope:
@@ -150,12 +151,17 @@ class h3_weights_scope:
     (include/insenticap_hip.h: isc_h3_weights_begin), so their f16 planes are built once per block, not per launch.
     The scope belongs to the CURRENT stream (library side: one slot per stream; here: one plane buffer and one
     nesting depth per (device, stream)), so two host threads running two captioners on two streams are independent.
-    Nested scopes on the same stream are ignored (the outer one stays in force)."""
+    Nested scopes on the same stream are ignored (the outer one stays in force).
+    `key` (hashable, optional): identifies the weight VALUES (Captioner passes the parameters' storage pointers and
+    version counters).  A keyed scope is suspended, not closed, on exit; the next keyed scope on the stream with an
+    equal key resumes it with its planes intact - consecutive eval-mode calls then split the weights once."""
     _depth = {}
+    _suspended = {}          # (device, stream) -> key of the suspended scope
     _lock = threading.Lock()
 
-    def __init__(self, device):
+    def __init__(self, device, key=None):
         self.device = torch.device(device)
+        self.wkey = key
 
     def __enter__(self):
         cls = h3_weights_scope
@@ -163,25 +169,39 @@ class h3_weights_scope:
         self.key = key = (index, torch.cuda.current_stream(index).cuda_stream)     # one buffer per stream, as splitk_ws
         with cls._lock:
             depth = cls._depth[key] = cls._depth.get(key, 0) + 1
-            buf = None
-            if depth == 1 and WS_OVERRIDE is None:        # not while a HIP graph is being captured
+            buf = was = None
+            if depth == 1 and WS_OVERRIDE is not None:    # a HIP graph is being captured: the graph owns the plane
+                buf = H3W_OVERRIDE                        # buffer, and replays must re-split (weights may change
+                self.wkey = None                          # in place between replays): never keyed, never resumed
+            elif depth == 1:
                 buf = _H3W_BUF.get(key)
                 if buf is None:
                     buf = _H3W_BUF[key] = torch.empty(H3W_BYTES, dtype=torch.uint8, device=self.device)
+                was = cls._suspended.pop(key, None)
         self.opened = False
         if buf is not None:
-            rc = _lib.load().isc_h3_weights_begin(buf.data_ptr(), buf.numel(), C.c_void_p(key[1]))
-            if rc != -4:                                  # ISC_E_WORKSPACE: all scope slots taken - run without one
-                _lib.check(rc, 'isc_h3_weights_begin')
+            lib = _lib.load()
+            if self.wkey is not None and was == self.wkey and \
+                    lib.isc_h3_weights_resume(buf.data_ptr(), C.c_void_p(key[1])) == 0:
                 self.opened = True
+            else:
+                rc = lib.isc_h3_weights_begin(buf.data_ptr(), buf.numel(), C.c_void_p(key[1]))
+                if rc != -4:                              # ISC_E_WORKSPACE: all scope slots taken - run without one
+                    _lib.check(rc, 'isc_h3_weights_begin')
+                    self.opened = True
         return self
 
     def __exit__(self, *exc):
         cls = h3_weights_scope
         with cls._lock:
             cls._depth[self.key] -= 1
+            if self.opened and self.wkey is not None and exc[0] is None:
+                cls._suspended[self.key] = self.wkey
         if self.opened:
-            _lib.load().isc_h3_weights_end(C.c_void_p(self.key[1]))
+            if self.wkey is not None and exc[0] is None:
+                _lib.load().isc_h3_weights_suspend(C.c_void_p(self.key[1]))
+            else:
+                _lib.load().isc_h3_weights_end(C.c_void_p(self.key[1]))
         return False
 
 
