@@ -1095,8 +1095,8 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 template <int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_h3_kernel(const DevLaunch L) {
     constexpr int BM = 128, BN = 128, TN = 4;
-    constexpr int PL = 128 * 64;                        // bytes per plane tile
-    constexpr int ST = 4 * PL;                          // bytes per buffer
+    constexpr int PA = 128 * 128, PB = 128 * 128;       // bytes per A / W image (row = 128 B: 32 hi | 32 lo halfs)
+    constexpr int ST = PA + PB;                         // bytes per buffer
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char *lds = reinterpret_cast<char *>(smem);
 
@@ -1109,15 +1109,18 @@ __global__ __launch_bounds__(256, 2) void gemm_h3_kernel(const DevLaunch L) {
     const int M = P.M, N = P.N, Kp = P.Kp;
     const int row0 = tm * BM, col0 = tn * BN;
 
-    // staging: per plane, wave w issues pieces 2w and 2w+1; piece ii = tile rows 16*ii .. +16, 4 lanes per row.
+    // staging in pieces of 8 rows x 128 B = whole lines of the interleaved plane layout (a row's 32 hi + 32 lo halfs
+    // of a k-block): wave w issues A pieces 4w .. 4w+3 and W pieces 4w .. 4w+3; piece ii = image rows 8*ii .. +8,
+    // 8 lanes per row.  (Pieces of 16 rows x 64 B - hi and lo fetched by different instructions - touched every line
+    // twice and ran 9-14 % slower: tools/h3_gemm_lab.hip, r02.)  Image position p of row r holds chunk p ^ ((r>>1)&7).
     // W planes are K-packed [N, Kp]; A planes come by K-segment (P.ap: the split kernel's packed planes as one
     // segment, or the producers' per-tensor planes), switched at chunk boundaries.
     const _Float16 *src[8];
-    int arow[2], aq[2];
+    int arow[4], aq[4];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int t = 16 * (2 * wm + i) + (lane >> 2);
-        const int q = (lane & 3) ^ ((t >> 2) & 3);
+    for (int i = 0; i < 4; ++i) {
+        const int t = 32 * wm + 8 * i + (lane >> 3);
+        const int q = (lane & 7) ^ ((t >> 1) & 7);
         int ar = row0 + t;
         arow[i] = ar < M ? ar : M - 1;
         aq[i] = q * 8;
@@ -1129,28 +1132,24 @@ __global__ __launch_bounds__(256, 2) void gemm_h3_kernel(const DevLaunch L) {
             wr = c < N ? c : N - 1;
         }
         src[4 + i] = P.Wh + wr * 2 * Kp + q * 8;
-        src[6 + i] = P.Wl + wr * 2 * Kp + q * 8;
     }
     int cs = 0, ck = 0, segK = 0;
     auto set_aseg = [&](int si) __attribute__((always_inline)) {
         const DevASeg a = P.ap[si];
         segK = a.K;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            src[0 + i] = a.hi + (long long)arow[i] * a.ld + aq[i];
-            src[2 + i] = a.lo + (long long)arow[i] * a.ld + aq[i];
-        }
+        for (int i = 0; i < 4; ++i) src[i] = a.hi + (long long)arow[i] * a.ld + aq[i];
     };
     set_aseg(0);
-    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds + wm * 2048);
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds + wm * 4096);
     auto stage = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
-        for (int p = 0; p < 4; ++p)
+        for (int p = 0; p < 2; ++p)
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < 4; ++i) {
                 asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off"
-                             :: "s"(lds0 + buf * ST + p * PL + i * 1024), "v"(src[2 * p + i]) : "memory");
-                src[2 * p + i] += 64;                     // next 32-k block: 32 hi + 32 lo halfs further
+                             :: "s"(lds0 + buf * ST + p * PA + i * 1024), "v"(src[4 * p + i]) : "memory");
+                src[4 * p + i] += 64;                     // next 32-k block: 32 hi + 32 lo halfs further
             }
         ck += 32;
         if (ck >= segK) {
@@ -1167,20 +1166,20 @@ __global__ __launch_bounds__(256, 2) void gemm_h3_kernel(const DevLaunch L) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc0[j][r] = 0.f; acc1[j][r] = 0.f; }
 
-    const int fr = lane & 31, fh = lane >> 5, fsw = (fr >> 2) & 3;
+    const int fr = lane & 31, fh = lane >> 5, fsw = (fr >> 1) & 7;
     h8 a1[2], a2[2], b1[2][TN], b2[2][TN];
     auto lfrag = [&](int buf, auto ksc, auto setc) __attribute__((always_inline)) {
         constexpr int kk = decltype(ksc)::value, S = decltype(setc)::value;
-        const int slot = ((2 * kk + fh) ^ fsw) * 16;
+        const int ph = ((2 * kk + fh) ^ fsw) * 16, pl = ((4 + 2 * kk + fh) ^ fsw) * 16;
         const char *base = lds + buf * ST;
-        const int ra = (wm * 32 + fr) * 64 + slot;
-        a1[S] = *reinterpret_cast<const h8 *>(base + ra);
-        a2[S] = *reinterpret_cast<const h8 *>(base + PL + ra);
+        const int ra = (wm * 32 + fr) * 128;
+        a1[S] = *reinterpret_cast<const h8 *>(base + ra + ph);
+        a2[S] = *reinterpret_cast<const h8 *>(base + ra + pl);
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int rb = (j * 32 + fr) * 64 + slot;
-            b1[S][j] = *reinterpret_cast<const h8 *>(base + 2 * PL + rb);
-            b2[S][j] = *reinterpret_cast<const h8 *>(base + 3 * PL + rb);
+            const int rb = PA + (j * 32 + fr) * 128;
+            b1[S][j] = *reinterpret_cast<const h8 *>(base + rb + ph);
+            b2[S][j] = *reinterpret_cast<const h8 *>(base + rb + pl);
         }
     };
     auto mma = [&](auto setc) __attribute__((always_inline)) {
@@ -1231,8 +1230,8 @@ __global__ __launch_bounds__(256, 2) void gemm_h3_kernel(const DevLaunch L) {
 template <int EPI>
 __global__ __launch_bounds__(512) void gemm_h3x_kernel(const DevLaunch L) {
     constexpr int BM = 256, BN = 128, TN = 4;
-    constexpr int PA = 256 * 64, PB = 128 * 64;         // bytes per A / W plane tile
-    constexpr int ST = 2 * PA + 2 * PB;                 // bytes per buffer (48 KB)
+    constexpr int PA = 256 * 128, PB = 128 * 128;       // bytes per A / W image (row = 128 B: 32 hi | 32 lo halfs)
+    constexpr int ST = PA + PB;                         // bytes per buffer (48 KB)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char *lds = reinterpret_cast<char *>(smem);
 
@@ -1245,19 +1244,21 @@ __global__ __launch_bounds__(512) void gemm_h3x_kernel(const DevLaunch L) {
     const int M = P.M, N = P.N, Kp = P.Kp;
     const int row0 = tm * BM, col0 = tn * BN;
 
-    // staging pieces of 16 rows x 64 B: A planes 16 pieces (two per wave), W planes 8 (one per wave).  A by K-segment.
+    // staging pieces of 8 rows x 128 B (whole lines, see gemm_h3_kernel): A image 32 pieces (four per wave), W image 16
+    // (two per wave).  A by K-segment.
     const _Float16 *src[6];
-    int arow[2], aq[2];
+    int arow[4], aq[4];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int t = 16 * (2 * wm + i) + (lane >> 2);
+    for (int i = 0; i < 4; ++i) {
+        const int t = 32 * wm + 8 * i + (lane >> 3);
         int ar = row0 + t;
         arow[i] = ar < M ? ar : M - 1;
-        aq[i] = ((lane & 3) ^ ((t >> 2) & 3)) * 8;
+        aq[i] = ((lane & 7) ^ ((t >> 1) & 7)) * 8;
     }
-    {
-        const int t = 16 * wm + (lane >> 2);
-        const int q = (lane & 3) ^ ((t >> 2) & 3);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int t = 16 * wm + 8 * i + (lane >> 3);
+        const int q = (lane & 7) ^ ((t >> 1) & 7);
         long long wr;
         if (EPI == EPI_LSTM) {
             wr = (long long)(t >> 5) * P.H + tn * 32 + (t & 31);
@@ -1265,18 +1266,14 @@ __global__ __launch_bounds__(512) void gemm_h3x_kernel(const DevLaunch L) {
             const int c = col0 + t;
             wr = c < N ? c : N - 1;
         }
-        src[4] = P.Wh + wr * 2 * Kp + q * 8;
-        src[5] = P.Wl + wr * 2 * Kp + q * 8;
+        src[4 + i] = P.Wh + wr * 2 * Kp + q * 8;
     }
     int cs = 0, ck = 0, segK = 0;
     auto set_aseg = [&](int si) __attribute__((always_inline)) {
         const DevASeg a = P.ap[si];
         segK = a.K;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            src[0 + i] = a.hi + (long long)arow[i] * a.ld + aq[i];
-            src[2 + i] = a.lo + (long long)arow[i] * a.ld + aq[i];
-        }
+        for (int i = 0; i < 4; ++i) src[i] = a.hi + (long long)arow[i] * a.ld + aq[i];
     };
     set_aseg(0);
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds);
@@ -1288,12 +1285,9 @@ __global__ __launch_bounds__(512) void gemm_h3x_kernel(const DevLaunch L) {
     auto stage = [&](int buf) __attribute__((always_inline)) {
         const unsigned b = lds0 + buf * ST;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            dma1(b + (2 * wv + i) * 1024, src[0 + i]);
-            dma1(b + PA + (2 * wv + i) * 1024, src[2 + i]);
-        }
-        dma1(b + 2 * PA + wv * 1024, src[4]);
-        dma1(b + 2 * PA + PB + wv * 1024, src[5]);
+        for (int i = 0; i < 4; ++i) dma1(b + (4 * wv + i) * 1024, src[i]);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) dma1(b + PA + (2 * wv + i) * 1024, src[4 + i]);
         ck += 32;
         if (ck >= segK) {
             ck = 0;
@@ -1309,20 +1303,20 @@ __global__ __launch_bounds__(512) void gemm_h3x_kernel(const DevLaunch L) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc0[j][r] = 0.f; acc1[j][r] = 0.f; }
 
-    const int fr = lane & 31, fh = lane >> 5, fsw = (fr >> 2) & 3;
+    const int fr = lane & 31, fh = lane >> 5, fsw = (fr >> 1) & 7;
     h8 a1[2], a2[2], b1[2][TN], b2[2][TN];
     auto lfrag = [&](int buf, auto ksc, auto setc) __attribute__((always_inline)) {
         constexpr int kk = decltype(ksc)::value, S = decltype(setc)::value;
-        const int slot = ((2 * kk + fh) ^ fsw) * 16;
+        const int ph = ((2 * kk + fh) ^ fsw) * 16, pl = ((4 + 2 * kk + fh) ^ fsw) * 16;
         const char *base = lds + buf * ST;
-        const int ra = (wm * 32 + fr) * 64 + slot;
-        a1[S] = *reinterpret_cast<const h8 *>(base + ra);
-        a2[S] = *reinterpret_cast<const h8 *>(base + PA + ra);
+        const int ra = (wm * 32 + fr) * 128;
+        a1[S] = *reinterpret_cast<const h8 *>(base + ra + ph);
+        a2[S] = *reinterpret_cast<const h8 *>(base + ra + pl);
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int rb = (j * 32 + fr) * 64 + slot;
-            b1[S][j] = *reinterpret_cast<const h8 *>(base + 2 * PA + rb);
-            b2[S][j] = *reinterpret_cast<const h8 *>(base + 2 * PA + PB + rb);
+            const int rb = PA + (j * 32 + fr) * 128;
+            b1[S][j] = *reinterpret_cast<const h8 *>(base + rb + ph);
+            b2[S][j] = *reinterpret_cast<const h8 *>(base + rb + pl);
         }
     };
     auto mma = [&](auto setc) __attribute__((always_inline)) {
@@ -1376,8 +1370,8 @@ __global__ __launch_bounds__(512) void gemm_h3x_kernel(const DevLaunch L) {
 // Per chunk: A planes 2 x 4 KB, W planes 2 x 8 KB; four buffers = 96 KB, one workgroup per CU.
 __global__ __launch_bounds__(256) void gemm_h3m_kernel(const DevLaunch L) {
     constexpr int TN = 2;
-    constexpr int PA = 64 * 64, PB = 128 * 64;          // bytes per A / W plane tile
-    constexpr int ST = 2 * PA + 2 * PB;                 // bytes per buffer
+    constexpr int PA = 64 * 128, PB = 128 * 128;        // bytes per A / W image (row = 128 B: 32 hi | 32 lo halfs)
+    constexpr int ST = PA + PB;                         // bytes per buffer
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char *lds = reinterpret_cast<char *>(smem);
 
@@ -1390,31 +1384,31 @@ __global__ __launch_bounds__(256) void gemm_h3m_kernel(const DevLaunch L) {
     const int M = P.M, N = P.N, Kp = P.Kp;
     const int row0 = tm * 64, col0 = tn * 128;
 
-    // staging pieces of 16 rows x 64 B: A planes one piece per wave (by K-segment, as in gemm_h3_kernel), W planes two
+    // staging pieces of 8 rows x 128 B (whole lines, see gemm_h3_kernel): A image two pieces per wave (by K-segment),
+    // W image four
     const _Float16 *src[6];
-    int arow, aq;
-    {
-        const int t = 16 * w + (lane >> 2);
-        const int q = (lane & 3) ^ ((t >> 2) & 3);
-        int ar = row0 + t;
-        arow = ar < M ? ar : M - 1;
-        aq = q * 8;
-    }
+    int arow[2], aq[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const int t = 16 * (2 * w + i) + (lane >> 2);
-        const int q = (lane & 3) ^ ((t >> 2) & 3);
+        const int t = 16 * w + 8 * i + (lane >> 3);
+        int ar = row0 + t;
+        arow[i] = ar < M ? ar : M - 1;
+        aq[i] = ((lane & 7) ^ ((t >> 1) & 7)) * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int t = 32 * w + 8 * i + (lane >> 3);
+        const int q = (lane & 7) ^ ((t >> 1) & 7);
         int c = col0 + t;
         c = c < N ? c : N - 1;
         src[2 + i] = P.Wh + (long long)c * 2 * Kp + q * 8;
-        src[4 + i] = P.Wl + (long long)c * 2 * Kp + q * 8;
     }
     int cs = 0, ck = 0, segK = 0;
     auto set_aseg = [&](int si) __attribute__((always_inline)) {
         const DevASeg a = P.ap[si];
         segK = a.K;
-        src[0] = a.hi + (long long)arow * a.ld + aq;
-        src[1] = a.lo + (long long)arow * a.ld + aq;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) src[i] = a.hi + (long long)arow[i] * a.ld + aq[i];
     };
     set_aseg(0);
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds);
@@ -1425,13 +1419,10 @@ __global__ __launch_bounds__(256) void gemm_h3m_kernel(const DevLaunch L) {
     };
     auto stage = [&](int buf) __attribute__((always_inline)) {
         const unsigned b = lds0 + buf * ST;
-        dma1(b + wv * 1024, src[0]);
-        dma1(b + PA + wv * 1024, src[1]);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            dma1(b + 2 * PA + (2 * wv + i) * 1024, src[2 + i]);
-            dma1(b + 2 * PA + PB + (2 * wv + i) * 1024, src[4 + i]);
-        }
+        for (int i = 0; i < 2; ++i) dma1(b + (2 * wv + i) * 1024, src[i]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dma1(b + PA + (4 * wv + i) * 1024, src[2 + i]);
         ck += 32;
         if (ck >= segK) {
             ck = 0;
@@ -1447,20 +1438,20 @@ __global__ __launch_bounds__(256) void gemm_h3m_kernel(const DevLaunch L) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc0[j][r] = 0.f; acc1[j][r] = 0.f; }
 
-    const int fr = lane & 31, fh = lane >> 5, fsw = (fr >> 2) & 3;
+    const int fr = lane & 31, fh = lane >> 5, fsw = (fr >> 1) & 7;
     h8 a1[2], a2[2], b1[2][TN], b2[2][TN];
     auto lfrag = [&](int buf, auto ksc, auto setc) __attribute__((always_inline)) {
         constexpr int kk = decltype(ksc)::value, S = decltype(setc)::value;
-        const int slot = ((2 * kk + fh) ^ fsw) * 16;
+        const int ph = ((2 * kk + fh) ^ fsw) * 16, pl = ((4 + 2 * kk + fh) ^ fsw) * 16;
         const char *base = lds + buf * ST;
-        const int ra = (wm * 32 + fr) * 64 + slot;
-        a1[S] = *reinterpret_cast<const h8 *>(base + ra);
-        a2[S] = *reinterpret_cast<const h8 *>(base + PA + ra);
+        const int ra = (wm * 32 + fr) * 128;
+        a1[S] = *reinterpret_cast<const h8 *>(base + ra + ph);
+        a2[S] = *reinterpret_cast<const h8 *>(base + ra + pl);
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int rb = (wn * 64 + j * 32 + fr) * 64 + slot;
-            b1[S][j] = *reinterpret_cast<const h8 *>(base + 2 * PA + rb);
-            b2[S][j] = *reinterpret_cast<const h8 *>(base + 2 * PA + PB + rb);
+            const int rb = PA + (wn * 64 + j * 32 + fr) * 128;
+            b1[S][j] = *reinterpret_cast<const h8 *>(base + rb + ph);
+            b2[S][j] = *reinterpret_cast<const h8 *>(base + rb + pl);
         }
     };
     auto mma = [&](auto setc) __attribute__((always_inline)) {
