@@ -145,6 +145,71 @@ def bench_xe_train(cap, dev, rank, world, iters=6, B=128):
                 grad_allreduce_mb=round(arena.nbytes / 1e6, 2) if arena else 0.0)
 
 
+def bench_small_batches(cap, dev, batches=(4, 128, 512)):
+    """Latency regime of the headline path: greedy roll-outs (prologue + 20 steps, no host sync inside) at few captions
+    per call.  ms_per_rollout: 10 roll-outs enqueued back to back (the headline's timing form); single_call_ms: one
+    call bracketed by synchronisation (median of 10), which also exposes the host's enqueue time."""
+    out = {}
+    with torch.no_grad(), no_gc():
+        for B in batches:
+            inputs, _ = device_inputs(B, 700 + B, dev)
+            for _ in range(3):
+                cap(*inputs, T, 1, mode='rl')
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                cap(*inputs, T, 1, mode='rl')
+            torch.cuda.synchronize()
+            loop = (time.perf_counter() - t0) / 10
+            ts = []
+            for i in range(10):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                cap(*inputs, T, 1, mode='rl')
+                torch.cuda.synchronize()
+                ts.append(time.perf_counter() - t0)
+            ts.sort()
+            out[str(B)] = dict(ms_per_rollout=round(loop * 1e3, 3), captions_per_s=round(B / loop, 1),
+                               single_call_ms=round(ts[len(ts) // 2] * 1e3, 3))
+    return out
+
+
+def bench_exact_fp32(cap, inputs, B, reps=3):
+    """The same B=4096 roll-out with the split-f16 engine off (isc_set_h3_mode(0)): every GEMM on the exact-fp32 MFMA
+    tiles (v_mfma_f32_32x32x2_f32, peak 157.3 TFLOP/s)."""
+    prev = ops.set_h3_mode(0)
+    try:
+        with torch.no_grad(), no_gc():
+            cap(*inputs, T, 1, mode='rl')
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                cap(*inputs, T, 1, mode='rl')
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+    finally:
+        ops.set_h3_mode(prev)
+    return dict(captions_per_s=round(B * reps / el, 1), ms_per_rollout=round(el / reps * 1e3, 2),
+                engine='v_mfma_f32_32x32x2_f32 only (--h3-mode 0)')
+
+
+def bench_table_build(cap, inputs):
+    """Cost of what the timed roll-outs amortise: the [V,4H] token table relu(Emb) W_x^T and the two [V,512] sentiment-
+    word tables are functions of the (frozen) weights, built by the first roll-out after a weight change and reused
+    by every later one; one-off, outside the timed region."""
+    with torch.no_grad(), no_gc():
+        cap._tab_cache = cap._senti_tab_cache = None
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        p = cap._p()
+        with ops.h3_weights_scope(cap._dev):
+            cap._embedding_table(p, build=True)
+            cap._senti_tables(p)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+    return dict(ms=round(el * 1e3, 2), gflop=round(2.0 * V * 512 * (2048 + 512) / 1e9, 1))
+
+
 def bench_scan_sweep(dev, batches=(128, 512, 1024, 2048, 4096)):
     """the attention scan's algorithmic GB/s at the config batch sizes as well as where its rows
     (B x 192 512 B for content + sentiment) exceed the 256 MB last-level cache.  Isolated kernel, HIP events."""
@@ -172,7 +237,7 @@ def bench_scan_sweep(dev, batches=(128, 512, 1024, 2048, 4096)):
     return out
 
 
-def bench_rl(dev, iters=3, B=512):
+def bench_rl(dev, iters=3, B=512, cache_image_sentiments=True):
     """BASELINE.json configs[4]: self-critical RL iteration (Detector.forward, training=True): sampled +
     greedy roll-out per image, CIDEr-D + classifier rewards, XE (ss 0.5) + seq2seq (ss 0.25) passes,
     backward, clamp, Adam; B=512, T=20, 6x6x2048 grid for the sentiment detector, 5 GT captions/image."""
@@ -181,6 +246,7 @@ def bench_rl(dev, iters=3, B=512):
     det = Detector(synth.make_idx2word(V), T, synth.SENTIMENT_CATEGORIES, {'cap_lr': 4e-5}, st)
     det.captioner.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_weights(V, st, seed=0).items()})
     det.to(dev)
+    det.cache_image_sentiments = cache_image_sentiments      # False: the frozen conv net runs on every image, every iteration
     batches, split = synth.make_rl_batches(1, B, V, st, grid=(6, 6), seq_len=T, seed=90)
     det.set_ciderd_scorer(split)
     tt = torch.from_numpy
@@ -213,7 +279,7 @@ def bench_rl(dev, iters=3, B=512):
     finally:
         dmod.get_self_critical_reward = orig
     return dict(iters=iters, batch=B, ms_per_iter=round(el / iters * 1e3, 1),
-                images_per_s=round(B * iters / el, 1),
+                images_per_s=round(B * iters / el, 1), image_sentiment_cache=bool(cache_image_sentiments),
                 cider_ms_per_iter=round(cider_t[0] / iters * 1e3, 1), cider_threads=det.ciderd_scorer.n_threads,
                 losses={k: round(float(v), 4) for k, v in losses.items()})
 
@@ -238,18 +304,36 @@ def bench_beam(cap, inputs, n_img=64, beam=5):
         cap.sample_batch(fc, att, sw, lab, beam, 1, T)
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
+        # the same search forced through all T steps: with random-init weights captions end early, a trained model's
+        # often do not.  No candidate can end when <EOS> is an id the vocabulary does not contain.
+        eos, full = cap.eos_id, []
+        cap.eos_id = -7
+        try:
+            cap.sample(fc[0], att[0], sw[0], lab[0:1], beam, 1, T)
+            for i in range(16):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                cap.sample(fc[i], att[i], sw[i], lab[i:i + 1], beam, 1, T)
+                torch.cuda.synchronize()
+                full.append(time.perf_counter() - t0)
+                assert cap.last_beam_steps == T
+        finally:
+            cap.eos_id = eos
     lat.sort()
     per_step.sort()
+    full.sort()
     # latency is bimodal with random-init weights: captions either end after ~9 steps or run all T=20;
     # per_step_p50_us (latency / executed decode steps) is the number to compare between runs
     return dict(beam=beam, per_image_p50_ms=round(lat[len(lat) // 2] * 1e3, 2),
                 per_image_p95_ms=round(lat[int(len(lat) * 0.95) - 1] * 1e3, 2),
                 per_image_min_ms=round(lat[0] * 1e3, 2), per_image_max_ms=round(lat[-1] * 1e3, 2),
                 per_step_p50_us=round(per_step[len(per_step) // 2] * 1e6, 1),
+                full_search_steps=T, full_search_p50_ms=round(full[len(full) // 2] * 1e3, 2),
+                full_search_p95_ms=round(full[int(len(full) * 0.95) - 1] * 1e3, 2),
                 batched_images=n_img, batched_images_per_s=round(n_img / el, 1))
 
 
-PMC_SUMMARY = os.path.join(ROOT, 'profiles', 'r01_j_pmc_summary_B4096.json')
+PMC_SUMMARY = os.path.join(ROOT, 'profiles', 'r02_a_pmc_summary_B4096.json')
 # bench kernel label -> device symbols it may run as (first one present in the PMC summary wins)
 KERNEL_SYMBOL = {'vocab[': ['void gemm_h3_kernel<2>', 'void gemm_ld_kernel<2>', 'void gemm_kernel<4, 1, 4, 2, false, false>'],
                  'lstm[4096x2048x1536': ['void gemm_h3x_kernel<1>', 'void gemm_h3_kernel<1>', 'void gemm_xl_kernel<1>'],
@@ -274,6 +358,26 @@ def pmc_traffic(name, batch):
                     if sym in ('void gemm_h3_kernel<1>', 'void gemm_h3x_kernel<1>'):   # both LSTM cells: no per-shape figure
                         return None
                     return d['kernels'][sym]['traffic_bytes']
+    return None
+
+
+def pmc_counters(name, batch):
+    """Matrix-pipe counters of the kernel behind a bench label, from the same committed PMC summary (separate
+    rocprofv3 --pmc passes, tools/profile_round.sh): mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x
+    GRBM_GUI_ACTIVE / 8), the clock the chip held, the L2 hit rate.  Per symbol (both LSTM cells share one)."""
+    try:
+        d = json.load(open(PMC_SUMMARY))
+    except (OSError, ValueError):
+        return None
+    if d.get('batch_per_gpu') != batch:
+        return None
+    for prefix, syms in KERNEL_SYMBOL.items():
+        if name.startswith(prefix):
+            for sym in syms:
+                k = d['kernels'].get(sym)
+                if k and 'mfma_util' in k:
+                    return {'symbol': sym, 'mfma_util': k['mfma_util'], 'clock_ghz': k.get('clock_ghz'),
+                            'l2_hit': k.get('l2_hit'), 'source': os.path.basename(PMC_SUMMARY)}
     return None
 
 
@@ -367,23 +471,26 @@ def run(args):
     extra = {}
     if not args.no_extras:
         # secondary measurements (never part of `value`); failures are reported, not fatal
+        if world == 1:
+            # measurements on the headline's own weights first; the training benches (which update them) last
+            for key, fn in (('exact_fp32_engine', lambda: bench_exact_fp32(cap, inputs, B)),
+                            ('greedy_small_batches', lambda: bench_small_batches(cap, dev)),
+                            ('beam5', lambda: bench_beam(cap, inputs)),
+                            ('scan_sweep', lambda: bench_scan_sweep(dev)),
+                            ('table_build', lambda: bench_table_build(cap, inputs)),
+                            ('rl_iteration', lambda: bench_rl(dev)),
+                            ('rl_iteration_cold_sentiment_cache', lambda: bench_rl(dev, cache_image_sentiments=False))):
+                try:
+                    extra[key] = fn()
+                except Exception as e:  # noqa: BLE001 - side measurements are reported, never fatal
+                    extra[key] = {'error': repr(e)[:300]}
         try:
             extra['xe_train'] = bench_xe_train(cap, dev, rank, world)
+            if world == 1:
+                extra['xe_train_by_batch'] = {str(b): bench_xe_train(cap, dev, rank, world, iters=3, B=b)['ms_per_iter']
+                                              for b in (512, 1024)}
         except Exception as e:  # noqa: BLE001
             extra['xe_train'] = {'error': repr(e)[:200]}
-        if world == 1:
-            try:
-                extra['beam5'] = bench_beam(cap, inputs)
-            except Exception as e:  # noqa: BLE001
-                extra['beam5'] = {'error': repr(e)[:200]}
-            try:
-                extra['scan_sweep'] = bench_scan_sweep(dev)
-            except Exception as e:      # noqa: BLE001 - side measurement only
-                extra['scan_sweep'] = {'error': repr(e)}
-            try:
-                extra['rl_iteration'] = bench_rl(dev)
-            except Exception as e:  # noqa: BLE001
-                extra['rl_iteration'] = {'error': repr(e)[:300]}
     if rank != 0:
         torch.distributed.destroy_process_group()
         return None
@@ -395,6 +502,9 @@ def run(args):
     for name, rec in summ.items():
         e = roofline_entry(name, rec)
         e['traffic'] = pmc_traffic(name, B)
+        pc = pmc_counters(name, B)
+        if pc:
+            e['pmc'] = pc
         e['algorithmic'] = rec['flops'] if rec['flops'] > 0 else rec['bytes']
         e['phase'] = rec['phase']
         e['per_rollout_ms'] = round(rec['avg_ms'] * (1 if rec['phase'] == 'prologue' else T), 3)
@@ -409,7 +519,10 @@ def run(args):
         'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': 'greedy decode forward_rl(sample_max=1): B=%d captions/GPU/step, R=%d '
                                'regions x 2048, V=%d, T=%d, sentiment-word attention + gate on, '
-                               'prologue included, random-init reference-architecture weights' % (B, R, V, T),
+                               'prologue included, random-init reference-architecture weights; the weight-only '
+                               'tables (relu(Emb) W_x^T [V,4H], sentiment-word tables 2 x [V,512]; 26 GFLOP) and '
+                               'the f16 weight planes are built by the first roll-out after a weight change, i.e. '
+                               'in warm-up, and reused by the timed ones (extra.table_build)' % (B, R, V, T),
                    'batch_per_gpu': B, 'parallelism': 'dp%d (batch shard, no collective)' % world,
                    'gemm_engine': {1: 'split-f16 x3 MFMA for large forward GEMMs (fp32 in/out/accumulate), fp32 MFMA elsewhere',
                                    0: 'fp32 MFMA only (--h3-mode 0)', 2: 'split-f16 forced'}[args.h3_mode]},

@@ -1,15 +1,25 @@
+# One round's profile set for profiles/: kernel-trace statistics, HBM-side traffic (FETCH_SIZE / WRITE_SIZE in separate
+# passes) and matrix-pipe counters of the default bench.py workload (B = 4096 greedy roll-out).
+#   usage (on the GPU box):  bash tools/profile_round.sh r02_a
+# rocprofv3 gets the program directly after `--` (no env / shell hop: the profiler has initialised the GPU by then).
 set -e
 R=$GRAFT_REPO_ROOT
+TAG=${1:-r02}
+O=$R/gpurun_out/prof_$TAG
+rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-rm -rf $R/gpurun_out/prof_stats $R/gpurun_out/prof_fetch $R/gpurun_out/prof_write
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_stats -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $R/gpurun_out/prof_stats.log 2>&1
-python3 $R/tools/h3_op_breakdown.py $R/gpurun_out/prof_stats > $R/gpurun_out/h3_op_breakdown.json
+ARGS="--no-cpu-baseline --no-extras"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 3 --warmup 1 $ARGS > $O/stats.log 2>&1
+python3 $R/tools/h3_op_breakdown.py $O/stats > $O/h3_op_breakdown.json || true
 echo stats done
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/prof_fetch -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras > $R/gpurun_out/prof_fetch.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 $R/bench.py --steps 2 --warmup 1 $ARGS > $O/fetch.log 2>&1
 echo fetch done
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/prof_write -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras > $R/gpurun_out/prof_write.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- python3 $R/bench.py --steps 2 --warmup 1 $ARGS > $O/write.log 2>&1
 echo write done
-python3 $R/tools/pmc_summary.py $R/gpurun_out/prof_fetch $R/gpurun_out/prof_write 4096 > $R/gpurun_out/pmc_summary.json
-cp $R/gpurun_out/pmc_summary.json $R/profiles/r01_j_pmc_summary_B4096.json
-cd $R && python3 bench.py > gpurun_out/bench.json 2> gpurun_out/bench.err
+timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_VALU_MFMA_MOPS_F32 --output-format csv -d $O/mfma -- python3 $R/bench.py --steps 2 --warmup 1 $ARGS > $O/mfma.log 2>&1
+echo mfma done
+timeout -k 10 300 rocprofv3 --pmc GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/clk -- python3 $R/bench.py --steps 2 --warmup 1 $ARGS > $O/clk.log 2>&1 || echo clk pass failed
+echo clk done
+python3 $R/tools/pmc_summary.py $O/fetch $O/write 4096 $O/mfma $O/clk $O/stats > $O/pmc_summary.json
+cd $R && python3 bench.py > $O/bench.json 2> $O/bench.err
 echo bench done
