@@ -233,23 +233,26 @@ def _backward(cap, S, dlogp, d_fc_feats, d_cpt_feats):
         bp.dv, bp.ds = dv.data_ptr(), ds.data_ptr()
         bp.dwg_rows, bp.dbg_rows = dwg_rows.data_ptr(), dbg_rows.data_ptr()
         bp.beta_ld = S.bG.stride(0)
-    for t in range(T - 1, -1, -1):
-        cur, nxt = t & 1, (t + 1) & 1
-        bp.first, bp.last = int(t == T - 1), int(t == 0)
-        bp.g1, bp.c1_prev, bp.c1 = S.g1[t].data_ptr(), S.c1[t].data_ptr(), S.c1[t + 1].data_ptr()
-        bp.g2, bp.c2_prev, bp.c2 = S.g2[t].data_ptr(), S.c2[t].data_ptr(), S.c2[t + 1].data_ptr()
-        bp.dhd, bp.dG1, bp.dG2 = dhd[t].data_ptr(), dG1[t].data_ptr(), dG2[t].data_ptr()
-        bp.dc1_in, bp.dc1_out = dc1_rec[nxt].data_ptr(), dc1_rec[cur].data_ptr()
-        bp.dc2_in, bp.dc2_out = dc2_rec[nxt].data_ptr(), dc2_rec[cur].data_ptr()
-        if has_c:
-            bp.qa, bp.v, bp.alpha_c, bp.dqa = S.qa[t].data_ptr(), S.v[t].data_ptr(), S.aC[:, t].data_ptr(), \
-                dqa[t].data_ptr()
-        if has_s:
-            bp.qw, bp.s, bp.alpha_s, bp.dqw = S.qw[t].data_ptr(), S.s[t].data_ptr(), S.aS[:, t].data_ptr(), \
-                dqw[t].data_ptr()
-        if gate:
-            bp.z, bp.beta, bp.dz = S.z[t].data_ptr(), S.bG[:, t:t + 1].data_ptr(), dz[t].data_ptr()
-        ops.step_bwd(bp)
+    # the weights do not change during the sweep: few-row launches take the one-launch skinny split-f16 kernel on
+    # planes of W^T built once here (isc_gemm_bwd, NN layout), instead of fp32 split-K slabs + a reduce kernel per GEMM
+    with ops.h3_weights_scope(cap._dev):
+        for t in range(T - 1, -1, -1):
+            cur, nxt = t & 1, (t + 1) & 1
+            bp.first, bp.last = int(t == T - 1), int(t == 0)
+            bp.g1, bp.c1_prev, bp.c1 = S.g1[t].data_ptr(), S.c1[t].data_ptr(), S.c1[t + 1].data_ptr()
+            bp.g2, bp.c2_prev, bp.c2 = S.g2[t].data_ptr(), S.c2[t].data_ptr(), S.c2[t + 1].data_ptr()
+            bp.dhd, bp.dG1, bp.dG2 = dhd[t].data_ptr(), dG1[t].data_ptr(), dG2[t].data_ptr()
+            bp.dc1_in, bp.dc1_out = dc1_rec[nxt].data_ptr(), dc1_rec[cur].data_ptr()
+            bp.dc2_in, bp.dc2_out = dc2_rec[nxt].data_ptr(), dc2_rec[cur].data_ptr()
+            if has_c:
+                bp.qa, bp.v, bp.alpha_c, bp.dqa = S.qa[t].data_ptr(), S.v[t].data_ptr(), S.aC[:, t].data_ptr(), \
+                    dqa[t].data_ptr()
+            if has_s:
+                bp.qw, bp.s, bp.alpha_s, bp.dqw = S.qw[t].data_ptr(), S.s[t].data_ptr(), S.aS[:, t].data_ptr(), \
+                    dqw[t].data_ptr()
+            if gate:
+                bp.z, bp.beta, bp.dz = S.z[t].data_ptr(), S.bG[:, t:t + 1].data_ptr(), dz[t].data_ptr()
+            ops.step_bwd(bp)
 
     # ---- weight gradients: one contraction over all T*B rows each
     dG1f, dG2f = dG1.view(TB, 4 * H), dG2.view(TB, 4 * H)

@@ -1505,6 +1505,7 @@ struct SplitJob {
     int kstart[ISC_MAX_SEG];
     int nseg, rows, Kp, first_block;
     _Float16 *hi, *lo;
+    int transposed, _pad;             // source segments are [K_s, rows] (k-major): planes of the TRANSPOSE are built
 };
 #define H3_MAX_JOBS 12
 struct SplitLaunch {
@@ -1521,6 +1522,29 @@ __global__ __launch_bounds__(256) void h3_split_kernel(const SplitLaunch S) {
     const int k8n = J.Kp >> 3;
     const long long idx = (long long)(blockIdx.x - J.first_block) * 256 + threadIdx.x;
     if (idx >= (long long)J.rows * k8n) return;
+    if (J.transposed) {
+        // backward-pass weights: segment s is W_s [K_s, rows] as stored (dX = dY * W contracts over W's rows); plane row n
+        // = column n of the source.  Neighbouring threads take neighbouring n: the strided reads coalesce across them.
+        const int n = (int)(idx % J.rows);
+        const int kq = (int)(idx / J.rows) * 8;
+        const float *sp = J.src[0];
+        int ld = J.ld[0], k0 = 0;
+#pragma unroll
+        for (int sg = 1; sg < ISC_MAX_SEG; ++sg)
+            if (sg < J.nseg && kq >= J.kstart[sg]) { sp = J.src[sg]; ld = J.ld[sg]; k0 = J.kstart[sg]; }
+        h8 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float x = sp[(long long)(kq - k0 + e) * ld + n];
+            const _Float16 h = (_Float16)x;
+            hi[e] = h;
+            lo[e] = (_Float16)((x - (float)h) * 2048.f);
+        }
+        const long long o = plane_index(n, kq, J.Kp);
+        *reinterpret_cast<h8 *>(J.hi + o) = hi;
+        *reinterpret_cast<h8 *>(J.lo + o) = lo;
+        return;
+    }
     const int row = (int)(idx / k8n);
     int k = (int)(idx - (long long)row * k8n) * 8;
     const long long o = plane_index(row, k, J.Kp);        // 8 consecutive k never leave their 32-block
@@ -2216,17 +2240,18 @@ static int h3_kp(const DevProb &p) {
 // per step.  Host-side table, valid on the stream order of the launches that filled it.
 struct H3WEntry {
     const float *W[ISC_MAX_SEG];
-    int ldw[ISC_MAX_SEG], K[ISC_MAX_SEG], nseg, rows;
+    int ldw[ISC_MAX_SEG], K[ISC_MAX_SEG], nseg, rows, transposed;
     const _Float16 *hi, *lo;
 };
 // One scope per stream (isc_h3_weights_begin(buf, bytes, stream)): the slot table is guarded by a mutex, a slot's
 // entries are only touched by launches on its own stream (which the caller issues in one order, like the launches
 // themselves), so two host threads driving two captioners on two streams never see each other's planes.
+#define H3W_MAX_ENTRIES 40
 struct H3WScope {
     hipStream_t stream = nullptr;
     char *buf = nullptr;
     size_t bytes = 0, used = 0;
-    H3WEntry e[24];
+    H3WEntry e[H3W_MAX_ENTRIES];
     int n = 0;
     bool active = false;
 };
@@ -2283,11 +2308,11 @@ extern "C" int isc_h3_weights_resume(void *buf, void *stream) {
     return ISC_E_STATE;
 }
 
-static const H3WEntry *h3w_find(const H3WScope *sc, const DevProb &p) {
+static const H3WEntry *h3w_find(const H3WScope *sc, const DevProb &p, int transposed = 0) {
     if (!sc) return nullptr;
     for (int i = 0; i < sc->n; ++i) {
         const H3WEntry &e = sc->e[i];
-        bool eq = e.nseg == p.nseg && e.rows == p.N;
+        bool eq = e.nseg == p.nseg && e.rows == p.N && e.transposed == transposed;
         for (int s = 0; eq && s < p.nseg; ++s)
             eq = e.W[s] == p.seg[s].W && e.ldw[s] == p.seg[s].ldw && e.K[s] == p.seg[s].K;
         if (eq) return &e;
@@ -2350,9 +2375,11 @@ struct H3Planner {
     H3WScope *scope;                                   // the launch stream's weights scope, or null
     explicit H3Planner(float *ws, H3WScope *sc = nullptr) : at(reinterpret_cast<char *>(ws)), scope(sc) {}
     // planes of segments [s0, s1) of an operand, K-packed
-    void add(const DevProb &p, bool is_w, int rows, const _Float16 *&hi, const _Float16 *&lo, int s0 = 0, int s1 = -1) {
+    void add(const DevProb &p, bool is_w, int rows, const _Float16 *&hi, const _Float16 *&lo, int s0 = 0, int s1 = -1,
+             int transposed = 0) {
         if (s1 < 0) s1 = p.nseg;
         SplitJob &J = S.j[S.njobs++];
+        J.transposed = transposed;
         int k0 = 0;
         for (int s = s0; s < s1; ++s) {
             J.src[s - s0] = is_w ? p.seg[s].W : p.seg[s].A;
@@ -2391,21 +2418,21 @@ struct H3Planner {
         }
     }
     // weight operand: cached planes if the caller opened a weights scope, else planes in the workspace
-    void add_w(const DevProb &p, const _Float16 *&hi, const _Float16 *&lo) {
-        if (const H3WEntry *e = h3w_find(scope, p)) { hi = e->hi; lo = e->lo; return; }
+    void add_w(const DevProb &p, const _Float16 *&hi, const _Float16 *&lo, int transposed = 0) {
+        if (const H3WEntry *e = h3w_find(scope, p, transposed)) { hi = e->hi; lo = e->lo; return; }
         const size_t bytes = (((size_t)p.N * h3_kp(p) * 4) + 255) & ~(size_t)255;
-        if (scope && scope->n < 24 && scope->used + bytes <= scope->bytes) {
+        if (scope && scope->n < H3W_MAX_ENTRIES && scope->used + bytes <= scope->bytes) {
             char *keep = at;
             at = scope->buf + scope->used;
-            add(p, true, p.N, hi, lo);
+            add(p, true, p.N, hi, lo, 0, -1, transposed);
             at = keep;
             scope->used += bytes;
             H3WEntry &e = scope->e[scope->n++];
-            e.nseg = p.nseg; e.rows = p.N; e.hi = hi; e.lo = lo;
+            e.nseg = p.nseg; e.rows = p.N; e.hi = hi; e.lo = lo; e.transposed = transposed;
             for (int s = 0; s < p.nseg; ++s) { e.W[s] = p.seg[s].W; e.ldw[s] = p.seg[s].ldw; e.K[s] = p.seg[s].K; }
             return;
         }
-        add(p, true, p.N, hi, lo);
+        add(p, true, p.N, hi, lo, 0, -1, transposed);
     }
     int launch(hipStream_t st) {
         if (!S.njobs) return ISC_OK;
@@ -2525,6 +2552,7 @@ static int try_h3(DevLaunch &L, float *ws, long long ws_floats, hipStream_t st, 
 static std::atomic<long long> g_h3s_launches{0};
 extern "C" long long isc_h3s_launches(void) { return g_h3s_launches.load(); }
 #define H3S_MAX_ROWS 2048
+#define H3S_MAX_ROWS_NN 512     // dX = dY * W: beyond this the fp32 tiles' contraction rate wins over the 32-row tiles' ingest
 
 template <int EPI>
 static int launch_h3s(const DevLaunch &L, hipStream_t st) {
@@ -2546,7 +2574,7 @@ static int launch_h3s(const DevLaunch &L, hipStream_t st) {
 // more rows than H3S_MAX_ROWS, or a launch the large split-f16 kernels take (>= H3_MIN_TILES 128 x 128 tiles).
 // Mode 3 forces it (tests): without a scope the weight planes then go to the workspace.
 template <int EPI>
-static int try_h3s(DevLaunch &L, float *ws, long long ws_floats, hipStream_t st, int &rc) {
+static int try_h3s(DevLaunch &L, float *ws, long long ws_floats, hipStream_t st, int &rc, int transposed = 0) {
     const int mode = g_h3_mode.load();
     if ((mode != 1 && mode != 3) || g_tile_override.load() >= 0) return 0;
     H3WScope *sc = h3w_scope_of(st);
@@ -2554,8 +2582,10 @@ static int try_h3s(DevLaunch &L, float *ws, long long ws_floats, hipStream_t st,
     long long tiles = 0, need = 0;
     for (int i = 0; i < L.nprob; ++i) {
         const DevProb &p = L.p[i];
-        if (p.M > H3S_MAX_ROWS) return 0;
+        if (p.M > (transposed ? H3S_MAX_ROWS_NN : H3S_MAX_ROWS)) return 0;
         if (EPI == EPI_LSTM && (p.H & 7)) return 0;
+        for (int sg = 0; sg < p.nseg; ++sg)
+            if (p.seg[sg].K & 31) return 0;                 // (the backward entry point accepts other K)
         const long long Kp = h3_kp(p);
         if (Kp > (1 << 20)) return 0;
         tiles += (long long)((p.M + 127) / 128) * ((p.N + 127) / 128);
@@ -2583,7 +2613,7 @@ static int try_h3s(DevLaunch &L, float *ws, long long ws_floats, hipStream_t st,
             p.ap[s] = DevASeg{planes ? p.seg[s].A_hi : nullptr, planes ? p.seg[s].A_lo : nullptr, 2 * p.seg[s].K,
                               p.seg[s].K};
         }
-        pl.add_w(p, p.Wh, p.Wl);
+        pl.add_w(p, p.Wh, p.Wl, transposed);
         p.ksplit = 1;
         p.tiles_m = (p.M + 31) / 32;
         p.tiles_n = (p.N + BN - 1) / BN;
@@ -2697,6 +2727,10 @@ extern "C" int isc_gemm_bwd(const isc_linear_problem *pr, int n_prob, int layout
         d.M = q.M; d.N = q.N; d.relu = 0;
         d.bias0 = q.bias0; d.bias1 = q.bias1; d.bias2 = q.bias2;
         d.ldc = q.ldc; d.C = q.C; d.accumulate = q.accumulate;
+    }
+    if (layout == ISC_LAYOUT_NN) {     // few rows inside a weights scope: skinny split-f16 tiles on planes of W^T
+        int rc = ISC_OK;
+        if (try_h3s<EPI_LINEAR>(L, pr[0].splitk_ws, pr[0].splitk_ws_floats, (hipStream_t)stream, rc, 1)) return rc;
     }
     const int S = plan_splitk(L, pr[0].splitk_ws, pr[0].splitk_ws_floats);
     const int tile = S > 1 ? 2 : pick_tile(L, false, false);

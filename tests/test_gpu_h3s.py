@@ -194,3 +194,35 @@ def test_auto_mode_takes_the_skinny_kernel_only_inside_a_weights_scope():
     with ops.h3_weights_scope(dev()):
         assert torch.equal(run(), plain)                   # mode 0: exact-fp32 tiles only
     assert _launches() == n0 + 2
+
+
+@pytest.mark.parametrize('M,N,K1,K2', [(128, 512, 2048, 0), (80, 1024, 512, 512), (5, 96, 64, 0), (300, 512, 2048, 0)])
+def test_backward_nn_contraction_on_the_skinny_kernel(M, N, K1, K2):
+    """isc_gemm_bwd, NN layout (dX = dY W, W as stored [K, N]): inside a weights scope the few-row launches run on the
+    skinny kernel over planes of W^T built by the transposing split; accumulate and K-segments included."""
+    g = torch.Generator().manual_seed(M + N + K1)
+    dy1, w1 = _rand(g, M, K1), _rand(g, K1, N + 64, scale=K1 ** -0.5)     # W is a column slice of a wider matrix
+    prior = _rand(g, M, N)
+    ref = prior.double() + dy1.double() @ w1.double()[:, 32:32 + N]
+    segs = [(dy1.to(dev()), w1.to(dev())[:, 32:32 + N])]
+    if K2:
+        dy2, w2 = _rand(g, M, K2), _rand(g, K2, N, scale=K2 ** -0.5)
+        ref = ref + dy2.double() @ w2.double()
+        segs.append((dy2.to(dev()), w2.to(dev())))
+    outs = {}
+    for mode in (3, 0):
+        ops.set_h3_mode(mode)
+        n0 = _launches()
+        out = prior.clone().to(dev())
+        with ops.h3_weights_scope(dev()):
+            ops.gemm_bwd([ops.gemm_problem(segs, out, ops.NN, accumulate=True)], ops.NN)
+            ops.gemm_bwd([ops.gemm_problem(segs, out, ops.NN, accumulate=False)], ops.NN)      # planes re-used
+            again = out.clone()
+            out.copy_(prior)
+            ops.gemm_bwd([ops.gemm_problem(segs, out, ops.NN, accumulate=True)], ops.NN)
+        torch.cuda.synchronize()
+        assert _launches() - n0 == (3 if mode == 3 else 0)
+        np.testing.assert_allclose(out.cpu().numpy(), ref.float().numpy(), atol=3e-5, rtol=1e-5)
+        np.testing.assert_allclose(again.cpu().numpy(), (ref - prior.double()).float().numpy(), atol=3e-5, rtol=1e-5)
+        outs[mode] = (out.double().cpu() - ref).pow(2).mean().sqrt().item()
+    assert outs[3] <= outs[0] * 1.05 + 1e-9, outs
