@@ -1092,7 +1092,24 @@ __global__ __launch_bounds__(256) void gemm_ld_kernel(const DevLaunch L) {
 // k-octet q = s ^ ((r >> 2) & 3), which makes the ds_read_b128 fragment reads conflict-free.
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 
-template <int EPI>
+// A-operand fragment from an fp32 image row (32 floats = 8 chunks of 16 B, chunk c at position c ^ sw): the 8 values of
+// k-octet `oct` (chunks 2*oct, 2*oct+1) split into their hi / lo halfs in registers - what h3_split_kernel would have
+// written, bit for bit.
+__device__ __forceinline__ void h3_frag_from_f32(const char *row, int oct, int sw, h8 &hi, h8 &lo) {
+    const float4 v0 = *reinterpret_cast<const float4 *>(row + (((2 * oct) ^ sw) * 16));
+    const float4 v1 = *reinterpret_cast<const float4 *>(row + (((2 * oct + 1) ^ sw) * 16));
+    const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const _Float16 h = (_Float16)x[e];
+        hi[e] = h;
+        lo[e] = (_Float16)((x[e] - (float)h) * 2048.f);
+    }
+}
+
+// AF32: some activation segment comes as fp32 rows (split after the fragment read); false = every segment has planes,
+// and the per-buffer test is compiled out of the fragment loads (it cost the all-planes decode loop ~5-10 %).
+template <int EPI, bool AF32>
 __global__ __launch_bounds__(256, 2) void gemm_h3_kernel(const DevLaunch L) {
     constexpr int BM = 128, BN = 128, TN = 4;
     constexpr int PA = 128 * 128, PB = 128 * 128;       // bytes per A / W image (row = 128 B: 32 hi | 32 lo halfs)
@@ -1134,15 +1151,21 @@ __global__ __launch_bounds__(256, 2) void gemm_h3_kernel(const DevLaunch L) {
         src[4 + i] = P.Wh + wr * 2 * Kp + q * 8;
     }
     int cs = 0, ck = 0, segK = 0;
+    bool seg_f32 = false;                // the segment has no planes: its fp32 rows are staged (128 B per row and chunk,
+    unsigned f32_bufs = 0;               // like a plane row) and split after the fragment read; bit b: buffer b holds fp32
     auto set_aseg = [&](int si) __attribute__((always_inline)) {
         const DevASeg a = P.ap[si];
         segK = a.K;
+        seg_f32 = AF32 && a.hi == nullptr;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) src[i] = a.hi + (long long)arow[i] * a.ld + aq[i];
+        for (int i = 0; i < 4; ++i)
+            src[i] = seg_f32 ? reinterpret_cast<const _Float16 *>(P.seg[si].A + (long long)arow[i] * P.seg[si].lda) + aq[i]
+                             : a.hi + (long long)arow[i] * a.ld + aq[i];
     };
     set_aseg(0);
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds + wm * 4096);
     auto stage = [&](int buf) __attribute__((always_inline)) {
+        f32_bufs = (f32_bufs & ~(1u << buf)) | ((seg_f32 ? 1u : 0u) << buf);
 #pragma unroll
         for (int p = 0; p < 2; ++p)
 #pragma unroll
@@ -1173,8 +1196,12 @@ __global__ __launch_bounds__(256, 2) void gemm_h3_kernel(const DevLaunch L) {
         const int ph = ((2 * kk + fh) ^ fsw) * 16, pl = ((4 + 2 * kk + fh) ^ fsw) * 16;
         const char *base = lds + buf * ST;
         const int ra = (wm * 32 + fr) * 128;
-        a1[S] = *reinterpret_cast<const h8 *>(base + ra + ph);
-        a2[S] = *reinterpret_cast<const h8 *>(base + ra + pl);
+        if (AF32 && ((f32_bufs >> buf) & 1u)) {
+            h3_frag_from_f32(base + ra, 2 * kk + fh, fsw, a1[S], a2[S]);
+        } else {
+            a1[S] = *reinterpret_cast<const h8 *>(base + ra + ph);
+            a2[S] = *reinterpret_cast<const h8 *>(base + ra + pl);
+        }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int rb = PA + (j * 32 + fr) * 128;
@@ -1227,7 +1254,7 @@ __global__ __launch_bounds__(256, 2) void gemm_h3_kernel(const DevLaunch L) {
 // one workgroup per CU keeps two chunks of DMA in flight (96 KB against the 64 KB of two 128-row workgroups with one
 // chunk each) - these launches are bound by the DMA round trip, not by the matrix pipe: [4096 x 9984 x 512] 178 -> 137 us,
 // [4096 x 2048 x 1536] 97 -> 76 us (tools/h3_gemm_lab.hip).  Used when the launch has >= 224 such tiles.
-template <int EPI>
+template <int EPI, bool AF32>
 __global__ __launch_bounds__(512) void gemm_h3x_kernel(const DevLaunch L) {
     constexpr int BM = 256, BN = 128, TN = 4;
     constexpr int PA = 256 * 128, PB = 128 * 128;       // bytes per A / W image (row = 128 B: 32 hi | 32 lo halfs)
@@ -1269,11 +1296,16 @@ __global__ __launch_bounds__(512) void gemm_h3x_kernel(const DevLaunch L) {
         src[4 + i] = P.Wh + wr * 2 * Kp + q * 8;
     }
     int cs = 0, ck = 0, segK = 0;
+    bool seg_f32 = false;                // the segment has no planes: its fp32 rows are staged (128 B per row and chunk,
+    unsigned f32_bufs = 0;               // like a plane row) and split after the fragment read; bit b: buffer b holds fp32
     auto set_aseg = [&](int si) __attribute__((always_inline)) {
         const DevASeg a = P.ap[si];
         segK = a.K;
+        seg_f32 = AF32 && a.hi == nullptr;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) src[i] = a.hi + (long long)arow[i] * a.ld + aq[i];
+        for (int i = 0; i < 4; ++i)
+            src[i] = seg_f32 ? reinterpret_cast<const _Float16 *>(P.seg[si].A + (long long)arow[i] * P.seg[si].lda) + aq[i]
+                             : a.hi + (long long)arow[i] * a.ld + aq[i];
     };
     set_aseg(0);
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds);
@@ -1284,6 +1316,7 @@ __global__ __launch_bounds__(512) void gemm_h3x_kernel(const DevLaunch L) {
     };
     auto stage = [&](int buf) __attribute__((always_inline)) {
         const unsigned b = lds0 + buf * ST;
+        f32_bufs = (f32_bufs & ~(1u << buf)) | ((seg_f32 ? 1u : 0u) << buf);
 #pragma unroll
         for (int i = 0; i < 4; ++i) dma1(b + (4 * wv + i) * 1024, src[i]);
 #pragma unroll
@@ -1310,8 +1343,12 @@ __global__ __launch_bounds__(512) void gemm_h3x_kernel(const DevLaunch L) {
         const int ph = ((2 * kk + fh) ^ fsw) * 16, pl = ((4 + 2 * kk + fh) ^ fsw) * 16;
         const char *base = lds + buf * ST;
         const int ra = (wm * 32 + fr) * 128;
-        a1[S] = *reinterpret_cast<const h8 *>(base + ra + ph);
-        a2[S] = *reinterpret_cast<const h8 *>(base + ra + pl);
+        if (AF32 && ((f32_bufs >> buf) & 1u)) {
+            h3_frag_from_f32(base + ra, 2 * kk + fh, fsw, a1[S], a2[S]);
+        } else {
+            a1[S] = *reinterpret_cast<const h8 *>(base + ra + ph);
+            a2[S] = *reinterpret_cast<const h8 *>(base + ra + pl);
+        }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int rb = PA + (j * 32 + fr) * 128;
@@ -1368,6 +1405,7 @@ __global__ __launch_bounds__(512) void gemm_h3x_kernel(const DevLaunch L) {
 // H3 on the 64 x 128 geometry (2 x 2 waves, 32 x 64 accumulators each; linear epilogue): launches whose 128-row
 // tiling would leave CUs idle - the per-step projections with N = 512 at 4096 rows are 256 tiles of 64 x 128.
 // Per chunk: A planes 2 x 4 KB, W planes 2 x 8 KB; four buffers = 96 KB, one workgroup per CU.
+template <bool AF32>
 __global__ __launch_bounds__(256) void gemm_h3m_kernel(const DevLaunch L) {
     constexpr int TN = 2;
     constexpr int PA = 64 * 128, PB = 128 * 128;        // bytes per A / W image (row = 128 B: 32 hi | 32 lo halfs)
@@ -1404,11 +1442,16 @@ __global__ __launch_bounds__(256) void gemm_h3m_kernel(const DevLaunch L) {
         src[2 + i] = P.Wh + (long long)c * 2 * Kp + q * 8;
     }
     int cs = 0, ck = 0, segK = 0;
+    bool seg_f32 = false;                // see gemm_h3_kernel
+    unsigned f32_bufs = 0;
     auto set_aseg = [&](int si) __attribute__((always_inline)) {
         const DevASeg a = P.ap[si];
         segK = a.K;
+        seg_f32 = AF32 && a.hi == nullptr;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) src[i] = a.hi + (long long)arow[i] * a.ld + aq[i];
+        for (int i = 0; i < 2; ++i)
+            src[i] = seg_f32 ? reinterpret_cast<const _Float16 *>(P.seg[si].A + (long long)arow[i] * P.seg[si].lda) + aq[i]
+                             : a.hi + (long long)arow[i] * a.ld + aq[i];
     };
     set_aseg(0);
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds);
@@ -1419,6 +1462,7 @@ __global__ __launch_bounds__(256) void gemm_h3m_kernel(const DevLaunch L) {
     };
     auto stage = [&](int buf) __attribute__((always_inline)) {
         const unsigned b = lds0 + buf * ST;
+        f32_bufs = (f32_bufs & ~(1u << buf)) | ((seg_f32 ? 1u : 0u) << buf);
 #pragma unroll
         for (int i = 0; i < 2; ++i) dma1(b + (2 * wv + i) * 1024, src[i]);
 #pragma unroll
@@ -1445,8 +1489,12 @@ __global__ __launch_bounds__(256) void gemm_h3m_kernel(const DevLaunch L) {
         const int ph = ((2 * kk + fh) ^ fsw) * 16, pl = ((4 + 2 * kk + fh) ^ fsw) * 16;
         const char *base = lds + buf * ST;
         const int ra = (wm * 32 + fr) * 128;
-        a1[S] = *reinterpret_cast<const h8 *>(base + ra + ph);
-        a2[S] = *reinterpret_cast<const h8 *>(base + ra + pl);
+        if (AF32 && ((f32_bufs >> buf) & 1u)) {
+            h3_frag_from_f32(base + ra, 2 * kk + fh, fsw, a1[S], a2[S]);
+        } else {
+            a1[S] = *reinterpret_cast<const h8 *>(base + ra + ph);
+            a2[S] = *reinterpret_cast<const h8 *>(base + ra + pl);
+        }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int rb = PA + (wn * 64 + j * 32 + fr) * 128;
@@ -2221,10 +2269,18 @@ extern "C" int isc_set_h3_mode(int mode) {
 }
 #define H3_MIN_TILES 160
 
+static bool h3_any_f32(const DevLaunch &L) {
+    for (int i = 0; i < L.nprob; ++i)
+        for (int s = 0; s < L.p[i].nap; ++s)
+            if (!L.p[i].ap[s].hi) return true;
+    return false;
+}
+
 template <int EPI>
 static int launch_h3(const DevLaunch &L, hipStream_t st) {
     constexpr size_t lds = 65536;                                          // two workgroups per CU
-    hipLaunchKernelGGL((gemm_h3_kernel<EPI>), dim3(L.total_tiles), dim3(256), lds, st, L);
+    if (h3_any_f32(L)) hipLaunchKernelGGL((gemm_h3_kernel<EPI, true>), dim3(L.total_tiles), dim3(256), lds, st, L);
+    else hipLaunchKernelGGL((gemm_h3_kernel<EPI, false>), dim3(L.total_tiles), dim3(256), lds, st, L);
     ISC_LAUNCH_CHECK();
     return ISC_OK;
 }
@@ -2325,12 +2381,16 @@ static int launch_h3x(const DevLaunch &L, hipStream_t st) {
     constexpr size_t lds = 3 * (2 * 256 * 64 + 2 * 128 * 64);             // 147456: one workgroup per CU
     static std::atomic<bool> attr_set{false};
     if (!attr_set.load()) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_h3x_kernel<EPI>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_h3x_kernel<EPI, false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_h3x_kernel<EPI, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr_set.store(true);
     }
-    hipLaunchKernelGGL((gemm_h3x_kernel<EPI>), dim3(L.total_tiles), dim3(512), lds, st, L);
+    if (h3_any_f32(L)) hipLaunchKernelGGL((gemm_h3x_kernel<EPI, true>), dim3(L.total_tiles), dim3(512), lds, st, L);
+    else hipLaunchKernelGGL((gemm_h3x_kernel<EPI, false>), dim3(L.total_tiles), dim3(512), lds, st, L);
     ISC_LAUNCH_CHECK();
     return ISC_OK;
 }
@@ -2357,12 +2417,16 @@ static int launch_h3m(const DevLaunch &L, hipStream_t st) {
     constexpr size_t lds = 4 * (2 * 64 * 64 + 2 * 128 * 64);             // 98304: one workgroup per CU
     static std::atomic<bool> attr_set{false};
     if (!attr_set.load()) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_h3m_kernel),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_h3m_kernel<false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_h3m_kernel<true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr_set.store(true);
     }
-    hipLaunchKernelGGL(gemm_h3m_kernel, dim3(L.total_tiles), dim3(256), lds, st, L);
+    if (h3_any_f32(L)) hipLaunchKernelGGL(gemm_h3m_kernel<true>, dim3(L.total_tiles), dim3(256), lds, st, L);
+    else hipLaunchKernelGGL(gemm_h3m_kernel<false>, dim3(L.total_tiles), dim3(256), lds, st, L);
     ISC_LAUNCH_CHECK();
     return ISC_OK;
 }
@@ -2394,27 +2458,14 @@ struct H3Planner {
         hi = J.hi; lo = J.lo;
         blocks += (int)(((long long)rows * (k0 >> 3) + 255) / 256);
     }
-    // activation operand: the caller's per-tensor planes where given, split jobs for the rest
+    // activation operand: the caller's per-tensor planes where given; a segment without planes is read as fp32 rows
+    // and split in registers after the fragment read (ap.hi == nullptr) - no split launch, no plane copy in memory
     void add_a(DevProb &p) {
-        bool any = false;
-        for (int s = 0; s < p.nseg; ++s) any = any || (p.seg[s].A_hi && p.seg[s].A_lo);
-        if (!any) {
-            const _Float16 *hi, *lo;
-            add(p, false, p.M, hi, lo);
-            p.nap = 1;
-            p.ap[0] = DevASeg{hi, lo, 2 * p.Kp, p.Kp};
-            return;
-        }
         p.nap = p.nseg;
         for (int s = 0; s < p.nseg; ++s) {
             const int K = p.seg[s].K;
-            if (p.seg[s].A_hi && p.seg[s].A_lo) {
-                p.ap[s] = DevASeg{p.seg[s].A_hi, p.seg[s].A_lo, 2 * K, K};
-            } else {
-                const _Float16 *hi, *lo;
-                add(p, false, p.M, hi, lo, s, s + 1);
-                p.ap[s] = DevASeg{hi, lo, 2 * K, K};
-            }
+            const bool planes = p.seg[s].A_hi && p.seg[s].A_lo;
+            p.ap[s] = DevASeg{planes ? p.seg[s].A_hi : nullptr, planes ? p.seg[s].A_lo : nullptr, 2 * K, K};
         }
     }
     // weight operand: cached planes if the caller opened a weights scope, else planes in the workspace
@@ -2442,40 +2493,6 @@ struct H3Planner {
     }
 };
 
-// A linear problem whose planes do not fit the workspace (the prologue's region projections: 147456 rows) goes
-// through it in row chunks: split chunk -> GEMM chunk -> next.  (Tried: two plane buffers with the split of chunk
-// c+1 on a side stream under the GEMM of chunk c - 5-19 % SLOWER: the split's workgroups take CU slots and HBM
-// bandwidth from a GEMM that is bound by its DMA round trips, and the event hand-offs add their own gaps.)  A chunk's planes (<= the workspace, 128 MB) are
-// written and read back while still resident in L2 / the 256 MB memory-side cache.
-static int h3_linear_chunked(const DevProb &p0, float *ws, long long ws_floats, long long chunk_rows, hipStream_t st) {
-    const int Kp = h3_kp(p0);
-    for (long long r0 = 0; r0 < p0.M; r0 += chunk_rows) {
-        DevLaunch L = {};
-        L.nprob = 1;
-        DevProb &p = L.p[0];
-        p = p0;
-        p.M = (int)((p0.M - r0) < chunk_rows ? (p0.M - r0) : chunk_rows);
-        p.Kp = Kp;
-        for (int s = 0; s < p.nseg; ++s) p.seg[s].A = p0.seg[s].A + r0 * p0.seg[s].lda;
-        p.C = p0.C + r0 * p0.ldc;
-        if (p0.C_pre) p.C_pre = p0.C_pre + r0 * p0.ldc;
-        if (p0.mask) p.mask = p0.mask + r0 * p0.N;
-        H3Planner pl(ws);
-        const _Float16 *wh, *wl;
-        pl.add(p0, true, p0.N, wh, wl);              // same place every chunk; only the first chunk's job is launched
-        if (r0 != 0) { pl.S.njobs = 0; pl.blocks = 0; }
-        p.Wh = wh; p.Wl = wl;                        // (in the workspace, not the weights scope: used once per call)
-        for (int s = 0; s < p.nseg; ++s) p.seg[s].A_hi = p.seg[s].A_lo = nullptr;   // planes are per chunk
-        pl.add_a(p);
-        int rc = pl.launch(st);
-        if (rc) return rc;
-        rc = launch_h3_big<EPI_LINEAR>(L, st);
-        if (rc) return rc;
-        ++g_h3_launches;
-    }
-    return ISC_OK;
-}
-
 // Plans the planes of every problem inside the caller's workspace, launches the operand split and the GEMM.
 // Returns 1 when the launch went out on this path (rc = its status), 0 when the path does not apply.
 template <int EPI>
@@ -2489,51 +2506,23 @@ static int try_h3(DevLaunch &L, float *ws, long long ws_floats, hipStream_t st, 
         tiles += (long long)((p.M + 127) / 128) * ((p.N + 127) / 128);
         const long long Kp = h3_kp(p);
         if (Kp > (1 << 20)) return 0;
-        need += ((long long)p.M + p.N) * Kp + 1024;       // floats: 2 planes x 2 bytes per element, both operands,
-                                                          // + the 256-byte round-up of up to five plane buffers
+        need += (long long)p.N * Kp + 1024;               // floats: the weight planes (2 x 2 bytes per element) when the
+                                                          // stream has no weights scope; activations are never copied
     }
     // linear launches that cannot give every CU a 128-row tile go out on the 64-row H3 tile
     const bool half_tile = EPI == EPI_LINEAR && tiles < 256;
     if (h3_mode != 2 && tiles < (half_tile ? H3_MIN_TILES / 2 : H3_MIN_TILES)) return 0;
-    if (need > ws_floats) {
-        if constexpr (EPI != EPI_LINEAR) return 0;
-        long long chunk[3];
-        for (int i = 0; i < L.nprob; ++i) {               // every problem must chunk usefully before anything is launched
-            const DevProb &p = L.p[i];
-            const long long Kp = h3_kp(p);
-            chunk[i] = ((ws_floats - (long long)p.N * Kp - 512) / Kp) & ~127LL;
-            if (chunk[i] < 2048) return 0;
-        }
-        for (int i = 0; i < L.nprob; ++i) {
-            rc = h3_linear_chunked(L.p[i], ws, ws_floats, chunk[i], st);
-            if (rc) return 1;
-        }
-        return 1;
-    }
+    if (need > ws_floats) return 0;
     {
         int jobs = 0;
-        for (int i = 0; i < L.nprob; ++i) jobs += L.p[i].nseg + 1;
+        for (int i = 0; i < L.nprob; ++i) jobs += 1;
         if (jobs > H3_MAX_JOBS) return 0;
     }
     H3Planner pl(ws, h3w_scope_of(st));
     for (int i = 0; i < L.nprob; ++i) {
         DevProb &p = L.p[i];
         p.Kp = h3_kp(p);
-        int same = -1;                                   // problems of one launch often share their activations
-        for (int j = 0; j < i && same < 0; ++j) {
-            const DevProb &o = L.p[j];
-            bool eq = o.nseg == p.nseg && o.M == p.M;
-            for (int s = 0; eq && s < p.nseg; ++s)
-                eq = o.seg[s].A == p.seg[s].A && o.seg[s].lda == p.seg[s].lda && o.seg[s].K == p.seg[s].K &&
-                     o.seg[s].A_hi == p.seg[s].A_hi && o.seg[s].A_lo == p.seg[s].A_lo;
-            if (eq) same = j;
-        }
-        if (same >= 0) {
-            p.nap = L.p[same].nap;
-            for (int s = 0; s < p.nap; ++s) p.ap[s] = L.p[same].ap[s];
-        } else {
-            pl.add_a(p);
-        }
+        pl.add_a(p);
         pl.add_w(p, p.Wh, p.Wl);
     }
     rc = pl.launch(st);
