@@ -174,6 +174,24 @@ def bench_small_batches(cap, dev, batches=(4, 128, 512)):
     return out
 
 
+def bench_batch_sweep(cap, dev, batches=(8192,)):
+    """The headline workload at larger batches per step (same weights, same path): captions/s of 4 roll-outs."""
+    out = {}
+    with torch.no_grad(), no_gc():
+        for B in batches:
+            inputs, _ = device_inputs(B, 800 + B, dev)
+            cap(*inputs, T, 1, mode='rl')
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(4):
+                cap(*inputs, T, 1, mode='rl')
+            torch.cuda.synchronize()
+            el = (time.perf_counter() - t0) / 4
+            out[str(B)] = dict(ms_per_rollout=round(el * 1e3, 2), captions_per_s=round(B / el, 1))
+            del inputs
+    return out
+
+
 def bench_exact_fp32(cap, inputs, B, reps=3):
     """The same B=4096 roll-out with the split-f16 engine off (isc_set_h3_mode(0)): every GEMM on the exact-fp32 MFMA
     tiles (v_mfma_f32_32x32x2_f32, peak 157.3 TFLOP/s)."""
@@ -475,6 +493,7 @@ def run(args):
             # measurements on the headline's own weights first; the training benches (which update them) last
             for key, fn in (('exact_fp32_engine', lambda: bench_exact_fp32(cap, inputs, B)),
                             ('greedy_small_batches', lambda: bench_small_batches(cap, dev)),
+                            ('batch_sweep', lambda: bench_batch_sweep(cap, dev)),
                             ('beam5', lambda: bench_beam(cap, inputs)),
                             ('scan_sweep', lambda: bench_scan_sweep(dev)),
                             ('table_build', lambda: bench_table_build(cap, inputs)),

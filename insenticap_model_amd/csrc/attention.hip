@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256) void gate_mix_kernel(const float *z, const flo
     acc = wave_sum(acc);
     const float beta = isc_sigmoid(acc + (w_bias ? w_bias[0] : 0.f));
     if (lane == 0 && beta_out) beta_out[(long long)b * beta_ld] = beta;
-    if ((D & 3) == 0) {      // rows are 16-byte aligned (D % 4 == 0, cudaMalloc'd bases): four outputs per lane and pass
+    if ((D & 3) == 0) {      // rows are 16-byte aligned (D % 4 == 0, device-allocated bases): four outputs per lane and pass
         const float4 *v4 = reinterpret_cast<const float4 *>(v + (long long)b * D);
         const float4 *s4 = reinterpret_cast<const float4 *>(s + (long long)b * D);
         float4 *o4 = reinterpret_cast<float4 *>(out + (long long)b * D);

@@ -1,4 +1,14 @@
-// Lab: fp32-accurate GEMM on the f16 matrix cores by operand splitting.
+// Lab harness (stand-alone: hipcc --offload-arch=gfx950 -O3 -std=c++17 -o h3_gemm_lab tools/h3_gemm_lab.hip) for the
+// split-f16 GEMM kernels of csrc/gemm_f32.hip: times tile / staging variants on the decoder's shapes and checks them
+// against fp64.  Round-2 variants: v6 = 256x128 tile, 8 waves, DMA pieces of 16 rows x 64 B (the round-1 kernel);
+// v8 = the same with whole-line pieces of 8 rows x 128 B (adopted: -9..-14 %); v10 = 4 compute waves (64x128, ONE
+// accumulator set, cross-term operands scaled in registers) + 4 loader waves (-3..-8 % more; not adopted);
+// v12 = 256x256 tile, single accumulator (no gain: 2.4 rounds of one workgroup per CU).  Environment: LAB_SHAPE=0|1
+// (classifier / lang-LSTM shape only), LAB_ONLY=<variant>, LAB_IT=<timed launches>, LAB_ZERO=1 (all-zero operands:
+// the same binaries run 35-45 % faster - the random-data ceiling of these kernels is the chip's power management,
+// MI355X_MICROARCH.md "DVFS give-back").  tools/pmc_lab.sh collects SQ / TCC / TCP counters for one variant.
+//
+// fp32-accurate GEMM on the f16 matrix cores by operand splitting.
 //   x = hi + lo * 2^-11  with hi = f16(x), lo = f16((x - hi) * 2^11)   (>= 22 significant bits for |x| >= 2^-14)
 //   C = sum hi_a*hi_b  +  2^-11 * sum (hi_a*lo_b + lo_a*hi_b)          (lo*lo dropped: <= 2^-22 relative)
 // C[M,N] = A[M,K] * W[N,K]^T; 128x128 tile, 4 waves (2x2) of 64x64, BK = 32 halfs, LDS-DMA, 2 buffers.
@@ -34,133 +44,10 @@ __global__ void split_kernel(const float *x, _Float16 *hi, _Float16 *lo, long lo
         h[e] = (_Float16)a[e];
         l[e] = (_Float16)((a[e] - (float)h[e]) * 2048.f);
     }
-    *reinterpret_cast<uint2 *>(hi + i) = *reinterpret_cast<uint2 *>(h);
-    *reinterpret_cast<uint2 *>(lo + i) = *reinterpret_cast<uint2 *>(l);
-}
-
-// LDS per stage: planes A_hi, A_lo, B_hi, B_lo, each [128 rows][4 slots of 16 B]; slot s of row r holds
-// k-quad (8 halfs) q = s ^ ((r>>2)&3)
-template <int NBUF, int TI, int TJ>
-__global__ __launch_bounds__(256, 2) void gemm_h3(const _Float16 *Ah, const _Float16 *Al, const _Float16 *Wh,
-                                                  const _Float16 *Wl, float *C, int M, int N, int K) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int PL = 128 * 64;                    // bytes per plane tile
-    constexpr int ST = 4 * PL;                      // bytes per stage
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wm = TI == 2 ? w >> 1 : w, wn = TI == 2 ? w & 1 : 0;
-    int tm, tn;
-    tile_coords(M / 128, N / 128, tm, tn);
-    const int row0 = tm * 128, col0 = tn * 128;
-    f32x16 acc0[TI][TJ], acc1[TI][TJ];
-#pragma unroll
-    for (int i = 0; i < TI; ++i)
-#pragma unroll
-        for (int j = 0; j < TJ; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { acc0[i][j][r] = 0.f; acc1[i][j][r] = 0.f; }
-    // staging: per plane, wave w issues instructions ii = 2w, 2w+1; instruction ii covers rows 16*ii + (lane>>2)
-    const _Float16 *src[8];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int r = 16 * (2 * w + i) + (lane >> 2);
-        const int q = (lane & 3) ^ ((r >> 2) & 3);
-        src[0 + i] = Ah + (long long)(row0 + r) * K + q * 8;
-        src[2 + i] = Al + (long long)(row0 + r) * K + q * 8;
-        src[4 + i] = Wh + (long long)(col0 + r) * K + q * 8;
-        src[6 + i] = Wl + (long long)(col0 + r) * K + q * 8;
-    }
-    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)smem + w * 2048);
-    auto stage = [&](int buf) __attribute__((always_inline)) {
-#pragma unroll
-        for (int p = 0; p < 4; ++p)
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off"
-                             :: "s"(lds0 + buf * ST + p * PL + i * 1024), "v"(src[2 * p + i]) : "memory");
-                src[2 * p + i] += 32;
-            }
-    };
-    const int fr = lane & 31, fh = lane >> 5, fsw = (fr >> 2) & 3;
-    h8 a1[2][TI], a2[2][TI], b1[2][TJ], b2[2][TJ];      // [set][tile]
-    auto lfrag = [&](int buf, auto ksc, auto setc) __attribute__((always_inline)) {
-        constexpr int ks = decltype(ksc)::value, S = decltype(setc)::value;
-        const int slot = ((2 * ks + fh) ^ fsw) * 16;
-        const char *base = smem + buf * ST;
-#pragma unroll
-        for (int i = 0; i < TI; ++i) {
-            const int ra = (wm * 32 * TI + i * 32 + fr) * 64 + slot;
-            a1[S][i] = *reinterpret_cast<const h8 *>(base + ra);
-            a2[S][i] = *reinterpret_cast<const h8 *>(base + PL + ra);
-        }
-#pragma unroll
-        for (int i = 0; i < TJ; ++i) {
-            const int rb = (wn * 32 * TJ + i * 32 + fr) * 64 + slot;
-            b1[S][i] = *reinterpret_cast<const h8 *>(base + 2 * PL + rb);
-            b2[S][i] = *reinterpret_cast<const h8 *>(base + 3 * PL + rb);
-        }
-    };
-    auto mma = [&](auto setc) __attribute__((always_inline)) {
-        constexpr int S = decltype(setc)::value;
-#pragma unroll
-        for (int i = 0; i < TI; ++i)
-#pragma unroll
-            for (int j = 0; j < TJ; ++j) {
-                acc0[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[S][i], b1[S][j], acc0[i][j], 0, 0, 0);
-                acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[S][i], b2[S][j], acc1[i][j], 0, 0, 0);
-                acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2[S][i], b1[S][j], acc1[i][j], 0, 0, 0);
-            }
-    };
-    const int n = K / 32;
-    if constexpr (NBUF == 2) {
-        stage(0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        lfrag(0, I0{}, I0{});
-        for (int c = 0; c < n; ++c) {
-            const int cur = c & 1, nxt = cur ^ 1;
-            const bool has1 = c + 1 < n;
-            if (has1) stage(nxt);
-            lfrag(cur, I1{}, I1{});
-            mma(I0{});
-            if (has1) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); lfrag(nxt, I0{}, I0{}); }
-            mma(I1{});
-        }
-    } else {
-        // 3 buffers: chunk c in LDS[c%3]; DMA of chunk c+2 issued at the top of chunk c
-        stage(0);
-        if (n > 1) stage(1);
-        if (n > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        lfrag(0, I0{}, I0{});
-        int cur = 0;
-        for (int c = 0; c < n; ++c) {
-            const int nxt = cur == 2 ? 0 : cur + 1, nn = nxt == 2 ? 0 : nxt + 1;
-            const bool has1 = c + 1 < n, has2 = c + 2 < n;
-            if (has2) stage(nn);
-            lfrag(cur, I1{}, I1{});
-            mma(I0{});
-            if (has1) {
-                if (has2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                __builtin_amdgcn_sched_barrier(0);
-                lfrag(nxt, I0{}, I0{});
-            }
-            mma(I1{});
-            cur = nxt;
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < TI; ++i)
-#pragma unroll
-        for (int j = 0; j < TJ; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = row0 + wm * 32 * TI + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const int col = col0 + wn * 32 * TJ + j * 32 + (lane & 31);
-                C[(long long)row * N + col] = acc0[i][j][r] + acc1[i][j][r] * (1.f / 2048.f);
-            }
+    // interleaved: element i = (row, k) with K % 32 == 0 -> block (i >> 5) of 64 halfs: [hi 32 | lo 32]
+    const long long o = (i >> 5) * 64 + (i & 31);
+    *reinterpret_cast<uint2 *>(hi + o) = *reinterpret_cast<uint2 *>(h);
+    *reinterpret_cast<uint2 *>(hi + o + 32) = *reinterpret_cast<uint2 *>(l);
 }
 
 // variant X: 256x128 tile, 8 waves (each 32x128), 3 buffers of 48 KB, two chunks in flight, one workgroup per CU
@@ -182,20 +69,20 @@ __global__ __launch_bounds__(512) void gemm_h3x(const _Float16 *Ah, const _Float
     for (int i = 0; i < 2; ++i) {
         const int r = 16 * (2 * w + i) + (lane >> 2);
         const int q = (lane & 3) ^ ((r >> 2) & 3);
-        src[0 + i] = Ah + (long long)(row0 + r) * K + q * 8;
-        src[2 + i] = Al + (long long)(row0 + r) * K + q * 8;
+        src[0 + i] = Ah + (long long)(row0 + r) * 2 * K + q * 8;
+        src[2 + i] = Ah + (long long)(row0 + r) * 2 * K + q * 8 + 32;
     }
     {
         const int r = 16 * w + (lane >> 2);
         const int q = (lane & 3) ^ ((r >> 2) & 3);
-        src[4] = Wh + (long long)(col0 + r) * K + q * 8;
-        src[5] = Wl + (long long)(col0 + r) * K + q * 8;
+        src[4] = Wh + (long long)(col0 + r) * 2 * K + q * 8;
+        src[5] = Wh + (long long)(col0 + r) * 2 * K + q * 8 + 32;
     }
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)smem);
     const unsigned wv = __builtin_amdgcn_readfirstlane((unsigned)w);
     auto dma1 = [&](unsigned dst, const _Float16 *&p) __attribute__((always_inline)) {
         asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(dst), "v"(p) : "memory");
-        p += 32;
+        p += 64;
     };
     auto stage = [&](int buf) __attribute__((always_inline)) {
         const unsigned b = lds0 + buf * ST;
@@ -266,53 +153,63 @@ __global__ __launch_bounds__(512) void gemm_h3x(const _Float16 *Ah, const _Float
         }
 }
 
-// variant 7: 128x128, 4 waves (32x128), 16-deep sub-chunks of 16 KB, four buffers, three sub-chunks in flight, 2 WG/CU
-__global__ __launch_bounds__(256, 2) void gemm_h3s(const _Float16 *Ah, const _Float16 *Al, const _Float16 *Wh,
-                                                   const _Float16 *Wl, float *C, int M, int N, int K) {
+
+// variant F: the same 256x128 tile, but every DMA piece is 8 rows x 128 B = whole lines of the interleaved plane
+// layout (hi and lo of a 32-k block together); LDS image row = 128 B, position p of row r holds chunk p ^ ((r>>1)&7)
+__global__ __launch_bounds__(512) void gemm_h3xf(const _Float16 *Ah, const _Float16 *Al, const _Float16 *Wh,
+                                                 const _Float16 *Wl, float *C, int M, int N, int K) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int PL = 128 * 32, ST = 4 * PL;      // 4 KB planes, 16 KB per buffer
+    constexpr int PA = 256 * 128, PB = 128 * 128, ST = PA + PB;      // 48 KB per buffer
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     int tm, tn;
-    tile_coords(M / 128, N / 128, tm, tn);
-    const int row0 = tm * 128, col0 = tn * 128;
+    tile_coords(M / 256, N / 128, tm, tn);
+    const int row0 = tm * 256, col0 = tn * 128;
     f32x16 acc0[4], acc1[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc0[j][r] = 0.f; acc1[j][r] = 0.f; }
-    // piece w of each plane: rows 32w + (lane>>1), slot lane&1 holds k-octet (lane&1) ^ ((row>>3)&1)
-    const _Float16 *src[4];
-    {
-        const int r = 32 * w + (lane >> 1);
-        const int q = (lane & 1) ^ ((r >> 3) & 1);
-        src[0] = Ah + (long long)(row0 + r) * K + q * 8;
-        src[1] = Al + (long long)(row0 + r) * K + q * 8;
-        src[2] = Wh + (long long)(col0 + r) * K + q * 8;
-        src[3] = Wl + (long long)(col0 + r) * K + q * 8;
-    }
-    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)smem + w * 1024);
-    auto stage = [&](int buf) __attribute__((always_inline)) {
+    // wave w: A pieces 4w..4w+3 (rows 32w + 8i + (lane>>3)), W pieces 2w, 2w+1 (rows 16w + 8i + (lane>>3))
+    const char *src[6];
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off"
-                         :: "s"(lds0 + buf * ST + p * PL), "v"(src[p]) : "memory");
-            src[p] += 16;
-        }
+    for (int i = 0; i < 4; ++i) {
+        const int r = 32 * w + 8 * i + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        src[i] = reinterpret_cast<const char *>(Ah + (long long)(row0 + r) * 2 * K) + c * 16;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = 16 * w + 8 * i + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        src[4 + i] = reinterpret_cast<const char *>(Wh + (long long)(col0 + r) * 2 * K) + c * 16;
+    }
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)smem);
+    const unsigned wv = __builtin_amdgcn_readfirstlane((unsigned)w);
+    auto dma1 = [&](unsigned dst, const char *&p) __attribute__((always_inline)) {
+        asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(dst), "v"(p) : "memory");
+        p += 128;
     };
-    const int fr = lane & 31, fh = lane >> 5;
+    auto stage = [&](int buf) __attribute__((always_inline)) {
+        const unsigned b = lds0 + buf * ST;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dma1(b + (4 * wv + i) * 1024, src[i]);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) dma1(b + PA + (2 * wv + i) * 1024, src[4 + i]);
+    };
+    const int fr = lane & 31, fh = lane >> 5, fsw = (fr >> 1) & 7;
     h8 a1[2], a2[2], b1[2][4], b2[2][4];
-    auto lfrag = [&](int buf, auto setc) __attribute__((always_inline)) {
-        constexpr int S = decltype(setc)::value;
-        const int slot = (fh ^ ((fr >> 3) & 1)) * 16;
+    auto lfrag = [&](int buf, auto ksc, auto setc) __attribute__((always_inline)) {
+        constexpr int ks = decltype(ksc)::value, S = decltype(setc)::value;
+        const int ph = ((2 * ks + fh) ^ fsw) * 16, pl = ((4 + 2 * ks + fh) ^ fsw) * 16;
         const char *base = smem + buf * ST;
-        const int ra = (w * 32 + fr) * 32 + slot;
-        a1[S] = *reinterpret_cast<const h8 *>(base + ra);
-        a2[S] = *reinterpret_cast<const h8 *>(base + PL + ra);
+        const int ra = (w * 32 + fr) * 128;
+        a1[S] = *reinterpret_cast<const h8 *>(base + ra + ph);
+        a2[S] = *reinterpret_cast<const h8 *>(base + ra + pl);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int rb = (j * 32 + fr) * 32 + slot;
-            b1[S][j] = *reinterpret_cast<const h8 *>(base + 2 * PL + rb);
-            b2[S][j] = *reinterpret_cast<const h8 *>(base + 3 * PL + rb);
+            const int rb = PA + (j * 32 + fr) * 128;
+            b1[S][j] = *reinterpret_cast<const h8 *>(base + rb + ph);
+            b2[S][j] = *reinterpret_cast<const h8 *>(base + rb + pl);
         }
     };
     auto mma = [&](auto setc) __attribute__((always_inline)) {
@@ -324,35 +221,29 @@ __global__ __launch_bounds__(256, 2) void gemm_h3s(const _Float16 *Ah, const _Fl
             acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2[S], b1[S][j], acc1[j], 0, 0, 0);
         }
     };
-    const int n = K / 16;                           // sub-chunks (n >= 4 and even assumed)
+    const int n = K / 32;
     auto wait_for = [&](int in_flight) __attribute__((always_inline)) {
-        if (in_flight >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (in_flight == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if (in_flight >= 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
-    stage(0); stage(1); stage(2);
-    wait_for(2);
+    stage(0);
+    if (n > 1) stage(1);
+    wait_for(n > 1 ? 1 : 0);
     __syncthreads();
-    lfrag(0, I0{});
-    for (int c = 0; c < n; c += 2) {
-        // sub-chunk c (set 0)
-        if (c + 3 < n) stage((c + 3) & 3);
-        {
-            const int last = n - 1 < c + 3 ? n - 1 : c + 3;
-            wait_for(last - (c + 1));
-            __syncthreads();
-            lfrag((c + 1) & 3, I1{});
-        }
+    lfrag(0, I0{}, I0{});
+    int cur = 0;
+    for (int c = 0; c < n; ++c) {
+        const int nxt = cur == 2 ? 0 : cur + 1, nn = nxt == 2 ? 0 : nxt + 1;
+        if (c + 2 < n) stage(nn);
+        lfrag(cur, I1{}, I1{});
         mma(I0{});
-        // sub-chunk c+1 (set 1)
-        if (c + 4 < n) stage((c + 4) & 3);
-        if (c + 2 < n) {
-            const int last = n - 1 < c + 4 ? n - 1 : c + 4;
-            wait_for(last - (c + 2));
+        if (c + 1 < n) {
+            wait_for(c + 2 < n ? 1 : 0);
             __syncthreads();
-            lfrag((c + 2) & 3, I0{});
+            lfrag(nxt, I0{}, I0{});
         }
         mma(I1{});
+        cur = nxt;
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -362,6 +253,213 @@ __global__ __launch_bounds__(256, 2) void gemm_h3s(const _Float16 *Ah, const _Fl
             const int col = col0 + j * 32 + (lane & 31);
             C[(long long)row * N + col] = acc0[j][r] + acc1[j][r] * (1.f / 2048.f);
         }
+}
+
+
+// variant P: 256x128 tile, 4 COMPUTE waves (64x128 each, ONE accumulator set: the cross terms are brought to the main
+// term's scale in registers, hi' = hi * 2^-5, lo' = lo * 2^-6, so hi*hi + hi'*lo' + lo'*hi' shares an accumulator) and
+// 4 LOADER waves that only issue the LDS-DMA pieces (full lines) - compute waves never stall on DMA issue.
+__global__ __launch_bounds__(512) void gemm_h3p(const _Float16 *Ah, const _Float16 *Al, const _Float16 *Wh,
+                                                const _Float16 *Wl, float *C, int M, int N, int K) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int PA = 256 * 128, PB = 128 * 128, ST = PA + PB;      // 48 KB per buffer, 3 buffers
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int tm, tn;
+    tile_coords(M / 256, N / 128, tm, tn);
+    const int row0 = tm * 256, col0 = tn * 128;
+    const int n = K / 32;
+    if (w >= 4) {
+        // ---- loader wave l: A pieces 8l .. 8l+7 (rows 64l + 8i + (lane>>3)), W pieces 4l .. 4l+3 (rows 32l + 8i + (lane>>3))
+        const int l = w - 4;
+        const char *srcA[8], *srcW[4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int r = 64 * l + 8 * i + (lane >> 3);
+            srcA[i] = reinterpret_cast<const char *>(Ah + (long long)(row0 + r) * 2 * K) + ((lane & 7) ^ ((r >> 1) & 7)) * 16;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = 32 * l + 8 * i + (lane >> 3);
+            srcW[i] = reinterpret_cast<const char *>(Wh + (long long)(col0 + r) * 2 * K) + ((lane & 7) ^ ((r >> 1) & 7)) * 16;
+        }
+        const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)smem);
+        auto stage = [&](int buf) __attribute__((always_inline)) {
+            const unsigned b = lds0 + buf * ST;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(b + (8 * l + i) * 1024), "v"(srcA[i]) : "memory");
+                srcA[i] += 128;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(b + PA + (4 * l + i) * 1024), "v"(srcW[i]) : "memory");
+                srcW[i] += 128;
+            }
+        };
+        stage(0);
+        if (n > 1) stage(1);
+        if (n > 1) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                   // chunk 0 landed
+        for (int c = 0; c < n; ++c) {
+            if (c + 2 < n) stage((c + 2) % 3);             // its buffer held chunk c-1: consumers left it before the last barrier
+            if (c + 1 < n) {
+                if (c + 2 < n) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __syncthreads();                               // chunk c+1 landed; consumers are done with chunk c
+        }
+        return;
+    }
+    // ---- compute wave w: rows 64w .. 64w+63, all 128 columns
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int fr = lane & 31, fh = lane >> 5, fsw = (fr >> 1) & 7;
+    const h8 s5 = {(_Float16)0.03125f, (_Float16)0.03125f, (_Float16)0.03125f, (_Float16)0.03125f,
+                   (_Float16)0.03125f, (_Float16)0.03125f, (_Float16)0.03125f, (_Float16)0.03125f};
+    const h8 s6 = s5 * (_Float16)0.5f;
+    __syncthreads();                                       // chunk 0 landed
+    for (int c = 0; c < n; ++c) {
+        const char *base = smem + (c % 3) * ST;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int ph = ((2 * ks + fh) ^ fsw) * 16, pl = ((4 + 2 * ks + fh) ^ fsw) * 16;
+            h8 a1[2], a1s[2], a2s[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int ra = (w * 64 + i * 32 + fr) * 128;
+                a1[i] = *reinterpret_cast<const h8 *>(base + ra + ph);
+                const h8 lo = *reinterpret_cast<const h8 *>(base + ra + pl);
+                a1s[i] = a1[i] * s5;
+                a2s[i] = lo * s6;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int rb = PA + (j * 32 + fr) * 128;
+                const h8 b1 = *reinterpret_cast<const h8 *>(base + rb + ph);
+                const h8 b2 = *reinterpret_cast<const h8 *>(base + rb + pl);
+                const h8 b1s = b1 * s5, b2s = b2 * s6;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[i], b1, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1s[i], b2s, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2s[i], b1s, acc[i][j], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row0 + w * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int col = col0 + j * 32 + (lane & 31);
+                C[(long long)row * N + col] = acc[i][j][r];
+            }
+}
+
+
+// variant Q: 256x256 tile, 8 waves (4 in M x 2 in N, 64x128 each), ONE accumulator set (in-register 2^-5 / 2^-6 scaling of
+// the cross-term operands), full-line pieces, 2 buffers of 64 KB; every wave issues 8 DMA pieces per chunk.
+__global__ __launch_bounds__(512) void gemm_h3q(const _Float16 *Ah, const _Float16 *Al, const _Float16 *Wh,
+                                                const _Float16 *Wl, float *C, int M, int N, int K) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int PA = 256 * 128, PB = 256 * 128, ST = PA + PB;      // 64 KB per buffer
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6), wm = w >> 1, wn = w & 1;
+    int tm, tn;
+    tile_coords(M / 256, N / 256, tm, tn);
+    const int row0 = tm * 256, col0 = tn * 256;
+    const int n = K / 32;
+    // wave w: A pieces 4w..4w+3 (rows 32w + 8i + (lane>>3)), W pieces 4w..4w+3
+    const char *srcA[4], *srcW[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = 32 * w + 8 * i + (lane >> 3);
+        const int c = ((lane & 7) ^ ((r >> 1) & 7)) * 16;
+        srcA[i] = reinterpret_cast<const char *>(Ah + (long long)(row0 + r) * 2 * K) + c;
+        srcW[i] = reinterpret_cast<const char *>(Wh + (long long)(col0 + r) * 2 * K) + c;
+    }
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)smem);
+    auto stage = [&](int buf) __attribute__((always_inline)) {
+        const unsigned b = lds0 + buf * ST;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(b + (4 * w + i) * 1024), "v"(srcA[i]) : "memory");
+            srcA[i] += 128;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(b + PA + (4 * w + i) * 1024), "v"(srcW[i]) : "memory");
+            srcW[i] += 128;
+        }
+    };
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int fr = lane & 31, fh = lane >> 5, fsw = (fr >> 1) & 7;
+    const h8 s5 = {(_Float16)0.03125f, (_Float16)0.03125f, (_Float16)0.03125f, (_Float16)0.03125f,
+                   (_Float16)0.03125f, (_Float16)0.03125f, (_Float16)0.03125f, (_Float16)0.03125f};
+    const h8 s6 = s5 * (_Float16)0.5f;
+    stage(0);
+    for (int c = 0; c < n; ++c) {
+        if (c + 1 < n) {
+            stage((c + 1) & 1);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();                                   // chunk c landed everywhere
+        const char *base = smem + (c & 1) * ST;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int ph = ((2 * ks + fh) ^ fsw) * 16, pl = ((4 + 2 * ks + fh) ^ fsw) * 16;
+            h8 a1[2], a1s[2], a2s[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int ra = (wm * 64 + i * 32 + fr) * 128;
+                a1[i] = *reinterpret_cast<const h8 *>(base + ra + ph);
+                const h8 lo = *reinterpret_cast<const h8 *>(base + ra + pl);
+                a1s[i] = a1[i] * s5;
+                a2s[i] = lo * s6;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int rb = PA + (wn * 128 + j * 32 + fr) * 128;
+                const h8 b1 = *reinterpret_cast<const h8 *>(base + rb + ph);
+                const h8 b2 = *reinterpret_cast<const h8 *>(base + rb + pl);
+                const h8 b1s = b1 * s5, b2s = b2 * s6;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[i], b1, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1s[i], b2s, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2s[i], b1s, acc[i][j], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();                                   // everyone is done with buffer c & 1 before it is refilled
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int col = col0 + wn * 128 + j * 32 + (lane & 31);
+                C[(long long)row * N + col] = acc[i][j][r];
+            }
 }
 
 // plain fp32 reference GEMM (one thread per output, fmaf chain) for the accuracy comparison
@@ -381,11 +479,12 @@ static void run_shape(int M, int N, int K, float wscale, int dist) {
     std::normal_distribution<float> g(0.f, 1.f);
     for (auto &x : hA) x = dist == 0 ? u(rng) : g(rng) * 3.f;
     for (auto &x : hW) x = g(rng) * wscale;
+    if (getenv("LAB_ZERO")) { for (auto &x : hA) x = 0.f; for (auto &x : hW) x = 0.f; }
     float *dA, *dW, *dC, *dR;
     _Float16 *Ah, *Al, *Wh, *Wl;
     CK(hipMalloc(&dA, hA.size() * 4)); CK(hipMalloc(&dW, hW.size() * 4)); CK(hipMalloc(&dC, (size_t)M * N * 4));
-    CK(hipMalloc(&Ah, hA.size() * 2)); CK(hipMalloc(&Al, hA.size() * 2));
-    CK(hipMalloc(&Wh, hW.size() * 2)); CK(hipMalloc(&Wl, hW.size() * 2));
+    CK(hipMalloc(&Ah, hA.size() * 4)); CK(hipMalloc(&Al, hA.size() * 2));
+    CK(hipMalloc(&Wh, hW.size() * 4)); CK(hipMalloc(&Wl, hW.size() * 2));
     CK(hipMemcpy(dA, hA.data(), hA.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(dW, hW.data(), hW.size() * 4, hipMemcpyHostToDevice));
     hipEvent_t e0, e1;
@@ -395,33 +494,30 @@ static void run_shape(int M, int N, int K, float wscale, int dist) {
     };
     split(dA, Ah, Al, hA.size()); split(dW, Wh, Wl, hW.size());
     CK(hipDeviceSynchronize());
-    const int grid = (M / 128) * (N / 128);
-    CK(hipFuncSetAttribute((const void *)gemm_h3<3, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 32768));
-    CK(hipFuncSetAttribute((const void *)gemm_h3<2, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 32768));
-    CK(hipFuncSetAttribute((const void *)gemm_h3<3, 1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 32768));
-    CK(hipFuncSetAttribute((const void *)gemm_h3<2, 1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 32768));
     CK(hipFuncSetAttribute((const void *)gemm_h3x, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 49152));
-    CK(hipFuncSetAttribute((const void *)gemm_h3s, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
-    for (int nb = 4; nb <= 7; ++nb) {
+    CK(hipFuncSetAttribute((const void *)gemm_h3xf, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 49152));
+    CK(hipFuncSetAttribute((const void *)gemm_h3p, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 49152));
+    CK(hipFuncSetAttribute((const void *)gemm_h3q, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 65536));
+    const int only = getenv("LAB_ONLY") ? atoi(getenv("LAB_ONLY")) : 0;
+    for (int nb = 6; nb <= 12; nb += 2) {
+        if (only && nb != only) continue;
         auto launch = [&]() {
-            if (nb == 7) { gemm_h3s<<<grid, 256, 65536>>>(Ah, Al, Wh, Wl, dC, M, N, K); return; }
-            if (nb == 6) { gemm_h3x<<<(M / 256) * (N / 128), 512, 3 * 49152>>>(Ah, Al, Wh, Wl, dC, M, N, K); return; }
-            if (nb == 2) gemm_h3<2, 2, 2><<<grid, 256, 2 * 32768>>>(Ah, Al, Wh, Wl, dC, M, N, K);
-            else if (nb == 3) gemm_h3<3, 2, 2><<<grid, 256, 3 * 32768>>>(Ah, Al, Wh, Wl, dC, M, N, K);
-            else if (nb == 4) gemm_h3<2, 1, 4><<<grid, 256, 2 * 32768>>>(Ah, Al, Wh, Wl, dC, M, N, K);
-            else gemm_h3<3, 1, 4><<<grid, 256, 3 * 32768>>>(Ah, Al, Wh, Wl, dC, M, N, K);
+            if (nb == 6) gemm_h3x<<<(M / 256) * (N / 128), 512, 3 * 49152>>>(Ah, Al, Wh, Wl, dC, M, N, K);
+            else if (nb == 8) gemm_h3xf<<<(M / 256) * (N / 128), 512, 3 * 49152>>>(Ah, Al, Wh, Wl, dC, M, N, K);
+            else if (nb == 10) gemm_h3p<<<(M / 256) * (N / 128), 512, 3 * 49152>>>(Ah, Al, Wh, Wl, dC, M, N, K);
+            else { if (N % 256) return; gemm_h3q<<<(M / 256) * (N / 256), 512, 2 * 65536>>>(Ah, Al, Wh, Wl, dC, M, N, K); }
         };
-        for (int i = 0; i < 20; ++i) launch();
+        const int it = getenv("LAB_IT") ? atoi(getenv("LAB_IT")) : 50;
+        for (int i = 0; i < (it < 20 ? 2 : 20); ++i) launch();
         CK(hipDeviceSynchronize());
-        const int it = 50;
         CK(hipEventRecord(e0));
         for (int i = 0; i < it; ++i) launch();
         CK(hipEventRecord(e1));
         CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         const double us = ms * 1000.0 / it;
-        printf("M=%d N=%d K=%d  h3 v%d (2,3: 2x2 waves nbuf 2,3; 4,5: 4x1 waves; 6: 256x128 8 waves 3 buf; 7: 128x128 16-deep x4 buf): %.1f us  %.1f TF(fp32-equivalent)  %.1f TF(f16 executed)\n", M, N, K, nb, us,
-               2.0 * M * N * K / us * 1e-6, 6.0 * M * N * K / us * 1e-6);
+        printf("M=%d N=%d K=%d  v%d (6: 256x128 half-line pieces; 8: 256x128 full-line pieces; 10: 4 compute + 4 loader waves, single accumulator; 12: 256x256 single accumulator): %.1f us  %.1f TF(fp32-eq)  frac-of-833 %.3f\n", M, N, K, nb, us,
+               2.0 * M * N * K / us * 1e-6, 2.0 * M * N * K / us * 1e-6 / 833.3);
     }
     // split cost
     {
@@ -457,6 +553,9 @@ static void run_shape(int M, int N, int K, float wscale, int dist) {
 }
 
 int main() {
+    const int shape = getenv("LAB_SHAPE") ? atoi(getenv("LAB_SHAPE")) : -1;
+    if (shape == 0) { run_shape(4096, 9984, 512, 0.05f, 0); return 0; }
+    if (shape == 1) { run_shape(4096, 2048, 1536, 0.05f, 0); return 0; }
     run_shape(4096, 9984, 512, 0.05f, 0);      // classifier
     run_shape(4096, 2048, 1536, 0.05f, 0);     // lang-LSTM
     run_shape(4096, 2048, 2048, 0.05f, 0);     // att-LSTM (no table)
