@@ -286,7 +286,8 @@ def _backward(cap, S, dlogp, d_fc_feats, d_cpt_feats):
     probs = [nn([(dG1_sum, Wih1[:, H:H + E])], d_fc_e), nn([(dG1f, Wih1[:, H + E:])], dxt)]
     if d_label_e is not None:
         probs.append(nn([(dG1_sum, Wih1[:, H + E:])], d_label_e))
-    ops.gemm_bwd(probs, NN)
+    with ops.h3_weights_scope(cap._dev):      # dX over all T*B rows: split-f16 on planes of the W_ih slices' transposes
+        ops.gemm_bwd(probs, NN)
     emb = p['word_embed.0.weight']
     dEmb = zeros(V, Wd)
     ops.embed_relu_bwd(emb, S.tok.view(-1), dxt, dEmb, TB, skip_id=cap.pad_id)    # the <PAD> row is zeroed below

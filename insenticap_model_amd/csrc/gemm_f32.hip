@@ -1569,30 +1569,44 @@ __global__ __launch_bounds__(256) void h3_split_kernel(const SplitLaunch S) {
     const SplitJob &J = S.j[ji];
     const int k8n = J.Kp >> 3;
     const long long idx = (long long)(blockIdx.x - J.first_block) * 256 + threadIdx.x;
-    if (idx >= (long long)J.rows * k8n) return;
     if (J.transposed) {
-        // backward-pass weights: segment s is W_s [K_s, rows] as stored (dX = dY * W contracts over W's rows); plane row n
-        // = column n of the source.  Neighbouring threads take neighbouring n: the strided reads coalesce across them.
-        const int n = (int)(idx % J.rows);
-        const int kq = (int)(idx / J.rows) * 8;
+        // source segments are [K_s, rows] (k-major: the backward pass's W for dX = dY W, and both operands of dW = dY^T X);
+        // plane row n = column n of the source.  One workgroup transposes a tile of 32 k x 64 n through LDS: the reads are
+        // 256-byte row pieces, and each output row receives its whole 128-byte line (32 hi + 32 lo halfs of the k-block).
+        __shared__ float t[32][65];
+        const int ntile = (J.rows + 63) >> 6;
+        const int bid = blockIdx.x - J.first_block;
+        const int kb = bid / ntile, n0 = (bid - kb * ntile) * 64, kq = kb * 32;
         const float *sp = J.src[0];
         int ld = J.ld[0], k0 = 0;
 #pragma unroll
         for (int sg = 1; sg < ISC_MAX_SEG; ++sg)
             if (sg < J.nseg && kq >= J.kstart[sg]) { sp = J.src[sg]; ld = J.ld[sg]; k0 = J.kstart[sg]; }
-        h8 hi, lo;
+        const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float x = sp[(long long)(kq - k0 + e) * ld + n];
-            const _Float16 h = (_Float16)x;
-            hi[e] = h;
-            lo[e] = (_Float16)((x - (float)h) * 2048.f);
+        for (int r = 0; r < 8; ++r) {
+            const int k = ty * 8 + r;
+            t[k][tx] = n0 + tx < J.rows ? sp[(long long)(kq - k0 + k) * ld + n0 + tx] : 0.f;
         }
-        const long long o = plane_index(n, kq, J.Kp);
-        *reinterpret_cast<h8 *>(J.hi + o) = hi;
-        *reinterpret_cast<h8 *>(J.lo + o) = lo;
+        __syncthreads();
+        // thread -> (n = tid / 4, 8 consecutive k = 8 * (tid % 4)): four threads write one row's 64 B of hi and 64 B of lo
+        const int n = threadIdx.x >> 2, q = (threadIdx.x & 3) * 8;
+        if (n0 + n < J.rows) {
+            h8 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float x = t[q + e][n];
+                const _Float16 h = (_Float16)x;
+                hi[e] = h;
+                lo[e] = (_Float16)((x - (float)h) * 2048.f);
+            }
+            const long long o = plane_index(n0 + n, kq + q, J.Kp);
+            *reinterpret_cast<h8 *>(J.hi + o) = hi;
+            *reinterpret_cast<h8 *>(J.lo + o) = lo;
+        }
         return;
     }
+    if (idx >= (long long)J.rows * k8n) return;
     const int row = (int)(idx / k8n);
     int k = (int)(idx - (long long)row * k8n) * 8;
     const long long o = plane_index(row, k, J.Kp);        // 8 consecutive k never leave their 32-block
@@ -2456,7 +2470,7 @@ struct H3Planner {
         J.hi = reinterpret_cast<_Float16 *>(at); at += bytes;
         J.lo = J.hi + 32;
         hi = J.hi; lo = J.lo;
-        blocks += (int)(((long long)rows * (k0 >> 3) + 255) / 256);
+        blocks += transposed ? ((rows + 63) / 64) * (k0 >> 5) : (int)(((long long)rows * (k0 >> 3) + 255) / 256);
     }
     // activation operand: the caller's per-tensor planes where given; a segment without planes is read as fp32 rows
     // and split in registers after the fragment read (ap.hi == nullptr) - no split launch, no plane copy in memory
@@ -2496,7 +2510,7 @@ struct H3Planner {
 // Plans the planes of every problem inside the caller's workspace, launches the operand split and the GEMM.
 // Returns 1 when the launch went out on this path (rc = its status), 0 when the path does not apply.
 template <int EPI>
-static int try_h3(DevLaunch &L, float *ws, long long ws_floats, hipStream_t st, int &rc) {
+static int try_h3(DevLaunch &L, float *ws, long long ws_floats, hipStream_t st, int &rc, int transposed = 0) {
     const int h3_mode = g_h3_mode.load();
     if (h3_mode == 0 || g_tile_override.load() >= 0 || !ws || ((uintptr_t)ws & 255)) return 0;
     long long tiles = 0, need = 0;
@@ -2523,7 +2537,7 @@ static int try_h3(DevLaunch &L, float *ws, long long ws_floats, hipStream_t st, 
         DevProb &p = L.p[i];
         p.Kp = h3_kp(p);
         pl.add_a(p);
-        pl.add_w(p, p.Wh, p.Wl);
+        pl.add_w(p, p.Wh, p.Wl, transposed);
     }
     rc = pl.launch(st);
     if (rc) return 1;
@@ -2541,7 +2555,7 @@ static int try_h3(DevLaunch &L, float *ws, long long ws_floats, hipStream_t st, 
 static std::atomic<long long> g_h3s_launches{0};
 extern "C" long long isc_h3s_launches(void) { return g_h3s_launches.load(); }
 #define H3S_MAX_ROWS 2048
-#define H3S_MAX_ROWS_NN 512     // dX = dY * W: beyond this the fp32 tiles' contraction rate wins over the 32-row tiles' ingest
+#define H3S_MAX_ROWS_NN 2048
 
 template <int EPI>
 static int launch_h3s(const DevLaunch &L, hipStream_t st) {
@@ -2617,6 +2631,86 @@ static int try_h3s(DevLaunch &L, float *ws, long long ws_floats, hipStream_t st,
     rc = launch_h3s<EPI>(L, st);
     ++g_h3s_launches;
     return 1;
+}
+
+// dW = dY^T X (ISC_LAYOUT_TN: both operands are [K_s, .] with the contraction over their ROWS) on the split-f16
+// kernels: planes of dY^T [M, Kp] and X^T [N, Kp] are built by the transposing split into the workspace (both operands
+// are activations: new every call, never cached), then the NT kernels run as for any linear problem - the large tiles,
+// the 64-row tile or the skinny tile by size.  A single-segment problem whose planes exceed the workspace goes through it
+// in K chunks that accumulate into C.  Problems of a launch are handled one by one; returns the bit mask of the problems
+// that went out on this path (the caller runs the others - a segment with K % 32 != 0, a small contraction - on the
+// fp32 tiles); rc != 0 reports a launch error.
+static unsigned try_h3_tn(DevLaunch &L, float *ws, long long ws_floats, hipStream_t st, int &rc) {
+    const int mode = g_h3_mode.load();
+    if (mode == 0 || g_tile_override.load() >= 0 || !ws || ((uintptr_t)ws & 255)) return 0;
+    long long chunk[3];
+    unsigned take = 0;
+    for (int i = 0; i < L.nprob; ++i) {
+        const DevProb &p = L.p[i];
+        long long Kp = 0;
+        bool ok = true;
+        for (int s = 0; s < p.nseg; ++s) {
+            ok = ok && (p.seg[s].K & 31) == 0;
+            Kp += p.seg[s].K;
+        }
+        if (2.0 * p.M * p.N * (double)Kp < 2.5e8 && mode != 2) ok = false;    // small: the fp32 tiles' launch is as quick
+        const long long per_k = (long long)p.M + p.N;
+        chunk[i] = Kp;
+        if (ok && per_k * Kp + 1024 > ws_floats) {
+            chunk[i] = ((ws_floats - 1024) / per_k) & ~31LL;
+            if (p.nseg != 1 || chunk[i] < 512) ok = false;
+        }
+        if (ok) take |= 1u << i;
+    }
+    for (int i = 0; i < L.nprob; ++i) {
+        if (!(take & (1u << i))) continue;
+        const DevProb &p0 = L.p[i];
+        long long Kp = 0;
+        for (int s = 0; s < p0.nseg; ++s) Kp += p0.seg[s].K;
+        for (long long k0 = 0; k0 < Kp; k0 += chunk[i]) {
+            const long long kc = Kp - k0 < chunk[i] ? Kp - k0 : chunk[i];
+            DevLaunch L1 = {};
+            L1.nprob = 1;
+            DevProb &q = L1.p[0];
+            q = p0;
+            if (p0.nseg == 1) {                                   // (multi-segment problems are never chunked)
+                q.seg[0].A = p0.seg[0].A + k0 * p0.seg[0].lda;
+                q.seg[0].W = p0.seg[0].W + k0 * p0.seg[0].ldw;
+                q.seg[0].K = (int)kc;
+            }
+            q.Kp = (int)kc;
+            if (k0 > 0) { q.accumulate = 1; q.bias0 = q.bias1 = q.bias2 = nullptr; }
+            H3Planner pl(ws, nullptr);
+            const _Float16 *ah, *al;
+            pl.add(q, false, q.M, ah, al, 0, -1, 1);
+            pl.add(q, true, q.N, q.Wh, q.Wl, 0, -1, 1);
+            q.nap = 1;
+            q.ap[0] = DevASeg{ah, al, 2 * (int)kc, (int)kc};
+            q.nseg = 1;                                           // the kernels see one packed K-segment
+            q.seg[0].K = (int)kc;
+            q.ksplit = 1;
+            rc = pl.launch(st);
+            if (rc) return take;
+            const long long tiles = (long long)((q.M + 127) / 128) * ((q.N + 127) / 128);
+            if (tiles >= H3_MIN_TILES) {
+                rc = launch_h3_big<EPI_LINEAR>(L1, st);
+            } else if (tiles >= H3_MIN_TILES / 2) {
+                finish_tiling(L1, 1);
+                rc = launch_h3m(L1, st);
+            } else {
+                q.tiles_m = (q.M + 31) / 32;
+                q.tiles_n = (q.N + 31) / 32;
+                q.tile_start = 0;
+                q.m_fastest = 0;
+                q.grp_n = (q.tiles_n + 7) / 8;
+                L1.total_tiles = q.tiles_m * q.tiles_n;
+                rc = launch_h3s<EPI_LINEAR>(L1, st);
+            }
+            if (rc) return take;
+            ++g_h3_launches;
+        }
+    }
+    return take;
 }
 
 // Split-K plan for launches with too few tiles to occupy the chip (small M): every workgroup would
@@ -2717,9 +2811,26 @@ extern "C" int isc_gemm_bwd(const isc_linear_problem *pr, int n_prob, int layout
         d.bias0 = q.bias0; d.bias1 = q.bias1; d.bias2 = q.bias2;
         d.ldc = q.ldc; d.C = q.C; d.accumulate = q.accumulate;
     }
-    if (layout == ISC_LAYOUT_NN) {     // few rows inside a weights scope: skinny split-f16 tiles on planes of W^T
-        int rc = ISC_OK;
-        if (try_h3s<EPI_LINEAR>(L, pr[0].splitk_ws, pr[0].splitk_ws_floats, (hipStream_t)stream, rc, 1)) return rc;
+    int rc_h3 = ISC_OK;
+    bool k32 = true;
+    for (int i = 0; i < n_prob; ++i)
+        for (int s = 0; s < pr[i].nseg; ++s) k32 = k32 && (pr[i].seg[s].K & 31) == 0;
+    if (layout == ISC_LAYOUT_NN && k32 && (h3w_scope_of((hipStream_t)stream) || g_h3_mode.load() >= 2)) {
+        // inside a weights scope (the BPTT sweep): dX = dY W on planes of W^T built once per scope - the skinny tiles for
+        // few rows, the large split-f16 kernels otherwise; dY is read as fp32 rows and split in registers
+        if (try_h3s<EPI_LINEAR>(L, pr[0].splitk_ws, pr[0].splitk_ws_floats, (hipStream_t)stream, rc_h3, 1)) return rc_h3;
+        if (try_h3<EPI_LINEAR>(L, pr[0].splitk_ws, pr[0].splitk_ws_floats, (hipStream_t)stream, rc_h3, 1)) return rc_h3;
+    }
+    if (layout == ISC_LAYOUT_TN) {
+        const unsigned took = try_h3_tn(L, pr[0].splitk_ws, pr[0].splitk_ws_floats, (hipStream_t)stream, rc_h3);
+        if (rc_h3) return rc_h3;
+        if (took) {                                     // the rest of the launch stays on the fp32 tiles
+            int n = 0;
+            for (int i = 0; i < L.nprob; ++i)
+                if (!(took & (1u << i))) { if (n != i) L.p[n] = L.p[i]; ++n; }
+            if (n == 0) return ISC_OK;
+            L.nprob = n;
+        }
     }
     const int S = plan_splitk(L, pr[0].splitk_ws, pr[0].splitk_ws_floats);
     const int tile = S > 1 ? 2 : pick_tile(L, false, false);

@@ -226,3 +226,32 @@ def test_backward_nn_contraction_on_the_skinny_kernel(M, N, K1, K2):
         np.testing.assert_allclose(again.cpu().numpy(), (ref - prior.double()).float().numpy(), atol=3e-5, rtol=1e-5)
         outs[mode] = (out.double().cpu() - ref).pow(2).mean().sqrt().item()
     assert outs[3] <= outs[0] * 1.05 + 1e-9, outs
+
+
+@pytest.mark.parametrize('K1,K2,M,N', [(2560, 0, 2048, 1536), (640, 0, 512, 512), (2560, 128, 2048, 512), (12288, 0, 2048, 2048),
+                                       (1600, 0, 10000, 512)])
+def test_backward_tn_contraction_on_split_f16(K1, K2, M, N):
+    """isc_gemm_bwd, TN layout (dW = dY^T X: both operands [K rows, .]): planes of both TRANSPOSES are built into the
+    workspace and the NT split-f16 kernels contract them - large / 64-row / skinny tiles by size, K chunks that
+    accumulate when the planes exceed the workspace, two K-segments, an output with 10000 rows."""
+    g = torch.Generator().manual_seed(K1 + M)
+    a1, w1 = _rand(g, K1, M), _rand(g, K1, N, scale=K1 ** -0.5)
+    prior = _rand(g, M, N)
+    ref = prior.double() + a1.double().t() @ w1.double()
+    segs = [(a1.to(dev()), w1.to(dev()))]
+    if K2:
+        a2, w2 = _rand(g, K2, M), _rand(g, K2, N, scale=K2 ** -0.5)
+        ref = ref + a2.double().t() @ w2.double()
+        segs.append((a2.to(dev()), w2.to(dev())))
+    errs = {}
+    for mode in (1, 0):
+        ops.set_h3_mode(mode)
+        n0 = ops._lib.load().isc_h3_launches()
+        out = prior.clone().to(dev())
+        ops.gemm_bwd([ops.gemm_problem(segs, out, ops.TN, accumulate=True)], ops.TN)
+        torch.cuda.synchronize()
+        took = ops._lib.load().isc_h3_launches() - n0
+        assert took == ((2 if K1 == 12288 else 1) if mode == 1 else 0), took
+        np.testing.assert_allclose(out.cpu().numpy(), ref.float().numpy(), atol=5e-5, rtol=1e-5)
+        errs[mode] = (out.double().cpu() - ref).pow(2).mean().sqrt().item()
+    assert errs[1] <= errs[0] * 1.05 + 1e-9, errs
