@@ -1,6 +1,7 @@
-"""Random-shape sweep over the forward GEMM entry points (linear / grouped linear / LSTM cell / vocabulary projection)
-with the split-f16 path forced wherever it applies (small launches still take the fp32 split-K / tile routes), each
-case against an fp64 reference: ragged M, K-segments, partial column tiles, grouped problems, producer-written planes.
+"""Random-shape sweep over the GEMM entry points (linear / grouped linear / LSTM cell / vocabulary projection forward;
+the backward NN / TN contractions) with a split-f16 engine forced per case - the large kernels (mode 2), the skinny
+kernel (mode 3), or auto inside a weights scope - each case against an fp64 reference: ragged M, K-segments, partial
+column tiles, grouped problems, producer-written planes, accumulate.
 
     python tools/fuzz_gemm_paths.py [seed] [cases]        (on the MI355X box; tests/test_gpu_fuzz.py runs a short one)
 """
@@ -20,11 +21,14 @@ def run(seed=0, cases=120, verbose=True):
     def R(*s, scale=1.0): return ((torch.rand(*s, generator=g) * 2 - 1) * scale)
     bad = 0
     for it in range(cases):
-        kind = random.choice(['linear', 'lstm', 'vocab', 'linear3'])
+        kind = random.choice(['linear', 'lstm', 'vocab', 'linear3', 'nn', 'tn'])
         M = random.choice([1, 5, 31, 33, 127, 129, 255, 257, 700, 1023, 2050, random.randint(1, 3000)])
         nseg = random.randint(1, 3)
         Ks = [32 * random.randint(1, 16) for _ in range(nseg)]
-        ops.set_h3_mode(2)
+        mode = random.choice([2, 3, 1])
+        ops.set_h3_mode(mode)
+        scope = ops.h3_weights_scope(dev)
+        scope.__enter__()
         try:
             if kind in ('linear', 'linear3'):
                 nprob = 1 if kind == 'linear' else random.randint(2, 3)
@@ -68,6 +72,26 @@ def run(seed=0, cases=120, verbose=True):
                 back = (buf[:, :, 0, :] + buf[:, :, 1, :] / 2048.0).reshape(M, H)
                 perr = (back - h.cpu()).abs().max().item()
                 if not (err < 3e-5 and perr < 1e-6): bad += 1; print('BAD lstm', M, H, Ks, err, perr)
+            elif kind in ('nn', 'tn'):
+                N = 4 * random.randint(1, 300)
+                prior = R(M, N)
+                if kind == 'nn':          # C[M,N] += sum_s A_s[M,K_s] W_s[K_s,N]
+                    As = [R(M, k) for k in Ks]
+                    Ws = [R(k, N, scale=k ** -0.5) for k in Ks]
+                    ref = prior.double() + sum(a.double() @ w.double() for a, w in zip(As, Ws))
+                else:                     # C[M,N] += sum_s A_s[K_s,M]^T W_s[K_s,N]; M % 4 == 0 required
+                    M = max(4, M // 4 * 4)
+                    prior = R(M, N)
+                    As = [R(k, M) for k in Ks]
+                    Ws = [R(k, N, scale=k ** -0.5) for k in Ks]
+                    ref = prior.double() + sum(a.double().t() @ w.double() for a, w in zip(As, Ws))
+                out = prior.clone().to(dev)
+                lay = ops.NN if kind == 'nn' else ops.TN
+                ops.gemm_bwd([ops.gemm_problem([(a.to(dev), w.to(dev)) for a, w in zip(As, Ws)], out, lay,
+                                               accumulate=True)], lay)
+                torch.cuda.synchronize()
+                err = (out.double().cpu() - ref).abs().max().item()
+                if not err < 5e-5: bad += 1; print('BAD', kind, mode, M, N, Ks, err)
             else:
                 V = random.choice([1000, 9487, 10000, 130, 4 * random.randint(40, 3000)])
                 K = Ks[0]
@@ -88,9 +112,12 @@ def run(seed=0, cases=120, verbose=True):
                 if not (err < 5e-5 and lerr < 5e-5 and ok): bad += 1; print('BAD vocab', M, V, K, err, lerr, ok)
         except Exception as e:
             bad += 1; print('EXC', kind, M, Ks, repr(e)[:200])
+        finally:
+            scope.__exit__(None, None, None)
     ops.set_h3_mode(1)
     if verbose:
-        print('cases done, bad =', bad, 'h3 launches', ops._lib.load().isc_h3_launches())
+        print('cases done, bad =', bad, 'large / skinny split-f16 launches', ops._lib.load().isc_h3_launches(),
+              ops._lib.load().isc_h3s_launches())
     return bad
 
 
