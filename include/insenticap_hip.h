@@ -54,12 +54,13 @@ int isc_set_tile_override(int tile);
  * are split into two f16 planes each (x = hi + lo * 2^-11) inside the caller's workspace and contracted with three
  * f16 MFMAs per k-step into fp32 accumulators - fp32 in, fp32 out, error against an fp64 contraction no larger than
  * an fp32 FMA chain's (tests/test_gpu_h3.py), at 2-2.5x the fp32 MFMA rate.  Operand domain |x| < 65504.
- * mode 0 = off (fp32 MFMA tiles only), 1 = auto (default: launches of >= 160 128x128 tiles take the large split-f16
- * kernels; smaller ones take the skinny split-f16 kernel - one launch per GEMM, no split-K slabs - when their stream
- * holds a weights scope, else the fp32 tiles), 2 = the large kernels whenever shapes and workspace allow, 3 = the
- * skinny kernel whenever shapes allow (test hook: without a scope its weight planes go to the workspace).  The planes of a launch must fit the workspace; a linear
- * problem that does not goes through it in row chunks (the prologue's region projections).  A tile override
- * (>= 0) also disables it.  Returns the previous mode. */
+ * mode 0 = off (fp32 MFMA tiles only); 1 = auto (default): on a stream that holds a weights scope a launch takes the
+ * skinny split-f16 kernel (one launch per GEMM, no split-K slabs; 32 x 32 or 64 x 64 tiles, whichever needs fewer
+ * rounds of the chip) while that is at most ~4 rounds of small tiles, else the large split-f16 kernels; without a
+ * scope, launches of >= 160 128x128 tiles take the large kernels and the rest the fp32 tiles; 2 = the large kernels
+ * whenever shapes and workspace allow; 3 / 4 = the skinny kernel with 32 x 32 / 64 x 64 tiles whenever shapes allow
+ * (test hooks: without a scope the weight planes go to the workspace).  The planes of a launch must fit the
+ * workspace.  A tile override (>= 0) also disables the path.  Returns the previous mode. */
 int isc_set_h3_mode(int mode);
 /* Number of launches that went out on the split-f16 path so far (process-wide; measurement / test hook);
  * isc_h3x_launches: those of them that took the 256x128 eight-wave tile (launches of >= 224 such tiles). */

@@ -1779,15 +1779,22 @@ __device__ __forceinline__ void h3s_dma(unsigned lds_addr, const char *src) {
     asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(lds_addr), "v"(src) : "memory");
 }
 
-template <int EPI>
+// T = 2 (K-split epilogues only) doubles the tile to 64 x 64: a loaded row then feeds two MFMA tiles instead of one, so
+// a launch needs half the bytes per output - the shape for launches of several rounds of 32 x 32 tiles (LSTM cell at
+// M = 512 ... 1024) that are still too few 128-row tiles to fill the chip.  Its slots are 16 KB (64-row images), its
+// ring two slots, and a slot is re-issued as soon as its fragments sit in registers (before the MFMAs), so two
+// blocks - 32 KB per wave - stay in flight as in the 4-slot ring of the small tile.
+template <int EPI, int T>
 __global__ __launch_bounds__(256) void gemm_h3s_kernel(const DevLaunch L) {
     constexpr bool KSPLIT = EPI != EPI_VOCAB;
-    constexpr int BM = 32, BN = KSPLIT ? 32 : 128;
+    static_assert(T == 1 || (T == 2 && KSPLIT), "wide skinny tile: K-split epilogues only");
+    constexpr int BM = 32 * T, BN = KSPLIT ? 32 * T : 128;
     // ring depth: 4 slots (three blocks in flight, 128 KB: one workgroup per CU) for the K-split tiles, whose launches
     // have at most ~256 workgroups; 2 slots (64 KB: two workgroups per CU) for the vocabulary projection, whose 79
     // column tiles x row tiles do not fit one round of single-workgroup CUs (316 workgroups at M = 128: 32 -> 17 us)
-    constexpr int R = KSPLIT ? 4 : 2, SLOT = 8192, LDR = 33;
-    extern __shared__ __attribute__((aligned(16))) float smem[];     // 4 waves x R slots x (4 KB A + 4 KB W)
+    constexpr int R = KSPLIT && T == 1 ? 4 : 2, IMG = 4096 * T, SLOT = 2 * IMG, NP = 4 * T, LDR = BN + 1;
+    constexpr bool EARLY = T == 2;                      // slot released after the fragment read, not after the MFMAs
+    extern __shared__ __attribute__((aligned(16))) float smem[];     // 4 waves x R slots x (A image + W image)
     char *lds = reinterpret_cast<char *>(smem);
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1804,18 +1811,18 @@ __global__ __launch_bounds__(256) void gemm_h3s_kernel(const DevLaunch L) {
 
     // DMA lanes: piece p covers image rows 8p + (lane >> 3); lane position lane & 7 fetches chunk pos ^ swizzle(row)
     const int prow = lane >> 3;
-    int a_row[4];
-    const char *w_src[4];
-    int chunk_off[4];
+    int a_row[NP];
+    const char *w_src[NP];
+    int chunk_off[NP];
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
+    for (int p = 0; p < NP; ++p) {
         const int r = 8 * p + prow;
         chunk_off[p] = ((lane & 7) ^ ((r >> 1) & 7)) * 16;
         const int ar = row0 + r;
         a_row[p] = ar < M ? ar : M - 1;                 // rows past the edge fetch a valid row, never stored
         long long wr;
-        if (EPI == EPI_LSTM) {
-            wr = (long long)p * P.H + tn * 8 + prow;    // image row r = gate p, unit tn*8 + prow
+        if (EPI == EPI_LSTM) {                          // image row r = gate r / (8T), unit tn*8T + r % (8T)
+            wr = (long long)(p / T) * P.H + tn * (8 * T) + (p % T) * 8 + prow;
         } else {
             const int c = col0 + cw * 32 + r;
             wr = c < N ? c : N - 1;
@@ -1830,13 +1837,13 @@ __global__ __launch_bounds__(256) void gemm_h3s_kernel(const DevLaunch L) {
     while (cs < P.nap - 1 && cb >= (P.ap[cs].K >> 5)) { cb -= P.ap[cs].K >> 5; ++cs; }
     int seg_blocks = 0;
     bool seg_f32 = false;
-    const char *a_src[4];
+    const char *a_src[NP];
     auto set_aseg = [&](int si) __attribute__((always_inline)) {
         const DevASeg a = P.ap[si];
         seg_blocks = a.K >> 5;
         seg_f32 = a.hi == nullptr;
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
+        for (int p = 0; p < NP; ++p) {
             if (seg_f32)
                 a_src[p] = reinterpret_cast<const char *>(P.seg[si].A + (long long)a_row[p] * P.seg[si].lda) + chunk_off[p];
             else
@@ -1851,57 +1858,87 @@ __global__ __launch_bounds__(256) void gemm_h3s_kernel(const DevLaunch L) {
         const unsigned slot = ring + (i & (R - 1)) * SLOT;
         f32_bits = (f32_bits & ~(1u << (i & (R - 1)))) | ((seg_f32 ? 1u : 0u) << (i & (R - 1)));
 #pragma unroll
-        for (int p = 0; p < 4; ++p) h3s_dma(slot + p * 1024, a_src[p] + (long long)cb * 128);
+        for (int p = 0; p < NP; ++p) h3s_dma(slot + p * 1024, a_src[p] + (long long)cb * 128);
 #pragma unroll
-        for (int p = 0; p < 4; ++p) h3s_dma(slot + 4096 + p * 1024, w_src[p] + (long long)lb * 128);
+        for (int p = 0; p < NP; ++p) h3s_dma(slot + IMG + p * 1024, w_src[p] + (long long)lb * 128);
         ++lb;
         if (++cb >= seg_blocks && cs + 1 < P.nap) { cb = 0; set_aseg(++cs); }
     };
 
-    f32x16 acc0, acc1;
+    f32x16 acc0[T][T], acc1[T][T];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    for (int i = 0; i < T; ++i)
+#pragma unroll
+        for (int j = 0; j < T; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc0[i][j][r] = 0.f; acc1[i][j][r] = 0.f; }
     const int fsw = (fr >> 1) & 7;
-    for (int i = 0; i < R - 1 && i < n; ++i) issue(i);
+    constexpr int AHEAD = EARLY ? R : R - 1;             // blocks issued before the loop / kept ahead of the consumer
+    for (int i = 0; i < AHEAD && i < n; ++i) issue(i);
     for (int i = 0; i < n; ++i) {
-        if (i + R - 1 < n) issue(i + R - 1);             // its slot was consumed in iteration i - 1
-        const int younger = n - 1 - i < R - 1 ? n - 1 - i : R - 1;    // blocks issued after block i
-        if (R > 3 && younger == 3) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-        else if (R > 2 && younger == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        else if (younger == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!EARLY && i + R - 1 < n) issue(i + R - 1);   // its slot was consumed in iteration i - 1
+        const int younger = n - 1 - i < R - 1 ? n - 1 - i : R - 1;    // blocks issued after block i, still in flight
+        if (T == 1) {
+            if (R > 3 && younger == 3) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+            else if (R > 2 && younger == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else if (younger == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            if (younger == 1) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         const char *img = lds + wave * (R * SLOT) + (i & (R - 1)) * SLOT + fr * 128;
         const bool af32 = (f32_bits >> (i & (R - 1))) & 1u;
+        h8 a1[T][2], a2[T][2], b1[T][2], b2[T][2];
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            h8 a1, a2;
-            if (af32) {
-                const float4 v0 = *reinterpret_cast<const float4 *>(img + (((4 * kk + 2 * fh) ^ fsw) * 16));
-                const float4 v1 = *reinterpret_cast<const float4 *>(img + (((4 * kk + 2 * fh + 1) ^ fsw) * 16));
-                const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const _Float16 h = (_Float16)x[e];
-                    a1[e] = h;
-                    a2[e] = (_Float16)((x[e] - (float)h) * 2048.f);
+            for (int t = 0; t < T; ++t) {
+                const char *ia = img + t * 4096;
+                if (af32) {
+                    const float4 v0 = *reinterpret_cast<const float4 *>(ia + (((4 * kk + 2 * fh) ^ fsw) * 16));
+                    const float4 v1 = *reinterpret_cast<const float4 *>(ia + (((4 * kk + 2 * fh + 1) ^ fsw) * 16));
+                    const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const _Float16 h = (_Float16)x[e];
+                        a1[t][kk][e] = h;
+                        a2[t][kk][e] = (_Float16)((x[e] - (float)h) * 2048.f);
+                    }
+                } else {
+                    a1[t][kk] = *reinterpret_cast<const h8 *>(ia + (((2 * kk + fh) ^ fsw) * 16));
+                    a2[t][kk] = *reinterpret_cast<const h8 *>(ia + (((4 + 2 * kk + fh) ^ fsw) * 16));
                 }
-            } else {
-                a1 = *reinterpret_cast<const h8 *>(img + (((2 * kk + fh) ^ fsw) * 16));
-                a2 = *reinterpret_cast<const h8 *>(img + (((4 + 2 * kk + fh) ^ fsw) * 16));
+                const char *iw = img + IMG + t * 4096;
+                b1[t][kk] = *reinterpret_cast<const h8 *>(iw + (((2 * kk + fh) ^ fsw) * 16));
+                b2[t][kk] = *reinterpret_cast<const h8 *>(iw + (((4 + 2 * kk + fh) ^ fsw) * 16));
             }
-            const h8 b1 = *reinterpret_cast<const h8 *>(img + 4096 + (((2 * kk + fh) ^ fsw) * 16));
-            const h8 b2 = *reinterpret_cast<const h8 *>(img + 4096 + (((4 + 2 * kk + fh) ^ fsw) * 16));
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b2, acc1, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2, b1, acc1, 0, 0, 0);
         }
+        if (EARLY) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the fragments are in registers: the slot is free
+            if (i + R < n) issue(i + R);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int ti = 0; ti < T; ++ti)
+#pragma unroll
+                for (int tj = 0; tj < T; ++tj) {
+                    acc0[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[ti][kk], b1[tj][kk], acc0[ti][tj], 0, 0, 0);
+                    acc1[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[ti][kk], b2[tj][kk], acc1[ti][tj], 0, 0, 0);
+                    acc1[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2[ti][kk], b1[tj][kk], acc1[ti][tj], 0, 0, 0);
+                }
     }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc0[r] = fmaf(acc1[r], 1.f / 2048.f, acc0[r]);
+    for (int i = 0; i < T; ++i)
+#pragma unroll
+        for (int j = 0; j < T; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc0[i][j][r] = fmaf(acc1[i][j][r], 1.f / 2048.f, acc0[i][j][r]);
     __syncthreads();                                     // every wave is done with its ring: LDS is free
 
     if constexpr (EPI == EPI_VOCAB) {
-        f32x16 accv[1] = {acc0};
+        f32x16 accv[1] = {acc0[0][0]};
         epi_vocab_frag<1, 4, BM>(P, accv, 0, wave * 32, wave, lane, row0, col0, tn, smem);
         float *smx = smem;
         float *ssm = smem + 4 * BM;
@@ -1933,53 +1970,69 @@ __global__ __launch_bounds__(256) void gemm_h3s_kernel(const DevLaunch L) {
         // partial tile of this wave -> LDS (C/D layout: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5))
         float *mine = smem + wave * (BM * LDR);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) mine[((r & 3) + 8 * (r >> 2) + 4 * fh) * LDR + fr] = acc0[r];
+        for (int i = 0; i < T; ++i)
+#pragma unroll
+            for (int j = 0; j < T; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    mine[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh) * LDR + j * 32 + fr] = acc0[i][j][r];
         __syncthreads();
         auto red = [&](int row, int col) __attribute__((always_inline)) {
             const float *q = smem + row * LDR + col;
             return ((q[0] + q[BM * LDR]) + q[2 * BM * LDR]) + q[3 * BM * LDR];     // fixed order: bit-repeatable
         };
         if constexpr (EPI == EPI_LINEAR) {
-            const int row = tid >> 3, c4 = (tid & 7) * 4;
-            const int gm = row0 + row, gn = col0 + c4;
-            if (gm >= M || gn >= N) return;
-            float o[4], pre[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = red(row, c4 + e);
+            for (int q = 0; q < T * T; ++q) {
+                const int grp = tid + 256 * q;                       // float4 group of the tile
+                const int row = grp / (BN / 4), c4 = (grp % (BN / 4)) * 4;
+                const int gm = row0 + row, gn = col0 + c4;
+                if (gm >= M || gn >= N) continue;
+                float o[4], pre[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int nn = gn + e;
-                pre[e] = 0.f;
-                if (nn < N) {
-                    if (P.bias0) o[e] += P.bias0[nn];
-                    if (P.bias1) o[e] += P.bias1[nn];
-                    if (P.bias2) o[e] += P.bias2[nn];
-                    if (P.accumulate) o[e] += P.C[(long long)gm * P.ldc + nn];
-                    if (P.relu) o[e] = fmaxf(o[e], 0.f);
-                    pre[e] = o[e];
-                    if (P.mask) o[e] = o[e] * (float)P.mask[(long long)gm * N + nn] * P.mask_scale;
+                for (int e = 0; e < 4; ++e) o[e] = red(row, c4 + e);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int nn = gn + e;
+                    pre[e] = 0.f;
+                    if (nn < N) {
+                        if (P.bias0) o[e] += P.bias0[nn];
+                        if (P.bias1) o[e] += P.bias1[nn];
+                        if (P.bias2) o[e] += P.bias2[nn];
+                        if (P.accumulate) o[e] += P.C[(long long)gm * P.ldc + nn];
+                        if (P.relu) o[e] = fmaxf(o[e], 0.f);
+                        pre[e] = o[e];
+                        if (P.mask) o[e] = o[e] * (float)P.mask[(long long)gm * N + nn] * P.mask_scale;
+                    }
                 }
-            }
-            float *dst = P.C + (long long)gm * P.ldc + gn;
-            if ((P.ldc & 3) == 0 && gn + 3 < N) {
-                *reinterpret_cast<float4 *>(dst) = make_float4(o[0], o[1], o[2], o[3]);
-                if (P.C_pre)
-                    *reinterpret_cast<float4 *>(P.C_pre + (long long)gm * P.ldc + gn) =
-                        make_float4(pre[0], pre[1], pre[2], pre[3]);
-            } else {
-                for (int e = 0; e < 4 && gn + e < N; ++e) {
-                    dst[e] = o[e];
-                    if (P.C_pre) P.C_pre[(long long)gm * P.ldc + gn + e] = pre[e];
+                float *dst = P.C + (long long)gm * P.ldc + gn;
+                if ((P.ldc & 3) == 0 && gn + 3 < N) {
+                    *reinterpret_cast<float4 *>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+                    if (P.C_pre)
+                        *reinterpret_cast<float4 *>(P.C_pre + (long long)gm * P.ldc + gn) =
+                            make_float4(pre[0], pre[1], pre[2], pre[3]);
+                } else {
+                    for (int e = 0; e < 4 && gn + e < N; ++e) {
+                        dst[e] = o[e];
+                        if (P.C_pre) P.C_pre[(long long)gm * P.ldc + gn + e] = pre[e];
+                    }
                 }
             }
         } else {
-            const int row = tid >> 3, u = tid & 7;
-            int gm[1] = {row0 + row};
-            bool ok[1] = {gm[0] < M};
-            float g[1][4];
+            constexpr int UN = 8 * T, NR = T * T;                    // units of the tile; rows per thread
+            const int rbase = tid / UN, u = tid % UN;
+            int gm[NR];
+            bool ok[NR];
+            float g[NR][4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) g[0][k] = red(row, k * 8 + u);
-            lstm_cells<1>(P, gm, tn * 8 + u, ok, g);
+            for (int e = 0; e < NR; ++e) {
+                const int row = rbase + e * (256 / UN);
+                gm[e] = row0 + row;
+                ok[e] = gm[e] < M;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) g[e][k] = red(row, k * UN + u);
+            }
+            lstm_cells<NR>(P, gm, tn * UN + u, ok, g);
         }
     }
 }
@@ -2272,16 +2325,17 @@ static void finish_tiling(DevLaunch &L, int tile) {
 }
 
 // ---- split-f16 path (gemm_h3_kernel) ----
-// isc_set_h3_mode: 0 = off, 1 = auto (launches of at least H3_MIN_TILES 128x128 tiles), 2 = whenever the shapes allow
+// isc_set_h3_mode: 0 = off, 1 = auto, 2 = large kernels whenever the shapes allow, 3 / 4 = skinny kernel (32 / 64 tiles)
 static std::atomic<int> g_h3_mode{1};
 static std::atomic<long long> g_h3_launches{0}, g_h3x_launches{0};
 extern "C" long long isc_h3_launches(void) { return g_h3_launches.load(); }
 extern "C" long long isc_h3x_launches(void) { return g_h3x_launches.load(); }
 extern "C" int isc_set_h3_mode(int mode) {
-    if (mode >= 0 && mode <= 3) return g_h3_mode.exchange(mode);
+    if (mode >= 0 && mode <= 4) return g_h3_mode.exchange(mode);
     return g_h3_mode.load();
 }
 #define H3_MIN_TILES 160
+#define H3_MIN_TILES_SCOPE 16
 
 static bool h3_any_f32(const DevLaunch &L) {
     for (int i = 0; i < L.nprob; ++i)
@@ -2525,14 +2579,18 @@ static int try_h3(DevLaunch &L, float *ws, long long ws_floats, hipStream_t st, 
     }
     // linear launches that cannot give every CU a 128-row tile go out on the 64-row H3 tile
     const bool half_tile = EPI == EPI_LINEAR && tiles < 256;
-    if (h3_mode != 2 && tiles < (half_tile ? H3_MIN_TILES / 2 : H3_MIN_TILES)) return 0;
+    H3WScope *scope = h3w_scope_of(st);
+    // inside a weights scope the planes are already there and the skinny kernel has taken what it does better
+    // (try_h3s ran first): whatever is left with a few tiles is still faster here than on the fp32 tiles
+    const long long min_tiles = scope && h3_mode == 1 ? H3_MIN_TILES_SCOPE : (half_tile ? H3_MIN_TILES / 2 : H3_MIN_TILES);
+    if (h3_mode != 2 && tiles < min_tiles) return 0;
     if (need > ws_floats) return 0;
     {
         int jobs = 0;
         for (int i = 0; i < L.nprob; ++i) jobs += 1;
         if (jobs > H3_MAX_JOBS) return 0;
     }
-    H3Planner pl(ws, h3w_scope_of(st));
+    H3Planner pl(ws, scope);
     for (int i = 0; i < L.nprob; ++i) {
         DevProb &p = L.p[i];
         p.Kp = h3_kp(p);
@@ -2556,33 +2614,81 @@ static std::atomic<long long> g_h3s_launches{0};
 extern "C" long long isc_h3s_launches(void) { return g_h3s_launches.load(); }
 #define H3S_MAX_ROWS 2048
 #define H3S_MAX_ROWS_NN 2048
+#define H3S_MAX_WGS_VOCAB 384
 
-template <int EPI>
+template <int EPI, int T>
 static int launch_h3s(const DevLaunch &L, hipStream_t st) {
-    constexpr size_t lds = (size_t)4 * (EPI == EPI_VOCAB ? 2 : 4) * 8192;      // 4 waves x ring slots x 8 KB
+    // 4 waves x ring slots x (A image + W image): 128 KB for the K-split tiles, 64 KB for the vocabulary projection
+    constexpr size_t lds = (size_t)4 * (EPI != EPI_VOCAB && T == 1 ? 4 : 2) * 8192 * T;
     static std::atomic<bool> attr_set{false};
     if (lds > 65536 && !attr_set.load()) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_h3s_kernel<EPI>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_h3s_kernel<EPI, T>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr_set.store(true);
     }
-    hipLaunchKernelGGL((gemm_h3s_kernel<EPI>), dim3(L.total_tiles), dim3(256), lds, st, L);
+    hipLaunchKernelGGL((gemm_h3s_kernel<EPI, T>), dim3(L.total_tiles), dim3(256), lds, st, L);
     ISC_LAUNCH_CHECK();
     return ISC_OK;
 }
 
+// Tile choice of a skinny launch.  One workgroup per CU and every workgroup ingest-bound (~35-40 GB/s per CU), so a
+// launch costs ~4 us + its rounds of the chip x the bytes a workgroup takes in: per k ~6.5 ns for the 32 x 32 tile,
+// twice that for the 64 x 64 tile (four times the outputs), against ~30 ns for a 128 x 128 tile of the large kernels
+// (kernel-trace medians of tools/skinny_bench.py in modes 3 / 4 / 2, M = 128 ... 2048; LSTM cell K = 1536: M = 512
+// 43 / 24 / 41 us, M = 1024 79 / 45 / 53 us, M = 2048 149 / 88 / 61 us).  So: the tile with fewer weighted rounds, and
+// the large kernels past ~4.6 of them.  The vocabulary tile (32 x 128, two workgroups per CU) crosses earlier:
+// M = 128 24 vs 28 us, M = 256 38 vs 22 us.
+// Returns the tile factor T (1 or 2), or 0 when the large kernels should take the launch (auto mode only).
+#define H3S_WIDE_COST 2.0
+#define H3S_MAX_COST 4.6
+template <int EPI>
+static int h3s_pick_tile(const DevLaunch &L, int mode) {
+    long long w1 = 0, w2 = 0;
+    bool wide_ok = EPI != EPI_VOCAB;
+    for (int i = 0; i < L.nprob; ++i) {
+        const DevProb &p = L.p[i];
+        w1 += (long long)((p.M + 31) / 32) * ((p.N + (EPI == EPI_VOCAB ? 127 : 31)) / (EPI == EPI_VOCAB ? 128 : 32));
+        w2 += (long long)((p.M + 63) / 64) * ((p.N + 63) / 64);
+        if (EPI == EPI_LSTM && (p.H & 15)) wide_ok = false;
+    }
+    if (mode == 4) return wide_ok ? 2 : 1;
+    if (mode == 3) return 1;
+    if (EPI == EPI_VOCAB) return w1 < H3S_MAX_WGS_VOCAB ? 1 : 0;
+    const double c1 = (double)((w1 + 255) / 256), c2 = wide_ok ? H3S_WIDE_COST * (double)((w2 + 255) / 256) : 1e30;
+    if ((c1 < c2 ? c1 : c2) >= H3S_MAX_COST) return 0;
+    return c2 < c1 ? 2 : 1;
+}
+
+static void h3s_tile_problem(DevProb &p, int bm, int bn, int &start) {
+    p.ksplit = 1;
+    p.tiles_m = (p.M + bm - 1) / bm;
+    p.tiles_n = (p.N + bn - 1) / bn;
+    p.tile_start = start;
+    p.m_fastest = 0;                                      // tn fastest: neighbouring workgroups share their A rows
+    p.grp_n = (p.tiles_n + 7) / 8;
+    start += p.tiles_m * p.tiles_n;
+}
+
+template <int EPI>
+static int launch_h3s_t(const DevLaunch &L, int T, hipStream_t st) {
+    if constexpr (EPI != EPI_VOCAB) {
+        if (T == 2) return launch_h3s<EPI, 2>(L, st);
+    }
+    return launch_h3s<EPI, 1>(L, st);
+}
+
 // Returns 1 when the launch went out on the skinny path (rc = its status), 0 when it does not apply: mode off / tile
 // override, no weights scope on this stream in auto mode (the weight planes would have to be rebuilt per launch),
-// more rows than H3S_MAX_ROWS, or a launch the large split-f16 kernels take (>= H3_MIN_TILES 128 x 128 tiles).
-// Mode 3 forces it (tests): without a scope the weight planes then go to the workspace.
+// more rows than H3S_MAX_ROWS, or a launch the large split-f16 kernels do better (h3s_pick_tile).
+// Modes 3 / 4 force the 32 x 32 / 64 x 64 tile (tests): without a scope the weight planes then go to the workspace.
 template <int EPI>
 static int try_h3s(DevLaunch &L, float *ws, long long ws_floats, hipStream_t st, int &rc, int transposed = 0) {
     const int mode = g_h3_mode.load();
-    if ((mode != 1 && mode != 3) || g_tile_override.load() >= 0) return 0;
+    if ((mode != 1 && mode != 3 && mode != 4) || g_tile_override.load() >= 0) return 0;
     H3WScope *sc = h3w_scope_of(st);
-    if (!sc && mode != 3) return 0;
-    long long tiles = 0, need = 0;
+    if (!sc && mode == 1) return 0;
+    long long need = 0;
     for (int i = 0; i < L.nprob; ++i) {
         const DevProb &p = L.p[i];
         if (p.M > (transposed ? H3S_MAX_ROWS_NN : H3S_MAX_ROWS)) return 0;
@@ -2591,22 +2697,14 @@ static int try_h3s(DevLaunch &L, float *ws, long long ws_floats, hipStream_t st,
             if (p.seg[sg].K & 31) return 0;                 // (the backward entry point accepts other K)
         const long long Kp = h3_kp(p);
         if (Kp > (1 << 20)) return 0;
-        tiles += (long long)((p.M + 127) / 128) * ((p.N + 127) / 128);
         need += (long long)p.N * Kp + 256;
     }
-    if (mode == 1) {
-        const bool half_tile = EPI == EPI_LINEAR && tiles < 256;
-        if (tiles >= (half_tile ? H3_MIN_TILES / 2 : H3_MIN_TILES)) return 0;      // the large kernels' launch
-    }
+    const int T = h3s_pick_tile<EPI>(L, mode);
+    if (!T) return 0;                                     // the large kernels' launch
     if (!ws || ((uintptr_t)ws & 255) || need > ws_floats) return 0;   // planes that do not fit the scope go here
-    {
-        int jobs = 0;
-        for (int i = 0; i < L.nprob; ++i) jobs += 1;
-        if (jobs > H3_MAX_JOBS) return 0;
-    }
+    if (L.nprob > H3_MAX_JOBS) return 0;
     H3Planner pl(ws, sc);
     int start = 0;
-    constexpr int BN = EPI == EPI_VOCAB ? 128 : 32;
     for (int i = 0; i < L.nprob; ++i) {
         DevProb &p = L.p[i];
         p.Kp = h3_kp(p);
@@ -2617,18 +2715,12 @@ static int try_h3s(DevLaunch &L, float *ws, long long ws_floats, hipStream_t st,
                               p.seg[s].K};
         }
         pl.add_w(p, p.Wh, p.Wl, transposed);
-        p.ksplit = 1;
-        p.tiles_m = (p.M + 31) / 32;
-        p.tiles_n = (p.N + BN - 1) / BN;
-        p.tile_start = start;
-        p.m_fastest = 0;                                  // tn fastest: neighbouring workgroups share their A rows
-        p.grp_n = (p.tiles_n + 7) / 8;
-        start += p.tiles_m * p.tiles_n;
+        h3s_tile_problem(p, 32 * T, EPI == EPI_VOCAB ? 128 : 32 * T, start);
     }
     L.total_tiles = start;
     rc = pl.launch(st);                                   // weight planes not yet in the scope (first use only)
     if (rc) return 1;
-    rc = launch_h3s<EPI>(L, st);
+    rc = launch_h3s_t<EPI>(L, T, st);
     ++g_h3s_launches;
     return 1;
 }
@@ -2698,13 +2790,11 @@ static unsigned try_h3_tn(DevLaunch &L, float *ws, long long ws_floats, hipStrea
                 finish_tiling(L1, 1);
                 rc = launch_h3m(L1, st);
             } else {
-                q.tiles_m = (q.M + 31) / 32;
-                q.tiles_n = (q.N + 31) / 32;
-                q.tile_start = 0;
-                q.m_fastest = 0;
-                q.grp_n = (q.tiles_n + 7) / 8;
-                L1.total_tiles = q.tiles_m * q.tiles_n;
-                rc = launch_h3s<EPI_LINEAR>(L1, st);
+                int T = h3s_pick_tile<EPI_LINEAR>(L1, mode == 2 ? 1 : mode), start = 0;
+                if (!T) T = 2;
+                h3s_tile_problem(q, 32 * T, 32 * T, start);
+                L1.total_tiles = start;
+                rc = launch_h3s_t<EPI_LINEAR>(L1, T, st);
             }
             if (rc) return take;
             ++g_h3_launches;

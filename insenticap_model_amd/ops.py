@@ -137,8 +137,8 @@ def set_tile_override(tile):
 
 
 def set_h3_mode(mode):
-    """Split-f16 GEMM path: 0 = off, 1 = auto (default), 2 = whenever shapes allow (include/insenticap_hip.h);
-    returns the previous mode."""
+    """Split-f16 GEMM path: 0 = off, 1 = auto (default), 2 = large kernels whenever shapes allow, 3 / 4 = skinny kernel
+    with 32 x 32 / 64 x 64 tiles whenever shapes allow (include/insenticap_hip.h); returns the previous mode."""
     return _lib.load().isc_set_h3_mode(int(mode))
 
 

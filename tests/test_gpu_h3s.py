@@ -1,5 +1,5 @@
-"""Skinny split-f16 GEMM path (gemm_h3s_kernel; isc_set_h3_mode(3) forces it, auto mode takes it for few-row launches
-inside a weights scope): one launch per GEMM instead of split-K slabs + a reduce kernel.  Checked against fp64 through
+"""Skinny split-f16 GEMM path (gemm_h3s_kernel; isc_set_h3_mode(3) / (4) force its 32 x 32 / 64 x 64 tile, auto mode
+takes it for few-row launches inside a weights scope): one launch per GEMM instead of split-K slabs + a reduce kernel.  Checked against fp64 through
 every epilogue (linear with bias / ReLU / accumulate / keep-mask / pre-activation copy, LSTM cell with hoisted terms
 and the token table, vocabulary statistics with and without logits), on ragged shapes, mixed plane / fp32 activation
 segments, grouped launches; bit-repeatable; and that auto mode selects it exactly where it should."""
@@ -41,8 +41,9 @@ def _launches():
 
 
 @pytest.mark.parametrize('M,N,K1,K2,planes', [(5, 512, 512, 0, False), (37, 96, 64, 32, True), (128, 520, 512, 512, True),
-                                              (300, 1536, 1024, 0, False), (1, 32, 32, 0, False), (80, 2048, 96, 32, False)])
-def test_linear_skinny_vs_fp64(M, N, K1, K2, planes):
+                                              (300, 1536, 1024, 0, False), (1, 32, 32, 0, False), (80, 2048, 96, 32, False), (1000, 1100, 1536, 64, True)])
+@pytest.mark.parametrize('skinny', [3, 4])
+def test_linear_skinny_vs_fp64(M, N, K1, K2, planes, skinny):
     g = torch.Generator().manual_seed(M * 31 + N)
     x1, w1, b = _rand(g, M, K1), _rand(g, N, K1, scale=K1 ** -0.5), _rand(g, N)
     keep = (torch.rand(M, N, generator=g) > 0.5).to(torch.uint8)
@@ -58,7 +59,7 @@ def test_linear_skinny_vs_fp64(M, N, K1, K2, planes):
     ref_out = ref_pre * keep.double() * 2.0
     outs = []
     for rep in range(2):
-        ops.set_h3_mode(3)
+        ops.set_h3_mode(skinny)
         n0 = _launches()
         out = prior.clone().to(dev())
         pre = torch.full((M, N), float('nan'), device=dev())
@@ -82,14 +83,15 @@ def test_linear_skinny_vs_fp64(M, N, K1, K2, planes):
     assert e3 <= e0 * 1.05 + 1e-9, (e3, e0)
 
 
-def test_linear_grouped_three_problems_one_skinny_launch():
+@pytest.mark.parametrize('skinny', [3, 4])
+def test_linear_grouped_three_problems_one_skinny_launch(skinny):
     g = torch.Generator().manual_seed(4)
     M, K = 100, 512
     x = _rand(g, M, K).to(dev())
     xp = _planes(x)
     ws = [_rand(g, n, K, scale=K ** -0.5).to(dev()) for n in (512, 512, 480)]
     bs = [_rand(g, n).to(dev()) for n in (512, 512, 480)]
-    ops.set_h3_mode(3)
+    ops.set_h3_mode(skinny)
     n0 = _launches()
     outs = [torch.empty(M, w.shape[0], device=dev()) for w in ws]
     ops.linear_fwd([ops.linear_problem([(x, w, xp)], o, b) for w, o, b in zip(ws, outs, bs)])
@@ -102,7 +104,8 @@ def test_linear_grouped_three_problems_one_skinny_launch():
 
 @pytest.mark.parametrize('M,H,with_pre,with_tab', [(5, 64, True, False), (128, 512, True, True), (200, 512, False, False),
                                                    (33, 32, False, False)])
-def test_lstm_skinny(M, H, with_pre, with_tab):
+@pytest.mark.parametrize('skinny', [3, 4])
+def test_lstm_skinny(M, H, with_pre, with_tab, skinny):
     g = torch.Generator().manual_seed(M + H)
     ks = (max(32, H // 32 * 32), 64, 32)
     xs = [_rand(g, M, k) for k in ks]
@@ -124,7 +127,7 @@ def test_lstm_skinny(M, H, with_pre, with_tab):
     h_ref = torch.sigmoid(o) * torch.tanh(c_ref)
     dx = [x.to(dev()) for x in xs]
     dsegs = [(dx[0], ws[0].to(dev()), _planes(dx[0])), (dx[1], ws[1].to(dev())), (dx[2], ws[2].to(dev()), _planes(dx[2]))]
-    ops.set_h3_mode(3)
+    ops.set_h3_mode(skinny)
     n0 = _launches()
     h, c = torch.empty(M, H, device=dev()), torch.empty(M, H, device=dev())
     gates = torch.empty(M, 4 * H, device=dev())
@@ -197,7 +200,8 @@ def test_auto_mode_takes_the_skinny_kernel_only_inside_a_weights_scope():
 
 
 @pytest.mark.parametrize('M,N,K1,K2', [(128, 512, 2048, 0), (80, 1024, 512, 512), (5, 96, 64, 0), (300, 512, 2048, 0)])
-def test_backward_nn_contraction_on_the_skinny_kernel(M, N, K1, K2):
+@pytest.mark.parametrize('skinny', [3, 4])
+def test_backward_nn_contraction_on_the_skinny_kernel(M, N, K1, K2, skinny):
     """isc_gemm_bwd, NN layout (dX = dY W, W as stored [K, N]): inside a weights scope the few-row launches run on the
     skinny kernel over planes of W^T built by the transposing split; accumulate and K-segments included."""
     g = torch.Generator().manual_seed(M + N + K1)
@@ -210,7 +214,7 @@ def test_backward_nn_contraction_on_the_skinny_kernel(M, N, K1, K2):
         ref = ref + dy2.double() @ w2.double()
         segs.append((dy2.to(dev()), w2.to(dev())))
     outs = {}
-    for mode in (3, 0):
+    for mode in (skinny, 0):
         ops.set_h3_mode(mode)
         n0 = _launches()
         out = prior.clone().to(dev())
@@ -221,11 +225,11 @@ def test_backward_nn_contraction_on_the_skinny_kernel(M, N, K1, K2):
             out.copy_(prior)
             ops.gemm_bwd([ops.gemm_problem(segs, out, ops.NN, accumulate=True)], ops.NN)
         torch.cuda.synchronize()
-        assert _launches() - n0 == (3 if mode == 3 else 0)
+        assert _launches() - n0 == (3 if mode == skinny else 0)
         np.testing.assert_allclose(out.cpu().numpy(), ref.float().numpy(), atol=3e-5, rtol=1e-5)
         np.testing.assert_allclose(again.cpu().numpy(), (ref - prior.double()).float().numpy(), atol=3e-5, rtol=1e-5)
         outs[mode] = (out.double().cpu() - ref).pow(2).mean().sqrt().item()
-    assert outs[3] <= outs[0] * 1.05 + 1e-9, outs
+    assert outs[skinny] <= outs[0] * 1.05 + 1e-9, outs
 
 
 @pytest.mark.parametrize('K1,K2,M,N', [(2560, 0, 2048, 1536), (640, 0, 512, 512), (2560, 128, 2048, 512), (12288, 0, 2048, 2048),

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Times the few-row GEMM entry points (the decode step's launches at B <= a few hundred) per launch with HIP events:
     python tools/skinny_bench.py [--mode 3] [--rows 5,32,128,320]
-mode 3 = skinny split-f16 kernel, 0 = fp32 split-K + reduce (what it replaces), 1 = auto."""
+mode 3 / 4 = skinny split-f16 kernel with 32 x 32 / 64 x 64 tiles, 2 = large split-f16 kernels, 0 = fp32 split-K + reduce, 1 = auto."""
 import argparse
 import os
 import sys
