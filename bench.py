@@ -305,11 +305,14 @@ def bench_rl(dev, iters=3, B=512, cache_image_sentiments=True):
 
 def bench_beam(cap, inputs, n_img=64, beam=5):
     """BASELINE.json configs[2]: beam 5, sentiment attention on. Reference API (one image per call)
-    latency and the batched path's throughput."""
+    latency and the batched path's throughput; `hip_graphs`: the same single-image calls served from captured graphs
+    (Captioner.enable_beam_graphs: opt-in, as a serving process would)."""
     fc, att, _, sw, lab = [x[:n_img] for x in inputs]
-    lat, per_step = [], []
-    with torch.no_grad(), no_gc():
-        cap.sample(fc[0], att[0], sw[0], lab[0:1], beam, 1, T)
+
+    def single_image(warm):
+        lat, per_step = [], []
+        for _ in range(warm):
+            cap.sample(fc[0], att[0], sw[0], lab[0:1], beam, 1, T)
         for i in range(16):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -317,30 +320,37 @@ def bench_beam(cap, inputs, n_img=64, beam=5):
             torch.cuda.synchronize()
             lat.append(time.perf_counter() - t0)
             per_step.append(lat[-1] / max(1, cap.last_beam_steps))
+        lat.sort()
+        per_step.sort()
+        return lat, per_step
+
+    def forced_full(warm):
+        # the same search forced through all T steps: with random-init weights captions end early, a trained model's
+        # often do not.  No candidate can end when <EOS> is an id the vocabulary does not contain.
+        eos = cap.eos_id
+        cap.eos_id = -7
+        try:
+            full, _ = single_image(warm)
+            assert cap.last_beam_steps == T
+        finally:
+            cap.eos_id = eos
+        return full
+
+    with torch.no_grad(), no_gc():
+        lat, per_step = single_image(1)
         cap.sample_batch(fc, att, sw, lab, beam, 1, T)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         cap.sample_batch(fc, att, sw, lab, beam, 1, T)
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
-        # the same search forced through all T steps: with random-init weights captions end early, a trained model's
-        # often do not.  No candidate can end when <EOS> is an id the vocabulary does not contain.
-        eos, full = cap.eos_id, []
-        cap.eos_id = -7
+        full = forced_full(1)
+        cap.enable_beam_graphs(True)
         try:
-            cap.sample(fc[0], att[0], sw[0], lab[0:1], beam, 1, T)
-            for i in range(16):
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                cap.sample(fc[i], att[i], sw[i], lab[i:i + 1], beam, 1, T)
-                torch.cuda.synchronize()
-                full.append(time.perf_counter() - t0)
-                assert cap.last_beam_steps == T
+            g_lat, g_step = single_image(3)            # first call eager, second captures, then replays
+            g_full = forced_full(3)
         finally:
-            cap.eos_id = eos
-    lat.sort()
-    per_step.sort()
-    full.sort()
+            cap.enable_beam_graphs(False)
     # latency is bimodal with random-init weights: captions either end after ~9 steps or run all T=20;
     # per_step_p50_us (latency / executed decode steps) is the number to compare between runs
     return dict(beam=beam, per_image_p50_ms=round(lat[len(lat) // 2] * 1e3, 2),
@@ -349,7 +359,11 @@ def bench_beam(cap, inputs, n_img=64, beam=5):
                 per_step_p50_us=round(per_step[len(per_step) // 2] * 1e6, 1),
                 full_search_steps=T, full_search_p50_ms=round(full[len(full) // 2] * 1e3, 2),
                 full_search_p95_ms=round(full[int(len(full) * 0.95) - 1] * 1e3, 2),
-                batched_images=n_img, batched_images_per_s=round(n_img / el, 1))
+                batched_images=n_img, batched_images_per_s=round(n_img / el, 1),
+                hip_graphs=dict(per_image_p50_ms=round(g_lat[len(g_lat) // 2] * 1e3, 2),
+                                per_step_p50_us=round(g_step[len(g_step) // 2] * 1e6, 1),
+                                full_search_p50_ms=round(g_full[len(g_full) // 2] * 1e3, 2),
+                                full_search_p95_ms=round(g_full[int(len(g_full) * 0.95) - 1] * 1e3, 2)))
 
 
 PMC_SUMMARY = os.path.join(ROOT, 'profiles', 'r02_c_pmc_summary_B4096.json')

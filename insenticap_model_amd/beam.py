@@ -135,140 +135,234 @@ class _VectorMerge:
 
 
 def beam_search_batch(cap, fc_feats, att_feats, senti_words, senti_labels, beam, decoding_constraint, T):
-    p = cap._p()
-    n_img = fc_feats.shape[0]
-    P = cap._prologue(p, 'beam', fc_feats, att_feats, None, senti_words,
-                      senti_labels if senti_words is not None else None, want_table='build',
-                      words_table=getattr(cap, 'words_table', True))
-    dev = cap._dev
-    H, Wd, V = cap.att_lstm.hidden_size, cap.settings['word_emb_dim'], cap.vocab_size
-    rows = n_img * beam
-    # expand the step-invariant tensors to one copy per beam row (row = img*beam + k)
-    rep = torch.arange(n_img, device=dev).repeat_interleave(beam)
-
-    def expand(x):
-        return None if x is None else x.index_select(0, rep).contiguous()
-    Pb = type(P)()
-    Pb.B, Pb.R, Pb.Mw = rows, P.R, P.Mw
-    for name in ('fc_e', 'att_e3', 'att_p3', 'words_e3', 'words_p3', 'label_e', 'label_w', 'pre1'):
-        if P.words_ids is not None and name in ('words_e3', 'words_p3'):
-            setattr(Pb, name, getattr(P, name))           # shared [V,.] tables: only the ids are per row
-        else:
-            setattr(Pb, name, expand(getattr(P, name)))
-    Pb.words_ids = expand(P.words_ids)
-    Pb.tab = P.tab
-    ws = cap._alloc_step_ws(rows, Pb)
-    # recurrent state as ONE tensor [h|c, layer, row, H] per buffer: the per-step beam re-ordering is then a
-    # single gather over [next ; current] rows instead of four index_selects and two wheres
-    st_cur = cap._zeros(2, 2, rows, H)
-    st_nxt = cap._new(2, 2, rows, H)
-    logits = cap._new(rows, V)
-    xt = cap._new(rows, Wd)
-    # top-k ids and values share one byte buffer: ONE device->host copy per step (ids first: 8-byte aligned)
-    nk = rows * beam
-    top_buf = torch.empty(nk * 12, dtype=torch.uint8, device=dev)
-    top_idx = top_buf[:nk * 8].view(torch.int64).view(rows, beam)
-    top_val = top_buf[nk * 8:].view(torch.float32).view(rows, beam)
-    emb = p['word_embed.0.weight']
-    mask_special = cap.pad_id != cap.eos_id
-
-    cap.last_beam_steps = 0                    # decode steps executed (bench.py: latency per step)
-    if getattr(cap, 'beam_device_merge', True) and beam <= 8:
-        return _search_device_merge(cap, p, Pb, ws, st_cur, st_nxt, logits, xt, emb, top_val, top_idx, n_img, beam, T,
-                                    decoding_constraint, mask_special)
-    merge = _VectorMerge(n_img, beam, T, cap.sos_id, cap.eos_id) if n_img >= 4 else \
-        _ListMerge(n_img, beam, cap.sos_id, cap.eos_id)
-    ctrl_h = torch.empty(2, rows, dtype=torch.int64).pin_memory()     # [last word ; gather index], one upload per step
-    ctrl_np = ctrl_h.numpy()
-    ctrl_np[0, :] = cap.sos_id
-    ctrl_d = ctrl_h.to(dev, non_blocking=True)
-    with ops.h3_weights_scope(dev):               # frozen weights: their f16 planes are built once per search
-        for t in range(T):
-            cap.last_beam_steps = t + 1
-            last_d = ctrl_d[0]
-            h_cur, c_cur, h_nxt, c_nxt = st_cur[0], st_cur[1], st_nxt[0], st_nxt[1]
-            if Pb.tab is None:
-                ops.embed_relu_fwd(emb, last_d, xt)
-            cap._step(p, Pb, ws, xt, h_cur, c_cur, h_nxt, c_nxt, logits=logits, tok=last_d)
-            ops.beam_topk(logits, ws['pmax'], ws['psum'], last_d, beam, cap.pad_id, cap.sos_id, cap.unk_id,
-                          mask_special, decoding_constraint, top_val, top_idx)
-            hb = top_buf.cpu().numpy()        # the single host read of this step
-            ti = hb[:nk * 8].view(np.int64).reshape(rows, beam)
-            tv = hb[nk * 8:].view(np.float32).reshape(rows, beam)
-            # new state of row r = stepped ? nxt[parent] : cur[parent]  ==  [nxt ; cur][parent + (stepped ? 0 : rows)]
-            any_live = merge.step(t, ti, tv, ctrl_np[0], ctrl_np[1])
-            if not any_live:
-                break
-            ctrl_d = ctrl_h.to(dev, non_blocking=True)
-            st_cur = torch.cat([st_nxt, st_cur], dim=2).index_select(2, ctrl_d[1])
-    cap.cont_weights, cap.senti_weights, cap.cont_senti_weights = [], [], []
-    captions, scores, ids = [], [], []
-    for i, cands in enumerate(merge.result()):
-        captions.append([' '.join(cap.idx2word[w] for w in words if w != cap.eos_id) for (_, words) in cands])
-        scores.append([s for (s, _) in cands])
-        ids.append([list(words) for (_, words) in cands])
-    return captions, scores, ids
+    if (cap.__dict__.get('_beam_graphs') is not None and getattr(cap, 'beam_device_merge', True) and beam <= 8
+            and ops.TIMER.arm_step is None):
+        return _graphed_search(cap, fc_feats, att_feats, senti_words, senti_labels, beam, decoding_constraint, T)
+    return _search(cap, fc_feats, att_feats, senti_words, senti_labels, beam, decoding_constraint, T)
 
 
-def _search_device_merge(cap, p, Pb, ws, st_cur, st_nxt, logits, xt, emb, top_val, top_idx, n_img, beam, T,
-                         decoding_constraint, mask_special):
-    """The search loop with the candidate merge on the device: nothing is read back until the end, except the
-    live-image counter every fourth step (the reference's early exit, captioner.py:379-381)."""
-    from ._lib import BeamMergeArgs
-    dev, rows = cap._dev, n_img * beam
-    score = [torch.zeros(rows, dtype=torch.float64, device=dev) for _ in range(2)]
-    last = [torch.full((rows,), cap.sos_id, dtype=torch.int64, device=dev) for _ in range(2)]
-    words = [torch.zeros(rows, T, dtype=torch.int64, device=dev) for _ in range(2)]
-    length = [torch.zeros(rows, dtype=torch.int32, device=dev) for _ in range(2)]
-    done = torch.zeros(n_img, dtype=torch.int32, device=dev)
-    gather = torch.empty(rows, dtype=torch.int64, device=dev)
-    live = torch.zeros(T + 1, dtype=torch.int32, device=dev)
-    a = BeamMergeArgs()
-    a.n_img, a.beam, a.T, a.eos_id = n_img, beam, T, cap.eos_id
-    a.top_val, a.top_idx = top_val.data_ptr(), top_idx.data_ptr()
-    a.done, a.gather, a.live = done.data_ptr(), gather.data_ptr(), live.data_ptr()
-    st_free = torch.empty_like(st_cur)         # third state buffer: target of the per-step re-ordering
-    cur = 0
-    with ops.h3_weights_scope(dev):
-        for t in range(T):
-            cap.last_beam_steps = t + 1
-            last_d = last[cur]
-            h_cur, c_cur, h_nxt, c_nxt = st_cur[0], st_cur[1], st_nxt[0], st_nxt[1]
-            if Pb.tab is None:
-                ops.embed_relu_fwd(emb, last_d, xt)
-            cap._step(p, Pb, ws, xt, h_cur, c_cur, h_nxt, c_nxt, logits=logits, tok=last_d)
-            ops.beam_topk(logits, ws['pmax'], ws['psum'], last_d, beam, cap.pad_id, cap.sos_id, cap.unk_id,
-                          mask_special, decoding_constraint, top_val, top_idx)
-            nxt = cur ^ 1
-            a.t = t
-            a.score_in, a.score_out = score[cur].data_ptr(), score[nxt].data_ptr()
-            a.last_in, a.last_out = last[cur].data_ptr(), last[nxt].data_ptr()
-            a.words_in, a.words_out = words[cur].data_ptr(), words[nxt].data_ptr()
-            a.len_in, a.len_out = length[cur].data_ptr(), length[nxt].data_ptr()
-            ops.beam_merge(a)
-            cur = nxt
-            if (t & 3) == 3 or t == T - 1:
-                if int(live[t + 1].item()) == 0:          # the one host read: every image has finished
+def _search(cap, fc_feats, att_feats, senti_words, senti_labels, beam, decoding_constraint, T):
+    s = _Search(cap, fc_feats, att_feats, senti_words, senti_labels, beam, decoding_constraint, T)
+    if s.device_merge:
+        with ops.h3_weights_scope(cap._dev):
+            for t in range(T):
+                s.step(t)
+                if ((t & 3) == 3 or t == T - 1) and s.all_done(t):     # the one host read, every fourth step
                     break
-            # new state of row r = stepped ? nxt[parent] : cur[parent]  ==  [nxt ; cur][gather[r]]
-            ops.beam_gather(st_nxt, st_cur, gather, st_free)
-            st_cur, st_free = st_free, st_cur
-    cap.cont_weights, cap.senti_weights, cap.cont_senti_weights = [], [], []
-    sc = score[cur].view(n_img, beam).cpu().tolist()
-    wd = words[cur].view(n_img, beam, T).cpu().numpy()
-    ln = length[cur].view(n_img, beam).cpu().numpy()
-    # executed steps as the reference counts them: up to and including the step after which nobody was live
-    lv = live.cpu().numpy()
-    steps = cap.last_beam_steps
-    for t in range(steps):
-        if lv[t + 1] == 0:
-            steps = t + 1
+        return s.finish()
+    return s.run_host_merge()
+
+
+CHUNK = 4          # decode steps per captured graph = steps between two looks at the live-image counter
+
+
+def _graphed_search(cap, fc_feats, att_feats, senti_words, senti_labels, beam, decoding_constraint, T):
+    """The search served from captured HIP graphs (Captioner.enable_beam_graphs).  A single-image beam-5 step is
+    ~14 small launches behind four FFI calls and the host needs longer to enqueue them than the device to run them;
+    the loop has no host read except the live-image counter every CHUNK steps, so the prologue + steps 0..3 capture
+    into one graph and every further CHUNK steps into another (one pool, buffers shared): a search costs one input copy,
+    <= ceil(T / CHUNK) graph launches with one counter read between them, and the read-back."""
+    dev = cap._dev
+    ins = [cap._f32(fc_feats), cap._f32(att_feats), senti_words, senti_labels]
+    versions = tuple(q._version for q in (cap.word_embed[0].weight, cap.att_lstm.weight_ih, cap.senti2att[0].weight,
+                                          cap.senti2att[0].bias))
+    key = (tuple(None if x is None else (tuple(x.shape), x.dtype) for x in ins), beam, decoding_constraint, T, versions,
+           ops.WEIGHT_EPOCH, cap.eos_id, torch.cuda.current_device())
+    cache = cap._beam_graphs
+    entry = cache.get(key)
+    if entry is None:                       # first sight: run eagerly (builds the cached tables, warms the kernels)
+        while len(cache) >= cap._beam_graphs_max:
+            cache.pop(next(iter(cache)))
+        cache[key] = 'seen'
+        return _search(cap, *ins, beam, decoding_constraint, T)
+    if entry == 'seen':
+        static = [None if x is None else x.clone() for x in ins]
+        ws = torch.empty(ops.SPLITK_WS_FLOATS, dtype=torch.float32, device=dev)
+        wp = torch.empty(ops.H3W_BYTES, dtype=torch.uint8, device=dev)
+        stream = torch.cuda.Stream(device=dev)
+        pool = torch.cuda.graph_pool_handle()
+        graphs = []
+        torch.cuda.synchronize()
+        ops.WS_OVERRIDE, ops.H3W_OVERRIDE = ws, wp
+        try:
+            with torch.cuda.stream(stream):
+                scope = ops.h3_weights_scope(dev)      # ONE scope over all the captures (its planes live in `wp`,
+                scope.__enter__()                      # are split inside graph 0 and read by the later graphs)
+                try:
+                    search = None
+                    for t0 in range(0, T, CHUNK):
+                        g = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(g, pool=pool, stream=stream):
+                            if search is None:
+                                search = _Search(cap, *static, beam, decoding_constraint, T)
+                            for t in range(t0, min(t0 + CHUNK, T)):
+                                search.step(t)
+                        graphs.append(g)
+                finally:
+                    scope.__exit__(None, None, None)
+        finally:
+            ops.WS_OVERRIDE = ops.H3W_OVERRIDE = None
+        entry = cache[key] = (graphs, static, search, ws, wp, pool)
+    graphs, static, search = entry[:3]
+    for dst, src in zip(static, ins):
+        if dst is not None:
+            dst.copy_(src, non_blocking=True)
+    for i, g in enumerate(graphs):
+        g.replay()
+        t = min((i + 1) * CHUNK, T) - 1
+        cap.last_beam_steps = t + 1
+        if search.all_done(t):
             break
-    cap.last_beam_steps = steps
-    captions, scores, ids = [], [], []
-    for i in range(n_img):
-        cand = [wd[i, k, :ln[i, k]].tolist() for k in range(beam)]
-        captions.append([' '.join(cap.idx2word[w] for w in words_k if w != cap.eos_id) for words_k in cand])
-        scores.append([float(x) for x in sc[i]])
-        ids.append(cand)
-    return captions, scores, ids
+    return search.finish()
+
+
+class _Search:
+    """State of one batched search: the prologue, the per-row copies, the device-side candidate table; step(t)
+    enqueues decode step t (preceded by the state re-ordering that step t - 1 decided)."""
+
+    def __init__(self, cap, fc_feats, att_feats, senti_words, senti_labels, beam, decoding_constraint, T):
+        p = cap._p()
+        n_img = fc_feats.shape[0]
+        P = cap._prologue(p, 'beam', fc_feats, att_feats, None, senti_words,
+                          senti_labels if senti_words is not None else None, want_table='build',
+                          words_table=getattr(cap, 'words_table', True))
+        dev = cap._dev
+        H, Wd, V = cap.att_lstm.hidden_size, cap.settings['word_emb_dim'], cap.vocab_size
+        rows = n_img * beam
+        # expand the step-invariant tensors to one copy per beam row (row = img*beam + k)
+        rep = torch.arange(n_img, device=dev).repeat_interleave(beam)
+
+        def expand(x):
+            return None if x is None else x.index_select(0, rep).contiguous()
+        Pb = type(P)()
+        Pb.B, Pb.R, Pb.Mw = rows, P.R, P.Mw
+        for name in ('fc_e', 'att_e3', 'att_p3', 'words_e3', 'words_p3', 'label_e', 'label_w', 'pre1'):
+            if P.words_ids is not None and name in ('words_e3', 'words_p3'):
+                setattr(Pb, name, getattr(P, name))           # shared [V,.] tables: only the ids are per row
+            else:
+                setattr(Pb, name, expand(getattr(P, name)))
+        Pb.words_ids = expand(P.words_ids)
+        Pb.tab = P.tab
+        self.cap, self.p, self.Pb = cap, p, Pb
+        self.n_img, self.beam, self.T, self.rows, self.dc = n_img, beam, T, rows, decoding_constraint
+        self.ws = cap._alloc_step_ws(rows, Pb)
+        # recurrent state as ONE tensor [h|c, layer, row, H] per buffer: the per-step beam re-ordering is then a
+        # single gather over [next ; current] rows instead of four index_selects and two wheres
+        self.st_cur = cap._zeros(2, 2, rows, H)
+        self.st_nxt = cap._new(2, 2, rows, H)
+        self.logits = cap._new(rows, V)
+        self.xt = cap._new(rows, Wd)
+        # top-k ids and values share one byte buffer: ONE device->host copy per step (ids first: 8-byte aligned)
+        nk = self.nk = rows * beam
+        self.top_buf = torch.empty(nk * 12, dtype=torch.uint8, device=dev)
+        self.top_idx = self.top_buf[:nk * 8].view(torch.int64).view(rows, beam)
+        self.top_val = self.top_buf[nk * 8:].view(torch.float32).view(rows, beam)
+        self.emb = p['word_embed.0.weight']
+        self.mask_special = cap.pad_id != cap.eos_id
+        cap.last_beam_steps = 0                    # decode steps executed (bench.py: latency per step)
+        self.device_merge = getattr(cap, 'beam_device_merge', True) and beam <= 8
+        if self.device_merge:
+            from ._lib import BeamMergeArgs
+            self.score = [torch.zeros(rows, dtype=torch.float64, device=dev) for _ in range(2)]
+            self.last = [torch.full((rows,), cap.sos_id, dtype=torch.int64, device=dev) for _ in range(2)]
+            self.words = [torch.zeros(rows, T, dtype=torch.int64, device=dev) for _ in range(2)]
+            self.length = [torch.zeros(rows, dtype=torch.int32, device=dev) for _ in range(2)]
+            self.done = torch.zeros(n_img, dtype=torch.int32, device=dev)
+            self.gather = torch.empty(rows, dtype=torch.int64, device=dev)
+            self.live = torch.zeros(T + 1, dtype=torch.int32, device=dev)
+            a = self.args = BeamMergeArgs()
+            a.n_img, a.beam, a.T, a.eos_id = n_img, beam, T, cap.eos_id
+            a.top_val, a.top_idx = self.top_val.data_ptr(), self.top_idx.data_ptr()
+            a.done, a.gather, a.live = self.done.data_ptr(), self.gather.data_ptr(), self.live.data_ptr()
+            self.st_free = torch.empty_like(self.st_cur)   # third state buffer: target of the per-step re-ordering
+            self.cur = 0
+
+    def step(self, t):
+        """Decode step t on the device-side candidate table: nothing is read back (the reference's early exit,
+        captioner.py:379-381, is the caller's look at the live-image counter every fourth step)."""
+        cap, a = self.cap, self.args
+        if t > 0:
+            # new state of row r = stepped ? nxt[parent] : cur[parent]  ==  [nxt ; cur][gather[r]]
+            ops.beam_gather(self.st_nxt, self.st_cur, self.gather, self.st_free)
+            self.st_cur, self.st_free = self.st_free, self.st_cur
+        cap.last_beam_steps = t + 1
+        cur = self.cur
+        last_d = self.last[cur]
+        h_cur, c_cur, h_nxt, c_nxt = self.st_cur[0], self.st_cur[1], self.st_nxt[0], self.st_nxt[1]
+        if self.Pb.tab is None:
+            ops.embed_relu_fwd(self.emb, last_d, self.xt)
+        cap._step(self.p, self.Pb, self.ws, self.xt, h_cur, c_cur, h_nxt, c_nxt, logits=self.logits, tok=last_d)
+        ops.beam_topk(self.logits, self.ws['pmax'], self.ws['psum'], last_d, self.beam, cap.pad_id, cap.sos_id,
+                      cap.unk_id, self.mask_special, self.dc, self.top_val, self.top_idx)
+        nxt = cur ^ 1
+        a.t = t
+        a.score_in, a.score_out = self.score[cur].data_ptr(), self.score[nxt].data_ptr()
+        a.last_in, a.last_out = self.last[cur].data_ptr(), self.last[nxt].data_ptr()
+        a.words_in, a.words_out = self.words[cur].data_ptr(), self.words[nxt].data_ptr()
+        a.len_in, a.len_out = self.length[cur].data_ptr(), self.length[nxt].data_ptr()
+        ops.beam_merge(a)
+        self.cur = nxt
+
+    def all_done(self, t):
+        return int(self.live[t + 1].item()) == 0
+
+    def finish(self):
+        cap, n_img, beam, T = self.cap, self.n_img, self.beam, self.T
+        cap.cont_weights, cap.senti_weights, cap.cont_senti_weights = [], [], []
+        # the tables of the last EXECUTED step: a replayed graph chain may stop before the step the capture ended on
+        steps = cap.last_beam_steps
+        cur = steps & 1                             # step t writes buffer (t + 1) & 1
+        sc = self.score[cur].view(n_img, beam).cpu().tolist()
+        wd = self.words[cur].view(n_img, beam, T).cpu().numpy()
+        ln = self.length[cur].view(n_img, beam).cpu().numpy()
+        # executed steps as the reference counts them: up to and including the step after which nobody was live
+        lv = self.live.cpu().numpy()
+        for t in range(steps):
+            if lv[t + 1] == 0:
+                steps = t + 1
+                break
+        cap.last_beam_steps = steps
+        captions, scores, ids = [], [], []
+        for i in range(n_img):
+            cand = [wd[i, k, :ln[i, k]].tolist() for k in range(beam)]
+            captions.append([' '.join(cap.idx2word[w] for w in words_k if w != cap.eos_id) for words_k in cand])
+            scores.append([float(x) for x in sc[i]])
+            ids.append(cand)
+        return captions, scores, ids
+
+    def run_host_merge(self):
+        cap, p, Pb, ws, T = self.cap, self.p, self.Pb, self.ws, self.T
+        n_img, beam, rows, nk, dev = self.n_img, self.beam, self.rows, self.nk, cap._dev
+        st_cur, st_nxt, logits, xt, emb, top_buf = self.st_cur, self.st_nxt, self.logits, self.xt, self.emb, self.top_buf
+        merge = _VectorMerge(n_img, beam, T, cap.sos_id, cap.eos_id) if n_img >= 4 else \
+            _ListMerge(n_img, beam, cap.sos_id, cap.eos_id)
+        ctrl_h = torch.empty(2, rows, dtype=torch.int64).pin_memory()     # [last word ; gather index], one upload per step
+        ctrl_np = ctrl_h.numpy()
+        ctrl_np[0, :] = cap.sos_id
+        ctrl_d = ctrl_h.to(dev, non_blocking=True)
+        with ops.h3_weights_scope(dev):               # frozen weights: their f16 planes are built once per search
+            for t in range(T):
+                cap.last_beam_steps = t + 1
+                last_d = ctrl_d[0]
+                h_cur, c_cur, h_nxt, c_nxt = st_cur[0], st_cur[1], st_nxt[0], st_nxt[1]
+                if Pb.tab is None:
+                    ops.embed_relu_fwd(emb, last_d, xt)
+                cap._step(p, Pb, ws, xt, h_cur, c_cur, h_nxt, c_nxt, logits=logits, tok=last_d)
+                ops.beam_topk(logits, ws['pmax'], ws['psum'], last_d, beam, cap.pad_id, cap.sos_id, cap.unk_id,
+                              self.mask_special, self.dc, self.top_val, self.top_idx)
+                hb = top_buf.cpu().numpy()        # the single host read of this step
+                ti = hb[:nk * 8].view(np.int64).reshape(rows, beam)
+                tv = hb[nk * 8:].view(np.float32).reshape(rows, beam)
+                # new state of row r = stepped ? nxt[parent] : cur[parent]  ==  [nxt ; cur][parent + (stepped ? 0 : rows)]
+                any_live = merge.step(t, ti, tv, ctrl_np[0], ctrl_np[1])
+                if not any_live:
+                    break
+                ctrl_d = ctrl_h.to(dev, non_blocking=True)
+                st_cur = torch.cat([st_nxt, st_cur], dim=2).index_select(2, ctrl_d[1])
+        cap.cont_weights, cap.senti_weights, cap.cont_senti_weights = [], [], []
+        captions, scores, ids = [], [], []
+        for i, cands in enumerate(merge.result()):
+            captions.append([' '.join(cap.idx2word[w] for w in words if w != cap.eos_id) for (_, words) in cands])
+            scores.append([s for (s, _) in cands])
+            ids.append([list(words) for (_, words) in cands])
+        return captions, scores, ids

@@ -627,6 +627,14 @@ class Captioner(nn.Module):
         self._weights_pending = pending          # attention weights of this replay (resolved lazily, as always)
         return tuple(o.clone() for o in outs)
 
+    def enable_beam_graphs(self, on=True, max_graphs=4):
+        """Serve beam searches (sample / sample_batch, device-side merge) from captured HIP graphs: the prologue and
+        steps 0-3 in one graph, every further four steps in another, the live-image counter read between them
+        (beam.py: _graphed_search).  Inputs must keep their shapes to hit the cache; weights may change in place
+        (a change of the embedding / att-LSTM / senti2att weights re-captures: the cached tables depend on them)."""
+        self._beam_graphs = {} if on else None
+        self._beam_graphs_max = max_graphs
+
     def _weights_key(self):
         """Identifies the current parameter VALUES (storage pointers + version counters + the epoch bumped by the fused
         optimizer, which writes behind torch's back): equal keys => the f16 weight planes of an earlier call are

@@ -388,6 +388,56 @@ def test_beam_device_merge_equals_host_merge():
         cap.beam_device_merge = True
 
 
+def test_beam_search_from_hip_graphs_equals_the_eager_search():
+    """Captioner.enable_beam_graphs: prologue + steps 0-3 in one captured graph, every further four steps in another.
+    Replays must return bit-identical captions, ids, fp64 scores and executed-step counts as the eager search: for
+    images whose searches end early and late, for a search forced through all 20 steps, for a 3-image batch, and again
+    after the weights changed in place (the planes are re-split inside graph 0)."""
+    cap, c, st, w, _, _ = make_captioner('cfg1')
+    n, Tn = 8, 20
+    d = synth.make_inputs(n, c['V'], st, regions=36, seq_len=Tn, seed=77)
+    fc, att, sw, lab = T(d, 'fc_feats'), T(d, 'att_feats'), T(d, 'senti_words'), T(d, 'senti_labels')
+
+    def search(sl, beam=5):
+        out = cap.sample_batch(fc[sl], att[sl], sw[sl], lab[sl], beam, 1, Tn)
+        return out, cap.last_beam_steps
+    cases = [slice(i, i + 1) for i in range(n)] + [slice(0, 3)]
+    eos = cap.eos_id
+    try:
+        eager = [search(sl) for sl in cases]
+        cap.eos_id = -7
+        eager_full = search(cases[0])
+        cap.eos_id = eos
+        assert eager_full[1] == Tn and len({e[1] for e in eager}) > 1      # searches of different lengths in the set
+        cap.enable_beam_graphs(True, max_graphs=4)
+        for rep in range(3):                                   # eager first sight, capture, replay
+            for sl, ref in zip(cases, eager):
+                got = search(sl)
+                assert got[0][0] == ref[0][0] and got[0][2] == ref[0][2], (rep, sl)
+                np.testing.assert_array_equal(np.asarray(got[0][1]), np.asarray(ref[0][1]))
+                assert got[1] == ref[1], (rep, sl, got[1], ref[1])
+        cap.eos_id = -7
+        for rep in range(3):
+            got = search(cases[0])
+            assert got[0][0] == eager_full[0][0] and got[1] == Tn
+            np.testing.assert_array_equal(np.asarray(got[0][1]), np.asarray(eager_full[0][1]))
+        cap.eos_id = eos
+        # weights change in place (not the table-defining ones): same graphs, new planes
+        with torch.no_grad():
+            cap.classifier.weight.mul_(1.03)
+        graphs, cap._beam_graphs = cap._beam_graphs, None      # eager reference with the new weights ...
+        ref2 = search(cases[1])
+        cap._beam_graphs = graphs                              # ... then the graphs captured with the old ones
+        assert ref2[0][1] != eager[1][0][1]
+        for rep in range(2):
+            got = search(cases[1])
+            assert got[0][0] == ref2[0][0] and got[1] == ref2[1]
+            np.testing.assert_array_equal(np.asarray(got[0][1]), np.asarray(ref2[0][1]))
+    finally:
+        cap.eos_id = eos
+        cap.enable_beam_graphs(False)
+
+
 @pytest.mark.parametrize('rows,V,beam', [(5, 10000, 5), (7, 9487, 3), (3, 130, 8), (2, 10000, 12)])
 def test_beam_topk_kernel_order_ties_and_masks(rows, V, beam):
     """isc_beam_topk (single-pass kernel for beam <= 8, round-based above): top-`beam` of the masked log-probs in

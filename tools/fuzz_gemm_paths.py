@@ -1,6 +1,6 @@
 """Random-shape sweep over the GEMM entry points (linear / grouped linear / LSTM cell / vocabulary projection forward;
 the backward NN / TN contractions) with a split-f16 engine forced per case - the large kernels (mode 2), the skinny
-kernel (mode 3), or auto inside a weights scope - each case against an fp64 reference: ragged M, K-segments, partial
+kernel with 32 x 32 or 64 x 64 tiles (modes 3 / 4), or auto inside a weights scope - each case against an fp64 reference: ragged M, K-segments, partial
 column tiles, grouped problems, producer-written planes, accumulate.
 
     python tools/fuzz_gemm_paths.py [seed] [cases]        (on the MI355X box; tests/test_gpu_fuzz.py runs a short one)
@@ -25,7 +25,7 @@ def run(seed=0, cases=120, verbose=True):
         M = random.choice([1, 5, 31, 33, 127, 129, 255, 257, 700, 1023, 2050, random.randint(1, 3000)])
         nseg = random.randint(1, 3)
         Ks = [32 * random.randint(1, 16) for _ in range(nseg)]
-        mode = random.choice([2, 3, 1])
+        mode = random.choice([2, 3, 4, 1])
         ops.set_h3_mode(mode)
         scope = ops.h3_weights_scope(dev)
         scope.__enter__()
