@@ -2665,7 +2665,9 @@ static void h3s_tile_problem(DevProb &p, int bm, int bn, int &start) {
     p.tiles_m = (p.M + bm - 1) / bm;
     p.tiles_n = (p.N + bn - 1) / bn;
     p.tile_start = start;
-    p.m_fastest = 0;                                      // tn fastest: neighbouring workgroups share their A rows
+    // One slice of the column tiles per XCD (map_tile's grouped order) once there are several row tiles: the XCD's
+    // workgroups then share a weight slice of 1/8 that its L2 keeps, instead of every XCD streaming most of W.
+    p.m_fastest = p.tiles_m > 1 ? 1 : 0;
     p.grp_n = (p.tiles_n + 7) / 8;
     start += p.tiles_m * p.tiles_n;
 }
