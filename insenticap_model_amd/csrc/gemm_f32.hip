@@ -2577,12 +2577,18 @@ static int try_h3(DevLaunch &L, float *ws, long long ws_floats, hipStream_t st, 
         need += (long long)p.N * Kp + 1024;               // floats: the weight planes (2 x 2 bytes per element) when the
                                                           // stream has no weights scope; activations are never copied
     }
-    // linear launches that cannot give every CU a 128-row tile go out on the 64-row H3 tile
-    const bool half_tile = EPI == EPI_LINEAR && tiles < 256;
+    // linear launches that cannot give every CU a 128-row tile: the 64-row tile, unless it then needs more rounds of
+    // the chip than it saves in bytes per workgroup (rounds x (rows + 128 columns) of operand lines per workgroup:
+    // [4608 x 512] K=2048 is 288 64-row tiles = two rounds, 97 us, against one round of 144 128-row tiles)
+    long long tiles64 = 0;
+    for (int i = 0; i < L.nprob; ++i) tiles64 += (long long)((L.p[i].M + 63) / 64) * ((L.p[i].N + 127) / 128);
+    const bool half_tile = EPI == EPI_LINEAR && tiles < 256 &&
+                           ((tiles64 + 255) / 256) * 192 < ((tiles + 255) / 256) * 256;
     H3WScope *scope = h3w_scope_of(st);
     // inside a weights scope the planes are already there and the skinny kernel has taken what it does better
     // (try_h3s ran first): whatever is left with a few tiles is still faster here than on the fp32 tiles
-    const long long min_tiles = scope && h3_mode == 1 ? H3_MIN_TILES_SCOPE : (half_tile ? H3_MIN_TILES / 2 : H3_MIN_TILES);
+    const long long min_tiles = scope && h3_mode == 1 ? H3_MIN_TILES_SCOPE
+                                                      : (EPI == EPI_LINEAR && tiles < 256 ? H3_MIN_TILES / 2 : H3_MIN_TILES);
     if (h3_mode != 2 && tiles < min_tiles) return 0;
     if (need > ws_floats) return 0;
     {
