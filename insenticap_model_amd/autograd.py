@@ -167,15 +167,24 @@ def _backward(cap, S, dlogp, d_fc_feats, d_cpt_feats):
     Wc = p['classifier.weight']
     hdrop_tb = (S.hdrop if S.hdrop is not None else S.h2[1:]).reshape(TB, H)
     dhd = new(TB, H)
+    # d h = d logits . W_c contracts over the vocabulary; the split-f16 kernels want a multiple of 32
+    Vm = V // 32 * 32
     if Vp != V and TB >= 8192:
-        # d h = d logits . W_c contracts over the vocabulary; the split-f16 kernels want a multiple of 32, d logits is
-        # already zero-padded to Vp columns: give W_c the matching zero rows (a 20 MB copy; worth it from ~100 GFLOP on)
+        # d logits is already zero-padded to Vp columns: give W_c the matching zero rows (a 20 MB copy; worth it from
+        # ~100 GFLOP on, where the large kernels run the contraction)
         Wc_k = zeros(Vp, H)
         Wc_k[:V].copy_(Wc)
+        with ops.h3_weights_scope(cap._dev):
+            ops.gemm_bwd([nn([(dlogits, Wc_k)], dhd)], NN)
+    elif Vm != V and Vm >= 4096:
+        # fewer rows (B = 128: [2560 x 512] over K = 10 000): the first Vm vocabulary rows on the K-split skinny tile,
+        # the last V - Vm (< 32) on the fp32 tiles, accumulating
+        with ops.h3_weights_scope(cap._dev):
+            ops.gemm_bwd([nn([(dlogits[:, :Vm], Wc[:Vm])], dhd)], NN)
+        ops.gemm_bwd([nn([(dlogits[:, Vm:], Wc[Vm:])], dhd, True)], NN)
     else:
-        Wc_k = Wc
-    with ops.h3_weights_scope(cap._dev):
-        ops.gemm_bwd([nn([(dlogits, Wc_k)], dhd)], NN)
+        with ops.h3_weights_scope(cap._dev):
+            ops.gemm_bwd([nn([(dlogits, Wc)], dhd)], NN)
     if V % 4 == 0:
         dWc = new(V, H)
         ops.gemm_bwd([ops.gemm_problem([(dlogits[:, :V], hdrop_tb)], dWc, TN)], TN)

@@ -1830,8 +1830,12 @@ __global__ __launch_bounds__(256) void gemm_h3s_kernel(const DevLaunch L) {
         w_src[p] = reinterpret_cast<const char *>(P.Wh) + wr * 4 * Kp + chunk_off[p];
     }
     // this wave's k-blocks, and a cursor over the A segments positioned on its first block
+    // ... of this workgroup's share of K (P.ksplit > 1: long contractions on few tiles are also split over workgroups;
+    // the partial tiles then go to slabs and splitk_linear_kernel sums them and applies the epilogue)
     const int nblk = Kp >> 5;
-    const int b_lo = KSPLIT ? (nblk * wave) >> 2 : 0, b_hi = KSPLIT ? (nblk * (wave + 1)) >> 2 : nblk;
+    const int g_lo = (int)((long long)nblk * ks / ksplit), g_hi = (int)((long long)nblk * (ks + 1) / ksplit);
+    const int nb = g_hi - g_lo;
+    const int b_lo = KSPLIT ? g_lo + ((nb * wave) >> 2) : 0, b_hi = KSPLIT ? g_lo + ((nb * (wave + 1)) >> 2) : nblk;
     const int n = b_hi - b_lo;
     int cs = 0, cb = b_lo;
     while (cs < P.nap - 1 && cb >= (P.ap[cs].K >> 5)) { cb -= P.ap[cs].K >> 5; ++cs; }
@@ -1991,6 +1995,11 @@ __global__ __launch_bounds__(256) void gemm_h3s_kernel(const DevLaunch L) {
                 float o[4], pre[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = red(row, c4 + e);
+                if (ksplit > 1) {                                    // raw partial sums (N % 4 == 0 on this route)
+                    *reinterpret_cast<float4 *>(P.slab + (long long)ks * P.slab_stride + (long long)gm * N + gn) =
+                        make_float4(o[0], o[1], o[2], o[3]);
+                    continue;
+                }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int nn = gn + e;
@@ -2619,7 +2628,7 @@ static int try_h3(DevLaunch &L, float *ws, long long ws_floats, hipStream_t st, 
 static std::atomic<long long> g_h3s_launches{0};
 extern "C" long long isc_h3s_launches(void) { return g_h3s_launches.load(); }
 #define H3S_MAX_ROWS 2048
-#define H3S_MAX_ROWS_NN 2048
+#define H3S_MAX_ROWS_NN 4096
 #define H3S_MAX_WGS_VOCAB 384
 
 template <int EPI, int T>
@@ -2666,8 +2675,8 @@ static int h3s_pick_tile(const DevLaunch &L, int mode) {
     return c2 < c1 ? 2 : 1;
 }
 
-static void h3s_tile_problem(DevProb &p, int bm, int bn, int &start) {
-    p.ksplit = 1;
+static void h3s_tile_problem(DevProb &p, int bm, int bn, int &start, int ksplit = 1) {
+    p.ksplit = ksplit;
     p.tiles_m = (p.M + bm - 1) / bm;
     p.tiles_n = (p.N + bn - 1) / bn;
     p.tile_start = start;
@@ -2675,7 +2684,35 @@ static void h3s_tile_problem(DevProb &p, int bm, int bn, int &start) {
     // workgroups then share a weight slice of 1/8 that its L2 keeps, instead of every XCD streaming most of W.
     p.m_fastest = p.tiles_m > 1 ? 1 : 0;
     p.grp_n = (p.tiles_n + 7) / 8;
-    start += p.tiles_m * p.tiles_n;
+    start += p.tiles_m * p.tiles_n * ksplit;
+}
+
+static int launch_splitk_linear_reduce(const DevLaunch &L, hipStream_t st);
+
+// Cross-workgroup K split of a skinny linear launch: a long contraction on few tiles (the classifier's dX at B = 128:
+// [2560 x 512] over K = 9984 is 320 wide tiles = 1.25 rounds of ~130 us each) packs the chip better in S slices -
+// cost in k per workgroup-round, as h3s_pick_tile, plus ~1000 for the reduce launch.  S <= 8, >= 16 k-blocks per slice.
+static int h3s_pick_ksplit(const DevLaunch &L, int T, long long slab_floats) {
+    long long w = 0, mn = 0;
+    int kp_min = 1 << 30, kp_max = 0;
+    for (int i = 0; i < L.nprob; ++i) {
+        const DevProb &p = L.p[i];
+        if (p.N & 3) return 1;
+        w += (long long)((p.M + 32 * T - 1) / (32 * T)) * ((p.N + 32 * T - 1) / (32 * T));
+        mn += (long long)p.M * p.N;
+        const int kp = h3_kp(p);
+        if (kp < kp_min) kp_min = kp;
+        if (kp > kp_max) kp_max = kp;
+    }
+    if (kp_min < 4096) return 1;
+    int best = 1;
+    long long best_cost = ((w + 255) / 256) * kp_max;
+    for (int S = 2; S <= 8; ++S) {
+        if (kp_min / S < 512 || S * mn > slab_floats) break;
+        const long long cost = ((w * S + 255) / 256) * (kp_max / S) + 1000;
+        if (cost < best_cost) { best_cost = cost; best = S; }
+    }
+    return best;
 }
 
 template <int EPI>
@@ -2699,7 +2736,8 @@ static int try_h3s(DevLaunch &L, float *ws, long long ws_floats, hipStream_t st,
     long long need = 0;
     for (int i = 0; i < L.nprob; ++i) {
         const DevProb &p = L.p[i];
-        if (p.M > (transposed ? H3S_MAX_ROWS_NN : H3S_MAX_ROWS)) return 0;
+        // (dX contractions over a vocabulary-sized K - long K, few tiles - also run here above H3S_MAX_ROWS, K-split)
+        if (p.M > (transposed && h3_kp(p) >= 4096 ? H3S_MAX_ROWS_NN : H3S_MAX_ROWS)) return 0;
         if (EPI == EPI_LSTM && (p.H & 7)) return 0;
         for (int sg = 0; sg < p.nseg; ++sg)
             if (p.seg[sg].K & 31) return 0;                 // (the backward entry point accepts other K)
@@ -2711,6 +2749,9 @@ static int try_h3s(DevLaunch &L, float *ws, long long ws_floats, hipStream_t st,
     if (!T) return 0;                                     // the large kernels' launch
     if (!ws || ((uintptr_t)ws & 255) || need > ws_floats) return 0;   // planes that do not fit the scope go here
     if (L.nprob > H3_MAX_JOBS) return 0;
+    int S = 1;
+    if constexpr (EPI == EPI_LINEAR) S = h3s_pick_ksplit(L, T, ws_floats - need - 64);
+    float *slab = ws + ((ws_floats - 64) & ~63LL);        // slabs from the end of the workspace, planes from its start
     H3Planner pl(ws, sc);
     int start = 0;
     for (int i = 0; i < L.nprob; ++i) {
@@ -2723,13 +2764,19 @@ static int try_h3s(DevLaunch &L, float *ws, long long ws_floats, hipStream_t st,
                               p.seg[s].K};
         }
         pl.add_w(p, p.Wh, p.Wl, transposed);
-        h3s_tile_problem(p, 32 * T, EPI == EPI_VOCAB ? 128 : 32 * T, start);
+        h3s_tile_problem(p, 32 * T, EPI == EPI_VOCAB ? 128 : 32 * T, start, S);
+        if (S > 1) {
+            p.slab_stride = (long long)p.M * p.N;
+            slab -= S * p.slab_stride;
+            p.slab = slab;
+        }
     }
     L.total_tiles = start;
     rc = pl.launch(st);                                   // weight planes not yet in the scope (first use only)
     if (rc) return 1;
     rc = launch_h3s_t<EPI>(L, T, st);
     ++g_h3s_launches;
+    if (!rc && S > 1) rc = launch_splitk_linear_reduce(L, st);
     return 1;
 }
 

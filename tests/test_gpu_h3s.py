@@ -199,7 +199,8 @@ def test_auto_mode_takes_the_skinny_kernel_only_inside_a_weights_scope():
     assert _launches() == n0 + 2
 
 
-@pytest.mark.parametrize('M,N,K1,K2', [(128, 512, 2048, 0), (80, 1024, 512, 512), (5, 96, 64, 0), (300, 512, 2048, 0)])
+@pytest.mark.parametrize('M,N,K1,K2', [(128, 512, 2048, 0), (80, 1024, 512, 512), (5, 96, 64, 0), (300, 512, 2048, 0),
+                                       (2560, 512, 9984, 0), (700, 96, 4096, 512)])      # long K: split over workgroups too
 @pytest.mark.parametrize('skinny', [3, 4])
 def test_backward_nn_contraction_on_the_skinny_kernel(M, N, K1, K2, skinny):
     """isc_gemm_bwd, NN layout (dX = dY W, W as stored [K, N]): inside a weights scope the few-row launches run on the
