@@ -1784,16 +1784,19 @@ __device__ __forceinline__ void h3s_dma(unsigned lds_addr, const char *src) {
 // M = 512 ... 1024) that are still too few 128-row tiles to fill the chip.  Its slots are 16 KB (64-row images), its
 // ring two slots, and a slot is re-issued as soon as its fragments sit in registers (before the MFMAs), so two
 // blocks - 32 KB per wave - stay in flight as in the 4-slot ring of the small tile.
-template <int EPI, int T>
-__global__ __launch_bounds__(256) void gemm_h3s_kernel(const DevLaunch L) {
+template <int EPI, int T, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void gemm_h3s_kernel(const DevLaunch L) {
     constexpr bool KSPLIT = EPI != EPI_VOCAB;
     static_assert(T == 1 || (T == 2 && KSPLIT), "wide skinny tile: K-split epilogues only");
+    static_assert(NW == 4 || (NW == 8 && T == 1 && KSPLIT), "eight waves: the small K-split tile only");
     constexpr int BM = 32 * T, BN = KSPLIT ? 32 * T : 128;
     // ring depth: 4 slots (three blocks in flight, 128 KB: one workgroup per CU) for the K-split tiles, whose launches
     // have at most ~256 workgroups; 2 slots (64 KB: two workgroups per CU) for the vocabulary projection, whose 79
     // column tiles x row tiles do not fit one round of single-workgroup CUs (316 workgroups at M = 128: 32 -> 17 us)
-    constexpr int R = KSPLIT && T == 1 ? 4 : 2, IMG = 4096 * T, SLOT = 2 * IMG, NP = 4 * T, LDR = BN + 1;
-    constexpr bool EARLY = T == 2;                      // slot released after the fragment read, not after the MFMAs
+    // NW = 8: the K range over eight waves with two-slot rings (same 128 KB) - twice the waves issuing DMA
+    constexpr int R = KSPLIT && T == 1 && NW == 4 ? 4 : 2, IMG = 4096 * T, SLOT = 2 * IMG, NP = 4 * T, LDR = BN + 1;
+    constexpr bool EARLY = T == 2 || NW == 8;           // slot released after the fragment read, not after the MFMAs
+    constexpr int LOGW = NW == 8 ? 3 : 2;
     extern __shared__ __attribute__((aligned(16))) float smem[];     // 4 waves x R slots x (A image + W image)
     char *lds = reinterpret_cast<char *>(smem);
 
@@ -1835,7 +1838,7 @@ __global__ __launch_bounds__(256) void gemm_h3s_kernel(const DevLaunch L) {
     const int nblk = Kp >> 5;
     const int g_lo = (int)((long long)nblk * ks / ksplit), g_hi = (int)((long long)nblk * (ks + 1) / ksplit);
     const int nb = g_hi - g_lo;
-    const int b_lo = KSPLIT ? g_lo + ((nb * wave) >> 2) : 0, b_hi = KSPLIT ? g_lo + ((nb * (wave + 1)) >> 2) : nblk;
+    const int b_lo = KSPLIT ? g_lo + ((nb * wave) >> LOGW) : 0, b_hi = KSPLIT ? g_lo + ((nb * (wave + 1)) >> LOGW) : nblk;
     const int n = b_hi - b_lo;
     int cs = 0, cb = b_lo;
     while (cs < P.nap - 1 && cb >= (P.ap[cs].K >> 5)) { cb -= P.ap[cs].K >> 5; ++cs; }
@@ -1882,12 +1885,12 @@ __global__ __launch_bounds__(256) void gemm_h3s_kernel(const DevLaunch L) {
     for (int i = 0; i < n; ++i) {
         if (!EARLY && i + R - 1 < n) issue(i + R - 1);   // its slot was consumed in iteration i - 1
         const int younger = n - 1 - i < R - 1 ? n - 1 - i : R - 1;    // blocks issued after block i, still in flight
-        if (T == 1) {
+        if (T == 1) {                                    // 8 DMA instructions per block
             if (R > 3 && younger == 3) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
             else if (R > 2 && younger == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
             else if (younger == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        } else {
+        } else {                                         // 16
             if (younger == 1) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -1981,9 +1984,12 @@ __global__ __launch_bounds__(256) void gemm_h3s_kernel(const DevLaunch L) {
                 for (int r = 0; r < 16; ++r)
                     mine[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh) * LDR + j * 32 + fr] = acc0[i][j][r];
         __syncthreads();
+        if (NW > 4 && tid >= 256) return;                // the epilogue maps 256 threads onto the tile
         auto red = [&](int row, int col) __attribute__((always_inline)) {
             const float *q = smem + row * LDR + col;
-            return ((q[0] + q[BM * LDR]) + q[2 * BM * LDR]) + q[3 * BM * LDR];     // fixed order: bit-repeatable
+            float v = ((q[0] + q[BM * LDR]) + q[2 * BM * LDR]) + q[3 * BM * LDR];   // fixed order: bit-repeatable
+            if (NW == 8) v += ((q[4 * BM * LDR] + q[5 * BM * LDR]) + q[6 * BM * LDR]) + q[7 * BM * LDR];
+            return v;
         };
         if constexpr (EPI == EPI_LINEAR) {
 #pragma unroll
@@ -2629,20 +2635,21 @@ static std::atomic<long long> g_h3s_launches{0};
 extern "C" long long isc_h3s_launches(void) { return g_h3s_launches.load(); }
 #define H3S_MAX_ROWS 2048
 #define H3S_MAX_ROWS_NN 4096
+#define H3S_EIGHT_WAVES_MIN_K 1024
 #define H3S_MAX_WGS_VOCAB 384
 
-template <int EPI, int T>
+template <int EPI, int T, int NW = 4>
 static int launch_h3s(const DevLaunch &L, hipStream_t st) {
-    // 4 waves x ring slots x (A image + W image): 128 KB for the K-split tiles, 64 KB for the vocabulary projection
-    constexpr size_t lds = (size_t)4 * (EPI != EPI_VOCAB && T == 1 ? 4 : 2) * 8192 * T;
+    // waves x ring slots x (A image + W image): 128 KB for the K-split tiles, 64 KB for the vocabulary projection
+    constexpr size_t lds = (size_t)NW * (EPI != EPI_VOCAB && T == 1 && NW == 4 ? 4 : 2) * 8192 * T;
     static std::atomic<bool> attr_set{false};
     if (lds > 65536 && !attr_set.load()) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_h3s_kernel<EPI, T>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_h3s_kernel<EPI, T, NW>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr_set.store(true);
     }
-    hipLaunchKernelGGL((gemm_h3s_kernel<EPI, T>), dim3(L.total_tiles), dim3(256), lds, st, L);
+    hipLaunchKernelGGL((gemm_h3s_kernel<EPI, T, NW>), dim3(L.total_tiles), dim3(64 * NW), lds, st, L);
     ISC_LAUNCH_CHECK();
     return ISC_OK;
 }
@@ -2719,6 +2726,14 @@ template <int EPI>
 static int launch_h3s_t(const DevLaunch &L, int T, hipStream_t st) {
     if constexpr (EPI != EPI_VOCAB) {
         if (T == 2) return launch_h3s<EPI, 2>(L, st);
+        int kp_min = 1 << 30;
+        for (int i = 0; i < L.nprob; ++i) {
+            const int kq = L.p[i].Kp / (L.p[i].ksplit > 1 ? L.p[i].ksplit : 1);
+            if (kq < kp_min) kp_min = kq;
+        }
+        // from 32 k-blocks on, eight waves (four blocks or more each) beat four: twice the waves issuing DMA for the
+        // same 128 KB of rings (LSTM cell M = 512, K = 1536: 38.7 -> 33.5 us; B = 128 roll-out -4 %)
+        if (kp_min >= H3S_EIGHT_WAVES_MIN_K) return launch_h3s<EPI, 1, 8>(L, st);
     }
     return launch_h3s<EPI, 1>(L, st);
 }
