@@ -1788,7 +1788,7 @@ template <int EPI, int T, int NW = 4>
 __global__ __launch_bounds__(64 * NW) void gemm_h3s_kernel(const DevLaunch L) {
     constexpr bool KSPLIT = EPI != EPI_VOCAB;
     static_assert(T == 1 || (T == 2 && KSPLIT), "wide skinny tile: K-split epilogues only");
-    static_assert(NW == 4 || (NW == 8 && T == 1 && KSPLIT), "eight waves: the small K-split tile only");
+    static_assert(NW == 4 || (NW == 8 && T == 1), "eight waves: the small tiles only");
     constexpr int BM = 32 * T, BN = KSPLIT ? 32 * T : 128;
     // ring depth: 4 slots (three blocks in flight, 128 KB: one workgroup per CU) for the K-split tiles, whose launches
     // have at most ~256 workgroups; 2 slots (64 KB: two workgroups per CU) for the vocabulary projection, whose 79
@@ -1810,7 +1810,9 @@ __global__ __launch_bounds__(64 * NW) void gemm_h3s_kernel(const DevLaunch L) {
     const int M = P.M, N = P.N, Kp = P.Kp;
     const int row0 = tm * BM, col0 = tn * BN;
     const int fr = lane & 31, fh = lane >> 5;
-    const int cw = KSPLIT ? 0 : wave;                   // this wave's 32-column block inside the tile
+    // this wave's 32-column block inside the tile (vocabulary tile on eight waves: waves w and w + 4 share block w
+    // and take one half of K each)
+    const int cw = KSPLIT ? 0 : (wave & 3);
 
     // DMA lanes: piece p covers image rows 8p + (lane >> 3); lane position lane & 7 fetches chunk pos ^ swizzle(row)
     const int prow = lane >> 3;
@@ -1838,7 +1840,9 @@ __global__ __launch_bounds__(64 * NW) void gemm_h3s_kernel(const DevLaunch L) {
     const int nblk = Kp >> 5;
     const int g_lo = (int)((long long)nblk * ks / ksplit), g_hi = (int)((long long)nblk * (ks + 1) / ksplit);
     const int nb = g_hi - g_lo;
-    const int b_lo = KSPLIT ? g_lo + ((nb * wave) >> LOGW) : 0, b_hi = KSPLIT ? g_lo + ((nb * (wave + 1)) >> LOGW) : nblk;
+    const int khalf = wave >> 2;                         // (vocabulary tile, NW = 8)
+    const int b_lo = KSPLIT ? g_lo + ((nb * wave) >> LOGW) : (NW == 8 ? (nblk * khalf) >> 1 : 0);
+    const int b_hi = KSPLIT ? g_lo + ((nb * (wave + 1)) >> LOGW) : (NW == 8 ? (nblk * (khalf + 1)) >> 1 : nblk);
     const int n = b_hi - b_lo;
     int cs = 0, cb = b_lo;
     while (cs < P.nap - 1 && cb >= (P.ap[cs].K >> 5)) { cb -= P.ap[cs].K >> 5; ++cs; }
@@ -1945,8 +1949,21 @@ __global__ __launch_bounds__(64 * NW) void gemm_h3s_kernel(const DevLaunch L) {
     __syncthreads();                                     // every wave is done with its ring: LDS is free
 
     if constexpr (EPI == EPI_VOCAB) {
+        if (NW == 8) {                                   // upper-half-of-K partials -> the wave that owns the block
+            float *xch = smem + (wave & 3) * (16 * 64);
+            if (wave >= 4) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) xch[r * 64 + lane] = acc0[0][0][r];
+            }
+            __syncthreads();
+            if (wave < 4) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc0[0][0][r] += xch[r * 64 + lane];
+            }
+            __syncthreads();                             // the exchange area is the statistics' combine area next
+        }
         f32x16 accv[1] = {acc0[0][0]};
-        epi_vocab_frag<1, 4, BM>(P, accv, 0, wave * 32, wave, lane, row0, col0, tn, smem);
+        if (NW == 4 || wave < 4) epi_vocab_frag<1, 4, BM>(P, accv, 0, wave * 32, wave, lane, row0, col0, tn, smem);
         float *smx = smem;
         float *ssm = smem + 4 * BM;
         int *six = reinterpret_cast<int *>(smem + 2 * 4 * BM);
@@ -2734,6 +2751,10 @@ static int launch_h3s_t(const DevLaunch &L, int T, hipStream_t st) {
         // from 32 k-blocks on, eight waves (four blocks or more each) beat four: twice the waves issuing DMA for the
         // same 128 KB of rings (LSTM cell M = 512, K = 1536: 38.7 -> 33.5 us; B = 128 roll-out -4 %)
         if (kp_min >= H3S_EIGHT_WAVES_MIN_K) return launch_h3s<EPI, 1, 8>(L, st);
+    }
+    if constexpr (EPI == EPI_VOCAB) {
+        // one workgroup per CU at most (M <= 96 at V = 10 000; beam rows): eight waves, two per column block
+        if (L.total_tiles <= 256) return launch_h3s<EPI, 1, 8>(L, st);
     }
     return launch_h3s<EPI, 1>(L, st);
 }
