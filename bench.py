@@ -371,7 +371,7 @@ PMC_SUMMARY = os.path.join(ROOT, 'profiles', 'r02_d_pmc_summary_B4096.json')
 KERNEL_SYMBOL = {'vocab[': ['void gemm_h3_kernel<2, false>', 'void gemm_h3_kernel<2>', 'void gemm_ld_kernel<2>', 'void gemm_kernel<4, 1, 4, 2, false, false>'],
                  'lstm[4096x2048x1536': ['void gemm_h3x_kernel<1, false>', 'void gemm_h3x_kernel<1>', 'void gemm_h3_kernel<1>', 'void gemm_xl_kernel<1>'],
                  'lstm[': ['void gemm_h3x_kernel<1, false>', 'void gemm_h3x_kernel<1>', 'void gemm_h3_kernel<1>', 'void gemm_ld_kernel<1>', 'void gemm_kernel<4, 1, 4, 1, false, false>', 'void gemm_xl_kernel<1>'],
-                 'attn_scan[': ['void attn_scan_kernel<2>'], 'gate_mix[': ['gate_mix_kernel'],
+                 'attn_scan[': ['void attn_scan_kernel<2, true>', 'void attn_scan_kernel<2, false>', 'void attn_scan_kernel<2>'], 'gate_mix[': ['gate_mix_kernel'],
                  'rollout_finalize[': ['rollout_finalize_kernel']}
 
 

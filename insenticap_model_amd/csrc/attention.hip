@@ -29,7 +29,24 @@ struct DevScan {
 };
 struct DevScanLaunch {
     DevScan p[2];
+    int nt;                    // the per-caption P / V rows are streamed with non-temporal loads (host decides)
 };
+// A launch whose per-caption rows do not fit the Infinity Cache (256 MB) next to the step's other traffic re-reads
+// them from HBM every step anyway; loading them non-temporally (no allocation on the way) measured 149 -> 128 us at
+// B = 4096 (788 MB per launch: 6.2 TB/s, what a bare read sweep reaches), and the step's GEMMs keep their weights in
+// the cache: whole roll-outs B = 1536 6.57 -> 6.03 ms, B = 2048 7.65 -> 6.97 ms, B = 4096 12.44 -> 11.96 ms.  With only
+// the first 1024 / 1536 / 2048 of 4096 captions on the default policy (hoping to keep those resident) the scan took
+// 140 / 148 / 153 us.  Smaller launches keep the default - their rows DO stay resident from one step to the next
+// (B = 512: 20 us default vs 24 us non-temporal; B = 1024, 151 MB: 35.4 vs 35.9 us, roll-out 4.84 vs 4.75 ms).
+#define ISC_SCAN_NT_BYTES (128LL << 20)
+typedef float f4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld4(const float4 *p, bool nt) {
+    if (nt) {
+        const f4v v = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(p));
+        return make_float4(v.x, v.y, v.z, v.w);
+    }
+    return *p;
+}
 
 // f16 planes of four consecutive outputs d .. d+3 of row `row` of a [rows, D] tensor (split-f16 GEMM operands:
 // hi = f16(x), lo = f16((x - hi) * 2048); interleaved layout of gemm_f32.hip: per row and 32-wide block 32 hi then
@@ -48,7 +65,7 @@ __device__ __forceinline__ void store_planes4(_Float16 *hi, _Float16 *lo, long l
     *reinterpret_cast<h4 *>(lo + o) = b;
 }
 
-template <int NA>  // float4 per lane along A: A <= 256*NA
+template <int NA, bool NT>  // float4 per lane along A: A <= 256*NA; NT: per-caption rows by non-temporal loads
 __global__ __launch_bounds__(256) void attn_scan_kernel(const DevScanLaunch L) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const DevScan &S = L.p[blockIdx.y];
@@ -61,6 +78,7 @@ __global__ __launch_bounds__(256) void attn_scan_kernel(const DevScanLaunch L) {
     // cache-resident, instead of [B,R,.] copies streamed from HBM every step): row ids of this caption in LDS
     int *rid = reinterpret_cast<int *>(smem + S.rid_off);
     const bool gather = S.ids != nullptr;
+    const bool nt = NT && !gather;
     if (gather) {
         for (int r = tid; r < R; r += 256) rid[r] = (int)S.ids[(long long)b * S.ids_ld + r];
         __syncthreads();
@@ -97,7 +115,7 @@ __global__ __launch_bounds__(256) void attn_scan_kernel(const DevScanLaunch L) {
             for (int i = 0; i < NA; ++i) {
                 const int a4 = lane + 64 * i;
                 const long long pr = (r < R && gather) ? rid[r] : r;
-                p[u][i] = (r < R && a4 < na4) ? Pb[pr * na4 + a4] : make_float4(0.f, 0.f, 0.f, 0.f);
+                p[u][i] = (r < R && a4 < na4) ? ld4(&Pb[pr * na4 + a4], nt) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
         float acc[3];
@@ -155,7 +173,7 @@ __global__ __launch_bounds__(256) void attn_scan_kernel(const DevScanLaunch L) {
                 for (int u = 0; u < 6; ++u) {
                     const int r = r0 + u * ngrp;
                     const int rc = r < R ? r : R - 1;
-                    v[u] = Vb[(long long)(gather ? rid[rc] : rc) * nd4 + d4];
+                    v[u] = ld4(&Vb[(long long)(gather ? rid[rc] : rc) * nd4 + d4], nt);
                     a[u] = r < R ? sc[rc] : 0.f;
                 }
 #pragma unroll
@@ -217,11 +235,21 @@ extern "C" int isc_attn_scan_fwd(const isc_scan_problem *pr, int n_prob, int B, 
     }
     lds *= sizeof(float);
     if (lds > 60000) return ISC_E_SHAPE;
+    long long streamed = 0;                                // bytes of per-caption rows (gathered tables are shared)
+    for (int i = 0; i < n_prob; ++i)
+        if (!pr[i].row_ids) streamed += (long long)B * pr[i].R * ((long long)pr[i].A + pr[i].D) * 4;
+    L.nt = streamed > ISC_SCAN_NT_BYTES;
     dim3 grid(B, n_prob), block(256);
     hipStream_t st = (hipStream_t)stream;
-    if (maxA <= 256) hipLaunchKernelGGL(attn_scan_kernel<1>, grid, block, lds, st, L);
-    else if (maxA <= 512) hipLaunchKernelGGL(attn_scan_kernel<2>, grid, block, lds, st, L);
-    else hipLaunchKernelGGL(attn_scan_kernel<4>, grid, block, lds, st, L);
+    if (L.nt) {
+        if (maxA <= 256) hipLaunchKernelGGL((attn_scan_kernel<1, true>), grid, block, lds, st, L);
+        else if (maxA <= 512) hipLaunchKernelGGL((attn_scan_kernel<2, true>), grid, block, lds, st, L);
+        else hipLaunchKernelGGL((attn_scan_kernel<4, true>), grid, block, lds, st, L);
+    } else {
+        if (maxA <= 256) hipLaunchKernelGGL((attn_scan_kernel<1, false>), grid, block, lds, st, L);
+        else if (maxA <= 512) hipLaunchKernelGGL((attn_scan_kernel<2, false>), grid, block, lds, st, L);
+        else hipLaunchKernelGGL((attn_scan_kernel<4, false>), grid, block, lds, st, L);
+    }
     ISC_LAUNCH_CHECK();
     return ISC_OK;
 }
