@@ -447,6 +447,15 @@ int isc_embed_relu_bwd(const float *emb, int V, int W, const int64_t *ids, int64
                        int n_rows, int rows_per_grad, int pad_first, int64_t pad_id, const float *dout,
                        float scale, const uint8_t *keep_mask, float mask_scale, float *demb,
                        int64_t skip_id, void *stream);
+/* The same gradient, bit for bit, through a position index built in `workspace` (>= (4 V + 64 + n_rows) * 4 bytes,
+ * 16-byte aligned): count per id, offsets, every position dropped into its id's segment, one workgroup per
+ * occurring id that sorts its segment and sums in ascending position order.  Linear in n_rows where the entry
+ * point above is quadratic (each workgroup scans the id array); falls back to it without a workspace or below
+ * 1024 positions. */
+int isc_embed_relu_bwd_ws(const float *emb, int V, int W, const int64_t *ids, int64_t ids_stride,
+                          int n_rows, int rows_per_grad, int pad_first, int64_t pad_id,
+                          const float *dout, float scale, const uint8_t *keep_mask, float mask_scale,
+                          float *demb, int64_t skip_id, void *workspace, int64_t workspace_bytes, void *stream);
 
 /* out[n] (+)= sum_m x[m,n]  (bias gradients). With a workspace of >= 64*N floats tall matrices are
  * summed in two deterministic stages (row chunks in parallel, then the chunks in order). */

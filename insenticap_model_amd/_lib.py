@@ -160,6 +160,9 @@ SIGNATURES = {
     'isc_embed_relu_bwd': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_int,
                                      C.c_int, C.c_int64, C.c_void_p, C.c_float, C.c_void_p, C.c_float,
                                      C.c_void_p, C.c_int64, C.c_void_p]),
+    'isc_embed_relu_bwd_ws': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_int,
+                                        C.c_int, C.c_int64, C.c_void_p, C.c_float, C.c_void_p, C.c_float,
+                                        C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
     'isc_colsum': (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int64,
                              C.c_void_p]),
     'isc_relu_mask_bwd': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int64, C.c_void_p,

@@ -542,9 +542,11 @@ def embed_relu_bwd(emb, ids, dout, demb, n_rows, rows_per_grad=1, scale=1.0, ids
     lib = _lib.load()
     V, W = emb.shape
     assert dout.is_contiguous() and demb.is_contiguous() and ids.dtype == torch.int64
-    check(lib.isc_embed_relu_bwd(emb.data_ptr(), V, W, ids.data_ptr(), ids_stride, n_rows, rows_per_grad,
-                                 pad_first, pad_id, dout.data_ptr(), scale, ptr(keep_mask), mask_scale,
-                                 demb.data_ptr(), skip_id, stream()), 'isc_embed_relu_bwd')
+    ws = splitk_ws(emb.device)          # position index of the ids (the stream's workspace: launches are ordered)
+    check(lib.isc_embed_relu_bwd_ws(emb.data_ptr(), V, W, ids.data_ptr(), ids_stride, n_rows, rows_per_grad,
+                                    pad_first, pad_id, dout.data_ptr(), scale, ptr(keep_mask), mask_scale,
+                                    demb.data_ptr(), skip_id, ws.data_ptr(), ws.numel() * 4, stream()),
+          'isc_embed_relu_bwd_ws')
 
 
 def colsum(x, out, accumulate=False):
