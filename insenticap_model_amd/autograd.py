@@ -21,6 +21,15 @@ class _Saved:
     pass
 
 
+
+def _weights_scope(cap):
+    """Weights scope keyed by the parameter VALUES (Captioner._weights_key): the forward unrolls of one training
+    iteration (sampled roll-out, XE, the greedy baseline in between) and its backward sweeps all see the same weights,
+    so the f16 planes - forward layout and transposes - are built once per iteration and stream, not once per scope
+    (91 -> ~40 split launches per RL iteration at B=512)."""
+    return ops.h3_weights_scope(cap._dev, key=cap._weights_key())
+
+
 def _pad32(v):
     return (v + 31) // 32 * 32
 
@@ -88,7 +97,7 @@ def _train_forward(cap, mode, fc, att, cpt_words, senti_words, tokens_in, senti_
         ops.embed_relu_fwd(emb, S.tok.view(-1), S.xt.view(T * B, Wd))
     # the weights are fixed for the whole unroll: their f16 planes are built once (few-row launches then take the
     # one-launch skinny split-f16 kernels instead of split-K + reduce pairs)
-    with ops.h3_weights_scope(cap._dev):
+    with _weights_scope(cap):
         for t in range(T):
             if sampling:
                 if t >= 1:
@@ -174,16 +183,16 @@ def _backward(cap, S, dlogp, d_fc_feats, d_cpt_feats):
         # ~100 GFLOP on, where the large kernels run the contraction)
         Wc_k = zeros(Vp, H)
         Wc_k[:V].copy_(Wc)
-        with ops.h3_weights_scope(cap._dev):
+        with _weights_scope(cap):
             ops.gemm_bwd([nn([(dlogits, Wc_k)], dhd)], NN)
     elif Vm != V and Vm >= 4096:
         # fewer rows (B = 128: [2560 x 512] over K = 10 000): the first Vm vocabulary rows on the K-split skinny tile,
         # the last V - Vm (< 32) on the fp32 tiles, accumulating
-        with ops.h3_weights_scope(cap._dev):
+        with _weights_scope(cap):
             ops.gemm_bwd([nn([(dlogits[:, :Vm], Wc[:Vm])], dhd)], NN)
         ops.gemm_bwd([nn([(dlogits[:, Vm:], Wc[Vm:])], dhd, True)], NN)
     else:
-        with ops.h3_weights_scope(cap._dev):
+        with _weights_scope(cap):
             ops.gemm_bwd([nn([(dlogits, Wc)], dhd)], NN)
     if V % 4 == 0:
         dWc = new(V, H)
@@ -252,7 +261,7 @@ def _backward(cap, S, dlogp, d_fc_feats, d_cpt_feats):
         bp.beta_ld = S.bG.stride(0)
     # the weights do not change during the sweep: few-row launches take the one-launch skinny split-f16 kernel on
     # planes of W^T built once here (isc_gemm_bwd, NN layout), instead of fp32 split-K slabs + a reduce kernel per GEMM
-    with ops.h3_weights_scope(cap._dev):
+    with _weights_scope(cap):
         for t in range(T - 1, -1, -1):
             cur, nxt = t & 1, (t + 1) & 1
             bp.first, bp.last = int(t == T - 1), int(t == 0)
@@ -303,7 +312,7 @@ def _backward(cap, S, dlogp, d_fc_feats, d_cpt_feats):
     probs = [nn([(dG1_sum, Wih1[:, H:H + E])], d_fc_e), nn([(dG1f, Wih1[:, H + E:])], dxt)]
     if d_label_e is not None:
         probs.append(nn([(dG1_sum, Wih1[:, H + E:])], d_label_e))
-    with ops.h3_weights_scope(cap._dev):      # dX over all T*B rows: split-f16 on planes of the W_ih slices' transposes
+    with _weights_scope(cap):      # dX over all T*B rows: split-f16 on planes of the W_ih slices' transposes
         ops.gemm_bwd(probs, NN)
     emb = p['word_embed.0.weight']
     dEmb = zeros(V, Wd)

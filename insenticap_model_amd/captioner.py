@@ -532,7 +532,7 @@ class Captioner(nn.Module):
         mask_for = self._mask_source(masks)
         emb = p['word_embed.0.weight']
         mask_for.predraw('out', T, B, self.att_lstm.hidden_size)
-        with ops.h3_weights_scope(self._dev):      # frozen weights for the whole unroll
+        with ops.h3_weights_scope(self._dev, key=self._weights_key()):      # frozen weights for the whole unroll
             for i in range(T):
                 it = tokens_in[:, i]
                 if self.training and i >= 1 and ss_prob > 0.0:       # scheduled sampling, on the device (no host test)

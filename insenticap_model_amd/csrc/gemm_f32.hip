@@ -2402,7 +2402,7 @@ struct H3WEntry {
 // One scope per stream (isc_h3_weights_begin(buf, bytes, stream)): the slot table is guarded by a mutex, a slot's
 // entries are only touched by launches on its own stream (which the caller issues in one order, like the launches
 // themselves), so two host threads driving two captioners on two streams never see each other's planes.
-#define H3W_MAX_ENTRIES 40
+#define H3W_MAX_ENTRIES 72
 struct H3WScope {
     hipStream_t stream = nullptr;
     char *buf = nullptr;

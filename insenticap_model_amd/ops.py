@@ -143,7 +143,7 @@ def set_h3_mode(mode):
 
 
 _H3W_BUF = {}
-H3W_BYTES = 96 * 1024 * 1024
+H3W_BYTES = 192 * 1024 * 1024     # forward planes of every weight (~62 MB) + the transposes the backward uses (~60 MB)
 
 
 class h3_weights_scope:
