@@ -474,10 +474,13 @@ __global__ __launch_bounds__(256) void beam_topk8_kernel(const float *logits, lo
     __shared__ int si[2][4];
     __shared__ float sh[2];
     __shared__ int sel[256];               // selected tile ids (n_tile <= 256 on this path)
+    __shared__ float spm[256];             // this row's tile maxima
     __shared__ int nsel;
     const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) nsel = 0;
+    if (tid >= 64 && tid - 64 < n_tile) spm[tid - 64] = pmax[(long long)row * n_tile + tid - 64];   // (waves 1-3 idle here)
     if (tid < 64) {
+        if (n_tile > 192) for (int j = 192 + tid; j < n_tile; j += 64) spm[j] = pmax[(long long)row * n_tile + j];
         float gmax, S;
         int gi;
         fold_row_stats(pmax + (long long)row * n_tile, psum + (long long)row * n_tile, nullptr, n_tile,
@@ -488,12 +491,11 @@ __global__ __launch_bounds__(256) void beam_topk8_kernel(const float *logits, lo
     const float gmax = sh[0], logS = sh[1];
     // tile selection: rank of this thread's tile among the tile maxima (ties by tile id); tiles tied with the last
     // admitted maximum are admitted as well because the comparison below is on values, not ranks
-    const float *pm = pmax + (long long)row * n_tile;
     const int want = beam + 4;
     if (tid < n_tile) {
-        const float mine = pm[tid];
+        const float mine = spm[tid];
         int larger = 0;
-        for (int j = 0; j < n_tile; ++j) larger += pm[j] > mine;
+        for (int j = 0; j < n_tile; ++j) larger += spm[j] > mine;     // LDS broadcasts (was n_tile global loads)
         if (larger < want) sel[atomicAdd(&nsel, 1)] = tid;     // order of `sel` is irrelevant: ids break ties later
     }
     __syncthreads();
@@ -521,13 +523,23 @@ __global__ __launch_bounds__(256) void beam_topk8_kernel(const float *logits, lo
             id = better ? oi : id;
         }
     };
-    // two selected tiles per pass: thread t takes column (t & 127) of tile sel[2*pass + (t >> 7)]
-    for (int s0 = 0; s0 < ns; s0 += 2) {
-        const int si2 = s0 + (tid >> 7);
-        if (si2 < ns) {
-            const int i = sel[si2] * 128 + (tid & 127);
-            if (i < V) offer(x[i], i);
+    // two selected tiles per pass: thread t takes column (t & 127) of tile sel[2*pass + (t >> 7)]; the loads of four
+    // passes are issued together (the ~9 selected tiles used to be five dependent-looking L2 round trips)
+    for (int s0 = 0; s0 < ns; s0 += 8) {
+        float xv[4];
+        int xi[4];
+        bool ok[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int si2 = s0 + 2 * u + (tid >> 7);
+            ok[u] = si2 < ns;
+            xi[u] = ok[u] ? sel[si2] * 128 + (tid & 127) : 0;
+            ok[u] = ok[u] && xi[u] < V;
+            xv[u] = x[ok[u] ? xi[u] : 0];
         }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (ok[u]) offer(xv[u], xi[u]);
     }
     for (int k = 0; k < beam; ++k) {
         float mx = tv[0];
