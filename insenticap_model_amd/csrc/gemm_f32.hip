@@ -2748,9 +2748,11 @@ static int launch_h3s_t(const DevLaunch &L, int T, hipStream_t st) {
             const int kq = L.p[i].Kp / (L.p[i].ksplit > 1 ? L.p[i].ksplit : 1);
             if (kq < kp_min) kp_min = kq;
         }
-        // from 32 k-blocks on, eight waves (four blocks or more each) beat four: twice the waves issuing DMA for the
-        // same 128 KB of rings (LSTM cell M = 512, K = 1536: 38.7 -> 33.5 us; B = 128 roll-out -4 %)
-        if (kp_min >= H3S_EIGHT_WAVES_MIN_K) return launch_h3s<EPI, 1, 8>(L, st);
+        // from 32 k-blocks on, eight waves (four blocks or more each) beat four when activation segments arrive as
+        // fp32 rows (training: the in-register split is shared by twice the waves; kernel-trace sums of an XE
+        // iteration at B = 128: LSTM cells -9 %, linears -3 %); with every operand on planes (the decode loop) four
+        // waves with four-slot rings are the faster form (LSTM cell 9.5 vs 10.3 us)
+        if (kp_min >= H3S_EIGHT_WAVES_MIN_K && h3_any_f32(L)) return launch_h3s<EPI, 1, 8>(L, st);
     }
     if constexpr (EPI == EPI_VOCAB) {
         // one workgroup per CU at most (M <= 96 at V = 10 000; beam rows): eight waves, two per column block
