@@ -109,6 +109,10 @@ def broadcast_parameters(module, src=0, group=None):
     for p in ps:
         p.copy_(flat[off:off + p.numel()].view_as(p))
         off += p.numel()
+    # written through `.data`: the parameters' version counters did not move - tell the caches keyed on the weight
+    # VALUES (f16 weight planes, token tables, captured graphs) that they are stale
+    from . import ops
+    ops.WEIGHT_EPOCH += 1
 
 
 def shard(n_items, rank, world):
