@@ -141,6 +141,41 @@ def test_attention_scan_vs_fp64(B, R, A):
     np.testing.assert_allclose(out.cpu().numpy(), ref.float().numpy(), atol=1e-5)
 
 
+def test_attention_scan_streaming_policy_does_not_change_the_numbers():
+    """A launch that streams more than 128 MB of per-caption rows loads them non-temporally (attention.hip); the same
+    rows in two half launches take the default policy: the outputs must be bit-identical (and so must the backward's,
+    which applies the same rule to its P / V reads)."""
+    D = dev()
+    B, R, A = 1024, 36, 512                                   # 2 * 36 * 512 * 4 B * 1024 = 151 MB > 128 MB
+    g = torch.Generator().manual_seed(5)
+    Pm, Vm = torch.randn(B, R, A, generator=g).to(D), torch.randn(B, R, A, generator=g).to(D)
+    q, w, wb = torch.randn(B, A, generator=g).to(D), (torch.randn(1, A, generator=g) * 0.3).to(D), torch.randn(1, generator=g).to(D)
+
+    def fwd(sl):
+        n = sl.stop - sl.start
+        out, alpha = torch.empty(n, A, device=D), torch.empty(n, R, device=D)
+        ops.attn_scan_fwd([ops.scan_problem(Pm[sl].contiguous(), Vm[sl].contiguous(), q[sl].contiguous(), w, wb, out, alpha)], n)
+        return out, alpha
+    whole = fwd(slice(0, B))
+    halves = [fwd(slice(0, B // 2)), fwd(slice(B // 2, B))]
+    torch.cuda.synchronize()
+    assert torch.equal(whole[0], torch.cat([h[0] for h in halves])) and torch.equal(whole[1], torch.cat([h[1] for h in halves]))
+    dout = torch.randn(B, A, generator=g).to(D)
+
+    def bwd(sl):
+        n = sl.stop - sl.start
+        dP, dV = torch.empty(n, R, A, device=D), torch.empty(n, R, A, device=D)
+        dq, dw = torch.empty(n, A, device=D), torch.empty(n, A, device=D)
+        ops.attn_scan_bwd([ops.scan_bwd_problem(Pm[sl].contiguous(), Vm[sl].contiguous(), q[sl].contiguous(), w,
+                                                whole[1][sl].contiguous(), dout[sl].contiguous(), dP, dV, dq, dw, False)], n)
+        return dP, dV, dq, dw
+    bw = bwd(slice(0, B))
+    bh = [bwd(slice(0, B // 2)), bwd(slice(B // 2, B))]
+    torch.cuda.synchronize()
+    for k in range(4):
+        assert torch.equal(bw[k], torch.cat([h[k] for h in bh])), k
+
+
 # ----------------------------------------------------------------------------- end to end
 def test_tiny_xe_and_seq2seq_forward_vs_golden(golden):
     g = golden('tiny')
