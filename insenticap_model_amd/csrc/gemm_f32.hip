@@ -1,7 +1,10 @@
 // Grouped, K-segmented GEMM (NT forward, NN / TN backward) with fused epilogues, on two engines:
 //   * fp32 MFMA (v_mfma_f32_32x32x2_f32): every layout, every size (tile kernels below);
-//   * split-f16 (v_mfma_f32_32x32x16_f16 on hi/lo f16 planes of the fp32 operands, fp32 accumulators): the large
-//     forward launches - gemm_h3_kernel / gemm_h3x_kernel / gemm_h3m_kernel, h3_split_kernel, try_h3 further down.
+//   * split-f16 (v_mfma_f32_32x32x16_f16 on hi/lo f16 planes of the fp32 operands, fp32 accumulators): forward and
+//     backward launches alike - the large tiles gemm_h3_kernel (128 x 128) / gemm_h3x_kernel (256 x 128) /
+//     gemm_h3m_kernel (64 x 128), the skinny tiles gemm_h3s_kernel (32 x 32, 64 x 64, 32 x 128 vocabulary; K split over
+//     the waves of a workgroup and, for long contractions, over workgroups), h3_split_kernel for the weight planes
+//     (and both operands of the TN layout); dispatch in try_h3s / try_h3 / try_h3_tn further down.
 //
 //   acc[M,N] = sum_s A_s[M,K_s] * W_s[N,K_s]^T          (s = up to 4 K-segments)
 //
