@@ -746,6 +746,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const DevLaunch L) {
 // ---------------------------------------------------------------- XL tile: 256 x 128, one workgroup per CU
 // For batch-sized NT problems.  4 waves stacked in M, each owning a 64 x 128 accumulator (2 x 4 MFMA
 // fragments, 128 AGPRs): twice the MFMAs per staged byte of the 128 x 128 tile.  Operand chunks go
+// (M0 carries the LDS destination of an LDS-DMA; it is written in the same asm statement that uses it, with the one
+// wait state the ISA asks for between an SALU write of M0 and a memory instruction with the LDS modifier: hipcc's hazard
+// recogniser does not look inside inline asm.)
 // global -> LDS by LDS-DMA (global_load_lds_dwordx4: no staging VGPRs, no ds_write pass) into a
 // 3-deep ring (144 KB), so the DMA of chunk c+2 is in flight while chunk c is contracted and only a
 // counted vmcnt (never 0 in steady state) precedes the one barrier per chunk.  The 12 DMA
@@ -807,11 +810,11 @@ __global__ __launch_bounds__(256) void gemm_xl_kernel(const DevLaunch L) {
     auto dma = [&](auto bufc, auto idxc) __attribute__((always_inline)) {
         constexpr int BUF = decltype(bufc)::value, IDX = decltype(idxc)::value;
         if constexpr (IDX < 8) {
-            asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off"
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
                          :: "s"(a_lds0 + (BUF * TSA + 8 * IDX * BK) * 4), "v"(pa[IDX]) : "memory");
             pa[IDX] += BK;
         } else {
-            asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off"
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
                          :: "s"(b_lds0 + (BUF * TSB + 8 * (IDX - 8) * BK) * 4), "v"(pb[IDX - 8]) : "memory");
             pb[IDX - 8] += BK;
         }
@@ -981,11 +984,11 @@ __global__ __launch_bounds__(256) void gemm_ld_kernel(const DevLaunch L) {
     auto dma = [&](auto bufc, auto idxc) __attribute__((always_inline)) {
         constexpr int BUF = decltype(bufc)::value, IDX = decltype(idxc)::value;
         if constexpr (IDX < 4) {
-            asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off"
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
                          :: "s"(a_lds0 + (BUF * TS + 8 * IDX * BK) * 4), "v"(pa[IDX]) : "memory");
             pa[IDX] += BK;
         } else {
-            asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off"
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
                          :: "s"(b_lds0 + (BUF * TS + 8 * (IDX - 4) * BK) * 4), "v"(pb[IDX - 4]) : "memory");
             pb[IDX - 4] += BK;
         }
@@ -1173,7 +1176,7 @@ __global__ __launch_bounds__(256, 2) void gemm_h3_kernel(const DevLaunch L) {
         for (int p = 0; p < 2; ++p)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off"
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
                              :: "s"(lds0 + buf * ST + p * PA + i * 1024), "v"(src[4 * p + i]) : "memory");
                 src[4 * p + i] += 64;                     // next 32-k block: 32 hi + 32 lo halfs further
             }
@@ -1314,7 +1317,7 @@ __global__ __launch_bounds__(512) void gemm_h3x_kernel(const DevLaunch L) {
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds);
     const unsigned wv = __builtin_amdgcn_readfirstlane((unsigned)wm);
     auto dma1 = [&](unsigned dst, const _Float16 *&p) __attribute__((always_inline)) {
-        asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(dst), "v"(p) : "memory");
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(dst), "v"(p) : "memory");
         p += 64;
     };
     auto stage = [&](int buf) __attribute__((always_inline)) {
@@ -1460,7 +1463,7 @@ __global__ __launch_bounds__(256) void gemm_h3m_kernel(const DevLaunch L) {
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds);
     const unsigned wv = __builtin_amdgcn_readfirstlane((unsigned)w);
     auto dma1 = [&](unsigned dst, const _Float16 *&p) __attribute__((always_inline)) {
-        asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(dst), "v"(p) : "memory");
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(dst), "v"(p) : "memory");
         p += 64;
     };
     auto stage = [&](int buf) __attribute__((always_inline)) {
@@ -1679,11 +1682,11 @@ __global__ __launch_bounds__(256) void gemm_md_kernel(const DevLaunch L) {
     auto dma = [&](auto bufc, auto idxc) __attribute__((always_inline)) {
         constexpr int BUF = decltype(bufc)::value, IDX = decltype(idxc)::value;
         if constexpr (IDX < 2) {
-            asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off"
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
                          :: "s"(a_lds0 + (BUF * TSA + 8 * IDX * BK) * 4), "v"(pa[IDX]) : "memory");
             pa[IDX] += BK;
         } else {
-            asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off"
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
                          :: "s"(b_lds0 + (BUF * TSB + 8 * (IDX - 2) * BK) * 4), "v"(pb[IDX - 2]) : "memory");
             pb[IDX - 2] += BK;
         }
@@ -1779,7 +1782,7 @@ __global__ __launch_bounds__(256) void gemm_md_kernel(const DevLaunch L) {
 // Weights come as f16 planes from the stream's weights scope; an activation segment comes as planes when its
 // producer wrote them, else as fp32 rows (same 128 bytes per row and block) and is split after the fragment read.
 __device__ __forceinline__ void h3s_dma(unsigned lds_addr, const char *src) {
-    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(lds_addr), "v"(src) : "memory");
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(lds_addr), "v"(src) : "memory");
 }
 
 // T = 2 (K-split epilogues only) doubles the tile to 64 x 64: a loaded row then feeds two MFMA tiles instead of one, so
