@@ -431,6 +431,11 @@ typedef struct {
 } isc_scan_bwd_problem;
 
 int isc_attn_scan_bwd(const isc_scan_bwd_problem *probs_host, int n_prob, int B, void *stream);
+/* dV may be NULL in a problem above: the caller then forms dV once after its sweep from the per-step gradients,
+ * dV[b,r,:] = sum_{t = T-1 .. 0} alpha[b*alpha_ld_b + t*alpha_ld_t + r] * dout[(t*B + b)*D + :] (the sweep's order of
+ * additions: bit-identical to the per-step accumulation), instead of re-reading and re-writing [B,R,D] at every step. */
+int isc_attn_dv_from_alpha(const float *alpha, int64_t alpha_ld_b, int64_t alpha_ld_t, const float *dout,
+                           int B, int T, int R, int D, float *dV, void *stream);
 
 /* Backward of isc_gate_mix_fwd: dv = beta*dfeat, ds = (1-beta)*dfeat, dz, per-row partials of
  * d w (dw_rows [B,A]) and d w_bias (db_rows [B]). */

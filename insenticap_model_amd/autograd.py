@@ -214,15 +214,17 @@ def _backward(cap, S, dlogp, d_fc_feats, d_cpt_feats):
     Wih2, Whh2 = p['lang_lstm.weight_ih'], p['lang_lstm.weight_hh']
     dG1, dG2 = new(T, B, 4 * H), new(T, B, 4 * H)
     dG1_sum = zeros(B, 4 * H)
-    d_feat, dh1 = new(B, E), new(B, H)
+    # d feat of every step is kept ([T,B,E]): where it is the scan's output gradient, dV = sum_t alpha_t x dout_t is
+    # formed once after the sweep (ops.attn_dv_from_alpha) instead of a read-modify-write of [B,R,E] at every step
+    d_feat_all, dh1 = new(T, B, E), new(B, H)
     dh2_rec, dh1_rec = new(B, H), new(B, H)
     dc1_rec, dc2_rec = [new(B, H), new(B, H)], [new(B, H), new(B, H)]
     if has_c:
-        dqa, dv = new(T, B, A), new(B, E)
+        dqa, dv_all = new(T, B, A), (new(T, B, E) if gate else d_feat_all)
         dP_att, dV_att = new(B, P.R, A), new(B, P.R, E)
         dwc_rows = new(B, A)
     if has_s:
-        dqw, ds = new(T, B, A), new(B, E)
+        dqw, ds_all = new(T, B, A), (new(T, B, E) if gate else d_feat_all)
         dP_w, dV_w = new(B, P.Mw, A), new(B, P.Mw, Wd)
         dws_rows = new(B, A)
     if gate:
@@ -247,16 +249,15 @@ def _backward(cap, S, dlogp, d_fc_feats, d_cpt_feats):
         setattr(bp, field, ptr(t_))
     skws = ops.splitk_ws(cap._dev)
     bp.splitk_ws, bp.splitk_ws_floats = skws.data_ptr(), skws.numel()
-    bp.dG1_sum, bp.d_feat, bp.dh1 = dG1_sum.data_ptr(), d_feat.data_ptr(), dh1.data_ptr()
+    bp.dG1_sum, bp.dh1 = dG1_sum.data_ptr(), dh1.data_ptr()
     bp.dh2_rec, bp.dh1_rec = dh2_rec.data_ptr(), dh1_rec.data_ptr()
     if has_c:
-        bp.dP_att, bp.dV_att, bp.dwc_rows = dP_att.data_ptr(), dV_att.data_ptr(), dwc_rows.data_ptr()
+        bp.dP_att, bp.dV_att, bp.dwc_rows = dP_att.data_ptr(), None, dwc_rows.data_ptr()
         bp.alpha_c_ld = S.aC.stride(0)
     if has_s:
-        bp.dP_w, bp.dV_w, bp.dws_rows = dP_w.data_ptr(), dV_w.data_ptr(), dws_rows.data_ptr()
+        bp.dP_w, bp.dV_w, bp.dws_rows = dP_w.data_ptr(), None, dws_rows.data_ptr()
         bp.alpha_s_ld = S.aS.stride(0)
     if gate:
-        bp.dv, bp.ds = dv.data_ptr(), ds.data_ptr()
         bp.dwg_rows, bp.dbg_rows = dwg_rows.data_ptr(), dbg_rows.data_ptr()
         bp.beta_ld = S.bG.stride(0)
     # the weights do not change during the sweep: few-row launches take the one-launch skinny split-f16 kernel on
@@ -268,6 +269,9 @@ def _backward(cap, S, dlogp, d_fc_feats, d_cpt_feats):
             bp.g1, bp.c1_prev, bp.c1 = S.g1[t].data_ptr(), S.c1[t].data_ptr(), S.c1[t + 1].data_ptr()
             bp.g2, bp.c2_prev, bp.c2 = S.g2[t].data_ptr(), S.c2[t].data_ptr(), S.c2[t + 1].data_ptr()
             bp.dhd, bp.dG1, bp.dG2 = dhd[t].data_ptr(), dG1[t].data_ptr(), dG2[t].data_ptr()
+            bp.d_feat = d_feat_all[t].data_ptr()
+            if gate:
+                bp.dv, bp.ds = dv_all[t].data_ptr(), ds_all[t].data_ptr()
             bp.dc1_in, bp.dc1_out = dc1_rec[nxt].data_ptr(), dc1_rec[cur].data_ptr()
             bp.dc2_in, bp.dc2_out = dc2_rec[nxt].data_ptr(), dc2_rec[cur].data_ptr()
             if has_c:
@@ -279,6 +283,11 @@ def _backward(cap, S, dlogp, d_fc_feats, d_cpt_feats):
             if gate:
                 bp.z, bp.beta, bp.dz = S.z[t].data_ptr(), S.bG[:, t:t + 1].data_ptr(), dz[t].data_ptr()
             ops.step_bwd(bp)
+
+    if has_c:
+        ops.attn_dv_from_alpha(S.aC, dv_all, dV_att)
+    if has_s:
+        ops.attn_dv_from_alpha(S.aS, ds_all, dV_w)
 
     # ---- weight gradients: one contraction over all T*B rows each
     dG1f, dG2f = dG1.view(TB, 4 * H), dG2.view(TB, 4 * H)

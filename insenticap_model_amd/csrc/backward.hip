@@ -133,9 +133,10 @@ __global__ __launch_bounds__(1024) void attn_scan_bwd_kernel(const DevScanBwdLau
     for (int r = tid; r < R; r += NT) de[r] = alpha[r] * (de[r] - s);   // d e_r (softmax backward)
     __syncthreads();
 
-    // dV[r,:] (+)= alpha_r * dout
+    // dV[r,:] (+)= alpha_r * dout   (S.dV == nullptr: the caller sums alpha_t x dout_t over the steps in one pass
+    // afterwards - isc_attn_dv_from_alpha - instead of re-reading and re-writing dV at every step)
     float4 *dVb = reinterpret_cast<float4 *>(S.dV + (long long)b * R * D);
-    {
+    if (S.dV) {
         const int dgrp = NT / D4;                         // row groups working in parallel
         const int d = tid % D4, g0 = tid / D4;
         if (g0 < dgrp) {
@@ -200,11 +201,11 @@ extern "C" int isc_attn_scan_bwd(const isc_scan_bwd_problem *pr, int n_prob, int
     size_t lds = 0;
     for (int i = 0; i < n_prob; ++i) {
         const isc_scan_bwd_problem &q = pr[i];
-        if (!q.P || !q.V || !q.q || !q.w || !q.alpha || !q.dout || !q.dP || !q.dV || !q.dq || !q.dw_rows)
-            return ISC_E_NULL;
+        if (!q.P || !q.V || !q.q || !q.w || !q.alpha || !q.dout || !q.dP || !q.dq || !q.dw_rows)
+            return ISC_E_NULL;                     // (dV may be null: isc_attn_dv_from_alpha)
         if (q.R <= 0 || q.A <= 0 || q.D <= 0 || q.A > 1024) return ISC_E_SHAPE;
         if ((q.A & 3) || (q.D & 3) || (1024 % (q.A / 4)) != 0 || (1024 % (q.D / 4)) != 0) return ISC_E_SHAPE;
-        if (!isc_aligned16(q.P) || !isc_aligned16(q.V) || !isc_aligned16(q.dP) || !isc_aligned16(q.dV) ||
+        if (!isc_aligned16(q.P) || !isc_aligned16(q.V) || !isc_aligned16(q.dP) || (q.dV && !isc_aligned16(q.dV)) ||
             !isc_aligned16(q.q) || !isc_aligned16(q.w) || !isc_aligned16(q.dout) || (q.q2 && !isc_aligned16(q.q2)))
             return ISC_E_ALIGN;
         DevScanBwd &d = L.p[i];
@@ -218,6 +219,67 @@ extern "C" int isc_attn_scan_bwd(const isc_scan_bwd_problem *pr, int n_prob, int
     lds *= sizeof(float);
     if (lds > 60000) return ISC_E_SHAPE;
     hipLaunchKernelGGL(attn_scan_bwd_kernel, dim3(B, n_prob), dim3(1024), lds, (hipStream_t)stream, L);
+    ISC_LAUNCH_CHECK();
+    return ISC_OK;
+}
+
+// dV[b,r,:] = sum over the steps, in the order of the backward sweep (t = T-1 ... 0), of alpha[b,t,r] * dout[t,b,:]:
+// the accumulation that attn_scan_bwd_kernel otherwise does as a read-modify-write of the whole [B,R,D] tensor at every
+// step (a third of its traffic), done once from the T small per-step gradients.  Same products, same order of additions.
+#define ISC_DV_TMAX 24
+__global__ __launch_bounds__(256) void attn_dv_from_alpha_kernel(const float *alpha, long long ld_b, long long ld_t,
+                                                                 const float *dout, int B, int T, int R, int D,
+                                                                 float *dV) {
+#pragma clang fp contract(off)
+    extern __shared__ float sa[];                  // [T][R]
+    const int b = blockIdx.x, tid = threadIdx.x;
+    for (int i = tid; i < T * R; i += 256) sa[i] = alpha[(long long)b * ld_b + (long long)(i / R) * ld_t + (i % R)];
+    __syncthreads();
+    const int D4 = D >> 2, ngrp = 256 / D4, d4 = tid % D4, grp = tid / D4;
+    if (grp >= ngrp) return;
+    const float4 *g4 = reinterpret_cast<const float4 *>(dout);
+    float4 *o4 = reinterpret_cast<float4 *>(dV + (long long)b * R * D);
+    if (T <= ISC_DV_TMAX) {
+        float4 g[ISC_DV_TMAX];
+#pragma unroll
+        for (int t = 0; t < ISC_DV_TMAX; ++t)
+            g[t] = t < T ? g4[((long long)t * B + b) * D4 + d4] : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int r = grp; r < R; r += ngrp) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int t = ISC_DV_TMAX - 1; t >= 0; --t) {
+                if (t < T) {
+                    const float al = sa[t * R + r];
+                    // product rounded, then added (contraction is off in this kernel): what the per-step kernel's
+                    // `v = alpha * g; v += previous` compiles to - checked bit for bit by tests/test_gpu_backward.py
+                    acc.x = al * g[t].x + acc.x; acc.y = al * g[t].y + acc.y;
+                    acc.z = al * g[t].z + acc.z; acc.w = al * g[t].w + acc.w;
+                }
+            }
+            o4[(long long)r * D4 + d4] = acc;
+        }
+    } else {
+        for (int r = grp; r < R; r += ngrp) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int t = T - 1; t >= 0; --t) {
+                const float al = sa[t * R + r];
+                const float4 g = g4[((long long)t * B + b) * D4 + d4];
+                acc.x = al * g.x + acc.x; acc.y = al * g.y + acc.y; acc.z = al * g.z + acc.z; acc.w = al * g.w + acc.w;
+            }
+            o4[(long long)r * D4 + d4] = acc;
+        }
+    }
+}
+
+extern "C" int isc_attn_dv_from_alpha(const float *alpha, int64_t alpha_ld_b, int64_t alpha_ld_t, const float *dout,
+                                      int B, int T, int R, int D, float *dV, void *stream) {
+    if (!alpha || !dout || !dV) return ISC_E_NULL;
+    if (B <= 0 || T <= 0 || R <= 0 || D <= 0 || (D & 3) || (256 % (D / 4)) != 0 || D > 1024) return ISC_E_SHAPE;
+    if (!isc_aligned16(dout) || !isc_aligned16(dV)) return ISC_E_ALIGN;
+    const size_t lds = (size_t)T * R * sizeof(float);
+    if (lds > 60000) return ISC_E_SHAPE;
+    hipLaunchKernelGGL(attn_dv_from_alpha_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, alpha,
+                       (long long)alpha_ld_b, (long long)alpha_ld_t, dout, B, T, R, D, dV);
     ISC_LAUNCH_CHECK();
     return ISC_OK;
 }

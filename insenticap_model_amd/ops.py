@@ -507,14 +507,24 @@ def lstm_bwd(dh, dh2, dc_next, gates, c_prev, c, dgates, dc_prev, dgates_sum=Non
 def scan_bwd_problem(P, V, q, w, alpha, dout, dP, dV, dq, dw_rows, accumulate, q2=None):
     s = _lib.ScanBwdProblem()
     for x in (P, V, q, dout, dP, dV, dq, dw_rows):
-        assert x.is_contiguous()
+        assert x is None or x.is_contiguous()          # (dV None: attn_dv_from_alpha forms it after the sweep)
     assert alpha.stride(1) == 1
     s.P, s.V, s.q, s.q2, s.w = P.data_ptr(), V.data_ptr(), q.data_ptr(), ptr(q2), w.data_ptr()
     s.alpha, s.alpha_ld, s.dout = alpha.data_ptr(), alpha.stride(0), dout.data_ptr()
     s.R, s.A, s.D = P.shape[1], P.shape[2], V.shape[2]
     s.accumulate = int(accumulate)
-    s.dP, s.dV, s.dq, s.dw_rows = dP.data_ptr(), dV.data_ptr(), dq.data_ptr(), dw_rows.data_ptr()
+    s.dP, s.dV, s.dq, s.dw_rows = dP.data_ptr(), ptr(dV), dq.data_ptr(), dw_rows.data_ptr()
     return s
+
+
+def attn_dv_from_alpha(alpha, dout_all, dV):
+    """dV[b,r,:] = sum_t alpha[b,t,r] * dout_all[t,b,:] in the backward sweep's order (isc_attn_dv_from_alpha).
+    alpha: [B,T,R] view with unit inner stride; dout_all [T,B,D] contiguous; dV [B,R,D] contiguous."""
+    B, T, R = alpha.shape
+    D = dV.shape[2]
+    assert alpha.stride(2) == 1 and dout_all.is_contiguous() and dV.is_contiguous() and dout_all.shape == (T, B, D)
+    check(_lib.load().isc_attn_dv_from_alpha(alpha.data_ptr(), alpha.stride(0), alpha.stride(1), dout_all.data_ptr(),
+                                             B, T, R, D, dV.data_ptr(), stream()), 'isc_attn_dv_from_alpha')
 
 
 def attn_scan_bwd(problems, B):

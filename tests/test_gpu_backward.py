@@ -206,3 +206,32 @@ def test_fullsize_train_iteration_digests(golden, name):
         if gkey in g.files and g[gkey][2] > 1e-6:
             assert abs(got[2] - ref[2]) <= 5e-5 * ref[2] + 1e-6, k    # noise-gradient elements may step the other way
         np.testing.assert_allclose(got[3:], ref[3:], atol=4.1e-4, err_msg=k)
+
+
+def test_dv_summed_after_the_sweep_equals_the_per_step_accumulation():
+    """isc_attn_dv_from_alpha (dV = sum_t alpha_t x dout_t once, after the sweep) against isc_attn_scan_bwd accumulating
+    dV at every step in the sweep's order: bit-identical; the other outputs of the scan backward do not change when dV is
+    left out of it."""
+    D_ = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(11)
+    B, T, R, A = 37, 7, 36, 512
+    Pm, Vm = torch.randn(B, R, A, generator=g).to(D_), torch.randn(B, R, A, generator=g).to(D_)
+    w = (torch.randn(1, A, generator=g) * 0.3).to(D_)
+    q = torch.randn(T, B, A, generator=g).to(D_)
+    alpha = torch.softmax(torch.randn(B, T, R, generator=g), dim=-1).to(D_)
+    dout = torch.randn(T, B, A, generator=g).to(D_)
+    outs = {}
+    for with_dv in (True, False):
+        dP, dV = torch.empty(B, R, A, device=D_), (torch.empty(B, R, A, device=D_) if with_dv else None)
+        dq, dw = torch.empty(T, B, A, device=D_), torch.empty(B, A, device=D_)
+        for i, t in enumerate(range(T - 1, -1, -1)):
+            ops.attn_scan_bwd([ops.scan_bwd_problem(Pm, Vm, q[t], w, alpha[:, t], dout[t], dP, dV, dq[t], dw, i > 0)], B)
+        outs[with_dv] = (dP, dq, dw, dV)
+    dV2 = torch.empty(B, R, A, device=D_)
+    ops.attn_dv_from_alpha(alpha, dout, dV2)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[True][3], dV2)
+    for k in range(3):
+        assert torch.equal(outs[True][k], outs[False][k]), k
+    ref = torch.einsum('btr,tbd->brd', alpha.double().cpu(), dout.double().cpu())
+    np.testing.assert_allclose(dV2.cpu().numpy(), ref.float().numpy(), atol=2e-5)
