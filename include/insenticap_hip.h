@@ -400,6 +400,8 @@ typedef struct {
     float *dwc_rows, *dws_rows, *dwg_rows, *dbg_rows;
     float *splitk_ws;                   /* optional split-K workspace */
     int64_t splitk_ws_floats;
+    float *de_c, *de_s;                 /* optional [rows,R] / [rows,Mw]: this step's d e of the two scans (isc_scan_bwd_problem.de_out);
+                                           dP_att / dP_w and dV_att / dV_w may then be NULL (isc_attn_dp_from_de, _dv_from_alpha) */
 } isc_step_bwd_plan;
 
 int isc_step_bwd(const isc_step_bwd_plan *plan_host, void *stream);
@@ -428,6 +430,7 @@ typedef struct {
     int64_t alpha_ld;
     int32_t R, A, D, accumulate;
     float *dP, *dV, *dq, *dw_rows;
+    float *de_out;            /* optional [B,R]: this step's d e (softmax backward); required when dP is NULL */
 } isc_scan_bwd_problem;
 
 int isc_attn_scan_bwd(const isc_scan_bwd_problem *probs_host, int n_prob, int B, void *stream);
@@ -436,6 +439,11 @@ int isc_attn_scan_bwd(const isc_scan_bwd_problem *probs_host, int n_prob, int B,
  * additions: bit-identical to the per-step accumulation), instead of re-reading and re-writing [B,R,D] at every step. */
 int isc_attn_dv_from_alpha(const float *alpha, int64_t alpha_ld_b, int64_t alpha_ld_t, const float *dout,
                            int B, int T, int R, int D, float *dV, void *stream);
+/* dP may be NULL as well (with de_out given): dP[b,r,a] = sum_{t = T-1 .. 0} de[(t*B + b)*R + r] * w[a] *
+ * (1 - tanh^2(P[b,r,a] + q[(t*B + b)*A + a] (+ q2[b*A + a]))) is then formed once after the sweep - P read once, the
+ * tanh terms recomputed; same expression and order of additions as the per-step accumulation.  R <= 18 * 1024 / A. */
+int isc_attn_dp_from_de(const float *P, const float *q, const float *q2, const float *w, const float *de,
+                        int B, int T, int R, int A, float *dP, void *stream);
 
 /* Backward of isc_gate_mix_fwd: dv = beta*dfeat, ds = (1-beta)*dfeat, dz, per-row partials of
  * d w (dw_rows [B,A]) and d w_bias (db_rows [B]). */

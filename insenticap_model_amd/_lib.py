@@ -51,7 +51,8 @@ class ScanBwdProblem(C.Structure):
     _fields_ = [('P', C.c_void_p), ('V', C.c_void_p), ('q', C.c_void_p), ('q2', C.c_void_p),
                 ('w', C.c_void_p), ('alpha', C.c_void_p), ('dout', C.c_void_p), ('alpha_ld', C.c_int64),
                 ('R', C.c_int32), ('A', C.c_int32), ('D', C.c_int32), ('accumulate', C.c_int32),
-                ('dP', C.c_void_p), ('dV', C.c_void_p), ('dq', C.c_void_p), ('dw_rows', C.c_void_p)]
+                ('dP', C.c_void_p), ('dV', C.c_void_p), ('dq', C.c_void_p), ('dw_rows', C.c_void_p),
+                ('de_out', C.c_void_p)]
 
 
 def _f(names, ctype):
@@ -85,7 +86,7 @@ class StepBwdPlan(C.Structure):
                 _f('alpha_c_ld alpha_s_ld beta_ld', C.c_int64) +
                 _f('dhd dG1 dG2 dG1_sum d_feat dh1 dv ds dh2_rec dh1_rec dc1_in dc2_in dc1_out dc2_out '
                    'dqa dqw dz dP_att dV_att dP_w dV_w dwc_rows dws_rows dwg_rows dbg_rows splitk_ws',
-                   C.c_void_p) + [('splitk_ws_floats', C.c_int64)])
+                   C.c_void_p) + [('splitk_ws_floats', C.c_int64), ('de_c', C.c_void_p), ('de_s', C.c_void_p)])
 
 
 class BeamMergeArgs(C.Structure):
@@ -156,6 +157,8 @@ SIGNATURES = {
     'isc_attn_scan_bwd': (C.c_int, [C.POINTER(ScanBwdProblem), C.c_int, C.c_int, C.c_void_p]),
     'isc_attn_dv_from_alpha': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                          C.c_int, C.c_void_p, C.c_void_p]),
+    'isc_attn_dp_from_de': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                      C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     'isc_gate_mix_bwd': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                    C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),

@@ -222,10 +222,12 @@ def _backward(cap, S, dlogp, d_fc_feats, d_cpt_feats):
     if has_c:
         dqa, dv_all = new(T, B, A), (new(T, B, E) if gate else d_feat_all)
         dP_att, dV_att = new(B, P.R, A), new(B, P.R, E)
+        de_c = new(T, B, P.R)           # d e of every step: dP is formed once after the sweep (ops.attn_dp_from_de)
         dwc_rows = new(B, A)
     if has_s:
         dqw, ds_all = new(T, B, A), (new(T, B, E) if gate else d_feat_all)
         dP_w, dV_w = new(B, P.Mw, A), new(B, P.Mw, Wd)
+        de_s = new(T, B, P.Mw)
         dws_rows = new(B, A)
     if gate:
         dz = new(T, B, A)
@@ -252,10 +254,10 @@ def _backward(cap, S, dlogp, d_fc_feats, d_cpt_feats):
     bp.dG1_sum, bp.dh1 = dG1_sum.data_ptr(), dh1.data_ptr()
     bp.dh2_rec, bp.dh1_rec = dh2_rec.data_ptr(), dh1_rec.data_ptr()
     if has_c:
-        bp.dP_att, bp.dV_att, bp.dwc_rows = dP_att.data_ptr(), None, dwc_rows.data_ptr()
+        bp.dP_att, bp.dV_att, bp.dwc_rows = None, None, dwc_rows.data_ptr()
         bp.alpha_c_ld = S.aC.stride(0)
     if has_s:
-        bp.dP_w, bp.dV_w, bp.dws_rows = dP_w.data_ptr(), None, dws_rows.data_ptr()
+        bp.dP_w, bp.dV_w, bp.dws_rows = None, None, dws_rows.data_ptr()
         bp.alpha_s_ld = S.aS.stride(0)
     if gate:
         bp.dwg_rows, bp.dbg_rows = dwg_rows.data_ptr(), dbg_rows.data_ptr()
@@ -277,17 +279,21 @@ def _backward(cap, S, dlogp, d_fc_feats, d_cpt_feats):
             if has_c:
                 bp.qa, bp.v, bp.alpha_c, bp.dqa = S.qa[t].data_ptr(), S.v[t].data_ptr(), S.aC[:, t].data_ptr(), \
                     dqa[t].data_ptr()
+                bp.de_c = de_c[t].data_ptr()
             if has_s:
                 bp.qw, bp.s, bp.alpha_s, bp.dqw = S.qw[t].data_ptr(), S.s[t].data_ptr(), S.aS[:, t].data_ptr(), \
                     dqw[t].data_ptr()
+                bp.de_s = de_s[t].data_ptr()
             if gate:
                 bp.z, bp.beta, bp.dz = S.z[t].data_ptr(), S.bG[:, t:t + 1].data_ptr(), dz[t].data_ptr()
             ops.step_bwd(bp)
 
     if has_c:
         ops.attn_dv_from_alpha(S.aC, dv_all, dV_att)
+        ops.attn_dp_from_de(P.att_p3, S.qa, p['attention.cont_att.att_alpha.weight'], de_c, dP_att)
     if has_s:
         ops.attn_dv_from_alpha(S.aS, ds_all, dV_w)
+        ops.attn_dp_from_de(P.words_p3, S.qw, p['attention.senti_att.word_alpha.weight'], de_s, dP_w, q2=P.label_w)
 
     # ---- weight gradients: one contraction over all T*B rows each
     dG1f, dG2f = dG1.view(TB, 4 * H), dG2.view(TB, 4 * H)

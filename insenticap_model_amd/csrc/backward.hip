@@ -79,11 +79,20 @@ extern "C" int isc_lstm_bwd(const float *dh, const float *dh2, const float *dc_n
 }
 
 // ------------------------------------------------------------------ attention scan backward
+// d e * w * (1 - tanh^2) with a fixed instruction sequence (one fused 1 - t^2, two multiplications, nothing fused into
+// what follows): the per-step kernel and isc_attn_dp_from_de must produce the same bits from the same inputs.
+__device__ __forceinline__ float isc_dtanh_term(float der, float w, float t) {
+#pragma clang fp contract(off)
+    const float omt = __builtin_fmaf(-t, t, 1.0f);
+    float r = (der * w) * omt;
+    asm volatile("" : "+v"(r));
+    return r;
+}
 struct DevScanBwd {
     const float *P, *V, *q, *q2, *w, *alpha, *dout;
     long long alpha_ld;
     int R, A, D, accumulate;
-    float *dP, *dV, *dq, *dw_rows;
+    float *dP, *dV, *dq, *dw_rows, *de_out;
 };
 struct DevScanBwdLaunch {
     DevScanBwd p[2];
@@ -130,7 +139,11 @@ __global__ __launch_bounds__(1024) void attn_scan_bwd_kernel(const DevScanBwdLau
     float s = 0.f;
     for (int r = 0; r < R; ++r) s += alpha[r] * de[r];
     __syncthreads();
-    for (int r = tid; r < R; r += NT) de[r] = alpha[r] * (de[r] - s);   // d e_r (softmax backward)
+    for (int r = tid; r < R; r += NT) {                                  // d e_r (softmax backward)
+        const float d = alpha[r] * (de[r] - s);
+        de[r] = d;
+        if (S.de_out) S.de_out[(long long)b * R + r] = d;                // kept per step: isc_attn_dp_from_de
+    }
     __syncthreads();
 
     // dV[r,:] (+)= alpha_r * dout   (S.dV == nullptr: the caller sums alpha_t x dout_t over the steps in one pass
@@ -168,12 +181,14 @@ __global__ __launch_bounds__(1024) void attn_scan_bwd_kernel(const DevScanBwdLau
             const float der = de[r];
             const float tx = isc_tanh(pv.x + qa.x), ty = isc_tanh(pv.y + qa.y);
             const float tz = isc_tanh(pv.z + qa.z), tw = isc_tanh(pv.w + qa.w);
-            float4 gr = make_float4(der * wa.x * (1.f - tx * tx), der * wa.y * (1.f - ty * ty),
-                                    der * wa.z * (1.f - tz * tz), der * wa.w * (1.f - tw * tw));
+            float4 gr = make_float4(isc_dtanh_term(der, wa.x, tx), isc_dtanh_term(der, wa.y, ty),
+                                    isc_dtanh_term(der, wa.z, tz), isc_dtanh_term(der, wa.w, tw));
             dq.x += gr.x; dq.y += gr.y; dq.z += gr.z; dq.w += gr.w;
             dw.x += der * tx; dw.y += der * ty; dw.z += der * tz; dw.w += der * tw;
-            if (S.accumulate) { const float4 c = dPb[o]; gr.x += c.x; gr.y += c.y; gr.z += c.z; gr.w += c.w; }
-            dPb[o] = gr;
+            if (S.dP) {      // (nullptr: dP is formed once after the sweep from the per-step d e - isc_attn_dp_from_de)
+                if (S.accumulate) { const float4 c = dPb[o]; gr.x += c.x; gr.y += c.y; gr.z += c.z; gr.w += c.w; }
+                dPb[o] = gr;
+            }
         }
         reinterpret_cast<float4 *>(red + grp * A)[a4] = dq;
         reinterpret_cast<float4 *>(red + (ngrp + grp) * A)[a4] = dw;
@@ -201,17 +216,18 @@ extern "C" int isc_attn_scan_bwd(const isc_scan_bwd_problem *pr, int n_prob, int
     size_t lds = 0;
     for (int i = 0; i < n_prob; ++i) {
         const isc_scan_bwd_problem &q = pr[i];
-        if (!q.P || !q.V || !q.q || !q.w || !q.alpha || !q.dout || !q.dP || !q.dq || !q.dw_rows)
-            return ISC_E_NULL;                     // (dV may be null: isc_attn_dv_from_alpha)
+        if (!q.P || !q.V || !q.q || !q.w || !q.alpha || !q.dout || !q.dq || !q.dw_rows)
+            return ISC_E_NULL;                     // (dV / dP may be null: isc_attn_dv_from_alpha / isc_attn_dp_from_de)
+        if (!q.dP && !q.de_out) return ISC_E_NULL;
         if (q.R <= 0 || q.A <= 0 || q.D <= 0 || q.A > 1024) return ISC_E_SHAPE;
         if ((q.A & 3) || (q.D & 3) || (1024 % (q.A / 4)) != 0 || (1024 % (q.D / 4)) != 0) return ISC_E_SHAPE;
-        if (!isc_aligned16(q.P) || !isc_aligned16(q.V) || !isc_aligned16(q.dP) || (q.dV && !isc_aligned16(q.dV)) ||
+        if (!isc_aligned16(q.P) || !isc_aligned16(q.V) || (q.dP && !isc_aligned16(q.dP)) || (q.dV && !isc_aligned16(q.dV)) ||
             !isc_aligned16(q.q) || !isc_aligned16(q.w) || !isc_aligned16(q.dout) || (q.q2 && !isc_aligned16(q.q2)))
             return ISC_E_ALIGN;
         DevScanBwd &d = L.p[i];
         d.P = q.P; d.V = q.V; d.q = q.q; d.q2 = q.q2; d.w = q.w; d.alpha = q.alpha; d.dout = q.dout;
         d.alpha_ld = q.alpha_ld; d.R = q.R; d.A = q.A; d.D = q.D; d.accumulate = q.accumulate;
-        d.dP = q.dP; d.dV = q.dV; d.dq = q.dq; d.dw_rows = q.dw_rows;
+        d.dP = q.dP; d.dV = q.dV; d.dq = q.dq; d.dw_rows = q.dw_rows; d.de_out = q.de_out;
         const int ngrp = 1024 / (q.A / 4);
         const size_t need = (((size_t)q.R + 3) & ~(size_t)3) + (size_t)2 * ngrp * q.A;
         if (need > lds) lds = need;
@@ -280,6 +296,72 @@ extern "C" int isc_attn_dv_from_alpha(const float *alpha, int64_t alpha_ld_b, in
     if (lds > 60000) return ISC_E_SHAPE;
     hipLaunchKernelGGL(attn_dv_from_alpha_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, alpha,
                        (long long)alpha_ld_b, (long long)alpha_ld_t, dout, B, T, R, D, dV);
+    ISC_LAUNCH_CHECK();
+    return ISC_OK;
+}
+
+// dP[b,r,a] = sum over the steps, in the sweep's order, of d e[t,b,r] * w[a] * (1 - tanh^2(P[b,r,a] + q_t[b,a] (+ q2[b,a]))):
+// the other per-step read-modify-write of attn_scan_bwd_kernel, done once from the T small per-step vectors d e_t and
+// q_t.  P is read once and kept in registers over the steps; the tanh terms are recomputed (the per-step kernel needs
+// them anyway for d q).  Same expression, same order of additions as the per-step accumulation.
+#define ISC_DP_RMAX 18          // regions per thread: R <= 2 * ISC_DP_RMAX with A = 512 (two region groups)
+__global__ __launch_bounds__(256) void attn_dp_from_de_kernel(const float *P, const float *q, const float *q2,
+                                                              const float *w, const float *de, int B, int T, int R,
+                                                              int A, float *dP) {
+    extern __shared__ float sde[];                 // [T][R]
+    const int b = blockIdx.x, tid = threadIdx.x;
+    for (int i = tid; i < T * R; i += 256) sde[i] = de[((long long)(i / R) * B + b) * R + (i % R)];
+    __syncthreads();
+    const int A4 = A >> 2, ngrp = 256 / A4, a4 = tid % A4, grp = tid / A4;
+    if (grp >= ngrp) return;
+    const float4 *Pb = reinterpret_cast<const float4 *>(P + (long long)b * R * A);
+    float4 *dPb = reinterpret_cast<float4 *>(dP + (long long)b * R * A);
+    const float4 wa = reinterpret_cast<const float4 *>(w)[a4];
+    float4 q2v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (q2) q2v = reinterpret_cast<const float4 *>(q2 + (long long)b * A)[a4];
+    float4 pv[ISC_DP_RMAX], acc[ISC_DP_RMAX];
+#pragma unroll
+    for (int i = 0; i < ISC_DP_RMAX; ++i) {
+        const int r = grp + i * ngrp;
+        pv[i] = r < R ? Pb[(long long)r * A4 + a4] : make_float4(0.f, 0.f, 0.f, 0.f);
+        acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (int t = T - 1; t >= 0; --t) {
+        float4 qa = reinterpret_cast<const float4 *>(q + ((long long)t * B + b) * A)[a4];
+        if (q2) { qa.x += q2v.x; qa.y += q2v.y; qa.z += q2v.z; qa.w += q2v.w; }
+#pragma unroll
+        for (int i = 0; i < ISC_DP_RMAX; ++i) {
+            const int r = grp + i * ngrp;
+            if (r < R) {
+                const float der = sde[t * R + r];
+                const float tx = isc_tanh(pv[i].x + qa.x), ty = isc_tanh(pv[i].y + qa.y);
+                const float tz = isc_tanh(pv[i].z + qa.z), tw = isc_tanh(pv[i].w + qa.w);
+                const float4 gr = make_float4(isc_dtanh_term(der, wa.x, tx), isc_dtanh_term(der, wa.y, ty),
+                                              isc_dtanh_term(der, wa.z, tz), isc_dtanh_term(der, wa.w, tw));
+                // (the per-step kernel adds the finished value to what it read back: an add, never fused)
+                acc[i].x = gr.x + acc[i].x; acc[i].y = gr.y + acc[i].y;
+                acc[i].z = gr.z + acc[i].z; acc[i].w = gr.w + acc[i].w;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < ISC_DP_RMAX; ++i) {
+        const int r = grp + i * ngrp;
+        if (r < R) dPb[(long long)r * A4 + a4] = acc[i];
+    }
+}
+
+extern "C" int isc_attn_dp_from_de(const float *P, const float *q, const float *q2, const float *w, const float *de,
+                                   int B, int T, int R, int A, float *dP, void *stream) {
+    if (!P || !q || !w || !de || !dP) return ISC_E_NULL;
+    if (B <= 0 || T <= 0 || R <= 0 || A <= 0 || (A & 3) || (256 % (A / 4)) != 0 || A > 1024) return ISC_E_SHAPE;
+    if (R > ISC_DP_RMAX * (256 / (A / 4))) return ISC_E_SHAPE;
+    if (!isc_aligned16(P) || !isc_aligned16(q) || !isc_aligned16(w) || !isc_aligned16(dP) || (q2 && !isc_aligned16(q2)))
+        return ISC_E_ALIGN;
+    const size_t lds = (size_t)T * R * sizeof(float);
+    if (lds > 60000) return ISC_E_SHAPE;
+    hipLaunchKernelGGL(attn_dp_from_de_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, P, q, q2, w, de, B, T, R, A,
+                       dP);
     ISC_LAUNCH_CHECK();
     return ISC_OK;
 }

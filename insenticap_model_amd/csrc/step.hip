@@ -167,13 +167,13 @@ extern "C" int isc_step_bwd(const isc_step_bwd_plan *p, void *stream) {
             isc_scan_bwd_problem &x = sc[n++];
             x.P = p->att_p; x.V = p->att_e; x.q = p->qa; x.w = p->w_alpha_c; x.alpha = p->alpha_c;
             x.alpha_ld = p->alpha_c_ld; x.dout = dv; x.R = p->R; x.A = A; x.D = E; x.accumulate = acc;
-            x.dP = p->dP_att; x.dV = p->dV_att; x.dq = p->dqa; x.dw_rows = p->dwc_rows;
+            x.dP = p->dP_att; x.dV = p->dV_att; x.dq = p->dqa; x.dw_rows = p->dwc_rows; x.de_out = p->de_c;
         }
         if (has_s) {
             isc_scan_bwd_problem &x = sc[n++];
             x.P = p->words_p; x.V = p->words_e; x.q = p->qw; x.q2 = p->label_w; x.w = p->w_alpha_s;
             x.alpha = p->alpha_s; x.alpha_ld = p->alpha_s_ld; x.dout = dsw; x.R = p->Mw; x.A = A; x.D = W;
-            x.accumulate = acc; x.dP = p->dP_w; x.dV = p->dV_w; x.dq = p->dqw; x.dw_rows = p->dws_rows;
+            x.accumulate = acc; x.dP = p->dP_w; x.dV = p->dV_w; x.dq = p->dqw; x.dw_rows = p->dws_rows; x.de_out = p->de_s;
         }
         RET(isc_attn_scan_bwd(sc, n, rows, stream));
     }

@@ -504,7 +504,7 @@ def lstm_bwd(dh, dh2, dc_next, gates, c_prev, c, dgates, dc_prev, dgates_sum=Non
                            stream()), 'isc_lstm_bwd')
 
 
-def scan_bwd_problem(P, V, q, w, alpha, dout, dP, dV, dq, dw_rows, accumulate, q2=None):
+def scan_bwd_problem(P, V, q, w, alpha, dout, dP, dV, dq, dw_rows, accumulate, q2=None, de_out=None):
     s = _lib.ScanBwdProblem()
     for x in (P, V, q, dout, dP, dV, dq, dw_rows):
         assert x is None or x.is_contiguous()          # (dV None: attn_dv_from_alpha forms it after the sweep)
@@ -513,7 +513,8 @@ def scan_bwd_problem(P, V, q, w, alpha, dout, dP, dV, dq, dw_rows, accumulate, q
     s.alpha, s.alpha_ld, s.dout = alpha.data_ptr(), alpha.stride(0), dout.data_ptr()
     s.R, s.A, s.D = P.shape[1], P.shape[2], V.shape[2]
     s.accumulate = int(accumulate)
-    s.dP, s.dV, s.dq, s.dw_rows = dP.data_ptr(), ptr(dV), dq.data_ptr(), dw_rows.data_ptr()
+    s.dP, s.dV, s.dq, s.dw_rows = ptr(dP), ptr(dV), dq.data_ptr(), dw_rows.data_ptr()
+    s.de_out = ptr(de_out)
     return s
 
 
@@ -525,6 +526,18 @@ def attn_dv_from_alpha(alpha, dout_all, dV):
     assert alpha.stride(2) == 1 and dout_all.is_contiguous() and dV.is_contiguous() and dout_all.shape == (T, B, D)
     check(_lib.load().isc_attn_dv_from_alpha(alpha.data_ptr(), alpha.stride(0), alpha.stride(1), dout_all.data_ptr(),
                                              B, T, R, D, dV.data_ptr(), stream()), 'isc_attn_dv_from_alpha')
+
+
+def attn_dp_from_de(P, q_all, w, de_all, dP, q2=None):
+    """dP[b,r,:] = sum_t de_all[t,b,r] * w * (1 - tanh^2(P[b,r,:] + q_all[t,b,:] (+ q2[b,:]))) in the backward sweep's
+    order (isc_attn_dp_from_de).  P, dP [B,R,A]; q_all [T,B,A]; de_all [T,B,R]; all contiguous."""
+    B, R, A = P.shape
+    T = q_all.shape[0]
+    for x in (P, q_all, de_all, dP, q2):
+        assert x is None or x.is_contiguous()
+    assert q_all.shape == (T, B, A) and de_all.shape == (T, B, R) and dP.shape == P.shape
+    check(_lib.load().isc_attn_dp_from_de(P.data_ptr(), q_all.data_ptr(), ptr(q2), w.data_ptr(), de_all.data_ptr(),
+                                          B, T, R, A, dP.data_ptr(), stream()), 'isc_attn_dp_from_de')
 
 
 def attn_scan_bwd(problems, B):

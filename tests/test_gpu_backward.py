@@ -208,30 +208,40 @@ def test_fullsize_train_iteration_digests(golden, name):
         np.testing.assert_allclose(got[3:], ref[3:], atol=4.1e-4, err_msg=k)
 
 
-def test_dv_summed_after_the_sweep_equals_the_per_step_accumulation():
-    """isc_attn_dv_from_alpha (dV = sum_t alpha_t x dout_t once, after the sweep) against isc_attn_scan_bwd accumulating
-    dV at every step in the sweep's order: bit-identical; the other outputs of the scan backward do not change when dV is
-    left out of it."""
+def test_dv_and_dp_summed_after_the_sweep_equal_the_per_step_accumulation():
+    """isc_attn_dv_from_alpha / isc_attn_dp_from_de (dV = sum_t alpha_t x dout_t and dP = sum_t d e_t w (1 - tanh^2) once,
+    after the sweep) against isc_attn_scan_bwd accumulating dV and dP at every step in the sweep's order: bit-identical;
+    the other outputs of the scan backward do not change when the two are left out of it.  With and without q2."""
     D_ = torch.device('cuda:0')
     g = torch.Generator().manual_seed(11)
-    B, T, R, A = 37, 7, 36, 512
-    Pm, Vm = torch.randn(B, R, A, generator=g).to(D_), torch.randn(B, R, A, generator=g).to(D_)
-    w = (torch.randn(1, A, generator=g) * 0.3).to(D_)
-    q = torch.randn(T, B, A, generator=g).to(D_)
-    alpha = torch.softmax(torch.randn(B, T, R, generator=g), dim=-1).to(D_)
-    dout = torch.randn(T, B, A, generator=g).to(D_)
-    outs = {}
-    for with_dv in (True, False):
-        dP, dV = torch.empty(B, R, A, device=D_), (torch.empty(B, R, A, device=D_) if with_dv else None)
-        dq, dw = torch.empty(T, B, A, device=D_), torch.empty(B, A, device=D_)
-        for i, t in enumerate(range(T - 1, -1, -1)):
-            ops.attn_scan_bwd([ops.scan_bwd_problem(Pm, Vm, q[t], w, alpha[:, t], dout[t], dP, dV, dq[t], dw, i > 0)], B)
-        outs[with_dv] = (dP, dq, dw, dV)
-    dV2 = torch.empty(B, R, A, device=D_)
-    ops.attn_dv_from_alpha(alpha, dout, dV2)
-    torch.cuda.synchronize()
-    assert torch.equal(outs[True][3], dV2)
-    for k in range(3):
-        assert torch.equal(outs[True][k], outs[False][k]), k
-    ref = torch.einsum('btr,tbd->brd', alpha.double().cpu(), dout.double().cpu())
-    np.testing.assert_allclose(dV2.cpu().numpy(), ref.float().numpy(), atol=2e-5)
+    for B, T, R, A, with_q2 in ((37, 7, 36, 512, False), (21, 20, 11, 512, True), (5, 3, 6, 64, False)):
+        Pm, Vm = torch.randn(B, R, A, generator=g).to(D_), torch.randn(B, R, A, generator=g).to(D_)
+        w = (torch.randn(1, A, generator=g) * 0.3).to(D_)
+        q = torch.randn(T, B, A, generator=g).to(D_)
+        q2 = torch.randn(B, A, generator=g).to(D_) if with_q2 else None
+        alpha = torch.softmax(torch.randn(B, T, R, generator=g), dim=-1).to(D_)
+        dout = torch.randn(T, B, A, generator=g).to(D_)
+        outs = {}
+        for deferred in (False, True):
+            dP = None if deferred else torch.empty(B, R, A, device=D_)
+            dV = None if deferred else torch.empty(B, R, A, device=D_)
+            de = torch.empty(T, B, R, device=D_)
+            dq, dw = torch.empty(T, B, A, device=D_), torch.empty(B, A, device=D_)
+            for i, t in enumerate(range(T - 1, -1, -1)):
+                ops.attn_scan_bwd([ops.scan_bwd_problem(Pm, Vm, q[t], w, alpha[:, t], dout[t], dP, dV, dq[t], dw, i > 0,
+                                                        q2=q2, de_out=de[t])], B)
+            outs[deferred] = (dq, dw, de, dP, dV)
+        dV2, dP2 = torch.empty(B, R, A, device=D_), torch.empty(B, R, A, device=D_)
+        ops.attn_dv_from_alpha(alpha, dout, dV2)
+        ops.attn_dp_from_de(Pm, q, w, outs[True][2], dP2, q2=q2)
+        torch.cuda.synchronize()
+        assert torch.equal(outs[False][4], dV2), (B, T, R, A)
+        assert torch.equal(outs[False][3], dP2), (B, T, R, A)
+        for k in range(3):
+            assert torch.equal(outs[False][k], outs[True][k]), k
+        ref = torch.einsum('btr,tbd->brd', alpha.double().cpu(), dout.double().cpu())
+        np.testing.assert_allclose(dV2.cpu().numpy(), ref.float().numpy(), atol=2e-5)
+        qq = q.double().cpu() + (q2.double().cpu() if with_q2 else 0.0)
+        th = torch.tanh(Pm.double().cpu().unsqueeze(0) + qq.unsqueeze(2))                 # [T,B,R,A]
+        refP = (outs[True][2].double().cpu().unsqueeze(-1) * w.double().cpu().view(1, 1, 1, A) * (1 - th * th)).sum(0)
+        np.testing.assert_allclose(dP2.cpu().numpy(), refP.float().numpy(), atol=3e-5)

@@ -73,7 +73,7 @@ def _worker(rank, world, port, results):
 
 
 def test_two_rank_training_matches_single_process():
-    mgr = mp.Manager()
+    mgr = mp.get_context('spawn').Manager()      # (never fork a process that has initialised the GPU)
     results = mgr.dict()
     mp.spawn(_worker, args=(2, _free_port(), results), nprocs=2, join=True)
     cap = _make()
@@ -173,7 +173,7 @@ def test_two_rank_rl_step_matches_single_process():
     """Detector.forward(training=True) under DP: two ranks on half the fact batch and half the seq2seq batch each
     (different token counts and mask sums per rank), multinomial draws replayed, against ONE process on the whole
     batches: the loss dictionaries, the all-reduced gradient and the parameters after 3 steps."""
-    mgr = mp.Manager()
+    mgr = mp.get_context('spawn').Manager()      # (never fork a process that has initialised the GPU)
     results = mgr.dict()
     mp.spawn(_rl_worker, args=(2, _free_port(), results), nprocs=2, join=True)
     det = _make_detector()
