@@ -1766,6 +1766,11 @@ __global__ __launch_bounds__(256) void gemm_md_kernel(const DevLaunch L) {
 
 
 // ---------------------------------------------------------------- H3S: skinny split-f16 tiles for few-row launches
+// (H3S_LAB_MODE = 1 / 2 / 3 builds time-only variants of the kernel below - DMA only / + fragment reads / MFMAs without
+// reads - for tools/h3s_lab_modes.sh; 0, the default, compiles none of it.)
+#ifndef H3S_LAB_MODE
+#define H3S_LAB_MODE 0
+#endif
 // Launches with few rows (B <= a few hundred captions, beam rows, the 80-row seq2seq unroll) are not contraction-
 // bound: each of their GEMMs streams a weight matrix far larger than its activations, and the step is a chain of
 // such launches.  The fp32 route gave them a 32 x 128 tile per workgroup, split K over up to 16 workgroups, wrote
@@ -1904,9 +1909,18 @@ __global__ __launch_bounds__(64 * NW) void gemm_h3s_kernel(const DevLaunch L) {
             if (younger == 1) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
+#if H3S_LAB_MODE == 1                                      // lab: DMA only (tools/h3s_lab_modes.sh; wrong results)
+        if (EARLY) { if (i + R < n) issue(i + R); }
+        continue;
+#endif
         const char *img = lds + wave * (R * SLOT) + (i & (R - 1)) * SLOT + fr * 128;
         const bool af32 = (f32_bits >> (i & (R - 1))) & 1u;
         h8 a1[T][2], a2[T][2], b1[T][2], b2[T][2];
+#if H3S_LAB_MODE == 3                                      // lab: MFMAs on constant fragments, no LDS reads
+        for (int kk = 0; kk < 2; ++kk) for (int t = 0; t < T; ++t) for (int e = 0; e < 8; ++e) {
+            a1[t][kk][e] = (_Float16)1.f; a2[t][kk][e] = (_Float16)1.f; b1[t][kk][e] = (_Float16)2.f; b2[t][kk][e] = (_Float16)3.f; }
+        if (false)
+#endif
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
@@ -1935,6 +1949,11 @@ __global__ __launch_bounds__(64 * NW) void gemm_h3s_kernel(const DevLaunch L) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the fragments are in registers: the slot is free
             if (i + R < n) issue(i + R);
         }
+#if H3S_LAB_MODE == 2                                      // lab: DMA + fragment reads, no MFMAs
+        for (int kk = 0; kk < 2; ++kk) for (int t = 0; t < T; ++t)
+            asm volatile("" :: "v"(a1[t][kk]), "v"(a2[t][kk]), "v"(b1[t][kk]), "v"(b2[t][kk]));
+        continue;
+#endif
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
