@@ -4,11 +4,18 @@ pre-extracted 36x2048 region features, V=10k, length 20, sentiment-word attentio
 (BASELINE.json metric). One "step" = one greedy roll-out of a batch of B captions per GPU,
 inputs resident in HBM, weights random-init of the reference architecture.
 
-    python bench.py [--gpus N --steps K --warmup W --batch B]
+    python bench.py [--gpus N --steps K --warmup W --batch B --scaling weak|strong]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
 Images are independent, so multi-GPU is a pure shard of the batch (no data-path collective):
-weak scaling, value = N*B*K captions / max-over-ranks time.
+weak scaling (default), value = N*B*K captions / max-over-ranks time; `--scaling strong` keeps the GLOBAL batch at B.
+`--gpus N` with N > 1 and no launcher environment starts the N rank processes itself (python -m
+torch.distributed.run, 127.0.0.1 rendezvous) BEFORE this process makes any GPU call, relays rank 0's one JSON line and
+exits with the launcher's code; it refuses (exit 2) when the box has fewer than N GPUs, and a launcher whose WORLD_SIZE
+differs from --gpus is an error - a line can never say n_gpus: 1 for a --gpus 8 request.
+With N > 1 the line's `extra` carries the training curves of BASELINE configs[3] / [4]: `xe_train` (fixed 128 captions per
+GPU: weak), `xe_train_strong` (fixed GLOBAL batch 1024 -> 1024/N per GPU), `rl_iteration` (Detector.forward under DP, global
+B=512) and `grad_allreduce` (the 88 MB arena all-reduce alone, RCCL over xGMI).
 
 Extra objects on the JSON line:
   roofline      dominant kernel (largest share of the decode step): achieved algorithmic
@@ -24,13 +31,22 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
+import socket
+import subprocess
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from insenticap_model_amd import Captioner, ops, synth  # noqa: E402
+torch = np = Captioner = ops = synth = None
+
+
+def load_product():
+    """Imports of torch and the product, AFTER main() has decided whether this process is only a launcher."""
+    global torch, np, Captioner, ops, synth
+    import numpy as np_
+    import torch as torch_
+    from insenticap_model_amd import Captioner as Cap_, ops as ops_, synth as synth_
+    torch, np, Captioner, ops, synth = torch_, np_, Cap_, ops_, synth_
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_F16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense f16 / bf16 MFMA peak
@@ -50,6 +66,8 @@ def parse():
     ap.add_argument('--cpu-seconds', type=float, default=15.0)
     ap.add_argument('--h3-mode', type=int, default=1, choices=(0, 1, 2),
                     help='split-f16 GEMM path: 1 auto (default), 0 off = exact-fp32 MFMA tiles only, 2 force')
+    ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak',
+                    help='weak (default): --batch captions per GPU; strong: --batch captions over all GPUs')
     return ap.parse_args()
 
 
@@ -112,37 +130,72 @@ def cpu_baseline(weights, seconds):
                        'torch CPU fp32, %d threads, %.1f s' % (n, Bc, T, R, V, cores, el))
 
 
-def bench_xe_train(cap, dev, rank, world, iters=6, B=128):
-    """BASELINE.json configs[1]/[3]: XE forward+backward+clamp+Adam, B=128 captions per GPU (plus the
-    80-row seq2seq batch of train_xe.py:132-134), train-mode dropout, DP gradient all-reduce if N>1."""
+def dist_on():
+    return torch.distributed.is_available() and torch.distributed.is_initialized()
+
+
+def timed_region(fn, iters, dev):
+    """barrier + synchronize, `iters` calls of fn, barrier + synchronize; MAX over ranks of the elapsed seconds."""
+    def fence():
+        if dist_on():
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        fn()
+    fence()
+    el = time.perf_counter() - t0
+    if dist_on():
+        tt = torch.tensor([el], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        el = float(tt)
+    return el
+
+
+def bench_xe_train(cap, dev, rank, world, iters=6, B=128, s2s_rows=80, curve='weak'):
+    """BASELINE.json configs[1]/[3]: XE forward+backward+clamp+Adam on B captions per GPU plus `s2s_rows` rows of the
+    seq2seq batch (train_xe.py:132-134 uses 80), train-mode dropout; under a process group the step takes its
+    data-parallel form (normaliser all-reduce, 88 MB gradient-arena all-reduce before the clamp, loss all-reduce:
+    train_xe.py:189-192 with the exchange between :190 and :191).  `curve`: 'weak' = B fixed per GPU, 'strong' = the
+    caller divided a fixed global batch by the rank count."""
     from insenticap_model_amd import dp
     from insenticap_model_amd.train import xe_train_step
     cap.train()
     optim, xe_crit, da_crit = cap.get_optim_criterion(4e-4)
-    arena = dp.GradArena(cap.parameters()) if world > 1 else None
+    arena = dp.GradArena(cap.parameters()) if dist_on() else None
     d = synth.make_inputs(B, V, synth.DEFAULT_SETTINGS, regions=R, seq_len=T, seed=500 + rank)
-    s = synth.make_inputs(80, V, synth.DEFAULT_SETTINGS, regions=R, seq_len=T, seed=600 + rank)
+    s = synth.make_inputs(s2s_rows, V, synth.DEFAULT_SETTINGS, regions=R, seq_len=T, seed=600 + rank)
     tt = lambda x: torch.from_numpy(x).to(dev)
     fact = (None, tt(d['fc_feats']), tt(d['att_feats']), (tt(d['captions']), d['lengths']), tt(d['cpt_words']))
     labels = tt(d['senti_labels'])
     scs = ((tt(s['captions']), s['lengths']), tt(s['cpt_words']), tt(s['senti_words']), tt(s['senti_labels']))
+    step = lambda: xe_train_step(cap, optim, xe_crit, da_crit, fact, labels, scs, 0.0, 0.1, arena=arena)
     with no_gc():
+        c0 = dp.COLLECTIVES
         for _ in range(2):
-            xe_train_step(cap, optim, xe_crit, da_crit, fact, labels, scs, 0.0, 0.1, arena=arena)
-        if world > 1:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(iters):
-            xe_train_step(cap, optim, xe_crit, da_crit, fact, labels, scs, 0.0, 0.1, arena=arena)
-        if world > 1:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
-        el = time.perf_counter() - t0
+            step()
+        per_iter = (dp.COLLECTIVES - c0) // 2
+        el = timed_region(step, iters, dev)
     cap.eval()
-    return dict(iters=iters, batch_per_gpu=B, seq2seq_rows=80, ms_per_iter=round(el / iters * 1e3, 2),
-                captions_per_s=round(world * B * iters / el, 1),
-                grad_allreduce_mb=round(arena.nbytes / 1e6, 2) if arena else 0.0)
+    for q in cap.parameters():          # the arena's views must not outlive this measurement
+        q.grad = None
+    return dict(curve=curve, iters=iters, batch_per_gpu=B, global_batch=world * B, seq2seq_rows_per_gpu=s2s_rows,
+                ms_per_iter=round(el / iters * 1e3, 2), captions_per_s=round(world * B * iters / el, 1),
+                grad_allreduce_mb=round(arena.nbytes / 1e6, 2) if arena else 0.0, all_reduces_per_iter=per_iter)
+
+
+def bench_grad_allreduce(cap, dev, world, reps=10):
+    """The gradient exchange alone: one sum-all-reduce of the flat 22 063 379-float arena (RCCL over xGMI), nothing
+    to overlap it with (no gradient is final before BPTT ends) - this is the exposed time inside every DP iteration."""
+    n = sum(q.numel() for q in cap.parameters())
+    flat = torch.zeros(n, dtype=torch.float32, device=dev)
+    for _ in range(3):
+        torch.distributed.all_reduce(flat)
+    el = timed_region(lambda: torch.distributed.all_reduce(flat), reps, dev)
+    ms = el / reps * 1e3
+    return dict(mb=round(n * 4 / 1e6, 2), ranks=world, ms=round(ms, 3), backend=torch.distributed.get_backend(),
+                bus_gb_per_s=round(2.0 * (world - 1) / max(world, 1) * n * 4 / (ms * 1e-3) / 1e9, 1))
 
 
 def bench_small_batches(cap, dev, batches=(4, 128, 512)):
@@ -256,25 +309,33 @@ def bench_scan_sweep(dev, batches=(128, 512, 1024, 2048, 4096)):
     return out
 
 
-def bench_rl(dev, iters=3, B=512, cache_image_sentiments=True):
+def bench_rl(dev, iters=3, B=512, cache_image_sentiments=True, rank=0, world=1):
     """BASELINE.json configs[4]: self-critical RL iteration (Detector.forward, training=True): sampled +
     greedy roll-out per image, CIDEr-D + classifier rewards, XE (ss 0.5) + seq2seq (ss 0.25) passes,
-    backward, clamp, Adam; B=512, T=20, 6x6x2048 grid for the sentiment detector, 5 GT captions/image."""
-    from insenticap_model_amd import Detector, rewards
+    backward, clamp, Adam; GLOBAL B=512, T=20, 6x6x2048 grid for the sentiment detector, 5 GT captions/image.
+    Under a process group: Detector.enable_data_parallel, rank r takes rows [r*B/N, (r+1)*B/N) of the fact batch and
+    of the 80-row seq2seq batch; document frequencies are built from ALL images on every rank (models/decoder.py:
+    163-167 with the gradient all-reduce between :165 and :166)."""
+    from insenticap_model_amd import Detector, dp, rewards
     st = dict(synth.DEFAULT_SETTINGS, **synth.HELPER_SETTINGS)
     det = Detector(synth.make_idx2word(V), T, synth.SENTIMENT_CATEGORIES, {'cap_lr': 4e-5}, st)
     det.captioner.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_weights(V, st, seed=0).items()})
     det.to(dev)
+    if dist_on():
+        det.enable_data_parallel()
     det.cache_image_sentiments = cache_image_sentiments      # False: the frozen conv net runs on every image, every iteration
     batches, split = synth.make_rl_batches(1, B, V, st, grid=(6, 6), seq_len=T, seed=90)
     det.set_ciderd_scorer(split)
     tt = torch.from_numpy
     b = batches[0]
-    fact = [(b[0], tt(b[1]).to(dev), tt(b[2]).to(dev), (tt(b[3][0]).to(dev), b[3][1]), tt(b[4]).to(dev),
-             tt(b[5]).to(dev), b[6])]
+    lo, hi = dp.shard(B, rank, world, drop_last=True)
+    fns = b[0][lo:hi]
+    fact = [(fns, tt(b[1][lo:hi]).to(dev), tt(b[2][lo:hi]).to(dev), (tt(b[3][0][lo:hi]).to(dev), b[3][1][lo:hi]),
+             tt(b[4][lo:hi]).to(dev), tt(b[5][lo:hi]).to(dev), {fn: b[6][fn] for fn in fns})]
     s = synth.make_inputs(80, V, st, regions=R, seq_len=T, seed=91)
-    scs = [((tt(s['captions']).to(dev), s['lengths']), tt(s['cpt_words']).to(dev), tt(s['senti_words']).to(dev),
-            tt(s['senti_labels']).to(dev))]
+    s_lo, s_hi = dp.shard(80, rank, world, drop_last=True)
+    scs = [((tt(s['captions'][s_lo:s_hi]).to(dev), s['lengths'][s_lo:s_hi]), tt(s['cpt_words'][s_lo:s_hi]).to(dev),
+            tt(s['senti_words'][s_lo:s_hi]).to(dev), tt(s['senti_labels'][s_lo:s_hi]).to(dev))]
     cider_t = [0.0]
     orig = rewards.get_self_critical_reward
 
@@ -285,21 +346,23 @@ def bench_rl(dev, iters=3, B=512, cache_image_sentiments=True):
         return r
     import insenticap_model_amd.detector as dmod
     dmod.get_self_critical_reward = timed
+    losses = {}
+
+    def one():
+        losses.update(det((fact, scs), 'fact', True))
     try:
-        det((fact, scs), 'fact', True)            # warm-up
+        one()                                     # warm-up
         torch.cuda.synchronize()
         cider_t[0] = 0.0
         with no_gc():
-            t0 = time.perf_counter()
-            for _ in range(iters):
-                losses = det((fact, scs), 'fact', True)
-            torch.cuda.synchronize()
-            el = time.perf_counter() - t0
+            el = timed_region(one, iters, dev)
     finally:
         dmod.get_self_critical_reward = orig
-    return dict(iters=iters, batch=B, ms_per_iter=round(el / iters * 1e3, 1),
-                images_per_s=round(B * iters / el, 1), image_sentiment_cache=bool(cache_image_sentiments),
+    return dict(iters=iters, global_batch=(hi - lo) * world, batch_per_gpu=hi - lo, seq2seq_rows_per_gpu=s_hi - s_lo,
+                ms_per_iter=round(el / iters * 1e3, 1), images_per_s=round((hi - lo) * world * iters / el, 1),
+                image_sentiment_cache=bool(cache_image_sentiments),
                 cider_ms_per_iter=round(cider_t[0] / iters * 1e3, 1), cider_threads=det.ciderd_scorer.n_threads,
+                grad_arena_all_reduces=det.dp_arena.collectives if det.dp_arena is not None else 0,
                 losses={k: round(float(v), 4) for k, v in losses.items()})
 
 
@@ -436,8 +499,49 @@ def roofline_entry(name, rec):
                 launches_timed=rec['n'])
 
 
+def free_port():
+    sk = socket.socket()
+    sk.bind(('127.0.0.1', 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    return port
+
+
+def launch_ranks(args):
+    """`bench.py --gpus N` (N > 1) outside a launcher: start N rank processes.  This parent NEVER initialises HIP
+    (torch.cuda.device_count() reads the device list without creating a context on this image; nothing else here
+    touches the GPU, the product is not even imported), so there is no exec / fork of a GPU-initialised process: the
+    ranks are fresh children of torch.distributed.run."""
+    import torch as torch_
+    have = torch_.cuda.device_count()
+    if have < args.gpus:
+        sys.stderr.write('bench.py: --gpus %d requested but this box exposes %d GPU(s); refusing to report a '
+                         '%d-GPU line from fewer ranks\n' % (args.gpus, have, args.gpus))
+        return 2
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [x for x in r.stdout.splitlines() if x.startswith('{') and '"metric"' in x]
+    if r.returncode != 0 or not lines:
+        sys.stderr.write('bench.py: the %d-rank run failed (launcher exit code %d, %d result line(s))\n'
+                         % (args.gpus, r.returncode, len(lines)))
+        sys.stderr.write(r.stdout[-2000:])
+        return r.returncode or 1
+    print(lines[-1], flush=True)
+    return 0
+
+
 def main():
     args = parse()
+    under_launcher = 'RANK' in os.environ and 'WORLD_SIZE' in os.environ
+    if under_launcher and int(os.environ['WORLD_SIZE']) != args.gpus:
+        sys.stderr.write('bench.py: --gpus %d but the launcher started WORLD_SIZE=%s ranks\n'
+                         % (args.gpus, os.environ['WORLD_SIZE']))
+        sys.exit(2)
+    if args.gpus > 1 and not under_launcher:
+        sys.exit(launch_ranks(args))
+    load_product()
     # stdout must carry exactly ONE JSON line: send everything libraries print (RCCL's version banner,
     # MIOpen notices ...) to stderr until the result is ready
     sys.stdout.flush()
@@ -462,8 +566,13 @@ def run(args):
         import torch.distributed as dist
         torch.cuda.set_device(local)
         dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
     dev = torch.device('cuda', local if (world > 1 or under_launcher) else 0)
     torch.cuda.set_device(dev)
+    if args.scaling == 'strong':
+        if args.batch % world:
+            raise SystemExit('--scaling strong: --batch %d is not a multiple of %d ranks' % (args.batch, world))
+        args.batch //= world
     B = args.batch
     ops.set_h3_mode(args.h3_mode)
 
@@ -518,13 +627,24 @@ def run(args):
                     extra[key] = fn()
                 except Exception as e:  # noqa: BLE001 - side measurements are reported, never fatal
                     extra[key] = {'error': repr(e)[:300]}
-        try:
-            extra['xe_train'] = bench_xe_train(cap, dev, rank, world)
-            if world == 1:
-                extra['xe_train_by_batch'] = {str(b): bench_xe_train(cap, dev, rank, world, iters=3, B=b)['ms_per_iter']
-                                              for b in (512, 1024)}
-        except Exception as e:  # noqa: BLE001
-            extra['xe_train'] = {'error': repr(e)[:200]}
+        # training curves of BASELINE configs[3] (XE) and [4] (RL); every rank runs them (they hold collectives).
+        # weak: 128 captions + 80 seq2seq rows per GPU; strong: GLOBAL 1024 captions + 80 seq2seq rows over the ranks
+        jobs = [('xe_train', lambda: bench_xe_train(cap, dev, rank, world))]
+        if 1024 % world == 0 and 80 % world == 0:
+            jobs.append(('xe_train_strong', lambda: bench_xe_train(cap, dev, rank, world, iters=4, B=1024 // world,
+                                                                   s2s_rows=80 // world, curve='strong')))
+        if world == 1:
+            jobs.append(('xe_train_by_batch', lambda: {str(b): bench_xe_train(cap, dev, rank, world, iters=3, B=b)[
+                'ms_per_iter'] for b in (512,)}))
+        if dist_on():
+            jobs.append(('grad_allreduce', lambda: bench_grad_allreduce(cap, dev, world)))
+            if 512 % world == 0 and 80 % world == 0:
+                jobs.append(('rl_iteration', lambda: bench_rl(dev, rank=rank, world=world)))
+        for key, fn in jobs:
+            try:
+                extra[key] = fn()
+            except Exception as e:  # noqa: BLE001
+                extra[key] = {'error': repr(e)[:300]}
     if rank != 0:
         torch.distributed.destroy_process_group()
         return None
@@ -549,7 +669,7 @@ def run(args):
         'value': round(total / el, 1), 'unit': 'captions/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(el / args.steps * 1e3, 3),
-        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None,
         'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': 'greedy decode forward_rl(sample_max=1): B=%d captions/GPU/step, R=%d '
                                'regions x 2048, V=%d, T=%d, sentiment-word attention + gate on, '
@@ -557,7 +677,10 @@ def run(args):
                                'tables (relu(Emb) W_x^T [V,4H], sentiment-word tables 2 x [V,512]; 26 GFLOP) and '
                                'the f16 weight planes are built by the first roll-out after a weight change, i.e. '
                                'in warm-up, and reused by the timed ones (extra.table_build)' % (B, R, V, T),
-                   'batch_per_gpu': B, 'parallelism': 'dp%d (batch shard, no collective)' % world,
+                   'batch_per_gpu': B, 'global_batch': B * world,
+                   'parallelism': 'dp%d (batch shard, no collective)' % world,
+                   'ranks': torch.distributed.get_world_size() if dist_on() else 1,
+                   'collective_backend': torch.distributed.get_backend() if dist_on() else None,
                    'gemm_engine': {1: 'split-f16 x3 MFMA for large forward GEMMs (fp32 in/out/accumulate), fp32 MFMA elsewhere',
                                    0: 'fp32 MFMA only (--h3-mode 0)', 2: 'split-f16 forced'}[args.h3_mode]},
         'roofline': entries[0] if entries else None,

@@ -441,7 +441,8 @@ int isc_attn_dv_from_alpha(const float *alpha, int64_t alpha_ld_b, int64_t alpha
                            int B, int T, int R, int D, float *dV, void *stream);
 /* dP may be NULL as well (with de_out given): dP[b,r,a] = sum_{t = T-1 .. 0} de[(t*B + b)*R + r] * w[a] *
  * (1 - tanh^2(P[b,r,a] + q[(t*B + b)*A + a] (+ q2[b*A + a]))) is then formed once after the sweep - P read once, the
- * tanh terms recomputed; same expression and order of additions as the per-step accumulation.  R <= 18 * 1024 / A. */
+ * tanh terms recomputed; same expression and order of additions as the per-step accumulation.  Any R (the grid walks
+ * region chunks: the reference encoder's 14 x 14 = 196 regions are six chunks at A = 512), any A, D with A % 4 == D % 4 == 0. */
 int isc_attn_dp_from_de(const float *P, const float *q, const float *q2, const float *w, const float *de,
                         int B, int T, int R, int A, float *dP, void *stream);
 

@@ -30,10 +30,16 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+LAST_BUILD = {'compiled': [], 'reused': [], 'linked': False}      # what the last build() call actually did
+
+
 def build(force=False, verbose=False):
+    """mtime-driven: an object is recompiled when its source or a header is newer (or `force`); LAST_BUILD records which
+    translation units were compiled and which in-tree objects were reused, so a caller can say which it was."""
     os.makedirs(LIB_DIR, exist_ok=True)
     hipcc = _hipcc()
     objs = []
+    LAST_BUILD.update(compiled=[], reused=[], linked=False)
     for s in SOURCES:
         src = os.path.join(CSRC, s)
         obj = os.path.join(LIB_DIR, s.replace('.hip', '.o'))
@@ -42,30 +48,39 @@ def build(force=False, verbose=False):
             if verbose:
                 print(' '.join(cmd))
             subprocess.check_call(cmd)
+            LAST_BUILD['compiled'].append(s)
+        else:
+            LAST_BUILD['reused'].append(s)
         objs.append(obj)
     if force or _stale(LIB_PATH, objs):
         cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB_PATH] + objs
         if verbose:
             print(' '.join(cmd))
         subprocess.check_call(cmd)
-    build_cider(force, verbose)
+        LAST_BUILD['linked'] = True
+    if build_cider(force, verbose, _report=True):
+        LAST_BUILD['compiled'].append('cider.cpp')
+    else:
+        LAST_BUILD['reused'].append('cider.cpp')
     return LIB_PATH
 
 
 CIDER_LIB_PATH = os.path.join(LIB_DIR, 'libinsenticap_cider.so')
 
 
-def build_cider(force=False, verbose=False):
+def build_cider(force=False, verbose=False, _report=False):
     """Host-side CIDEr-D reward library (plain C++, g++)."""
     os.makedirs(LIB_DIR, exist_ok=True)
     src = os.path.join(CSRC, 'cider.cpp')
     hdr = os.path.join(os.path.dirname(HERE), 'include', 'insenticap_cider.h')
+    did = False
     if force or _stale(CIDER_LIB_PATH, [src, hdr]):
         cmd = ['g++', '-O2', '-std=c++17', '-fPIC', '-shared', '-pthread', '-Wall', src, '-o', CIDER_LIB_PATH]
         if verbose:
             print(' '.join(cmd))
         subprocess.check_call(cmd)
-    return CIDER_LIB_PATH
+        did = True
+    return did if _report else CIDER_LIB_PATH
 
 
 def resource_report():

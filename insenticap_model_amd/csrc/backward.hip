@@ -242,16 +242,23 @@ extern "C" int isc_attn_scan_bwd(const isc_scan_bwd_problem *pr, int n_prob, int
 // dV[b,r,:] = sum over the steps, in the order of the backward sweep (t = T-1 ... 0), of alpha[b,t,r] * dout[t,b,:]:
 // the accumulation that attn_scan_bwd_kernel otherwise does as a read-modify-write of the whole [B,R,D] tensor at every
 // step (a third of its traffic), done once from the T small per-step gradients.  Same products, same order of additions.
+// Any R, any D % 4 == 0: the grid is (B, region chunks, column blocks of 256 float4); a chunk holds as many regions as
+// fit the [T][Rc] LDS image (the 14x14 = 196-region grid of the reference's encoder at T = 20: 4 chunks).  An output
+// element's additions do not depend on the chunking.
 #define ISC_DV_TMAX 24
+#define ISC_POST_LDS_BYTES 60000
 __global__ __launch_bounds__(256) void attn_dv_from_alpha_kernel(const float *alpha, long long ld_b, long long ld_t,
-                                                                 const float *dout, int B, int T, int R, int D,
+                                                                 const float *dout, int B, int T, int R, int D, int Rc,
                                                                  float *dV) {
 #pragma clang fp contract(off)
-    extern __shared__ float sa[];                  // [T][R]
+    extern __shared__ float sa[];                  // [T][Rc]
     const int b = blockIdx.x, tid = threadIdx.x;
-    for (int i = tid; i < T * R; i += 256) sa[i] = alpha[(long long)b * ld_b + (long long)(i / R) * ld_t + (i % R)];
+    const int r_lo = blockIdx.y * Rc, nr = min(Rc, R - r_lo);
+    for (int i = tid; i < T * nr; i += 256)
+        sa[(i / nr) * Rc + (i % nr)] = alpha[(long long)b * ld_b + (long long)(i / nr) * ld_t + r_lo + (i % nr)];
     __syncthreads();
-    const int D4 = D >> 2, ngrp = 256 / D4, d4 = tid % D4, grp = tid / D4;
+    const int D4 = D >> 2, c_lo = blockIdx.z * 256, cols = min(256, D4 - c_lo);
+    const int ngrp = 256 / cols, d4 = c_lo + tid % cols, grp = tid / cols;
     if (grp >= ngrp) return;
     const float4 *g4 = reinterpret_cast<const float4 *>(dout);
     float4 *o4 = reinterpret_cast<float4 *>(dV + (long long)b * R * D);
@@ -260,29 +267,29 @@ __global__ __launch_bounds__(256) void attn_dv_from_alpha_kernel(const float *al
 #pragma unroll
         for (int t = 0; t < ISC_DV_TMAX; ++t)
             g[t] = t < T ? g4[((long long)t * B + b) * D4 + d4] : make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int r = grp; r < R; r += ngrp) {
+        for (int r = grp; r < nr; r += ngrp) {
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
             for (int t = ISC_DV_TMAX - 1; t >= 0; --t) {
                 if (t < T) {
-                    const float al = sa[t * R + r];
+                    const float al = sa[t * Rc + r];
                     // product rounded, then added (contraction is off in this kernel): what the per-step kernel's
                     // `v = alpha * g; v += previous` compiles to - checked bit for bit by tests/test_gpu_backward.py
                     acc.x = al * g[t].x + acc.x; acc.y = al * g[t].y + acc.y;
                     acc.z = al * g[t].z + acc.z; acc.w = al * g[t].w + acc.w;
                 }
             }
-            o4[(long long)r * D4 + d4] = acc;
+            o4[(long long)(r_lo + r) * D4 + d4] = acc;
         }
     } else {
-        for (int r = grp; r < R; r += ngrp) {
+        for (int r = grp; r < nr; r += ngrp) {
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
             for (int t = T - 1; t >= 0; --t) {
-                const float al = sa[t * R + r];
+                const float al = sa[t * Rc + r];
                 const float4 g = g4[((long long)t * B + b) * D4 + d4];
                 acc.x = al * g.x + acc.x; acc.y = al * g.y + acc.y; acc.z = al * g.z + acc.z; acc.w = al * g.w + acc.w;
             }
-            o4[(long long)r * D4 + d4] = acc;
+            o4[(long long)(r_lo + r) * D4 + d4] = acc;
         }
     }
 }
@@ -290,12 +297,16 @@ __global__ __launch_bounds__(256) void attn_dv_from_alpha_kernel(const float *al
 extern "C" int isc_attn_dv_from_alpha(const float *alpha, int64_t alpha_ld_b, int64_t alpha_ld_t, const float *dout,
                                       int B, int T, int R, int D, float *dV, void *stream) {
     if (!alpha || !dout || !dV) return ISC_E_NULL;
-    if (B <= 0 || T <= 0 || R <= 0 || D <= 0 || (D & 3) || (256 % (D / 4)) != 0 || D > 1024) return ISC_E_SHAPE;
+    if (B <= 0 || T <= 0 || R <= 0 || D <= 0 || (D & 3)) return ISC_E_SHAPE;
     if (!isc_aligned16(dout) || !isc_aligned16(dV)) return ISC_E_ALIGN;
-    const size_t lds = (size_t)T * R * sizeof(float);
-    if (lds > 60000) return ISC_E_SHAPE;
-    hipLaunchKernelGGL(attn_dv_from_alpha_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, alpha,
-                       (long long)alpha_ld_b, (long long)alpha_ld_t, dout, B, T, R, D, dV);
+    int Rc = ISC_POST_LDS_BYTES / (int)sizeof(float) / T;      // regions per chunk: [T][Rc] floats of LDS
+    if (Rc < 1) return ISC_E_SHAPE;                             // T > 15000 steps
+    if (Rc > R) Rc = R;
+    const int nchunk = (R + Rc - 1) / Rc, ncol = (D / 4 + 255) / 256;
+    if (nchunk > 65535 || ncol > 65535) return ISC_E_SHAPE;
+    const size_t lds = (size_t)T * Rc * sizeof(float);
+    hipLaunchKernelGGL(attn_dv_from_alpha_kernel, dim3(B, nchunk, ncol), dim3(256), lds, (hipStream_t)stream, alpha,
+                       (long long)alpha_ld_b, (long long)alpha_ld_t, dout, B, T, R, D, Rc, dV);
     ISC_LAUNCH_CHECK();
     return ISC_OK;
 }
@@ -304,18 +315,23 @@ extern "C" int isc_attn_dv_from_alpha(const float *alpha, int64_t alpha_ld_b, in
 // the other per-step read-modify-write of attn_scan_bwd_kernel, done once from the T small per-step vectors d e_t and
 // q_t.  P is read once and kept in registers over the steps; the tanh terms are recomputed (the per-step kernel needs
 // them anyway for d q).  Same expression, same order of additions as the per-step accumulation.
-#define ISC_DP_RMAX 18          // regions per thread: R <= 2 * ISC_DP_RMAX with A = 512 (two region groups)
+// Grid (B, region chunks, column blocks): a thread keeps ISC_DP_RMAX regions in registers, so a chunk is
+// ISC_DP_RMAX x (region groups of the workgroup) regions (A = 512: 36 - the 36-region features in one chunk, 196 in six).
+#define ISC_DP_RMAX 18
 __global__ __launch_bounds__(256) void attn_dp_from_de_kernel(const float *P, const float *q, const float *q2,
                                                               const float *w, const float *de, int B, int T, int R,
-                                                              int A, float *dP) {
-    extern __shared__ float sde[];                 // [T][R]
+                                                              int A, int Rc, float *dP) {
+    extern __shared__ float sde[];                 // [T][Rc]
     const int b = blockIdx.x, tid = threadIdx.x;
-    for (int i = tid; i < T * R; i += 256) sde[i] = de[((long long)(i / R) * B + b) * R + (i % R)];
+    const int r_lo = blockIdx.y * Rc, nr = min(Rc, R - r_lo);
+    for (int i = tid; i < T * nr; i += 256)
+        sde[(i / nr) * Rc + (i % nr)] = de[((long long)(i / nr) * B + b) * R + r_lo + (i % nr)];
     __syncthreads();
-    const int A4 = A >> 2, ngrp = 256 / A4, a4 = tid % A4, grp = tid / A4;
+    const int A4 = A >> 2, c_lo = blockIdx.z * 256, cols = min(256, A4 - c_lo);
+    const int ngrp = 256 / cols, a4 = c_lo + tid % cols, grp = tid / cols;
     if (grp >= ngrp) return;
-    const float4 *Pb = reinterpret_cast<const float4 *>(P + (long long)b * R * A);
-    float4 *dPb = reinterpret_cast<float4 *>(dP + (long long)b * R * A);
+    const float4 *Pb = reinterpret_cast<const float4 *>(P + ((long long)b * R + r_lo) * A);
+    float4 *dPb = reinterpret_cast<float4 *>(dP + ((long long)b * R + r_lo) * A);
     const float4 wa = reinterpret_cast<const float4 *>(w)[a4];
     float4 q2v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (q2) q2v = reinterpret_cast<const float4 *>(q2 + (long long)b * A)[a4];
@@ -323,7 +339,7 @@ __global__ __launch_bounds__(256) void attn_dp_from_de_kernel(const float *P, co
 #pragma unroll
     for (int i = 0; i < ISC_DP_RMAX; ++i) {
         const int r = grp + i * ngrp;
-        pv[i] = r < R ? Pb[(long long)r * A4 + a4] : make_float4(0.f, 0.f, 0.f, 0.f);
+        pv[i] = r < nr ? Pb[(long long)r * A4 + a4] : make_float4(0.f, 0.f, 0.f, 0.f);
         acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     for (int t = T - 1; t >= 0; --t) {
@@ -332,8 +348,8 @@ __global__ __launch_bounds__(256) void attn_dp_from_de_kernel(const float *P, co
 #pragma unroll
         for (int i = 0; i < ISC_DP_RMAX; ++i) {
             const int r = grp + i * ngrp;
-            if (r < R) {
-                const float der = sde[t * R + r];
+            if (r < nr) {
+                const float der = sde[t * Rc + r];
                 const float tx = isc_tanh(pv[i].x + qa.x), ty = isc_tanh(pv[i].y + qa.y);
                 const float tz = isc_tanh(pv[i].z + qa.z), tw = isc_tanh(pv[i].w + qa.w);
                 const float4 gr = make_float4(isc_dtanh_term(der, wa.x, tx), isc_dtanh_term(der, wa.y, ty),
@@ -347,21 +363,27 @@ __global__ __launch_bounds__(256) void attn_dp_from_de_kernel(const float *P, co
 #pragma unroll
     for (int i = 0; i < ISC_DP_RMAX; ++i) {
         const int r = grp + i * ngrp;
-        if (r < R) dPb[(long long)r * A4 + a4] = acc[i];
+        if (r < nr) dPb[(long long)r * A4 + a4] = acc[i];
     }
 }
 
 extern "C" int isc_attn_dp_from_de(const float *P, const float *q, const float *q2, const float *w, const float *de,
                                    int B, int T, int R, int A, float *dP, void *stream) {
     if (!P || !q || !w || !de || !dP) return ISC_E_NULL;
-    if (B <= 0 || T <= 0 || R <= 0 || A <= 0 || (A & 3) || (256 % (A / 4)) != 0 || A > 1024) return ISC_E_SHAPE;
-    if (R > ISC_DP_RMAX * (256 / (A / 4))) return ISC_E_SHAPE;
+    if (B <= 0 || T <= 0 || R <= 0 || A <= 0 || (A & 3)) return ISC_E_SHAPE;
     if (!isc_aligned16(P) || !isc_aligned16(q) || !isc_aligned16(w) || !isc_aligned16(dP) || (q2 && !isc_aligned16(q2)))
         return ISC_E_ALIGN;
-    const size_t lds = (size_t)T * R * sizeof(float);
-    if (lds > 60000) return ISC_E_SHAPE;
-    hipLaunchKernelGGL(attn_dp_from_de_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, P, q, q2, w, de, B, T, R, A,
-                       dP);
+    const int A4 = A / 4, cols = A4 < 256 ? A4 : 256;          // (a ragged last column block only has MORE groups)
+    int Rc = ISC_DP_RMAX * (256 / cols);                        // what a workgroup's threads hold in registers
+    const int lds_cap = ISC_POST_LDS_BYTES / (int)sizeof(float) / T;
+    if (lds_cap < 1) return ISC_E_SHAPE;
+    if (Rc > lds_cap) Rc = lds_cap;
+    if (Rc > R) Rc = R;
+    const int nchunk = (R + Rc - 1) / Rc, ncol = (A4 + 255) / 256;
+    if (nchunk > 65535 || ncol > 65535) return ISC_E_SHAPE;
+    const size_t lds = (size_t)T * Rc * sizeof(float);
+    hipLaunchKernelGGL(attn_dp_from_de_kernel, dim3(B, nchunk, ncol), dim3(256), lds, (hipStream_t)stream, P, q, q2, w,
+                       de, B, T, R, A, Rc, dP);
     ISC_LAUNCH_CHECK();
     return ISC_OK;
 }

@@ -89,10 +89,18 @@ class Detector(nn.Module):
             sums[key] = sums[key] + (value.detach() if torch.is_tensor(value) else value)
 
         device = next(self.parameters()).device
-        world = dp.world_size(self.dp_group) if self.dp_arena is not None else 1
+        # data-parallel branches: taken whenever DP is enabled and a process group exists - also a one-rank group
+        # (shares are then exactly 1.0), so a one-GPU RCCL run crosses the code an 8-rank run does
+        dist_on = self.dp_arena is not None and dp.distributed(self.dp_group)
         seq2seq_iter = iter(data[1]) if training else None
         caption_iter = iter(data[0])
-        for _ in range(min(self.MAX_BATCHES_PER_CALL, len(data[0]))):
+        n_iter = min(self.MAX_BATCHES_PER_CALL, len(data[0]))
+        if dist_on:
+            # every iteration issues collectives: ranks whose loaders differ in length (or in data_type) would hang
+            # inside RCCL - check once per call instead (shard with dp.shard(..., drop_last=True))
+            dp.assert_same_across_ranks(n_iter * 4 + (2 if training else 0) + (data_type == 'fact'), device,
+                                        self.dp_group, 'Detector.forward: iterations / data_type / training')
+        for _ in range(n_iter):
             item = next(caption_iter)
             s2s_batch = None
             if training:                                  # fetched here (same loader order) so that its token
@@ -121,14 +129,12 @@ class Detector(nn.Module):
             da_loss = self.cap_da_crit(cap.cpt_feats, cap.fc_feats.detach())
             # DP: each term's share of the global normaliser (mask sum, XE tokens, seq2seq tokens, rows)
             w_rl = w_xe = w_s2s = w_rows = None
-            share = (lambda x, w: x * w) if world > 1 else (lambda x, w: x)    # single process: graph untouched
-            if world > 1:
-                n_local = torch.cat([seq_masks.sum().reshape(1), ops.upload(
-                    [float(sum(lengths)) if data_type == 'fact' else 0.0,
+            share = (lambda x, w: x * w) if dist_on else (lambda x, w: x)      # single process: graph untouched
+            if dist_on:
+                n_local, n_global = dp.global_counts(
+                    [seq_masks.sum(), float(sum(lengths)) if data_type == 'fact' else 0.0,
                      float(sum(s2s_batch[0][1])) if s2s_batch is not None else 0.0,
-                     float(fc_feats.shape[0])], torch.float32, device)])
-                n_global = n_local.clone()
-                torch.distributed.all_reduce(n_global, group=self.dp_group)
+                     float(fc_feats.shape[0])], device, self.dp_group)
                 w_rl, w_xe, w_s2s, w_rows = (n_local / n_global.clamp_min(1.0)).unbind(0)
             da_loss = share(da_loss, w_rows)
             add('da_loss', da_loss)
@@ -207,11 +213,13 @@ class Detector(nn.Module):
                 clip_gradient(self.cap_optim)            # 0.1, fused into the Adam launch
                 self.cap_optim.step()
 
-        if world > 1 and sums:                           # global statistics: one small all-reduce per call
-            keys = sorted(sums)
+        if dist_on and sums:                             # global statistics: one small all-reduce per call
+            keys = sorted(sums)                          # (same keys on every rank: data_type / training were checked)
             vec = torch.stack([torch.as_tensor(sums[k], dtype=torch.float32, device=device).reshape(()) for k in keys])
-            torch.distributed.all_reduce(vec, group=self.dp_group)
+            dp.all_reduce_(vec, self.dp_group)
             sums = dict(zip(keys, vec.tolist()))
+        # len(data) is the length of the (loader, loader) TUPLE, as in the reference (decoder.py:178-179) - the same
+        # on every rank, so globally summed statistics divide by the same number everywhere
         return {k: float(v) / len(data) for k, v in sums.items()}
 
     def _image_sentiments(self, fns, att_feats):

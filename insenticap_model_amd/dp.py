@@ -37,8 +37,32 @@ def init_from_env(backend=None):
     return rank, world, local
 
 
+COLLECTIVES = 0          # all-reduces issued by this process through all_reduce_ (tests assert on it)
+
+
 def world_size(group=None):
     return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+
+
+def distributed(group=None):
+    """True when a process group exists - ALSO a one-rank group.  The training steps take their data-parallel branches
+    (count all-reduce, loss shares, arena all-reduce, statistics all-reduce) whenever this holds, so a one-rank RCCL
+    group on a one-GPU box drives exactly the code an 8-rank run does (shares are then 1.0: same numbers)."""
+    return dist.is_available() and dist.is_initialized()
+
+
+def all_reduce_(t, group=None, op=None):
+    """The ONE place a collective of this package is issued.  RCCL ("nccl") only moves device tensors: a CPU tensor
+    handed to it raises here with the caller's name on the stack instead of "No backend type associated with device
+    type cpu" from deep inside c10d (round 2: `global_count` built its count on the host; gloo hid it in every test)."""
+    if not distributed(group):
+        return t
+    if dist.get_backend(group) == 'nccl' and t.device.type != 'cuda':
+        raise TypeError('collective on a %s tensor with backend nccl (RCCL): build it on the rank\'s GPU' % t.device.type)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM if op is None else op, group=group)
+    global COLLECTIVES
+    COLLECTIVES += 1
+    return t
 
 
 class GradArena:
@@ -67,8 +91,8 @@ class GradArena:
         """Sum the gradients of all ranks: one collective over the whole arena.  Issued whenever a process group
         exists - also a one-rank group, where it is a no-op arithmetically but still goes through the backend
         (tests/test_gpu_dp.py drives RCCL that way on a one-GPU box)."""
-        if dist.is_available() and dist.is_initialized():
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+        if distributed(group):
+            all_reduce_(self.flat, group)
             self.collectives += 1
         return self.flat
 
@@ -77,25 +101,50 @@ class GradArena:
         return self.flat.numel() * self.flat.element_size()
 
 
-def global_count(local_count, group=None):
-    """All-reduce a token count (python number or 0-dim tensor) -> tensor on the same device."""
-    t = local_count.detach().clone().float() if torch.is_tensor(local_count) else torch.tensor(float(local_count))
-    if world_size(group) > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-    return t
+def global_counts(local_counts, device, group=None):
+    """Sum over ranks of a short list of per-rank normalisers (token counts, mask sums, row counts): ONE small
+    all-reduce.  `local_counts`: python numbers and / or 0-dim tensors; the vector is built on `device` - the rank's
+    GPU under RCCL.  Returns (local [n], global [n]) float32 tensors on `device`."""
+    device = torch.device(device)
+    parts = [c.detach().to(device=device, dtype=torch.float32).reshape(1) if torch.is_tensor(c)
+             else torch.tensor([float(c)], dtype=torch.float32, device=device) for c in local_counts]
+    local = torch.cat(parts)
+    return local, all_reduce_(local.clone(), group)
+
+
+def global_count(local_count, group=None, device=None):
+    """All-reduce ONE count (python number or 0-dim tensor).  A python number needs `device` (the rank's GPU under
+    RCCL; defaults to the CPU, which only gloo accepts - `all_reduce_` says so loudly)."""
+    if device is None:
+        device = local_count.device if torch.is_tensor(local_count) else 'cpu'
+    return global_counts([local_count], device, group)[1][0]
 
 
 def dp_token_mean(local_mean_loss, local_tokens, group=None):
     """Rescales a per-rank token-mean loss so that SUM-reduced gradients equal those of the global
-    token mean: loss_r * n_r / sum_r n_r.  Returns (scaled loss for backward, global token count)."""
-    n = global_count(local_tokens, group)
-    lt = local_tokens if torch.is_tensor(local_tokens) else float(local_tokens)
-    return local_mean_loss * (lt / n.to(local_mean_loss.device)), n
+    token mean: loss_r * n_r / sum_r n_r.  Returns (scaled loss for backward, global token count).  The count lives
+    on the loss's device."""
+    n = global_count(local_tokens, group, device=local_mean_loss.device)
+    lt = local_tokens.to(local_mean_loss.device) if torch.is_tensor(local_tokens) else float(local_tokens)
+    return local_mean_loss * (lt / n), n
 
 
 def dp_batch_mean(local_mean_loss, group=None):
     """Same for a plain batch mean with equal per-rank batch sizes (the domain-align MSE)."""
     return local_mean_loss / world_size(group)
+
+
+def assert_same_across_ranks(value, device, group=None, what='value'):
+    """Every rank must pass the same integer (loop trip counts, key-set digests): a mismatch would otherwise show as a
+    hang inside RCCL.  One 2-int all-reduce (MIN of v and of -v)."""
+    if not distributed(group):
+        return
+    t = torch.tensor([int(value), -int(value)], dtype=torch.int64, device=device)
+    all_reduce_(t, group, op=dist.ReduceOp.MIN)
+    lo, hi = int(t[0]), -int(t[1])
+    if lo != hi:
+        raise RuntimeError('%s differs across ranks (min %d, max %d, here %d): shard the loaders to equal lengths '
+                           '(dp.shard with drop_last)' % (what, lo, hi, int(value)))
 
 
 def broadcast_parameters(module, src=0, group=None):
@@ -104,6 +153,8 @@ def broadcast_parameters(module, src=0, group=None):
         return
     ps = [p.data for p in module.parameters()]
     flat = torch.cat([p.reshape(-1) for p in ps])
+    if dist.get_backend(group) == 'nccl' and flat.device.type != 'cuda':
+        raise TypeError('broadcast of CPU parameters with backend nccl (RCCL): move the module to the GPU first')
     dist.broadcast(flat, src=src, group=group)
     off = 0
     for p in ps:
@@ -115,8 +166,12 @@ def broadcast_parameters(module, src=0, group=None):
     ops.WEIGHT_EPOCH += 1
 
 
-def shard(n_items, rank, world):
-    """Contiguous shard [lo, hi) of n_items for this rank (inference: images are independent)."""
+def shard(n_items, rank, world, drop_last=False):
+    """Contiguous shard [lo, hi) of n_items for this rank (inference: images are independent).  `drop_last`: equal
+    shards of n_items // world (training: every rank must run the same number of iterations)."""
+    if drop_last:
+        per = n_items // world
+        return rank * per, (rank + 1) * per
     per = (n_items + world - 1) // world
     lo = min(rank * per, n_items)
     return lo, min(lo + per, n_items)

@@ -50,19 +50,24 @@ def xe_train_step(captioner, optim, xe_crit, da_crit, fact_batch, xe_senti_label
     fc_feats, att_feats = fc_feats.to(device), att_feats.to(device)
     caps_tensor, cpts_tensor = caps_tensor.to(device), cpts_tensor.to(device)
     xe_senti_labels = xe_senti_labels.to(device)
-    world = dp.world_size(group)
+    # data-parallel: taken whenever a process group exists (also a one-rank one: shares are then exactly 1.0), so the
+    # single-GPU RCCL test crosses every branch an 8-rank run does
+    dist_on = dp.distributed(group)
+    share = (lambda x, w: x * w) if dist_on else (lambda x, w: x)      # single process: graph untouched
+    w_xe = w_s2s = w_rows = None
+    if dist_on:
+        # each loss term's share of ITS global normaliser (XE tokens, seq2seq tokens, rows): ONE 3-float all-reduce,
+        # built on the rank's GPU (RCCL moves device tensors only), before any compute depends on it
+        local, glob = dp.global_counts(
+            [float(sum(lengths)), float(sum(scs_batch[0][1])) if scs_batch is not None else 0.0,
+             float(fc_feats.shape[0])], device, group)
+        w_xe, w_s2s, w_rows = (local / glob.clamp_min(1.0)).unbind(0)
 
     pred = captioner(fc_feats, att_feats, cpts_tensor, caps_tensor, xe_senti_labels, ss_prob, mode='xe')
-    xe_loss = xe_crit(pred, caps_tensor[:, 1:], lengths)
-    da_loss = da_crit(captioner.cpt_feats, captioner.fc_feats.detach())
-    if world > 1:
-        xe_bwd, _ = dp.dp_token_mean(xe_loss, float(sum(lengths)), group)
-        da_bwd = dp.dp_batch_mean(da_loss, group)
-    else:
-        xe_bwd, da_bwd = xe_loss, da_loss
+    xe_bwd = share(xe_crit(pred, caps_tensor[:, 1:], lengths), w_xe)
+    da_bwd = share(da_crit(captioner.cpt_feats, captioner.fc_feats.detach()), w_rows)
     total = xe_bwd + da_bwd
     out = {'xe_loss': xe_bwd.detach(), 'da_loss': da_bwd.detach()}
-    out['cap_loss'] = out['xe_loss'] + out['da_loss']
     out['seq2seq_loss'] = torch.zeros((), device=device)
     if scs_batch is not None:
         (s_caps, s_lengths), s_cpts, s_sentis, s_labels = scs_batch
@@ -70,16 +75,13 @@ def xe_train_step(captioner, optim, xe_crit, da_crit, fact_batch, xe_senti_label
         s_sentis, s_labels = s_sentis.to(device), s_labels.to(device)
         def seq2seq_unroll():
             pred2 = captioner(s_caps, s_cpts, s_sentis, s_labels, ss_prob, mode='seq2seq')
-            return xe_crit(pred2, s_caps[:, 1:], s_lengths)
+            return share(xe_crit(pred2, s_caps[:, 1:], s_lengths), w_s2s)
         if overlap_unrolls and torch.device(device).type == 'cuda':
             s2s = run_on_side_stream(torch.device(device), seq2seq_unroll)
         else:
             s2s = seq2seq_unroll()
-        if world > 1:
-            s2s, _ = dp.dp_token_mean(s2s, float(sum(s_lengths)), group)
         total = total + s2s
         out['seq2seq_loss'] = s2s.detach()
-    out['all_loss'] = out['cap_loss'] + out['seq2seq_loss']
 
     if arena is not None:
         arena.zero_()
@@ -88,9 +90,11 @@ def xe_train_step(captioner, optim, xe_crit, da_crit, fact_batch, xe_senti_label
     total.backward()
     if arena is not None:
         arena.all_reduce(group)          # one 88 MB sum over xGMI; clamp must see reduced grads
-    if world > 1:
-        for k in out:                    # report global losses (sum of the pre-scaled locals)
-            torch.distributed.all_reduce(out[k], group=group)
+    if dist_on:                          # report global losses (sum of the pre-scaled locals): one 3-float all-reduce
+        vec = dp.all_reduce_(torch.stack([out['xe_loss'], out['da_loss'], out['seq2seq_loss']]), group)
+        out['xe_loss'], out['da_loss'], out['seq2seq_loss'] = vec.unbind(0)
+    out['cap_loss'] = out['xe_loss'] + out['da_loss']
+    out['all_loss'] = out['cap_loss'] + out['seq2seq_loss']
     clip_gradient(optim, grad_clip)      # fused into the Adam launch
     optim.step()
     return out

@@ -1,7 +1,9 @@
 """Child program of tests/test_gpu_dp.py::test_rccl_all_reduce_in_a_fresh_process - NOT a test module.
 
 Started as a fresh process (nothing has touched the GPU before `init_from_env`), it builds a one-rank process group with
-backend "nccl" (= RCCL on ROCm), runs two `xe_train_step`s of the tiny captioner with a gradient arena, and prints one
+backend "nccl" (= RCCL on ROCm), runs two `xe_train_step`s of the tiny captioner with a gradient arena (a one-rank group
+takes every data-parallel branch of the step: the 3-float count all-reduce, the loss shares, the arena all-reduce and the
+loss-statistics all-reduce - `dp.distributed()`), and prints one
 JSON line with what the parent asserts on: the backend, that librccl is mapped into the process, how many collectives
 the arena issued, and that the parameters moved.  NCCL_DEBUG=INFO output (RCCL's own log of the AllReduce calls) goes to
 stdout next to it."""
@@ -56,6 +58,7 @@ def main():
     moved = sum(int(not torch.equal(before[k], v)) for k, v in cap.state_dict().items())
     print('RCCL_CHILD ' + json.dumps(dict(
         backend=dist.get_backend(), rccl_mapped=('librccl' in maps), collectives=arena.collectives,
+        all_reduces=dp.COLLECTIVES,
         arena_bytes=arena.nbytes, losses=losses, identity=identity, moved=moved,
         nccl_version=list(torch.cuda.nccl.version()))), flush=True)
     dist.barrier()

@@ -112,3 +112,68 @@ def test_single_process_helpers_are_identity():
     s, n = dp.dp_token_mean(t * 2, 5.0)
     assert float(n) == 5.0 and float(s.detach()) == 6.0
     assert float(dp.dp_batch_mean(t).detach()) == 3.0
+
+
+def _guard_worker(rank, world, port, results):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    dp.init_from_env('gloo')
+    out = {}
+    # the group really is gloo; pretend it is RCCL: every collective of the package must then refuse a CPU tensor
+    real = dist.get_backend
+    dist.get_backend = lambda group=None: 'nccl'
+    try:
+        for name, fn in (('global_count', lambda: dp.global_count(5.0)),
+                         ('global_counts', lambda: dp.global_counts([1.0, 2.0], 'cpu')),
+                         ('dp_token_mean', lambda: dp.dp_token_mean(torch.tensor(1.0), 3.0)),
+                         ('arena', lambda: dp.GradArena(Toy().parameters()).all_reduce()),
+                         ('same', lambda: dp.assert_same_across_ranks(3, 'cpu')),
+                         ('broadcast', lambda: dp.broadcast_parameters(Toy()))):
+            try:
+                fn()
+                out[name] = 'no error'
+            except TypeError as e:
+                out[name] = str(e)
+    finally:
+        dist.get_backend = real
+    # and with the true backend the same calls go through (and count)
+    before = dp.COLLECTIVES
+    n = dp.global_count(5.0 + rank)
+    loc, glob = dp.global_counts([1.0, torch.tensor(2.0 * (rank + 1))], 'cpu')
+    dp.assert_same_across_ranks(7, 'cpu')
+    try:
+        dp.assert_same_across_ranks(7 + rank, 'cpu', what='trip count')
+        mismatch = 'no error'
+    except RuntimeError as e:
+        mismatch = str(e)
+    results[rank] = dict(guard=out, n=float(n), glob=glob.tolist(), loc=loc.tolist(), issued=dp.COLLECTIVES - before,
+                         mismatch=mismatch)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_collectives_refuse_cpu_tensors_under_rccl_and_mismatched_ranks_raise():
+    """Round-2 defect: `global_count` all-reduced a CPU tensor; gloo accepted it, RCCL would not have.  With the
+    backend name mocked to "nccl" every collective entry of dp.py must raise on a CPU tensor (so a count built on the
+    host can never reach RCCL), and unequal trip counts across ranks raise instead of hanging."""
+    world, port = 2, _free_port()
+    results = mp.Manager().dict()
+    mp.spawn(_guard_worker, args=(world, port, results), nprocs=world, join=True)
+    for r in (0, 1):
+        g = results[r]['guard']
+        assert set(g) == {'global_count', 'global_counts', 'dp_token_mean', 'arena', 'same', 'broadcast'}
+        for k, msg in g.items():
+            assert 'nccl' in msg, (k, msg)
+        assert results[r]['n'] == 11.0
+        assert results[r]['glob'] == [2.0, 6.0] and results[r]['loc'] == [1.0, 2.0 * (r + 1)]
+        assert results[r]['issued'] == 4
+        assert 'trip count differs across ranks' in results[r]['mismatch']
+
+
+def test_shard_drop_last_gives_equal_shards():
+    for n in (0, 7, 64, 1001):
+        for world in (1, 2, 8):
+            spans = [dp.shard(n, r, world, drop_last=True) for r in range(world)]
+            assert len({hi - lo for lo, hi in spans}) == 1
+            assert spans[0][0] == 0 and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert spans[-1][1] == (n // world) * world

@@ -214,7 +214,10 @@ def test_dv_and_dp_summed_after_the_sweep_equal_the_per_step_accumulation():
     the other outputs of the scan backward do not change when the two are left out of it.  With and without q2."""
     D_ = torch.device('cuda:0')
     g = torch.Generator().manual_seed(11)
-    for B, T, R, A, with_q2 in ((37, 7, 36, 512, False), (21, 20, 11, 512, True), (5, 3, 6, 64, False)):
+    # (R = 196: the reference encoder's 14 x 14 grid - several region chunks; A = 96 / 1040: column counts that do not
+    # divide the workgroup / exceed one column block)
+    for B, T, R, A, with_q2 in ((37, 7, 36, 512, False), (21, 20, 11, 512, True), (5, 3, 6, 64, False),
+                                (9, 20, 196, 512, False), (3, 20, 196, 512, True), (4, 5, 50, 96, True)):
         Pm, Vm = torch.randn(B, R, A, generator=g).to(D_), torch.randn(B, R, A, generator=g).to(D_)
         w = (torch.randn(1, A, generator=g) * 0.3).to(D_)
         q = torch.randn(T, B, A, generator=g).to(D_)

@@ -216,6 +216,8 @@ def test_rccl_all_reduce_in_a_fresh_process():
     info = json.loads(line[-1][len('RCCL_CHILD '):])
     assert info['backend'] == 'nccl' and info['rccl_mapped']
     assert info['collectives'] == 3 and info['identity']            # 2 training steps + the probe
+    # per step: normaliser counts + gradient arena + loss statistics, all on device tensors through RCCL
+    assert info['all_reduces'] == 2 * 3 + 1
     assert info['arena_bytes'] == 4 * sum(int(np.prod(s)) for s in synth.param_shapes(V, ST).values())
     assert info['moved'] >= 30 and all(np.isfinite(x) for x in info['losses'])
     log = r.stdout + r.stderr
