@@ -486,6 +486,50 @@ int isc_relu_mask_bwd(const float *dy, const float *y, const uint8_t *keep_mask,
 int isc_xe_loss_bwd(const int64_t *target, const int32_t *lengths, int B, int T, int V,
                     const float *gout, const float *sum_count, float *dlogp, void *stream);
 
+/* XECriterion backward in the sparse form isc_logsoftmax_bwd_sparse takes: coef [B,T] = -gout/count at unmasked
+ * tokens and 0 elsewhere (the column of row (b,t) is target[b,t] itself) - no [B,T,V] tensor. */
+int isc_xe_loss_bwd_sparse(const int32_t *lengths, int B, int T, const float *gout, const float *sum_count,
+                           float *coef, void *stream);
+
+/* RewardCriterion (self_critical/utils.py:169-177; called at models/decoder.py:160): the masked REINFORCE loss
+ * -sum(logp * mask * reward) / sum(mask) over [B,T] fp32 tensors, one launch each way.
+ * fwd: out2 = { sum(-logp*mask*reward), sum(mask) } (the caller divides: keeps sum and count for the backward and for
+ * data-parallel normalisation).  bwd: d_seq_logprobs[b,t] = -gout[0] * mask * reward / sum_count[1]. */
+int isc_reward_loss_fwd(const float *seq_logprobs, const float *seq_masks, const float *reward, int B, int T,
+                        float *out2, void *stream);
+int isc_reward_loss_bwd(const float *seq_masks, const float *reward, int B, int T, const float *gout,
+                        const float *sum_count, float *d_seq_logprobs, void *stream);
+
+/* Log-softmax backward with the criteria's gradient handed over SPARSE: XECriterion (captioner.py:427-440) and the
+ * REINFORCE gather (captioner.py:336) touch one column per (caption, step) row, so their d log-prob is `coef[m]` at
+ * column `ids[m]` - up to ISC_SPARSE_MAX such (ids, coef) pairs (HOST arrays of device pointers to [M] vectors, rows
+ * in [B,T] order) plus an optional dense part `dlogp_dense` [M, ld_in] (NULL when every consumer of the log-probs was
+ * one of the two criteria: no [B,T,V] gradient tensor is then written or read at all).
+ *   dlogits[m', v] = scale * (dense[m,v] + sum_j coef_j[m] [v == ids_j[m]] - exp(logp[m,v]) * (sum_v dense + sum_j coef_j))
+ * `scale`: optional device scalar (isc_grad_scale's out2[0]); rows are written time-major when remap_T > 0 and
+ * columns V..ld_out-1 are zero-filled, as isc_logsoftmax_bwd does. */
+#define ISC_SPARSE_MAX 2
+int isc_logsoftmax_bwd_sparse(const float *dlogp_dense, const float *logp, int64_t ld_in, int M, int V,
+                              const int64_t *const *ids_host, const float *const *coef_host, int n_sparse,
+                              const float *scale, float *dlogits, int64_t ld_out, int remap_T, void *stream);
+
+/* Power-of-two gradient scale for a backward sweep whose contractions run on the split-f16 engine: out2 = { S, 1/S },
+ * S = 2^k with max |x| over the given tensors (HOST arrays of device pointers / element counts, <= ISC_SCALE_SRC_MAX)
+ * brought into [2^-4, 2^-3); S = 1 when they are all zero.  The caller multiplies what enters the sweep by S (exact)
+ * and the parameter gradients by 1/S (exact): gradients of a token-mean loss are <= 1/N_tokens, below the f16 normal
+ * range at training batch sizes, where the planes x = hi + lo 2^-11 would keep ~22 bits relative to 2^-14 instead of to
+ * the element. */
+#define ISC_SCALE_SRC_MAX 4
+int isc_grad_scale(const float *const *src_host, const int64_t *numel_host, int n_src, float *out2, void *stream);
+
+/* Workspace sizes (the library allocates nothing; these say what to hand it).
+ * isc_splitk_workspace_bytes: bytes that let a launch with an [M, N] output use the deepest K split (16 slabs);
+ *   isc_*_problem.splitk_ws may be smaller (fewer slabs) or NULL (no split, no out-of-scope split-f16 launches).
+ * isc_h3_weights_workspace_bytes: bytes of an isc_h3_weights_begin buffer that holds the f16 planes (hi + lo) of
+ *   `weight_elements` fp32 weight values, twice that when the backward's transposed planes are wanted too. */
+int64_t isc_splitk_workspace_bytes(int64_t M, int64_t N);
+int64_t isc_h3_weights_workspace_bytes(int64_t weight_elements, int with_transposes);
+
 /* clip_gradient (train_xe.py:19-23, decoder.py:14-18: elementwise clamp_ to +-clip, in place)
  * followed by torch.optim.Adam's update (captioner.py:422-423), all tensors in one launch.
  * Pointer tables are HOST arrays of device pointers. clip <= 0 disables the clamp. */

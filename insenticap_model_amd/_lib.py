@@ -174,6 +174,16 @@ SIGNATURES = {
                                     C.c_void_p]),
     'isc_xe_loss_bwd': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                   C.c_void_p, C.c_void_p, C.c_void_p]),
+    'isc_xe_loss_bwd_sparse': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'isc_reward_loss_fwd': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    'isc_reward_loss_bwd': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_void_p]),
+    'isc_logsoftmax_bwd_sparse': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int,
+                                            C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int, C.c_void_p,
+                                            C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
+    'isc_grad_scale': (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_int, C.c_void_p, C.c_void_p]),
+    'isc_splitk_workspace_bytes': (C.c_int64, [C.c_int64, C.c_int64]),
+    'isc_h3_weights_workspace_bytes': (C.c_int64, [C.c_int64, C.c_int]),
     'isc_clamp_adam': (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                  C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_int, C.c_double,
                                  C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int,

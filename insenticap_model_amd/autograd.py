@@ -144,9 +144,14 @@ def _train_forward(cap, mode, fc, att, cpt_words, senti_words, tokens_in, senti_
 
 
 # ------------------------------------------------------------------------------ backward
-def _backward(cap, S, dlogp, d_fc_feats, d_cpt_feats):
-    """Returns {param name: gradient}. dlogp [B,T,V] (contiguous), optional gradients of the
-    `fc_feats` (pre-dropout) and `cpt_feats` attributes."""
+def _backward(cap, S, dlogp, d_fc_feats, d_cpt_feats, sparse=()):
+    """Returns {param name: gradient}.  The gradient of the log-probs arrives as `dlogp` [B,T,V] (contiguous; None when
+    every consumer handed its part over sparse) plus `sparse` = [(ids [B,T] int64, coef [B,T] fp32)]: coef at column ids
+    of each row (XELossFn / GatherLogpFn below).  Optional gradients of the `fc_feats` (pre-dropout) and `cpt_feats`
+    attributes.
+    Gradient scale: the sweep is linear in what enters it, so everything entering is multiplied by a power of two S
+    (isc_grad_scale: the largest entering |gradient| -> 2^-4..2^-3) and the parameter gradients by 1/S at the end -
+    both exact - which keeps the f16 planes of the split-f16 contractions in their normal range."""
     p, P, B, T = S.p, S.P, S.B, S.T
     st = cap.settings
     E, A, H, Wd, V = st['feat_emb_dim'], st['att_hid_dim'], st['rnn_hid_dim'], st['word_emb_dim'], cap.vocab_size
@@ -172,7 +177,23 @@ def _backward(cap, S, dlogp, d_fc_feats, d_cpt_feats):
     # ---- classifier + log-softmax: outside the recurrence, all T*B rows at once (time-major rows)
     Vp = _pad32(V)
     dlogits = new(TB, Vp)
-    ops.logsoftmax_bwd(dlogp, S.logp, dlogits, B * T, V, remap_T=T)
+    gs = None
+    if getattr(cap, 'grad_scaling', True):
+        gs = new(2)
+        srcs = [c for _, c in sparse] + [d_fc_feats.contiguous() if d_fc_feats is not None else None,
+                                         d_cpt_feats.contiguous() if d_cpt_feats is not None else None]
+        if dlogp is not None:
+            srcs.append(dlogp.abs().amax().reshape(1))        # (a caller-defined dense loss: one extra pass)
+        ops.grad_scale(srcs, gs)
+        if d_fc_feats is not None:
+            d_fc_feats = d_fc_feats * gs[0]
+        if d_cpt_feats is not None:
+            d_cpt_feats = d_cpt_feats * gs[0]
+    if dlogp is None and not sparse:
+        dlogits.zero_()
+    else:
+        ops.logsoftmax_bwd_sparse(dlogp, S.logp, list(sparse), dlogits, B * T, V, remap_T=T,
+                                  scale=gs[0:1] if gs is not None else None)
     Wc = p['classifier.weight']
     hdrop_tb = (S.hdrop if S.hdrop is not None else S.h2[1:]).reshape(TB, H)
     dhd = new(TB, H)
@@ -425,6 +446,8 @@ def _backward(cap, S, dlogp, d_fc_feats, d_cpt_feats):
                            skip_id=cap.pad_id)
     dEmb[cap.pad_id].zero_()     # nn.Embedding(padding_idx=pad_id): the <PAD> row never gets a gradient
     G['word_embed.0.weight'] = dEmb
+    if gs is not None:           # undo the gradient scale: x 1/S, a power of two
+        torch._foreach_mul_(list(G.values()), gs[1])
     return G
 
 
@@ -447,6 +470,9 @@ class DecodeFn(torch.autograd.Function):
         S.P.cpt_pre = cap.cpt_feats
         cap._last_sample = getattr(S, 'sample', None)
         ctx.cap, ctx.S, ctx.names = cap, S, names
+        # side channel for the criteria: XELossFn / GatherLogpFn find this node as `logp.grad_fn` and append their
+        # (ids, coef) pairs here in THEIR backward (which precedes this node's) instead of returning a [B,T,V] tensor
+        ctx._isc_sparse = []
         ctx.set_materialize_grads(False)
         outs = [logp, cap.cpt_feats]
         if mode != 'seq2seq':
@@ -457,10 +483,9 @@ class DecodeFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dlogp, d_cpt, d_fc=None):
         cap, S = ctx.cap, ctx.S
-        if dlogp is None:
-            dlogp = torch.zeros_like(S.logp)
+        sparse, ctx._isc_sparse = ctx._isc_sparse, []
         with torch.no_grad():
-            G = _backward(cap, S, dlogp.contiguous(), d_fc, d_cpt)
+            G = _backward(cap, S, dlogp.contiguous() if dlogp is not None else None, d_fc, d_cpt, sparse)
         grads = tuple(G.get(n) for n in ctx.names)
         ctx.S = None
         return (None,) * 11 + grads
@@ -499,29 +524,93 @@ def rollout_with_grad(cap, fc, att, cpt_words, senti_words, senti_labels, T, rep
     cap.cpt_feats, cap.fc_feats = outs[1], outs[2]
     seq, seq_masks, raw, alive = cap._last_sample
     cap._last_sample = None
-    lp = logp.gather(2, raw.unsqueeze(2)).squeeze(2)
-    live = (alive[:T] > 0).to(lp.dtype)      # step t ran iff some row was unfinished before it: zero after the early break
-    return seq, lp * live, seq_masks
+    live = (alive[:T] > 0).to(logp.dtype)    # step t ran iff some row was unfinished before it: zero after the early break
+    lp = GatherLogpFn.apply(logp, raw, live, _decode_node(logp))
+    return seq, lp, seq_masks
+
+
+def _decode_node(logp):
+    """The DecodeFn node behind `logp` if the criterion may use its sparse side channel: `logp` must be that node's
+    own output (a slice or a copy of it has another grad_fn) - else None (dense hand-over)."""
+    node = logp.grad_fn
+    return node if node is not None and hasattr(node, '_isc_sparse') else None
+
+
+class GatherLogpFn(torch.autograd.Function):
+    """log p(drawn token) * live (captioner.py:336, zero after the early break).  Backward: the gradient w.r.t. the
+    [B,T,V] log-probs is g[b,t] * live[t] at column raw[b,t] - handed to the decode node as an (ids, coef) pair."""
+
+    @staticmethod
+    def forward(ctx, logp, raw, live, node):
+        ctx.node, ctx.shape = node, logp.shape
+        ctx.save_for_backward(raw, live)
+        return logp.gather(2, raw.unsqueeze(2)).squeeze(2) * live
+
+    @staticmethod
+    def backward(ctx, g):
+        raw, live = ctx.saved_tensors
+        coef = (g * live).contiguous()
+        if ctx.node is not None:
+            ctx.node._isc_sparse.append((raw.contiguous(), coef))
+            return None, None, None, None
+        d = torch.zeros(ctx.shape, dtype=coef.dtype, device=coef.device)
+        d.scatter_(2, raw.unsqueeze(2), coef.unsqueeze(2))
+        return d, None, None, None
 
 
 class XELossFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, pred, target, lengths_i32):
+    def forward(ctx, pred, target, lengths_i32, node):
         out2 = torch.empty(2, dtype=torch.float32, device=pred.device)
         ops.xe_loss_fwd(pred, target, lengths_i32, out2)
         ctx.save_for_backward(target, lengths_i32, out2)
-        ctx.shape = pred.shape
+        ctx.shape, ctx.node = pred.shape, node
         return out2[0] / out2[1]
 
     @staticmethod
     def backward(ctx, g):
         target, lengths_i32, out2 = ctx.saved_tensors
+        gout = g.reshape(1).contiguous().float()
+        if ctx.node is not None:        # pred is a decode node's own output: hand (target, coef) over, no [B,T,V] tensor
+            coef = torch.empty(ctx.shape[:2], dtype=torch.float32, device=target.device)
+            ops.xe_loss_bwd_sparse(lengths_i32, ctx.shape[1], gout, out2, coef)
+            ctx.node._isc_sparse.append((target, coef))
+            return None, None, None, None
         dlogp = torch.zeros(ctx.shape, dtype=torch.float32, device=target.device)
-        ops.xe_loss_bwd(target, lengths_i32, g.reshape(1).contiguous().float(), out2, dlogp)
-        return dlogp, None, None
+        ops.xe_loss_bwd(target, lengths_i32, gout, out2, dlogp)
+        return dlogp, None, None, None
 
 
 def xe_criterion_with_grad(pred, target, lengths):
     ops.require_device(pred, target)
     ln = ops.upload(lengths, torch.int32, pred.device)
-    return XELossFn.apply(pred.contiguous(), target.long().contiguous(), ln)
+    node = _decode_node(pred) if pred.is_contiguous() else None
+    return XELossFn.apply(pred.contiguous(), target.long().contiguous(), ln, node)
+
+
+class RewardLossFn(torch.autograd.Function):
+    """RewardCriterion (self_critical/utils.py:169-177) as one launch each way (isc_reward_loss_fwd / _bwd)."""
+
+    @staticmethod
+    def forward(ctx, seq_logprobs, seq_masks, reward):
+        out2 = torch.empty(2, dtype=torch.float32, device=seq_logprobs.device)
+        ops.reward_loss_fwd(seq_logprobs, seq_masks, reward, out2)
+        ctx.save_for_backward(seq_masks, reward, out2)
+        return out2[0] / out2[1]
+
+    @staticmethod
+    def backward(ctx, g):
+        seq_masks, reward, out2 = ctx.saved_tensors
+        d = torch.empty_like(seq_masks)
+        ops.reward_loss_bwd(seq_masks, reward, g.reshape(1).contiguous().float(), out2, d)
+        return d, None, None
+
+
+def reward_criterion(seq_logprobs, seq_masks, reward):
+    """-sum(logp * mask * reward) / sum(mask) on the device; `reward` may be a [B,T] tensor of any float dtype or
+    broadcastable to it."""
+    ops.require_device(seq_logprobs, seq_masks)
+    lp = seq_logprobs.float().contiguous()
+    mk = seq_masks.float().contiguous()
+    rw = torch.as_tensor(reward, dtype=torch.float32, device=lp.device).expand_as(lp).contiguous()
+    return RewardLossFn.apply(lp, mk, rw)

@@ -172,36 +172,32 @@ def _graphed_search(cap, fc_feats, att_feats, senti_words, senti_labels, beam, d
     entry = cache.get(key)
     if entry is None:                       # first sight: run eagerly (builds the cached tables, warms the kernels)
         while len(cache) >= cap._beam_graphs_max:
-            cache.pop(next(iter(cache)))
+            cache.pop(next(iter(cache)))    # least recently used (hits re-insert their key at the end)
         cache[key] = 'seen'
         return _search(cap, *ins, beam, decoding_constraint, T)
+    cache[key] = cache.pop(key)             # LRU order
     if entry == 'seen':
         static = [None if x is None else x.clone() for x in ins]
-        ws = torch.empty(ops.SPLITK_WS_FLOATS, dtype=torch.float32, device=dev)
-        wp = torch.empty(ops.H3W_BYTES, dtype=torch.uint8, device=dev)
+        ws, wp = cap._graph_buffers()          # ONE workspace / plane-buffer pair for all graphs of this captioner
         stream = torch.cuda.Stream(device=dev)
         pool = torch.cuda.graph_pool_handle()
         graphs = []
         torch.cuda.synchronize()
-        ops.WS_OVERRIDE, ops.H3W_OVERRIDE = ws, wp
-        try:
-            with torch.cuda.stream(stream):
-                scope = ops.h3_weights_scope(dev)      # ONE scope over all the captures (its planes live in `wp`,
-                scope.__enter__()                      # are split inside graph 0 and read by the later graphs)
-                try:
-                    search = None
-                    for t0 in range(0, T, CHUNK):
-                        g = torch.cuda.CUDAGraph()
-                        with torch.cuda.graph(g, pool=pool, stream=stream):
-                            if search is None:
-                                search = _Search(cap, *static, beam, decoding_constraint, T)
-                            for t in range(t0, min(t0 + CHUNK, T)):
-                                search.step(t)
-                        graphs.append(g)
-                finally:
-                    scope.__exit__(None, None, None)
-        finally:
-            ops.WS_OVERRIDE = ops.H3W_OVERRIDE = None
+        with ops.capture_buffers(ws, wp), torch.cuda.stream(stream):
+            scope = ops.h3_weights_scope(dev)      # ONE scope over all the captures (its planes live in `wp`,
+            scope.__enter__()                      # are split inside graph 0 and read by the later graphs)
+            try:
+                search = None
+                for t0 in range(0, T, CHUNK):
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, pool=pool, stream=stream):
+                        if search is None:
+                            search = _Search(cap, *static, beam, decoding_constraint, T)
+                        for t in range(t0, min(t0 + CHUNK, T)):
+                            search.step(t)
+                    graphs.append(g)
+            finally:
+                scope.__exit__(None, None, None)
         entry = cache[key] = (graphs, static, search, ws, wp, pool)
     graphs, static, search = entry[:3]
     for dst, src in zip(static, ins):

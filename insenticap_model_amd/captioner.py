@@ -6,6 +6,9 @@ The nn.Module containers below exist only to own the parameters under the refere
 names (checkpoint compatibility); their `forward`s are never called.
 PyTorch is used for device memory, streams and (in train mode) random numbers only.
 """
+import itertools
+import weakref
+
 import torch
 import torch.nn as nn
 
@@ -59,6 +62,17 @@ class _Pro:
     sc = 1.0
 
 
+_INSTANCE_NONCE = itertools.count(1)
+
+
+def _forget_instance(nonce):
+    """A Captioner was freed: its suspended weights scopes (f16 planes keyed on its weights) must never be resumed."""
+    try:
+        ops.h3_weights_scope.forget(lambda wk: wk and wk[0][0] == 'captioner' and wk[0][1] <= nonce[0])
+    except Exception:       # noqa: BLE001 - interpreter shutdown
+        pass
+
+
 class Captioner(nn.Module):
     def __init__(self, idx2word, sentiment_categories, settings):
         super().__init__()
@@ -95,6 +109,10 @@ class Captioner(nn.Module):
         self.classifier = nn.Linear(H, self.vocab_size)
         self.fc_feats = self.cpt_feats = None
         self.cont_weights, self.senti_weights, self.cont_senti_weights = [], [], []
+        # identity of this instance's weights in the process-wide caches keyed on weight values (ops.h3_weights_scope):
+        # a one-element list so that the finalizer below sees renewals
+        self._wnonce = [next(_INSTANCE_NONCE)]
+        weakref.finalize(self, _forget_instance, self._wnonce)
 
     # ------------------------------------------------------------------ plumbing
     def _p(self):
@@ -602,22 +620,20 @@ class Captioner(nn.Module):
         entry = cache.get(key)
         if entry is None:                       # first sight: run eagerly (warms kernels and one-time attributes)
             while len(cache) >= self._rollout_graphs_max:
-                cache.pop(next(iter(cache)))
+                cache.pop(next(iter(cache)))    # least recently used (hits re-insert their key at the end)
             cache[key] = 'seen'
             return self._rollout(*ins, T, 1, None, None)[:3]
+        cache[key] = cache.pop(key)             # LRU order
         if entry == 'seen':
             static = [x.clone() for x in ins]
             graph = torch.cuda.CUDAGraph()
             torch.cuda.synchronize()
-            with torch.cuda.graph(graph):
-                # the graph owns its split-K workspace (allocated from the graph's private pool): the per-stream
-                # one would be keyed on the capture stream and outlive or predate this graph
-                ops.WS_OVERRIDE = ws = torch.empty(ops.SPLITK_WS_FLOATS, dtype=torch.float32, device=self._dev)
-                ops.H3W_OVERRIDE = wp = torch.empty(ops.H3W_BYTES, dtype=torch.uint8, device=self._dev)
-                try:
-                    outs = self._rollout(*static, T, 1, None, None)[:3]
-                finally:
-                    ops.WS_OVERRIDE = ops.H3W_OVERRIDE = None
+            # the graphs of this captioner share ONE split-K workspace and ONE weight-plane buffer (the per-stream
+            # ones would be keyed on the capture stream and could be freed under the graph); replays are enqueued on
+            # one stream at a time, so they never overlap
+            ws, wp = self._graph_buffers()
+            with ops.capture_buffers(ws, wp), torch.cuda.graph(graph):
+                outs = self._rollout(*static, T, 1, None, None)[:3]
                 pending = self.__dict__.get('_weights_pending')
             entry = cache[key] = (graph, static, outs, pending, ws, wp)
         graph, static, outs, pending = entry[:4]
@@ -636,10 +652,35 @@ class Captioner(nn.Module):
         self._beam_graphs_max = max_graphs
 
     def _weights_key(self):
-        """Identifies the current parameter VALUES (storage pointers + version counters + the epoch bumped by the fused
-        optimizer, which writes behind torch's back): equal keys => the f16 weight planes of an earlier call are
-        still valid (ops.h3_weights_scope(key=...))."""
-        return tuple((q.data_ptr(), q._version) for q in self.parameters()) + (ops.WEIGHT_EPOCH,)
+        """Identifies the current parameter VALUES of THIS instance (its nonce + storage pointers + version counters +
+        the epoch bumped by the fused optimizer, which writes behind torch's back): equal keys => the f16 weight planes
+        of an earlier call are still valid (ops.h3_weights_scope(key=...)).  The nonce matters: the caching allocator
+        hands a freed model's addresses to the next one of the same shapes, with equal version counters."""
+        return (('captioner', self._wnonce[0]),) + tuple((q.data_ptr(), q._version) for q in self.parameters()) + \
+            (ops.WEIGHT_EPOCH,)
+
+    def _renew_weights_nonce(self):
+        self._wnonce[0] = next(_INSTANCE_NONCE)
+
+    def _apply(self, fn, *args, **kwargs):               # .to() / .cuda() / .float(): new storages
+        out = super()._apply(fn, *args, **kwargs)
+        self._renew_weights_nonce()
+        return out
+
+    def load_state_dict(self, *args, **kwargs):          # new values (copied in place)
+        out = super().load_state_dict(*args, **kwargs)
+        self._renew_weights_nonce()
+        return out
+
+    def _graph_buffers(self):
+        """The split-K workspace (128 MB) and weight-plane buffer (192 MB) that every HIP graph captured for this
+        captioner - roll-out and beam graphs alike - launches into: 320 MB per captioner, not per cached graph."""
+        gb = self.__dict__.get('_graph_bufs')
+        if gb is None or gb[0].device != self._dev:
+            gb = self.__dict__['_graph_bufs'] = (
+                torch.empty(ops.splitk_ws_floats(), dtype=torch.float32, device=self._dev),
+                torch.empty(ops.h3w_bytes(), dtype=torch.uint8, device=self._dev))
+        return gb
 
     def _rollout(self, fc_feats, att_feats, cpt_words, senti_words, senti_labels, T, sample_max, replay,
                  masks):

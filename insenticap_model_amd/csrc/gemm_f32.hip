@@ -2447,6 +2447,18 @@ static H3WScope *h3w_scope_of(hipStream_t st) {
     return nullptr;
 }
 
+extern "C" int64_t isc_splitk_workspace_bytes(int64_t M, int64_t N) {
+    if (M <= 0 || N <= 0) return 0;
+    const int64_t b = 16 * M * N * (int64_t)sizeof(float);            // plan_splitk: S <= 16 slabs of [M, N]
+    return (b + 255) / 256 * 256;
+}
+extern "C" int64_t isc_h3_weights_workspace_bytes(int64_t weight_elements, int with_transposes) {
+    if (weight_elements <= 0) return 0;
+    const int64_t one = weight_elements * 2 * (int64_t)sizeof(uint16_t);     // hi + lo f16 plane per value
+    const int64_t b = one * (with_transposes ? 2 : 1);
+    return (b + 1048575) / 1048576 * 1048576;
+}
+
 extern "C" int isc_h3_weights_begin(void *buf, long long bytes, void *stream) {
     if (!buf || bytes <= 0) return ISC_E_NULL;
     if ((uintptr_t)buf & 255) return ISC_E_ALIGN;

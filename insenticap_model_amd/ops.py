@@ -66,25 +66,64 @@ def _seg_k(segs):
 
 
 _SPLITK_WS = {}
-SPLITK_WS_FLOATS = 32 * 1024 * 1024     # 128 MB per device and stream: [ksplit, M, N] partial slabs of small-M GEMMs,
-                                        # or the f16 operand planes of the split-f16 path
+_WS_SIZES = {}
 
 
-WS_OVERRIDE = None      # set while a HIP graph is being captured: the graph owns its workspace
-H3W_OVERRIDE = None     # ... and its weight-plane buffer (h3_weights_scope)
+def splitk_ws_floats():
+    """Size of a per-(device, stream) split-K workspace, asked of the library (isc_splitk_workspace_bytes): the
+    deepest K split of a [4096 x 512] output - the widest few-tile launch of the step at the headline batch - =
+    128 MB; also holds the f16 weight planes of a split-f16 launch issued outside a weights scope."""
+    if 'ws' not in _WS_SIZES:
+        _WS_SIZES['ws'] = int(_lib.load().isc_splitk_workspace_bytes(4096, 512)) // 4
+    return _WS_SIZES['ws']
+
+
+def h3w_bytes():
+    """Size of a weights-scope plane buffer (isc_h3_weights_workspace_bytes): hi + lo planes of up to 24 Mi weight
+    values (the reference architecture at V = 10k has 22 063 379, of which ~16 M are GEMM operands) in the forward
+    layout AND transposed for the backward = 192 MB."""
+    if 'h3w' not in _WS_SIZES:
+        _WS_SIZES['h3w'] = int(_lib.load().isc_h3_weights_workspace_bytes(24 * 1024 * 1024, 1))
+    return _WS_SIZES['h3w']
+
+
+_CAPTURE = threading.local()      # per host thread: the (workspace, weight-plane buffer) pair of a HIP-graph capture
+
+
+class capture_buffers:
+    """`with ops.capture_buffers(ws, wp):` - while THIS thread captures a HIP graph, split-K launches use `ws` and
+    weights scopes put their planes into `wp` (the graph's owner keeps both alive for the replays) instead of the
+    per-stream buffers.  Thread-local: another thread entering a scope on its own stream meanwhile is unaffected."""
+
+    def __init__(self, ws, wp):
+        self.pair = (ws, wp)
+
+    def __enter__(self):
+        self.prev = getattr(_CAPTURE, 'pair', None)
+        _CAPTURE.pair = self.pair
+        return self
+
+    def __exit__(self, *exc):
+        _CAPTURE.pair = self.prev
+        return False
+
+
+def _capture_pair():
+    return getattr(_CAPTURE, 'pair', None) or (None, None)
 
 
 def splitk_ws(device=None):
     """Split-K workspace of the CURRENT stream on `device` (allocated once per (device, stream)): kernels on one
     stream use it one after another; two streams never share one - their split-K launches may overlap."""
-    if WS_OVERRIDE is not None:
-        return WS_OVERRIDE
+    cap_ws = _capture_pair()[0]
+    if cap_ws is not None:
+        return cap_ws
     device = torch.device(device if device is not None else torch.cuda.current_device())
     index = device.index if device.index is not None else torch.cuda.current_device()
     key = (index, torch.cuda.current_stream(index).cuda_stream)
     ws = _SPLITK_WS.get(key)
     if ws is None:
-        ws = _SPLITK_WS[key] = torch.empty(SPLITK_WS_FLOATS, dtype=torch.float32, device=device)
+        ws = _SPLITK_WS[key] = torch.empty(splitk_ws_floats(), dtype=torch.float32, device=device)
     return ws
 
 
@@ -143,7 +182,6 @@ def set_h3_mode(mode):
 
 
 _H3W_BUF = {}
-H3W_BYTES = 192 * 1024 * 1024     # forward planes of every weight (~62 MB) + the transposes the backward uses (~60 MB)
 
 
 class h3_weights_scope:
@@ -159,6 +197,14 @@ class h3_weights_scope:
     _suspended = {}          # (device, stream) -> key of the suspended scope
     _lock = threading.Lock()
 
+    @classmethod
+    def forget(cls, pred):
+        """Drops the suspended scopes whose key satisfies `pred` (a Captioner being freed: its planes must never be
+        resumed); the next scope on such a stream begins afresh."""
+        with cls._lock:
+            for k in [k for k, wk in cls._suspended.items() if pred(wk)]:
+                del cls._suspended[k]
+
     def __init__(self, device, key=None):
         self.device = torch.device(device)
         self.wkey = key
@@ -167,28 +213,37 @@ class h3_weights_scope:
         cls = h3_weights_scope
         index = self.device.index if self.device.index is not None else torch.cuda.current_device()
         self.key = key = (index, torch.cuda.current_stream(index).cuda_stream)     # one buffer per stream, as splitk_ws
+        self.opened = False
         with cls._lock:
             depth = cls._depth[key] = cls._depth.get(key, 0) + 1
-            buf = was = None
-            if depth == 1 and WS_OVERRIDE is not None:    # a HIP graph is being captured: the graph owns the plane
-                buf = H3W_OVERRIDE                        # buffer, and replays must re-split (weights may change
+        try:                      # anything that raises below must give the depth back: __exit__ will not run, and a
+            buf = was = None      # depth stuck at >= 1 would turn every later scope on this stream into a no-op
+            cap_wp = _capture_pair()[1]
+            if depth == 1 and cap_wp is not None:         # a HIP graph is being captured: the graph owns the plane
+                buf = cap_wp                              # buffer, and replays must re-split (weights may change
                 self.wkey = None                          # in place between replays): never keyed, never resumed
             elif depth == 1:
-                buf = _H3W_BUF.get(key)
+                with cls._lock:
+                    buf = _H3W_BUF.get(key)
+                    was = cls._suspended.pop(key, None)
                 if buf is None:
-                    buf = _H3W_BUF[key] = torch.empty(H3W_BYTES, dtype=torch.uint8, device=self.device)
-                was = cls._suspended.pop(key, None)
-        self.opened = False
-        if buf is not None:
-            lib = _lib.load()
-            if self.wkey is not None and was == self.wkey and \
-                    lib.isc_h3_weights_resume(buf.data_ptr(), C.c_void_p(key[1])) == 0:
-                self.opened = True
-            else:
-                rc = lib.isc_h3_weights_begin(buf.data_ptr(), buf.numel(), C.c_void_p(key[1]))
-                if rc != -4:                              # ISC_E_WORKSPACE: all scope slots taken - run without one
-                    _lib.check(rc, 'isc_h3_weights_begin')
+                    buf = torch.empty(h3w_bytes(), dtype=torch.uint8, device=self.device)
+                    with cls._lock:
+                        _H3W_BUF[key] = buf
+            if buf is not None:
+                lib = _lib.load()
+                if self.wkey is not None and was == self.wkey and \
+                        lib.isc_h3_weights_resume(buf.data_ptr(), C.c_void_p(key[1])) == 0:
                     self.opened = True
+                else:
+                    rc = lib.isc_h3_weights_begin(buf.data_ptr(), buf.numel(), C.c_void_p(key[1]))
+                    if rc != -4:                          # ISC_E_WORKSPACE: all scope slots taken - run without one
+                        _lib.check(rc, 'isc_h3_weights_begin')
+                        self.opened = True
+        except BaseException:
+            with cls._lock:
+                cls._depth[key] -= 1
+            raise
         return self
 
     def __exit__(self, *exc):
@@ -492,6 +547,51 @@ def logsoftmax_bwd(dlogp, logp, dlogits, M, V, remap_T=0):
     assert dlogp.is_contiguous() and logp.is_contiguous() and dlogits.stride(1) == 1
     check(lib.isc_logsoftmax_bwd(dlogp.data_ptr(), logp.data_ptr(), V, M, V, dlogits.data_ptr(),
                                  dlogits.stride(0), remap_T, stream()), 'isc_logsoftmax_bwd')
+
+
+def logsoftmax_bwd_sparse(dense, logp, sparse, dlogits, M, V, remap_T=0, scale=None):
+    """isc_logsoftmax_bwd_sparse: d logits from an optional dense d log-prob [M,V] plus up to two (ids [M] int64,
+    coef [M] fp32) pairs - one column per row each - times the optional device scalar `scale`."""
+    lib = _lib.load()
+    assert logp.is_contiguous() and dlogits.stride(1) == 1 and (dense is None or dense.is_contiguous())
+    n = len(sparse)
+    ids = (C.c_void_p * max(n, 1))(*[i.data_ptr() for i, _ in sparse])
+    cf = (C.c_void_p * max(n, 1))(*[c.data_ptr() for _, c in sparse])
+    for i, c in sparse:
+        assert i.dtype == torch.int64 and c.dtype == torch.float32 and i.is_contiguous() and c.is_contiguous()
+        assert i.numel() == M and c.numel() == M
+    check(lib.isc_logsoftmax_bwd_sparse(ptr(dense), logp.data_ptr(), V, M, V, ids, cf, n, ptr(scale),
+                                        dlogits.data_ptr(), dlogits.stride(0), remap_T, stream()),
+          'isc_logsoftmax_bwd_sparse')
+
+
+def grad_scale(sources, out2):
+    """isc_grad_scale: out2 = {S, 1/S}, S the power of two that brings max |x| over `sources` into [2^-4, 2^-3)."""
+    srcs = [x for x in sources if x is not None and x.numel() > 0]
+    for x in srcs:
+        assert x.dtype == torch.float32 and x.is_contiguous()
+    n = len(srcs)
+    pp = (C.c_void_p * max(n, 1))(*[x.data_ptr() for x in srcs])
+    nn_ = (C.c_int64 * max(n, 1))(*[x.numel() for x in srcs])
+    check(_lib.load().isc_grad_scale(pp, nn_, n, out2.data_ptr(), stream()), 'isc_grad_scale')
+
+
+def xe_loss_bwd_sparse(lengths_i32, T, gout, sum_count, coef):
+    B = lengths_i32.numel()
+    check(_lib.load().isc_xe_loss_bwd_sparse(lengths_i32.data_ptr(), B, T, gout.data_ptr(), sum_count.data_ptr(),
+                                             coef.data_ptr(), stream()), 'isc_xe_loss_bwd_sparse')
+
+
+def reward_loss_fwd(seq_logprobs, seq_masks, reward, out2):
+    B, T = seq_logprobs.shape
+    check(_lib.load().isc_reward_loss_fwd(seq_logprobs.data_ptr(), seq_masks.data_ptr(), reward.data_ptr(), B, T,
+                                          out2.data_ptr(), stream()), 'isc_reward_loss_fwd')
+
+
+def reward_loss_bwd(seq_masks, reward, gout, sum_count, dlogp):
+    B, T = seq_masks.shape
+    check(_lib.load().isc_reward_loss_bwd(seq_masks.data_ptr(), reward.data_ptr(), B, T, gout.data_ptr(),
+                                          sum_count.data_ptr(), dlogp.data_ptr(), stream()), 'isc_reward_loss_bwd')
 
 
 def lstm_bwd(dh, dh2, dc_next, gates, c_prev, c, dgates, dc_prev, dgates_sum=None):

@@ -20,13 +20,14 @@ _cider = None
 
 
 class RewardCriterion(nn.Module):
-    """Masked REINFORCE loss: -sum(logp * mask * reward) / sum(mask) over [B,T] tensors.
-    `seq_logprobs` comes from Captioner.forward_rl (differentiable when sampling in train mode);
-    the three [B,T] operands are tiny, so this stays elementwise tensor math on the device."""
+    """Masked REINFORCE loss: -sum(logp * mask * reward) / sum(mask) over [B,T] tensors (self_critical/utils.py:
+    169-177).  `seq_logprobs` comes from Captioner.forward_rl (differentiable when sampling in train mode).  One HIP
+    launch forward (isc_reward_loss_fwd: fixed-order sums, bit-repeatable) and one backward (isc_reward_loss_bwd) whose
+    [B,T] result reaches the roll-out's BPTT as (drawn token, weight) pairs - no [B,T,V] gradient tensor exists."""
 
     def forward(self, seq_logprobs, seq_masks, reward):
-        output = -seq_logprobs * seq_masks * reward
-        return output.sum() / seq_masks.sum()
+        from .autograd import reward_criterion
+        return reward_criterion(seq_logprobs, seq_masks, reward)
 
 
 def _load_cider():

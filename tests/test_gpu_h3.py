@@ -311,3 +311,74 @@ def test_sentiment_word_tables_match_per_caption_features():
     np.testing.assert_allclose(outs[True][2].numpy(), outs[False][2].numpy(), atol=1e-5)
     assert outs[True][3] == outs[False][3]
     np.testing.assert_allclose(np.asarray(outs[True][4]), np.asarray(outs[False][4]), atol=1e-4)
+
+
+def test_freed_captioners_planes_are_never_resumed_by_the_next_model():
+    """Round-2 advisor finding: the suspended weights scope is process-global per stream and was keyed only on
+    (data_ptr, version) of the parameters.  A checkpoint-evaluation loop frees one Captioner and builds the next with
+    the same shapes: the caching allocator hands back the same addresses with the same version counters, and the
+    second model would decode with the FIRST model's f16 planes.  The key now carries a per-instance nonce (renewed by
+    .to() and load_state_dict), and a freed instance's suspended scopes are forgotten."""
+    import gc
+    from insenticap_model_amd import Captioner, synth
+    V, st = 512, synth.DEFAULT_SETTINGS
+    d = synth.make_inputs(256, V, st, regions=8, seq_len=6, seed=3)
+    a = [torch.from_numpy(np.asarray(d[k])).to(dev()) for k in ('fc_feats', 'att_feats', 'cpt_words', 'senti_words',
+                                                                 'senti_labels')]
+
+    def decode(seed, mode):
+        ops.set_h3_mode(mode)
+        cap = Captioner(synth.make_idx2word(V), synth.SENTIMENT_CATEGORIES, st)
+        cap.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_weights(V, st, seed=seed).items()})
+        cap.to(dev()).eval()
+        with torch.no_grad():
+            seq, lp, _ = cap(*a, 6, 1, mode='rl')
+            seq2, lp2, _ = cap(*a, 6, 1, mode='rl')          # second call: resumes ITS OWN suspended scope
+        assert torch.equal(lp, lp2)
+        ptrs = sorted(q.data_ptr() for q in cap.parameters())
+        key = cap._weights_key()
+        out = (seq.cpu(), lp.cpu())
+        del cap
+        gc.collect()
+        return out, ptrs, key
+
+    (s1, l1), p1, k1 = decode(1, 2)
+    (s2, l2), p2, k2 = decode(2, 2)             # same shapes, other weights, (very likely) the same addresses
+    (s2x, l2x), _, _ = decode(2, 0)             # the exact-fp32 engine never uses planes
+    assert k1[0] != k2[0]                       # distinct nonces whatever the allocator did
+    assert not torch.equal(l1, l2)
+    np.testing.assert_allclose(l2.numpy(), l2x.numpy(), atol=2e-5)
+    if p1 == p2:                                # the hazard was real on this run: same storages, same versions
+        assert k1[1:] == k2[1:]
+    # load_state_dict and .to() renew the nonce of a live instance
+    cap = Captioner(synth.make_idx2word(V), synth.SENTIMENT_CATEGORIES, st)
+    n0 = cap._weights_key()[0]
+    cap.load_state_dict(cap.state_dict())
+    n1 = cap._weights_key()[0]
+    cap.to(dev())
+    assert len({n0, n1, cap._weights_key()[0]}) == 3
+
+
+def test_weights_scope_gives_its_depth_back_when_begin_fails():
+    """A scope whose isc_h3_weights_begin raises must not leave the stream's nesting depth at 1: every later scope on
+    the stream would otherwise be taken for a nested one and silently never open."""
+    import ctypes
+    from insenticap_model_amd import _lib
+    lib = _lib.load()
+    real = lib.isc_h3_weights_begin
+    key = (0, torch.cuda.current_stream(0).cuda_stream)
+    before = ops.h3_weights_scope._depth.get(key, 0)
+
+    class Boom:
+        def __call__(self, *a):
+            return -1                          # ISC_E_NULL
+    try:
+        lib.isc_h3_weights_begin = Boom()
+        with pytest.raises(_lib.HipLibraryError):
+            with ops.h3_weights_scope(dev()):
+                pass
+    finally:
+        lib.isc_h3_weights_begin = real
+    assert ops.h3_weights_scope._depth.get(key, 0) == before
+    with ops.h3_weights_scope(dev()) as sc:     # and the next scope opens normally
+        assert sc.opened
