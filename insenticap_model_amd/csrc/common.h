@@ -67,6 +67,29 @@ __device__ __forceinline__ void half_argmax(float &v, int &i) {
 #undef ISC_ARGMAX_STEP
 }
 
+// all-reduce over each 16-lane row of the wavefront (the lanes that share (lane >> 4): one output row of the 16x16 MFMA's
+// C/D layout): four DPP steps, no LDS crossbar
+__device__ __forceinline__ float row16_sum(float v) {
+    v += isc_dpp<ISC_DPP_XOR1>(v);
+    v += isc_dpp<ISC_DPP_XOR2>(v);
+    v += isc_dpp<ISC_DPP_HALF_MIRROR>(v);
+    return v + isc_dpp<ISC_DPP_MIRROR>(v);
+}
+// (value, index) arg-max over each 16-lane row; ties resolve to the smaller index
+__device__ __forceinline__ void row16_argmax(float &v, int &i) {
+#define ISC_ARGMAX_STEP(OV, OI)                                        \
+    {                                                                  \
+        const float ov = (OV);                                         \
+        const int oi = (OI);                                           \
+        if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }         \
+    }
+    ISC_ARGMAX_STEP(isc_dpp<ISC_DPP_XOR1>(v), isc_dpp<ISC_DPP_XOR1>(i))
+    ISC_ARGMAX_STEP(isc_dpp<ISC_DPP_XOR2>(v), isc_dpp<ISC_DPP_XOR2>(i))
+    ISC_ARGMAX_STEP(isc_dpp<ISC_DPP_HALF_MIRROR>(v), isc_dpp<ISC_DPP_HALF_MIRROR>(i))
+    ISC_ARGMAX_STEP(isc_dpp<ISC_DPP_MIRROR>(v), isc_dpp<ISC_DPP_MIRROR>(i))
+#undef ISC_ARGMAX_STEP
+}
+
 // 64-lane butterfly reductions (wavefront = 64 on CDNA4).
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

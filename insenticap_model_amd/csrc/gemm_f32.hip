@@ -1079,6 +1079,252 @@ __global__ __launch_bounds__(256) void gemm_ld_kernel(const DevLaunch L) {
     }
 }
 
+// ---- epilogues for the C/D layout of v_mfma_f32_16x16x32_f16 (the split-f16 tile kernels, round 3) ----------------
+// A wave's tile = 2 row blocks x NB column blocks of 16 x 16; acc[i][j] is an f32x4 whose element r on lane l is tile
+// row frow0 + 16 i + 4 (l >> 4) + r, tile column fcol0 + 16 j + (l & 15): a lane holds 8 rows x NB columns, and a row's
+// 16 NB columns sit on the 16 lanes of ONE DPP row - per-row reductions are four DPP steps, no swizzle.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Vocabulary statistics (max, arg-max, sum exp(x - max)) of the wave's 32 rows over its 16 NB columns (= the whole
+// 128-column tile: the kernels that use this have one wave across N), straight from the registers.
+template <int NB>
+__device__ __forceinline__ void epi_vocab_frag16(const DevProb &P, f32x4 (&acc)[2][NB], int frow0, int lane, int row0,
+                                                 int col0, int tn) {
+    const int M = P.M, N = P.N;
+    float bv[NB];
+    bool cok[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int gn = col0 + j * 16 + (lane & 15);
+        cok[j] = gn < N;
+        bv[j] = cok[j] ? P.bias0[gn] : 0.f;
+    }
+    float mx[8], sm[8];
+    int ix[8];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int e = i * 4 + r;
+            mx[e] = -INFINITY;
+            ix[e] = 0x7fffffff;
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                acc[i][j][r] = cok[j] ? acc[i][j][r] + bv[j] : -INFINITY;      // acc now holds the logits
+                const int gn = col0 + j * 16 + (lane & 15);
+                if (acc[i][j][r] > mx[e]) { mx[e] = acc[i][j][r]; ix[e] = gn; }   // j ascending => smaller column wins ties
+            }
+        }
+    if (P.C) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int gm = row0 + frow0 + i * 16 + 4 * (lane >> 4) + r;
+                if (gm < M) {
+                    float *crow = P.C + (long long)gm * P.ld_logits + col0 + (lane & 15);
+#pragma unroll
+                    for (int j = 0; j < NB; ++j)
+                        if (cok[j]) crow[j * 16] = acc[i][j][r];
+                }
+            }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) row16_argmax(mx[e], ix[e]);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int e = i * 4 + r;
+            sm[e] = 0.f;
+#pragma unroll
+            for (int j = 0; j < NB; ++j) sm[e] += cok[j] ? __expf(acc[i][j][r] - mx[e]) : 0.f;   // padded columns add 0
+        }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sm[e] = row16_sum(sm[e]);
+    if ((lane & 15) == 0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int gm = row0 + frow0 + (e >> 2) * 16 + 4 * (lane >> 4) + (e & 3);
+            if (gm < M) {
+                const long long o = (long long)gm * P.ntile_total + tn;
+                P.pmax[o] = mx[e];
+                P.psum[o] = sm[e];
+                P.pidx[o] = ix[e];
+            }
+        }
+    }
+}
+
+// LSTM cells from a 32 x 128 gate-interleaved tile.  The kernels stage W so that tile column t = 32 gate + 16 hf + l
+// holds (gate, unit 2 l + hf) of the tile's 32 units (h3_lstm_wrow): column block j = gate j >> 1, hf = j & 1, and lane l
+// owns all four gates of the ADJACENT units 2 (l & 15), 2 (l & 15) + 1 for its 8 rows.  Every global operand of the
+// epilogue (c_prev, the hoisted `pre` term, the embedding-table row, h / c out, the f16 planes of h) is then one
+// float2 per lane and 16 lanes x 8 B = a full 128-byte segment per row - with one unit per lane (64-byte segments,
+// twice the instructions) the att-LSTM's epilogue, which streams 16 KB per caption of `pre` and table rows, cost the
+// kernel 14 us at B = 4096.  All loads of a row batch are issued before any arithmetic (see lstm_cells).
+__device__ __forceinline__ int h3_lstm_wrow_in_gate(int t) { return 2 * (t & 15) + ((t >> 4) & 1); }
+
+__device__ __forceinline__ void epi_lstm_frag16(const DevProb &P, f32x4 (&acc)[2][8], int frow0, int lane, int row0,
+                                                int tn) {
+    const int H = P.H, u0 = tn * 32 + 2 * (lane & 15);
+    const bool has_b = P.bias0 != nullptr, has_pre = P.pre != nullptr, has_tab = P.tab != nullptr;
+    float2 b[4];
+    if (has_b) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float2 x = *reinterpret_cast<const float2 *>(P.bias0 + k * H + u0);
+            const float2 y = *reinterpret_cast<const float2 *>(P.bias1 + k * H + u0);
+            b[k] = make_float2(x.x + y.x, x.y + y.y);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {            // one row block = 4 rows per lane at a time (register budget)
+        int gm[4];
+        bool ok[4];
+        long long tok[4];
+        float2 cp[4], q[4][4], t[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            gm[r] = row0 + frow0 + i * 16 + 4 * (lane >> 4) + r;
+            ok[r] = gm[r] < P.M;
+        }
+        if (has_tab) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tok[r] = ok[r] ? P.tab_ids[(long long)gm[r] * P.tab_ids_stride] : 0;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            cp[r] = ok[r] ? *reinterpret_cast<const float2 *>(P.c_prev + (long long)gm[r] * H + u0) : make_float2(0.f, 0.f);
+        if (has_pre) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    q[r][k] = ok[r] ? *reinterpret_cast<const float2 *>(P.pre + (long long)gm[r] * 4 * H + k * H + u0)
+                                    : make_float2(0.f, 0.f);
+        }
+        if (has_tab) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    t[r][k] = ok[r] ? *reinterpret_cast<const float2 *>(P.tab + tok[r] * 4 * H + k * H + u0)
+                                    : make_float2(0.f, 0.f);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float h2[2], c2[2], ga[2][4];
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                float g[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    g[k] = acc[i][2 * k + hf][r];
+                    // g += (b_ih + b_hh);  g += pre;  g += table row   (same order in every kernel: lstm_cells)
+                    if (has_b) g[k] += hf ? b[k].y : b[k].x;
+                    if (has_pre) g[k] += hf ? q[r][k].y : q[r][k].x;
+                    if (has_tab) g[k] += hf ? t[r][k].y : t[r][k].x;
+                }
+                const float gi = isc_sigmoid(g[0]), gf = isc_sigmoid(g[1]), gg = isc_tanh(g[2]), go = isc_sigmoid(g[3]);
+                c2[hf] = gf * (hf ? cp[r].y : cp[r].x) + gi * gg;
+                h2[hf] = go * isc_tanh(c2[hf]);
+                ga[hf][0] = gi; ga[hf][1] = gf; ga[hf][2] = gg; ga[hf][3] = go;
+            }
+            if (ok[r]) {
+                const long long o = (long long)gm[r] * H + u0;
+                *reinterpret_cast<float2 *>(P.c_out + o) = make_float2(c2[0], c2[1]);
+                *reinterpret_cast<float2 *>(P.h_out + o) = make_float2(h2[0], h2[1]);
+                if (P.h_hi) {
+                    typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+                    const _Float16 a0 = (_Float16)h2[0], a1 = (_Float16)h2[1];
+                    const long long po = plane_index(gm[r], u0, H);          // u0 even: the pair stays in its 32-block
+                    h2v hi = {a0, a1};
+                    h2v lo = {(_Float16)((h2[0] - (float)a0) * 2048.f), (_Float16)((h2[1] - (float)a1) * 2048.f)};
+                    *reinterpret_cast<h2v *>(P.h_hi + po) = hi;
+                    *reinterpret_cast<h2v *>(P.h_lo + po) = lo;
+                }
+                if (P.hmask) {
+                    const uint8_t m0 = P.hmask[o], m1 = P.hmask[o + 1];
+                    *reinterpret_cast<float2 *>(P.hdrop + o) =
+                        make_float2(h2[0] * (float)m0 * P.mask_scale, h2[1] * (float)m1 * P.mask_scale);
+                }
+                if (P.gates_out) {
+                    float *go_ = P.gates_out + (long long)gm[r] * 4 * H + u0;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        *reinterpret_cast<float2 *>(go_ + k * H) = make_float2(ga[0][k], ga[1][k]);
+                }
+            }
+        }
+    }
+}
+
+// Linear epilogue (same feature set and template split as epi_linear_frag).
+template <int NB, bool EDGE, bool FEAT, bool RELU>
+__device__ __forceinline__ void epi_linear_frag16_impl(const DevProb &P, f32x4 (&acc)[2][NB], int frow0, int fcol0,
+                                                       int lane, int row0, int col0) {
+    const int M = P.M, N = P.N;
+    float b0[NB], b1[NB], b2[NB];
+    bool cok[NB];
+    const bool h0 = P.bias0 != nullptr, h1 = P.bias1 != nullptr, h2 = P.bias2 != nullptr;
+    const bool f_acc = FEAT && P.accumulate, f_pre = FEAT && P.C_pre != nullptr, f_mask = FEAT && P.mask != nullptr;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int gn = col0 + fcol0 + j * 16 + (lane & 15);
+        cok[j] = !EDGE || gn < N;
+        b0[j] = (h0 && cok[j]) ? P.bias0[gn] : 0.f;
+        b1[j] = (h1 && cok[j]) ? P.bias1[gn] : 0.f;
+        b2[j] = (h2 && cok[j]) ? P.bias2[gn] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int gm = row0 + frow0 + i * 16 + 4 * (lane >> 4) + r;
+            if (EDGE && gm >= M) continue;
+            float *crow = P.C + (long long)gm * P.ldc + col0 + fcol0 + (lane & 15);
+            float prev[NB];
+            if (f_acc) {                                   // all loads of the row before any arithmetic
+#pragma unroll
+                for (int j = 0; j < NB; ++j) prev[j] = (!EDGE || cok[j]) ? crow[j * 16] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                if (EDGE && !cok[j]) continue;
+                float o = acc[i][j][r];
+                if (h0) o += b0[j];
+                if (h1) o += b1[j];
+                if (h2) o += b2[j];
+                if (f_acc) o += prev[j];
+                if (RELU) o = fmaxf(o, 0.f);
+                if constexpr (FEAT) {
+                    const int gn = col0 + fcol0 + j * 16 + (lane & 15);
+                    if (f_pre) P.C_pre[(long long)gm * P.ldc + gn] = o;
+                    if (f_mask) o = o * (float)P.mask[(long long)gm * N + gn] * P.mask_scale;
+                }
+                crow[j * 16] = o;
+            }
+        }
+}
+
+template <int NB>
+__device__ __forceinline__ void epi_linear_frag16(const DevProb &P, f32x4 (&acc)[2][NB], int frow0, int fcol0, int lane,
+                                                  int row0, int col0) {
+    const bool feat = P.accumulate || P.C_pre || P.mask;
+    const bool edge = !(row0 + frow0 + 32 <= P.M && col0 + fcol0 + 16 * NB <= P.N);
+    const bool relu = P.relu != 0;
+#define ISC_EPI_CASE(E, F, R) epi_linear_frag16_impl<NB, E, F, R>(P, acc, frow0, fcol0, lane, row0, col0)
+    if (edge) {
+        if (relu) ISC_EPI_CASE(true, true, true); else ISC_EPI_CASE(true, true, false);
+    } else if (feat) {
+        if (relu) ISC_EPI_CASE(false, true, true); else ISC_EPI_CASE(false, true, false);
+    } else {
+        if (relu) ISC_EPI_CASE(false, false, true); else ISC_EPI_CASE(false, false, false);
+    }
+#undef ISC_EPI_CASE
+}
+
 // ---------------------------------------------------------------- H3 tile: 128 x 128 on the f16 matrix cores
 // fp32 operands, fp32 results, f16 MFMA rate.  Every operand value is split once into two f16 planes,
 //     x = hi + lo * 2^-11,   hi = f16(x),   lo = f16((x - hi) * 2^11)
@@ -1149,7 +1395,7 @@ __global__ __launch_bounds__(256, 2) void gemm_h3_kernel(const DevLaunch L) {
         aq[i] = q * 8;
         long long wr;
         if (EPI == EPI_LSTM) {
-            wr = (long long)(t >> 5) * P.H + tn * 32 + (t & 31);
+            wr = (long long)(t >> 5) * P.H + tn * 32 + h3_lstm_wrow_in_gate(t);     // (gate, unit): see epi_lstm_frag16
         } else {
             const int c = col0 + t;
             wr = c < N ? c : N - 1;
@@ -1189,70 +1435,113 @@ __global__ __launch_bounds__(256, 2) void gemm_h3_kernel(const DevLaunch L) {
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
 
-    f32x16 acc0[TN], acc1[TN];
+    // v_mfma_f32_16x16x32_f16 (round 3; the 32x32x16 form of rounds 1-2 ran 7-16 % slower on the same tile, staging and
+    // LDS image - tools/h3_mfma16_lab.hip): the wave's 32 x 16 NB tile = 2 row blocks x NB column blocks, ONE MFMA per
+    // block, product term and 32-k chunk.  Fragment of lane l: row (l & 15) of the block, k-octet (l >> 4) = 16-byte
+    // chunk (l >> 4) of the row image's hi half, chunk 4 + (l >> 4) of its lo half (positions XOR-swizzled as staged).
+    constexpr int NB = 2 * TN, NQ = NB / 2;             // NQ groups of two column blocks per chunk
+    f32x4 acc0[2][NB], acc1[2][NB];
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { acc0[j][r] = 0.f; acc1[j][r] = 0.f; }
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { acc0[i][j][r] = 0.f; acc1[i][j][r] = 0.f; }
 
-    const int fr = lane & 31, fh = lane >> 5, fsw = (fr >> 1) & 7;
-    h8 a1[2], a2[2], b1[2][TN], b2[2][TN];
-    auto lfrag = [&](int buf, auto ksc, auto setc) __attribute__((always_inline)) {
-        constexpr int kk = decltype(ksc)::value, S = decltype(setc)::value;
-        const int ph = ((2 * kk + fh) ^ fsw) * 16, pl = ((4 + 2 * kk + fh) ^ fsw) * 16;
+    const int fr = lane & 15, fq = lane >> 4, fsw = (fr >> 1) & 7;
+    const int ph = (fq ^ fsw) * 16, pl = ((4 + fq) ^ fsw) * 16;
+    h8 ah[2][2], al[2][2], bh[2][2], bl[2][2];          // A: [set][row block]; W: [slot][column block of the group]
+    auto lfragA = [&](int buf, auto setc) __attribute__((always_inline)) {
+        constexpr int S = decltype(setc)::value;
         const char *base = lds + buf * ST;
-        const int ra = (wm * 32 + fr) * 128;
-        if (AF32 && ((f32_bufs >> buf) & 1u)) {
-            h3_frag_from_f32(base + ra, 2 * kk + fh, fsw, a1[S], a2[S]);
-        } else {
-            a1[S] = *reinterpret_cast<const h8 *>(base + ra + ph);
-            a2[S] = *reinterpret_cast<const h8 *>(base + ra + pl);
-        }
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int rb = PA + (j * 32 + fr) * 128;
-            b1[S][j] = *reinterpret_cast<const h8 *>(base + rb + ph);
-            b2[S][j] = *reinterpret_cast<const h8 *>(base + rb + pl);
+        for (int i = 0; i < 2; ++i) {
+            const int ra = (wm * 32 + i * 16 + fr) * 128;
+            if (AF32 && ((f32_bufs >> buf) & 1u)) {
+                h3_frag_from_f32(base + ra, fq, fsw, ah[S][i], al[S][i]);
+            } else {
+                ah[S][i] = *reinterpret_cast<const h8 *>(base + ra + ph);
+                al[S][i] = *reinterpret_cast<const h8 *>(base + ra + pl);
+            }
         }
     };
-    auto mma = [&](auto setc) __attribute__((always_inline)) {
-        constexpr int S = decltype(setc)::value;
+    auto lfragB = [&](int buf, auto grpc, auto slotc) __attribute__((always_inline)) {
+        constexpr int Q = decltype(grpc)::value, SL = decltype(slotc)::value;
+        const char *base = lds + buf * ST + PA;
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            acc0[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[S], b1[S][j], acc0[j], 0, 0, 0);
-            acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[S], b2[S][j], acc1[j], 0, 0, 0);
-            acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2[S], b1[S][j], acc1[j], 0, 0, 0);
+        for (int j = 0; j < 2; ++j) {
+            const int rb = ((Q * 2 + j) * 16 + fr) * 128;
+            bh[SL][j] = *reinterpret_cast<const h8 *>(base + rb + ph);
+            bl[SL][j] = *reinterpret_cast<const h8 *>(base + rb + pl);
+        }
+    };
+    auto mma = [&](auto setc, auto grpc, auto slotc) __attribute__((always_inline)) {
+        constexpr int S = decltype(setc)::value, Q = decltype(grpc)::value, SL = decltype(slotc)::value;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                acc0[i][Q * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[S][i], bh[SL][j], acc0[i][Q * 2 + j], 0, 0, 0);
+                acc1[i][Q * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[S][i], bl[SL][j], acc1[i][Q * 2 + j], 0, 0, 0);
+                acc1[i][Q * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[S][i], bh[SL][j], acc1[i][Q * 2 + j], 0, 0, 0);
+            }
+    };
+    // one chunk's MFMAs with the W fragments of group q + 1 read under the MFMAs of group q; `between` runs in front of
+    // the last group (the barrier, then the next chunk's A fragments into the other A set and its group-0 W fragments)
+    using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>;
+    auto chunk_mma = [&](int cur, auto setc, auto between) __attribute__((always_inline)) {
+        if constexpr (NQ == 4) {
+            lfragB(cur, I1{}, I1{}); mma(setc, I0{}, I0{});
+            lfragB(cur, I2{}, I0{}); mma(setc, I1{}, I1{});
+            lfragB(cur, I3{}, I1{}); mma(setc, I2{}, I0{});
+            between();
+            mma(setc, I3{}, I1{});
+        } else {
+            static_assert(NQ == 2, "two or four groups of column blocks per chunk");
+            lfragB(cur, I1{}, I1{}); mma(setc, I0{}, I0{});
+            between();
+            mma(setc, I1{}, I1{});
         }
     };
     const int nchunks = Kp / 32;
     stage(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    lfrag(0, I0{}, I0{});
-    for (int c = 0; c < nchunks; ++c) {
+    lfragA(0, I0{});
+    lfragB(0, I0{}, I0{});
+    // per chunk: the second half's W fragments are read under the first half's MFMAs, the next chunk's A fragments
+    // (into the other A set) and first-half W fragments under the second half's
+    auto chunk = [&](int c, auto setc, auto nsetc) __attribute__((always_inline)) {
         const int cur = c & 1, nxt = cur ^ 1;
         const bool has1 = c + 1 < nchunks;
         if (has1) stage(nxt);                 // buffer nxt was last read in front of the previous barrier
-        lfrag(cur, I1{}, I1{});
-        mma(I0{});
-        if (has1) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            lfrag(nxt, I0{}, I0{});
-        }
-        mma(I1{});
+        chunk_mma(cur, setc, [&]() __attribute__((always_inline)) {
+            if (has1) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                lfragA(nxt, nsetc);
+                lfragB(nxt, I0{}, I0{});
+            }
+        });
+    };
+    for (int c = 0; c < nchunks; c += 2) {
+        chunk(c, I0{}, I1{});
+        if (c + 1 < nchunks) chunk(c + 1, I1{}, I0{});
     }
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc0[j][r] = fmaf(acc1[j][r], 1.f / 2048.f, acc0[j][r]);
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc0[i][j][r] = fmaf(acc1[i][j][r], 1.f / 2048.f, acc0[i][j][r]);
 
     if constexpr (EPI == EPI_VOCAB) {
-        epi_vocab_frag<TN, 1, BM>(P, acc0, wm * 32, 0, 0, lane, row0, col0, tn, smem);
+        epi_vocab_frag16<NB>(P, acc0, wm * 32, lane, row0, col0, tn);
     } else if constexpr (EPI == EPI_LSTM) {
-        epi_lstm_frag(P, acc0, wm * 32, lane, row0, tn);
+        epi_lstm_frag16(P, acc0, wm * 32, lane, row0, tn);
     } else {
-        epi_linear_frag<4>(P, acc0, wm * 32, 0, lane, row0, col0);
+        epi_linear_frag16<NB>(P, acc0, wm * 32, 0, lane, row0, col0);
     }
 }
 
@@ -1294,7 +1583,7 @@ __global__ __launch_bounds__(512) void gemm_h3x_kernel(const DevLaunch L) {
         const int q = (lane & 7) ^ ((t >> 1) & 7);
         long long wr;
         if (EPI == EPI_LSTM) {
-            wr = (long long)(t >> 5) * P.H + tn * 32 + (t & 31);
+            wr = (long long)(t >> 5) * P.H + tn * 32 + h3_lstm_wrow_in_gate(t);     // (gate, unit): see epi_lstm_frag16
         } else {
             const int c = col0 + t;
             wr = c < N ? c : N - 1;
@@ -1336,39 +1625,73 @@ __global__ __launch_bounds__(512) void gemm_h3x_kernel(const DevLaunch L) {
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
 
-    f32x16 acc0[TN], acc1[TN];
+    // v_mfma_f32_16x16x32_f16 (round 3; the 32x32x16 form of rounds 1-2 ran 7-16 % slower on the same tile, staging and
+    // LDS image - tools/h3_mfma16_lab.hip): the wave's 32 x 16 NB tile = 2 row blocks x NB column blocks, ONE MFMA per
+    // block, product term and 32-k chunk.  Fragment of lane l: row (l & 15) of the block, k-octet (l >> 4) = 16-byte
+    // chunk (l >> 4) of the row image's hi half, chunk 4 + (l >> 4) of its lo half (positions XOR-swizzled as staged).
+    constexpr int NB = 2 * TN, NQ = NB / 2;             // NQ groups of two column blocks per chunk
+    f32x4 acc0[2][NB], acc1[2][NB];
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { acc0[j][r] = 0.f; acc1[j][r] = 0.f; }
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { acc0[i][j][r] = 0.f; acc1[i][j][r] = 0.f; }
 
-    const int fr = lane & 31, fh = lane >> 5, fsw = (fr >> 1) & 7;
-    h8 a1[2], a2[2], b1[2][TN], b2[2][TN];
-    auto lfrag = [&](int buf, auto ksc, auto setc) __attribute__((always_inline)) {
-        constexpr int kk = decltype(ksc)::value, S = decltype(setc)::value;
-        const int ph = ((2 * kk + fh) ^ fsw) * 16, pl = ((4 + 2 * kk + fh) ^ fsw) * 16;
+    const int fr = lane & 15, fq = lane >> 4, fsw = (fr >> 1) & 7;
+    const int ph = (fq ^ fsw) * 16, pl = ((4 + fq) ^ fsw) * 16;
+    h8 ah[2][2], al[2][2], bh[2][2], bl[2][2];          // A: [set][row block]; W: [slot][column block of the group]
+    auto lfragA = [&](int buf, auto setc) __attribute__((always_inline)) {
+        constexpr int S = decltype(setc)::value;
         const char *base = lds + buf * ST;
-        const int ra = (wm * 32 + fr) * 128;
-        if (AF32 && ((f32_bufs >> buf) & 1u)) {
-            h3_frag_from_f32(base + ra, 2 * kk + fh, fsw, a1[S], a2[S]);
-        } else {
-            a1[S] = *reinterpret_cast<const h8 *>(base + ra + ph);
-            a2[S] = *reinterpret_cast<const h8 *>(base + ra + pl);
-        }
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int rb = PA + (j * 32 + fr) * 128;
-            b1[S][j] = *reinterpret_cast<const h8 *>(base + rb + ph);
-            b2[S][j] = *reinterpret_cast<const h8 *>(base + rb + pl);
+        for (int i = 0; i < 2; ++i) {
+            const int ra = (wm * 32 + i * 16 + fr) * 128;
+            if (AF32 && ((f32_bufs >> buf) & 1u)) {
+                h3_frag_from_f32(base + ra, fq, fsw, ah[S][i], al[S][i]);
+            } else {
+                ah[S][i] = *reinterpret_cast<const h8 *>(base + ra + ph);
+                al[S][i] = *reinterpret_cast<const h8 *>(base + ra + pl);
+            }
         }
     };
-    auto mma = [&](auto setc) __attribute__((always_inline)) {
-        constexpr int S = decltype(setc)::value;
+    auto lfragB = [&](int buf, auto grpc, auto slotc) __attribute__((always_inline)) {
+        constexpr int Q = decltype(grpc)::value, SL = decltype(slotc)::value;
+        const char *base = lds + buf * ST + PA;
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            acc0[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[S], b1[S][j], acc0[j], 0, 0, 0);
-            acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[S], b2[S][j], acc1[j], 0, 0, 0);
-            acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2[S], b1[S][j], acc1[j], 0, 0, 0);
+        for (int j = 0; j < 2; ++j) {
+            const int rb = ((Q * 2 + j) * 16 + fr) * 128;
+            bh[SL][j] = *reinterpret_cast<const h8 *>(base + rb + ph);
+            bl[SL][j] = *reinterpret_cast<const h8 *>(base + rb + pl);
+        }
+    };
+    auto mma = [&](auto setc, auto grpc, auto slotc) __attribute__((always_inline)) {
+        constexpr int S = decltype(setc)::value, Q = decltype(grpc)::value, SL = decltype(slotc)::value;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                acc0[i][Q * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[S][i], bh[SL][j], acc0[i][Q * 2 + j], 0, 0, 0);
+                acc1[i][Q * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[S][i], bl[SL][j], acc1[i][Q * 2 + j], 0, 0, 0);
+                acc1[i][Q * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[S][i], bh[SL][j], acc1[i][Q * 2 + j], 0, 0, 0);
+            }
+    };
+    // one chunk's MFMAs with the W fragments of group q + 1 read under the MFMAs of group q; `between` runs in front of
+    // the last group (the barrier, then the next chunk's A fragments into the other A set and its group-0 W fragments)
+    using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>;
+    auto chunk_mma = [&](int cur, auto setc, auto between) __attribute__((always_inline)) {
+        if constexpr (NQ == 4) {
+            lfragB(cur, I1{}, I1{}); mma(setc, I0{}, I0{});
+            lfragB(cur, I2{}, I0{}); mma(setc, I1{}, I1{});
+            lfragB(cur, I3{}, I1{}); mma(setc, I2{}, I0{});
+            between();
+            mma(setc, I3{}, I1{});
+        } else {
+            static_assert(NQ == 2, "two or four groups of column blocks per chunk");
+            lfragB(cur, I1{}, I1{}); mma(setc, I0{}, I0{});
+            between();
+            mma(setc, I1{}, I1{});
         }
     };
     // three buffers, two chunks in flight (6 DMAs per wave and chunk): vmcnt(6) leaves the younger chunk outstanding
@@ -1378,33 +1701,40 @@ __global__ __launch_bounds__(512) void gemm_h3x_kernel(const DevLaunch L) {
     if (nchunks > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    lfrag(0, I0{}, I0{});
+    lfragA(0, I0{});
+    lfragB(0, I0{}, I0{});
     int cur = 0;
-    for (int c = 0; c < nchunks; ++c) {
+    auto chunk = [&](int c, auto setc, auto nsetc) __attribute__((always_inline)) {
         const int nxt = cur == 2 ? 0 : cur + 1, nn = nxt == 2 ? 0 : nxt + 1;
         if (c + 2 < nchunks) stage(nn);           // buffer nn was last read in front of the previous barrier
-        lfrag(cur, I1{}, I1{});
-        mma(I0{});
-        if (c + 1 < nchunks) {
-            if (c + 2 < nchunks) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            lfrag(nxt, I0{}, I0{});
-        }
-        mma(I1{});
+        chunk_mma(cur, setc, [&]() __attribute__((always_inline)) {
+            if (c + 1 < nchunks) {
+                if (c + 2 < nchunks) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                lfragA(nxt, nsetc);
+                lfragB(nxt, I0{}, I0{});
+            }
+        });
         cur = nxt;
+    };
+    for (int c = 0; c < nchunks; c += 2) {
+        chunk(c, I0{}, I1{});
+        if (c + 1 < nchunks) chunk(c + 1, I1{}, I0{});
     }
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc0[j][r] = fmaf(acc1[j][r], 1.f / 2048.f, acc0[j][r]);
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc0[i][j][r] = fmaf(acc1[i][j][r], 1.f / 2048.f, acc0[i][j][r]);
 
     if constexpr (EPI == EPI_VOCAB) {
-        epi_vocab_frag<TN, 1, BM>(P, acc0, wm * 32, 0, 0, lane, row0, col0, tn, smem);
+        epi_vocab_frag16<NB>(P, acc0, wm * 32, lane, row0, col0, tn);
     } else if constexpr (EPI == EPI_LSTM) {
-        epi_lstm_frag(P, acc0, wm * 32, lane, row0, tn);
+        epi_lstm_frag16(P, acc0, wm * 32, lane, row0, tn);
     } else {
-        epi_linear_frag<4>(P, acc0, wm * 32, 0, lane, row0, col0);
+        epi_linear_frag16<NB>(P, acc0, wm * 32, 0, lane, row0, col0);
     }
 }
 
@@ -1482,39 +1812,73 @@ __global__ __launch_bounds__(256) void gemm_h3m_kernel(const DevLaunch L) {
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
 
-    f32x16 acc0[TN], acc1[TN];
+    // v_mfma_f32_16x16x32_f16 (round 3; the 32x32x16 form of rounds 1-2 ran 7-16 % slower on the same tile, staging and
+    // LDS image - tools/h3_mfma16_lab.hip): the wave's 32 x 16 NB tile = 2 row blocks x NB column blocks, ONE MFMA per
+    // block, product term and 32-k chunk.  Fragment of lane l: row (l & 15) of the block, k-octet (l >> 4) = 16-byte
+    // chunk (l >> 4) of the row image's hi half, chunk 4 + (l >> 4) of its lo half (positions XOR-swizzled as staged).
+    constexpr int NB = 2 * TN, NQ = NB / 2;             // NQ groups of two column blocks per chunk
+    f32x4 acc0[2][NB], acc1[2][NB];
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { acc0[j][r] = 0.f; acc1[j][r] = 0.f; }
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { acc0[i][j][r] = 0.f; acc1[i][j][r] = 0.f; }
 
-    const int fr = lane & 31, fh = lane >> 5, fsw = (fr >> 1) & 7;
-    h8 a1[2], a2[2], b1[2][TN], b2[2][TN];
-    auto lfrag = [&](int buf, auto ksc, auto setc) __attribute__((always_inline)) {
-        constexpr int kk = decltype(ksc)::value, S = decltype(setc)::value;
-        const int ph = ((2 * kk + fh) ^ fsw) * 16, pl = ((4 + 2 * kk + fh) ^ fsw) * 16;
+    const int fr = lane & 15, fq = lane >> 4, fsw = (fr >> 1) & 7;
+    const int ph = (fq ^ fsw) * 16, pl = ((4 + fq) ^ fsw) * 16;
+    h8 ah[2][2], al[2][2], bh[2][2], bl[2][2];          // A: [set][row block]; W: [slot][column block of the group]
+    auto lfragA = [&](int buf, auto setc) __attribute__((always_inline)) {
+        constexpr int S = decltype(setc)::value;
         const char *base = lds + buf * ST;
-        const int ra = (wm * 32 + fr) * 128;
-        if (AF32 && ((f32_bufs >> buf) & 1u)) {
-            h3_frag_from_f32(base + ra, 2 * kk + fh, fsw, a1[S], a2[S]);
-        } else {
-            a1[S] = *reinterpret_cast<const h8 *>(base + ra + ph);
-            a2[S] = *reinterpret_cast<const h8 *>(base + ra + pl);
-        }
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int rb = PA + (wn * 64 + j * 32 + fr) * 128;
-            b1[S][j] = *reinterpret_cast<const h8 *>(base + rb + ph);
-            b2[S][j] = *reinterpret_cast<const h8 *>(base + rb + pl);
+        for (int i = 0; i < 2; ++i) {
+            const int ra = (wm * 32 + i * 16 + fr) * 128;
+            if (AF32 && ((f32_bufs >> buf) & 1u)) {
+                h3_frag_from_f32(base + ra, fq, fsw, ah[S][i], al[S][i]);
+            } else {
+                ah[S][i] = *reinterpret_cast<const h8 *>(base + ra + ph);
+                al[S][i] = *reinterpret_cast<const h8 *>(base + ra + pl);
+            }
         }
     };
-    auto mma = [&](auto setc) __attribute__((always_inline)) {
-        constexpr int S = decltype(setc)::value;
+    auto lfragB = [&](int buf, auto grpc, auto slotc) __attribute__((always_inline)) {
+        constexpr int Q = decltype(grpc)::value, SL = decltype(slotc)::value;
+        const char *base = lds + buf * ST + PA;
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            acc0[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[S], b1[S][j], acc0[j], 0, 0, 0);
-            acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[S], b2[S][j], acc1[j], 0, 0, 0);
-            acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2[S], b1[S][j], acc1[j], 0, 0, 0);
+        for (int j = 0; j < 2; ++j) {
+            const int rb = (wn * 64 + (Q * 2 + j) * 16 + fr) * 128;
+            bh[SL][j] = *reinterpret_cast<const h8 *>(base + rb + ph);
+            bl[SL][j] = *reinterpret_cast<const h8 *>(base + rb + pl);
+        }
+    };
+    auto mma = [&](auto setc, auto grpc, auto slotc) __attribute__((always_inline)) {
+        constexpr int S = decltype(setc)::value, Q = decltype(grpc)::value, SL = decltype(slotc)::value;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                acc0[i][Q * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[S][i], bh[SL][j], acc0[i][Q * 2 + j], 0, 0, 0);
+                acc1[i][Q * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[S][i], bl[SL][j], acc1[i][Q * 2 + j], 0, 0, 0);
+                acc1[i][Q * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[S][i], bh[SL][j], acc1[i][Q * 2 + j], 0, 0, 0);
+            }
+    };
+    // one chunk's MFMAs with the W fragments of group q + 1 read under the MFMAs of group q; `between` runs in front of
+    // the last group (the barrier, then the next chunk's A fragments into the other A set and its group-0 W fragments)
+    using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>;
+    auto chunk_mma = [&](int cur, auto setc, auto between) __attribute__((always_inline)) {
+        if constexpr (NQ == 4) {
+            lfragB(cur, I1{}, I1{}); mma(setc, I0{}, I0{});
+            lfragB(cur, I2{}, I0{}); mma(setc, I1{}, I1{});
+            lfragB(cur, I3{}, I1{}); mma(setc, I2{}, I0{});
+            between();
+            mma(setc, I3{}, I1{});
+        } else {
+            static_assert(NQ == 2, "two or four groups of column blocks per chunk");
+            lfragB(cur, I1{}, I1{}); mma(setc, I0{}, I0{});
+            between();
+            mma(setc, I1{}, I1{});
         }
     };
     // four buffers, three chunks in flight: these launches run one workgroup per CU, so the DMA round trip
@@ -1530,25 +1894,32 @@ __global__ __launch_bounds__(256) void gemm_h3m_kernel(const DevLaunch L) {
     if (nchunks > 2) stage(2);
     wait_for((nchunks < 3 ? nchunks : 3) - 1);
     __syncthreads();
-    lfrag(0, I0{}, I0{});
-    for (int c = 0; c < nchunks; ++c) {
+    lfragA(0, I0{});
+    lfragB(0, I0{}, I0{});
+    auto chunk = [&](int c, auto setc, auto nsetc) __attribute__((always_inline)) {
         const int cur = c & 3, nxt = (c + 1) & 3;
         if (c + 3 < nchunks) stage((c + 3) & 3);      // that buffer was last read in front of the previous barrier
-        lfrag(cur, I1{}, I1{});
-        mma(I0{});
-        if (c + 1 < nchunks) {
-            const int last = nchunks - 1 < c + 3 ? nchunks - 1 : c + 3;
-            wait_for(last - (c + 1));
-            __syncthreads();
-            lfrag(nxt, I0{}, I0{});
-        }
-        mma(I1{});
+        chunk_mma(cur, setc, [&]() __attribute__((always_inline)) {
+            if (c + 1 < nchunks) {
+                const int last = nchunks - 1 < c + 3 ? nchunks - 1 : c + 3;
+                wait_for(last - (c + 1));
+                __syncthreads();
+                lfragA(nxt, nsetc);
+                lfragB(nxt, I0{}, I0{});
+            }
+        });
+    };
+    for (int c = 0; c < nchunks; c += 2) {
+        chunk(c, I0{}, I1{});
+        if (c + 1 < nchunks) chunk(c + 1, I1{}, I0{});
     }
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc0[j][r] = fmaf(acc1[j][r], 1.f / 2048.f, acc0[j][r]);
-    epi_linear_frag<TN>(P, acc0, wm * 32, wn * 64, lane, row0, col0);
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc0[i][j][r] = fmaf(acc1[i][j][r], 1.f / 2048.f, acc0[i][j][r]);
+    epi_linear_frag16<NB>(P, acc0, wm * 32, wn * 64, lane, row0, col0);
 }
 
 // Operand split in front of gemm_h3_kernel: gathers the K-segments of one operand into the two packed f16 planes

@@ -473,6 +473,84 @@ def case_detector():
     print('detector: %d arrays' % len(out))
 
 
+def case_det_train():
+    """Detector.forward(data, 'fact', training=True) (models/decoder.py:52-180 incl. the update at :161-167) on tiny
+    dims with dropout_p = 0: two iterations (two fact batches, one seq2seq batch served twice).  Every stochastic draw
+    is recorded so the build can replay it: the raw multinomial draws of each sampled roll-out, and the tokens the XE
+    (ss_prob 0.5) and seq2seq (ss_prob 0.25) unrolls actually fed under scheduled sampling.  Stored: the 7-key loss
+    dictionary, every captioner parameter after the two clamp + Adam steps, and the (clamped) gradient of iteration 2."""
+    from models.decoder import Detector
+    V, Tn, B = 64, 8, 4
+    st = dict(synth.TINY_SETTINGS, **synth.HELPER_SETTINGS)
+    st['dropout_p'] = 0.0
+    idx2word = synth.make_idx2word(V)
+    det = Detector(idx2word, Tn, synth.SENTIMENT_CATEGORIES, {'cap_lr': 4e-4}, st)
+    det.captioner.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_weights(V, st, seed=1).items()})
+    for name, mod, seed in (('senti_detector', det.senti_detector, 51), ('sent_senti_cls', det.sent_senti_cls, 52)):
+        shapes = {k: tuple(v.shape) for k, v in mod.state_dict().items()}
+        mod.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_module_weights(shapes, seed).items()})
+    batches, split = synth.make_rl_batches(2, B, V, st, seq_len=Tn)
+    det.set_ciderd_scorer(split)
+    tens = lambda b: (b[0], torch.from_numpy(b[1]), torch.from_numpy(b[2]), (torch.from_numpy(b[3][0]), b[3][1]),
+                      torch.from_numpy(b[4]), torch.from_numpy(b[5]), b[6])
+    s = synth.make_inputs(3, V, st, regions=6, seq_len=Tn, seed=77)
+    t = torch.from_numpy
+    scs = [((t(s['captions']), s['lengths']), t(s['cpt_words']), t(s['senti_words']), t(s['senti_labels']))]
+    cap = det.captioner
+    ms, spy = MultinomialSpy(), StepSpy(cap)
+    rl_bounds, xe_bounds, s2s_bounds = [], [], []
+    o_rl, o_xe, o_s2s = cap.forward_rl, cap.forward_xe, cap.forward_seq2seq
+
+    def spy_rl(*a, **k):
+        n0 = len(ms.draws)
+        r = o_rl(*a, **k)
+        if not k.get('sample_max', a[-1] if len(a) >= 7 else 1):
+            rl_bounds.append((n0, len(ms.draws)))
+        return r
+
+    def spy_xe(*a, **k):
+        n0 = len(spy.fed)
+        r = o_xe(*a, **k)
+        xe_bounds.append((n0, len(spy.fed)))
+        return r
+
+    def spy_s2s(*a, **k):
+        n0 = len(spy.fed)
+        r = o_s2s(*a, **k)
+        s2s_bounds.append((n0, len(spy.fed)))
+        return r
+    cap.forward_rl, cap.forward_xe, cap.forward_seq2seq = spy_rl, spy_xe, spy_s2s
+    torch.manual_seed(4242)
+    losses = det(([tens(b) for b in batches], scs), 'fact', True)
+    ms.close()
+    spy.close()
+    cap.forward_rl, cap.forward_xe, cap.forward_seq2seq = o_rl, o_xe, o_s2s
+    assert len(rl_bounds) == len(xe_bounds) == len(s2s_bounds) == 2, (rl_bounds, xe_bounds, s2s_bounds)
+    out = {}
+    sampled = 0
+    for i in range(2):
+        a, b = rl_bounds[i]
+        dr = torch.stack(ms.draws[a:b], dim=1).numpy()
+        out['dt/draws%d' % i] = np.pad(dr, ((0, 0), (0, Tn - dr.shape[1])))
+        out['dt/steps%d' % i] = np.array([dr.shape[1]])
+        for name, (a, b), src in (('xe', xe_bounds[i], batches[i][3][0]), ('s2s', s2s_bounds[i], s['captions'])):
+            fed = torch.stack(spy.fed[a:b], dim=1).numpy()
+            out['dt/fed_%s%d' % (name, i)] = fed
+            sampled += int((fed != np.asarray(src)[:, :fed.shape[1]]).sum())
+    assert sampled > 0, 'scheduled sampling never replaced a token'
+    for k, v in losses.items():
+        out['dt/loss_' + k] = np.array([v], dtype=np.float64)
+    assert set(losses) == {'da_loss', 'fact_reward', 'cls_reward', 'all_rewards', 'cap_loss', 'xe_loss', 'seq2seq_loss'}
+    for k, v in cap.state_dict().items():
+        out['dt/after/' + k] = v.detach().numpy().copy()
+    for k, q in cap.named_parameters():          # what .grad holds after the call: iteration 2's gradient, clamped
+        if q.grad is not None:
+            out['dt/grad2/' + k] = q.grad.detach().numpy().copy()
+    print({k: round(v, 5) for k, v in losses.items()}, 'tokens replaced by scheduled sampling:', sampled)
+    np.savez_compressed(os.path.join(HERE, 'det_train.npz'), **out)
+    print('det_train: %d arrays' % len(out))
+
+
 def case_checkpoint():
     """A checkpoint file exactly as train_xe.py:241-254 writes it (tiny model, after one training step with
     the reference's Adam), plus the parameters the reference reaches after a SECOND step from that state:
@@ -687,7 +765,7 @@ def case_collate():
 
 CASES = {'tiny': case_tiny, 'cfg1': case_cfg1, 'b128': case_b128, 'cider': case_cider, 'detector': case_detector,
          'checkpoint': case_checkpoint, 'beam64': case_beam64, 'det512': case_det512,
-         'collate': case_collate}
+         'collate': case_collate, 'det_train': case_det_train}
 
 if __name__ == '__main__':
     which = sys.argv[1:] or list(CASES)

@@ -129,3 +129,76 @@ def test_detector_training_iteration_runs():
     for k, v in det.sent_senti_cls.state_dict().items():      # helper nets stay frozen
         assert torch.equal(v, helper_before[k])
     assert not det.sent_senti_cls.training and not det.senti_detector.training
+
+
+@pytest.mark.gpu
+def test_detector_training_iterations_match_the_reference(golden):
+    """Detector.forward(data, 'fact', training=True) - the RL training iteration of train_rl.py (models/decoder.py:
+    52-180: sampled roll-out with REINFORCE gradients, greedy baseline, CIDEr-D + classifier rewards, XE with ss_prob
+    0.5, seq2seq with ss_prob 0.25, backward, clamp, Adam) - two iterations against the reference's own run
+    (tests/golden/det_train.npz: dropout_p = 0, the multinomial draws of the sampled roll-outs and the tokens fed under
+    scheduled sampling replayed): the 7-key loss dictionary, iteration 2's clamped gradient, every parameter after
+    the two steps."""
+    from insenticap_model_amd.detector import Detector
+    g = golden('det_train')
+    dev = torch.device('cuda:0')
+    st = dict(ST, dropout_p=0.0)
+    det = Detector(synth.make_idx2word(V), TN, synth.SENTIMENT_CATEGORIES, {'cap_lr': 4e-4}, st)
+    det.captioner.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_weights(V, st, seed=1).items()})
+    load_helper(det.senti_detector, 51)
+    load_helper(det.sent_senti_cls, 52)
+    det.to(dev)
+    batches, split = synth.make_rl_batches(2, B, V, st, seq_len=TN)
+    det.set_ciderd_scorer(split)
+    s = synth.make_inputs(3, V, st, regions=6, seq_len=TN, seed=77)
+    t = torch.from_numpy
+    scs = [((t(s['captions']), s['lengths']), t(s['cpt_words']), t(s['senti_words']), t(s['senti_labels']))]
+    cap = det.captioner
+    o_rl, o_xe, o_s2s = cap.forward_rl, cap.forward_xe, cap.forward_seq2seq
+    n = {'rl': 0, 'xe': 0, 's2s': 0}
+
+    def fed_as_captions(key):
+        fed = torch.from_numpy(g[key]).to(dev)
+        return torch.cat([fed, fed[:, -1:]], dim=1)            # the unrolls feed captions[:, :-1]
+
+    def replay_rl(*a, **k):
+        if not k.get('sample_max', a[-1] if len(a) >= 7 else 1):
+            k['_replay'] = torch.from_numpy(g['dt/draws%d' % n['rl']]).to(dev)
+            n['rl'] += 1
+        return o_rl(*a, **k)
+
+    def replay_xe(fc, att, cpts, caps, labels, ss_prob=0.0, **k):
+        assert ss_prob == 0.5                                    # models/decoder.py:139
+        out = o_xe(fc, att, cpts, fed_as_captions('dt/fed_xe%d' % n['xe']), labels, 0.0, **k)
+        n['xe'] += 1
+        return out
+
+    def replay_s2s(caps, cpts, sentis, labels, ss_prob=0.0, **k):
+        assert ss_prob == 0.25                                   # models/decoder.py:155
+        out = o_s2s(fed_as_captions('dt/fed_s2s%d' % n['s2s']), cpts, sentis, labels, 0.0, **k)
+        n['s2s'] += 1
+        return out
+    cap.forward_rl, cap.forward_xe, cap.forward_seq2seq = replay_rl, replay_xe, replay_s2s
+    losses = det(([_tensors(b) for b in batches], scs), 'fact', True)
+    assert n == {'rl': 2, 'xe': 2, 's2s': 2}
+    assert set(losses) == {'da_loss', 'fact_reward', 'cls_reward', 'all_rewards', 'cap_loss', 'xe_loss',
+                           'seq2seq_loss'}
+    for k, v in losses.items():
+        np.testing.assert_allclose(v, g['dt/loss_' + k][0], rtol=2e-4, atol=2e-5, err_msg=k)
+    checked = 0
+    for k, q in cap.named_parameters():
+        key = 'dt/grad2/' + k
+        if key in g.files:
+            ref = g[key]
+            np.testing.assert_allclose(q.grad.cpu().numpy(), ref, atol=1e-4 * np.abs(ref).max() + 1e-7, err_msg=k)
+            checked += 1
+    assert checked >= 38                                          # (the RL iteration trains the gate as well)
+    for k, q in cap.state_dict().items():
+        ref = g['dt/after/' + k]
+        diff = np.abs(q.cpu().numpy() - ref)
+        # two Adam steps of lr 4e-4.  A step is lr * m / (sqrt(v) + eps) - it normalises the gradient away - so where
+        # a gradient element is small next to its rounding error the two sides may step differently by up to lr; the
+        # gradients themselves are held to 1e-4 of the tensor's largest above.  Here: nothing moves further than two
+        # full steps from the reference, and the typical element lands on it.
+        assert diff.max() <= 2 * 2 * 4e-4 * 1.01, k
+        assert np.median(diff) <= 2e-6, (k, float(np.median(diff)))

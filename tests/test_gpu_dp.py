@@ -15,6 +15,9 @@ from insenticap_model_amd.train import xe_train_step
 pytestmark = pytest.mark.gpu
 
 V, ST, R, TLEN, STEPS = 64, synth.TINY_SETTINGS, 6, 8, 3
+TINY = dict(V=V, st='tiny', R=R, T=TLEN, B=8, S=4, steps=STEPS, wseed=9)
+# BASELINE configs[3] per-rank shape: 128 captions per rank (+ 40 of the 80 seq2seq rows), V = 10k, T = 20, 36 x 2048
+FULL = dict(V=10000, st='default', R=36, T=20, B=256, S=80, steps=2, wseed=0)
 
 
 def _free_port():
@@ -25,29 +28,36 @@ def _free_port():
     return port
 
 
-def _batches(lo, hi):
-    d = synth.make_inputs(8, V, ST, regions=R, seq_len=TLEN, seed=31)
-    s = synth.make_inputs(4, V, ST, regions=R, seq_len=TLEN, seed=32)
+def _settings(cfg):
+    return synth.TINY_SETTINGS if cfg['st'] == 'tiny' else synth.DEFAULT_SETTINGS
+
+
+def _batches(lo, hi, cfg=TINY):
+    st = _settings(cfg)
+    d = synth.make_inputs(cfg['B'], cfg['V'], st, regions=cfg['R'], seq_len=cfg['T'], seed=31)
+    s = synth.make_inputs(cfg['S'], cfg['V'], st, regions=cfg['R'], seq_len=cfg['T'], seed=32)
     t = torch.from_numpy
     fact = (None, t(d['fc_feats'][lo:hi]), t(d['att_feats'][lo:hi]),
             (t(d['captions'][lo:hi]), d['lengths'][lo:hi]), t(d['cpt_words'][lo:hi]))
     labels = t(d['senti_labels'][lo:hi])
-    s_lo, s_hi = (0, 4) if (lo, hi) == (0, 8) else ((0, 2) if lo == 0 else (2, 4))
+    half = cfg['S'] // 2
+    s_lo, s_hi = (0, cfg['S']) if (lo, hi) == (0, cfg['B']) else ((0, half) if lo == 0 else (half, cfg['S']))
     scs = ((t(s['captions'][s_lo:s_hi]), s['lengths'][s_lo:s_hi]), t(s['cpt_words'][s_lo:s_hi]),
            t(s['senti_words'][s_lo:s_hi]), t(s['senti_labels'][s_lo:s_hi]))
     return fact, labels, scs
 
 
-def _make():
-    cap = Captioner(synth.make_idx2word(V), synth.SENTIMENT_CATEGORIES, ST)
-    cap.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_weights(V, ST, seed=9).items()})
+def _make(cfg=TINY):
+    st = _settings(cfg)
+    cap = Captioner(synth.make_idx2word(cfg['V']), synth.SENTIMENT_CATEGORIES, st)
+    cap.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_weights(cfg['V'], st, seed=cfg['wseed']).items()})
     cap.to('cuda:0').eval()            # eval-mode dropout => deterministic, gradients still flow
     return cap
 
 
-def _run(cap, lo, hi, arena, steps):
+def _run(cap, lo, hi, arena, steps, cfg=TINY):
     optim, xe_crit, da_crit = cap.get_optim_criterion(4e-4)
-    fact, labels, scs = _batches(lo, hi)
+    fact, labels, scs = _batches(lo, hi, cfg)
     losses, first_grad = [], None
     for i in range(steps):
         out = xe_train_step(cap, optim, xe_crit, da_crit, fact, labels, scs, 0.0, 0.1, arena=arena)
@@ -57,19 +67,49 @@ def _run(cap, lo, hi, arena, steps):
     return losses, first_grad
 
 
-def _worker(rank, world, port, results):
+def _worker(rank, world, port, results, cfg=TINY):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK='0')
     dp.init_from_env('gloo')
-    cap = _make()
+    cap = _make(cfg)
     dp.broadcast_parameters(cap)
     arena = dp.GradArena(cap.parameters())
-    lo, hi = dp.shard(8, rank, world)
-    losses, g1 = _run(cap, lo, hi, arena, STEPS)
+    lo, hi = dp.shard(cfg['B'], rank, world)
+    losses, g1 = _run(cap, lo, hi, arena, cfg['steps'], cfg)
     torch.cuda.synchronize()
-    results[rank] = ({k: v.detach().cpu().numpy() for k, v in cap.state_dict().items()}, losses, g1)
+    params = {k: v.detach().cpu().numpy() for k, v in cap.state_dict().items()}
+    big = cfg['V'] >= 1000                                 # (spawn pickles cfg: compare by value, not identity)
+    if big and rank != 0:                                  # (88 MB per copy through the manager: rank 0's is enough)
+        params = {k: float(np.abs(v).sum()) for k, v in params.items()}
+    results[rank] = (params, losses, g1 if (not big or rank == 0) else float(np.abs(g1).sum()), arena.nbytes)
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
+
+
+def test_two_rank_training_at_the_config_size_matches_single_process():
+    """BASELINE configs[3] per-rank shape: two ranks x (128 captions + 40 seq2seq rows) at V = 10k, T = 20, 36 x 2048
+    features - the 88 MB gradient arena under a real two-rank all-reduce (gloo: both ranks share this box's one GPU) -
+    against one process on all 256 + 80 rows: losses, the reduced gradient, lock-step parameters after two steps."""
+    cfg = FULL
+    mgr = mp.get_context('spawn').Manager()
+    results = mgr.dict()
+    mp.spawn(_worker, args=(2, _free_port(), results, cfg), nprocs=2, join=True)
+    cap = _make(cfg)
+    arena = dp.GradArena(cap.parameters())
+    ref_losses, ref_g1 = _run(cap, 0, cfg['B'], arena, cfg['steps'], cfg)
+    ref = {k: v.detach().cpu().numpy() for k, v in cap.state_dict().items()}
+    (p0, l0, g0, nb0), (p1, l1, g1_sum, nb1) = results[0], results[1]
+    assert nb0 == nb1 == 4 * 22063379                      # the 88.25 MB arena of the reference architecture at V = 10k
+    np.testing.assert_allclose(l0, ref_losses, rtol=3e-5)
+    np.testing.assert_allclose(l1, l0, rtol=1e-6)
+    assert float(np.abs(g0).sum()) == g1_sum                # bit-identical reduced gradient on both ranks
+    off = 0
+    for k, v in ref.items():
+        a, b = g0[off:off + v.size], ref_g1[off:off + v.size]
+        np.testing.assert_allclose(a, b, atol=2e-4 * np.abs(b).max() + 1e-7, err_msg=k)
+        off += v.size
+        assert float(np.abs(p0[k]).sum()) == p1[k], k      # ranks stay in lock-step
+        assert np.abs(p0[k] - ref[k]).max() <= cfg['steps'] * 4e-4 * 1.05, k
 
 
 def test_two_rank_training_matches_single_process():
@@ -80,7 +120,7 @@ def test_two_rank_training_matches_single_process():
     arena = dp.GradArena(cap.parameters())
     ref_losses, ref_g1 = _run(cap, 0, 8, arena, STEPS)
     ref = {k: v.detach().cpu().numpy() for k, v in cap.state_dict().items()}
-    (p0, l0, g0), (p1, l1, g1) = results[0], results[1]
+    (p0, l0, g0, _), (p1, l1, g1, _) = results[0], results[1]
     np.testing.assert_allclose(l0, ref_losses, rtol=2e-5)      # the loss trajectory depends on the updates
     np.testing.assert_allclose(l1, l0, rtol=1e-6)
     # all-reduced gradient of the two half-batches == gradient of the whole batch

@@ -91,8 +91,11 @@ def _hip_iteration(w, V, st, d, s2s):
 def _compare(hip, ora, n_expected=32, ora64=None):
     """Gradients within 1e-4 of the tensor's max.  With `ora64` (the fp64 oracle) the comparison is
     against IT, and a tensor on which the reference's own fp32 arithmetic is further than 1e-4/3 from the fp64 result
-    (at B=1024 `att2att`: 1.8e-4 - its gradient is what is left of ~37 000 cancelling rows) gets three times that
-    error as its bound: the HIP path must be as close to the exact gradient as the fp32 reference is, to a factor."""
+    gets three times that error as its bound: the HIP path must be as close to the exact gradient as the fp32
+    reference is, to a factor.  At B=1024 that is `att2att` (fp32 reference: 1.8e-4): of the 18.9 M pre-activations of
+    its ReLU a few lie within 1e-7 of zero, fp32 and fp64 put them on different sides (counted on the CPU: 1 in
+    att2att, 2 in att_embed), and each flip adds or drops one whole row's contribution to the weight gradient -
+    a kink of the function, not an arithmetic error; which elements flip depends on the rounding of the forward GEMM."""
     (hl, hg, hp), (ol, og, op_) = hip, ora
     np.testing.assert_allclose(hl, ol, rtol=3e-5)
     assert set(hg) == set(og) and len(og) == n_expected, (sorted(set(hg) ^ set(og)), len(og))
@@ -103,10 +106,10 @@ def _compare(hip, ora, n_expected=32, ora64=None):
         tol = GRAD_RTOL
         if ora64 is not None:
             tol = max(GRAD_RTOL, 3.0 * float(np.abs(ref32 - ref).max() / (scale + 1e-30)))
-        worst[k] = (float(np.abs(hg[k] - ref).max() / (scale + 1e-30)), tol)
         if scale < 1e-12:              # softmax-shift-invariant biases: the true gradient is 0, all sides hold noise
             assert np.abs(hg[k]).max() < 1e-6, k
             continue
+        worst[k] = (float(np.abs(hg[k] - ref).max() / (scale + 1e-30)), tol)
         np.testing.assert_allclose(hg[k], ref, atol=tol * scale + 1e-7, err_msg=k)
     for k, ref in op_.items():
         # one Adam step moves an element by at most lr = 4e-4; elements whose gradient is rounding noise may step
@@ -128,7 +131,7 @@ def test_xe_train_iteration_b1024_v10k_vs_oracle_autograd():
     ora = _oracle_iteration(w, V, d, s2s, chunk=256)
     ora64 = _oracle_iteration(w, V, d, s2s, chunk=256, dtype=torch.float64)
     worst = _compare(hip, ora, ora64=ora64)
-    loose = {k: v for k, v in worst.items() if v[1] > GRAD_RTOL}
+    loose = {k: v for k, v in worst.items() if v[0] > GRAD_RTOL}
     assert set(loose) <= {'att2att.0.weight', 'att2att.0.bias'}, loose     # every other tensor holds the plain 1e-4
 
 
