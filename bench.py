@@ -429,7 +429,7 @@ def bench_beam(cap, inputs, n_img=64, beam=5):
                                 full_search_p95_ms=round(g_full[int(len(g_full) * 0.95) - 1] * 1e3, 2)))
 
 
-PMC_SUMMARY = os.path.join(ROOT, 'profiles', 'r02_e_pmc_summary_B4096.json')
+PMC_SUMMARY = os.path.join(ROOT, 'profiles', 'r03_a_pmc_summary_B4096.json')
 # bench kernel label -> device symbols it may run as (first one present in the PMC summary wins)
 KERNEL_SYMBOL = {'vocab[': ['void gemm_h3_kernel<2, false>', 'void gemm_h3_kernel<2>', 'void gemm_ld_kernel<2>', 'void gemm_kernel<4, 1, 4, 2, false, false>'],
                  'lstm[4096x2048x1536': ['void gemm_h3x_kernel<1, false>', 'void gemm_h3x_kernel<1>', 'void gemm_h3_kernel<1>', 'void gemm_xl_kernel<1>'],

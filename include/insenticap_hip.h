@@ -84,6 +84,10 @@ int isc_h3_weights_end(void *stream);
  * the slot has meanwhile been recycled (then: _begin).  Between the two, launches on the stream run without a scope. */
 int isc_h3_weights_suspend(void *stream);
 int isc_h3_weights_resume(void *buf, void *stream);
+/* Re-split every weight the stream's scope (active or suspended) holds planes of from the weights' current values - for an
+ * optimiser that has just updated them in place on the same stream: the scope can then be resumed instead of rebuilt entry
+ * by entry (few batched split launches instead of one per weight operand).  ISC_E_STATE: the stream has no scope. */
+int isc_h3_weights_refresh(void *stream);
 
 /* One K-segment of a contraction: acc += A[M,K] * W[N,K]^T.  Replaces the
  * torch.cat([...],1) + nn.Linear / nn.LSTMCell pattern of captioner.py:174-175,180-181. */
@@ -187,6 +191,10 @@ int isc_vocab_fwd(const float *h, int ldh, const float *W, int ldw, const float 
 int isc_logsoftmax_apply(float *logits, int64_t ld_logits, int M, int V,
                          const float *part_max, const float *part_sum, float *lse_out,
                          void *stream);
+/* The same for all T steps of a teacher-forced unroll in ONE launch: logits [B,T,V] with row (b,t) at b*ld_b + t*ld_t,
+ * tile statistics stacked per step [T,B,n_tile] (each step's isc_vocab_fwd / isc_step_fwd wrote its slice). */
+int isc_logsoftmax_apply_steps(float *logits, int64_t ld_b, int64_t ld_t, int B, int T, int V,
+                               const float *part_max, const float *part_sum, void *stream);
 
 /* Additive attention scan (ContentAttention captioner.py:23-35 / SentiAttention :50-62):
  *   e_r = w . tanh(P[b,r,:] + q[b,:] (+ q2[b,:])) + *w_bias ; alpha = softmax_r(e) ;

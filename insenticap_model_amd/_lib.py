@@ -119,6 +119,7 @@ SIGNATURES = {
     'isc_h3_weights_end': (C.c_int, [C.c_void_p]),
     'isc_h3_weights_suspend': (C.c_int, [C.c_void_p]),
     'isc_h3_weights_resume': (C.c_int, [C.c_void_p, C.c_void_p]),
+    'isc_h3_weights_refresh': (C.c_int, [C.c_void_p]),
     'isc_linear_fwd': (C.c_int, [C.POINTER(LinearProblem), C.c_int, C.c_void_p]),
     'isc_gemm_bwd': (C.c_int, [C.POINTER(LinearProblem), C.c_int, C.c_int, C.c_void_p]),
     'isc_lstm_fwd': (C.c_int, [C.POINTER(LstmProblem), C.c_void_p]),
@@ -132,6 +133,8 @@ SIGNATURES = {
                                    C.c_void_p]),
     'isc_logsoftmax_apply': (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_void_p]),
+    'isc_logsoftmax_apply_steps': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                             C.c_void_p, C.c_void_p]),
     'isc_attn_scan_fwd': (C.c_int, [C.POINTER(ScanProblem), C.c_int, C.c_int, C.c_void_p]),
     'isc_gate_mix_fwd': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                    C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,

@@ -92,9 +92,13 @@ def _train_forward(cap, mode, fc, att, cpt_words, senti_words, tokens_in, senti_
         ops.embed_relu_fwd(emb, S.tok[0], S.xt[0])
     mask_for.predraw('out', T, B, H)
     fed_known = not sampling and not (cap.training and ss_prob > 0.0)
+    pm_all = ps_all = None
     if fed_known:                                         # every fed token is known up front: one copy, one gather
         S.tok.copy_(tokens_in.t())
         ops.embed_relu_fwd(emb, S.tok.view(-1), S.xt.view(T * B, Wd))
+        # ... and nothing reads a step's log-probs before the unroll ends: keep the per-step tile statistics and
+        # turn all T steps' logits into log-probs with ONE launch afterwards
+        pm_all, ps_all = new(T, B, n_tile), new(T, B, n_tile)
     # the weights are fixed for the whole unroll: their f16 planes are built once (few-row launches then take the
     # one-launch skinny split-f16 kernels instead of split-K + reduce pairs)
     with _weights_scope(cap):
@@ -117,7 +121,8 @@ def _train_forward(cap, mode, fc, att, cpt_words, senti_words, tokens_in, senti_
                 save['hdrop'] = S.hdrop[t]
                 S.out_scale = osc
             S.out_masks.append(om)
-            ws = {'pmax': pm, 'psum': ps, 'pidx': pi, '_plan': plan}
+            ws = {'pmax': pm if pm_all is None else pm_all[t], 'psum': ps if ps_all is None else ps_all[t], 'pidx': pi,
+                  '_plan': plan}
             if has_c:
                 ws['qa'], ws['v'] = S.qa[t], S.v[t]
             if has_s:
@@ -129,12 +134,14 @@ def _train_forward(cap, mode, fc, att, cpt_words, senti_words, tokens_in, senti_
                       (S.h1[t + 1], S.h2[t + 1]), (S.c1[t + 1], S.c2[t + 1]),
                       S.aC[:, t] if has_c else None, S.aS[:, t] if has_s else None,
                       S.bG[:, t:t + 1] if (has_c and has_s) else None, logits, om, osc, save=save,
-                      normalize=not sampling)
+                      normalize=not sampling and pm_all is None)
             if sampling:                                      # draw on the raw logits, then turn them into log-probs
                 rs.t, rs.logits = t, logits.data_ptr()
                 rs.xt_next = S.xt[t + 1].data_ptr() if t + 1 < T else None
                 ops.rollout_finalize(rs)
                 ops.logsoftmax_apply(logits, pm, ps)
+    if pm_all is not None:
+        ops.logsoftmax_apply_steps(out, pm_all, ps_all)
     if sampling:
         S.sample = (seq, seq_masks, raw, alive)
     cap._set_weights(S.aC if has_c else None, S.aS if has_s else None,

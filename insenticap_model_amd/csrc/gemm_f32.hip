@@ -2872,6 +2872,43 @@ extern "C" int isc_h3_weights_resume(void *buf, void *stream) {
     return ISC_E_STATE;
 }
 
+// Re-split every weight the stream's scope (active or suspended) holds planes of, from the weights' CURRENT values, into
+// the same planes: what an optimiser step calls after it has written the weights in place, so that the next forward /
+// backward sweeps resume the scope instead of rebuilding it plane by plane (39 one-job split launches per XE iteration at
+// B = 128 became ceil(entries / H3_MAX_JOBS) launches).  Enqueued on `stream`, i.e. ordered after whatever wrote the
+// weights there; the caller orders other streams.
+extern "C" int isc_h3_weights_refresh(void *stream) {
+    H3WScope *sc = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_h3w_mu);
+        for (int i = 0; i < H3W_MAX_SCOPES; ++i)
+            if (g_h3w[i].buf && g_h3w[i].stream == (hipStream_t)stream) sc = &g_h3w[i];
+    }
+    if (!sc) return ISC_E_STATE;
+    int i = 0, launches = 0;
+    while (i < sc->n) {
+        SplitLaunch S = {};
+        int blocks = 0;
+        for (; i < sc->n && S.njobs < H3_MAX_JOBS; ++i) {
+            const H3WEntry &e = sc->e[i];
+            SplitJob &J = S.j[S.njobs++];
+            int k0 = 0;
+            for (int sg = 0; sg < e.nseg; ++sg) {
+                J.src[sg] = e.W[sg]; J.ld[sg] = e.ldw[sg]; J.kstart[sg] = k0;
+                k0 += e.K[sg];
+            }
+            J.nseg = e.nseg; J.rows = e.rows; J.Kp = k0; J.first_block = blocks;
+            J.hi = const_cast<_Float16 *>(e.hi); J.lo = const_cast<_Float16 *>(e.lo);
+            J.transposed = e.transposed;
+            blocks += e.transposed ? ((e.rows + 63) / 64) * (k0 >> 5) : (int)(((long long)e.rows * (k0 >> 3) + 255) / 256);
+        }
+        hipLaunchKernelGGL(h3_split_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, S);
+        ISC_LAUNCH_CHECK();
+        ++launches;
+    }
+    return ISC_OK;
+}
+
 static const H3WEntry *h3w_find(const H3WScope *sc, const DevProb &p, int transposed = 0) {
     if (!sc) return nullptr;
     for (int i = 0; i < sc->n; ++i) {

@@ -361,6 +361,16 @@ def logsoftmax_apply(logits, part_max, part_sum, lse_out=None):
                                    part_sum.data_ptr(), ptr(lse_out), stream()), 'isc_logsoftmax_apply')
 
 
+def logsoftmax_apply_steps(logits_btv, part_max_tbn, part_sum_tbn):
+    """log-softmax in place over all steps of a [B,T,V] logits tensor from the per-step tile statistics [T,B,n_tile]."""
+    B, T, V = logits_btv.shape
+    assert logits_btv.stride(2) == 1 and part_max_tbn.is_contiguous() and part_sum_tbn.is_contiguous()
+    assert part_max_tbn.shape[:2] == (T, B) and part_sum_tbn.shape == part_max_tbn.shape
+    check(_lib.load().isc_logsoftmax_apply_steps(logits_btv.data_ptr(), logits_btv.stride(0), logits_btv.stride(1), B, T,
+                                                 V, part_max_tbn.data_ptr(), part_sum_tbn.data_ptr(), stream()),
+          'isc_logsoftmax_apply_steps')
+
+
 def _planes_ptrs(planes, like):
     if planes is None:
         return None, None
@@ -697,6 +707,37 @@ def xe_loss_bwd(target, lengths_i32, gout, sum_count, dlogp):
 
 
 WEIGHT_EPOCH = 0   # bumped by every in-place parameter update done behind torch's back (version counters)
+
+
+def refresh_weight_planes(epoch_before):
+    """After an in-place weight update enqueued on the current stream (the fused optimiser; WEIGHT_EPOCH was
+    `epoch_before` when it started): re-split the weights behind every suspended weights scope of this device whose key
+    was valid until then, in place and in few batched launches (isc_h3_weights_refresh), and re-key it to the new epoch -
+    the next forward / backward sweeps then RESUME their scope instead of rebuilding it with one split launch per weight
+    operand (39 per XE iteration at B = 128).  A scope on another stream (the seq2seq unroll's side stream) is refreshed
+    on ITS stream, after that stream has been made to wait for this one.  Returns the number of scopes refreshed."""
+    cls = h3_weights_scope
+    cur = torch.cuda.current_stream()
+    index = cur.device.index
+    with cls._lock:
+        items = [(k, wk) for k, wk in cls._suspended.items()
+                 if k[0] == index and isinstance(wk, tuple) and wk and wk[-1] == epoch_before
+                 and cls._depth.get(k, 0) == 0]
+    lib = _lib.load()
+    done = 0
+    for key, wk in items:
+        handle = key[1]
+        if handle != cur.cuda_stream:
+            torch.cuda.ExternalStream(handle, device=index).wait_stream(cur)
+        rc = lib.isc_h3_weights_refresh(C.c_void_p(handle))
+        with cls._lock:
+            if cls._suspended.get(key) == wk:
+                if rc == 0:
+                    cls._suspended[key] = wk[:-1] + (WEIGHT_EPOCH,)
+                    done += 1
+                else:
+                    del cls._suspended[key]
+    return done
 
 
 def clamp_adam(params, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, clip, step):

@@ -15,6 +15,7 @@ class FusedClampAdam(torch.optim.Adam):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0):
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         self._pending_clip = 0.0
+        self.refresh_weight_planes = True
 
     def set_clip(self, grad_clip):
         """Elementwise clamp to +-grad_clip fused into the next step() (then cleared)."""
@@ -27,6 +28,7 @@ class FusedClampAdam(torch.optim.Adam):
             with torch.enable_grad():
                 loss = closure()
         clip, self._pending_clip = self._pending_clip, 0.0
+        epoch_before = ops.WEIGHT_EPOCH
         for group in self.param_groups:
             ps, gs, ms, vs = [], [], [], []
             step_no = None
@@ -54,6 +56,10 @@ class FusedClampAdam(torch.optim.Adam):
                 vs.append(st['exp_avg_sq'])
             if ps:
                 self._launch(ps, gs, ms, vs, group, clip, step_no)
+        if ops.WEIGHT_EPOCH != epoch_before and self.refresh_weight_planes:
+            # the f16 weight planes the suspended weights scopes hold: re-split them now, in few batched launches,
+            # instead of one launch per weight operand inside the next iteration's sweeps
+            ops.refresh_weight_planes(epoch_before)
         return loss
 
     @staticmethod

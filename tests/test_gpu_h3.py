@@ -382,3 +382,37 @@ def test_weights_scope_gives_its_depth_back_when_begin_fails():
     assert ops.h3_weights_scope._depth.get(key, 0) == before
     with ops.h3_weights_scope(dev()) as sc:     # and the next scope opens normally
         assert sc.opened
+
+
+def test_optimizer_step_refreshes_the_suspended_weight_planes():
+    """FusedClampAdam.step() re-splits the weights behind the stream's suspended weights scope in place and in few
+    batched launches (isc_h3_weights_refresh), so the next sweep RESUMES its scope: its results equal those of a scope
+    built from scratch on the updated weights bit for bit, and the split-launch count of the second iteration drops."""
+    from insenticap_model_amd import Captioner, XECriterion, synth
+    from insenticap_model_amd.train import xe_train_step
+    V, st = 512, synth.DEFAULT_SETTINGS
+    d = synth.make_inputs(32, V, st, regions=8, seq_len=6, seed=3)
+    s2 = synth.make_inputs(16, V, st, regions=8, seq_len=6, seed=4)
+    t = torch.from_numpy
+    fact = (None, t(d['fc_feats']), t(d['att_feats']), (t(d['captions']), d['lengths']), t(d['cpt_words']))
+    scs = ((t(s2['captions']), s2['lengths']), t(s2['cpt_words']), t(s2['senti_words']), t(s2['senti_labels']))
+
+    def run(refresh):
+        cap = Captioner(synth.make_idx2word(V), synth.SENTIMENT_CATEGORIES, st)
+        cap.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_weights(V, st, seed=7).items()})
+        cap.to(dev()).eval()
+        optim, xe_crit, da_crit = cap.get_optim_criterion(4e-4)
+        optim.refresh_weight_planes = refresh
+        outs = []
+        for _ in range(3):
+            o = xe_train_step(cap, optim, xe_crit, da_crit, fact, t(d['senti_labels']), scs, 0.0, 0.1,
+                              overlap_unrolls=False)
+            outs.append(float(o['all_loss']))
+        torch.cuda.synchronize()
+        return outs, {k: v.detach().clone() for k, v in cap.state_dict().items()}
+    ops.set_h3_mode(2)
+    l1, p1 = run(True)
+    l0, p0 = run(False)
+    assert l1 == l0
+    for k in p0:
+        assert torch.equal(p0[k], p1[k]), k

@@ -5,6 +5,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
+bench.load_product()
 
 dev = torch.device('cuda:0')
 from insenticap_model_amd import Captioner, synth
