@@ -123,7 +123,7 @@ def cpu_baseline(weights, seconds):
             O.forward_rl(p, ids, *a, T, 1)
             n += 1
             el = time.perf_counter() - t0
-            if el >= seconds or n >= 50:
+            if el >= seconds or n >= 400:
                 break
     return dict(value=round(n * Bc / el, 2), unit='captions/s', cores=cores, kind='port',
                 sample='%d greedy roll-outs of B=%d (T=%d, R=%d, V=%d) by oracle/captioner_oracle.py, '
@@ -663,6 +663,17 @@ def run(args):
         e['phase'] = rec['phase']
         e['per_rollout_ms'] = round(rec['avg_ms'] * (1 if rec['phase'] == 'prologue' else T), 3)
         entries.append(e)
+    # The armed step runs through the per-op host path (one FFI call and two event records per kernel), where the device
+    # can go idle between launches: the event brackets then include those gaps and their sum exceeds the wall time of a
+    # roll-out on the plan path (one FFI call per step) that `value` measures.  `per_rollout_ms` is therefore the
+    # kernel's SHARE of the measured wall time (event time x wall / event sum when the sum is larger);
+    # `per_rollout_ms_events` keeps the raw event figure, `avg_us` / `achieved` / `frac` are per launch from the events.
+    wall_ms = el / args.steps * 1e3
+    ev_sum = sum(e['per_rollout_ms'] for e in entries)
+    scale = min(1.0, wall_ms / ev_sum) if ev_sum > 0 else 1.0
+    for e in entries:
+        e['per_rollout_ms_events'] = e['per_rollout_ms']
+        e['per_rollout_ms'] = round(e['per_rollout_ms'] * scale, 3)
     entries.sort(key=lambda e: -e['per_rollout_ms'])
     out = {
         'metric': 'captions/sec (greedy, 36-region feats, len-20)',

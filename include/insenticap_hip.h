@@ -538,6 +538,24 @@ int isc_grad_scale(const float *const *src_host, const int64_t *numel_host, int 
 int64_t isc_splitk_workspace_bytes(int64_t M, int64_t N);
 int64_t isc_h3_weights_workspace_bytes(int64_t weight_elements, int with_transposes);
 
+/* Sticky numerics status.  The caller registers two 32-bit words of HOST memory that the device can write (pinned /
+ * mapped: hipHostMalloc, a pinned torch tensor) with isc_set_status_words - per device, after selecting it; NULL
+ * unregisters.  A kernel that meets a non-finite value stores 1 into its word (error path only; nothing is written
+ * otherwise), and isc_status reads the words on the host WITHOUT any device call: it reports what the work the host has
+ * already waited for has flagged.  Bits of the return value:
+ *   ISC_STATUS_NONFINITE_STATS (1)  a vocabulary-statistics row (max / sum exp) was non-finite when a decode step folded
+ *                                   it (roll-out finalize, scheduled sampling, log-softmax passes, beam top-k)
+ *   ISC_STATUS_NONFINITE_LINEAR (2) a split-f16 linear launch over caller data staged as fp32 rows (the prologue's raw
+ *                                   region features, training-mode activations) produced a non-finite pre-activation
+ * Either means an operand left the split-f16 domain |x| < 65504 (its hi plane is inf) or was NaN / inf on entry (the
+ * linear epilogues' ReLU lets NaN through, as torch's does, so it reaches the statistics); results since the last clean
+ * read are not to be trusted.  isc_set_h3_mode(0) runs the exact-fp32 tiles, whose domain is fp32's.
+ * reset != 0 clears the words when any bit was set. */
+#define ISC_STATUS_NONFINITE_STATS 1
+#define ISC_STATUS_NONFINITE_LINEAR 2
+int isc_set_status_words(unsigned int *host_words2);
+int isc_status(int reset);
+
 /* clip_gradient (train_xe.py:19-23, decoder.py:14-18: elementwise clamp_ to +-clip, in place)
  * followed by torch.optim.Adam's update (captioner.py:422-423), all tensors in one launch.
  * Pointer tables are HOST arrays of device pointers. clip <= 0 disables the clamp. */

@@ -187,6 +187,8 @@ SIGNATURES = {
     'isc_grad_scale': (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_int, C.c_void_p, C.c_void_p]),
     'isc_splitk_workspace_bytes': (C.c_int64, [C.c_int64, C.c_int64]),
     'isc_h3_weights_workspace_bytes': (C.c_int64, [C.c_int64, C.c_int]),
+    'isc_status': (C.c_int, [C.c_int]),
+    'isc_set_status_words': (C.c_int, [C.c_void_p]),
     'isc_clamp_adam': (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                  C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_int, C.c_double,
                                  C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int,

@@ -120,6 +120,7 @@ class Captioner(nn.Module):
         if not p['classifier.weight'].is_cuda:
             raise _lib.HipLibraryError('Captioner parameters are on the CPU: call .to("cuda") - '
                                        'this implementation has no CPU path')
+        ops.register_status_words(p['classifier.weight'].device)      # numerics flags of this device (once)
         return p
 
     @property
@@ -786,8 +787,11 @@ class Captioner(nn.Module):
         self.eval()
         self._p()                                  # raises on CPU parameters before anything touches the device
         with ops.h3_weights_scope(self._dev, key=self._weights_key()):     # prologue + search: weights split once
-            return beam_search_batch(self, fc_feats, att_feats, senti_words, senti_labels, beam_size,
-                                     decoding_constraint, max_seq_len)
+            out = beam_search_batch(self, fc_feats, att_feats, senti_words, senti_labels, beam_size,
+                                    decoding_constraint, max_seq_len)
+        if getattr(self, 'numerics_checks', True):     # the host has the results, i.e. has waited: read the status too
+            ops.check_numerics('Captioner.sample')
+        return out
 
     def get_optim_criterion(self, lr, weight_decay=0):
         from .optim import FusedClampAdam   # a torch.optim.Adam subclass: same state_dict layout

@@ -23,6 +23,26 @@ static inline int isc_aligned16(const void *p) { return (((uintptr_t)p) & 15u) =
 __device__ __forceinline__ float isc_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float isc_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
 
+// ReLU that lets NaN through, as torch.relu does (v_max_f32 / fmaxf return the non-NaN operand: a NaN pre-activation would
+// come out as a clean 0 and an operand outside the split-f16 domain would go unnoticed - see isc_status).
+__device__ __forceinline__ float isc_relu(float x) { return x < 0.f ? 0.f : x; }
+
+// Sticky numerics status: two 32-bit words in host memory the caller registered (isc_set_status_words), visible to the
+// device; a kernel that meets a non-finite value stores 1 into its word - a plain store, raced benignly, executed only on
+// the error path - and the host reads the words as ordinary memory once it has waited for the work (no device call).
+// One pointer variable per translation unit (no relocatable device code): ISC_STATUS_DECL in each .hip that flags.
+#define ISC_STATUS_WORD_STATS 0
+#define ISC_STATUS_WORD_LINEAR 1
+#define ISC_STATUS_DECL(NAME)                                                                          \
+    __device__ unsigned int *g_isc_status_##NAME;                                                      \
+    int isc_set_status_##NAME##_(unsigned int *p) {                                                    \
+        return hipMemcpyToSymbol(HIP_SYMBOL(g_isc_status_##NAME), &p, sizeof(p)) == hipSuccess ? 0 : 1; \
+    }                                                                                                  \
+    __device__ __forceinline__ void isc_flag_##NAME(int word) {                                        \
+        unsigned int *sp = g_isc_status_##NAME;                                                        \
+        if (sp) __hip_atomic_store(sp + word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);        \
+    }
+
 // DPP lane exchanges inside a 16-lane row (VALU rate, no LDS crossbar): xor 1, xor 2, mirror inside each
 // 8-lane half, mirror inside the row.  Applied in this order with a commutative combine they leave every
 // lane of a row holding the row's reduction.

@@ -265,7 +265,7 @@ __device__ __forceinline__ void epi_linear_tile(const DevProb &P, const float *C
                 if (P.bias1) o[e] += P.bias1[n];
                 if (P.bias2) o[e] += P.bias2[n];
                 if (P.accumulate) o[e] += P.C[(long long)gm * P.ldc + n];
-                if (P.relu) o[e] = fmaxf(o[e], 0.f);
+                if (P.relu) o[e] = isc_relu(o[e]);
                 pre[e] = o[e];
                 if (P.mask) o[e] = o[e] * (float)P.mask[(long long)gm * N + n] * P.mask_scale;
             }
@@ -429,7 +429,7 @@ __device__ __forceinline__ void epi_linear_frag_impl(const DevProb &P, f32x16 (&
             if (h1) o += b1[j];
             if (h2) o += b2[j];
             if (f_acc) o += prev[j];
-            if (RELU) o = fmaxf(o, 0.f);
+            if (RELU) o = isc_relu(o);
             if constexpr (FEAT) {
                 const int gn = col0 + fcol0 + j * 32 + (lane & 31);
                 if (f_pre) P.C_pre[(long long)gm * P.ldc + gn] = o;
@@ -1260,8 +1260,13 @@ __device__ __forceinline__ void epi_lstm_frag16(const DevProb &P, f32x4 (&acc)[2
     }
 }
 
-// Linear epilogue (same feature set and template split as epi_linear_frag).
-template <int NB, bool EDGE, bool FEAT, bool RELU>
+// Numerics status (isc_status): word 1 = a split-f16 linear launch that staged CALLER data as fp32 rows (the raw region
+// features of the prologue, training-mode activations) produced a non-finite pre-activation - an operand at or beyond the
+// f16 range (|x| >= 65520: its hi plane is inf), or a NaN / inf fed in.
+ISC_STATUS_DECL(gemm)
+
+// Linear epilogue (same feature set and template split as epi_linear_frag).  CHECK: flag non-finite pre-activations.
+template <int NB, bool EDGE, bool FEAT, bool RELU, bool CHECK>
 __device__ __forceinline__ void epi_linear_frag16_impl(const DevProb &P, f32x4 (&acc)[2][NB], int frow0, int fcol0,
                                                        int lane, int row0, int col0) {
     const int M = P.M, N = P.N;
@@ -1269,6 +1274,7 @@ __device__ __forceinline__ void epi_linear_frag16_impl(const DevProb &P, f32x4 (
     bool cok[NB];
     const bool h0 = P.bias0 != nullptr, h1 = P.bias1 != nullptr, h2 = P.bias2 != nullptr;
     const bool f_acc = FEAT && P.accumulate, f_pre = FEAT && P.C_pre != nullptr, f_mask = FEAT && P.mask != nullptr;
+    bool bad = false;
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
         const int gn = col0 + fcol0 + j * 16 + (lane & 15);
@@ -1297,7 +1303,8 @@ __device__ __forceinline__ void epi_linear_frag16_impl(const DevProb &P, f32x4 (
                 if (h1) o += b1[j];
                 if (h2) o += b2[j];
                 if (f_acc) o += prev[j];
-                if (RELU) o = fmaxf(o, 0.f);
+                if constexpr (CHECK) bad |= !(fabsf(o) <= 3.0e38f);
+                if (RELU) o = isc_relu(o);
                 if constexpr (FEAT) {
                     const int gn = col0 + fcol0 + j * 16 + (lane & 15);
                     if (f_pre) P.C_pre[(long long)gm * P.ldc + gn] = o;
@@ -1306,15 +1313,18 @@ __device__ __forceinline__ void epi_linear_frag16_impl(const DevProb &P, f32x4 (
                 crow[j * 16] = o;
             }
         }
+    if constexpr (CHECK) {
+        if (__any(bad) && lane == 0) isc_flag_gemm(ISC_STATUS_WORD_LINEAR);
+    }
 }
 
-template <int NB>
+template <int NB, bool CHECK>
 __device__ __forceinline__ void epi_linear_frag16(const DevProb &P, f32x4 (&acc)[2][NB], int frow0, int fcol0, int lane,
                                                   int row0, int col0) {
     const bool feat = P.accumulate || P.C_pre || P.mask;
     const bool edge = !(row0 + frow0 + 32 <= P.M && col0 + fcol0 + 16 * NB <= P.N);
     const bool relu = P.relu != 0;
-#define ISC_EPI_CASE(E, F, R) epi_linear_frag16_impl<NB, E, F, R>(P, acc, frow0, fcol0, lane, row0, col0)
+#define ISC_EPI_CASE(E, F, R) epi_linear_frag16_impl<NB, E, F, R, CHECK>(P, acc, frow0, fcol0, lane, row0, col0)
     if (edge) {
         if (relu) ISC_EPI_CASE(true, true, true); else ISC_EPI_CASE(true, true, false);
     } else if (feat) {
@@ -1359,10 +1369,31 @@ __device__ __forceinline__ void h3_frag_from_f32(const char *row, int oct, int s
     }
 }
 
+// Diagnostic build only (-DH3_STAMP=1, tools/h3_stamp.sh; the shipped library compiles none of it): s_memtime stamps
+// around gemm_h3_kernel's main loop and epilogue, summed over waves into g_h3_stamp = {waves, setup, main loop, epilogue}
+// (shader cycles), read back by isc_debug_h3_stamps.  The stamps go to memory nothing else reads.
+#ifndef H3_STAMP
+#define H3_STAMP 0
+#endif
+#if H3_STAMP
+__device__ unsigned long long g_h3_stamp[4];
+extern "C" int isc_debug_h3_stamps(unsigned long long *out4_host, int reset) {
+    if (out4_host && hipMemcpyFromSymbol(out4_host, HIP_SYMBOL(g_h3_stamp), sizeof(g_h3_stamp)) != hipSuccess) return 1;
+    if (reset) {
+        const unsigned long long z[4] = {0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_h3_stamp), z, sizeof(z)) != hipSuccess) return 1;
+    }
+    return ISC_OK;
+}
+#endif
+
 // AF32: some activation segment comes as fp32 rows (split after the fragment read); false = every segment has planes,
 // and the per-buffer test is compiled out of the fragment loads (it cost the all-planes decode loop ~5-10 %).
 template <int EPI, bool AF32>
 __global__ __launch_bounds__(256, 2) void gemm_h3_kernel(const DevLaunch L) {
+#if H3_STAMP
+    const unsigned long long stamp0 = __builtin_amdgcn_s_memtime();
+#endif
     constexpr int BM = 128, BN = 128, TN = 4;
     constexpr int PA = 128 * 128, PB = 128 * 128;       // bytes per A / W image (row = 128 B: 32 hi | 32 lo halfs)
     constexpr int ST = PA + PB;                         // bytes per buffer
@@ -1505,6 +1536,9 @@ __global__ __launch_bounds__(256, 2) void gemm_h3_kernel(const DevLaunch L) {
         }
     };
     const int nchunks = Kp / 32;
+#if H3_STAMP
+    const unsigned long long stamp1 = __builtin_amdgcn_s_memtime();
+#endif
     stage(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -1529,6 +1563,9 @@ __global__ __launch_bounds__(256, 2) void gemm_h3_kernel(const DevLaunch L) {
         chunk(c, I0{}, I1{});
         if (c + 1 < nchunks) chunk(c + 1, I1{}, I0{});
     }
+#if H3_STAMP
+    const unsigned long long stamp2 = __builtin_amdgcn_s_memtime();
+#endif
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -1541,8 +1578,20 @@ __global__ __launch_bounds__(256, 2) void gemm_h3_kernel(const DevLaunch L) {
     } else if constexpr (EPI == EPI_LSTM) {
         epi_lstm_frag16(P, acc0, wm * 32, lane, row0, tn);
     } else {
-        epi_linear_frag16<NB>(P, acc0, wm * 32, 0, lane, row0, col0);
+        epi_linear_frag16<NB, AF32>(P, acc0, wm * 32, 0, lane, row0, col0);
     }
+#if H3_STAMP
+    if (EPI == EPI_VOCAB) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the epilogue's stores have left
+        const unsigned long long stamp3 = __builtin_amdgcn_s_memtime();
+        if (lane == 0) {
+            atomicAdd(&g_h3_stamp[0], 1ull);
+            atomicAdd(&g_h3_stamp[1], stamp1 - stamp0);
+            atomicAdd(&g_h3_stamp[2], stamp2 - stamp1);
+            atomicAdd(&g_h3_stamp[3], stamp3 - stamp2);
+        }
+    }
+#endif
 }
 
 // H3 on a 256 x 128 tile with EIGHT waves (32 x 128 accumulators, the same fragment code) and three 48 KB buffers:
@@ -1734,7 +1783,7 @@ __global__ __launch_bounds__(512) void gemm_h3x_kernel(const DevLaunch L) {
     } else if constexpr (EPI == EPI_LSTM) {
         epi_lstm_frag16(P, acc0, wm * 32, lane, row0, tn);
     } else {
-        epi_linear_frag16<NB>(P, acc0, wm * 32, 0, lane, row0, col0);
+        epi_linear_frag16<NB, AF32>(P, acc0, wm * 32, 0, lane, row0, col0);
     }
 }
 
@@ -1919,7 +1968,7 @@ __global__ __launch_bounds__(256) void gemm_h3m_kernel(const DevLaunch L) {
         for (int j = 0; j < NB; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc0[i][j][r] = fmaf(acc1[i][j][r], 1.f / 2048.f, acc0[i][j][r]);
-    epi_linear_frag16<NB>(P, acc0, wm * 32, wn * 64, lane, row0, col0);
+    epi_linear_frag16<NB, AF32>(P, acc0, wm * 32, wn * 64, lane, row0, col0);
 }
 
 // Operand split in front of gemm_h3_kernel: gathers the K-segments of one operand into the two packed f16 planes
@@ -2428,7 +2477,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_h3s_kernel(const DevLaunch L) {
                         if (P.bias1) o[e] += P.bias1[nn];
                         if (P.bias2) o[e] += P.bias2[nn];
                         if (P.accumulate) o[e] += P.C[(long long)gm * P.ldc + nn];
-                        if (P.relu) o[e] = fmaxf(o[e], 0.f);
+                        if (P.relu) o[e] = isc_relu(o[e]);
                         pre[e] = o[e];
                         if (P.mask) o[e] = o[e] * (float)P.mask[(long long)gm * N + nn] * P.mask_scale;
                     }
@@ -2492,7 +2541,7 @@ __global__ __launch_bounds__(256) void splitk_linear_kernel(const DevLaunch L) {
         if (P.bias1) o[e] += P.bias1[n];
         if (P.bias2) o[e] += P.bias2[n];
         if (P.accumulate) o[e] += P.C[(long long)gm * P.ldc + n];
-        if (P.relu) o[e] = fmaxf(o[e], 0.f);
+        if (P.relu) o[e] = isc_relu(o[e]);
         pre[e] = o[e];
         if (P.mask) o[e] = o[e] * (float)P.mask[(long long)gm * N + n] * P.mask_scale;
     }
@@ -2885,7 +2934,7 @@ extern "C" int isc_h3_weights_refresh(void *stream) {
             if (g_h3w[i].buf && g_h3w[i].stream == (hipStream_t)stream) sc = &g_h3w[i];
     }
     if (!sc) return ISC_E_STATE;
-    int i = 0, launches = 0;
+    int i = 0;
     while (i < sc->n) {
         SplitLaunch S = {};
         int blocks = 0;
@@ -2904,7 +2953,6 @@ extern "C" int isc_h3_weights_refresh(void *stream) {
         }
         hipLaunchKernelGGL(h3_split_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, S);
         ISC_LAUNCH_CHECK();
-        ++launches;
     }
     return ISC_OK;
 }

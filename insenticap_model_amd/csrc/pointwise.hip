@@ -198,6 +198,13 @@ extern "C" int isc_beam_gather(const float *state_next, const float *state_cur, 
 // Folds the per-tile (max, sumexp, argmax) triples of one row: returns the global max, its
 // vocabulary index (smallest index on ties) and S = sum exp(x - gmax).  All 64 lanes get
 // the result.
+// Numerics status (isc_status, include/insenticap_hip.h): word 0 = a row of vocabulary statistics held a non-finite
+// maximum or sum.  Every decode path folds the step's tile statistics through fold_row_stats (roll-out finalize,
+// scheduled sampling, the log-softmax passes, beam top-k), so whatever went non-finite upstream in the step - an operand
+// beyond the split-f16 domain |x| < 65504 whose hi plane became inf, a NaN feature (ReLU lets NaN through: isc_relu) -
+// is flagged within the same step at no measurable cost (one compare per row) instead of surfacing as garbage tokens.
+ISC_STATUS_DECL(pw)
+
 __device__ __forceinline__ void fold_row_stats(const float *pmax, const float *psum, const int *pidx,
                                                int n_tile, int lane, float &gmax, int &gidx, float &S) {
     float mx = -INFINITY;
@@ -212,7 +219,10 @@ __device__ __forceinline__ void fold_row_stats(const float *pmax, const float *p
     for (int i = lane; i < n_tile; i += 64) s += psum[i] * expf(pmax[i] - mx);
     S = wave_sum(s);
     gmax = mx;
-    gidx = ix;
+    // a row whose maxima are all NaN never satisfied `v > mx`: its index is still the sentinel, and a consumer would
+    // gather an embedding row 2^31 rows past the table.  Such a row decodes <PAD> (id 0) and is flagged.
+    gidx = ix == 0x7fffffff ? 0 : ix;
+    if (lane == 0 && !(fabsf(mx) <= 3.0e38f && S <= 3.0e38f)) isc_flag_pw(ISC_STATUS_WORD_STATS);     // NaN fails both
 }
 
 // ------------------------------------------------------------------ roll-out step
@@ -600,7 +610,7 @@ __global__ __launch_bounds__(256) void beam_topk8_kernel(const float *logits, lo
         }
         if (tid == 0) {
             top_val[(long long)row * beam + k] = bm;
-            top_idx[(long long)row * beam + k] = bi;
+            top_idx[(long long)row * beam + k] = (unsigned)bi < (unsigned)V ? bi : 0;      // (NaN rows: sentinel -> <PAD>)
         }
     }
 }
@@ -651,7 +661,7 @@ __global__ __launch_bounds__(256) void beam_topk_kernel(const float *logits, lon
                 if (sv[w] > bm || (sv[w] == bm && si[w] < bi)) { bm = sv[w]; bi = si[w]; }
             chosen[k] = bi;
             top_val[(long long)row * beam + k] = bm;
-            top_idx[(long long)row * beam + k] = bi;
+            top_idx[(long long)row * beam + k] = (unsigned)bi < (unsigned)V ? bi : 0;      // (NaN rows: sentinel -> <PAD>)
         }
         __syncthreads();
     }

@@ -197,3 +197,23 @@ extern "C" int isc_step_bwd(const isc_step_bwd_plan *p, void *stream) {
     }
     return ISC_OK;
 }
+
+// ------------------------------------------------------------------ numerics status
+int isc_set_status_gemm_(unsigned int *p);         // gemm_f32.hip
+int isc_set_status_pw_(unsigned int *p);           // pointwise.hip
+static unsigned int *g_status_host = nullptr;      // the words registered last (read by isc_status on the host)
+
+extern "C" int isc_set_status_words(unsigned int *words2) {
+    if (isc_set_status_gemm_(words2) || isc_set_status_pw_(words2)) return 1;
+    g_status_host = words2;
+    return ISC_OK;
+}
+
+extern "C" int isc_status(int reset) {
+    unsigned int *w = g_status_host;
+    if (!w) return 0;
+    volatile unsigned int *vw = w;
+    const int bits = (vw[0] ? ISC_STATUS_NONFINITE_STATS : 0) | (vw[1] ? ISC_STATUS_NONFINITE_LINEAR : 0);
+    if (reset && bits) { vw[0] = 0; vw[1] = 0; }
+    return bits;
+}

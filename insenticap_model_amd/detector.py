@@ -218,6 +218,8 @@ class Detector(nn.Module):
             vec = torch.stack([torch.as_tensor(sums[k], dtype=torch.float32, device=device).reshape(()) for k in keys])
             dp.all_reduce_(vec, self.dp_group)
             sums = dict(zip(keys, vec.tolist()))
+        if getattr(self.captioner, 'numerics_checks', True):
+            ops.check_numerics('Detector.forward')       # (the statistics below are read by the host anyway)
         # len(data) is the length of the (loader, loader) TUPLE, as in the reference (decoder.py:178-179) - the same
         # on every rank, so globally summed statistics divide by the same number everywhere
         return {k: float(v) / len(data) for k, v in sums.items()}

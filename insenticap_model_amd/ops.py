@@ -709,6 +709,52 @@ def xe_loss_bwd(target, lengths_i32, gout, sum_count, dlogp):
 WEIGHT_EPOCH = 0   # bumped by every in-place parameter update done behind torch's back (version counters)
 
 
+STATUS_NONFINITE_STATS, STATUS_NONFINITE_LINEAR = 1, 2
+
+
+_STATUS_WORDS = {}          # device index -> pinned int32[2] the kernels flag into (isc_set_status_words)
+
+
+def register_status_words(device=None):
+    """Once per device: hand the library two pinned host words for its numerics flags.  Cheap to call again."""
+    index = torch.device(device).index if device is not None else None
+    if index is None:
+        index = torch.cuda.current_device()
+    w = _STATUS_WORDS.get(index)
+    if w is None:
+        w = torch.zeros(2, dtype=torch.int32).pin_memory()
+        with torch.cuda.device(index):
+            check(_lib.load().isc_set_status_words(w.data_ptr()), 'isc_set_status_words')
+        _STATUS_WORDS[index] = w
+    return w
+
+
+def device_status(reset=True, device=None):
+    """Numerics bits flagged by the work the host has ALREADY waited for (no device call, no synchronisation)."""
+    w = register_status_words(device)
+    bits = (STATUS_NONFINITE_STATS if int(w[0]) else 0) | (STATUS_NONFINITE_LINEAR if int(w[1]) else 0)
+    if reset and bits:
+        w.zero_()
+    return bits
+
+
+def check_numerics(where=''):
+    """Raises HipLibraryError if a decode step or a split-f16 launch over caller data went non-finite since the last
+    check (and clears the flags).  Reads two host words: it sees what the host has waited for - call it after a
+    synchronisation or a host read of the results (the product does: beam search, the RL step)."""
+    st = device_status(reset=True)
+    if st:
+        what = []
+        if st & STATUS_NONFINITE_LINEAR:
+            what.append('a linear layer over caller-supplied features produced non-finite values')
+        if st & STATUS_NONFINITE_STATS:
+            what.append('a decode step saw non-finite logits')
+        raise _lib.HipLibraryError(
+            '%s%s: an input left the split-f16 domain |x| < 65504 (or was NaN / inf). Results since the last check '
+            'are invalid; scale the features, or run the exact-fp32 engine with ops.set_h3_mode(0).'
+            % (where + ': ' if where else '', '; '.join(what)))
+
+
 def refresh_weight_planes(epoch_before):
     """After an in-place weight update enqueued on the current stream (the fused optimiser; WEIGHT_EPOCH was
     `epoch_before` when it started): re-split the weights behind every suspended weights scope of this device whose key

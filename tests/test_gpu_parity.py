@@ -537,3 +537,48 @@ def test_sampled_rollout_b1024_replayed_by_the_oracle():
     np.testing.assert_allclose(lp.cpu()[:, :steps][live].numpy(), olp[:, :steps][live].numpy(), atol=LOGP_TOL)
     # the draws follow the distribution: mean log-prob of the drawn tokens ~ -entropy, far above uniform (-9.2)
     assert lp.cpu()[:, 0].mean().item() > -9.0
+
+
+def test_features_beyond_the_split_f16_domain_are_reported_not_decoded_silently():
+    """Round-2 finding: |x| >= 65504 in caller data turns the hi plane of x = hi + lo 2^-11 into inf and the roll-out
+    into NaN-derived garbage without any error.  Now: the prologue's linear epilogue flags the non-finite
+    pre-activation and every decode step flags non-finite vocabulary statistics (isc_status); beam search and the RL
+    step raise on it, a roll-out reports it through ops.check_numerics, and the exact-fp32 engine decodes the same
+    input (its domain is fp32's)."""
+    from insenticap_model_amd import _lib
+    from conftest import case_setup
+    c, st, w, d, _ = case_setup('cfg1')
+    cap = Captioner(synth.make_idx2word(c['V']), synth.SENTIMENT_CATEGORIES, st)
+    cap.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()})
+    cap.to(dev()).eval()
+    B = 512                                   # enough rows for the split-f16 prologue kernels in auto mode
+    big = synth.make_inputs(B, c['V'], st, regions=36, seq_len=6, seed=77)
+    a = [torch.from_numpy(np.asarray(big[k])).to(dev()) for k in ('fc_feats', 'att_feats', 'cpt_words', 'senti_words',
+                                                                   'senti_labels')]
+    ops.device_status(reset=True)
+    with torch.no_grad():
+        cap(*a, 6, 1, mode='rl')
+    torch.cuda.synchronize()                                      # the status words say what the host has waited for
+    assert ops.device_status(reset=True) == 0                     # healthy input: nothing flagged
+    bad = [x.clone() for x in a]
+    bad[1][3, 5, 100] = 1.0e5                                     # one region feature beyond the f16 range
+    with torch.no_grad():
+        seq, lp, mk = cap(*bad, 6, 1, mode='rl')
+    torch.cuda.synchronize()
+    st_bits = ops.device_status(reset=False)
+    assert st_bits & ops.STATUS_NONFINITE_STATS, st_bits          # the NaN reached the step's vocabulary statistics
+    assert st_bits & ops.STATUS_NONFINITE_LINEAR, st_bits
+    with pytest.raises(_lib.HipLibraryError, match='split-f16 domain'):
+        ops.check_numerics('test')
+    assert ops.device_status(reset=True) == 0                     # check_numerics cleared it
+    with pytest.raises(_lib.HipLibraryError, match='split-f16 domain'):
+        cap.sample(bad[0][3], bad[1][3], bad[3][3], bad[4][3:4], 3, 1, 6)
+    # the exact-fp32 engine takes the same features
+    prev = ops.set_h3_mode(0)
+    try:
+        with torch.no_grad():
+            seq0, lp0, _ = cap(*bad, 6, 1, mode='rl')
+        torch.cuda.synchronize()
+        assert ops.device_status(reset=True) == 0 and bool(torch.isfinite(lp0).all())
+    finally:
+        ops.set_h3_mode(prev)
