@@ -49,7 +49,7 @@ def test_no_kernel_spills_or_uses_scratch():
     assert gemm and all(r['occupancy'] >= 2 for r in gemm)   # 2 workgroups per CU (the LDS limit)
 
 
-def test_ctypes_struct_layout_matches_c():
+def test_ctypes_struct_layout_matches_c(tmp_path):
     """Compile a tiny C program against the header and compare sizeof/offsetof with ctypes."""
     prog = r'''
 #include <stdio.h>
@@ -70,9 +70,7 @@ int main(void) {
   return 0;
 }
 '''
-    tmp = os.path.join(ROOT, 'gpurun_out')
-    os.makedirs(tmp, exist_ok=True)
-    cfile, exe = os.path.join(tmp, 'layout.c'), os.path.join(tmp, 'layout')
+    cfile, exe = str(tmp_path / 'layout.c'), str(tmp_path / 'layout')      # nothing is written into the tree
     open(cfile, 'w').write(prog)
     subprocess.check_call(['gcc', '-I', os.path.join(ROOT, 'include'), cfile, '-o', exe])
     out = subprocess.check_output([exe]).decode().split()
