@@ -521,14 +521,15 @@ int isc_logsoftmax_bwd_sparse(const float *dlogp_dense, const float *logp, int64
                               const int64_t *const *ids_host, const float *const *coef_host, int n_sparse,
                               const float *scale, float *dlogits, int64_t ld_out, int remap_T, void *stream);
 
-/* Power-of-two gradient scale for a backward sweep whose contractions run on the split-f16 engine: out2 = { S, 1/S },
+/* Power-of-two gradient scale for a backward sweep whose contractions run on the split-f16 engine: out4[0..1] = { S, 1/S },
  * S = 2^k with max |x| over the given tensors (HOST arrays of device pointers / element counts, <= ISC_SCALE_SRC_MAX)
- * brought into [2^-4, 2^-3); S = 1 when they are all zero.  The caller multiplies what enters the sweep by S (exact)
- * and the parameter gradients by 1/S (exact): gradients of a token-mean loss are <= 1/N_tokens, below the f16 normal
- * range at training batch sizes, where the planes x = hi + lo 2^-11 would keep ~22 bits relative to 2^-14 instead of to
- * the element. */
+ * brought into [2^-4, 2^-3); S = 1 when they are all zero.  out4[2..3] are state words of the multi-workgroup reduction:
+ * the caller hands them in ZEROED (once; every call leaves them zeroed).  The caller multiplies what enters the sweep by
+ * S (exact) and the parameter gradients by 1/S (exact): gradients of a token-mean loss are <= 1/N_tokens, below the f16
+ * normal range at training batch sizes, where the planes x = hi + lo 2^-11 would keep ~22 bits relative to 2^-14 instead
+ * of to the element. */
 #define ISC_SCALE_SRC_MAX 4
-int isc_grad_scale(const float *const *src_host, const int64_t *numel_host, int n_src, float *out2, void *stream);
+int isc_grad_scale(const float *const *src_host, const int64_t *numel_host, int n_src, float *out4, void *stream);
 
 /* Workspace sizes (the library allocates nothing; these say what to hand it).
  * isc_splitk_workspace_bytes: bytes that let a launch with an [M, N] output use the deepest K split (16 slabs);

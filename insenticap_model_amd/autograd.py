@@ -186,7 +186,7 @@ def _backward(cap, S, dlogp, d_fc_feats, d_cpt_feats, sparse=()):
     dlogits = new(TB, Vp)
     gs = None
     if getattr(cap, 'grad_scaling', True):
-        gs = new(2)
+        gs = zeros(4)
         srcs = [c for _, c in sparse] + [d_fc_feats.contiguous() if d_fc_feats is not None else None,
                                          d_cpt_feats.contiguous() if d_cpt_feats is not None else None]
         if dlogp is not None:

@@ -125,42 +125,59 @@ struct ScaleSrc {
     int count;
 };
 
-__global__ __launch_bounds__(256) void grad_scale_kernel(const ScaleSrc src, float *out2) {
+// Many workgroups sweep the sources (the [B,512] feature gradients are half a million values at B = 1024: one workgroup
+// took 150 us), fold their maxima with an integer atomicMax on the bit pattern (order-preserving for non-negative
+// floats; deterministic - a maximum does not depend on the order), and the LAST one to finish turns the maximum into
+// { S, 1/S } and resets the two state words for the next call.  out4 = { S, 1/S, max bits, arrival counter }; the caller
+// provides the last two zeroed once (they are left zeroed).
+__global__ __launch_bounds__(256) void grad_scale_kernel(const ScaleSrc src, float *out4) {
     __shared__ float red[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long gtid = (long long)blockIdx.x * 256 + tid, gstride = (long long)gridDim.x * 256;
     float mx = 0.f;
     for (int k = 0; k < src.count; ++k)
-        for (long long i = tid; i < src.n[k]; i += 256) mx = fmaxf(mx, fabsf(src.p[k][i]));     // (NaN is skipped)
+        for (long long i = gtid; i < src.n[k]; i += gstride) mx = fmaxf(mx, fabsf(src.p[k][i]));     // (NaN is skipped)
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
     if (lane == 0) red[wave] = mx;
     __syncthreads();
-    if (tid == 0) {
-        mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-        float S = 1.f;
-        if (mx > 0.f && mx < 3.0e38f) {
-            int e;
-            frexpf(mx, &e);                      // mx = f * 2^e, f in [0.5, 1)
-            int k = -3 - e;                      // S * mx = f * 2^-3  in [2^-4, 2^-3)
-            k = k > 60 ? 60 : (k < -60 ? -60 : k);
-            S = ldexpf(1.f, k);
-        }
-        out2[0] = S;
-        out2[1] = 1.f / S;
+    if (tid != 0) return;
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    unsigned int *state = reinterpret_cast<unsigned int *>(out4 + 2);
+    atomicMax(&state[0], __float_as_uint(mx));
+    __threadfence();
+    if (atomicAdd(&state[1], 1u) != gridDim.x - 1) return;
+    mx = __uint_as_float(atomicMax(&state[0], 0u));          // every arrival's maximum is in (device-scope atomics)
+    float S = 1.f;
+    if (mx > 0.f && mx < 3.0e38f) {
+        int e;
+        frexpf(mx, &e);                      // mx = f * 2^e, f in [0.5, 1)
+        int k = -3 - e;                      // S * mx = f * 2^-3  in [2^-4, 2^-3)
+        k = k > 60 ? 60 : (k < -60 ? -60 : k);
+        S = ldexpf(1.f, k);
     }
+    out4[0] = S;
+    out4[1] = 1.f / S;
+    state[0] = 0u;
+    state[1] = 0u;
 }
 
-extern "C" int isc_grad_scale(const float *const *src_host, const int64_t *numel_host, int n_src, float *out2,
+extern "C" int isc_grad_scale(const float *const *src_host, const int64_t *numel_host, int n_src, float *out4,
                               void *stream) {
-    if (!src_host || !numel_host || !out2) return ISC_E_NULL;
+    if (!src_host || !numel_host || !out4) return ISC_E_NULL;
     if (n_src < 0 || n_src > ISC_SCALE_SRC_MAX) return ISC_E_SHAPE;
     ScaleSrc s = {};
+    long long total = 0;
     for (int k = 0; k < n_src; ++k) {
         if (numel_host[k] < 0 || (numel_host[k] > 0 && !src_host[k])) return ISC_E_NULL;
         if (numel_host[k] == 0) continue;
         s.p[s.count] = src_host[k]; s.n[s.count] = numel_host[k]; ++s.count;
+        total += numel_host[k];
     }
-    hipLaunchKernelGGL(grad_scale_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, s, out2);
+    long long blocks = (total + 4095) / 4096;                 // ~16 values per thread
+    if (blocks < 1) blocks = 1;
+    if (blocks > 256) blocks = 256;
+    hipLaunchKernelGGL(grad_scale_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, s, out4);
     ISC_LAUNCH_CHECK();
     return ISC_OK;
 }

@@ -1787,6 +1787,7 @@ __global__ __launch_bounds__(512) void gemm_h3x_kernel(const DevLaunch L) {
     }
 }
 
+#define H3M_NBUF 4
 // H3 on the 64 x 128 geometry (2 x 2 waves, 32 x 64 accumulators each; linear epilogue): launches whose 128-row
 // tiling would leave CUs idle - the per-step projections with N = 512 at 4096 rows are 256 tiles of 64 x 128.
 // Per chunk: A planes 2 x 4 KB, W planes 2 x 8 KB; four buffers = 96 KB, one workgroup per CU.
@@ -1930,33 +1931,44 @@ __global__ __launch_bounds__(256) void gemm_h3m_kernel(const DevLaunch L) {
             mma(setc, I1{}, I1{});
         }
     };
-    // four buffers, three chunks in flight: these launches run one workgroup per CU, so the DMA round trip
-    // (~1 us) has to be covered by the workgroup's own prefetch depth, not by a neighbour
+    // H3M_NBUF buffers, H3M_NBUF - 1 chunks in flight: these launches run one workgroup per CU, so the DMA round trip
+    // has to be covered by the workgroup's own prefetch depth, not by a neighbour.  (Round 3: six buffers = five chunks
+    // in flight measured the same as four / three - gate sum [4096 x 512 x 1024] 31.9 us either way - so the round trip
+    // is covered; what these N = 512 launches pay is the ISSUE of their LDS-DMA pieces: six per wave and chunk against
+    // 24 MFMAs, where the 256-row kernel has 48.)
     const int nchunks = Kp / 32;
-    auto wait_for = [&](int in_flight) __attribute__((always_inline)) {   // stages that may still be outstanding
-        if (in_flight >= 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    constexpr int NBUF = H3M_NBUF, AHEAD = NBUF - 1;
+    auto wait_for = [&](int in_flight) __attribute__((always_inline)) {   // stages that may still be outstanding (6 DMAs each)
+        if (in_flight >= 4) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+        else if (in_flight == 3) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+        else if (in_flight == 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
         else if (in_flight == 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
-    stage(0);
-    if (nchunks > 1) stage(1);
-    if (nchunks > 2) stage(2);
-    wait_for((nchunks < 3 ? nchunks : 3) - 1);
+    static_assert(AHEAD <= 5 && AHEAD >= 2, "wait_for covers up to 4 younger stages");
+#pragma unroll
+    for (int q = 0; q < AHEAD; ++q)
+        if (q < nchunks) stage(q);
+    wait_for((nchunks < AHEAD ? nchunks : AHEAD) - 1);
     __syncthreads();
     lfragA(0, I0{});
     lfragB(0, I0{}, I0{});
+    int cur = 0;                                       // ring position of chunk c
     auto chunk = [&](int c, auto setc, auto nsetc) __attribute__((always_inline)) {
-        const int cur = c & 3, nxt = (c + 1) & 3;
-        if (c + 3 < nchunks) stage((c + 3) & 3);      // that buffer was last read in front of the previous barrier
+        const int nxt = cur + 1 == NBUF ? 0 : cur + 1;
+        int far = cur + AHEAD;                         // where chunk c + AHEAD goes: the buffer chunk c - 1 left,
+        if (far >= NBUF) far -= NBUF;                  // last read in front of the previous barrier
+        if (c + AHEAD < nchunks) stage(far);
         chunk_mma(cur, setc, [&]() __attribute__((always_inline)) {
             if (c + 1 < nchunks) {
-                const int last = nchunks - 1 < c + 3 ? nchunks - 1 : c + 3;
+                const int last = nchunks - 1 < c + AHEAD ? nchunks - 1 : c + AHEAD;
                 wait_for(last - (c + 1));
                 __syncthreads();
                 lfragA(nxt, nsetc);
                 lfragB(nxt, I0{}, I0{});
             }
         });
+        cur = nxt;
     };
     for (int c = 0; c < nchunks; c += 2) {
         chunk(c, I0{}, I1{});
@@ -2997,7 +3009,7 @@ template <int EPI>
 static int launch_h3_big(DevLaunch &L, hipStream_t st) {
     long long t256 = 0;
     for (int i = 0; i < L.nprob; ++i) t256 += (long long)((L.p[i].M + 255) / 256) * ((L.p[i].N + 127) / 128);
-    if (EPI != EPI_VOCAB && t256 >= 224) {
+    if (EPI != EPI_VOCAB && t256 >= 224) {        // (round 3: 160 - the three h-projections on this kernel - measured the same)
         ++g_h3x_launches;
         finish_tiling(L, 3);
         return launch_h3x<EPI>(L, st);
@@ -3007,7 +3019,7 @@ static int launch_h3_big(DevLaunch &L, hipStream_t st) {
 }
 
 static int launch_h3m(const DevLaunch &L, hipStream_t st) {
-    constexpr size_t lds = 4 * (2 * 64 * 64 + 2 * 128 * 64);             // 98304: one workgroup per CU
+    constexpr size_t lds = H3M_NBUF * (2 * 64 * 64 + 2 * 128 * 64);      // 4 x 24 KB = 98304: one workgroup per CU
     static std::atomic<bool> attr_set{false};
     if (!attr_set.load()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_h3m_kernel<false>),

@@ -576,7 +576,9 @@ def logsoftmax_bwd_sparse(dense, logp, sparse, dlogits, M, V, remap_T=0, scale=N
 
 
 def grad_scale(sources, out2):
-    """isc_grad_scale: out2 = {S, 1/S}, S the power of two that brings max |x| over `sources` into [2^-4, 2^-3)."""
+    """isc_grad_scale: out[0:2] = {S, 1/S}, S the power of two that brings max |x| over `sources` into [2^-4, 2^-3);
+    `out2` is a ZEROED float32[4] (its last two words are the reduction's state, left zeroed)."""
+    assert out2.numel() >= 4
     srcs = [x for x in sources if x is not None and x.numel() > 0]
     for x in srcs:
         assert x.dtype == torch.float32 and x.is_contiguous()

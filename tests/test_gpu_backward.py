@@ -277,16 +277,21 @@ def test_reward_loss_kernels_vs_the_reference_formula():
 
 
 def test_grad_scale_kernel_picks_the_power_of_two():
-    out = torch.empty(2, device=dev())
+    out = torch.zeros(4, device=dev())
     for vals, want in (([5e-5, -1e-9], 2.0 ** 11), ([0.0, 0.0], 1.0), ([3.0], 2.0 ** -5), ([0.124], 1.0),
                        ([0.0624], 2.0), ([float('nan'), 1e-3], 2.0 ** 6), ([float('inf')], 1.0), ([1e-30], 2.0 ** 60)):
         a = torch.tensor(vals, device=dev())
         ops.grad_scale([a[:1].contiguous(), None, a[1:].contiguous()], out)
-        S, inv = out.tolist()
+        S, inv = out[:2].tolist()
+        assert out[2:].view(torch.int32).tolist() == [0, 0]          # state words left zeroed
         assert S == want and inv == 1.0 / want, (vals, S, want)
         finite = [abs(v) for v in vals if np.isfinite(v) and v != 0]
         if finite and want not in (1.0, 2.0 ** 60) or vals == [0.124]:
             assert 2.0 ** -4 <= max(finite) * S < 2.0 ** -3
+    big = torch.rand(3_000_000, device=dev()) * 1e-6                  # many workgroups: same answer as one
+    big[1_234_567] = -7.0e-4
+    ops.grad_scale([big, None, big[:5].contiguous()], out)
+    assert out[:2].tolist() == [2.0 ** 7, 2.0 ** -7] and out[2:].view(torch.int32).tolist() == [0, 0]
 
 
 def test_sparse_dlogp_handover_equals_the_dense_tensor_bit_for_bit():
