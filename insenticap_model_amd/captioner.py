@@ -113,6 +113,10 @@ class Captioner(nn.Module):
         # a one-element list so that the finalizer below sees renewals
         self._wnonce = [next(_INSTANCE_NONCE)]
         weakref.finalize(self, _forget_instance, self._wnonce)
+        # Beam searches are served from captured HIP graphs by default (round 3): a search geometry seen twice is
+        # captured on its second call and replayed from then on - bit-identical results, 2.3 instead of 2.6 ms for a
+        # single-image beam-5 search.  enable_beam_graphs(False) turns it off (320 MB of graph buffers per captioner).
+        self._beam_graphs, self._beam_graphs_max = {}, 4
 
     # ------------------------------------------------------------------ plumbing
     def _p(self):

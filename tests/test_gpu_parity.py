@@ -438,6 +438,8 @@ def test_beam_search_from_hip_graphs_equals_the_eager_search():
         return out, cap.last_beam_steps
     cases = [slice(i, i + 1) for i in range(n)] + [slice(0, 3)]
     eos = cap.eos_id
+    assert cap._beam_graphs is not None              # round 3: serving from graphs is the default ...
+    cap.enable_beam_graphs(False)                    # ... the eager reference switches it off
     try:
         eager = [search(sl) for sl in cases]
         cap.eos_id = -7
@@ -470,7 +472,7 @@ def test_beam_search_from_hip_graphs_equals_the_eager_search():
             np.testing.assert_array_equal(np.asarray(got[0][1]), np.asarray(ref2[0][1]))
     finally:
         cap.eos_id = eos
-        cap.enable_beam_graphs(False)
+        cap.enable_beam_graphs(True)
 
 
 @pytest.mark.parametrize('rows,V,beam', [(5, 10000, 5), (7, 9487, 3), (3, 130, 8), (2, 10000, 12)])
