@@ -221,6 +221,29 @@ typedef struct {
 
 int isc_attn_scan_fwd(const isc_scan_problem *probs_host, int n_prob, int B, void *stream);
 
+/* Both scans, the gate sum and the gate mix of one decode step (captioner.py:96-118) in ONE launch (few rows, inference):
+ * G[i] holds the rows of scan i's V carried through the gate's projection - G[0][b,r,:] = cont2att.weight V_c[b,r,:],
+ * G[1] = senti2att.weight V_s rows (a table indexed by scan[1].row_ids in gather mode), no bias - so that
+ *   z = zh + (b_gc + sum_r alpha_r G[0][b,r,:]) + (b_gs + sum_m alpha'_m G[1][.,:]) = h2att(h) + cont2att(v) + senti2att(s),
+ *   beta = sigmoid(w_gate . tanh(z) + *b_gate),  f = beta v + (1 - beta) s
+ * come out of the scan's own attention weights: the step's gate GEMM and gate-mix launches disappear, for R x A more
+ * floats streamed per row (why the host uses it for few rows only).  scan[0] = content, scan[1] = sentiment words; their
+ * .out / planes are optional here (v and s are only needed through f); A == D <= 1024 for both; zh [B,A] is the h-term
+ * incl. its bias.  alpha outputs as in isc_attn_scan_fwd. */
+typedef struct {
+    isc_scan_problem scan[2];
+    const float *G[2];
+    const float *zh;
+    const float *b_gc, *b_gs;     /* [A] biases of cont2att / senti2att */
+    const float *w_gate;          /* [A] attention.att_alpha.weight */
+    const float *b_gate;          /* device scalar or NULL */
+    float *f;                     /* [B,D] */
+    void *f_hi, *f_lo;            /* optional planes of f */
+    float *beta;                  /* optional, row stride beta_ld */
+    int64_t beta_ld;
+} isc_scan_gate_args;
+int isc_attn_scan_gate_fwd(const isc_scan_gate_args *args_host, int B, void *stream);
+
 /* Gate fusion (captioner.py:111-117): beta = sigmoid(w . tanh(z[b,:]) + *w_bias);
  * out = beta*v + (1-beta)*s.  z = cont2att(v)+senti2att(s)+h2att(h) from isc_linear_fwd. */
 int isc_gate_mix_fwd(const float *z, const float *w, const float *w_bias, const float *v,
@@ -378,6 +401,10 @@ typedef struct {
      * [V,A] / [V,W] tables and words_ids [rows, Mw] (row stride words_ids_ld) the word ids incl. the leading <PAD>. */
     const int64_t *words_ids;
     int64_t words_ids_ld;
+    /* Optional (few rows, inference; both attentions): the scans' features through the gate's projection -
+     * gate_Gc [rows,R,A] = cont2att.weight att_e rows, gate_Gs = senti2att.weight words_e rows ([rows,Mw,A], or the
+     * [V,A] table in gather mode).  Both non-NULL: scans + gate sum + gate mix run as isc_attn_scan_gate_fwd. */
+    const float *gate_Gc, *gate_Gs;
 } isc_step_plan;
 
 int isc_step_fwd(const isc_step_plan *plan_host, void *stream);

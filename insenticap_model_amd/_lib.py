@@ -55,6 +55,12 @@ class ScanBwdProblem(C.Structure):
                 ('de_out', C.c_void_p)]
 
 
+class ScanGateArgs(C.Structure):
+    _fields_ = [('scan', ScanProblem * 2), ('G', C.c_void_p * 2), ('zh', C.c_void_p), ('b_gc', C.c_void_p),
+                ('b_gs', C.c_void_p), ('w_gate', C.c_void_p), ('b_gate', C.c_void_p), ('f', C.c_void_p),
+                ('f_hi', C.c_void_p), ('f_lo', C.c_void_p), ('beta', C.c_void_p), ('beta_ld', C.c_int64)]
+
+
 def _f(names, ctype):
     return [(n, ctype) for n in names.split()]
 
@@ -74,7 +80,8 @@ class StepPlan(C.Structure):
                  ('pmax', C.c_void_p), ('psum', C.c_void_p), ('pidx', C.c_void_p),
                  ('splitk_ws', C.c_void_p), ('splitk_ws_floats', C.c_int64)] +
                 _f('h1_prev_hi h1_prev_lo h2_prev_hi h2_prev_lo h1_hi h1_lo h2_hi h2_lo '
-                   'v_hi v_lo s_hi s_lo f_hi f_lo words_ids', C.c_void_p) + [('words_ids_ld', C.c_int64)])
+                   'v_hi v_lo s_hi s_lo f_hi f_lo words_ids', C.c_void_p) + [('words_ids_ld', C.c_int64)] +
+                _f('gate_Gc gate_Gs', C.c_void_p))
 
 
 class StepBwdPlan(C.Structure):
@@ -136,6 +143,7 @@ SIGNATURES = {
     'isc_logsoftmax_apply_steps': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                              C.c_void_p, C.c_void_p]),
     'isc_attn_scan_fwd': (C.c_int, [C.POINTER(ScanProblem), C.c_int, C.c_int, C.c_void_p]),
+    'isc_attn_scan_gate_fwd': (C.c_int, [C.POINTER(ScanGateArgs), C.c_int, C.c_void_p]),
     'isc_gate_mix_fwd': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                    C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                    C.c_void_p]),

@@ -221,7 +221,7 @@ class _Search:
         n_img = fc_feats.shape[0]
         P = cap._prologue(p, 'beam', fc_feats, att_feats, None, senti_words,
                           senti_labels if senti_words is not None else None, want_table='build',
-                          words_table=getattr(cap, 'words_table', True))
+                          words_table=getattr(cap, 'words_table', True), gate_rows=fc_feats.shape[0] * beam)
         dev = cap._dev
         H, Wd, V = cap.att_lstm.hidden_size, cap.settings['word_emb_dim'], cap.vocab_size
         rows = n_img * beam
@@ -239,6 +239,11 @@ class _Search:
                 setattr(Pb, name, expand(getattr(P, name)))
         Pb.words_ids = expand(P.words_ids)
         Pb.tab = P.tab
+        # gated scan (few rows): per-region projections follow the regions, the word table is shared
+        gc, gs = getattr(P, 'gate_Gc', None), getattr(P, 'gate_Gs', None)
+        if gc is not None:
+            Pb.gate_Gc = expand(gc.view(n_img, P.R, -1)).view(rows * P.R, -1)
+            Pb.gate_Gs = gs if P.words_ids is not None else expand(gs.view(n_img, P.Mw, -1)).view(rows * P.Mw, -1)
         self.cap, self.p, self.Pb = cap, p, Pb
         self.n_img, self.beam, self.T, self.rows, self.dc = n_img, beam, T, rows, decoding_constraint
         self.ws = cap._alloc_step_ws(rows, Pb)

@@ -55,6 +55,8 @@ class _Pro:
     label_w = None   # [B,A]   label2word(label_e): step-invariant term of the senti attention
     pre1 = None      # [B,4H]  fc_e W_fc^T + label_e W_x^T + b_ih + b_hh: step-invariant att-LSTM input
     tab = None       # [V,4H]  relu(Emb) W_x^T (inference only): replaces the word-embedding K-segment
+    gate_Gc = None   # [B*R,A] att_e through cont2att.weight (few-row inference: isc_attn_scan_gate_fwd)
+    gate_Gs = None   # [B*M,A] / [V,A] words_e through senti2att.weight
     B = R = Mw = 0
     # kept for the backward pass: raw inputs, ids and dropout keep-masks
     x_fc = x_att = cmean = cpt = cpt_ids = label_ids = sw_ids = None
@@ -180,10 +182,15 @@ class Captioner(nn.Module):
         return f
 
     # ------------------------------------------------------------------ prologue
+    GATE_FUSED_MAX_ROWS = 768      # decode rows up to which scans + gate sum + gate mix run as ONE launch (inference)
+
     def _prologue(self, p, mode, fc=None, att=None, cpt_words=None, senti_words=None, senti_labels=None,
-                  masks=None, want_table=False, words_table=False):
+                  masks=None, want_table=False, words_table=False, gate_rows=0):
         """want_table: False | 'cached' (use the embedding table only if already built) | 'build'.
-        words_table: serve the sentiment words from the vocabulary-sized tables (no dropout on them, no autograd)."""
+        words_table: serve the sentiment words from the vocabulary-sized tables (no dropout on them, no autograd).
+        gate_rows: number of decode rows of an INFERENCE call (0: training / not applicable): up to
+        GATE_FUSED_MAX_ROWS the scans' features are also carried through the gate's projections here, once, so that
+        every decode step runs scans + gate sum + gate mix as one launch (isc_attn_scan_gate_fwd)."""
         P = _Pro()
         st = self.settings
         E, A, Wd = st['feat_emb_dim'], st['att_hid_dim'], st['word_emb_dim']
@@ -267,6 +274,19 @@ class Captioner(nn.Module):
             P.words_e3, P.words_p3 = words_e.view(B, P.Mw, Wd), words_p.view(B, P.Mw, A)
         if second:
             ops.linear_fwd(second)
+        if (0 < gate_rows <= self.GATE_FUSED_MAX_ROWS and getattr(self, 'gate_fused', True) and masks is None
+                and P.att_e3 is not None and P.words_e3 is not None and A == E == Wd and A <= 1024):
+            # G_c = att_e cont2att.weight^T per region; G_s = words_e senti2att.weight^T per word (or per vocabulary
+            # entry in table mode) - no bias: the biases are added once, with the h-term, inside the kernel
+            P.gate_Gc = self._new(B * R, A)
+            gl = [ops.linear_problem([(P.att_e3.view(B * R, E), p['attention.cont2att.weight'])], P.gate_Gc)]
+            if P.words_ids is not None:
+                P.gate_Gs = self._gate_senti_table(p, P.words_e3)
+            else:
+                P.gate_Gs = self._new(B * P.Mw, A)
+                gl.append(ops.linear_problem([(P.words_e3.view(B * P.Mw, Wd), p['attention.senti2att.weight'])],
+                                             P.gate_Gs))
+            ops.linear_fwd(gl)
         # Hoist the step-invariant inputs of the att-LSTM (captioner.py:174: cat[h_lang, fc, xt] with
         # xt = relu(Emb[it]) + label_e): fc_e W_fc^T + label_e W_x^T + b_ih + b_hh is computed once.
         H = st['rnn_hid_dim']
@@ -294,6 +314,19 @@ class Captioner(nn.Module):
         ops.linear_fwd([ops.linear_problem([(act, W2)], proj, b2, relu=True)])
         self._senti_tab_cache = (key, (act, proj))
         return act, proj
+
+    def _gate_senti_table(self, p, act):
+        """relu(Emb) attention.senti2att.weight^T [V,A]: the sentiment-word table carried through the gate's projection
+        (isc_attn_scan_gate_fwd), cached until the embedding or that weight change."""
+        emb, Wg = p['word_embed.0.weight'], p['attention.senti2att.weight']
+        key = (emb.data_ptr(), emb._version, Wg.data_ptr(), Wg._version, ops.WEIGHT_EPOCH)
+        cached = getattr(self, '_gate_tab_cache', None)
+        if cached is not None and cached[0] == key:
+            return cached[1]
+        tab = self._new(act.shape[0], Wg.shape[0])
+        ops.linear_fwd([ops.linear_problem([(act, Wg)], tab)])
+        self._gate_tab_cache = (key, tab)
+        return tab
 
     def _embedding_table(self, p, build):
         """relu(Emb) W_x^T [V,4H], cached until the embedding or the att-LSTM weights change
@@ -420,6 +453,7 @@ class Captioner(nn.Module):
         pl.logits, pl.ld_logits = (logits.data_ptr(), logits.stride(0)) if logits is not None else (None, 0)
         pl.apply_logsoftmax = int(normalize)
         pl.pmax, pl.psum, pl.pidx = ws['pmax'].data_ptr(), ws['psum'].data_ptr(), ws['pidx'].data_ptr()
+        pl.gate_Gc, pl.gate_Gs = ptr(getattr(P, 'gate_Gc', None)), ptr(getattr(P, 'gate_Gs', None))
         ops.step_fwd(pl)
 
     def _step_py(self, p, P, ws, xt, h_cur, c_cur, h_nxt, c_nxt, alpha_c=None, alpha_s=None, beta=None,
@@ -468,8 +502,17 @@ class Captioner(nn.Module):
             probs.append(ops.linear_problem([(h1, p['attention.h2att.weight'], pn(0))], ws['z'],
                                             p['attention.h2att.bias']))
         ops.linear_fwd(probs)
-        ops.attn_scan_fwd(scans, rows)
-        if gate:
+        fused_gate = gate and getattr(P, 'gate_Gc', None) is not None and getattr(P, 'gate_Gs', None) is not None
+        if fused_gate:       # few rows, inference: scans + gate sum + gate mix in one launch (as the step plan does)
+            ops.attn_scan_gate_fwd(scans, (P.gate_Gc, P.gate_Gs), ws['z'], p['attention.cont2att.bias'],
+                                   p['attention.senti2att.bias'], p['attention.att_alpha.weight'],
+                                   p['attention.att_alpha.bias'], ws['f'], beta, f_planes=wp('f'))
+            feat, featp = ws['f'], wp('f')
+        else:
+            ops.attn_scan_fwd(scans, rows)
+        if fused_gate:
+            pass
+        elif gate:
             # z = cont2att(v) + senti2att(s) + h2att(h1) (captioner.py:107-110): add the v / s terms
             ops.linear_fwd([ops.linear_problem(
                 [(ws['v'], p['attention.cont2att.weight'], wp('v')),
@@ -706,7 +749,8 @@ class Captioner(nn.Module):
         if not torch.is_grad_enabled() or not any(q.requires_grad for q in self.parameters()):
             want = 'build' if n_rows * T >= self.vocab_size // 4 else 'cached'
         P = self._prologue(p, 'rl', fc_feats, att_feats, cpt_words, senti_words, senti_labels, masks,
-                           want_table=want, words_table=bool(want) and getattr(self, 'words_table', True))
+                           want_table=want, words_table=bool(want) and getattr(self, 'words_table', True),
+                           gate_rows=n_rows if want else 0)
         ops.TIMER.armed, ops.TIMER.phase = False, 'step'
         B, V = P.B, self.vocab_size
         H, Wd = self.att_lstm.hidden_size, self.settings['word_emb_dim']

