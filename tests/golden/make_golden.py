@@ -546,7 +546,32 @@ def case_det_train():
     for k, q in cap.named_parameters():          # what .grad holds after the call: iteration 2's gradient, clamped
         if q.grad is not None:
             out['dt/grad2/' + k] = q.grad.detach().numpy().copy()
+    # the FIRST iteration alone (a fresh Detector, the same weights and seed: the same draws as iteration 1 above): the
+    # CPU oracle checks its loss dictionary without having to replay an optimiser step in between
+    det1 = Detector(idx2word, Tn, synth.SENTIMENT_CATEGORIES, {'cap_lr': 4e-4}, st)
+    det1.captioner.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_weights(V, st, seed=1).items()})
+    for name, mod, seed in (('senti_detector', det1.senti_detector, 51), ('sent_senti_cls', det1.sent_senti_cls, 52)):
+        shapes = {k: tuple(v.shape) for k, v in mod.state_dict().items()}
+        mod.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_module_weights(shapes, seed).items()})
+    det1.set_ciderd_scorer(split)
+    rec = {}
+    o_rl1 = det1.captioner.forward_rl
+
+    def spy_rl1(*a, **k):
+        r = o_rl1(*a, **k)
+        key = 'greedy' if k.get('sample_max', a[-1] if len(a) >= 7 else 1) else 'sample'
+        rec[key] = [x.detach().numpy().copy() for x in r]
+        return r
+    det1.captioner.forward_rl = spy_rl1
+    torch.manual_seed(4242)
+    losses1 = det1(([tens(batches[0])], scs), 'fact', True)
+    det1.captioner.forward_rl = o_rl1
+    for k, v in losses1.items():
+        out['dt1/loss_' + k] = np.array([v], dtype=np.float64)
+    out['dt1/sample_seq'], out['dt1/sample_logprobs'], out['dt1/sample_masks'] = rec['sample']
+    out['dt1/greedy_seq'] = rec['greedy'][0]
     print({k: round(v, 5) for k, v in losses.items()}, 'tokens replaced by scheduled sampling:', sampled)
+    print('iteration 1 alone:', {k: round(v, 5) for k, v in losses1.items()})
     np.savez_compressed(os.path.join(HERE, 'det_train.npz'), **out)
     print('det_train: %d arrays' % len(out))
 

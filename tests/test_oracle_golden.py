@@ -229,3 +229,61 @@ def test_beam5_all_64_images_oracle_vs_reference(golden):
                                         tt(d, 'senti_words')[i], tt(d, 'senti_labels')[i:i + 1], 5, 1, 20)
         assert list(caps) == [str(x) for x in g['beam/beam5_senti1_caps'][i]], i
         np.testing.assert_allclose(scores, g['beam/beam5_senti1_scores'][i], atol=1e-4)
+
+
+def test_oracle_reproduces_the_references_first_rl_training_iteration(golden):
+    """models/decoder.py:52-167 for ONE 'fact' batch in training mode (tests/golden/det_train.npz, `dt1/*`: a fresh
+    reference Detector, dropout 0): with the reference's multinomial draws and scheduled-sampling tokens replayed, the
+    oracle (captioner restatement + CIDEr-D restatement + the frozen helper nets) reproduces the sampled and greedy
+    roll-outs and all seven entries of the loss dictionary.  (The GPU test replays the same fixture through the product.)"""
+    from insenticap_model_amd.helper_nets import SentenceSentimentClassifier, SentimentDetector
+    from insenticap_model_amd.rewards import get_cls_reward
+    from oracle.ciderd_oracle import CiderDOracle
+    from test_detector import load_helper
+    g = golden('det_train')
+    V, Tn, B = 64, 8, 4
+    st = dict(synth.TINY_SETTINGS, **synth.HELPER_SETTINGS)
+    st['dropout_p'] = 0.0
+    idx2word = synth.make_idx2word(V)
+    ids = ids_for(V)
+    p = O.to_params(synth.make_weights(V, st, seed=1))
+    senti_det = load_helper(SentimentDetector(synth.SENTIMENT_CATEGORIES, st), 51)
+    sent_cls = load_helper(SentenceSentimentClassifier(idx2word, synth.SENTIMENT_CATEGORIES, st), 52)
+    batches, split = synth.make_rl_batches(2, B, V, st, seq_len=Tn)
+    fns, fc, att, (caps, lengths), cpts, sentis, gts = batches[0]
+    t = torch.from_numpy
+    fc, att, caps, cpts, sentis = t(fc), t(att), t(caps), t(cpts), t(sentis)
+    n_data = 2                                    # the reference divides by len(data) = len((fact, seq2seq)) = 2
+    with torch.no_grad():
+        labels = senti_det.sample(att, 0.7)[0]
+        att3 = att.reshape(B, -1, att.shape[-1])
+        draws = t(g['dt/draws0'])
+        seq, lp, mk, P, _, _ = O.forward_rl(p, ids, fc, att3, cpts, sentis, labels, Tn, 0, replay=draws)
+        gseq, _, gmk, _, _, _ = O.forward_rl(p, ids, fc, att3, cpts, sentis, labels, Tn, 1)
+    n_steps = g['dt1/sample_seq'].shape[1]
+    assert (seq.numpy()[:, :n_steps] == g['dt1/sample_seq']).all() and (gseq.numpy()[:, :g['dt1/greedy_seq'].shape[1]] == g['dt1/greedy_seq']).all()
+    np.testing.assert_allclose(lp.numpy()[:, :n_steps], g['dt1/sample_logprobs'], atol=2e-5)
+    np.testing.assert_allclose(mk.numpy()[:, :n_steps], g['dt1/sample_masks'])
+    got = {'da_loss': float(O.domain_align_loss(P.cpt, P.fc_raw)) / n_data}
+    # CIDEr-D reward: document frequencies over every image of the split, references of this batch
+    allcaps = {}
+    for v in split.values():
+        allcaps.update(v)
+    cd = CiderDOracle(list(allcaps.values()), ids.sos, ids.eos)
+    fact = np.array(cd.self_critical_reward(seq.numpy(), gseq.numpy(), [gts[fn] for fn in fns]))
+    got['fact_reward'] = float(fact.mean()) / n_data
+    cls = get_cls_reward(seq, mk, gseq, gmk, labels, sent_cls, on_device=True)
+    got['cls_reward'] = float(cls.mean(-1).mean(-1)) / n_data
+    rewards = torch.from_numpy(np.repeat(fact[:, None], Tn, 1)).float() + 0.4 * cls
+    got['all_rewards'] = float(rewards.mean(-1).mean(-1)) / n_data
+    got['cap_loss'] = float(O.reward_criterion(lp, mk, rewards)) / n_data
+    with torch.no_grad():
+        xl = sent_cls(caps[:, 1:], lengths)[0].softmax(dim=-1).argmax(dim=-1)
+        logp, _, _ = O.forward_xe(p, ids, fc, att3, cpts, caps, xl, fed_tokens=t(g['dt/fed_xe0']))
+        got['xe_loss'] = float(O.xe_criterion(logp, caps[:, 1:], list(lengths))) / n_data
+        s = synth.make_inputs(3, V, st, regions=6, seq_len=Tn, seed=77)
+        logp2, _, _ = O.forward_seq2seq(p, ids, t(s['captions']), t(s['cpt_words']), t(s['senti_words']),
+                                        t(s['senti_labels']), fed_tokens=t(g['dt/fed_s2s0']))
+        got['seq2seq_loss'] = float(O.xe_criterion(logp2, t(s['captions'])[:, 1:], list(s['lengths']))) / n_data
+    for k, v in got.items():
+        np.testing.assert_allclose(v, g['dt1/loss_' + k][0], rtol=2e-4, atol=2e-6, err_msg=k)
