@@ -365,6 +365,26 @@ __global__ __launch_bounds__(256) void rollout_finalize_kernel(const DevRollout 
     }
 }
 
+// Many rows: sixteen waves per workgroup, ONE row per wave (every row's dependent chain - two strided sweeps, a dozen
+// cross-lane steps, logf, stores - runs at the same time as all the others) and still one `alive` atomic per 16 rows.
+// (Round 3: the four-rows-per-wave form of rounds 1-2 walked its rows one after the other: 16.8 us at B = 4096.)
+__global__ __launch_bounds__(1024) void rollout_finalize_wide_kernel(const DevRollout R) {
+    __shared__ int cnt[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (R.alive[R.t] == 0) return;          // block-uniform
+    const int b = blockIdx.x * 16 + wave;
+    int alive = 0;
+    if (b < R.B) alive = rollout_finalize_row(R, b, lane);
+    if (lane == 0) cnt[wave] = alive;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int tot = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) tot += cnt[w];
+        if (tot) atomicAdd(&R.alive[R.t + 1], tot);
+    }
+}
+
 extern "C" int isc_rollout_finalize(const isc_rollout_step *s, void *stream) {
     if (!s) return ISC_E_NULL;
     if (!s->part_max || !s->part_sum || !s->part_idx || !s->seq || !s->seq_logprobs || !s->seq_masks ||
@@ -379,11 +399,12 @@ extern "C" int isc_rollout_finalize(const isc_rollout_step *s, void *stream) {
     R.eos_id = s->eos_id; R.seq = s->seq; R.seq_logprobs = s->seq_logprobs; R.seq_masks = s->seq_masks;
     R.unfinished = s->unfinished; R.alive = s->alive; R.raw_tokens = s->raw_tokens;
     R.emb = s->emb; R.xt_add = s->xt_add; R.xt_next = s->xt_next;
-    // few rows: one per wavefront (a wave walking 4 rows in turn is 12 us at B=4); many rows: 4 per wave, so that the
-    // `alive` counter sees one atomic per 16 rows
-    R.rows_per_wave = s->B <= 1024 ? 1 : ISC_FIN_ROWS_PER_WAVE;
-    hipLaunchKernelGGL(rollout_finalize_kernel, dim3((s->B + 4 * R.rows_per_wave - 1) / (4 * R.rows_per_wave)),
-                       dim3(256), 0, (hipStream_t)stream, R);
+    // one row per wavefront; many rows: 16 waves per workgroup, so that the `alive` counter sees one atomic per 16 rows
+    R.rows_per_wave = 1;
+    if (s->B > 1024)
+        hipLaunchKernelGGL(rollout_finalize_wide_kernel, dim3((s->B + 15) / 16), dim3(1024), 0, (hipStream_t)stream, R);
+    else
+        hipLaunchKernelGGL(rollout_finalize_kernel, dim3((s->B + 3) / 4), dim3(256), 0, (hipStream_t)stream, R);
     ISC_LAUNCH_CHECK();
     return ISC_OK;
 }
