@@ -439,13 +439,13 @@ def bench_beam(cap, inputs, n_img=64, beam=5):
                            batched_images_per_s=round(n_img / el, 1)))
 
 
-PMC_SUMMARY = os.path.join(ROOT, 'profiles', 'r03_a_pmc_summary_B4096.json')
+PMC_SUMMARY = os.path.join(ROOT, 'profiles', 'r03_c_pmc_summary_B4096.json')
 # bench kernel label -> device symbols it may run as (first one present in the PMC summary wins)
 KERNEL_SYMBOL = {'vocab[': ['void gemm_h3_kernel<2, false>', 'void gemm_h3_kernel<2>', 'void gemm_ld_kernel<2>', 'void gemm_kernel<4, 1, 4, 2, false, false>'],
                  'lstm[4096x2048x1536': ['void gemm_h3x_kernel<1, false>', 'void gemm_h3x_kernel<1>', 'void gemm_h3_kernel<1>', 'void gemm_xl_kernel<1>'],
                  'lstm[': ['void gemm_h3x_kernel<1, false>', 'void gemm_h3x_kernel<1>', 'void gemm_h3_kernel<1>', 'void gemm_ld_kernel<1>', 'void gemm_kernel<4, 1, 4, 1, false, false>', 'void gemm_xl_kernel<1>'],
                  'attn_scan[': ['void attn_scan_kernel<2, true>', 'void attn_scan_kernel<2, false>', 'void attn_scan_kernel<2>'], 'gate_mix[': ['gate_mix_kernel'],
-                 'rollout_finalize[': ['rollout_finalize_kernel']}
+                 'rollout_finalize[': ['rollout_finalize_wide_kernel', 'rollout_finalize_kernel']}
 
 
 def pmc_traffic(name, batch):
