@@ -164,8 +164,10 @@ def _graphed_search(cap, fc_feats, att_feats, senti_words, senti_labels, beam, d
     <= ceil(T / CHUNK) graph launches with one counter read between them, and the read-back."""
     dev = cap._dev
     ins = [cap._f32(fc_feats), cap._f32(att_feats), senti_words, senti_labels]
+    # (the cached tables a captured graph points at are functions of these weights: token table, sentiment-word tables,
+    # and - gated scan - the sentiment-word table through attention.senti2att)
     versions = tuple(q._version for q in (cap.word_embed[0].weight, cap.att_lstm.weight_ih, cap.senti2att[0].weight,
-                                          cap.senti2att[0].bias))
+                                          cap.senti2att[0].bias, cap.attention.senti2att.weight))
     key = (tuple(None if x is None else (tuple(x.shape), x.dtype) for x in ins), beam, decoding_constraint, T, versions,
            ops.WEIGHT_EPOCH, cap.eos_id, torch.cuda.current_device())
     cache = cap._beam_graphs

@@ -662,8 +662,9 @@ class Captioner(nn.Module):
     def _graphed_rollout(self, fc_feats, att_feats, cpt_words, senti_words, senti_labels, T):
         emb, Wih = self.word_embed[0].weight, self.att_lstm.weight_ih
         ins = [self._f32(fc_feats), self._f32(att_feats), cpt_words, senti_words, senti_labels]
-        key = (tuple((tuple(x.shape), x.dtype) for x in ins), T, emb._version, Wih._version, ops.WEIGHT_EPOCH,
-               torch.cuda.current_device())
+        key = (tuple((tuple(x.shape), x.dtype) for x in ins), T, emb._version, Wih._version,
+               self.senti2att[0].weight._version, self.senti2att[0].bias._version,
+               self.attention.senti2att.weight._version, ops.WEIGHT_EPOCH, torch.cuda.current_device())
         cache = self._rollout_graphs
         entry = cache.get(key)
         if entry is None:                       # first sight: run eagerly (warms kernels and one-time attributes)

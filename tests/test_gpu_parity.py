@@ -470,6 +470,17 @@ def test_beam_search_from_hip_graphs_equals_the_eager_search():
             got = search(cases[1])
             assert got[0][0] == ref2[0][0] and got[1] == ref2[1]
             np.testing.assert_array_equal(np.asarray(got[0][1]), np.asarray(ref2[0][1]))
+        # a weight behind a CACHED table changes in place (the gate's sentiment-word table, round 3): the graphs
+        # captured with the old table must not be replayed - the key carries that weight's version
+        with torch.no_grad():
+            cap.attention.senti2att.weight.mul_(1.5)
+        graphs, cap._beam_graphs = cap._beam_graphs, None
+        ref3 = search(cases[1])
+        cap._beam_graphs = graphs
+        for rep in range(3):                                   # first sight (eager), capture, replay
+            got = search(cases[1])
+            assert got[0][0] == ref3[0][0] and got[1] == ref3[1], rep
+            np.testing.assert_array_equal(np.asarray(got[0][1]), np.asarray(ref3[0][1]))
     finally:
         cap.eos_id = eos
         cap.enable_beam_graphs(True)
