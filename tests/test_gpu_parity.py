@@ -663,3 +663,58 @@ def test_gated_scan_equals_scans_plus_gate_gemm_plus_gate_mix():
     np.testing.assert_allclose(outs[True][1].numpy(), outs[False][1].numpy(), atol=2e-5)
     assert outs[True][2] == outs[False][2]
     np.testing.assert_allclose(outs[True][3], outs[False][3], atol=2e-5)
+
+
+@pytest.mark.parametrize('B,R,M,A,table', [(3, 1, 1, 64, False), (5, 196, 3, 256, True), (2, 7, 11, 1024, False),
+                                           (1, 36, 11, 512, True), (9, 13, 40, 128, False)])
+def test_gated_scan_odd_shapes_vs_fp64(B, R, M, A, table):
+    """isc_attn_scan_gate_fwd on shapes away from the decoder's (one region, one word, A = 64 ... 1024, per-caption and
+    gathered sentiment features) against the defining formulas in fp64."""
+    g = torch.Generator().manual_seed(B * 1000 + R)
+    D_ = dev()
+    r = lambda *s: (torch.rand(*s, generator=g) * 2 - 1)
+    Vn = 50
+    att_p, att_e = r(B, R, A), torch.relu(r(B, R, A))
+    if table:
+        w_p, w_e = torch.relu(r(Vn, A)), torch.relu(r(Vn, A))
+        ids = torch.randint(0, Vn, (B, M), generator=g)
+        P_s, E_s = w_p[ids], w_e[ids]                         # [B,M,A] views for the reference
+    else:
+        w_p, w_e = torch.relu(r(B, M, A)), torch.relu(r(B, M, A))
+        ids, P_s, E_s = None, w_p, w_e
+    qa, qw, q2, zh = r(B, A), r(B, A), r(B, A), r(B, A)
+    wc, ws_, wg = r(1, A) * 0.2, r(1, A) * 0.2, r(1, A) * 0.2
+    bc, bs, bg = r(1), r(1), r(1)
+    Wgc, Wgs = r(A, A) * A ** -0.5, r(A, A) * A ** -0.5
+    bgc, bgs = r(A), r(A)
+    d = lambda x: x.double()
+    ec = (torch.tanh(d(att_p) + d(qa)[:, None]) * d(wc)).sum(-1) + d(bc)
+    es = (torch.tanh(d(P_s) + (d(qw) + d(q2))[:, None]) * d(ws_)).sum(-1) + d(bs)
+    ac, as_ = torch.softmax(ec, -1), torch.softmax(es, -1)
+    v, s = (ac[..., None] * d(att_e)).sum(1), (as_[..., None] * d(E_s)).sum(1)
+    z = d(zh) + v @ d(Wgc).t() + d(bgc) + s @ d(Wgs).t() + d(bgs)
+    beta = torch.sigmoid((torch.tanh(z) * d(wg)).sum(-1, keepdim=True) + d(bg))
+    f = beta * v + (1 - beta) * s
+    # device: G tensors by fp64 then rounded (the kernel under test is the scan, not the projection GEMM)
+    Gc = (d(att_e) @ d(Wgc).t()).float().to(D_).contiguous().view(B * R, A)
+    if table:
+        Gs = (d(w_e) @ d(Wgs).t()).float().to(D_).contiguous()
+    else:
+        Gs = (d(w_e) @ d(Wgs).t()).float().to(D_).contiguous().view(B * M, A)
+    keep = []                                          # (scan_problem keeps raw pointers: hold the device copies)
+
+    def T_(x):
+        keep.append(x.to(D_).contiguous())
+        return keep[-1]
+    out_v, out_s = torch.empty(B, A, device=D_), torch.empty(B, A, device=D_)
+    aC, aS = torch.empty(B, R, device=D_), torch.empty(B, M, device=D_)
+    f2, b2 = torch.empty(B, A, device=D_), torch.empty(B, 1, device=D_)
+    scans = [ops.scan_problem(T_(att_p), T_(att_e), T_(qa), T_(wc), T_(bc), out_v, aC),
+             ops.scan_problem(T_(w_p), T_(w_e), T_(qw), T_(ws_), T_(bs), out_s, aS, q2=T_(q2),
+                              row_ids=None if ids is None else T_(ids))]
+    ops.attn_scan_gate_fwd(scans, (Gc, Gs), T_(zh), T_(bgc), T_(bgs), T_(wg), T_(bg), f2, b2)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(aC.cpu().numpy(), ac.float().numpy(), atol=3e-6)
+    np.testing.assert_allclose(aS.cpu().numpy(), as_.float().numpy(), atol=3e-6)
+    np.testing.assert_allclose(b2.cpu().numpy(), beta.float().numpy(), atol=5e-6)
+    np.testing.assert_allclose(f2.cpu().numpy(), f.float().numpy(), atol=1e-5)
