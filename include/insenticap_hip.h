@@ -578,7 +578,7 @@ int64_t isc_h3_weights_workspace_bytes(int64_t weight_elements, int with_transpo
  * Either means an operand left the split-f16 domain |x| < 65504 (its hi plane is inf) or was NaN / inf on entry (the
  * linear epilogues' ReLU lets NaN through, as torch's does, so it reaches the statistics); results since the last clean
  * read are not to be trusted.  isc_set_h3_mode(0) runs the exact-fp32 tiles, whose domain is fp32's.
- * reset != 0 clears the words when any bit was set. */
+ * reset != 0 clears the words when any bit was set.  Both calls act on the CURRENT device (hipGetDevice). */
 #define ISC_STATUS_NONFINITE_STATS 1
 #define ISC_STATUS_NONFINITE_LINEAR 2
 int isc_set_status_words(unsigned int *host_words2);
