@@ -580,6 +580,7 @@ def test_features_beyond_the_split_f16_domain_are_reported_not_decoded_silently(
     torch.cuda.synchronize()
     st_bits = ops.device_status(reset=False)
     assert st_bits & ops.STATUS_NONFINITE_STATS, st_bits          # the NaN reached the step's vocabulary statistics
+    assert _lib.load().isc_status(0) == st_bits                   # the C entry point reads the same words
     assert st_bits & ops.STATUS_NONFINITE_LINEAR, st_bits
     with pytest.raises(_lib.HipLibraryError, match='split-f16 domain'):
         ops.check_numerics('test')
