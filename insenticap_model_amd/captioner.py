@@ -747,24 +747,11 @@ class Captioner(nn.Module):
         # frozen weights + enough token-steps: the relu(Emb) W_x^T table pays for itself (21 GFLOP once)
         n_rows = fc_feats.shape[0]
         want = False
-        words_table = False
         if not torch.is_grad_enabled() or not any(q.requires_grad for q in self.parameters()):
-            # The vocabulary-sized tables (token table 21 GFLOP, sentiment-word tables 10 GFLOP) are functions of the
-            # weights alone: worth building when the call itself amortises them (>= 4 V token-steps) or when the
-            # weights have stayed put since the previous roll-out (inference loops).  A roll-out inside a TRAINING
-            # loop - the greedy baseline of the RL step - sees new weights every time: rebuilding the tables per
-            # iteration cost ~1 ms of a 35 ms RL iteration for ~0.15 ms saved in the roll-out, so it runs without.
-            emb, Wih = p['word_embed.0.weight'], p['att_lstm.weight_ih']
-            wk = (emb.data_ptr(), emb._version, Wih._version, ops.WEIGHT_EPOCH)
-            stable = self.__dict__.get('_rollout_wkey_seen') == wk
-            self._rollout_wkey_seen = wk
-            fresh = stable or n_rows * T >= 4 * self.vocab_size
-            want = 'build' if fresh and n_rows * T >= self.vocab_size // 4 else 'cached'
-            cached = self.__dict__.get('_senti_tab_cache')
-            words_table = getattr(self, 'words_table', True) and (fresh or (
-                cached is not None and cached[0][-1] == ops.WEIGHT_EPOCH and cached[0][1] == emb._version))
+            want = 'build' if n_rows * T >= self.vocab_size // 4 else 'cached'
         P = self._prologue(p, 'rl', fc_feats, att_feats, cpt_words, senti_words, senti_labels, masks,
-                           want_table=want, words_table=words_table, gate_rows=n_rows if want else 0)
+                           want_table=want, words_table=bool(want) and getattr(self, 'words_table', True),
+                           gate_rows=n_rows if want else 0)
         ops.TIMER.armed, ops.TIMER.phase = False, 'step'
         B, V = P.B, self.vocab_size
         H, Wd = self.att_lstm.hidden_size, self.settings['word_emb_dim']
