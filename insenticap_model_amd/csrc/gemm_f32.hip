@@ -2808,6 +2808,21 @@ static void finish_tiling(DevLaunch &L, int tile) {
         for (int s = 0; s < p.nseg; ++s) { wbytes += (long long)p.N * p.seg[s].K; abytes += (long long)p.M * p.seg[s].K; }
         p.m_fastest = wbytes > abytes;  // partition the larger operand across XCDs
         p.grp_n = (p.tiles_n + 7) / 8;
+        // ... or the smaller one when the fabric-traffic estimate of the grouped order is under half of row-major's: the C workgroups an XCD runs at a
+        // time form an a x b block of tiles and fetch a row panels + b column panels per round; a weight slice that
+        // fits the XCD's L2 is fetched once.  (The classifier at B = 16384 has the larger A, and row-major order put
+        // 64 different weight panels per round through each L2: 2.7 GB per launch, r03_e PMC; grouped: 8 A + W = 0.3 GB.)
+        {
+            const double Ap = 4.0 * BM * (double)(abytes / (p.M > 0 ? p.M : 1)), Wp = 4.0 * BN * (double)(wbytes / (p.N > 0 ? p.N : 1));
+            const double A = 4.0 * abytes, W = 4.0 * wbytes, L2 = 3.0 * 1048576.0;
+            const int C = BM >= 256 ? 32 : 64;
+            const double rounds = (double)p.tiles_m * p.tiles_n / (8.0 * C);
+            const int b = p.tiles_n < C ? p.tiles_n : C, a = C / p.tiles_n > 1 ? C / p.tiles_n : 1;
+            const double row = W <= L2 ? A + 8.0 * W : 8.0 * rounds * (a * Ap + b * Wp);
+            const int gb = p.grp_n < C ? p.grp_n : C, ga = C / p.grp_n > 1 ? C / p.grp_n : 1;
+            const double grp = p.grp_n * Wp <= L2 ? 8.0 * A + W : 8.0 * rounds * (ga * Ap + gb * Wp);
+            if (!p.m_fastest && grp < 0.5 * row) p.m_fastest = 1;   // (the opposite switch measured worse at B = 128)
+        }
         start += p.tiles_m * p.tiles_n * (p.ksplit > 1 ? p.ksplit : 1);
     }
     L.total_tiles = start;

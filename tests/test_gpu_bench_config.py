@@ -51,13 +51,18 @@ def check_rollout(seq, lp, mk, oseq, olp, omk, margins, Tn):
     return err
 
 
-def test_greedy_b4096_auto_mode_is_the_bench_path_and_matches_the_oracle():
-    """bench.py's headline workload: B=4096, R=36x2048, V=10k, T=20, auto engine selection.  Asserts that the
-    launches really went out on the split-f16 path AND on its 256x128 eight-wave tile (both LSTM cells need
-    >3328 rows for that), then holds the roll-out token-exact against the CPU oracle on trusted prefixes."""
+@pytest.mark.parametrize('B', [4096, 16384])
+def test_greedy_at_the_bench_batch_in_auto_mode_is_the_bench_path_and_matches_the_oracle(B):
+    """bench.py's headline workload: B captions per step (16384 is its default since round 3, 4096 was rounds 1-2
+    and stays in its batch sweep), R=36x2048, V=10k, T=20, auto engine selection.  Asserts that the launches really
+    went out on the split-f16 path AND on its 256x128 eight-wave tile (both LSTM cells need >3328 rows for that),
+    then holds the roll-out token-exact against the CPU oracle on trusted prefixes - every one of the B rows.  At
+    16384 rows the feature tensor is 4.8 GB: byte offsets pass 2^32, so this is also the 64-bit-indexing case."""
+    import bench
+    assert bench.DEFAULT_BATCH == 16384                               # the default this test pins
     cap, c, st, w = make_cfg1()
-    B, Tn = 4096, 20
-    d = synth.make_inputs(B, c['V'], st, regions=36, seq_len=Tn, seed=4096)
+    Tn = 20
+    d = synth.make_inputs(B, c['V'], st, regions=36, seq_len=Tn, seed=B)
     a = [torch.from_numpy(np.asarray(d[k])).to(dev()) for k in KEYS]
     lib = ops._lib.load()
     assert ops.set_h3_mode(1) == 1                                   # auto is the default and stays
