@@ -192,9 +192,11 @@ int isc_logsoftmax_apply(float *logits, int64_t ld_logits, int M, int V,
                          const float *part_max, const float *part_sum, float *lse_out,
                          void *stream);
 /* The same for all T steps of a teacher-forced unroll in ONE launch: logits [B,T,V] with row (b,t) at b*ld_b + t*ld_t,
- * tile statistics stacked per step [T,B,n_tile] (each step's isc_vocab_fwd / isc_step_fwd wrote its slice). */
+ * tile statistics stacked per step [T,B,n_tile] (each step's isc_vocab_fwd / isc_step_fwd wrote its slice).
+ * src (may be NULL = in place): raw logits stacked per step, contiguous [T*B, V] - what ONE isc_vocab_fwd over all
+ * steps' h_lang [T*B, H] writes (torch.stack(outputs, dim=1) of captioner.py:232 happens in this kernel's store). */
 int isc_logsoftmax_apply_steps(float *logits, int64_t ld_b, int64_t ld_t, int B, int T, int V,
-                               const float *part_max, const float *part_sum, void *stream);
+                               const float *part_max, const float *part_sum, const float *src, void *stream);
 
 /* Additive attention scan (ContentAttention captioner.py:23-35 / SentiAttention :50-62):
  *   e_r = w . tanh(P[b,r,:] + q[b,:] (+ q2[b,:])) + *w_bias ; alpha = softmax_r(e) ;

@@ -141,7 +141,7 @@ SIGNATURES = {
     'isc_logsoftmax_apply': (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_void_p]),
     'isc_logsoftmax_apply_steps': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p,
-                                             C.c_void_p, C.c_void_p]),
+                                             C.c_void_p, C.c_void_p, C.c_void_p]),
     'isc_attn_scan_fwd': (C.c_int, [C.POINTER(ScanProblem), C.c_int, C.c_int, C.c_void_p]),
     'isc_attn_scan_gate_fwd': (C.c_int, [C.POINTER(ScanGateArgs), C.c_int, C.c_void_p]),
     'isc_gate_mix_fwd': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,

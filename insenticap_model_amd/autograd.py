@@ -96,9 +96,11 @@ def _train_forward(cap, mode, fc, att, cpt_words, senti_words, tokens_in, senti_
     if fed_known:                                         # every fed token is known up front: one copy, one gather
         S.tok.copy_(tokens_in.t())
         ops.embed_relu_fwd(emb, S.tok.view(-1), S.xt.view(T * B, Wd))
-        # ... and nothing reads a step's log-probs before the unroll ends: keep the per-step tile statistics and
-        # turn all T steps' logits into log-probs with ONE launch afterwards
+        # ... and nothing reads a step's logits before the unroll ends: the classifier runs ONCE over all steps'
+        # h_lang [T*B, H] afterwards (at B = 128: 20 skinny launches of 24 us -> one [2560 x V] launch), and one
+        # more launch turns its [T,B,V] logits into the [B,T,V] log-probs
         pm_all, ps_all = new(T, B, n_tile), new(T, B, n_tile)
+        pi_all = new(T, B, n_tile, dtype=torch.int32)
     # the weights are fixed for the whole unroll: their f16 planes are built once (few-row launches then take the
     # one-launch skinny split-f16 kernels instead of split-K + reduce pairs)
     with _weights_scope(cap):
@@ -121,15 +123,14 @@ def _train_forward(cap, mode, fc, att, cpt_words, senti_words, tokens_in, senti_
                 save['hdrop'] = S.hdrop[t]
                 S.out_scale = osc
             S.out_masks.append(om)
-            ws = {'pmax': pm if pm_all is None else pm_all[t], 'psum': ps if ps_all is None else ps_all[t], 'pidx': pi,
-                  '_plan': plan}
+            ws = {'_plan': plan} if pm_all is not None else {'pmax': pm, 'psum': ps, 'pidx': pi, '_plan': plan}
             if has_c:
                 ws['qa'], ws['v'] = S.qa[t], S.v[t]
             if has_s:
                 ws['qw'], ws['s'] = S.qw[t], S.s[t]
             if has_c and has_s:
                 ws['z'], ws['f'] = S.z[t], S.f[t]
-            logits = out[:, t]
+            logits = out[:, t] if pm_all is None else None
             cap._step(p, P, ws, S.xt[t], (S.h1[t], S.h2[t]), (S.c1[t], S.c2[t]),
                       (S.h1[t + 1], S.h2[t + 1]), (S.c1[t + 1], S.c2[t + 1]),
                       S.aC[:, t] if has_c else None, S.aS[:, t] if has_s else None,
@@ -140,8 +141,13 @@ def _train_forward(cap, mode, fc, att, cpt_words, senti_words, tokens_in, senti_
                 rs.xt_next = S.xt[t + 1].data_ptr() if t + 1 < T else None
                 ops.rollout_finalize(rs)
                 ops.logsoftmax_apply(logits, pm, ps)
-    if pm_all is not None:
-        ops.logsoftmax_apply_steps(out, pm_all, ps_all)
+        if pm_all is not None:
+            hs = S.hdrop if S.hdrop is not None else S.h2[1:]
+            raw = new(T, B, V)
+            ops.vocab_fwd(hs.reshape(T * B, H), p['classifier.weight'], p['classifier.bias'], pm_all.view(T * B, n_tile),
+                          ps_all.view(T * B, n_tile), pi_all.view(T * B, n_tile), raw.view(T * B, V))
+            ops.logsoftmax_apply_steps(out, pm_all, ps_all, src_tbv=raw)
+            del raw
     if sampling:
         S.sample = (seq, seq_masks, raw, alive)
     cap._set_weights(S.aC if has_c else None, S.aS if has_s else None,

@@ -452,7 +452,7 @@ class Captioner(nn.Module):
         pl.out_mask, pl.out_scale, pl.hdrop = ptr(out_mask), out_scale, ptr(hdrop)
         pl.logits, pl.ld_logits = (logits.data_ptr(), logits.stride(0)) if logits is not None else (None, 0)
         pl.apply_logsoftmax = int(normalize)
-        pl.pmax, pl.psum, pl.pidx = ws['pmax'].data_ptr(), ws['psum'].data_ptr(), ws['pidx'].data_ptr()
+        pl.pmax, pl.psum, pl.pidx = ptr(ws.get('pmax')), ptr(ws.get('psum')), ptr(ws.get('pidx'))   # None: no classifier
         pl.gate_Gc, pl.gate_Gs = ptr(getattr(P, 'gate_Gc', None)), ptr(getattr(P, 'gate_Gs', None))
         ops.step_fwd(pl)
 
@@ -531,6 +531,8 @@ class Captioner(nn.Module):
                      p['lang_lstm.bias_ih'], p['lang_lstm.bias_hh'], c_cur[1], h_nxt[1], c_nxt[1],
                      gates_out=save.get('g2'), h_keep_mask=out_mask, mask_scale=out_scale, hdrop_out=hdrop,
                      h_planes=pn(1))
+        if ws.get('pmax') is None:            # the caller projects all steps at once after its unroll
+            return
         ops.vocab_fwd(hdrop if hdrop is not None else h_nxt[1], p['classifier.weight'],
                       p['classifier.bias'], ws['pmax'], ws['psum'], ws['pidx'], logits,
                       h_planes=None if hdrop is not None else pn(1))

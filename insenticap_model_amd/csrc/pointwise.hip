@@ -491,7 +491,8 @@ extern "C" int isc_logsoftmax_apply(float *logits, int64_t ld_logits, int M, int
 // before the unroll ends, so the T per-step launches (38 of the ~750 of an XE iteration at B = 128) become one.
 __global__ __launch_bounds__(256) void logsoftmax_apply_steps_kernel(float *logits, long long ld_b, long long ld_t,
                                                                      int B, int V, const float *pmax,
-                                                                     const float *psum, int n_tile) {
+                                                                     const float *psum, int n_tile,
+                                                                     const float *src) {
     __shared__ float sh[2];
     const int m = blockIdx.x;                 // = t * B + b
     const int tid = threadIdx.x;
@@ -508,18 +509,20 @@ __global__ __launch_bounds__(256) void logsoftmax_apply_steps_kernel(float *logi
     __syncthreads();
     const float gmax = sh[0], logS = sh[1];
     float *x = logits + (long long)(m % B) * ld_b + (long long)(m / B) * ld_t;
-    for (int i = blockIdx.y * 256 + tid; i < V; i += gridDim.y * 256) x[i] = (x[i] - gmax) - logS;
+    const float *y = src ? src + (long long)m * V : x;       // src: raw logits stacked per step, [T*B, V]
+    for (int i = blockIdx.y * 256 + tid; i < V; i += gridDim.y * 256) x[i] = (y[i] - gmax) - logS;
 }
 
 extern "C" int isc_logsoftmax_apply_steps(float *logits, int64_t ld_b, int64_t ld_t, int B, int T, int V,
-                                          const float *part_max, const float *part_sum, void *stream) {
+                                          const float *part_max, const float *part_sum, const float *src,
+                                          void *stream) {
     if (!logits || !part_max || !part_sum) return ISC_E_NULL;
     if (B <= 0 || T <= 0 || V <= 0 || (long long)B * T > 2147483647LL) return ISC_E_SHAPE;
     const int n_tile = (V + 127) / 128;
     int gy = (V + 2047) / 2048;
     if (gy < 1) gy = 1;
     hipLaunchKernelGGL(logsoftmax_apply_steps_kernel, dim3(B * T, gy), dim3(256), 0, (hipStream_t)stream, logits,
-                       (long long)ld_b, (long long)ld_t, B, V, part_max, part_sum, n_tile);
+                       (long long)ld_b, (long long)ld_t, B, V, part_max, part_sum, n_tile, src);
     ISC_LAUNCH_CHECK();
     return ISC_OK;
 }

@@ -125,14 +125,16 @@ extern "C" int isc_step_fwd(const isc_step_plan *p, void *stream) {
         l.splitk_ws = p->splitk_ws; l.splitk_ws_floats = p->splitk_ws_floats;
         RET(isc_lstm_fwd(&l, stream));
     }
-    // classifier + log-softmax statistics (captioner.py:183)
+    // classifier + log-softmax statistics (captioner.py:183); pmax == NULL: the caller projects all steps' h_lang at
+    // once after its unroll (teacher-forced training: nothing reads a step's logits before the unroll ends)
+    if (p->pmax)
     RET(isc_vocab_fwd(p->out_mask ? p->hdrop : p->h2, H, p->W_cls, H, p->b_cls, rows, V, H, p->logits,
                       p->ld_logits, p->pmax, p->psum, p->pidx, p->out_mask ? nullptr : PL(p->h2_hi),
                       p->out_mask ? nullptr : PL(p->h2_lo), p->splitk_ws, p->splitk_ws_floats, stream));
 #undef PL
 #undef PW
     if (p->apply_logsoftmax) {
-        if (!p->logits) return ISC_E_NULL;
+        if (!p->logits || !p->pmax) return ISC_E_NULL;
         RET(isc_logsoftmax_apply(p->logits, p->ld_logits, rows, V, p->pmax, p->psum, nullptr, stream));
     }
     return ISC_OK;

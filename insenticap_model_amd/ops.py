@@ -361,13 +361,16 @@ def logsoftmax_apply(logits, part_max, part_sum, lse_out=None):
                                    part_sum.data_ptr(), ptr(lse_out), stream()), 'isc_logsoftmax_apply')
 
 
-def logsoftmax_apply_steps(logits_btv, part_max_tbn, part_sum_tbn):
-    """log-softmax in place over all steps of a [B,T,V] logits tensor from the per-step tile statistics [T,B,n_tile]."""
+def logsoftmax_apply_steps(logits_btv, part_max_tbn, part_sum_tbn, src_tbv=None):
+    """log-softmax over all steps of a [B,T,V] logits tensor from the per-step tile statistics [T,B,n_tile]: in place,
+    or from raw logits stacked per step `src_tbv` [T,B,V] (one classifier launch over all steps)."""
     B, T, V = logits_btv.shape
     assert logits_btv.stride(2) == 1 and part_max_tbn.is_contiguous() and part_sum_tbn.is_contiguous()
     assert part_max_tbn.shape[:2] == (T, B) and part_sum_tbn.shape == part_max_tbn.shape
+    assert src_tbv is None or (src_tbv.is_contiguous() and src_tbv.shape == (T, B, V))
     check(_lib.load().isc_logsoftmax_apply_steps(logits_btv.data_ptr(), logits_btv.stride(0), logits_btv.stride(1), B, T,
-                                                 V, part_max_tbn.data_ptr(), part_sum_tbn.data_ptr(), stream()),
+                                                 V, part_max_tbn.data_ptr(), part_sum_tbn.data_ptr(), ptr(src_tbv),
+                                                 stream()),
           'isc_logsoftmax_apply_steps')
 
 
