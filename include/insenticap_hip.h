@@ -594,6 +594,14 @@ int isc_clamp_adam(float *const *params_host, float *const *grads_host, float *c
                    float *const *exp_avg_sq_host, const int64_t *numel_host, int n_tensors, double lr,
                    double beta1, double beta2, double eps, double weight_decay, double clip, int step,
                    void *stream);
+/* The same launch with its step-dependent scalars in DEVICE memory: hyper3_dev = {lr, 1 - beta1^step,
+ * sqrt(1 - beta2^step)} as floats (what isc_clamp_adam derives from lr / step on the host, in double).  For a training
+ * iteration captured into a HIP graph: kernel arguments are frozen at capture, the caller rewrites these three
+ * floats before every replay (train_graph.py). */
+int isc_clamp_adam_hyper(float *const *params_host, float *const *grads_host, float *const *exp_avg_host,
+                         float *const *exp_avg_sq_host, const int64_t *numel_host, int n_tensors,
+                         const float *hyper3_dev, double beta1, double beta2, double eps, double weight_decay,
+                         double clip, void *stream);
 
 #ifdef __cplusplus
 }

@@ -201,6 +201,9 @@ SIGNATURES = {
                                  C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_int, C.c_double,
                                  C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int,
                                  C.c_void_p]),
+    'isc_clamp_adam_hyper': (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                       C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_int, C.c_void_p,
+                                       C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p]),
 }
 
 _ERRORS = {-1: 'ISC_E_NULL (required pointer is null)', -2: 'ISC_E_SHAPE (unsupported size)',

@@ -215,10 +215,12 @@ def _backward(cap, S, dlogp, d_fc_feats, d_cpt_feats, sparse=()):
     if Vp != V and TB >= 8192:
         # d logits is already zero-padded to Vp columns: give W_c the matching zero rows (a 20 MB copy; worth it from
         # ~100 GFLOP on, where the large kernels run the contraction)
+        # NOT inside the weights scope: a scope keeps (pointer, planes) of every W operand it sees and the optimizer
+        # re-splits them all after its step - from the pointer.  This copy dies with the call; its planes are built in
+        # the workspace (one split launch).
         Wc_k = zeros(Vp, H)
         Wc_k[:V].copy_(Wc)
-        with _weights_scope(cap):
-            ops.gemm_bwd([nn([(dlogits, Wc_k)], dhd)], NN)
+        ops.gemm_bwd([nn([(dlogits, Wc_k)], dhd)], NN)
     elif Vm != V and Vm >= 4096:
         # fewer rows (B = 128: [2560 x 512] over K = 10 000): the first Vm vocabulary rows on the K-split skinny tile,
         # the last V - Vm (< 32) on the fp32 tiles, accumulating

@@ -1048,6 +1048,7 @@ struct DevAdam {
     long long n[ISC_ADAM_MAX_TENSORS];
     int count;
     float lr, b1, b2, eps, clip, bc1, bc2_sqrt, wd;
+    const float *hyper;      // device {lr, bc1, bc2_sqrt} (a captured launch: the step-dependent scalars cannot be arguments)
 };
 
 __global__ __launch_bounds__(256) void clamp_adam_kernel(const DevAdam Aa) {
@@ -1056,6 +1057,8 @@ __global__ __launch_bounds__(256) void clamp_adam_kernel(const DevAdam Aa) {
     const long long base = ((long long)blockIdx.x - Aa.blk_start[ti]) * 1024;
     float *p = Aa.p[ti], *g = Aa.g[ti], *m = Aa.m[ti], *v = Aa.v[ti];
     const long long n = Aa.n[ti];
+    const float lr = Aa.hyper ? Aa.hyper[0] : Aa.lr, bc1 = Aa.hyper ? Aa.hyper[1] : Aa.bc1,
+                bc2_sqrt = Aa.hyper ? Aa.hyper[2] : Aa.bc2_sqrt;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const long long i = base + k * 256 + threadIdx.x;
@@ -1067,15 +1070,15 @@ __global__ __launch_bounds__(256) void clamp_adam_kernel(const DevAdam Aa) {
         const float vv = Aa.b2 * v[i] + (1.f - Aa.b2) * gr * gr;
         m[i] = mm;
         v[i] = vv;
-        const float denom = sqrtf(vv) / Aa.bc2_sqrt + Aa.eps;
-        p[i] -= (Aa.lr / Aa.bc1) * (mm / denom);
+        const float denom = sqrtf(vv) / bc2_sqrt + Aa.eps;
+        p[i] -= (lr / bc1) * (mm / denom);
     }
 }
 
-extern "C" int isc_clamp_adam(float *const *params, float *const *grads, float *const *exp_avg,
-                              float *const *exp_avg_sq, const int64_t *numel, int n_tensors, double lr,
-                              double beta1, double beta2, double eps, double weight_decay, double clip,
-                              int step, void *stream) {
+static int clamp_adam_launch(float *const *params, float *const *grads, float *const *exp_avg,
+                             float *const *exp_avg_sq, const int64_t *numel, int n_tensors, double lr,
+                             double beta1, double beta2, double eps, double weight_decay, double clip,
+                             int step, const float *hyper, void *stream) {
     if (!params || !grads || !exp_avg || !exp_avg_sq || !numel) return ISC_E_NULL;
     if (n_tensors <= 0 || step <= 0) return ISC_E_SHAPE;
     for (int off = 0; off < n_tensors; off += ISC_ADAM_MAX_TENSORS) {
@@ -1097,9 +1100,27 @@ extern "C" int isc_clamp_adam(float *const *params, float *const *grads, float *
         // bias corrections in double, like torch.optim.Adam's Python-side scalars
         A.bc1 = (float)(1.0 - pow(beta1, (double)step));
         A.bc2_sqrt = (float)sqrt(1.0 - pow(beta2, (double)step));
+        A.hyper = hyper;
         if (blocks == 0) continue;
         hipLaunchKernelGGL(clamp_adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, A);
         ISC_LAUNCH_CHECK();
     }
     return ISC_OK;
+}
+
+extern "C" int isc_clamp_adam(float *const *params, float *const *grads, float *const *exp_avg,
+                              float *const *exp_avg_sq, const int64_t *numel, int n_tensors, double lr,
+                              double beta1, double beta2, double eps, double weight_decay, double clip,
+                              int step, void *stream) {
+    return clamp_adam_launch(params, grads, exp_avg, exp_avg_sq, numel, n_tensors, lr, beta1, beta2, eps, weight_decay,
+                             clip, step, nullptr, stream);
+}
+
+extern "C" int isc_clamp_adam_hyper(float *const *params, float *const *grads, float *const *exp_avg,
+                                    float *const *exp_avg_sq, const int64_t *numel, int n_tensors,
+                                    const float *hyper3_dev, double beta1, double beta2, double eps,
+                                    double weight_decay, double clip, void *stream) {
+    if (!hyper3_dev) return ISC_E_NULL;
+    return clamp_adam_launch(params, grads, exp_avg, exp_avg_sq, numel, n_tensors, 0.0, beta1, beta2, eps, weight_decay,
+                             clip, 1, hyper3_dev, stream);
 }

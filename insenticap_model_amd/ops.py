@@ -140,7 +140,12 @@ def ptr(t):
 def upload(values, dtype, device):
     """Small host list -> device tensor through pinned memory, asynchronously.  A pageable
     `torch.tensor(values, device=...)` is a stream-ordered blocking copy: the host would stall behind every
-    kernel already queued (1.2 ms per criterion call in the XE training step)."""
+    kernel already queued (1.2 ms per criterion call in the XE training step).  A tensor that already lives on the
+    device passes through (static inputs of a captured training iteration: no host copy may sit inside a graph)."""
+    if isinstance(values, torch.Tensor):
+        if values.is_cuda:
+            return values if values.dtype == dtype else values.to(dtype)
+        return values.to(dtype).pin_memory().to(device, non_blocking=True)
     return torch.tensor(values, dtype=dtype).pin_memory().to(device, non_blocking=True)
 
 
@@ -195,7 +200,25 @@ class h3_weights_scope:
     equal key resumes it with its planes intact - consecutive eval-mode calls then split the weights once."""
     _depth = {}
     _suspended = {}          # (device, stream) -> key of the suspended scope
+    _cold_begins = {}        # (device, stream) -> scopes begun afresh there (planes rebuilt, entries laid out anew)
     _lock = threading.Lock()
+
+    @classmethod
+    def cold_begins(cls, keys):
+        """How often a scope on these (device index, stream handle) pairs started afresh (HIP graphs captured there hold
+        plane addresses of the layout that was current at capture)."""
+        with cls._lock:
+            return sum(cls._cold_begins.get(k, 0) for k in keys)
+
+    @classmethod
+    def rekey_epoch(cls, keys, epoch_before):
+        """Suspended scopes on these streams whose key carried `epoch_before`: move them to the current WEIGHT_EPOCH
+        (their planes were refreshed by launches the host did not see: a replayed training graph)."""
+        with cls._lock:
+            for k in keys:
+                wk = cls._suspended.get(k)
+                if isinstance(wk, tuple) and wk and wk[-1] == epoch_before:
+                    cls._suspended[k] = wk[:-1] + (WEIGHT_EPOCH,)
 
     @classmethod
     def forget(cls, pred):
@@ -237,6 +260,8 @@ class h3_weights_scope:
                     self.opened = True
                 else:
                     rc = lib.isc_h3_weights_begin(buf.data_ptr(), buf.numel(), C.c_void_p(key[1]))
+                    with cls._lock:
+                        cls._cold_begins[key] = cls._cold_begins.get(key, 0) + 1
                     if rc != -4:                          # ISC_E_WORKSPACE: all scope slots taken - run without one
                         _lib.check(rc, 'isc_h3_weights_begin')
                         self.opened = True
@@ -785,6 +810,43 @@ def check_numerics(where=''):
             % (where + ': ' if where else '', '; '.join(what)))
 
 
+def release_stream_state(index, handle):
+    """Forget everything kept per (device index, stream handle): split-K workspace, weight-plane buffer, the suspended
+    weights scope and the library's scope slot.  For owners of private streams that go away (train_graph)."""
+    key = (index, handle)
+    cls = h3_weights_scope
+    with cls._lock:
+        if cls._depth.get(key, 0) != 0:
+            return False
+        cls._suspended.pop(key, None)
+        cls._cold_begins.pop(key, None)
+        _H3W_BUF.pop(key, None)
+    _SPLITK_WS.pop(key, None)
+    _lib.load().isc_h3_weights_end(C.c_void_p(handle))
+    return True
+
+
+_REFRESH = threading.local()
+
+
+class refresh_only:
+    """`with ops.refresh_only(stream_handles):` - refresh_weight_planes() on this thread touches only the suspended
+    scopes of these streams (a training iteration being captured into a HIP graph must not pull a stream that is not
+    part of the capture into it; the other streams' scopes go stale with the epoch and rebuild on their next use)."""
+
+    def __init__(self, handles):
+        self.only = frozenset(handles)
+
+    def __enter__(self):
+        self.prev = getattr(_REFRESH, 'only', None)
+        _REFRESH.only = self.only
+        return self
+
+    def __exit__(self, *exc):
+        _REFRESH.only = self.prev
+        return False
+
+
 def refresh_weight_planes(epoch_before):
     """After an in-place weight update enqueued on the current stream (the fused optimiser; WEIGHT_EPOCH was
     `epoch_before` when it started): re-split the weights behind every suspended weights scope of this device whose key
@@ -795,17 +857,21 @@ def refresh_weight_planes(epoch_before):
     cls = h3_weights_scope
     cur = torch.cuda.current_stream()
     index = cur.device.index
+    only = getattr(_REFRESH, 'only', None)
     with cls._lock:
         items = [(k, wk) for k, wk in cls._suspended.items()
                  if k[0] == index and isinstance(wk, tuple) and wk and wk[-1] == epoch_before
-                 and cls._depth.get(k, 0) == 0]
+                 and cls._depth.get(k, 0) == 0 and (only is None or k[1] in only)]
     lib = _lib.load()
     done = 0
     for key, wk in items:
         handle = key[1]
-        if handle != cur.cuda_stream:
-            torch.cuda.ExternalStream(handle, device=index).wait_stream(cur)
+        other = torch.cuda.ExternalStream(handle, device=index) if handle != cur.cuda_stream else None
+        if other is not None:
+            other.wait_stream(cur)
         rc = lib.isc_h3_weights_refresh(C.c_void_p(handle))
+        if other is not None and torch.cuda.is_current_stream_capturing():
+            cur.wait_stream(other)             # a capture must end with every forked stream joined
         with cls._lock:
             if cls._suspended.get(key) == wk:
                 if rc == 0:
@@ -816,7 +882,14 @@ def refresh_weight_planes(epoch_before):
     return done
 
 
-def clamp_adam(params, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, clip, step):
+def adam_hyper(lr, beta1, beta2, step):
+    """{lr, 1 - beta1^step, sqrt(1 - beta2^step)} as isc_clamp_adam derives them (double arithmetic, then float)."""
+    return [float(lr), 1.0 - beta1 ** float(step), (1.0 - beta2 ** float(step)) ** 0.5]
+
+
+def clamp_adam(params, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, clip, step, hyper=None):
+    """hyper: optional device float tensor {lr, bc1, bc2_sqrt} read by the kernel instead of lr / step (a launch that
+    is captured into a HIP graph; adam_hyper() gives the values to store there before each replay)."""
     global WEIGHT_EPOCH
     WEIGHT_EPOCH += 1
     lib = _lib.load()
@@ -825,5 +898,10 @@ def clamp_adam(params, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight
     for t in list(params) + list(grads) + list(exp_avg) + list(exp_avg_sq):
         assert t.is_contiguous() and t.dtype == torch.float32 and t.is_cuda
     numel = (C.c_int64 * n)(*[t.numel() for t in params])
+    if hyper is not None:
+        assert hyper.is_cuda and hyper.dtype == torch.float32 and hyper.numel() == 3 and hyper.is_contiguous()
+        check(lib.isc_clamp_adam_hyper(mk(params), mk(grads), mk(exp_avg), mk(exp_avg_sq), numel, n, hyper.data_ptr(),
+                                       beta1, beta2, eps, weight_decay, clip, stream()), 'isc_clamp_adam_hyper')
+        return
     check(lib.isc_clamp_adam(mk(params), mk(grads), mk(exp_avg), mk(exp_avg_sq), numel, n, lr, beta1, beta2,
                              eps, weight_decay, clip, step, stream()), 'isc_clamp_adam')

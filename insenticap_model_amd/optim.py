@@ -16,6 +16,7 @@ class FusedClampAdam(torch.optim.Adam):
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         self._pending_clip = 0.0
         self.refresh_weight_planes = True
+        self.device_hyper = None        # train_graph.py: {lr, bc1, bc2_sqrt} on the device while a step is captured
 
     def set_clip(self, grad_clip):
         """Elementwise clamp to +-grad_clip fused into the next step() (then cleared)."""
@@ -62,10 +63,10 @@ class FusedClampAdam(torch.optim.Adam):
             ops.refresh_weight_planes(epoch_before)
         return loss
 
-    @staticmethod
-    def _launch(ps, gs, ms, vs, group, clip, step_no):
+    def _launch(self, ps, gs, ms, vs, group, clip, step_no):
         b1, b2 = group['betas']
-        ops.clamp_adam(ps, gs, ms, vs, group['lr'], b1, b2, group['eps'], group['weight_decay'], clip, step_no)
+        ops.clamp_adam(ps, gs, ms, vs, group['lr'], b1, b2, group['eps'], group['weight_decay'], clip, step_no,
+                       hyper=self.device_hyper)
 
 
 def clip_gradient(optimizer, grad_clip=0.1):

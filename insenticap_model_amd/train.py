@@ -25,16 +25,83 @@ def _side_stream(device):
     return _SIDE_STREAMS[key]
 
 
-def run_on_side_stream(device, fn):
+def run_on_side_stream(device, fn, side=None):
     """fn() with its launches on the device's side stream, ordered after everything queued so far on the current
     stream; the current stream then waits for it.  Returns fn()'s tensor result (recorded on the current stream)."""
-    main, side = torch.cuda.current_stream(device), _side_stream(device)
+    main = torch.cuda.current_stream(device)
+    side = side if side is not None else _side_stream(device)
     side.wait_stream(main)
     with torch.cuda.stream(side):
         out = fn()
     main.wait_stream(side)
     out.record_stream(main)
     return out
+
+
+def _xe_loss(xe_crit, pred, target, lengths):
+    """xe_crit(pred, target, lengths) (train_xe.py:164); `lengths` already on the device (a captured iteration's static
+    input, validated by the caller): straight to the criterion's launch, no host-side max()."""
+    if isinstance(lengths, torch.Tensor) and lengths.is_cuda:
+        from .autograd import xe_criterion_with_grad
+        return xe_criterion_with_grad(pred, target, lengths)
+    return xe_crit(pred, target, lengths)
+
+
+def xe_forward_backward(captioner, optim, xe_crit, da_crit, fact, xe_senti_labels, scs=None, ss_prob=0.0, arena=None,
+                        weights3=None, overlap_unrolls=True, side_stream=None):
+    """train_xe.py:160-190 on device tensors: both unrolls, the three losses, backward.  `fact` = (fc, att, caps,
+    lengths, cpts), `scs` = (caps, lengths, cpts, sentis, labels) or None; `weights3` = this rank's shares of the three
+    global normalisers (XE tokens, seq2seq tokens, rows) as a device tensor, or None (single process: graph
+    untouched).  Returns the detached [xe, da, seq2seq] losses as one device tensor.  No collective, no host read:
+    this is the part of an iteration that train_graph.XETrainGraph captures into a HIP graph."""
+    fc_feats, att_feats, caps_tensor, lengths, cpts_tensor = fact
+    device = fc_feats.device
+    share = (lambda x, w: x * w) if weights3 is not None else (lambda x, w: x)
+    w_xe, w_s2s, w_rows = weights3.unbind(0) if weights3 is not None else (None, None, None)
+    pred = captioner(fc_feats, att_feats, cpts_tensor, caps_tensor, xe_senti_labels, ss_prob, mode='xe')
+    xe_bwd = share(_xe_loss(xe_crit, pred, caps_tensor[:, 1:], lengths), w_xe)
+    da_bwd = share(da_crit(captioner.cpt_feats, captioner.fc_feats.detach()), w_rows)
+    total = xe_bwd + da_bwd
+    s2s_d = torch.zeros((), device=device)
+    if scs is not None:
+        s_caps, s_lengths, s_cpts, s_sentis, s_labels = scs
+
+        def seq2seq_unroll():
+            pred2 = captioner(s_caps, s_cpts, s_sentis, s_labels, ss_prob, mode='seq2seq')
+            return share(_xe_loss(xe_crit, pred2, s_caps[:, 1:], s_lengths), w_s2s)
+        if overlap_unrolls and device.type == 'cuda':
+            s2s = run_on_side_stream(device, seq2seq_unroll, side_stream)
+        else:
+            s2s = seq2seq_unroll()
+        total = total + s2s
+        s2s_d = s2s.detach()
+    if arena is not None:
+        arena.zero_()
+    else:
+        optim.zero_grad()
+    total.backward()
+    return torch.stack([xe_bwd.detach(), da_bwd.detach(), s2s_d])
+
+
+def xe_update(optim, grad_clip):
+    """train_xe.py:191-192: clamp (fused into the Adam launch) + step."""
+    clip_gradient(optim, grad_clip)
+    optim.step()
+
+
+def loss_dict(vec3):
+    out = dict(zip(('xe_loss', 'da_loss', 'seq2seq_loss'), vec3.unbind(0)))
+    out['cap_loss'] = out['xe_loss'] + out['da_loss']
+    out['all_loss'] = out['cap_loss'] + out['seq2seq_loss']
+    return out
+
+
+def dp_shares(lengths, s_lengths, rows, device, group):
+    """Each loss term's share of ITS global normaliser (XE tokens, seq2seq tokens, rows): ONE 3-float all-reduce, built
+    on the rank's GPU (RCCL moves device tensors only), before any compute depends on it."""
+    local, glob = dp.global_counts([float(sum(lengths)), float(sum(s_lengths)) if s_lengths is not None else 0.0,
+                                    float(rows)], device, group)
+    return local / glob.clamp_min(1.0)
 
 
 def xe_train_step(captioner, optim, xe_crit, da_crit, fact_batch, xe_senti_labels, scs_batch=None,
@@ -44,57 +111,26 @@ def xe_train_step(captioner, optim, xe_crit, da_crit, fact_batch, xe_senti_label
     `overlap_unrolls`: the seq2seq unroll (80 text-only rows) runs on a side HIP stream.  It shares nothing
     with the XE unroll but the weights, and at these batch sizes both are chains of small launches that leave
     most of the chip idle; autograd replays each unroll's backward on the stream its forward ran on, so the
-    two backward sweeps overlap as well.  Same numbers either way (two-operand gradient sums commute)."""
-    device = device or next(captioner.parameters()).device
+    two backward sweeps overlap as well.  Same numbers either way (two-operand gradient sums commute).
+    (train_graph.XETrainGraph runs the same three phases from HIP graphs.)"""
+    device = torch.device(device) if device is not None else next(captioner.parameters()).device
     _, fc_feats, att_feats, (caps_tensor, lengths), cpts_tensor = fact_batch[:5]
-    fc_feats, att_feats = fc_feats.to(device), att_feats.to(device)
-    caps_tensor, cpts_tensor = caps_tensor.to(device), cpts_tensor.to(device)
+    fact = (fc_feats.to(device), att_feats.to(device), caps_tensor.to(device), lengths, cpts_tensor.to(device))
     xe_senti_labels = xe_senti_labels.to(device)
+    scs = None
+    if scs_batch is not None:
+        (s_caps, s_lengths), s_cpts, s_sentis, s_labels = scs_batch
+        scs = (s_caps.to(device), s_lengths, s_cpts.to(device), s_sentis.to(device), s_labels.to(device))
     # data-parallel: taken whenever a process group exists (also a one-rank one: shares are then exactly 1.0), so the
     # single-GPU RCCL test crosses every branch an 8-rank run does
     dist_on = dp.distributed(group)
-    share = (lambda x, w: x * w) if dist_on else (lambda x, w: x)      # single process: graph untouched
-    w_xe = w_s2s = w_rows = None
-    if dist_on:
-        # each loss term's share of ITS global normaliser (XE tokens, seq2seq tokens, rows): ONE 3-float all-reduce,
-        # built on the rank's GPU (RCCL moves device tensors only), before any compute depends on it
-        local, glob = dp.global_counts(
-            [float(sum(lengths)), float(sum(scs_batch[0][1])) if scs_batch is not None else 0.0,
-             float(fc_feats.shape[0])], device, group)
-        w_xe, w_s2s, w_rows = (local / glob.clamp_min(1.0)).unbind(0)
-
-    pred = captioner(fc_feats, att_feats, cpts_tensor, caps_tensor, xe_senti_labels, ss_prob, mode='xe')
-    xe_bwd = share(xe_crit(pred, caps_tensor[:, 1:], lengths), w_xe)
-    da_bwd = share(da_crit(captioner.cpt_feats, captioner.fc_feats.detach()), w_rows)
-    total = xe_bwd + da_bwd
-    out = {'xe_loss': xe_bwd.detach(), 'da_loss': da_bwd.detach()}
-    out['seq2seq_loss'] = torch.zeros((), device=device)
-    if scs_batch is not None:
-        (s_caps, s_lengths), s_cpts, s_sentis, s_labels = scs_batch
-        s_caps, s_cpts = s_caps.to(device), s_cpts.to(device)
-        s_sentis, s_labels = s_sentis.to(device), s_labels.to(device)
-        def seq2seq_unroll():
-            pred2 = captioner(s_caps, s_cpts, s_sentis, s_labels, ss_prob, mode='seq2seq')
-            return share(xe_crit(pred2, s_caps[:, 1:], s_lengths), w_s2s)
-        if overlap_unrolls and torch.device(device).type == 'cuda':
-            s2s = run_on_side_stream(torch.device(device), seq2seq_unroll)
-        else:
-            s2s = seq2seq_unroll()
-        total = total + s2s
-        out['seq2seq_loss'] = s2s.detach()
-
-    if arena is not None:
-        arena.zero_()
-    else:
-        optim.zero_grad()
-    total.backward()
+    weights3 = dp_shares(lengths, scs[1] if scs is not None else None, fact[0].shape[0], device, group) \
+        if dist_on else None
+    vec = xe_forward_backward(captioner, optim, xe_crit, da_crit, fact, xe_senti_labels, scs, ss_prob, arena, weights3,
+                              overlap_unrolls)
     if arena is not None:
         arena.all_reduce(group)          # one 88 MB sum over xGMI; clamp must see reduced grads
     if dist_on:                          # report global losses (sum of the pre-scaled locals): one 3-float all-reduce
-        vec = dp.all_reduce_(torch.stack([out['xe_loss'], out['da_loss'], out['seq2seq_loss']]), group)
-        out['xe_loss'], out['da_loss'], out['seq2seq_loss'] = vec.unbind(0)
-    out['cap_loss'] = out['xe_loss'] + out['da_loss']
-    out['all_loss'] = out['cap_loss'] + out['seq2seq_loss']
-    clip_gradient(optim, grad_clip)      # fused into the Adam launch
-    optim.step()
-    return out
+        vec = dp.all_reduce_(vec, group)
+    xe_update(optim, grad_clip)
+    return loss_dict(vec)

@@ -1,0 +1,242 @@
+"""The XE training iteration (train_xe.py:149-192) served from HIP graphs.
+
+At the reference's batch sizes an iteration is ~670 launches of 4-40 us each: on MI355X the device finishes them as
+fast as the host can enqueue them (7.1 ms of kernel time against 7.8 ms of host time per iteration at B = 128 + 80
+seq2seq rows), so whatever a kernel saves is not seen until the host is out of the loop.  `XETrainGraph.step` runs the
+same three phases as `train.xe_train_step` - (1) both unrolls, losses, backward; (2) the data-parallel exchange;
+(3) clamp + Adam + re-split of the weight planes - with (1) and (3) captured once per input geometry and replayed:
+
+    graph = XETrainGraph(captioner, optim, xe_crit, da_crit, grad_clip=0.1)
+    for batch ...:  losses = graph.step(fact_batch, senti_labels, scs_batch, ss_prob)
+
+What makes the capture sound:
+  * private streams: the capture stream and the seq2seq side stream belong to this object, so everything this library
+    keeps per stream (split-K workspace, f16 weight-plane buffer, weights-scope slot) is private to its graphs; the
+    seq2seq unroll stays a parallel branch of the graph (fork / join through events, as in the eager step);
+  * static inputs: every batch is copied into fixed device buffers first (caption lengths included: no host copy sits
+    inside a graph); a new geometry (batch size, caption length, ss_prob, train / eval mode) gets its own graph after
+    `warmup` eager iterations on the same streams;
+  * step-dependent scalars: Adam's lr and bias corrections live in three device floats rewritten before each replay
+    (isc_clamp_adam_hyper), computed exactly as the eager launch derives them, so graph and eager steps are
+    bit-identical; the optimizer's `state[...]['step']` counters advance per replay (state_dict layout unchanged);
+  * weight planes: the captured iteration ends with the refresh of its own streams' planes, so each replay leaves the
+    planes the next one starts from.  If anything else changed the weights in between (load_state_dict, an eager step,
+    another optimizer) - seen from `Captioner._weights_key()` - the iteration runs eagerly once (rebuilding the planes)
+    and, because a rebuilt scope may lay its planes out anew, every graph is captured again afterwards;
+  * no collective inside a graph: under a process group phase (2) runs between the two graphs on the same stream;
+  * gradient accumulation on the graph's streams: autograd runs a parameter's AccumulateGrad node on the stream that
+    was current when the node was CREATED, and the node lives as long as any graph piece that reaches it -
+    `captioner.cpt_feats` / `.fc_feats` of an earlier eager iteration do (they are outputs of the decode node, whose
+    inputs are all parameters).  `step` drops those two attributes first, so the nodes are created anew under this
+    object's stream; a caller that keeps other graph-attached results of an eager iteration alive (`pred`, a loss
+    that was not detached) must drop them before the first `step`, or the capture fails with
+    hipErrorStreamCaptureUnjoined / ...Implicit (work on a stream outside the capture).
+"""
+import collections
+import weakref
+
+import torch
+
+from . import dp, ops
+from .optim import FusedClampAdam
+from .train import dp_shares, loss_dict, xe_forward_backward, xe_update
+
+
+class _Geometry:
+    """Static buffers + the captured graphs of one input geometry."""
+
+    def __init__(self):
+        self.inputs = None          # dict name -> static device tensor
+        self.eager_runs = 0
+        self.g_fb = self.g_up = None
+        self.vec = None             # static [xe, da, seq2seq] losses (local values)
+        self.layout = None          # weights-scope cold-begin count the graphs were captured under
+
+
+class XETrainGraph:
+    def __init__(self, captioner, optim, xe_crit, da_crit, grad_clip=0.1, arena=None, group=None, warmup=2,
+                 max_geometries=4):
+        if not isinstance(optim, FusedClampAdam):
+            raise TypeError('XETrainGraph needs the fused optimizer (Captioner.get_optim_criterion)')
+        if len(optim.param_groups) != 1:
+            raise ValueError('one parameter group expected (captioner.py:422)')
+        self.cap, self.optim, self.xe_crit, self.da_crit = captioner, optim, xe_crit, da_crit
+        self.grad_clip, self.arena, self.group, self.warmup = grad_clip, arena, group, max(1, int(warmup))
+        self.device = next(captioner.parameters()).device
+        ops.require_device(*captioner.parameters())
+        self.stream = torch.cuda.Stream(device=self.device)
+        self.side = torch.cuda.Stream(device=self.device)
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self._scope_keys = ((idx, self.stream.cuda_stream), (idx, self.side.cuda_stream))
+        self._handles = (self.stream.cuda_stream, self.side.cuda_stream)
+        self.hyper = torch.zeros(3, dtype=torch.float32, device=self.device)
+        self.shares = torch.ones(3, dtype=torch.float32, device=self.device)
+        self._geoms = collections.OrderedDict()
+        self._max_geoms = max_geometries
+        self._valid_key = None       # Captioner._weights_key() after the last step this object ran
+        self.replays = self.eager_steps = self.captures = 0
+        # torch hands out streams from a pool of 32 per device, round robin: "private" holds while nobody else holds
+        # the same two.  The state this library keeps per stream is dropped with this object, so a later owner of the
+        # same handles starts clean (and 2 x 320 MB of workspace do not outlive the graphs that used them).
+        main = torch.cuda.current_stream(self.device).cuda_stream
+        if len({self.stream.cuda_stream, self.side.cuda_stream, main}) != 3:
+            raise RuntimeError('XETrainGraph needs two streams of its own (the stream pool handed out aliases)')
+        self._finalizer = weakref.finalize(self, XETrainGraph._release, self._scope_keys)
+
+    @staticmethod
+    def _release(keys):
+        for index, handle in keys:
+            try:
+                ops.release_stream_state(index, handle)
+            except Exception:           # interpreter shutdown: the library may be gone
+                pass
+
+    def close(self):
+        """Drop the graphs and this object's per-stream state now (also happens when the object is collected)."""
+        self._geoms.clear()
+        torch.cuda.synchronize(self.device)
+        self._finalizer()
+
+    # ------------------------------------------------------------------ helpers
+    def _dist(self):
+        return dp.distributed(self.group)
+
+    @staticmethod
+    def _as_list(lengths):
+        return [int(x) for x in (lengths.tolist() if isinstance(lengths, torch.Tensor) else lengths)]
+
+    def _signature(self, t, ss_prob):
+        return (tuple((k, tuple(v.shape), v.dtype) for k, v in sorted(t.items())), float(ss_prob),
+                bool(self.cap.training), self._dist())
+
+    def _stage(self, geo, t):
+        if geo.inputs is None:
+            geo.inputs = {k: torch.empty(v.shape, dtype=v.dtype, device=self.device) for k, v in t.items()}
+        for k, v in t.items():
+            if not v.is_cuda and not v.is_pinned():
+                v = v.pin_memory()
+            geo.inputs[k].copy_(v, non_blocking=True)
+
+    def _phase_args(self, geo):
+        i = geo.inputs
+        fact = (i['fc'], i['att'], i['caps'], i['len'], i['cpts'])
+        scs = (i['s_caps'], i['s_len'], i['s_cpts'], i['s_sentis'], i['s_labels']) if 's_caps' in i else None
+        return fact, i['labels'], scs
+
+    def _forward_backward(self, geo, ss_prob):
+        fact, labels, scs = self._phase_args(geo)
+        return xe_forward_backward(self.cap, self.optim, self.xe_crit, self.da_crit, fact, labels, scs, ss_prob,
+                                   self.arena, self.shares if self._dist() else None, True, self.side)
+
+    def _exchange(self, vec):
+        if self.arena is not None:
+            self.arena.all_reduce(self.group)
+        if self._dist():
+            vec = dp.all_reduce_(vec.clone(), self.group)
+        return vec
+
+    def _set_hyper(self, step_no):
+        g = self.optim.param_groups[0]
+        b1, b2 = g['betas']
+        h = torch.tensor(ops.adam_hyper(g['lr'], b1, b2, step_no), dtype=torch.float32).pin_memory()
+        self.hyper.copy_(h, non_blocking=True)
+
+    def _states(self):
+        return [self.optim.state[q] for q in self.optim.param_groups[0]['params'] if q in self.optim.state and
+                len(self.optim.state[q])]
+
+    def _capture(self, geo, ss_prob):
+        """Both graphs of this geometry, on this object's streams, scopes warm.  Capturing enqueues nothing: the
+        optimizer's step counters and the weight epoch the host logic advanced are taken back / carried by the
+        first replay."""
+        steps_before = [float(st['step']) for st in self._states()]
+        self.optim.device_hyper = self.hyper
+        try:
+            with ops.refresh_only(self._handles):
+                geo.g_fb = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(geo.g_fb, stream=self.stream):
+                    geo.vec = self._forward_backward(geo, ss_prob)
+                geo.g_up = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(geo.g_up, stream=self.stream, pool=geo.g_fb.pool()):
+                    xe_update(self.optim, self.grad_clip)
+        finally:
+            self.optim.device_hyper = None
+        for st, n in zip(self._states(), steps_before):
+            st['step'].fill_(n)
+        geo.layout = ops.h3_weights_scope.cold_begins(self._scope_keys)
+        self._valid_key = self.cap._weights_key()
+        self.captures += 1
+
+    def _replay(self, geo):
+        states = self._states()
+        for st in states:
+            st['step'] += 1
+        self._set_hyper(int(states[0]['step']))
+        geo.g_fb.replay()
+        vec = self._exchange(geo.vec)
+        geo.g_up.replay()
+        # what the captured host logic did once, per replay: the weights moved behind torch's back ...
+        epoch_before = ops.WEIGHT_EPOCH
+        ops.WEIGHT_EPOCH += 1
+        ops.h3_weights_scope.rekey_epoch(self._scope_keys, epoch_before)      # ... and OUR planes were refreshed
+        self._valid_key = self.cap._weights_key()
+        self.replays += 1
+        return vec
+
+    def _eager(self, geo, ss_prob):
+        with ops.refresh_only(self._handles):
+            vec = self._forward_backward(geo, ss_prob)
+            vec = self._exchange(vec)
+            xe_update(self.optim, self.grad_clip)
+        self._valid_key = self.cap._weights_key()
+        self.eager_steps += 1
+        return vec
+
+    # ------------------------------------------------------------------ the step
+    def step(self, fact_batch, xe_senti_labels, scs_batch=None, ss_prob=0.0):
+        """One iteration on the batch tuples of train.xe_train_step; returns its loss dictionary (0-dim device
+        tensors, global values under DP), valid on the caller's current stream."""
+        _, fc, att, (caps, lengths), cpts = fact_batch[:5]
+        lengths = self._as_list(lengths)
+        if caps.size(1) - 1 != max(lengths):
+            raise ValueError('captions are %d tokens wide, max(lengths)=%d (+1 for <SOS>)' % (caps.size(1), max(lengths)))
+        t = dict(fc=fc, att=att, caps=caps, cpts=cpts, labels=xe_senti_labels,
+                 len=torch.tensor(lengths, dtype=torch.int32))
+        s_lengths = None
+        if scs_batch is not None:
+            (s_caps, s_lengths), s_cpts, s_sentis, s_labels = scs_batch
+            s_lengths = self._as_list(s_lengths)
+            if s_caps.size(1) - 1 != max(s_lengths):
+                raise ValueError('seq2seq captions are %d tokens wide, max(lengths)=%d' % (s_caps.size(1), max(s_lengths)))
+            t.update(s_caps=s_caps, s_cpts=s_cpts, s_sentis=s_sentis, s_labels=s_labels,
+                     s_len=torch.tensor(s_lengths, dtype=torch.int32))
+        self.cap.cpt_feats = self.cap.fc_feats = None      # (see the module docstring: stale AccumulateGrad nodes)
+        sig = self._signature(t, ss_prob)
+        geo = self._geoms.get(sig)
+        if geo is None:
+            geo = self._geoms[sig] = _Geometry()
+            while len(self._geoms) > self._max_geoms:
+                self._geoms.popitem(last=False)
+        else:
+            self._geoms.move_to_end(sig)
+        caller = torch.cuda.current_stream(self.device)
+        self.stream.wait_stream(caller)
+        with torch.cuda.stream(self.stream):
+            self._stage(geo, t)
+            if self._dist():
+                self.shares.copy_(dp_shares(lengths, s_lengths, fc.shape[0], self.device, self.group))
+            planes_ok = self._valid_key is not None and self._valid_key == self.cap._weights_key()
+            if ops.h3_weights_scope.cold_begins(self._scope_keys) != geo.layout:
+                geo.g_fb = geo.g_up = None               # a scope on our streams was rebuilt since: addresses may differ
+            if geo.g_fb is None and planes_ok and geo.eager_runs >= self.warmup:
+                self._capture(geo, ss_prob)
+            if geo.g_fb is not None and planes_ok:
+                vec = self._replay(geo)
+            else:
+                vec = self._eager(geo, ss_prob)
+                geo.eager_runs += 1
+            out = loss_dict(vec.clone())
+        caller.wait_stream(self.stream)
+        for v in out.values():
+            v.record_stream(caller)
+        return out

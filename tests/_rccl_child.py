@@ -53,12 +53,36 @@ def main():
     arena.all_reduce()
     torch.cuda.synchronize()
     identity = bool(torch.equal(arena.flat, probe))
+    all_reduces_eager = dp.COLLECTIVES
+    # the same iteration from HIP graphs under the process group (train_graph.XETrainGraph: forward + backward and
+    # clamp + Adam are graphs, the three collectives run between them): five steps against an eager twin
+    from insenticap_model_amd.train_graph import XETrainGraph
+
+    def twin():
+        m = Captioner(synth.make_idx2word(V), synth.SENTIMENT_CATEGORIES, st)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_weights(V, st, seed=9).items()})
+        m.to('cuda:0').eval()
+        return m, dp.GradArena(m.parameters())
+    ref, ref_arena = twin()
+    ro, rx, rd = ref.get_optim_criterion(4e-4)
+    for _ in range(5):
+        xe_train_step(ref, ro, rx, rd, fact, t(d['senti_labels']), scs, 0.0, 0.1, arena=ref_arena)
+    gm, g_arena = twin()
+    go, gx, gd = gm.get_optim_criterion(4e-4)
+    tg = XETrainGraph(gm, go, gx, gd, grad_clip=0.1, arena=g_arena, warmup=2)
+    c0 = dp.COLLECTIVES
+    for _ in range(5):
+        tg.step(fact, t(d['senti_labels']), scs, 0.0)
+    torch.cuda.synchronize()
+    graph = dict(replays=tg.replays, eager=tg.eager_steps, all_reduces=dp.COLLECTIVES - c0,
+                 arena_collectives=g_arena.collectives,
+                 equal=all(bool(torch.equal(a, b)) for a, b in zip(ref.state_dict().values(), gm.state_dict().values())))
     with open('/proc/self/maps') as f:
         maps = f.read()
     moved = sum(int(not torch.equal(before[k], v)) for k, v in cap.state_dict().items())
     print('RCCL_CHILD ' + json.dumps(dict(
         backend=dist.get_backend(), rccl_mapped=('librccl' in maps), collectives=arena.collectives,
-        all_reduces=dp.COLLECTIVES,
+        all_reduces=all_reduces_eager, graph=graph,
         arena_bytes=arena.nbytes, losses=losses, identity=identity, moved=moved,
         nccl_version=list(torch.cuda.nccl.version()))), flush=True)
     dist.barrier()

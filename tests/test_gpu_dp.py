@@ -258,6 +258,9 @@ def test_rccl_all_reduce_in_a_fresh_process():
     assert info['collectives'] == 3 and info['identity']            # 2 training steps + the probe
     # per step: normaliser counts + gradient arena + loss statistics, all on device tensors through RCCL
     assert info['all_reduces'] == 2 * 3 + 1
+    # ... and the same under train_graph.XETrainGraph: 2 eager warm-up steps + 3 replays, three collectives each, the
+    # parameters of an eager twin bit for bit
+    assert info['graph'] == dict(replays=3, eager=2, all_reduces=5 * 3, arena_collectives=5, equal=True), info['graph']
     assert info['arena_bytes'] == 4 * sum(int(np.prod(s)) for s in synth.param_shapes(V, ST).values())
     assert info['moved'] >= 30 and all(np.isfinite(x) for x in info['losses'])
     log = r.stdout + r.stderr

@@ -1,0 +1,199 @@
+"""train_graph.XETrainGraph - the XE training iteration (train_xe.py:149-192) replayed from HIP graphs - against the
+eager `xe_train_step`: the SAME parameters, optimizer state and losses bit for bit (eval-mode dropout: no random
+draws), at the tiny geometry and at BASELINE configs[1]'s (B = 128 + 80 seq2seq rows, V = 10k, T = 20, 36 x 2048);
+what happens when the weights change behind the graph's back, when the batch geometry changes, under scheduled
+sampling and with train-mode dropout.  pytest -m gpu."""
+import numpy as np
+import pytest
+import torch
+
+from insenticap_model_amd import Captioner, ops, synth
+from insenticap_model_amd.train import xe_train_step
+from insenticap_model_amd.train_graph import XETrainGraph
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+TINY = dict(V=64, st=synth.TINY_SETTINGS, R=6, T=8, B=8, S=4)
+FULL = dict(V=10000, st=synth.DEFAULT_SETTINGS, R=36, T=20, B=128, S=80)
+
+
+def make(cfg, seed=9):
+    cap = Captioner(synth.make_idx2word(cfg['V']), synth.SENTIMENT_CATEGORIES, cfg['st'])
+    cap.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_weights(cfg['V'], cfg['st'], seed=seed).items()})
+    return cap.to(DEV).eval()
+
+
+def batch(cfg, seed, B=None, T=None, on_device=True):
+    B, T = B or cfg['B'], T or cfg['T']
+    d = synth.make_inputs(B, cfg['V'], cfg['st'], regions=cfg['R'], seq_len=T, seed=seed)
+    s = synth.make_inputs(cfg['S'], cfg['V'], cfg['st'], regions=cfg['R'], seq_len=T, seed=seed + 1000)
+    t = (lambda x: torch.from_numpy(x).to(DEV)) if on_device else torch.from_numpy
+    fact = (None, t(d['fc_feats']), t(d['att_feats']), (t(d['captions']), d['lengths']), t(d['cpt_words']))
+    scs = ((t(s['captions']), s['lengths']), t(s['cpt_words']), t(s['senti_words']), t(s['senti_labels']))
+    return fact, t(d['senti_labels']), scs
+
+
+def run_eager(cfg, batches, ss_prob=0.0):
+    cap = make(cfg)
+    optim, xc, dc = cap.get_optim_criterion(4e-4)
+    losses = [xe_train_step(cap, optim, xc, dc, f, l, s, ss_prob, 0.1) for f, l, s in batches]
+    torch.cuda.synchronize()
+    return cap, optim, [{k: float(v) for k, v in d.items()} for d in losses]
+
+
+def assert_same_state(cap_a, opt_a, cap_b, opt_b):
+    for (k, p), (_, q) in zip(cap_a.named_parameters(), cap_b.named_parameters()):
+        assert torch.equal(p.detach(), q.detach()), k
+    sa, sb = opt_a.state_dict()['state'], opt_b.state_dict()['state']
+    assert sa.keys() == sb.keys()
+    for i in sa:
+        assert float(sa[i]['step']) == float(sb[i]['step'])
+        assert torch.equal(sa[i]['exp_avg'], sb[i]['exp_avg']) and torch.equal(sa[i]['exp_avg_sq'], sb[i]['exp_avg_sq'])
+
+
+@pytest.mark.parametrize('cfg', [TINY, FULL], ids=['tiny', 'b128_v10k'])
+def test_graph_steps_equal_eager_steps_bit_for_bit(cfg):
+    n = 6 if cfg is TINY else 5
+    batches = [batch(cfg, 40 + i) for i in range(n)]
+    ref, ref_opt, ref_losses = run_eager(cfg, batches)
+    cap = make(cfg)
+    optim, xc, dc = cap.get_optim_criterion(4e-4)
+    g = XETrainGraph(cap, optim, xc, dc, grad_clip=0.1, warmup=2)
+    for i, (f, l, s) in enumerate(batches):
+        out = g.step(f, l, s, 0.0)
+        for k in ref_losses[i]:
+            assert float(out[k]) == ref_losses[i][k], (i, k)
+    torch.cuda.synchronize()
+    assert (g.eager_steps, g.captures, g.replays) == (2, 1, n - 2)
+    assert_same_state(ref, ref_opt, cap, optim)
+    # the planes the last replay left are the ones an eval roll-out on another stream must NOT trust: epoch moved
+    assert ops.device_status() == 0
+
+
+def test_weights_changed_behind_the_graph_fall_back_to_eager_and_recapture():
+    """load_state_dict between two graph steps: the planes the graph left no longer match the weights - the next step
+    must notice (Captioner._weights_key), run eagerly, and the graphs captured before must not be replayed again."""
+    cfg = TINY
+    batches = [batch(cfg, 60 + i) for i in range(8)]
+    other = {k: torch.from_numpy(v) for k, v in synth.make_weights(cfg['V'], cfg['st'], seed=77).items()}
+    # reference: eager all the way, weights replaced after step 4
+    ref = make(cfg)
+    ropt, xc, dc = ref.get_optim_criterion(4e-4)
+    for i, (f, l, s) in enumerate(batches):
+        if i == 4:
+            ref.load_state_dict(other)
+        xe_train_step(ref, ropt, xc, dc, f, l, s, 0.0, 0.1)
+    cap = make(cfg)
+    optim, xc2, dc2 = cap.get_optim_criterion(4e-4)
+    g = XETrainGraph(cap, optim, xc2, dc2, grad_clip=0.1, warmup=1)
+    seen = []
+    for i, (f, l, s) in enumerate(batches):
+        if i == 4:
+            cap.load_state_dict(other)
+        g.step(f, l, s, 0.0)
+        seen.append((g.eager_steps, g.captures, g.replays))
+    torch.cuda.synchronize()
+    # step 0 eager, 1-3 replays (capture at 1); step 4 eager again (weights replaced), 5 captures anew, 5-7 replays
+    assert seen[3] == (1, 1, 3) and seen[4] == (2, 1, 3) and seen[7] == (2, 2, 6), seen
+    assert_same_state(ref, ropt, cap, optim)
+
+
+def test_an_eager_step_of_another_model_in_between_is_noticed():
+    """ops.WEIGHT_EPOCH is global: any fused-optimizer step anywhere invalidates the key; the graph object then takes one
+    eager step (planes rebuilt) instead of trusting planes it can no longer vouch for - results stay those of eager."""
+    cfg = TINY
+    batches = [batch(cfg, 80 + i) for i in range(5)]
+    ref, ref_opt, _ = run_eager(cfg, batches)
+    cap = make(cfg)
+    optim, xc, dc = cap.get_optim_criterion(4e-4)
+    g = XETrainGraph(cap, optim, xc, dc, warmup=1)
+    bystander = make(cfg, seed=5)
+    bopt, bx, bd = bystander.get_optim_criterion(4e-4)
+    for i, (f, l, s) in enumerate(batches):
+        if i == 3:
+            xe_train_step(bystander, bopt, bx, bd, f, l, s, 0.0, 0.1)
+        g.step(f, l, s, 0.0)
+    torch.cuda.synchronize()
+    assert g.eager_steps == 2 and g.replays == 3
+    assert_same_state(ref, ref_opt, cap, optim)
+
+
+def test_geometries_get_their_own_graphs_and_host_batches_are_staged():
+    """Two caption lengths alternate (the reference's collate pads to the batch maximum, dataloader.py:11-58), batches
+    arrive as CPU tensors: each geometry warms up and is captured once, replays equal the eager steps."""
+    cfg = TINY
+    batches = [batch(cfg, 90 + i, T=(8 if i % 2 == 0 else 6), on_device=False) for i in range(8)]
+    ref, ref_opt, _ = run_eager(cfg, batches)
+    cap = make(cfg)
+    optim, xc, dc = cap.get_optim_criterion(4e-4)
+    g = XETrainGraph(cap, optim, xc, dc, warmup=1)
+    for f, l, s in batches:
+        g.step(f, l, s, 0.0)
+    torch.cuda.synchronize()
+    assert g.captures == 2 and g.eager_steps == 2 and g.replays == 6
+    assert_same_state(ref, ref_opt, cap, optim)
+
+
+def test_train_mode_dropout_and_scheduled_sampling_replay_with_fresh_draws():
+    """Random draws inside a replayed graph come from torch's graph-safe generator: every replay must see new dropout
+    masks / new scheduled-sampling coins (two replays on the same batch from the same weights-state differ), and the
+    loss of a model trained this way goes down."""
+    cfg = TINY
+    cap = make(cfg).train()
+    optim, xc, dc = cap.get_optim_criterion(4e-4)
+    g = XETrainGraph(cap, optim, xc, dc, warmup=1)
+    f, l, s = batch(cfg, 7)
+    losses = [float(g.step(f, l, s, 0.25)['all_loss']) for _ in range(30)]
+    assert g.replays == 29 and all(np.isfinite(losses))
+    assert np.mean(losses[-5:]) < np.mean(losses[:5])
+    # same weights, same batch, two replays: different masks -> different losses
+    snap = {k: v.detach().clone() for k, v in cap.state_dict().items()}
+    cap2 = make(cfg).train()
+    o2, x2, d2 = cap2.get_optim_criterion(0.0)                       # lr 0: the weights stay put
+    g2 = XETrainGraph(cap2, o2, x2, d2, warmup=1)
+    two = [float(g2.step(f, l, s, 0.25)['all_loss']) for _ in range(4)]
+    assert len(set(two[1:])) == 3, two
+    assert snap.keys() == cap.state_dict().keys()
+
+
+def test_lr_schedule_is_seen_by_replays():
+    """The learning rate is one of the three device floats rewritten before each replay: halving it in the optimizer's
+    param_group mid-run must give the eager result."""
+    cfg = TINY
+    batches = [batch(cfg, 120 + i) for i in range(6)]
+    ref = make(cfg)
+    ropt, xc, dc = ref.get_optim_criterion(4e-4)
+    cap = make(cfg)
+    optim, xc2, dc2 = cap.get_optim_criterion(4e-4)
+    for i, (f, l, s) in enumerate(batches):
+        if i == 3:
+            ropt.param_groups[0]['lr'] *= 0.5
+        xe_train_step(ref, ropt, xc, dc, f, l, s, 0.0, 0.1)
+    g = XETrainGraph(cap, optim, xc2, dc2, warmup=1)
+    for i, (f, l, s) in enumerate(batches):
+        if i == 3:
+            optim.param_groups[0]['lr'] *= 0.5
+        g.step(f, l, s, 0.0)
+    torch.cuda.synchronize()
+    assert g.replays == 5
+    assert_same_state(ref, ropt, cap, optim)
+
+
+def test_graph_after_eager_iterations_on_the_default_stream():
+    """The usual order in a trainer: some eager iterations first (their `captioner.cpt_feats` keeps every parameter's
+    AccumulateGrad node - created under the default stream - alive), then the graph object takes over.  Its capture
+    must not meet those nodes (they would run on a stream outside the capture)."""
+    cfg = TINY
+    batches = [batch(cfg, 140 + i) for i in range(6)]
+    ref, ref_opt, _ = run_eager(cfg, batches)
+    cap = make(cfg)
+    optim, xc, dc = cap.get_optim_criterion(4e-4)
+    for f, l, s in batches[:2]:
+        xe_train_step(cap, optim, xc, dc, f, l, s, 0.0, 0.1)
+    assert cap.cpt_feats is not None and cap.cpt_feats.grad_fn is not None
+    g = XETrainGraph(cap, optim, xc, dc, warmup=1)
+    for f, l, s in batches[2:]:
+        g.step(f, l, s, 0.0)
+    torch.cuda.synchronize()
+    assert g.replays == 3
+    assert_same_state(ref, ref_opt, cap, optim)

@@ -167,3 +167,42 @@ def test_post_sweep_dp_dv_kernels_odd_shapes_vs_fp64():
         th = torch.tanh(P.double().unsqueeze(0) + (q.double() + q2.double()).unsqueeze(2))
         refP = (de.double().unsqueeze(-1) * w.double().view(1, 1, 1, A) * (1 - th * th)).sum(0)
         np.testing.assert_allclose(dP.cpu().numpy(), refP.float().numpy(), atol=5e-5 * max(1.0, T / 20))
+
+
+def test_three_iterations_above_8192_rows_split_f16_engine_vs_exact_fp32_engine():
+    """Above 8192 unrolled rows with a vocabulary that is not a multiple of 32 the backward contracts d-logits with a
+    zero-padded COPY of the classifier.  A weights scope remembers (pointer, planes) of every W operand and the optimizer
+    re-splits them all after its step, from that pointer: the copy was once made inside the scope, i.e. a dead
+    temporary was re-read after every optimizer step (a GPU fault once the allocator has returned the block to the
+    driver - torch.cuda.graph's capture does that) and its planes could be found again under a recycled address.
+    The copy now stays outside the scope; this test pins what must hold either way: third-iteration gradients of the
+    split-f16 engine equal those of the exact-fp32 engine (which has no planes) to the engines' usual distance, not
+    to the ~1e-2 that one-step-stale classifier weights would give at this step size."""
+    from insenticap_model_amd import ops
+    from insenticap_model_amd.train import xe_train_step
+    V, st, B, T = 300, synth.DEFAULT_SETTINGS, 512, 16
+    assert (V + 31) // 32 * 32 != V and B * T >= 8192
+    w = synth.make_weights(V, st, seed=2)
+    d = synth.make_inputs(B, V, st, regions=36, seq_len=T, seed=77)
+    tt = lambda a: torch.from_numpy(np.asarray(a)).to(DEV)
+    fact = (None, tt(d['fc_feats']), tt(d['att_feats']), (tt(d['captions']), d['lengths']), tt(d['cpt_words']))
+    labels = tt(d['senti_labels'])
+
+    def third_iteration_grads(mode):
+        prev = ops.set_h3_mode(mode)
+        try:
+            cap = Captioner(synth.make_idx2word(V), synth.SENTIMENT_CATEGORIES, st)
+            cap.load_state_dict({k: torch.from_numpy(x) for k, x in w.items()})
+            cap.to(DEV).eval()
+            optim, xc, dc = cap.get_optim_criterion(4e-3)          # a large step: stale weights would show
+            for _ in range(3):
+                xe_train_step(cap, optim, xc, dc, fact, labels, None, 0.0, 0.0)
+            torch.cuda.synchronize()
+            return {k: q.grad.detach().cpu().numpy().copy() for k, q in cap.named_parameters() if q.grad is not None}
+        finally:
+            ops.set_h3_mode(prev)
+    fast, exact = third_iteration_grads(1), third_iteration_grads(0)
+    for k in ('lang_lstm.weight_ih', 'lang_lstm.weight_hh', 'att_lstm.weight_ih', 'classifier.weight'):
+        scale = np.abs(exact[k]).max()
+        err = float(np.abs(fast[k] - exact[k]).max() / scale)
+        assert err < 2e-3, (k, err)        # (two steps of Adam amplify the engines' 1e-5..1e-4 per-step differences)
