@@ -15,7 +15,7 @@
  *     `stream` (a hipStream_t passed as void*);
  *   - no data-carrying global state: entry points may be called from several host threads on
  *     distinct streams at once (tests/test_gpu_threads.py).  What the library keeps is (a) two
- *     process-wide tuning words, isc_set_tile_override / isc_set_h3_mode (atomic; they pick a
+ *     process-wide tuning words, isc_set_tile_override / isc_set_h3_mode / isc_set_gemv_rows (atomic; they pick a
  *     kernel, never change a result beyond fp32 summation order), (b) launch counters (atomic),
  *     and (c) the split-f16 weights scopes, which are keyed by stream (isc_h3_weights_begin);
  *   - return value: 0 ok; <0 bad argument / unsupported shape (ISC_E_*);
@@ -65,6 +65,14 @@ int isc_set_h3_mode(int mode);
 /* Number of launches that went out on the split-f16 path so far (process-wide; measurement / test hook);
  * isc_h3x_launches: those of them that took the 256x128 eight-wave tile (launches of >= 224 such tiles). */
 long long isc_h3_launches(void);
+/* Few rows (beam rows of one image, a handful of captions): isc_linear_fwd / isc_lstm_fwd / isc_vocab_fwd launches
+ * whose problems all have M <= rows (default and maximum 8) and K <= 4096 go out as ONE fused matrix-vector kernel
+ * each (gemv_rows_kernel: weights read as fp32 with the whole launch's traffic in flight, exact fp32 FMA, activations
+ * staged in LDS, LSTM cell / vocabulary statistics in the epilogue - north_star's "fused LSTM gate GEMV +
+ * sigmoid/tanh").  Modes 0 and 1 of isc_set_h3_mode only (2-4 force the split-f16 kernels).  rows = 0 switches the
+ * path off; returns the previous value.  isc_gemv_launches: launches that went out this way (test hook). */
+int isc_set_gemv_rows(int rows);
+long long isc_gemv_launches(void);
 long long isc_h3x_launches(void);
 /* Launches that took the skinny split-f16 kernel (few rows: one launch per GEMM instead of split-K + reduce). */
 long long isc_h3s_launches(void);

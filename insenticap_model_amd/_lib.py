@@ -120,6 +120,8 @@ SIGNATURES = {
     'isc_set_tile_override': (C.c_int, [C.c_int]),
     'isc_set_h3_mode': (C.c_int, [C.c_int]),
     'isc_h3_launches': (C.c_longlong, []),
+    'isc_set_gemv_rows': (C.c_int, [C.c_int]),
+    'isc_gemv_launches': (C.c_longlong, []),
     'isc_h3x_launches': (C.c_longlong, []),
     'isc_h3s_launches': (C.c_longlong, []),
     'isc_h3_weights_begin': (C.c_int, [C.c_void_p, C.c_longlong, C.c_void_p]),

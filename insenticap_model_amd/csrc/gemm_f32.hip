@@ -2656,6 +2656,249 @@ __global__ __launch_bounds__(256) void splitk_vocab_kernel(const DevLaunch L) {
     }
 }
 
+// ---------------------------------------------------------------- few rows: fused GEMV kernels (exact fp32)
+// Beam rows of one image (5), roll-outs of a handful of captions: with M <= 8 rows a "GEMM" is M matrix-vector
+// products that stream the weights once - no tile shape reuses anything, the 32-row MFMA tiles of the skinny kernel
+// are 84-97 % padding, and its launches sit at the latency of their 8-block DMA chains (LSTM cell at 5 rows: 9.4 us
+// for 16.8 MB of weight planes = 1.8 TB/s).  Here the weights are read as they are (fp32, no planes, no split - the
+// arithmetic is exact fp32 FMA) by wide per-lane loads with the whole launch's traffic in flight at once:
+//   * a workgroup (4 waves) stages the M activation rows [M, K] of the launch in LDS (fp32, all segments, <= 128 KB);
+//   * a wave owns 4 weight rows at a time (linear / vocabulary: 4 consecutive output columns; LSTM: the i, f, g, o
+//     rows of one hidden unit); lane l takes the float4 at k = 256 c + 4 l of each row for up to 8 chunks c - 32
+//     loads of 16 B per lane in flight (the vocabulary tile: 8 rows x 2 chunks) - and accumulates 4 x M dot products;
+//   * the 4 M (<= 32) per-lane sums are reduced across the 64 lanes by a reduce-scatter butterfly (each step halves
+//     the values a lane carries: 31 shuffles instead of 32 x 6), fixed order, deterministic;
+//   * epilogues from LDS: linear (biases, accumulate, ReLU, keep-mask, pre-mask copy), LSTM cell (lstm_cells<1>: the
+//     same code as the tile kernels - hoisted term, token-table row, planes of h for consumers, saved gates),
+//     vocabulary (logits + the per-128-column max / arg-max / sum-exp statistics of the tile kernels' epilogue).
+// north_star's "fused LSTM gate GEMV + sigmoid/tanh" is this kernel's <EPI_LSTM> form.
+#define GEMV_MAX_ROWS 8
+#define GEMV_MAX_K 4096
+// v[0 .. NV) per lane -> after the call v[0] of lane l holds the 64-lane sum of value index l / (64 / NV).
+template <int HALF, int MASK, int NV>
+__device__ __forceinline__ void wave_reduce_scatter_step(float (&v)[NV], int lane) {
+    const bool up = (lane & MASK) != 0;
+#pragma unroll
+    for (int i = 0; i < HALF; ++i) {
+        const float send = up ? v[i] : v[i + HALF];
+        const float keep = up ? v[i + HALF] : v[i];
+        v[i] = keep + __shfl_xor(send, MASK, 64);
+    }
+    if constexpr (HALF > 1) wave_reduce_scatter_step<HALF / 2, MASK / 2, NV>(v, lane);
+}
+template <int NV>
+__device__ __forceinline__ void wave_reduce_scatter(float (&v)[NV], int lane) {
+    static_assert(NV == 32 || NV == 64, "4 or 8 weight rows x 8 activation rows");
+    wave_reduce_scatter_step<NV / 2, 32, NV>(v, lane);
+    if (NV == 32) v[0] += __shfl_xor(v[0], 1, 64);
+}
+
+// One batch of CB 256-wide k-chunks: NR x CB unconditional 16-byte loads per lane (a lane past the segment's end reads
+// the row's last float4 again and meets a zero activation: no branch sits between a load and its use, so the loads
+// stay in flight together - a predicated load gets its own s_waitcnt), then the FMAs.
+template <int NR, int CB>
+__device__ __forceinline__ void gemv_batch(const float *Wb, const long long (&wrow)[NR], long long ldw, int Ks, int c0,
+                                           const float *Ak, int Ktot, int lane, float (&acc)[NR * GEMV_MAX_ROWS]) {
+    constexpr int MR = GEMV_MAX_ROWS;
+    float4 w[NR][CB];
+    int kc[CB];
+    bool in[CB];
+#pragma unroll
+    for (int c = 0; c < CB; ++c) {
+        const int kk = c0 + c * 256 + lane * 4;
+        in[c] = kk < Ks;
+        kc[c] = in[c] ? kk : Ks - 4;
+    }
+#pragma unroll
+    for (int r = 0; r < NR; ++r)
+#pragma unroll
+        for (int c = 0; c < CB; ++c) w[r][c] = *reinterpret_cast<const float4 *>(Wb + wrow[r] * ldw + kc[c]);
+#pragma unroll
+    for (int c = 0; c < CB; ++c) {
+#pragma unroll
+        for (int m = 0; m < MR; ++m) {
+            float4 a = *reinterpret_cast<const float4 *>(Ak + (long long)m * Ktot + kc[c]);
+            a.x = in[c] ? a.x : 0.f; a.y = in[c] ? a.y : 0.f; a.z = in[c] ? a.z : 0.f; a.w = in[c] ? a.w : 0.f;
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                float t = acc[r * MR + m];
+                t = fmaf(w[r][c].x, a.x, t);
+                t = fmaf(w[r][c].y, a.y, t);
+                t = fmaf(w[r][c].z, a.z, t);
+                t = fmaf(w[r][c].w, a.w, t);
+                acc[r * MR + m] = t;
+            }
+        }
+    }
+}
+
+// NQ x 4 weight rows against the MR staged activation rows over this wave's share of K: chunks [g_lo, g_hi) of the
+// launch's chunk list (the segments' 256-wide chunks, concatenated); at most CBMAX chunks per batch.
+template <int NQ, int CBMAX>
+__device__ __forceinline__ void gemv_accumulate(const DevProb &P, const long long (&wrow)[NQ * 4], const float *As,
+                                                int Ktot, int lane, int g_lo, int g_hi,
+                                                float (&acc)[NQ * 4 * GEMV_MAX_ROWS]) {
+    constexpr int NR = NQ * 4, MR = GEMV_MAX_ROWS;
+#pragma unroll
+    for (int i = 0; i < NR * MR; ++i) acc[i] = 0.f;
+    int koff = 0, g0 = 0;
+    for (int s = 0; s < P.nseg; ++s) {
+        const int Ks = P.seg[s].K, nch = (Ks + 255) >> 8;
+        const float *Wb = P.seg[s].W;
+        const long long ldw = P.seg[s].ldw;
+        const float *Ak = As + koff;
+        const int lo = g_lo > g0 ? g_lo - g0 : 0, hi = g_hi - g0 < nch ? g_hi - g0 : nch;   // this segment's chunks (uniform)
+        int c0 = lo * 256, rem = hi - lo;
+        if constexpr (CBMAX >= 8) {
+            while (rem >= 8) { gemv_batch<NR, 8>(Wb, wrow, ldw, Ks, c0, Ak, Ktot, lane, acc); c0 += 2048; rem -= 8; }
+        }
+        if constexpr (CBMAX >= 4) {
+            while (rem >= 4) { gemv_batch<NR, 4>(Wb, wrow, ldw, Ks, c0, Ak, Ktot, lane, acc); c0 += 1024; rem -= 4; }
+        }
+        while (rem >= 2) { gemv_batch<NR, 2>(Wb, wrow, ldw, Ks, c0, Ak, Ktot, lane, acc); c0 += 512; rem -= 2; }
+        if (rem >= 1) gemv_batch<NR, 1>(Wb, wrow, ldw, Ks, c0, Ak, Ktot, lane, acc);
+        koff += Ks;
+        g0 += nch;
+    }
+}
+
+// NW waves per workgroup.  Linear / LSTM (NW = 4): a tile is 4 / KS quads (4 output columns, or the 4 gate rows of a
+// hidden unit), each contracted by KS waves over 1 / KS of the chunk list (P.ksplit = KS in {1, 2, 4}: long contractions
+// spread over more waves so that every wave's loads fit one batch and the launch fills the chip - the LSTM cell over
+// K = 2048 at KS = 2 is 256 workgroups of 4 waves with 16 loads each); the KS partial sums meet in LDS in fixed order.
+// Vocabulary (NW = 8): a tile is 128 columns (its statistics are per 128), wave w takes columns 16 w .. 16 w + 15 in
+// two rounds of 8 rows.
+template <int EPI, int NW>
+__global__ __launch_bounds__(64 * NW) void gemv_rows_kernel(const DevLaunch L) {
+    constexpr int MR = GEMV_MAX_ROWS, NT = 64 * NW;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int pi = 0;
+    if (L.nprob > 1 && (int)blockIdx.x >= L.p[1].tile_start) pi = 1;
+    if (L.nprob > 2 && (int)blockIdx.x >= L.p[2].tile_start) pi = 2;
+    const DevProb &P = L.p[pi];
+    const int tile = blockIdx.x - P.tile_start;
+    const int M = P.M, N = P.N;
+    int Ktot = 0, nchunk = 0;
+    for (int s = 0; s < P.nseg; ++s) { Ktot += P.seg[s].K; nchunk += (P.seg[s].K + 255) >> 8; }
+    float *As = smem;                                   // [MR][Ktot]
+    float *red = smem + (long long)MR * Ktot;           // linear / LSTM: [4 waves][32]; vocabulary: [MR][128]
+    {                                                   // stage the activations (rows >= M: zeros)
+        int koff = 0;
+        for (int s = 0; s < P.nseg; ++s) {
+            const int Ks = P.seg[s].K, q4 = Ks >> 2;
+            const float *Ab = P.seg[s].A;
+            const long long lda = P.seg[s].lda;
+            for (int k4 = tid; k4 < q4; k4 += NT) {     // all MR row loads of a column in flight (rows >= M: row M - 1)
+                float4 v[MR];
+#pragma unroll
+                for (int m = 0; m < MR; ++m)
+                    v[m] = *reinterpret_cast<const float4 *>(Ab + (long long)(m < M ? m : M - 1) * lda + k4 * 4);
+#pragma unroll
+                for (int m = 0; m < MR; ++m) {
+                    if (m >= M) v[m] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    *reinterpret_cast<float4 *>(As + (long long)m * Ktot + koff + k4 * 4) = v[m];
+                }
+            }
+            koff += Ks;
+        }
+    }
+    __syncthreads();
+
+    if constexpr (EPI == EPI_VOCAB) {
+        const int col0 = tile * 128;
+        for (int rnd = 0; rnd < 2; ++rnd) {
+            long long wrow[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int c = col0 + wave * 16 + rnd * 8 + r;
+                wrow[r] = c < N ? c : N - 1;
+            }
+            float acc[8 * MR];
+            gemv_accumulate<2, 2>(P, wrow, As, Ktot, lane, 0, nchunk, acc);
+            wave_reduce_scatter<64>(acc, lane);          // lane l: value (row r = l / 8 of the round, m = l % 8)
+            red[(lane & 7) * 128 + wave * 16 + rnd * 8 + (lane >> 3)] = acc[0];
+        }
+        __syncthreads();
+        const int n_tile = P.ntile_total;
+        for (int m = wave; m < M; m += NW) {
+            float x[2];
+            int col[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                col[h] = col0 + lane + 64 * h;
+                const bool ok = col[h] < N;
+                x[h] = ok ? red[m * 128 + lane + 64 * h] + P.bias0[col[h]] : -INFINITY;
+                if (ok && P.C) P.C[(long long)m * P.ld_logits + col[h]] = x[h];
+            }
+            float mx = x[0];
+            int ix = col[0];
+            if (x[1] > mx) { mx = x[1]; ix = col[1]; }             // equal: the lower column stays
+            wave_argmax(mx, ix);
+            float sm = (x[0] > -INFINITY ? __expf(x[0] - mx) : 0.f) + (x[1] > -INFINITY ? __expf(x[1] - mx) : 0.f);
+            sm = wave_sum(sm);
+            if (lane == 0) {
+                const long long o = (long long)m * n_tile + tile;
+                P.pmax[o] = mx;
+                P.psum[o] = sm;
+                P.pidx[o] = ix;
+            }
+        }
+    } else {
+        const int KS = P.ksplit;                         // 1, 2 or 4 (try_gemv)
+        const int qpw = NW / KS;                         // quads per workgroup
+        const int qw = wave / KS, ks = wave - qw * KS;   // this wave: quad qw of the tile, k-slice ks
+        const int quad = tile * qpw + qw;
+        long long wrow[4];
+        bool live;
+        if constexpr (EPI == EPI_LSTM) {
+            live = quad < P.H;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) wrow[r] = (long long)r * P.H + (live ? quad : 0);
+        } else {
+            live = quad * 4 < N;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const int c = quad * 4 + r; wrow[r] = c < N ? c : N - 1; }
+        }
+        float acc[4 * MR];
+        gemv_accumulate<1, 8>(P, wrow, As, Ktot, lane, nchunk * ks / KS, nchunk * (ks + 1) / KS, acc);
+        wave_reduce_scatter<32>(acc, lane);              // lanes 2 i, 2 i + 1: value i = (row r = i / 8, m = i % 8)
+        if ((lane & 1) == 0) red[wave * 32 + (lane >> 1)] = acc[0];
+        __syncthreads();
+        if (ks == 0 && live) {                           // the quad's first wave sums the KS partials in order
+            const float *rq = red + wave * 32;
+            if constexpr (EPI == EPI_LSTM) {
+                if (lane < M) {
+                    const int gm[1] = {lane};
+                    const bool ok[1] = {true};
+                    float g[1][4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        float v = rq[k * MR + lane];
+                        for (int j = 1; j < KS; ++j) v += rq[j * 32 + k * MR + lane];
+                        g[0][k] = v;
+                    }
+                    lstm_cells<1>(P, gm, quad, ok, g);
+                }
+            } else {
+                const int m = lane >> 2, e = lane & 3, n = quad * 4 + e;
+                if (lane < 4 * MR && m < M && n < N) {
+                    float o = rq[e * MR + m];
+                    for (int j = 1; j < KS; ++j) o += rq[j * 32 + e * MR + m];
+                    if (P.bias0) o += P.bias0[n];
+                    if (P.bias1) o += P.bias1[n];
+                    if (P.bias2) o += P.bias2[n];
+                    if (P.accumulate) o += P.C[(long long)m * P.ldc + n];
+                    if (P.relu) o = isc_relu(o);
+                    if (P.C_pre) P.C_pre[(long long)m * P.ldc + n] = o;
+                    if (P.mask) o = o * (float)P.mask[(long long)m * N + n] * P.mask_scale;
+                    P.C[(long long)m * P.ldc + n] = o;
+                }
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------- host side
 static int check_segs(const isc_seg *seg, int nseg) {
     if (nseg < 1 || nseg > ISC_MAX_SEG) return ISC_E_SHAPE;
@@ -2838,6 +3081,67 @@ extern "C" int isc_set_h3_mode(int mode) {
     if (mode >= 0 && mode <= 4) return g_h3_mode.exchange(mode);
     return g_h3_mode.load();
 }
+static std::atomic<int> g_gemv_rows{GEMV_MAX_ROWS};
+static std::atomic<long long> g_gemv_launches{0};
+extern "C" int isc_set_gemv_rows(int rows) {           // 0 = off; returns the previous value
+    if (rows >= 0 && rows <= GEMV_MAX_ROWS) return g_gemv_rows.exchange(rows);
+    return g_gemv_rows.load();
+}
+extern "C" long long isc_gemv_launches(void) { return g_gemv_launches.load(); }
+
+// Takes the launch when every problem has <= g_gemv_rows rows and fits the LDS image.  Returns 1 when it went out.
+template <int EPI>
+static int try_gemv(DevLaunch &L, hipStream_t st, int &rc) {
+    constexpr int NW = EPI == EPI_VOCAB ? 8 : 4;
+    const int rows = g_gemv_rows.load(), mode = g_h3_mode.load();
+    if (rows <= 0 || mode > 1 || g_tile_override.load() >= 0) return 0;
+    int start = 0, kmax = 0;
+    for (int i = 0; i < L.nprob; ++i) {
+        DevProb &p = L.p[i];
+        if (p.M > rows || p.ksplit > 1) return 0;
+        int K = 0, nchunk = 0;
+        for (int s = 0; s < p.nseg; ++s) {
+            if ((p.seg[s].K & 3) || (p.seg[s].lda & 3) || (p.seg[s].ldw & 3)) return 0;
+            K += p.seg[s].K;
+            nchunk += (p.seg[s].K + 255) >> 8;
+        }
+        if (K > GEMV_MAX_K) return 0;
+        if (EPI == EPI_LSTM && (p.H <= 0 || p.N != 4 * p.H)) return 0;
+        kmax = K > kmax ? K : kmax;
+    }
+    for (int i = 0; i < L.nprob; ++i) {
+        DevProb &p = L.p[i];
+        int nchunk = 0;
+        for (int s = 0; s < p.nseg; ++s) nchunk += (p.seg[s].K + 255) >> 8;
+        // K slices inside the workgroup: at most 4 chunks (16 loads) per wave, and enough workgroups for the chip
+        const int quads = EPI == EPI_LSTM ? p.H : (p.N + 3) / 4;
+        int KS = 1;
+        if (EPI != EPI_VOCAB) {       // the smallest of 1, 2, 4 with <= 4 chunks per wave and >= 200 workgroups
+            while (KS < 4 && KS * 2 <= nchunk && ((nchunk + KS - 1) / KS > 4 || (long long)quads * KS / NW < 200)) KS *= 2;
+        }
+        p.ksplit = KS;
+        p.tile_start = start;
+        start += EPI == EPI_VOCAB ? (p.N + 127) / 128 : (quads + NW / KS - 1) / (NW / KS);
+    }
+    L.total_tiles = start;
+    const size_t lds = ((size_t)GEMV_MAX_ROWS * kmax + (EPI == EPI_VOCAB ? GEMV_MAX_ROWS * 128 : NW * 32)) * sizeof(float);
+    static std::atomic<bool> attr_set{false};
+    if (!attr_set.load()) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemv_rows_kernel<EPI, NW>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)(((size_t)GEMV_MAX_ROWS * GEMV_MAX_K + GEMV_MAX_ROWS * 128) * sizeof(float)));
+        if (e != hipSuccess) { rc = (int)e; return 1; }
+        attr_set.store(true);
+    }
+    hipLaunchKernelGGL((gemv_rows_kernel<EPI, NW>), dim3(L.total_tiles), dim3(64 * NW), lds, st, L);
+    rc = ISC_OK;
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) rc = (int)e;
+    for (int i = 0; i < L.nprob; ++i) L.p[i].ksplit = 0;
+    ++g_gemv_launches;
+    return 1;
+}
+
 #define H3_MIN_TILES 160
 #define H3_MIN_TILES_SCOPE 16
 
@@ -3480,6 +3784,7 @@ extern "C" int isc_linear_fwd(const isc_linear_problem *pr, int n_prob, void *st
         d.ldc = q.ldc; d.C = q.C; d.C_pre = q.C_pre; d.accumulate = q.accumulate;
     }
     int rc = ISC_OK;
+    if (try_gemv<EPI_LINEAR>(L, (hipStream_t)stream, rc)) return rc;
     if (try_h3s<EPI_LINEAR>(L, pr[0].splitk_ws, pr[0].splitk_ws_floats, (hipStream_t)stream, rc)) return rc;
     const int S = plan_splitk(L, pr[0].splitk_ws, pr[0].splitk_ws_floats);
     if (S == 1 && try_h3<EPI_LINEAR>(L, pr[0].splitk_ws, pr[0].splitk_ws_floats, (hipStream_t)stream, rc)) return rc;
@@ -3565,6 +3870,7 @@ extern "C" int isc_lstm_fwd(const isc_lstm_problem *q, void *stream) {
     if ((q->h_hi == nullptr) != (q->h_lo == nullptr)) return ISC_E_NULL;
     d.h_hi = static_cast<_Float16 *>(q->h_hi); d.h_lo = static_cast<_Float16 *>(q->h_lo);
     d.pre = q->pre; d.tab = q->tab; d.tab_ids = q->tab_ids; d.tab_ids_stride = q->tab_ids_stride;
+    if (try_gemv<EPI_LSTM>(L, (hipStream_t)stream, rc)) return rc;
     if (try_h3s<EPI_LSTM>(L, q->splitk_ws, q->splitk_ws_floats, (hipStream_t)stream, rc)) return rc;
     const int S = plan_splitk(L, q->splitk_ws, q->splitk_ws_floats);
     if (S > 1) {   // plain [M,4H] pre-activation slabs, then the cell update in the reduce kernel
@@ -3607,6 +3913,7 @@ extern "C" int isc_vocab_fwd(const float *h, int ldh, const float *W, int ldw, c
     d.ntile_total = (V + 127) / 128;
     // few rows (beam search, small batches): the 16-chunk contraction of a 32-row tile is a serial walk
     // of ~27 us; split it over K into raw [S,M,V] slabs and let the reduce kernel form the statistics
+    if (try_gemv<EPI_VOCAB>(L, (hipStream_t)stream, rc)) return rc;
     if (try_h3s<EPI_VOCAB>(L, splitk_ws, splitk_ws_floats, (hipStream_t)stream, rc)) return rc;
     const int S = plan_splitk(L, splitk_ws, splitk_ws_floats);
     if (S > 1) {

@@ -186,6 +186,11 @@ def set_h3_mode(mode):
     return _lib.load().isc_set_h3_mode(int(mode))
 
 
+def set_gemv_rows(rows):
+    """Few-row launches (M <= rows <= 8) as fused matrix-vector kernels; 0 = off.  Returns the previous value."""
+    return _lib.load().isc_set_gemv_rows(int(rows))
+
+
 _H3W_BUF = {}
 
 
