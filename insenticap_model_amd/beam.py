@@ -192,7 +192,7 @@ def _graphed_search(cap, fc_feats, att_feats, senti_words, senti_labels, beam, d
                 search = None
                 for t0 in range(0, T, CHUNK):
                     g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g, pool=pool, stream=stream):
+                    with ops.graph_capture(g, pool=pool, stream=stream):
                         if search is None:
                             search = _Search(cap, *static, beam, decoding_constraint, T)
                         for t in range(t0, min(t0 + CHUNK, T)):

@@ -683,7 +683,7 @@ class Captioner(nn.Module):
             # ones would be keyed on the capture stream and could be freed under the graph); replays are enqueued on
             # one stream at a time, so they never overlap
             ws, wp = self._graph_buffers()
-            with ops.capture_buffers(ws, wp), torch.cuda.graph(graph):
+            with ops.capture_buffers(ws, wp), ops.graph_capture(graph):
                 outs = self._rollout(*static, T, 1, None, None)[:3]
                 pending = self.__dict__.get('_weights_pending')
             entry = cache[key] = (graph, static, outs, pending, ws, wp)

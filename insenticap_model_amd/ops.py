@@ -2,6 +2,7 @@
 all arithmetic happens in libinsenticap_hip.so."""
 import ctypes as C
 import threading
+import time
 
 import torch
 
@@ -85,6 +86,31 @@ def h3w_bytes():
     if 'h3w' not in _WS_SIZES:
         _WS_SIZES['h3w'] = int(_lib.load().isc_h3_weights_workspace_bytes(24 * 1024 * 1024, 1))
     return _WS_SIZES['h3w']
+
+
+def graph_capture(graph, **kw):
+    """torch.cuda.graph(graph, **kw) for this package's captures, safe next to a torch.distributed process group.
+    The backend's watchdog thread polls the completion event of every collective still on its list (hipEventQuery,
+    every ~100 ms) and retires finished work only at such a pass.  On ROCm a poll of a collective issued shortly before a
+    capture opened, landing INSIDE the capture window, fails with hipErrorCapturedEvent - in the watchdog thread, which
+    aborts the process (RCCL, one rank: by chance at the full model size where a capture takes ~100 ms, for certain
+    with a 0.4 s window - tests/_rccl_child.py keeps that case).  So, with a group alive: everything queued is finished
+    and one watchdog pass is let go by before the capture opens (its list is then empty for the whole window - nothing
+    this package captures issues a collective), and the capture runs in 'thread_local' error mode (calls of other
+    host threads are not policed; autograd's backward thread launches into the capture in any mode).  Captures are
+    once per geometry: the 0.25 s do not recur."""
+    try:
+        import torch.distributed as dist
+        grouped = dist.is_available() and dist.is_initialized()
+    except Exception:                   # a torch build without distributed
+        grouped = False
+    if grouped:
+        kw.setdefault('capture_error_mode', 'thread_local')
+        # ... and no collective may still be on the watchdog's list when the capture opens: it retires finished work
+        # at its next pass (every 100 ms), so finish everything and let one pass go by.  Captures are once per geometry.
+        torch.cuda.synchronize()
+        time.sleep(0.25)
+    return torch.cuda.graph(graph, **kw)
 
 
 _CAPTURE = threading.local()      # per host thread: the (workspace, weight-plane buffer) pair of a HIP-graph capture

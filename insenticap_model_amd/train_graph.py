@@ -154,10 +154,10 @@ class XETrainGraph:
         try:
             with ops.refresh_only(self._handles):
                 geo.g_fb = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(geo.g_fb, stream=self.stream):
+                with ops.graph_capture(geo.g_fb, stream=self.stream):
                     geo.vec = self._forward_backward(geo, ss_prob)
                 geo.g_up = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(geo.g_up, stream=self.stream, pool=geo.g_fb.pool()):
+                with ops.graph_capture(geo.g_up, stream=self.stream, pool=geo.g_fb.pool()):
                     xe_update(self.optim, self.grad_clip)
         finally:
             self.optim.device_hyper = None

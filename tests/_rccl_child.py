@@ -71,8 +71,23 @@ def main():
     go, gx, gd = gm.get_optim_criterion(4e-4)
     tg = XETrainGraph(gm, go, gx, gd, grad_clip=0.1, arena=g_arena, warmup=2)
     c0 = dp.COLLECTIVES
+    # The backend's watchdog thread polls its work events every ~100 ms.  Keep the capture window open for 0.4 s (a host
+    # sleep inside the captured phase): had the all-reduce of the loss shares issued just before still been on the
+    # watchdog's list, its poll inside the window would raise hipErrorCapturedEvent in the watchdog and abort this
+    # process (seen at the full model size, where captures are that long by themselves); ops.graph_capture finishes
+    # all queued work and lets one watchdog pass go by before it opens a capture.
+    import time
+    from insenticap_model_amd import ops
+    real_refresh = ops.refresh_weight_planes
+
+    def slow_refresh(epoch_before):
+        if torch.cuda.is_current_stream_capturing():
+            time.sleep(0.4)
+        return real_refresh(epoch_before)
+    ops.refresh_weight_planes = slow_refresh
     for _ in range(5):
         tg.step(fact, t(d['senti_labels']), scs, 0.0)
+    ops.refresh_weight_planes = real_refresh
     torch.cuda.synchronize()
     graph = dict(replays=tg.replays, eager=tg.eager_steps, all_reduces=dp.COLLECTIVES - c0,
                  arena_collectives=g_arena.collectives,
