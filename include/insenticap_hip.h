@@ -521,6 +521,21 @@ int isc_embed_relu_bwd_ws(const float *emb, int V, int W, const int64_t *ids, in
 int isc_colsum(const float *x, int64_t ld, int M, int N, float *out, int accumulate, float *workspace,
                int64_t workspace_floats, void *stream);
 
+/* Several column sums in at most two launches (the bias gradients of one backward sweep): job i sums x_i [M_i, N_i]
+ * over its rows into each of its n_out outputs (tied biases share one reduction), or adds to them (accumulate).
+ * Fixed order, deterministic.  workspace: sum over jobs with M >= 256 of ceil-chunks * N floats (<= 64 N each). */
+#define ISC_COLSUM_MAX_JOBS 24
+#define ISC_COLSUM_MAX_OUT 3
+typedef struct {
+    const float *x;
+    int64_t ld;
+    int32_t M, N;
+    float *out[ISC_COLSUM_MAX_OUT];
+    int32_t n_out, accumulate;
+} isc_colsum_job;
+int isc_colsum_multi(const isc_colsum_job *jobs_host, int n_jobs, float *workspace, int64_t workspace_floats,
+                     void *stream);
+
 /* dz = dy * (y > 0) [* mask * scale]  (ReLU + Dropout backward of the prologue layers);
  * y == NULL skips the ReLU test (pure nn.Dropout backward, captioner.py:182). */
 int isc_relu_mask_bwd(const float *dy, const float *y, const uint8_t *keep_mask, float scale, int64_t n,

@@ -102,6 +102,14 @@ class BeamMergeArgs(C.Structure):
                    C.c_void_p))
 
 
+ISC_COLSUM_MAX_JOBS, ISC_COLSUM_MAX_OUT = 24, 3
+
+
+class ColsumJob(C.Structure):
+    _fields_ = [('x', C.c_void_p), ('ld', C.c_int64), ('M', C.c_int32), ('N', C.c_int32),
+                ('out', C.c_void_p * ISC_COLSUM_MAX_OUT), ('n_out', C.c_int32), ('accumulate', C.c_int32)]
+
+
 class RolloutStep(C.Structure):
     _fields_ = [('B', C.c_int32), ('V', C.c_int32), ('T', C.c_int32), ('t', C.c_int32),
                 ('n_tile', C.c_int32), ('W', C.c_int32),
@@ -121,6 +129,7 @@ SIGNATURES = {
     'isc_set_h3_mode': (C.c_int, [C.c_int]),
     'isc_h3_launches': (C.c_longlong, []),
     'isc_set_gemv_rows': (C.c_int, [C.c_int]),
+    'isc_colsum_multi': (C.c_int, [C.POINTER(ColsumJob), C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
     'isc_gemv_launches': (C.c_longlong, []),
     'isc_h3x_launches': (C.c_longlong, []),
     'isc_h3s_launches': (C.c_longlong, []),

@@ -54,7 +54,7 @@ def _train_forward(cap, mode, fc, att, cpt_words, senti_words, tokens_in, senti_
     S = _Saved()
     S.p, S.P, S.mode, S.B, S.T = p, P, mode, B, T
     new, zeros = cap._new, cap._zeros
-    S.h1, S.c1, S.h2, S.c2 = (zeros(T + 1, B, H) for _ in range(4))      # slot 0 = initial zero state
+    S.h1, S.c1, S.h2, S.c2 = zeros(4, T + 1, B, H).unbind(0)             # slot 0 = initial zero state (one fill)
     S.g1, S.g2 = new(T, B, 4 * H), new(T, B, 4 * H)
     S.xt, S.tok = new(T, B, Wd), torch.empty(T, B, dtype=torch.int64, device=cap._dev)
     if has_c:
@@ -182,10 +182,13 @@ def _backward(cap, S, dlogp, d_fc_feats, d_cpt_feats, sparse=()):
         ops.gemm_bwd([ops.gemm_problem([(a, w)], out, TN)], TN)
         return out
 
-    def csum(x, n=None):
-        out = new(x.shape[1])
-        ops.colsum(x, out)
-        return out
+    pending_sums = []      # (x, outs): every bias gradient of the sweep goes out in one isc_colsum_multi at the end
+
+    def csum(x, copies=1):
+        """Column sum of x, deferred; `copies` > 1: that many identical results (tied biases) from one reduction."""
+        outs = [new(x.shape[1]) for _ in range(copies)]
+        pending_sums.append((x, outs, False))
+        return outs[0] if copies == 1 else outs
 
     # ---- classifier + log-softmax: outside the recurrence, all T*B rows at once (time-major rows)
     Vp = _pad32(V)
@@ -352,10 +355,8 @@ def _backward(cap, S, dlogp, d_fc_feats, d_cpt_feats, sparse=()):
     G['att_lstm.weight_hh'] = gwhh1
     G['lang_lstm.weight_ih'] = gW2
     G['lang_lstm.weight_hh'] = tn(dG2f, h2_prev)
-    G['att_lstm.bias_ih'] = csum(dG1f)
-    G['att_lstm.bias_hh'] = G['att_lstm.bias_ih'].clone()
-    G['lang_lstm.bias_ih'] = csum(dG2f)
-    G['lang_lstm.bias_hh'] = G['lang_lstm.bias_ih'].clone()
+    G['att_lstm.bias_ih'], G['att_lstm.bias_hh'] = csum(dG1f, 2)
+    G['lang_lstm.bias_ih'], G['lang_lstm.bias_hh'] = csum(dG2f, 2)
     # inputs of the att-LSTM: fc (step-invariant), xt = relu(Emb[tok]) + label_e
     d_fc_e = new(B, E)
     d_label_e = new(B, Wd) if P.label_e is not None else None
@@ -394,9 +395,7 @@ def _backward(cap, S, dlogp, d_fc_feats, d_cpt_feats, sparse=()):
         G['attention.cont2att.weight'] = tn(dzf, S.v.view(TB, E))
         G['attention.senti2att.weight'] = tn(dzf, S.s.view(TB, E))
         G['attention.h2att.weight'] = tn(dzf, h1_cur)
-        bz = csum(dzf)
-        G['attention.cont2att.bias'], G['attention.senti2att.bias'], G['attention.h2att.bias'] = \
-            bz, bz.clone(), bz.clone()
+        G['attention.cont2att.bias'], G['attention.senti2att.bias'], G['attention.h2att.bias'] = csum(dzf, 3)
         G['attention.att_alpha.weight'] = csum(dwg_rows).view(1, A)
         G['attention.att_alpha.bias'] = csum(dbg_rows.view(B, 1))
 
@@ -461,6 +460,7 @@ def _backward(cap, S, dlogp, d_fc_feats, d_cpt_feats, sparse=()):
                            skip_id=cap.pad_id)
     dEmb[cap.pad_id].zero_()     # nn.Embedding(padding_idx=pad_id): the <PAD> row never gets a gradient
     G['word_embed.0.weight'] = dEmb
+    ops.colsum_multi(pending_sums)
     if gs is not None:           # undo the gradient scale: x 1/S, a power of two
         torch._foreach_mul_(list(G.values()), gs[1])
     return G

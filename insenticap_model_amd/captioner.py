@@ -159,6 +159,11 @@ class Captioner(nn.Module):
 
         pre = {}
 
+        def draw(shape):
+            # keep with probability 1 - p: ONE launch (uniform draw + compare + byte store; torch's generator, so it is
+            # graph-safe and replays draw afresh) instead of rand / >= / to(uint8)
+            return torch.empty(shape, dtype=torch.uint8, device=self._dev).bernoulli_(1.0 - p_drop)
+
         def f(key, *shape):
             if masks is not None:
                 m = masks.get(key)
@@ -169,13 +174,13 @@ class Captioner(nn.Module):
                 return None, 1.0
             if key in pre:
                 return pre[key], scale
-            return (torch.rand(shape, device=self._dev) >= p_drop).to(torch.uint8), scale
+            return draw(shape), scale
 
         def predraw(prefix, n, *shape):
             """Draw the masks `prefix0 .. prefix<n-1>` of one unroll in a single tensor (3 launches instead of 3n)."""
             if masks is not None or not self.training or p_drop == 0.0:
                 return
-            m = (torch.rand((n,) + tuple(shape), device=self._dev) >= p_drop).to(torch.uint8)
+            m = draw((n,) + tuple(shape))
             for i in range(n):
                 pre['%s%d' % (prefix, i)] = m[i]
         f.predraw = predraw

@@ -977,6 +977,104 @@ extern "C" int isc_colsum(const float *x, int64_t ld, int M, int N, float *out, 
     return ISC_OK;
 }
 
+// Many column sums in (at most) two launches: the bias gradients of one backward sweep are ~15 independent
+// reductions of 5-9 us each, most of them a launch floor.  Phase 1: every job's (column block, row chunk) partial -
+// written straight to the job's outputs when the job has one chunk; phase 2 (only if some job has several chunks):
+// the chunk partials in chunk order.  Same 4-way row interleave and pairwise finish as colsum_kernel; deterministic.
+// A job may have up to three outputs (tied biases: b_ih / b_hh of an LSTM, the three biases summed into the gate).
+struct DevColJob {
+    const float *x;
+    long long ld;
+    int M, N, chunks, rpc, blk0, blk1;          // blk0 / blk1: first block of the job in phase 1 / phase 2
+    long long part_off;
+    float *out[ISC_COLSUM_MAX_OUT];
+    int nout, accumulate;
+};
+struct DevColLaunch {
+    DevColJob j[ISC_COLSUM_MAX_JOBS];
+    int njobs;
+};
+
+__device__ __forceinline__ void colsum_store(const DevColJob &J, int n, float t) {
+    for (int o = 0; o < J.nout; ++o) J.out[o][n] = J.accumulate ? J.out[o][n] + t : t;
+}
+
+__global__ __launch_bounds__(256) void colsum_multi_kernel(const DevColLaunch L, float *part) {
+    __shared__ float red[4][64];
+    int ji = 0;
+    while (ji + 1 < L.njobs && (int)blockIdx.x >= L.j[ji + 1].blk0) ++ji;
+    const DevColJob &J = L.j[ji];
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int b = blockIdx.x - J.blk0, nb = (J.N + 63) / 64, cb = b % nb, chunk = b / nb;
+    const int n = cb * 64 + lane;
+    const int m0 = chunk * J.rpc;
+    int m1 = m0 + J.rpc;
+    if (m1 > J.M) m1 = J.M;
+    float s = 0.f;
+    if (n < J.N)
+        for (int m = m0 + grp; m < m1; m += 4) s += J.x[(long long)m * J.ld + n];
+    red[grp][lane] = s;
+    __syncthreads();
+    if (grp == 0 && n < J.N) {
+        const float t = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+        if (J.chunks == 1) colsum_store(J, n, t);
+        else part[J.part_off + (long long)chunk * J.N + n] = t;
+    }
+}
+
+__global__ __launch_bounds__(64) void colsum_multi_finish_kernel(const DevColLaunch L, const float *part) {
+    int ji = -1;
+    for (int i = 0; i < L.njobs; ++i)
+        if (L.j[i].chunks > 1 && (int)blockIdx.x >= L.j[i].blk1) ji = i;
+    const DevColJob &J = L.j[ji];
+    const int n = (blockIdx.x - J.blk1) * 64 + threadIdx.x;
+    if (n >= J.N) return;
+    float t = 0.f;
+    for (int c = 0; c < J.chunks; ++c) t += part[J.part_off + (long long)c * J.N + n];
+    colsum_store(J, n, t);
+}
+
+extern "C" int isc_colsum_multi(const isc_colsum_job *jobs, int n_jobs, float *workspace, int64_t workspace_floats,
+                                void *stream) {
+    if (!jobs) return ISC_E_NULL;
+    if (n_jobs < 1 || n_jobs > ISC_COLSUM_MAX_JOBS) return ISC_E_SHAPE;
+    DevColLaunch L = {};
+    L.njobs = n_jobs;
+    int blocks1 = 0, blocks2 = 0;
+    long long part = 0;
+    for (int i = 0; i < n_jobs; ++i) {
+        const isc_colsum_job &q = jobs[i];
+        if (!q.x || q.n_out < 1 || q.n_out > ISC_COLSUM_MAX_OUT) return q.x ? ISC_E_SHAPE : ISC_E_NULL;
+        if (q.M <= 0 || q.N <= 0) return ISC_E_SHAPE;
+        DevColJob &J = L.j[i];
+        J.x = q.x; J.ld = q.ld; J.M = q.M; J.N = q.N; J.nout = q.n_out; J.accumulate = q.accumulate;
+        for (int o = 0; o < q.n_out; ++o) {
+            if (!q.out[o]) return ISC_E_NULL;
+            J.out[o] = q.out[o];
+        }
+        int chunks = 1;
+        if (q.M >= 256) {
+            chunks = (q.M + 63) / 64;
+            if (chunks > 64) chunks = 64;
+        }
+        J.rpc = (q.M + chunks - 1) / chunks;
+        J.chunks = (q.M + J.rpc - 1) / J.rpc;
+        const int nb = (q.N + 63) / 64;
+        J.blk0 = blocks1; blocks1 += nb * J.chunks;
+        J.blk1 = blocks2; J.part_off = part;
+        if (J.chunks > 1) { blocks2 += nb; part += (long long)J.chunks * q.N; }
+    }
+    if (part > 0 && (!workspace || part > workspace_floats)) return ISC_E_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(colsum_multi_kernel, dim3(blocks1), dim3(256), 0, st, L, workspace);
+    ISC_LAUNCH_CHECK();
+    if (blocks2 > 0) {
+        hipLaunchKernelGGL(colsum_multi_finish_kernel, dim3(blocks2), dim3(64), 0, st, L, workspace);
+        ISC_LAUNCH_CHECK();
+    }
+    return ISC_OK;
+}
+
 // ------------------------------------------------------------------ ReLU (+dropout) backward
 __global__ __launch_bounds__(256) void relu_mask_bwd_kernel(const float *dy, const float *y,
                                                             const uint8_t *mask, float scale, long long n,

@@ -777,6 +777,26 @@ def colsum(x, out, accumulate=False):
                          ws.numel(), stream()), 'isc_colsum')
 
 
+def colsum_multi(jobs):
+    """jobs: list of (x [M,N], [out tensors, 1..3], accumulate) - every column sum in at most two launches per 24 jobs
+    (isc_colsum_multi).  The caller keeps every x alive and untouched until this returns."""
+    lib = _lib.load()
+    if not jobs:
+        return
+    ws = splitk_ws(jobs[0][0].device)
+    for lo in range(0, len(jobs), _lib.ISC_COLSUM_MAX_JOBS):
+        part = jobs[lo:lo + _lib.ISC_COLSUM_MAX_JOBS]
+        arr = (_lib.ColsumJob * len(part))()
+        for q, (x, outs, acc) in zip(arr, part):
+            M, N = x.shape
+            assert x.stride(1) == 1 and x.dtype == torch.float32 and 1 <= len(outs) <= _lib.ISC_COLSUM_MAX_OUT
+            q.x, q.ld, q.M, q.N, q.n_out, q.accumulate = x.data_ptr(), x.stride(0), M, N, len(outs), int(acc)
+            for i, o in enumerate(outs):
+                assert o.is_contiguous() and o.numel() >= N and o.dtype == torch.float32
+                q.out[i] = o.data_ptr()
+        check(lib.isc_colsum_multi(arr, len(part), ws.data_ptr(), ws.numel(), stream()), 'isc_colsum_multi')
+
+
 def relu_mask_bwd(dy, y, dz, keep_mask=None, scale=1.0):
     """dz = dy * (y > 0) [* mask * scale]; y=None skips the ReLU test (pure dropout backward)."""
     lib = _lib.load()
