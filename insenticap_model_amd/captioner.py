@@ -119,6 +119,11 @@ class Captioner(nn.Module):
         # captured on its second call and replayed from then on - bit-identical results, 2.3 instead of 2.6 ms for a
         # single-image beam-5 search.  enable_beam_graphs(False) turns it off (320 MB of graph buffers per captioner).
         self._beam_graphs, self._beam_graphs_max = {}, 4
+        # ... and so are eval-mode greedy roll-outs of at most ROLLOUT_GRAPH_MAX_ROWS captions (enable_rollout_graphs):
+        # at those sizes a roll-out is ~130 dependent small launches and the host is the slower side (B = 4: single call
+        # 1.90 -> 1.40 ms, B = 128: 1.99 -> 1.62; at 512 rows the device is, and the graph's per-replay weight split
+        # costs more than it saves: eager).
+        self._rollout_graphs, self._rollout_graphs_max = {}, 4
 
     # ------------------------------------------------------------------ plumbing
     def _p(self):
@@ -188,6 +193,7 @@ class Captioner(nn.Module):
 
     # ------------------------------------------------------------------ prologue
     GATE_FUSED_MAX_ROWS = 768      # decode rows up to which scans + gate sum + gate mix run as ONE launch (inference)
+    ROLLOUT_GRAPH_MAX_ROWS = 256   # greedy eval roll-outs up to this many captions are served from HIP graphs
 
     def _prologue(self, p, mode, fc=None, att=None, cpt_words=None, senti_words=None, senti_labels=None,
                   masks=None, want_table=False, words_table=False, gate_rows=0):
@@ -650,7 +656,8 @@ class Captioner(nn.Module):
             return rollout_with_grad(self, fc_feats, att_feats, cpt_words, senti_words, senti_labels,
                                      max_seq_len, _replay, _masks)
         if (sample_max and self.__dict__.get('_rollout_graphs') is not None and not self._needs_grad()
-                and not self.training and _replay is None and _masks is None and ops.TIMER.arm_step is None):
+                and not self.training and _replay is None and _masks is None and ops.TIMER.arm_step is None
+                and fc_feats.shape[0] <= self.ROLLOUT_GRAPH_MAX_ROWS and ops.graphs_allowed_here()):
             return self._graphed_rollout(fc_feats, att_feats, cpt_words, senti_words, senti_labels, max_seq_len)
         return self._rollout(fc_feats, att_feats, cpt_words, senti_words, senti_labels, max_seq_len,
                              sample_max, _replay, _masks)[:3]

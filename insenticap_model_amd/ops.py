@@ -88,6 +88,13 @@ def h3w_bytes():
     return _WS_SIZES['h3w']
 
 
+def graphs_allowed_here():
+    """Graph serving that is ON BY DEFAULT (beam search, small greedy roll-outs) applies on the main host thread only:
+    a capture begins with a device-wide synchronisation and an allocator sweep, and two threads capturing at once is
+    not something this package has exercised.  Worker threads run the same calls eagerly (same results)."""
+    return threading.current_thread() is threading.main_thread()
+
+
 def graph_capture(graph, **kw):
     """torch.cuda.graph(graph, **kw) for this package's captures, safe next to a torch.distributed process group.
     The backend's watchdog thread polls the completion event of every collective still on its list (hipEventQuery,
@@ -104,8 +111,10 @@ def graph_capture(graph, **kw):
         grouped = dist.is_available() and dist.is_initialized()
     except Exception:                   # a torch build without distributed
         grouped = False
+    # 'thread_local' always: another host thread serving its own captioner on its own stream (include/insenticap_hip.h
+    # allows that) may allocate or synchronise while this one captures; 'global' would fail ITS calls
+    kw.setdefault('capture_error_mode', 'thread_local')
     if grouped:
-        kw.setdefault('capture_error_mode', 'thread_local')
         # ... and no collective may still be on the watchdog's list when the capture opens: it retires finished work
         # at its next pass (every 100 ms), so finish everything and let one pass go by.  Captures are once per geometry.
         torch.cuda.synchronize()

@@ -145,7 +145,8 @@ def test_graph_replay_equals_eager_rollout(B):
     same geometry, and follows in-place weight changes."""
     cap = _cap().eval()
     ref = _cap().eval()
-    cap.enable_rollout_graphs(True)
+    cap.enable_rollout_graphs(True)        # (the default since round 3, for at most ROLLOUT_GRAPH_MAX_ROWS captions)
+    ref.enable_rollout_graphs(False)
     outs = []
     with torch.no_grad():
         for seed in (3, 4, 5, 6):                              # call 1 eager, call 2 captures, calls 3-4 replay
