@@ -3,16 +3,24 @@
 At the reference's batch sizes an iteration is ~670 launches of 4-40 us each: on MI355X the device finishes them as
 fast as the host can enqueue them (7.1 ms of kernel time against 7.8 ms of host time per iteration at B = 128 + 80
 seq2seq rows), so whatever a kernel saves is not seen until the host is out of the loop.  `XETrainGraph.step` runs the
-same three phases as `train.xe_train_step` - (1) both unrolls, losses, backward; (2) the data-parallel exchange;
-(3) clamp + Adam + re-split of the weight planes - with (1) and (3) captured once per input geometry and replayed:
+same phases as `train.xe_train_step` - (1) both unrolls, losses, backward; (2) the data-parallel exchange;
+(3) clamp + Adam + re-split of the weight planes - with (1) and (3) captured once per input geometry and replayed (one
+graph without a process group, two with the exchange between them):
 
     graph = XETrainGraph(captioner, optim, xe_crit, da_crit, grad_clip=0.1)
     for batch ...:  losses = graph.step(fact_batch, senti_labels, scs_batch, ss_prob)
 
 What makes the capture sound:
   * private streams: the capture stream and the seq2seq side stream belong to this object, so everything this library
-    keeps per stream (split-K workspace, f16 weight-plane buffer, weights-scope slot) is private to its graphs; the
-    seq2seq unroll stays a parallel branch of the graph (fork / join through events, as in the eager step);
+    keeps per stream (split-K workspace, f16 weight-plane buffer, weights-scope slot) is private to its graphs;
+  * two long branches: the seq2seq unroll - forward AND backward - forks off on the side stream before the XE unroll
+    starts and joins after it.  Its gradients go to tensors of their own (p.grad is swapped out around its backward)
+    and are added in one multi-tensor launch after the join: the same two-operand sums autograd's accumulation forms
+    in the eager step, bit for bit.  (The eager step forks the seq2seq FORWARD only after the XE forward is queued and
+    lets autograd interleave the backward sweeps: replayed as a graph that hid 1.1 of the branch's 2.9 ms; the two
+    full-length branches hide nearly all of it - 5.8 -> 4.9 ms per iteration at B = 128 + 80.  As two separately
+    launched graphs on the two streams the same work once died with a GPU memory fault on a second replay that could
+    not be reproduced or attributed; one graph with two branches ran 1500 iterations in a row and every test.)
   * static inputs: every batch is copied into fixed device buffers first (caption lengths included: no host copy sits
     inside a graph); a new geometry (batch size, caption length, ss_prob, train / eval mode) gets its own graph after
     `warmup` eager iterations on the same streams;
@@ -48,7 +56,8 @@ class _Geometry:
     def __init__(self):
         self.inputs = None          # dict name -> static device tensor
         self.eager_runs = 0
-        self.g_fb = self.g_up = None
+        self.g_iter = self.g_up = None
+        self.keep = None            # tensors the graphs read across each other (gradient lists, losses)
         self.vec = None             # static [xe, da, seq2seq] losses (local values)
         self.layout = None          # weights-scope cold-begin count the graphs were captured under
 
@@ -71,6 +80,7 @@ class XETrainGraph:
         self._scope_keys = ((idx, self.stream.cuda_stream), (idx, self.side.cuda_stream))
         self._handles = (self.stream.cuda_stream, self.side.cuda_stream)
         self.hyper = torch.zeros(3, dtype=torch.float32, device=self.device)
+        self._params = [q for q in captioner.parameters() if q.requires_grad]
         self.shares = torch.ones(3, dtype=torch.float32, device=self.device)
         self._geoms = collections.OrderedDict()
         self._max_geoms = max_geometries
@@ -141,10 +151,57 @@ class XETrainGraph:
         scs = (i['s_caps'], i['s_len'], i['s_cpts'], i['s_sentis'], i['s_labels']) if 's_caps' in i else None
         return fact, i['labels'], scs
 
-    def _forward_backward(self, geo, ss_prob):
-        fact, labels, scs = self._phase_args(geo)
-        return xe_forward_backward(self.cap, self.optim, self.xe_crit, self.da_crit, fact, labels, scs, ss_prob,
-                                   self.arena, self.shares if self._dist() else None, True, self.side)
+    # ---- the phases of an iteration (run eagerly while a geometry warms up, captured afterwards) ----------------
+    def _phase_xe(self, geo, ss_prob):
+        """XE unroll + domain-align loss, forward and backward, on self.stream; gradients land in p.grad (the arena's
+        views under DP).  Returns the detached [xe, da, 0] losses."""
+        fact, labels, _ = self._phase_args(geo)
+        self.cap.cpt_feats = self.cap.fc_feats = None
+        return xe_forward_backward(self.cap, self.optim, self.xe_crit, self.da_crit, fact, labels, None, ss_prob,
+                                   self.arena, self.shares if self._dist() else None, False, None)
+
+    def _phase_s2s(self, geo, ss_prob):
+        """seq2seq unroll, forward and backward, on self.side - concurrently with _phase_xe, so its gradients go to
+        tensors of their own (p.grad is swapped out around the backward) and are added afterwards (_phase_add): the
+        same two-operand sums autograd's accumulation forms in the eager step.  Returns (loss, gradient list)."""
+        from .train import _xe_loss
+        _, _, scs = self._phase_args(geo)
+        s_caps, s_len, s_cpts, s_sentis, s_labels = scs
+        params = self._params
+        self.cap.cpt_feats = self.cap.fc_feats = None          # the accumulate nodes are re-made under THIS stream
+        pred2 = self.cap(s_caps, s_cpts, s_sentis, s_labels, ss_prob, mode='seq2seq')
+        loss = _xe_loss(self.xe_crit, pred2, s_caps[:, 1:], s_len)
+        if self._dist():
+            loss = loss * self.shares[1]
+        main = [q.grad for q in params]
+        for q in params:
+            q.grad = None
+        try:
+            loss.backward()
+            own = [q.grad for q in params]
+        finally:
+            for q, g in zip(params, main):
+                q.grad = g
+        self.cap.cpt_feats = None
+        return loss.detach(), own
+
+    def _phase_add(self, geo, vec_xe, s2s):
+        """p.grad += the seq2seq unroll's gradients (one multi-tensor launch); the loss vector."""
+        if s2s is None:
+            return vec_xe
+        loss, own = s2s
+        dst, src = [], []
+        for q, g in zip(self._params, own):
+            if g is None:
+                continue
+            if q.grad is None:
+                q.grad = g                                      # a parameter only the seq2seq unroll reaches
+            else:
+                dst.append(q.grad)
+                src.append(g)
+        if dst:
+            torch._foreach_add_(dst, src)
+        return torch.stack([vec_xe[0], vec_xe[1], loss])
 
     def _exchange(self, vec):
         if self.arena is not None:
@@ -164,19 +221,37 @@ class XETrainGraph:
                 len(self.optim.state[q])]
 
     def _capture(self, geo, ss_prob):
-        """Both graphs of this geometry, on this object's streams, scopes warm.  Capturing enqueues nothing: the
-        optimizer's step counters and the weight epoch the host logic advanced are taken back / carried by the
+        """The graph(s) of this geometry, scopes warm: the seq2seq unroll as a branch on self.side around the XE unroll
+        on self.stream, then add + update (a second graph under a process group: the exchange sits in front of the
+        update).  Capturing enqueues nothing:
+        the optimizer's step counters and the weight epoch the host logic advanced are taken back / carried by the
         first replay."""
         steps_before = [float(st['step']) for st in self._states()]
         self.optim.device_hyper = self.hyper
+        has_s2s = 's_caps' in geo.inputs
         try:
             with ops.refresh_only(self._handles):
-                geo.g_fb = torch.cuda.CUDAGraph()
-                with ops.graph_capture(geo.g_fb, stream=self.stream):
-                    geo.vec = self._forward_backward(geo, ss_prob)
-                geo.g_up = torch.cuda.CUDAGraph()
-                with ops.graph_capture(geo.g_up, stream=self.stream, pool=geo.g_fb.pool()):
-                    xe_update(self.optim, self.grad_clip)
+                # ONE graph, two long branches: the seq2seq unroll (forward AND backward) forks off on self.side before
+                # the XE unroll starts on self.stream and joins after it
+                geo.g_iter = torch.cuda.CUDAGraph()
+                with ops.graph_capture(geo.g_iter, stream=self.stream):
+                    s2s = None
+                    if has_s2s:
+                        self.side.wait_stream(self.stream)
+                        with torch.cuda.stream(self.side):
+                            s2s = self._phase_s2s(geo, ss_prob)
+                    vec_xe = self._phase_xe(geo, ss_prob)
+                    if has_s2s:
+                        self.stream.wait_stream(self.side)
+                    geo.vec = self._phase_add(geo, vec_xe, s2s)
+                    if not self._dist():
+                        xe_update(self.optim, self.grad_clip)
+                geo.g_up = None
+                if self._dist():
+                    geo.g_up = torch.cuda.CUDAGraph()
+                    with ops.graph_capture(geo.g_up, stream=self.stream):
+                        xe_update(self.optim, self.grad_clip)
+                geo.keep = (vec_xe, s2s)
         finally:
             self.optim.device_hyper = None
         for st, n in zip(self._states(), steps_before):
@@ -190,9 +265,11 @@ class XETrainGraph:
         for st in states:
             st['step'] += 1
         self._set_hyper(int(states[0]['step']))
-        geo.g_fb.replay()
-        vec = self._exchange(geo.vec)
-        geo.g_up.replay()
+        geo.g_iter.replay()
+        vec = geo.vec
+        if geo.g_up is not None:
+            vec = self._exchange(vec)
+            geo.g_up.replay()
         # what the captured host logic did once, per replay: the weights moved behind torch's back ...
         epoch_before = ops.WEIGHT_EPOCH
         ops.WEIGHT_EPOCH += 1
@@ -202,8 +279,22 @@ class XETrainGraph:
         return vec
 
     def _eager(self, geo, ss_prob):
+        """The same phases, not captured (a geometry's first iterations; any iteration after something else moved the
+        weights): same streams, same order of dependencies."""
         with ops.refresh_only(self._handles):
-            vec = self._forward_backward(geo, ss_prob)
+            has_s2s = 's_caps' in geo.inputs
+            if has_s2s:
+                self.side.wait_stream(self.stream)
+            vec_xe = self._phase_xe(geo, ss_prob)
+            s2s = None
+            if has_s2s:
+                with torch.cuda.stream(self.side):
+                    s2s = self._phase_s2s(geo, ss_prob)
+                self.stream.wait_stream(self.side)
+                for g in s2s[1]:
+                    if g is not None:
+                        g.record_stream(self.stream)
+            vec = self._phase_add(geo, vec_xe, s2s)
             vec = self._exchange(vec)
             xe_update(self.optim, self.grad_clip)
         self._valid_key = self.cap._weights_key()
@@ -245,10 +336,10 @@ class XETrainGraph:
                 self.shares.copy_(dp_shares(lengths, s_lengths, fc.shape[0], self.device, self.group))
             planes_ok = self._valid_key is not None and self._valid_key == self.cap._weights_key()
             if ops.h3_weights_scope.cold_begins(self._scope_keys) != geo.layout:
-                geo.g_fb = geo.g_up = None               # a scope on our streams was rebuilt since: addresses may differ
-            if geo.g_fb is None and planes_ok and geo.eager_runs >= self.warmup:
+                geo.g_iter = geo.g_up = None                 # a scope of ours was rebuilt: addresses may differ
+            if geo.g_iter is None and planes_ok and geo.eager_runs >= self.warmup:
                 self._capture(geo, ss_prob)
-            if geo.g_fb is not None and planes_ok:
+            if geo.g_iter is not None and planes_ok:
                 vec = self._replay(geo)
             else:
                 vec = self._eager(geo, ss_prob)
