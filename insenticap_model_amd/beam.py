@@ -174,7 +174,9 @@ def _graphed_search(cap, fc_feats, att_feats, senti_words, senti_labels, beam, d
     entry = cache.get(key)
     if entry is None:                       # first sight: run eagerly (builds the cached tables, warms the kernels)
         while len(cache) >= cap._beam_graphs_max:
-            cache.pop(next(iter(cache)))    # least recently used (hits re-insert their key at the end)
+            cap._graph_evicted(cache.pop(next(iter(cache))), 'beam')    # least recently used
+            if cap._beam_graphs is None:
+                return _search(cap, *ins, beam, decoding_constraint, T)
         cache[key] = 'seen'
         return _search(cap, *ins, beam, decoding_constraint, T)
     cache[key] = cache.pop(key)             # LRU order

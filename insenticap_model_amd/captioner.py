@@ -672,6 +672,7 @@ class Captioner(nn.Module):
         the embedding / att-LSTM weights re-captures, because the cached token table depends on them)."""
         self._rollout_graphs = {} if on else None
         self._rollout_graphs_max = max_graphs
+        self._graphs_explicit = bool(on)
 
     def _graphed_rollout(self, fc_feats, att_feats, cpt_words, senti_words, senti_labels, T):
         emb, Wih = self.word_embed[0].weight, self.att_lstm.weight_ih
@@ -683,7 +684,9 @@ class Captioner(nn.Module):
         entry = cache.get(key)
         if entry is None:                       # first sight: run eagerly (warms kernels and one-time attributes)
             while len(cache) >= self._rollout_graphs_max:
-                cache.pop(next(iter(cache)))    # least recently used (hits re-insert their key at the end)
+                self._graph_evicted(cache.pop(next(iter(cache))), 'roll-out')    # least recently used
+                if self._rollout_graphs is None:
+                    return self._rollout(*ins, T, 1, None, None)[:3]
             cache[key] = 'seen'
             return self._rollout(*ins, T, 1, None, None)[:3]
         cache[key] = cache.pop(key)             # LRU order
@@ -706,6 +709,25 @@ class Captioner(nn.Module):
         self._weights_pending = pending          # attention weights of this replay (resolved lazily, as always)
         return tuple(o.clone() for o in outs)
 
+    GRAPH_THRASH_LIMIT = 8
+
+    def _graph_evicted(self, entry, what):
+        """A CAPTURED graph fell out of a cache of `max_graphs` geometries.  Graph serving that is on by default is for
+        callers with a few recurring geometries; one whose batch size wanders would pay a capture (~0.1 s: device-wide
+        synchronisation, allocator sweep) every few calls.  After GRAPH_THRASH_LIMIT such evictions both default caches
+        switch themselves off for this captioner (eager from then on, same results); enable_*_graphs(True, max_graphs=n)
+        switches them back on with room for the caller's geometries."""
+        if isinstance(entry, str):
+            return
+        n = self.__dict__['_graph_evictions'] = self.__dict__.get('_graph_evictions', 0) + 1
+        if n == self.GRAPH_THRASH_LIMIT and not self.__dict__.get('_graphs_explicit', False):
+            import warnings
+            warnings.warn('insenticap_model_amd: %d captured %s / beam graphs evicted - input geometries keep changing; '
+                          'default graph serving is off for this captioner (enable_rollout_graphs / enable_beam_graphs '
+                          'with a larger max_graphs to keep it)' % (n, what))
+            self._rollout_graphs = None
+            self._beam_graphs = None
+
     def enable_beam_graphs(self, on=True, max_graphs=4):
         """Serve beam searches (sample / sample_batch, device-side merge) from captured HIP graphs: the prologue and
         steps 0-3 in one graph, every further four steps in another, the live-image counter read between them
@@ -713,6 +735,7 @@ class Captioner(nn.Module):
         (a change of the embedding / att-LSTM / senti2att weights re-captures: the cached tables depend on them)."""
         self._beam_graphs = {} if on else None
         self._beam_graphs_max = max_graphs
+        self._graphs_explicit = bool(on)
 
     def _weights_key(self):
         """Identifies the current parameter VALUES of THIS instance (its nonce + storage pointers + version counters +

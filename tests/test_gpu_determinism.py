@@ -163,3 +163,27 @@ def test_graph_replay_equals_eager_rollout(B):
         got = cap(*args, sample_max=1, mode='rl')
         exp = ref(*args, sample_max=1, mode='rl')
         assert all(torch.equal(a, b) for a, b in zip(got, exp))
+
+
+def test_default_graph_serving_switches_itself_off_when_geometries_keep_changing():
+    """Roll-out graphs are on by default for small batches.  A caller whose batch size wanders evicts captured graphs
+    from the 4-geometry cache again and again - each capture is a device-wide synchronisation: after
+    Captioner.GRAPH_THRASH_LIMIT evictions the default caches switch themselves off (a warning says so) and the calls
+    run eagerly, with the same results throughout."""
+    import warnings
+    cap, ref = _cap().eval(), _cap().eval()
+    ref.enable_rollout_graphs(False)
+    assert cap._rollout_graphs == {} and not cap.__dict__.get('_graphs_explicit', False)
+    with torch.no_grad(), warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter('always')
+        for B in list(range(1, 15)) * 2:
+            d, t = _inputs(B, 1000, seed=B, T=6)
+            args = (t('fc_feats'), t('att_feats'), t('cpt_words'), t('senti_words'), t('senti_labels'), 6)
+            for rep in range(2):                   # second call of a geometry captures, so every new B evicts one
+                got, exp = cap(*args, sample_max=1, mode='rl'), ref(*args, sample_max=1, mode='rl')
+                assert all(torch.equal(a, b) for a, b in zip(got, exp)), (B, rep)
+    assert cap._rollout_graphs is None and cap._beam_graphs is None
+    assert cap.__dict__['_graph_evictions'] == Captioner.GRAPH_THRASH_LIMIT
+    assert any('default graph serving is off' in str(w.message) for w in caught)
+    cap.enable_rollout_graphs(True, max_graphs=16)                # the caller's answer: room for its geometries
+    assert cap._rollout_graphs == {} and cap._graphs_explicit
