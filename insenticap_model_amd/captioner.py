@@ -668,40 +668,67 @@ class Captioner(nn.Module):
         hundred captions a roll-out is ~260 dependent small launches: the host needs 110-140 us per decode step
         to enqueue them, the device ~105 us to run them.  The roll-out has no host read, so the whole T-step loop
         (prologue included) captures into ONE graph per input geometry; a call then costs one input copy and one
-        graph launch.  Inputs must keep their shapes to hit the cache; weights may change in place (a change of
-        the embedding / att-LSTM weights re-captures, because the cached token table depends on them)."""
+        graph launch.  Inputs must keep their shapes to hit the cache; a graph belongs to the weight VALUES it was
+        captured under (it contains no weight-split launches: the f16 planes stay on the captioner's roll-out stream) -
+        after any weight change the next call runs eagerly and the one after captures anew."""
         self._rollout_graphs = {} if on else None
         self._rollout_graphs_max = max_graphs
         self._graphs_explicit = bool(on)
 
+    def _rollout_stream(self):
+        """The stream every roll-out graph of this captioner is warmed up and captured on.  Everything the library keeps
+        per stream - split-K workspace, f16 weight-plane buffer, weights-scope slot - is then the graphs' own: the
+        planes a warm-up run builds there are still there, at the same addresses, when a replay reads them."""
+        st = self.__dict__.get('_ro_stream')
+        if st is None or st.device != self._dev:
+            st = self.__dict__['_ro_stream'] = torch.cuda.Stream(device=self._dev)
+            idx = self._dev.index if self._dev.index is not None else torch.cuda.current_device()
+            weakref.finalize(self, ops.release_stream_state, idx, st.cuda_stream)
+        return st
+
     def _graphed_rollout(self, fc_feats, att_feats, cpt_words, senti_words, senti_labels, T):
-        emb, Wih = self.word_embed[0].weight, self.att_lstm.weight_ih
         ins = [self._f32(fc_feats), self._f32(att_feats), cpt_words, senti_words, senti_labels]
-        key = (tuple((tuple(x.shape), x.dtype) for x in ins), T, emb._version, Wih._version,
-               self.senti2att[0].weight._version, self.senti2att[0].bias._version,
-               self.attention.senti2att.weight._version, ops.WEIGHT_EPOCH, torch.cuda.current_device())
+        # keyed on the weights' VALUES (every parameter's storage and version, the fused optimizer's epoch): a graph
+        # holds no weight-split launches - the planes its warm-up run left on the roll-out stream are valid exactly
+        # as long as this key is.  After a weight change the first call runs eagerly there (rebuilding the planes),
+        # the second captures anew.
+        key = (tuple((tuple(x.shape), x.dtype) for x in ins), T, self._weights_key(), torch.cuda.current_device())
         cache = self._rollout_graphs
+        st = self._rollout_stream()
+        idx = self._dev.index if self._dev.index is not None else torch.cuda.current_device()
+        skey = ((idx, st.cuda_stream),)
+        cur = torch.cuda.current_stream(self._dev)
+
+        def on_stream(fn):                      # fn() on the roll-out stream, ordered after / before the caller's
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                out = fn()
+            cur.wait_stream(st)
+            return out
         entry = cache.get(key)
-        if entry is None:                       # first sight: run eagerly (warms kernels and one-time attributes)
+        if isinstance(entry, tuple) and entry[4] != ops.h3_weights_scope.cold_begins(skey):
+            entry = cache[key] = 'seen'         # the stream's scope was rebuilt since the capture: addresses may differ
+        if entry is None:                       # first sight: run eagerly (warms kernels, builds tables and planes)
             while len(cache) >= self._rollout_graphs_max:
                 self._graph_evicted(cache.pop(next(iter(cache))), 'roll-out')    # least recently used
                 if self._rollout_graphs is None:
                     return self._rollout(*ins, T, 1, None, None)[:3]
             cache[key] = 'seen'
-            return self._rollout(*ins, T, 1, None, None)[:3]
+            outs = on_stream(lambda: self._rollout(*ins, T, 1, None, None)[:3])
+            for o in outs:
+                o.record_stream(cur)
+            return outs
         cache[key] = cache.pop(key)             # LRU order
         if entry == 'seen':
             static = [x.clone() for x in ins]
             graph = torch.cuda.CUDAGraph()
-            torch.cuda.synchronize()
-            # the graphs of this captioner share ONE split-K workspace and ONE weight-plane buffer (the per-stream
-            # ones would be keyed on the capture stream and could be freed under the graph); replays are enqueued on
-            # one stream at a time, so they never overlap
-            ws, wp = self._graph_buffers()
-            with ops.capture_buffers(ws, wp), ops.graph_capture(graph):
-                outs = self._rollout(*static, T, 1, None, None)[:3]
-                pending = self.__dict__.get('_weights_pending')
-            entry = cache[key] = (graph, static, outs, pending, ws, wp)
+
+            def capture():
+                with ops.graph_capture(graph, stream=st):
+                    o = self._rollout(*static, T, 1, None, None)[:3]
+                    return o, self.__dict__.get('_weights_pending')
+            outs, pending = on_stream(capture)
+            entry = cache[key] = (graph, static, outs, pending, ops.h3_weights_scope.cold_begins(skey))
         graph, static, outs, pending = entry[:4]
         for dst, src in zip(static, ins):
             dst.copy_(src, non_blocking=True)

@@ -157,7 +157,8 @@ def test_graph_replay_equals_eager_rollout(B):
             assert all(torch.equal(a, b) for a, b in zip(got, exp)), seed
             assert torch.equal(cap.cont_weights, ref.cont_weights)
         assert any(isinstance(v, tuple) for v in cap._rollout_graphs.values())
-        # in-place weight update (classifier bias): the graph reads weights by pointer
+        # in-place weight update (classifier bias): graphs belong to the weight values they were captured under -
+        # this call runs eagerly (and rebuilds the planes), the next one would capture anew
         for m in (cap, ref):
             m.classifier.bias.add_(torch.linspace(-1, 1, m.classifier.bias.numel(), device=dev()))
         got = cap(*args, sample_max=1, mode='rl')
