@@ -681,7 +681,7 @@ class Captioner(nn.Module):
         planes a warm-up run builds there are still there, at the same addresses, when a replay reads them."""
         st = self.__dict__.get('_ro_stream')
         if st is None or st.device != self._dev:
-            st = self.__dict__['_ro_stream'] = torch.cuda.Stream(device=self._dev)
+            st = self.__dict__['_ro_stream'] = ops.private_stream(self._dev)
             idx = self._dev.index if self._dev.index is not None else torch.cuda.current_device()
             weakref.finalize(self, ops.release_stream_state, idx, st.cuda_stream)
         return st

@@ -870,6 +870,26 @@ def check_numerics(where=''):
             % (where + ': ' if where else '', '; '.join(what)))
 
 
+_OWNED_STREAMS = set()      # (device index, stream handle) of the streams this package's objects hold for themselves
+
+
+def private_stream(device):
+    """A torch.cuda.Stream that no other owner inside this package holds (and that is not the caller's current stream).
+    torch hands out the 32 pool streams of a device round robin, so the 33rd Stream() IS the first again - and
+    everything kept per stream here (split-K workspace, weight planes, weights-scope slot) would be shared with it.
+    Owners: train_graph.XETrainGraph (two), a captioner's roll-out stream, the eager training step's side stream."""
+    device = torch.device(device)
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    cur = torch.cuda.current_stream(idx).cuda_stream
+    for _ in range(48):
+        st = torch.cuda.Stream(device=idx)
+        key = (idx, st.cuda_stream)
+        if key not in _OWNED_STREAMS and st.cuda_stream != cur:
+            _OWNED_STREAMS.add(key)
+            return st
+    raise RuntimeError('no free stream left in the pool of device %d (%d held by this package)' % (idx, len(_OWNED_STREAMS)))
+
+
 def release_stream_state(index, handle):
     """Forget everything kept per (device index, stream handle): split-K workspace, weight-plane buffer, the suspended
     weights scope and the library's scope slot.  For owners of private streams that go away (train_graph)."""
@@ -882,6 +902,7 @@ def release_stream_state(index, handle):
         cls._cold_begins.pop(key, None)
         _H3W_BUF.pop(key, None)
     _SPLITK_WS.pop(key, None)
+    _OWNED_STREAMS.discard(key)
     _lib.load().isc_h3_weights_end(C.c_void_p(handle))
     return True
 

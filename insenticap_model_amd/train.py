@@ -17,7 +17,8 @@ _SIDE_STREAMS = {}
 def _side_stream(device):
     key = (device.type, device.index)
     if key not in _SIDE_STREAMS:
-        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+        from . import ops
+        _SIDE_STREAMS[key] = ops.private_stream(device)
         # gradients of one parameter arrive from two streams by design
         warn_off = getattr(torch.autograd.graph, 'set_warn_on_accumulate_grad_stream_mismatch', None)
         if warn_off is not None:

@@ -75,8 +75,8 @@ class XETrainGraph:
         ops.require_device(*captioner.parameters())
         # (default priority on purpose: on high-priority streams the same replays took 18.3 instead of 5.8 ms)
         idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
-        self.stream = self._fresh_stream(idx)
-        self.side = self._fresh_stream(idx)
+        self.stream = ops.private_stream(self.device)
+        self.side = ops.private_stream(self.device)
         self._scope_keys = ((idx, self.stream.cuda_stream), (idx, self.side.cuda_stream))
         self._handles = (self.stream.cuda_stream, self.side.cuda_stream)
         self.hyper = torch.zeros(3, dtype=torch.float32, device=self.device)
@@ -86,29 +86,10 @@ class XETrainGraph:
         self._max_geoms = max_geometries
         self._valid_key = None       # Captioner._weights_key() after the last step this object ran
         self.replays = self.eager_steps = self.captures = 0
-        # torch hands out streams from a pool of 32 per device, round robin: "private" holds while nobody else holds
-        # the same two.  The state this library keeps per stream is dropped with this object, so a later owner of the
-        # same handles starts clean (and 2 x 320 MB of workspace do not outlive the graphs that used them).
-        main = torch.cuda.current_stream(self.device).cuda_stream
-        if len({self.stream.cuda_stream, self.side.cuda_stream, main}) != 3:
-            raise RuntimeError('XETrainGraph needs two streams of its own (the stream pool handed out aliases)')
+        # (ops.private_stream: no other owner in this package holds these two.)  The state the library keeps per stream
+        # is dropped with this object, so a later owner of the same handles starts clean (and 2 x 320 MB of workspace
+        # do not outlive the graphs that used them).
         self._finalizer = weakref.finalize(self, XETrainGraph._release, self._scope_keys)
-
-    _OWNED = set()      # (device index, stream handle) pairs held by live XETrainGraph objects
-
-    def _fresh_stream(self, idx):
-        """A stream no live XETrainGraph holds (torch hands out a device's 32 pool streams round robin: the 17th object
-        would otherwise share handles - and with them workspaces, planes and scope slots - with the first)."""
-        from . import train
-        taken = {torch.cuda.current_stream(self.device).cuda_stream}
-        taken.update(st.cuda_stream for st in train._SIDE_STREAMS.values())     # the eager step's side stream
-        for _ in range(40):
-            st = torch.cuda.Stream(device=self.device)
-            key = (idx, st.cuda_stream)
-            if key not in XETrainGraph._OWNED and st.cuda_stream not in taken:
-                XETrainGraph._OWNED.add(key)
-                return st
-        raise RuntimeError('no free stream: more than ~15 live XETrainGraph objects on this device')
 
     @staticmethod
     def _release(keys):
@@ -117,7 +98,6 @@ class XETrainGraph:
                 ops.release_stream_state(index, handle)
             except Exception:           # interpreter shutdown: the library may be gone
                 pass
-            XETrainGraph._OWNED.discard((index, handle))
 
     def close(self):
         """Drop the graphs and this object's per-stream state now (also happens when the object is collected)."""
