@@ -183,7 +183,9 @@ def _graphed_search(cap, fc_feats, att_feats, senti_words, senti_labels, beam, d
     if entry == 'seen':
         static = [None if x is None else x.clone() for x in ins]
         ws, wp = cap._graph_buffers()          # ONE workspace / plane-buffer pair for all graphs of this captioner
-        stream = torch.cuda.Stream(device=dev)
+        stream = cap.__dict__.get('_beam_stream')        # one capture stream per captioner, held for itself
+        if stream is None or stream.device != dev:
+            stream = cap.__dict__['_beam_stream'] = ops.private_stream(dev)
         pool = torch.cuda.graph_pool_handle()
         graphs = []
         torch.cuda.synchronize()
