@@ -419,6 +419,78 @@ typedef struct {
 
 int isc_step_fwd(const isc_step_plan *plan_host, void *stream);
 
+/* ------------------------------------------------------------------ decode rows (at most 8 rows, inference)
+ * The same forward_step (captioner.py:168-186) for the few-row regimes of the reference: the `beam_size` rows of one
+ * image inside sample() (captioner.py:380-411, one batch-1 forward_step per live candidate there), a greedy roll-out
+ * of a handful of captions (captioner.py:317-344).  Every contraction is then a few matrix-vector products that
+ * stream the weights once and every launch is a few microseconds of dependent memory round trips; csrc/rows.hip holds
+ * kernels built for that (weights straight to registers ahead of everything else, 16-lane-per-weight-row layout,
+ * index chains in a wave of their own).  Five launches: att-LSTM, the three projections of h_att, the gated scan,
+ * lang-LSTM, classifier.  The plan is isc_step_fwd's; this entry point requires both attentions with the
+ * pre-projected gate rows (gate_Gc / gate_Gs), A == E == W <= 512, no saved gates, no dropout mask, no in-place
+ * log-softmax (isc_rows_step_supported tells) and ignores the f16 plane pointers (nothing on this path reads planes).
+ *
+ * isc_rows_ext adds what the few-row callers fold into the step:
+ *  - src_row: row r of h*_prev / c*_prev is read from row src_row[r] (the beam search's re-ordering of the recurrent
+ *    state after each merge, captioner.py:405-409, as an index on the loads instead of a gather launch); NULL = r;
+ *  - stats_tile: the column-tile width of pmax / psum / pidx ([rows, ceil(V / stats_tile)]; isc_rows_stats_tile(V):
+ *    about V / 256 so that one round of workgroups covers the chip - NOT isc_vocab_fwd's 128);
+ *  - beam > 0: per (row, tile) the 8 largest MASKED logits and their word ids, descending, ties to the smaller id
+ *    (cand_val / cand_idx [rows, n_tile, 8]; masks as captioner.py:394-399: <PAD>, <SOS>, <UNK> when mask_special,
+ *    the row's last word when decoding_constraint) - the input of isc_beam_select.
+ * `logits` of the plan is optional here as well (row stride ld_logits). */
+typedef struct {
+    const int64_t *src_row;
+    int32_t stats_tile, beam;
+    float *cand_val;
+    int32_t *cand_idx;
+    const int64_t *last_word;     /* [rows] required iff decoding_constraint */
+    int64_t pad_id, sos_id, unk_id;
+    int32_t mask_special, decoding_constraint;
+} isc_rows_ext;
+int isc_rows_stats_tile(int V);
+int isc_rows_step_supported(const isc_step_plan *plan_host);
+int isc_rows_step_fwd(const isc_step_plan *plan_host, const isc_rows_ext *ext_host, void *stream);
+/* The classifier launch of that step alone (tests, tools): statistics per stats_tile columns (+ tile candidates). */
+int isc_rows_vocab_fwd(const float *h, int ldh, const float *W, int ldw, const float *bias, int M, int V, int K,
+                       float *part_max, float *part_sum, int32_t *part_idx, float *logits, int64_t ld_logits,
+                       const isc_rows_ext *ext_host, void *stream);
+/* Cache policy of the rows kernels' weight streams: 0 = default policy everywhere, 1 (default) = the classifier's weights
+ * non-temporal (read once per step: they pass through without evicting the LSTM / projection weights that the XCD L2s
+ * keep from step to step), 2 = every stream non-temporal.  Returns the previous value. */
+int isc_set_rows_nt(int mode);
+long long isc_rows_launches(void);    /* launches of rows kernels so far (tests assert the path was taken) */
+
+/* Top-k + candidate merge of one beam step in ONE launch (captioner.py:390-411), from the tile statistics and tile
+ * candidates isc_rows_step_fwd left: per row the log-softmax normaliser is folded from (pmax, psum), the row's top-`beam`
+ * (raw logit descending, ties to the smaller word id; log-prob = (x - max) - log(sum)) is merged out of its tiles'
+ * sorted candidate lists, then the image's candidates are formed, scored in fp64 and stably ranked exactly as
+ * isc_beam_merge does.  src_row[r] receives the PARENT row of new row r (the next step's isc_rows_ext.src_row; an ended
+ * candidate's state is never read again, captioner.py:383-385, so carried rows point at their parent's state as well);
+ * top_val / top_idx (optional, [n_img*beam, beam]) receive the rows' top-k for inspection. */
+typedef struct {
+    int32_t n_img, beam, T, t;
+    int32_t n_tile, V;
+    int64_t eos_id;
+    const float *part_max, *part_sum;     /* [n_img*beam, n_tile] */
+    const float *cand_val;                /* [n_img*beam, n_tile, 8] */
+    const int32_t *cand_idx;
+    const double *score_in;
+    double *score_out;
+    const int64_t *last_in;
+    int64_t *last_out;
+    const int64_t *words_in;
+    int64_t *words_out;
+    const int32_t *len_in;
+    int32_t *len_out;
+    int32_t *done;
+    int64_t *src_row;
+    int32_t *live;
+    float *top_val;
+    int64_t *top_idx;
+} isc_beam_select_args;
+int isc_beam_select(const isc_beam_select_args *args_host, void *stream);
+
 /* Reverse-sweep counterpart (one BPTT step, see autograd.py): lang-LSTM cell backward, input-gradient
  * contractions, gate / scan backward, att-LSTM cell backward, recurrent gradients for step t-1.
  * `first` = last time step (no incoming recurrent gradients), `last` = step 0 (no outgoing ones). */

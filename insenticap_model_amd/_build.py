@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB_DIR = os.path.join(HERE, 'lib')
 LIB_PATH = os.path.join(LIB_DIR, 'libinsenticap_hip.so')
-SOURCES = ['gemm_f32.hip', 'attention.hip', 'pointwise.hip', 'backward.hip', 'step.hip']
+SOURCES = ['gemm_f32.hip', 'attention.hip', 'pointwise.hip', 'backward.hip', 'step.hip', 'rows.hip']
 HEADERS = [os.path.join(CSRC, 'common.h'),
            os.path.join(os.path.dirname(HERE), 'include', 'insenticap_hip.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-Wall', '-Wno-unused-function']

@@ -102,6 +102,20 @@ class BeamMergeArgs(C.Structure):
                    C.c_void_p))
 
 
+class RowsExt(C.Structure):
+    """isc_rows_ext: what the few-row callers fold into the decode step (csrc/rows.hip)."""
+    _fields_ = [('src_row', C.c_void_p), ('stats_tile', C.c_int32), ('beam', C.c_int32), ('cand_val', C.c_void_p),
+                ('cand_idx', C.c_void_p), ('last_word', C.c_void_p), ('pad_id', C.c_int64), ('sos_id', C.c_int64),
+                ('unk_id', C.c_int64), ('mask_special', C.c_int32), ('decoding_constraint', C.c_int32)]
+
+
+class BeamSelectArgs(C.Structure):
+    _fields_ = ([('n_img', C.c_int32), ('beam', C.c_int32), ('T', C.c_int32), ('t', C.c_int32), ('n_tile', C.c_int32),
+                 ('V', C.c_int32), ('eos_id', C.c_int64)] +
+                _f('part_max part_sum cand_val cand_idx score_in score_out last_in last_out words_in words_out len_in '
+                   'len_out done src_row live top_val top_idx', C.c_void_p))
+
+
 ISC_COLSUM_MAX_JOBS, ISC_COLSUM_MAX_OUT = 24, 3
 
 
@@ -143,6 +157,15 @@ SIGNATURES = {
     'isc_lstm_fwd': (C.c_int, [C.POINTER(LstmProblem), C.c_void_p]),
     'isc_step_fwd': (C.c_int, [C.POINTER(StepPlan), C.c_void_p]),
     'isc_step_bwd': (C.c_int, [C.POINTER(StepBwdPlan), C.c_void_p]),
+    'isc_rows_stats_tile': (C.c_int, [C.c_int]),
+    'isc_rows_step_supported': (C.c_int, [C.POINTER(StepPlan)]),
+    'isc_rows_step_fwd': (C.c_int, [C.POINTER(StepPlan), C.POINTER(RowsExt), C.c_void_p]),
+    'isc_rows_vocab_fwd': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(RowsExt),
+                                     C.c_void_p]),
+    'isc_set_rows_nt': (C.c_int, [C.c_int]),
+    'isc_rows_launches': (C.c_longlong, []),
+    'isc_beam_select': (C.c_int, [C.POINTER(BeamSelectArgs), C.c_void_p]),
     'isc_vocab_fwd': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int,
                                 C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),

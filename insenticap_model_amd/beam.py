@@ -252,12 +252,17 @@ class _Search:
             Pb.gate_Gs = gs if P.words_ids is not None else expand(gs.view(n_img, P.Mw, -1)).view(rows * P.Mw, -1)
         self.cap, self.p, self.Pb = cap, p, Pb
         self.n_img, self.beam, self.T, self.rows, self.dc = n_img, beam, T, rows, decoding_constraint
-        self.ws = cap._alloc_step_ws(rows, Pb)
+        self.device_merge = getattr(cap, 'beam_device_merge', True) and beam <= 8
+        # <= 8 rows (one image's beam): the few-row step (csrc/rows.hip) - state re-ordering as an index on its loads,
+        # per-tile candidates out of the classifier, top-k + merge in one launch (isc_beam_select): six launches per step
+        self.rows_mode = self.device_merge and cap._rows_step_ok(rows, Pb)
+        self.stats_tile = ops.rows_stats_tile(V) if self.rows_mode else 128
+        self.ws = cap._alloc_step_ws(rows, Pb, self.stats_tile)
         # recurrent state as ONE tensor [h|c, layer, row, H] per buffer: the per-step beam re-ordering is then a
         # single gather over [next ; current] rows instead of four index_selects and two wheres
         self.st_cur = cap._zeros(2, 2, rows, H)
         self.st_nxt = cap._new(2, 2, rows, H)
-        self.logits = cap._new(rows, V)
+        self.logits = None if self.rows_mode else cap._new(rows, V)
         self.xt = cap._new(rows, Wd)
         # top-k ids and values share one byte buffer: ONE device->host copy per step (ids first: 8-byte aligned)
         nk = self.nk = rows * beam
@@ -267,9 +272,8 @@ class _Search:
         self.emb = p['word_embed.0.weight']
         self.mask_special = cap.pad_id != cap.eos_id
         cap.last_beam_steps = 0                    # decode steps executed (bench.py: latency per step)
-        self.device_merge = getattr(cap, 'beam_device_merge', True) and beam <= 8
         if self.device_merge:
-            from ._lib import BeamMergeArgs
+            from ._lib import BeamMergeArgs, BeamSelectArgs, RowsExt
             self.score = [torch.zeros(rows, dtype=torch.float64, device=dev) for _ in range(2)]
             self.last = [torch.full((rows,), cap.sos_id, dtype=torch.int64, device=dev) for _ in range(2)]
             self.words = [torch.zeros(rows, T, dtype=torch.int64, device=dev) for _ in range(2)]
@@ -281,13 +285,32 @@ class _Search:
             a.n_img, a.beam, a.T, a.eos_id = n_img, beam, T, cap.eos_id
             a.top_val, a.top_idx = self.top_val.data_ptr(), self.top_idx.data_ptr()
             a.done, a.gather, a.live = self.done.data_ptr(), self.gather.data_ptr(), self.live.data_ptr()
-            self.st_free = torch.empty_like(self.st_cur)   # third state buffer: target of the per-step re-ordering
             self.cur = 0
             self._plans = [None, None]                     # (step plan, merge arguments) of the even / odd steps
+            if self.rows_mode:
+                n_tile = self.ws['pmax'].shape[1]
+                self.cand_val = cap._new(rows, n_tile, 8)
+                self.cand_idx = cap._new(rows, n_tile, 8, dtype=torch.int32)
+                self.src_row = torch.arange(rows, dtype=torch.int64, device=dev)
+                x = self.ext = RowsExt()
+                x.src_row, x.stats_tile, x.beam = self.src_row.data_ptr(), self.stats_tile, beam
+                x.cand_val, x.cand_idx = self.cand_val.data_ptr(), self.cand_idx.data_ptr()
+                x.pad_id, x.sos_id, x.unk_id = cap.pad_id, cap.sos_id, cap.unk_id
+                x.mask_special, x.decoding_constraint = int(self.mask_special), int(decoding_constraint)
+                b = self.args = BeamSelectArgs()
+                b.n_img, b.beam, b.T, b.eos_id, b.n_tile, b.V = n_img, beam, T, cap.eos_id, n_tile, V
+                b.part_max, b.part_sum = self.ws['pmax'].data_ptr(), self.ws['psum'].data_ptr()
+                b.cand_val, b.cand_idx = x.cand_val, x.cand_idx
+                b.done, b.src_row, b.live = self.done.data_ptr(), self.src_row.data_ptr(), self.live.data_ptr()
+                b.top_val, b.top_idx = self.top_val.data_ptr(), self.top_idx.data_ptr()
+            else:
+                self.st_free = torch.empty_like(self.st_cur)   # third state buffer: target of the per-step re-ordering
 
     def step(self, t):
         """Decode step t on the device-side candidate table: nothing is read back (the reference's early exit,
         captioner.py:379-381, is the caller's look at the live-image counter every fourth step)."""
+        if self.rows_mode:
+            return self._step_rows(t)
         cap, a = self.cap, self.args
         if t > 0:
             # new state of row r = stepped ? nxt[parent] : cur[parent]  ==  [nxt ; cur][gather[r]]
@@ -324,6 +347,36 @@ class _Search:
                 plan = self.ws['_plan']
                 self._plans[t] = (type(plan).from_buffer_copy(plan), type(a).from_buffer_copy(a))
         ops.beam_merge(a)
+        self.cur = nxt
+
+    def _step_rows(self, t):
+        """Step t on the few-row kernels: rows read their parents' state through src_row (written by step t - 1's
+        select; the identity at t = 0), the state ping-pongs between two buffers, the select closes the step."""
+        cap, a, x = self.cap, self.args, self.ext
+        cap.last_beam_steps = t + 1
+        cur = self.cur
+        last_d = self.last[cur]
+        if self.Pb.tab is None:
+            ops.embed_relu_fwd(self.emb, last_d, self.xt)
+        fast = self._plans[t & 1] if t >= 2 else None
+        if fast is not None:
+            plan, x, a = fast
+            ops.rows_step_fwd(plan, x)
+        else:
+            x.last_word = last_d.data_ptr()
+            sc, sn = (self.st_cur, self.st_nxt) if (t & 1) == 0 else (self.st_nxt, self.st_cur)
+            cap._step(self.p, self.Pb, self.ws, self.xt, sc[0], sc[1], sn[0], sn[1], logits=None, tok=last_d, rows_ext=x)
+        nxt = cur ^ 1
+        a.t = t
+        if fast is None:
+            a.score_in, a.score_out = self.score[cur].data_ptr(), self.score[nxt].data_ptr()
+            a.last_in, a.last_out = self.last[cur].data_ptr(), self.last[nxt].data_ptr()
+            a.words_in, a.words_out = self.words[cur].data_ptr(), self.words[nxt].data_ptr()
+            a.len_in, a.len_out = self.length[cur].data_ptr(), self.length[nxt].data_ptr()
+            if t < 2 and '_plan' in self.ws:
+                plan = self.ws['_plan']
+                self._plans[t] = (type(plan).from_buffer_copy(plan), type(x).from_buffer_copy(x), type(a).from_buffer_copy(a))
+        ops.beam_select(a)
         self.cur = nxt
 
     def all_done(self, t):

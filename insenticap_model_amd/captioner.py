@@ -359,7 +359,19 @@ class Captioner(nn.Module):
         return tab
 
     # ------------------------------------------------------------------ one decode step
-    def _alloc_step_ws(self, rows, P):
+    ROWS_STEP_MAX = 8              # decode rows up to which an inference step runs on the few-row kernels (csrc/rows.hip)
+
+    def _rows_step_ok(self, rows, P):
+        """The conditions of isc_rows_step_supported that are known before a plan exists (both attentions with the
+        pre-projected gate rows, equal widths <= 512); `self.rows_step = False` keeps the general kernels."""
+        st = self.settings
+        E, A, Wd, H = st['feat_emb_dim'], st['att_hid_dim'], st['word_emb_dim'], st['rnn_hid_dim']
+        return (getattr(self, 'rows_step', True) and 0 < rows <= self.ROWS_STEP_MAX and not ops.TIMER.armed
+                and ops.TIMER.arm_step is None and getattr(P, 'gate_Gc', None) is not None
+                and getattr(P, 'gate_Gs', None) is not None and A == E == Wd and A <= 512 and A % 4 == 0 and H % 4 == 0
+                and H <= 1024)
+
+    def _alloc_step_ws(self, rows, P, stats_tile=128):
         st = self.settings
         E, A = st['feat_emb_dim'], st['att_hid_dim']
         has_cont, has_senti = P.att_e3 is not None, P.words_e3 is not None
@@ -370,7 +382,7 @@ class Captioner(nn.Module):
             ws['qw'], ws['s'] = self._new(rows, A), self._new(rows, E)
         if has_cont and has_senti:
             ws['z'], ws['f'] = self._new(rows, A), self._new(rows, E)
-        n_tile = (self.vocab_size + 127) // 128
+        n_tile = (self.vocab_size + stats_tile - 1) // stats_tile
         ws['pmax'] = self._new(rows, n_tile)
         ws['psum'] = self._new(rows, n_tile)
         ws['pidx'] = self._new(rows, n_tile, dtype=torch.int32)
@@ -413,8 +425,9 @@ class Captioner(nn.Module):
 
     def _step(self, p, P, ws, xt, h_cur, c_cur, h_nxt, c_nxt, alpha_c=None, alpha_s=None, beta=None,
               logits=None, out_mask=None, out_scale=1.0, save=None, tok=None, normalize=False,
-              hp_cur=None, hp_nxt=None):
-        """forward_step (captioner.py:168-186) on `rows` sequences: ONE library call (isc_step_fwd)
+              hp_cur=None, hp_nxt=None, rows_ext=None):
+        """forward_step (captioner.py:168-186) on `rows` sequences: ONE library call (isc_step_fwd; with `rows_ext`, an
+        isc_rows_ext, isc_rows_step_fwd: the few-row kernels, `ws` then holds statistics per rows_ext.stats_tile columns)
         that enqueues every kernel of the step. h/c arguments are indexable pairs (0 = att-LSTM,
         1 = lang-LSTM) of [rows,H] tensors; `save` (training) holds 'g1','g2' [rows,4H] and 'hdrop'
         [rows,H] buffers kept for the backward pass; `xt` = relu(Emb[token]) or None when P.tab
@@ -465,7 +478,10 @@ class Captioner(nn.Module):
         pl.apply_logsoftmax = int(normalize)
         pl.pmax, pl.psum, pl.pidx = ptr(ws.get('pmax')), ptr(ws.get('psum')), ptr(ws.get('pidx'))   # None: no classifier
         pl.gate_Gc, pl.gate_Gs = ptr(getattr(P, 'gate_Gc', None)), ptr(getattr(P, 'gate_Gs', None))
-        ops.step_fwd(pl)
+        if rows_ext is not None:
+            ops.rows_step_fwd(pl, rows_ext)
+        else:
+            ops.step_fwd(pl)
 
     def _step_py(self, p, P, ws, xt, h_cur, c_cur, h_nxt, c_nxt, alpha_c=None, alpha_s=None, beta=None,
                  logits=None, out_mask=None, out_scale=1.0, save=None, tok=None, normalize=False,
@@ -825,7 +841,13 @@ class Captioner(nn.Module):
         # write them next to h, so the state's GEMM segments are never split again
         hp = [torch.zeros(2, 2, B, H, dtype=torch.float16, device=self._dev) if getattr(self, 'state_planes', True)
               else None for _ in range(2)]
-        ws = self._alloc_step_ws(B, P)
+        # a handful of captions, no sampling: the few-row kernels (statistics per isc_rows_stats_tile columns)
+        rows_ext = None
+        if (sample_max or replay is not None) and masks is None and not self.training and self._rows_step_ok(B, P):
+            rows_ext = _lib.RowsExt()
+            rows_ext.stats_tile = ops.rows_stats_tile(V)
+            hp = [None, None]
+        ws = self._alloc_step_ws(B, P, rows_ext.stats_tile if rows_ext is not None else 128)
         if hp[0] is not None:
             for k in ('v', 's', 'f'):
                 if k in ws:
@@ -869,7 +891,7 @@ class Captioner(nn.Module):
                 # token fed at step t: <SOS>, then seq[:, t-1] (= it * unfinished, written by finalize)
                 self._step(p, P, ws, xt[cur], h[cur], c[cur], h[nxt], c[nxt], aC[:, t], aS[:, t], bG[:, t:t + 1],
                            logits, om, osc, tok=(sos if t == 0 else seq[:, t - 1]) if use_tab else None,
-                           hp_cur=hp[cur], hp_nxt=hp[nxt])
+                           hp_cur=hp[cur], hp_nxt=hp[nxt], rows_ext=rows_ext)
                 rs.t = t
                 rs.xt_next = None if use_tab else xt[nxt].data_ptr()
                 ops.rollout_finalize(rs)

@@ -43,6 +43,56 @@ __device__ __forceinline__ float isc_relu(float x) { return x < 0.f ? 0.f : x; }
         if (sp) __hip_atomic_store(sp + word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);        \
     }
 
+// Diagnostic build (tools/rows_stamp_lab.hip / tools/select_stamp_lab.hip define ROWS_STAMP 1 and include a source file):
+// lane 0 of every wave stores the 100 MHz wall clock at a few points into a buffer of its own ([workgroup][16 waves][8
+// slots]; slot 7: shader cycles between RSTAMP_CLK0 and RSTAMP_CLK1).  The default build compiles none of it.
+#ifndef ROWS_STAMP
+#define ROWS_STAMP 0
+#endif
+#if ROWS_STAMP
+__device__ long long *g_rows_stamp;
+#define RSTAMP(SLOT)                                                                                         \
+    do {                                                                                                     \
+        if ((threadIdx.x & 63) == 0 && g_rows_stamp)                                                          \
+            g_rows_stamp[((long long)blockIdx.x * 16 + (threadIdx.x >> 6)) * 8 + (SLOT)] = wall_clock64();     \
+    } while (0)
+#define RSTAMP2(W, SLOT)                                                                                     \
+    do {                                                                                                     \
+        if (threadIdx.x == 0 && g_rows_stamp) g_rows_stamp[((long long)blockIdx.x * 16 + (W)) * 8 + (SLOT)] = wall_clock64(); \
+    } while (0)
+#define RSTAMP_CLK0() const long long rstamp_c0 = clock64()
+#define RSTAMP_CLK1()                                                                                        \
+    do {                                                                                                     \
+        if ((threadIdx.x & 63) == 0 && g_rows_stamp)                                                          \
+            g_rows_stamp[((long long)blockIdx.x * 16 + (threadIdx.x >> 6)) * 8 + 7] = clock64() - rstamp_c0;   \
+    } while (0)
+#else
+#define RSTAMP(SLOT) do {} while (0)
+#define RSTAMP2(W, SLOT) do {} while (0)
+#define RSTAMP_CLK0() do {} while (0)
+#define RSTAMP_CLK1() do {} while (0)
+#endif
+
+// Kernel arguments are read by scalar loads where they are first used; every first touch of a 64-byte line of the
+// kernarg segment is a scalar-cache miss (a round trip to L2 or beyond), and hipcc places those loads lazily, one
+// dependent wait after the other - five lines cost five round trips in front of the first weight load.  This touches
+// one dword of each of the first NL lines in ONE batch and waits once: every later argument read hits the scalar cache.
+template <int NL>
+__device__ __forceinline__ void rows_kernarg_warm() {
+    static_assert(NL >= 1 && NL <= 8, "lines");
+    const unsigned long long kp = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+    int d[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // (the destinations stay live - inputs of the wait statement - until the loads have landed)
+#define ROWS_KA_LINE(I, OFF) \
+    if constexpr (NL > I) asm volatile("s_load_dword %0, %1, " OFF : "=&s"(d[I]) : "s"(kp) : "memory")
+    ROWS_KA_LINE(0, "0x0"); ROWS_KA_LINE(1, "0x40"); ROWS_KA_LINE(2, "0x80"); ROWS_KA_LINE(3, "0xc0");
+    ROWS_KA_LINE(4, "0x100"); ROWS_KA_LINE(5, "0x140"); ROWS_KA_LINE(6, "0x180"); ROWS_KA_LINE(7, "0x1c0");
+#undef ROWS_KA_LINE
+    asm volatile("s_waitcnt lgkmcnt(0)" :: "s"(d[0]), "s"(d[1]), "s"(d[2]), "s"(d[3]), "s"(d[4]), "s"(d[5]), "s"(d[6]), "s"(d[7])
+                 : "memory");
+}
+#define ROWS_KERNARG_LINES(T) ((int)((sizeof(T) + 63) / 64))
+
 // DPP lane exchanges inside a 16-lane row (VALU rate, no LDS crossbar): xor 1, xor 2, mirror inside each
 // 8-lane half, mirror inside the row.  Applied in this order with a commutative combine they leave every
 // lane of a row holding the row's reduction.

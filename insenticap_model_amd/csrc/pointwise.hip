@@ -1,5 +1,7 @@
 // Embedding gathers, roll-out bookkeeping, log-softmax finalisation, beam top-k and the
 // masked-NLL criterion (captioner.py:170-172, 201-202, 307-311, 329-344, 394-408, 427-440).
+#include <atomic>
+
 #include "common.h"
 
 // ------------------------------------------------------------------ embeddings
@@ -708,6 +710,308 @@ extern "C" int isc_beam_topk(const float *logits, int64_t ld_logits, const float
                            (long long)ld_logits, part_max, part_sum, n_tile, V, beam, last_word,
                            (long long)pad_id, (long long)sos_id, (long long)unk_id, mask_special,
                            decoding_constraint, top_val, top_idx);
+    ISC_LAUNCH_CHECK();
+    return ISC_OK;
+}
+
+// ------------------------------------------------------------------ beam step tail in one launch
+// isc_beam_select: what isc_beam_topk + isc_beam_merge + isc_beam_gather do in three launches, from the tile
+// statistics and per-tile sorted candidate lists the few-row classifier (rows.hip) leaves.  One workgroup per image,
+// one wave per beam row:
+//   1. the row's normaliser from (pmax, psum) - fold_row_stats, as every decode path;
+//   2. the row's tile candidates (value, id) [n_tile][8]: a lane owns tiles lane, lane + 64, ... and holds their lists
+//      in registers (one round trip, no staging);
+//   3. a `beam`-round k-way merge over the tiles' list heads: per round a lane's best head enters a wave arg-max (value
+//      descending, then (tile, position) ascending = word id ascending, since tiles are column ranges and lists are
+//      sorted), the winning lane pops that list;
+//   4. after a workgroup barrier the image's candidate bookkeeping, the same code path as beam_merge_kernel.
+// Word ids, log-probs ((x - max) - log(sum), the expression of beam_topk8_kernel) and tie order are those of the
+// three-launch path on the same logits and statistics.
+#define ISC_SEL_TILES_PER_LANE 4
+// One launch, one workgroup per image, and at this size every dependent memory round trip is a visible share of the
+// kernel: every global operand - candidates, tile statistics, the candidates' bookkeeping (last words, scores, lengths,
+// the parents' word lists) - is requested in the first instructions, all lane exchanges are DPP (one cross-half swap per
+// reduction), and the bookkeeping runs on every thread from LDS copies instead of one thread walking global memory.
+__device__ __forceinline__ void sel_argmax(float &v, int &k) {       // (value desc, key asc) over the wavefront
+    half_argmax(v, k);
+    const float ov = __shfl_xor(v, 32, 64);
+    const int ok = __shfl_xor(k, 32, 64);
+    if (ov > v || (ov == v && ok < k)) { v = ov; k = ok; }
+}
+// The same order as ONE unsigned 64-bit maximum: high word = the float's order-preserving bits, low word = 0x7fffffff - key.
+// A step of the reduction is then two lane moves, one 64-bit compare and two selects - no compound conditions, which
+// hipcc turns into exec-masked branches (the merge loop of the select kernel ran 2 400 cycles per round that way).
+__device__ __forceinline__ unsigned long long sel_pack(float v, int key) {
+    const unsigned u = __float_as_uint(v);
+    const unsigned hi = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    return ((unsigned long long)hi << 32) | (unsigned)(0x7fffffff - key);
+}
+__device__ __forceinline__ float sel_unpack_value(unsigned long long p) {
+    const unsigned hi = (unsigned)(p >> 32);
+    return __uint_as_float((hi & 0x80000000u) ? (hi & 0x7fffffffu) : ~hi);
+}
+__device__ __forceinline__ int sel_unpack_key(unsigned long long p) { return 0x7fffffff - (int)(unsigned)(p & 0xffffffffu); }
+template <int CTRL>
+__device__ __forceinline__ unsigned long long sel_dpp64(unsigned long long p) {
+    const unsigned lo = (unsigned)isc_dpp<CTRL>((int)(unsigned)p), hi = (unsigned)isc_dpp<CTRL>((int)(unsigned)(p >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ unsigned long long sel_max64(unsigned long long a, unsigned long long b) { return b > a ? b : a; }
+__device__ __forceinline__ unsigned long long sel_wave_max64(unsigned long long p) {
+    p = sel_max64(p, sel_dpp64<ISC_DPP_XOR1>(p));
+    p = sel_max64(p, sel_dpp64<ISC_DPP_XOR2>(p));
+    p = sel_max64(p, sel_dpp64<ISC_DPP_HALF_MIRROR>(p));
+    p = sel_max64(p, sel_dpp64<ISC_DPP_MIRROR>(p));
+    {
+        const unsigned lo = (unsigned)isc_swz16((int)(unsigned)p), hi = (unsigned)isc_swz16((int)(unsigned)(p >> 32));
+        p = sel_max64(p, ((unsigned long long)hi << 32) | lo);
+    }
+    {
+        const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)p, 32, 64), hi = (unsigned)__shfl_xor((int)(unsigned)(p >> 32), 32, 64);
+        p = sel_max64(p, ((unsigned long long)hi << 32) | lo);
+    }
+    return p;
+}
+// The winner's list (tile index Q of its lane: wave-uniform, so each of the four copies of this runs under a scalar
+// branch) advances: the lists stay where they are (register arrays with static indices), the lane's cursor moves and its
+// cached head is re-selected; the winner's word id is selected the same way and read from its lane.
+#define SEL_POP(Q)                                                                          \
+    do {                                                                                    \
+        const int cq_ = cur[Q], cn_ = cq_ + 1;                                              \
+        int ids_ = cid[Q][0];                                                               \
+        float hn_ = -INFINITY;                                                              \
+        _Pragma("unroll") for (int s_ = 1; s_ < 8; ++s_) {                                  \
+            ids_ = (cq_ == s_) ? cid[Q][s_] : ids_;                                         \
+            hn_ = (cn_ == s_) ? cvv[Q][s_] : hn_;                                           \
+        }                                                                                   \
+        wid = __builtin_amdgcn_readlane(ids_, wl);                                          \
+        const bool me_ = lane == wl;                                                        \
+        cur[Q] = me_ ? cn_ : cq_;                                                           \
+        head[Q] = me_ ? hn_ : head[Q];                                                      \
+    } while (0)
+
+__global__ __launch_bounds__(512) void beam_select_kernel(const isc_beam_select_args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sel_smem[];
+    __shared__ double cs[ISC_BEAM_MAX * ISC_BEAM_MAX], s_score[ISC_BEAM_MAX];
+    __shared__ long long ctok[ISC_BEAM_MAX * ISC_BEAM_MAX], s_last[ISC_BEAM_MAX];
+    __shared__ int cpar[ISC_BEAM_MAX * ISC_BEAM_MAX], ccar[ISC_BEAM_MAX * ISC_BEAM_MAX], s_len[ISC_BEAM_MAX];
+    __shared__ float tv[ISC_BEAM_MAX][ISC_BEAM_MAX];
+    __shared__ int ti[ISC_BEAM_MAX][ISC_BEAM_MAX];
+    __shared__ int w_par[ISC_BEAM_MAX], w_car[ISC_BEAM_MAX], w_len[ISC_BEAM_MAX];     // winners by rank
+    __shared__ long long w_tok[ISC_BEAM_MAX];
+    rows_kernarg_warm<ROWS_KERNARG_LINES(isc_beam_select_args)>();
+    const int i = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int beam = a.beam, T = a.T, base = i * beam, n_tile = a.n_tile;
+    RSTAMP(0);
+    // ---- everything this thread will need from memory, requested now: the image's `done` flag, the row's tile lists
+    // (a lane owns tiles lane, lane + 64, ..: 8 values + 8 ids each, straight to registers), the tile statistics, the
+    // candidates' bookkeeping and the parents' word lists
+    const int done_flag = a.done[i];
+    const int row = base + wave;
+    float cvv[ISC_SEL_TILES_PER_LANE][8];
+    int cid[ISC_SEL_TILES_PER_LANE][8];
+    float pm[ISC_SEL_TILES_PER_LANE], ps[ISC_SEL_TILES_PER_LANE];
+#pragma unroll
+    for (int q = 0; q < ISC_SEL_TILES_PER_LANE; ++q) {
+        const int tl = lane + 64 * q, tc = tl < n_tile ? tl : n_tile - 1;
+        const float4 *gv = reinterpret_cast<const float4 *>(a.cand_val + ((long long)row * n_tile + tc) * 8);
+        const int4 *gi = reinterpret_cast<const int4 *>(a.cand_idx + ((long long)row * n_tile + tc) * 8);
+        const float4 v0 = gv[0], v1 = gv[1];
+        const int4 i0 = gi[0], i1 = gi[1];
+        cvv[q][0] = v0.x; cvv[q][1] = v0.y; cvv[q][2] = v0.z; cvv[q][3] = v0.w;
+        cvv[q][4] = v1.x; cvv[q][5] = v1.y; cvv[q][6] = v1.z; cvv[q][7] = v1.w;
+        cid[q][0] = i0.x; cid[q][1] = i0.y; cid[q][2] = i0.z; cid[q][3] = i0.w;
+        cid[q][4] = i1.x; cid[q][5] = i1.y; cid[q][6] = i1.z; cid[q][7] = i1.w;
+        pm[q] = a.part_max[(long long)row * n_tile + tc];
+        ps[q] = a.part_sum[(long long)row * n_tile + tc];
+    }
+    long long my_last = 0;
+    double my_score = 0.0;
+    int my_len = 0;
+    if (tid < beam) { my_last = a.last_in[base + tid]; my_score = a.score_in[base + tid]; my_len = a.len_in[base + tid]; }
+    long long wv[4];                         // element e of the image's [beam][T] block of word lists
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int e = tid + q * (int)blockDim.x;
+        wv[q] = a.words_in[(long long)base * T + (e < beam * T ? e : 0)];
+    }
+    RSTAMP(1);
+    if (done_flag) {                      // frozen image: everything carried over unchanged (block-uniform)
+        if (tid < beam) {
+            a.src_row[base + tid] = base + tid;
+            a.last_out[base + tid] = my_last;
+            a.score_out[base + tid] = my_score;
+            a.len_out[base + tid] = my_len;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = tid + q * (int)blockDim.x;
+            if (e < beam * T) a.words_out[(long long)base * T + e] = wv[q];
+        }
+        return;
+    }
+#pragma unroll
+    for (int q = 0; q < ISC_SEL_TILES_PER_LANE; ++q)
+        if (lane + 64 * q >= n_tile) {
+            pm[q] = -INFINITY; ps[q] = 0.f;
+#pragma unroll
+            for (int s_ = 0; s_ < 8; ++s_) cvv[q][s_] = -INFINITY;
+        }
+    // ---- the row's normaliser: max over the tile maxima, sum of the rescaled tile sums
+    float gmax = fmaxf(fmaxf(pm[0], pm[1]), fmaxf(pm[2], pm[3]));
+    {
+        int dummy = lane;
+        sel_argmax(gmax, dummy);
+    }
+    float ssum = 0.f;
+#pragma unroll
+    for (int q = 0; q < ISC_SEL_TILES_PER_LANE; ++q) ssum += ps[q] * expf(pm[q] - gmax);
+    ssum = half_sum(ssum);
+    ssum += __shfl_xor(ssum, 32, 64);
+    if (lane == 0 && !(fabsf(gmax) <= 3.0e38f && ssum <= 3.0e38f)) isc_flag_pw(ISC_STATUS_WORD_STATS);     // NaN fails both
+    const float logS = logf(ssum);
+    if (tid < beam) { s_last[tid] = my_last; s_score[tid] = my_score; s_len[tid] = my_len; }
+    RSTAMP(2);
+    // ---- k-way merge over the tiles' list heads: per round the lanes' best heads meet in a wave arg-max (value
+    // descending, then (tile, position) ascending = word id ascending: tiles are column ranges, lists are sorted)
+    int cur[ISC_SEL_TILES_PER_LANE] = {0, 0, 0, 0};
+    float head[ISC_SEL_TILES_PER_LANE] = {cvv[0][0], cvv[1][0], cvv[2][0], cvv[3][0]};
+    RSTAMP(3);
+    RSTAMP_CLK0();
+    for (int k = 0; k < beam; ++k) {
+        unsigned long long best = 0;                            // (below every packed pair)
+#pragma unroll
+        for (int q = 0; q < ISC_SEL_TILES_PER_LANE; ++q) {     // tiles past the end / exhausted lists: -inf under a key past all
+            const bool ok = (lane + 64 * q < n_tile) & (cur[q] < 8);
+            const int kq = ok ? (lane + 64 * q) * 8 + cur[q] : 0x7ffffff0;
+            best = sel_max64(best, sel_pack(head[q], kq));
+        }
+        best = sel_wave_max64(best);
+        const float mx = sel_unpack_value(best);
+        const int key = sel_unpack_key(best);
+        const bool have = key < 0x7ffffff0;                    // wave-uniform, as are key and mx
+        int wid = 0;
+        if (have) {
+            const int wt = __builtin_amdgcn_readfirstlane(key >> 3);
+            const int wl = wt & 63, wq = wt >> 6;
+            if (wq == 0) SEL_POP(0); else if (wq == 1) SEL_POP(1); else if (wq == 2) SEL_POP(2); else SEL_POP(3);
+        }
+        if (lane == 0) {
+            tv[wave][k] = have ? (mx - gmax) - logS : -INFINITY;
+            ti[wave][k] = wid;
+        }
+    }
+    if (a.top_val && lane < beam) {
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        a.top_val[(long long)row * beam + lane] = tv[wave][lane];
+        const int id = ti[wave][lane];
+        a.top_idx[(long long)row * beam + lane] = (unsigned)id < (unsigned)a.V ? id : 0;
+    }
+    RSTAMP(4);
+    RSTAMP_CLK1();
+    __syncthreads();
+    // ---- the image's candidates (captioner.py:378-411; beam_merge_kernel's bookkeeping), every thread from LDS
+    const int ncand = a.t == 0 ? 1 : beam;
+    int coff[ISC_BEAM_MAX + 1];
+    int all_ended = 1;
+    {
+        int off = 0;
+#pragma unroll
+        for (int k = 0; k < ISC_BEAM_MAX; ++k) {
+            coff[k] = off;
+            if (k < ncand) {
+                const int ended = a.t > 0 && s_last[k] == a.eos_id;
+                off += ended ? 1 : beam;
+                all_ended &= ended;
+            }
+        }
+        coff[ISC_BEAM_MAX] = off;
+    }
+    const int n = coff[ISC_BEAM_MAX];
+    if (tid < ncand * beam) {
+        const int k = tid / beam, j = tid - k * beam;
+        const int ended = a.t > 0 && s_last[k] == a.eos_id;
+        int ck = 0;
+#pragma unroll
+        for (int q = 0; q < ISC_BEAM_MAX; ++q) ck = (k == q) ? coff[q] : ck;
+        if (ended) {
+            if (j == 0) { cs[ck] = s_score[k]; ctok[ck] = s_last[k]; cpar[ck] = k; ccar[ck] = 1; }
+        } else {
+            const int c = ck + j;
+            const int id = ti[k][j];
+            cs[c] = s_score[k] + (double)tv[k][j];
+            ctok[c] = (unsigned)id < (unsigned)a.V ? id : 0;
+            cpar[c] = k; ccar[c] = 0;
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        // stable descending rank of candidate `lane` (< n <= 64): the scores sit one per lane, candidate j's is read from
+        // its lane (no memory inside the loop)
+        const double sc = cs[lane < n ? lane : 0];
+        const int sc_lo = __double2loint(sc), sc_hi = __double2hiint(sc);
+        int rank = 0;
+        for (int j = 0; j < n; ++j) {
+            const double o = __hiloint2double(__builtin_amdgcn_readlane(sc_hi, j), __builtin_amdgcn_readlane(sc_lo, j));
+            rank += (int)(o > sc) | ((int)(o == sc) & (int)(j < lane));
+        }
+        if (lane < n && rank < beam) {
+            const int par = cpar[tid], car = ccar[tid], dst = base + rank, len = s_len[par];
+            a.score_out[dst] = sc;
+            a.last_out[dst] = ctok[tid];
+            a.src_row[dst] = base + par;
+            a.len_out[dst] = len + (car ? 0 : 1);
+            w_par[rank] = par; w_car[rank] = car; w_len[rank] = len; w_tok[rank] = ctok[tid];
+        }
+    }
+    if (tid == 0) {
+        if (all_ended) a.done[i] = 1;
+        else atomicAdd(&a.live[a.t + 1], 1);
+    }
+    RSTAMP(5);
+    // ---- word lists: element (rank r, position pos) = the parent's word, or the new token at the parent's length
+    {
+        long long *wl = reinterpret_cast<long long *>(sel_smem);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = tid + q * (int)blockDim.x;
+            if (e < beam * T) wl[e] = wv[q];
+        }
+        __syncthreads();
+        const int nfill = n < beam ? n : beam;               // (t == 0: one live parent still yields `beam` rows)
+        for (int e = tid; e < nfill * T; e += blockDim.x) {
+            const int r = e / T, pos = e - r * T;
+            const long long w = (!w_car[r] && pos == w_len[r]) ? w_tok[r] : wl[w_par[r] * T + pos];
+            a.words_out[(long long)(base + r) * T + pos] = w;
+        }
+    }
+    RSTAMP(6);
+}
+#undef SEL_POP
+
+extern "C" int isc_beam_select(const isc_beam_select_args *args, void *stream) {
+    if (!args) return ISC_E_NULL;
+    const isc_beam_select_args &a = *args;
+    if (!a.part_max || !a.part_sum || !a.cand_val || !a.cand_idx || !a.score_in || !a.score_out || !a.last_in ||
+        !a.last_out || !a.words_in || !a.words_out || !a.len_in || !a.len_out || !a.done || !a.src_row || !a.live)
+        return ISC_E_NULL;
+    if ((a.top_val == nullptr) != (a.top_idx == nullptr)) return ISC_E_NULL;
+    if (a.n_img <= 0 || a.beam <= 0 || a.beam > ISC_BEAM_MAX || a.T <= 0 || a.t < 0 || a.t >= a.T || a.V <= 0)
+        return ISC_E_SHAPE;
+    if (a.n_tile < 1 || a.n_tile > 64 * ISC_SEL_TILES_PER_LANE) return ISC_E_SHAPE;
+    if (!isc_aligned16(a.cand_val) || !isc_aligned16(a.cand_idx)) return ISC_E_ALIGN;
+    const size_t lds = (size_t)a.beam * a.T * 8;                                 // the parents' word lists
+    if (a.T > 256) return ISC_E_SHAPE;
+    static std::atomic<bool> attr_set{false};
+    if (!attr_set.load()) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&beam_select_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           ISC_BEAM_MAX * 64 * ISC_SEL_TILES_PER_LANE * 64);
+        if (e != hipSuccess) return (int)e;
+        attr_set.store(true);
+    }
+    hipLaunchKernelGGL(beam_select_kernel, dim3(a.n_img), dim3(64 * a.beam), lds, (hipStream_t)stream, a);
     ISC_LAUNCH_CHECK();
     return ISC_OK;
 }

@@ -396,6 +396,36 @@ def step_fwd(plan):
     check(_lib.load().isc_step_fwd(C.byref(plan), stream()), 'isc_step_fwd')
 
 
+def rows_stats_tile(V):
+    """Column-tile width of the few-row classifier's statistics (isc_rows_stats_tile)."""
+    return _lib.load().isc_rows_stats_tile(int(V))
+
+
+def rows_step_supported(plan):
+    return bool(_lib.load().isc_rows_step_supported(C.byref(plan)))
+
+
+def rows_step_fwd(plan, ext):
+    """One decode step on <= 8 rows from a prepared isc_step_plan + isc_rows_ext (csrc/rows.hip: five launches)."""
+    check(_lib.load().isc_rows_step_fwd(C.byref(plan), C.byref(ext), stream()), 'isc_rows_step_fwd')
+
+
+def rows_vocab_fwd(h, W, bias, part_max, part_sum, part_idx, ext, logits=None):
+    lib = _lib.load()
+    M, K = h.shape
+    V = W.shape[0]
+    assert h.stride(1) == 1 and W.stride(1) == 1
+    check(lib.isc_rows_vocab_fwd(h.data_ptr(), h.stride(0), W.data_ptr(), W.stride(0), bias.data_ptr(), M, V, K,
+                                 part_max.data_ptr(), part_sum.data_ptr(), part_idx.data_ptr(), ptr(logits),
+                                 logits.stride(0) if logits is not None else 0, C.byref(ext), stream()),
+          'isc_rows_vocab_fwd')
+
+
+def beam_select(args):
+    """Top-k + candidate merge of one beam step in one launch (isc_beam_select)."""
+    check(_lib.load().isc_beam_select(C.byref(args), stream()), 'isc_beam_select')
+
+
 def step_bwd(plan):
     check(_lib.load().isc_step_bwd(C.byref(plan), stream()), 'isc_step_bwd')
 

@@ -211,6 +211,7 @@ def test_beam5_search_and_small_rollout_on_this_path_match_the_replaced_kernels(
     (tokens on trusted margins, log-probs within 1e-4 - both sit within 1e-4 of the CPU oracle, test_gpu_parity)."""
     cap, V, st = _captioner()
     cap.enable_beam_graphs(False)
+    cap.rows_step = False                 # (the few-row decode step of csrc/rows.hip has its own tests: test_gpu_rows.py)
     d = synth.make_inputs(4, V, st, regions=36, seq_len=20, seed=11)
     t = lambda k: torch.from_numpy(np.asarray(d[k])).to(DEV)
     res = {}
