@@ -438,6 +438,13 @@ int isc_step_fwd(const isc_step_plan *plan_host, void *stream);
  *  - beam > 0: per (row, tile) the 8 largest MASKED logits and their word ids, descending, ties to the smaller id
  *    (cand_val / cand_idx [rows, n_tile, 8]; masks as captioner.py:394-399: <PAD>, <SOS>, <UNK> when mask_special,
  *    the row's last word when decoding_constraint) - the input of isc_beam_select.
+ *  - row_div > 1: the step-invariant tensors of the plan that belong to an IMAGE (pre1, att_p, att_e, gate_Gc, label_w,
+ *    words_ids; per-row words_p / words_e / gate_Gs as well) hold one entry per image and row r uses entry r / row_div -
+ *    the `beam` rows of an image share its regions (captioner.py:366-377 expands nothing either: it decodes candidate by
+ *    candidate), so a search keeps one copy per image instead of `beam`; rows % row_div == 0;
+ *  - live_in: optional device int; when it reads 0 every launch of the step returns at once (and isc_beam_select with it):
+ *    a search captured as ONE graph of T steps ends itself on the device (live[t] of isc_beam_select: images still
+ *    searching before step t) instead of the host reading that counter between graphs of a few steps.
  * `logits` of the plan is optional here as well (row stride ld_logits). */
 typedef struct {
     const int64_t *src_row;
@@ -447,6 +454,8 @@ typedef struct {
     const int64_t *last_word;     /* [rows] required iff decoding_constraint */
     int64_t pad_id, sos_id, unk_id;
     int32_t mask_special, decoding_constraint;
+    int32_t row_div, _pad;
+    const int32_t *live_in;
 } isc_rows_ext;
 int isc_rows_stats_tile(int V);
 int isc_rows_step_supported(const isc_step_plan *plan_host);
@@ -488,6 +497,7 @@ typedef struct {
     int32_t *live;
     float *top_val;
     int64_t *top_idx;
+    const int32_t *live_in;               /* optional: reads 0 -> the launch returns at once (see isc_rows_ext.live_in) */
 } isc_beam_select_args;
 int isc_beam_select(const isc_beam_select_args *args_host, void *stream);
 

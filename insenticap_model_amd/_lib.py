@@ -106,14 +106,15 @@ class RowsExt(C.Structure):
     """isc_rows_ext: what the few-row callers fold into the decode step (csrc/rows.hip)."""
     _fields_ = [('src_row', C.c_void_p), ('stats_tile', C.c_int32), ('beam', C.c_int32), ('cand_val', C.c_void_p),
                 ('cand_idx', C.c_void_p), ('last_word', C.c_void_p), ('pad_id', C.c_int64), ('sos_id', C.c_int64),
-                ('unk_id', C.c_int64), ('mask_special', C.c_int32), ('decoding_constraint', C.c_int32)]
+                ('unk_id', C.c_int64), ('mask_special', C.c_int32), ('decoding_constraint', C.c_int32),
+                ('row_div', C.c_int32), ('_pad', C.c_int32), ('live_in', C.c_void_p)]
 
 
 class BeamSelectArgs(C.Structure):
     _fields_ = ([('n_img', C.c_int32), ('beam', C.c_int32), ('T', C.c_int32), ('t', C.c_int32), ('n_tile', C.c_int32),
                  ('V', C.c_int32), ('eos_id', C.c_int64)] +
                 _f('part_max part_sum cand_val cand_idx score_in score_out last_in last_out words_in words_out len_in '
-                   'len_out done src_row live top_val top_idx', C.c_void_p))
+                   'len_out done src_row live top_val top_idx live_in', C.c_void_p))
 
 
 ISC_COLSUM_MAX_JOBS, ISC_COLSUM_MAX_OUT = 24, 3

@@ -193,15 +193,19 @@ def _graphed_search(cap, fc_feats, att_feats, senti_words, senti_labels, beam, d
             scope = ops.h3_weights_scope(dev)      # ONE scope over all the captures (its planes live in `wp`,
             scope.__enter__()                      # are split inside graph 0 and read by the later graphs)
             try:
-                search = None
-                for t0 in range(0, T, CHUNK):
+                search, t0 = None, 0
+                while t0 < T:
                     g = torch.cuda.CUDAGraph()
                     with ops.graph_capture(g, pool=pool, stream=stream):
                         if search is None:
                             search = _Search(cap, *static, beam, decoding_constraint, T)
-                        for t in range(t0, min(t0 + CHUNK, T)):
+                        # few-row searches end themselves on the device (isc_rows_ext.live_in): ONE graph, no counter
+                        # read in between; the general kernels run CHUNK steps per graph
+                        t1 = T if search.rows_mode else min(t0 + CHUNK, T)
+                        for t in range(t0, t1):
                             search.step(t)
-                    graphs.append(g)
+                    graphs.append((g, t1))
+                    t0 = t1
             finally:
                 scope.__exit__(None, None, None)
         entry = cache[key] = (graphs, static, search, ws, wp, pool)
@@ -209,11 +213,10 @@ def _graphed_search(cap, fc_feats, att_feats, senti_words, senti_labels, beam, d
     for dst, src in zip(static, ins):
         if dst is not None:
             dst.copy_(src, non_blocking=True)
-    for i, g in enumerate(graphs):
+    for g, t1 in graphs:
         g.replay()
-        t = min((i + 1) * CHUNK, T) - 1
-        cap.last_beam_steps = t + 1
-        if search.all_done(t):
+        cap.last_beam_steps = t1
+        if t1 < T and search.all_done(t1 - 1):
             break
     return search.finish()
 
@@ -231,36 +234,48 @@ class _Search:
         dev = cap._dev
         H, Wd, V = cap.att_lstm.hidden_size, cap.settings['word_emb_dim'], cap.vocab_size
         rows = n_img * beam
-        # expand the step-invariant tensors to one copy per beam row (row = img*beam + k)
-        rep = torch.arange(n_img, device=dev).repeat_interleave(beam)
-
-        def expand(x):
-            return None if x is None else x.index_select(0, rep).contiguous()
-        Pb = type(P)()
-        Pb.B, Pb.R, Pb.Mw = rows, P.R, P.Mw
-        for name in ('fc_e', 'att_e3', 'att_p3', 'words_e3', 'words_p3', 'label_e', 'label_w', 'pre1'):
-            if P.words_ids is not None and name in ('words_e3', 'words_p3'):
-                setattr(Pb, name, getattr(P, name))           # shared [V,.] tables: only the ids are per row
-            else:
-                setattr(Pb, name, expand(getattr(P, name)))
-        Pb.words_ids = expand(P.words_ids)
-        Pb.tab = P.tab
-        # gated scan (few rows): per-region projections follow the regions, the word table is shared
-        gc, gs = getattr(P, 'gate_Gc', None), getattr(P, 'gate_Gs', None)
-        if gc is not None:
-            Pb.gate_Gc = expand(gc.view(n_img, P.R, -1)).view(rows * P.R, -1)
-            Pb.gate_Gs = gs if P.words_ids is not None else expand(gs.view(n_img, P.Mw, -1)).view(rows * P.Mw, -1)
-        self.cap, self.p, self.Pb = cap, p, Pb
-        self.n_img, self.beam, self.T, self.rows, self.dc = n_img, beam, T, rows, decoding_constraint
         self.device_merge = getattr(cap, 'beam_device_merge', True) and beam <= 8
         # <= 8 rows (one image's beam): the few-row step (csrc/rows.hip) - state re-ordering as an index on its loads,
-        # per-tile candidates out of the classifier, top-k + merge in one launch (isc_beam_select): six launches per step
-        self.rows_mode = self.device_merge and cap._rows_step_ok(rows, Pb)
+        # per-tile candidates out of the classifier, top-k + merge in one launch (isc_beam_select): six launches per step.
+        # The rows of an image share its step-invariant tensors there (isc_rows_ext.row_div): nothing is expanded.
+        self.rows_mode = self.device_merge and cap._rows_step_ok(rows, P)
+        if self.rows_mode:
+            Pb = P
+        else:
+            # expand the step-invariant tensors to one copy per beam row (row = img*beam + k)
+            rep = torch.arange(n_img, device=dev).repeat_interleave(beam)
+
+            def expand(x):
+                return None if x is None else x.index_select(0, rep).contiguous()
+            Pb = type(P)()
+            Pb.B, Pb.R, Pb.Mw = rows, P.R, P.Mw
+            for name in ('fc_e', 'att_e3', 'att_p3', 'words_e3', 'words_p3', 'label_e', 'label_w', 'pre1'):
+                if P.words_ids is not None and name in ('words_e3', 'words_p3'):
+                    setattr(Pb, name, getattr(P, name))           # shared [V,.] tables: only the ids are per row
+                else:
+                    setattr(Pb, name, expand(getattr(P, name)))
+            Pb.words_ids = expand(P.words_ids)
+            Pb.tab = P.tab
+            # gated scan (few rows): per-region projections follow the regions, the word table is shared
+            gc, gs = getattr(P, 'gate_Gc', None), getattr(P, 'gate_Gs', None)
+            if gc is not None:
+                Pb.gate_Gc = expand(gc.view(n_img, P.R, -1)).view(rows * P.R, -1)
+                Pb.gate_Gs = gs if P.words_ids is not None else expand(gs.view(n_img, P.Mw, -1)).view(rows * P.Mw, -1)
+        self.cap, self.p, self.Pb = cap, p, Pb
+        self.n_img, self.beam, self.T, self.rows, self.dc = n_img, beam, T, rows, decoding_constraint
         self.stats_tile = ops.rows_stats_tile(V) if self.rows_mode else 128
         self.ws = cap._alloc_step_ws(rows, Pb, self.stats_tile)
+        # Everything that starts at zero lives in ONE zeroed arena (one fill launch instead of a dozen): the recurrent
+        # state [h|c, layer, row, H], fp64 scores, word lists, lengths, the done flags and the live-image counters.
+        def carve(arena, off, dtype, *shape):
+            n = int(np.prod(shape)) * torch.empty(0, dtype=dtype).element_size()
+            return arena[off:off + n].view(dtype).view(*shape), (off + n + 15) & ~15
+        need = 4 * (2 * 2 * rows * H) + 2 * 8 * rows + 2 * 8 * rows * T + 2 * 4 * rows + 4 * n_img + 4 * (T + 1) + 16 * 8
+        arena = torch.zeros(need, dtype=torch.uint8, device=dev)
+        off = 0
         # recurrent state as ONE tensor [h|c, layer, row, H] per buffer: the per-step beam re-ordering is then a
         # single gather over [next ; current] rows instead of four index_selects and two wheres
-        self.st_cur = cap._zeros(2, 2, rows, H)
+        self.st_cur, off = carve(arena, off, torch.float32, 2, 2, rows, H)
         self.st_nxt = cap._new(2, 2, rows, H)
         self.logits = None if self.rows_mode else cap._new(rows, V)
         self.xt = cap._new(rows, Wd)
@@ -274,13 +289,25 @@ class _Search:
         cap.last_beam_steps = 0                    # decode steps executed (bench.py: latency per step)
         if self.device_merge:
             from ._lib import BeamMergeArgs, BeamSelectArgs, RowsExt
-            self.score = [torch.zeros(rows, dtype=torch.float64, device=dev) for _ in range(2)]
-            self.last = [torch.full((rows,), cap.sos_id, dtype=torch.int64, device=dev) for _ in range(2)]
-            self.words = [torch.zeros(rows, T, dtype=torch.int64, device=dev) for _ in range(2)]
-            self.length = [torch.zeros(rows, dtype=torch.int32, device=dev) for _ in range(2)]
-            self.done = torch.zeros(n_img, dtype=torch.int32, device=dev)
+            span0 = off                                 # [scores | words | lengths | done | live]: ONE read-back at the end
+            spans = {}
+
+            def carve_host(name, dtype, npdtype, *shape):
+                nonlocal off
+                t, nxt_off = carve(arena, off, dtype, *shape)
+                spans[name] = (off - span0, npdtype, shape)
+                off = nxt_off
+                return t
+            sc2 = carve_host('score', torch.float64, np.float64, 2, rows)
+            wd2 = carve_host('words', torch.int64, np.int64, 2, rows, T)
+            ln2 = carve_host('length', torch.int32, np.int32, 2, rows)
+            self.done = carve_host('done', torch.int32, np.int32, n_img)
+            self.live = carve_host('live', torch.int32, np.int32, T + 1)
+            self._result_span, self._result_views = arena[span0:off], spans
+            self.score, self.words, self.length = [sc2[0], sc2[1]], [wd2[0], wd2[1]], [ln2[0], ln2[1]]
+            la2 = torch.full((2, rows), cap.sos_id, dtype=torch.int64, device=dev)
+            self.last = [la2[0], la2[1]]
             self.gather = torch.empty(rows, dtype=torch.int64, device=dev)
-            self.live = torch.zeros(T + 1, dtype=torch.int32, device=dev)
             a = self.args = BeamMergeArgs()
             a.n_img, a.beam, a.T, a.eos_id = n_img, beam, T, cap.eos_id
             a.top_val, a.top_idx = self.top_val.data_ptr(), self.top_idx.data_ptr()
@@ -291,9 +318,9 @@ class _Search:
                 n_tile = self.ws['pmax'].shape[1]
                 self.cand_val = cap._new(rows, n_tile, 8)
                 self.cand_idx = cap._new(rows, n_tile, 8, dtype=torch.int32)
-                self.src_row = torch.arange(rows, dtype=torch.int64, device=dev)
+                self.src_row = self.gather                  # written by step t's select, read by step t + 1
                 x = self.ext = RowsExt()
-                x.src_row, x.stats_tile, x.beam = self.src_row.data_ptr(), self.stats_tile, beam
+                x.src_row, x.stats_tile, x.beam, x.row_div = None, self.stats_tile, beam, beam   # (step 0: the identity)
                 x.cand_val, x.cand_idx = self.cand_val.data_ptr(), self.cand_idx.data_ptr()
                 x.pad_id, x.sos_id, x.unk_id = cap.pad_id, cap.sos_id, cap.unk_id
                 x.mask_special, x.decoding_constraint = int(self.mask_special), int(decoding_constraint)
@@ -358,12 +385,16 @@ class _Search:
         last_d = self.last[cur]
         if self.Pb.tab is None:
             ops.embed_relu_fwd(self.emb, last_d, self.xt)
-        fast = self._plans[t & 1] if t >= 2 else None
+        fast = self._plans[t & 1] if t >= 3 else None
+        live_in = self.live.data_ptr() + 4 * t if t > 0 else None     # live[t] == 0: the step's launches return at once
         if fast is not None:
             plan, x, a = fast
+            x.live_in = a.live_in = live_in
             ops.rows_step_fwd(plan, x)
         else:
             x.last_word = last_d.data_ptr()
+            x.src_row = self.src_row.data_ptr() if t > 0 else None
+            x.live_in = a.live_in = live_in
             sc, sn = (self.st_cur, self.st_nxt) if (t & 1) == 0 else (self.st_nxt, self.st_cur)
             cap._step(self.p, self.Pb, self.ws, self.xt, sc[0], sc[1], sn[0], sn[1], logits=None, tok=last_d, rows_ext=x)
         nxt = cur ^ 1
@@ -373,9 +404,9 @@ class _Search:
             a.last_in, a.last_out = self.last[cur].data_ptr(), self.last[nxt].data_ptr()
             a.words_in, a.words_out = self.words[cur].data_ptr(), self.words[nxt].data_ptr()
             a.len_in, a.len_out = self.length[cur].data_ptr(), self.length[nxt].data_ptr()
-            if t < 2 and '_plan' in self.ws:
+            if t in (1, 2) and '_plan' in self.ws:      # (step 0 has no source-row index: its plan is not a template)
                 plan = self.ws['_plan']
-                self._plans[t] = (type(plan).from_buffer_copy(plan), type(x).from_buffer_copy(x), type(a).from_buffer_copy(a))
+                self._plans[t & 1] = (type(plan).from_buffer_copy(plan), type(x).from_buffer_copy(x), type(a).from_buffer_copy(a))
         ops.beam_select(a)
         self.cur = nxt
 
@@ -385,19 +416,28 @@ class _Search:
     def finish(self):
         cap, n_img, beam, T = self.cap, self.n_img, self.beam, self.T
         cap.cont_weights, cap.senti_weights, cap.cont_senti_weights = [], [], []
-        # the tables of the last EXECUTED step: a replayed graph chain may stop before the step the capture ended on
-        steps = cap.last_beam_steps
-        cur = steps & 1                             # step t writes buffer (t + 1) & 1
-        sc = self.score[cur].view(n_img, beam).cpu().tolist()
-        wd = self.words[cur].view(n_img, beam, T).cpu().numpy()
-        ln = self.length[cur].view(n_img, beam).cpu().numpy()
         # executed steps as the reference counts them: up to and including the step after which nobody was live
-        lv = self.live.cpu().numpy()
+        steps = cap.last_beam_steps
+        hb = self._result_span.cpu().numpy()             # one device->host copy: scores, words, lengths, counters
+
+        def host(name):
+            o, dt, shape = self._result_views[name]
+            n = int(np.prod(shape)) * np.dtype(dt).itemsize
+            return hb[o:o + n].view(dt).reshape(shape)
+        lv = host('live')
+        executed = steps
         for t in range(steps):
             if lv[t + 1] == 0:
-                steps = t + 1
+                executed = t + 1
                 break
-        cap.last_beam_steps = steps
+        # the tables of the last step that WROTE them (step t writes buffer (t + 1) & 1): every enqueued step on the general
+        # kernels (a frozen image's rows are copied along), the last executed one on the few-row kernels (later launches
+        # return at once: isc_rows_ext.live_in)
+        cur = (executed if self.rows_mode else steps) & 1
+        sc = host('score')[cur].reshape(n_img, beam).tolist()
+        wd = host('words')[cur].reshape(n_img, beam, T)
+        ln = host('length')[cur].reshape(n_img, beam)
+        cap.last_beam_steps = executed
         captions, scores, ids = [], [], []
         for i in range(n_img):
             cand = [wd[i, k, :ln[i, k]].tolist() for k in range(beam)]

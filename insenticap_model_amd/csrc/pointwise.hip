@@ -808,6 +808,7 @@ __global__ __launch_bounds__(512) void beam_select_kernel(const isc_beam_select_
     // (a lane owns tiles lane, lane + 64, ..: 8 values + 8 ids each, straight to registers), the tile statistics, the
     // candidates' bookkeeping and the parents' word lists
     const int done_flag = a.done[i];
+    const int go = a.live_in ? *a.live_in : 1;
     const int row = base + wave;
     float cvv[ISC_SEL_TILES_PER_LANE][8];
     int cid[ISC_SEL_TILES_PER_LANE][8];
@@ -837,6 +838,7 @@ __global__ __launch_bounds__(512) void beam_select_kernel(const isc_beam_select_
         wv[q] = a.words_in[(long long)base * T + (e < beam * T ? e : 0)];
     }
     RSTAMP(1);
+    if (go == 0) return;                  // the search has ended (block-uniform)
     if (done_flag) {                      // frozen image: everything carried over unchanged (block-uniform)
         if (tid < beam) {
             a.src_row[base + tid] = base + tid;

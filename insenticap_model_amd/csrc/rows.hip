@@ -192,7 +192,8 @@ extern "C" long long isc_rows_launches(void) { return g_rows_launches.load(); }
 // applies the cell once the partials are in LDS.
 struct RLstmArgs {
     RSegs g;
-    int S, J, NH, M, H, pad;
+    int S, J, NH, M, H, row_div;     // row_div: rows per image of the per-image hoisted term `pre` (1: per row)
+    const int *skip;                 // optional: *skip == 0 -> nothing to do (the search has ended; see isc_rows_ext.live_in)
     const long long *src;            // never null (identity when the caller has no re-ordering)
     const RowsConst *rc;
     const float *c_prev;
@@ -211,6 +212,7 @@ __global__ __launch_bounds__(768) void rows_lstm_kernel(const RLstmArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // an SGPR: slice descriptors by scalar loads
     const int S = a.S, J = a.J, NWS = S * J, H = a.H, M = a.M;
     const int U = J * UPW, u0 = blockIdx.x * U;
+    const int run = a.skip ? *a.skip : 1;                   // (uniform; waited for at the first barrier, not before)
     if (wave < NWS) {
         const int sw = wave % S, j = wave / S;
         long long wrow[UPW];
@@ -227,6 +229,7 @@ __global__ __launch_bounds__(768) void rows_lstm_kernel(const RLstmArgs a) {
         float4 w[UPW][4];
         int si = sw;
         const RSlice s0 = rows_slice_of(a.g, si < a.g.nslice ? si : 0);
+        if (run == 0) return;
         __syncthreads();                                    // the helpers' activation DMAs are issued: they go first
         if (si < a.g.nslice) rows_issue<UPW, 4, NT, 0, 1>(s0, wrow, lane, w);
         __syncthreads();                                    // the staged activations
@@ -260,6 +263,7 @@ __global__ __launch_bounds__(768) void rows_lstm_kernel(const RLstmArgs a) {
     if (ok && a.tab) tok = a.tab_ids[(long long)m * a.tab_ids_stride];
     long long rs = 0;
     if (ok) rs = a.src[m];
+    if (run == 0) return;
     rows_stage<MR>(a.g, srcv, M, As, a.rc, hw, a.NH, lane);
     __syncthreads();                                        // DMAs issued
     float cp = 0.f, q[4] = {0.f, 0.f, 0.f, 0.f}, tb[4] = {0.f, 0.f, 0.f, 0.f}, b[4] = {0.f, 0.f, 0.f, 0.f};
@@ -267,7 +271,7 @@ __global__ __launch_bounds__(768) void rows_lstm_kernel(const RLstmArgs a) {
         cp = a.c_prev[rs * H + unit];
         if (a.pre) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) q[k] = a.pre[(long long)m * 4 * H + k * H + unit];
+            for (int k = 0; k < 4; ++k) q[k] = a.pre[(long long)(m / a.row_div) * 4 * H + k * H + unit];
         }
         if (a.b_ih) {
 #pragma unroll
@@ -355,7 +359,7 @@ static int rows_lstm_launch(const RLstmArgs &a, int grid, int threads, size_t ld
 static int rows_lstm(const float *const *A, const int *lda, const float *const *W, const int *ldw, const int *K,
                      const int *ind, int nseg, int M, int H, const int64_t *src, const float *c_prev, float *h_out,
                      float *c_out, const float *b_ih, const float *b_hh, const float *pre, const float *tab,
-                     const int64_t *tab_ids, int64_t tab_ids_stride, hipStream_t st) {
+                     const int64_t *tab_ids, int64_t tab_ids_stride, int row_div, const int *skip, hipStream_t st) {
     RLstmArgs a = {};
     const int nslice = rows_make_segs(a.g, A, lda, W, ldw, K, ind, nseg, 8);
     if (nslice < 1) return ISC_E_SHAPE;
@@ -377,7 +381,7 @@ static int rows_lstm(const float *const *A, const int *lda, const float *const *
     if (J * upw * MR > 64) upw = 1;
     a.J = J;
     a.NH = 3;
-    a.M = M; a.H = H;
+    a.M = M; a.H = H; a.row_div = row_div > 1 ? row_div : 1; a.skip = skip;
     a.rc = rows_const();
     if (!a.rc) return ISC_E_STATE;
     a.src = src ? reinterpret_cast<const long long *>(src) : a.rc->ident;
@@ -402,6 +406,7 @@ static int rows_lstm(const float *const *A, const int *lda, const float *const *
 struct RLinArgs {
     RSegs g;                         // .W is problem 0's; problem i's = W[i] + (slice.W - W[0])
     int S, J, NH, M, nprob, pad;
+    const int *skip;
     const RowsConst *rc;
     const float *W[3], *bias[3];
     float *C[3];
@@ -416,6 +421,7 @@ __global__ __launch_bounds__(768) void rows_linear_kernel(const RLinArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int S = a.S, J = a.J, NWS = S * J, M = a.M;
+    if (a.skip && *a.skip == 0) return;                     // (uniform)
     if (wave >= NWS) {                                      // helper waves: the activation image
         rows_stage<MR>(a.g, lane & 7, M, As, a.rc, wave - NWS, a.NH, lane);
         __syncthreads();
@@ -478,7 +484,7 @@ __global__ __launch_bounds__(768) void rows_linear_kernel(const RLinArgs a) {
 }
 
 static int rows_linear3(const float *A, int lda, int K, int M, const float *const *W, const float *const *bias,
-                        float *const *C, const int *N, const int *ldc, int nprob, hipStream_t st) {
+                        float *const *C, const int *N, const int *ldc, int nprob, const int *skip, hipStream_t st) {
     if (nprob < 1 || nprob > 3 || M < 1 || M > ROWS_MAX) return ISC_E_SHAPE;
     RLinArgs a = {};
     const int ldw = K, ind = 0;
@@ -492,7 +498,7 @@ static int rows_linear3(const float *A, int lda, int K, int M, const float *cons
         a.W[i] = W[i]; a.bias[i] = bias[i]; a.C[i] = C[i]; a.N[i] = N[i]; a.ldc[i] = ldc[i];
         Ntot += N[i];
     }
-    a.nprob = nprob; a.M = M;
+    a.nprob = nprob; a.M = M; a.skip = skip;
     a.rc = rows_const();
     if (!a.rc) return ISC_E_STATE;
     a.S = nslice < 8 ? nslice : 8;
@@ -524,6 +530,7 @@ static int rows_linear3(const float *A, int lda, int K, int M, const float *cons
 struct RVocabArgs {
     RSegs g;
     int S, J, NH, M, V, TW, n_tile, pad;
+    const int *skip;
     const RowsConst *rc;
     const float *bias;
     float *pmax, *psum;
@@ -554,6 +561,7 @@ __global__ __launch_bounds__(768) void rows_vocab_kernel(const RVocabArgs a) {
     // epilogue operands, fetched ahead of the weight stream: this lane's column bias, its row's last word
     const float bias_c = (lane < tw) ? a.bias[col0 + lane] : 0.f;
     const int lastv = (a.cons && a.last_word) ? (int)a.last_word[(lane & 7) < M ? (lane & 7) : M - 1] : -1;   // lane q: row q's
+    if (a.skip && *a.skip == 0) return;                     // (uniform)
     if (wave >= NWS) {                                      // helper waves: the activation image
         rows_stage<MR>(a.g, lane & 7, M, As, a.rc, wave - NWS, a.NH, lane);
         __syncthreads();
@@ -697,7 +705,7 @@ static int rows_vocab(const float *h, int ldh, const float *W, int ldw, const fl
     int np = (passes + J - 1) / J;
     if (16 * np < TW) np = (TW + 15) / 16;
     if (np > 4) return ISC_E_SHAPE;
-    a.J = J; a.NH = 2; a.M = M; a.V = V; a.TW = TW; a.n_tile = (V + TW - 1) / TW;
+    a.J = J; a.NH = 2; a.M = M; a.V = V; a.TW = TW; a.n_tile = (V + TW - 1) / TW; a.skip = x ? x->live_in : nullptr;
     a.rc = rows_const();
     if (!a.rc) return ISC_E_STATE;
     a.bias = bias; a.pmax = pmax; a.psum = psum; a.pidx = pidx; a.logits = logits; a.ld_logits = ld_logits;
@@ -742,7 +750,8 @@ struct RScanArgs {
     const float *q[2], *q2, *w[2], *wb[2];
     const long long *ids;                      // sentiment gather mode: word row ids [rows, ids_ld]
     long long ids_ld;
-    int R[2], A;
+    int R[2], A, row_div;                      // row_div: rows per image of the per-image P / V / G / ids / q2 (1: per row)
+    const int *skip;
     const float *zh, *b_c, *b_s, *w_g, *b_g;
     float *f, *alpha[2], *beta;
     long long alpha_ld[2], beta_ld;
@@ -764,10 +773,12 @@ __global__ __launch_bounds__(1024) void rows_scan_gate_kernel(const RScanArgs a)
     float *part = smem + Rp0 + Rp1;                            // [16 waves][2 (V, G)][A]
     float *fin = part + 16 * 2 * A;                            // [4][A]: v, Gc-sum, s, Gs-sum
     float *redw = fin + 4 * A;                                 // [16] wave partials of the gate dot
+    if (a.skip && *a.skip == 0) return;                        // (uniform)
     const bool gather = half && a.ids;
+    const int bi = b / a.row_div;                              // the image of this row: P / V / G / ids / q2 are per image
     const float *Pb = (half ? a.P[1] : a.P[0]), *Vb = (half ? a.V[1] : a.V[0]), *Gb = (half ? a.G[1] : a.G[0]);
     if (!gather) {
-        Pb += (long long)b * R * A; Vb += (long long)b * R * A; Gb += (long long)b * R * A;
+        Pb += (long long)bi * R * A; Vb += (long long)bi * R * A; Gb += (long long)bi * R * A;
     }
     const bool single = a.R[0] <= RS_NWC * RS_RPW && a.R[1] <= RS_NWS * RS_RPW;
     float4 pp[RS_RPW][2], vv[RS_RPW][2], gg[RS_RPW][2];
@@ -783,14 +794,14 @@ __global__ __launch_bounds__(1024) void rows_scan_gate_kernel(const RScanArgs a)
     for (int u = 0; u < RS_RPW; ++u) {
         const int r = wv + u * nwv;
         const int rc = r < R ? r : R - 1;
-        rrow[u] = gather ? a.ids[(long long)b * a.ids_ld + rc] : rc;
+        rrow[u] = gather ? a.ids[(long long)bi * a.ids_ld + rc] : rc;
     }
     float4 qv[2], q2v[2], wv4[2];
     const bool has_q2 = half && a.q2;                          // wave-uniform
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         qv[i] = reinterpret_cast<const float4 *>((half ? a.q[1] : a.q[0]) + (long long)b * A)[a4c[i]];
-        q2v[i] = has_q2 ? reinterpret_cast<const float4 *>(a.q2 + (long long)b * A)[a4c[i]] : z4;
+        q2v[i] = has_q2 ? reinterpret_cast<const float4 *>(a.q2 + (long long)bi * A)[a4c[i]] : z4;
         wv4[i] = reinterpret_cast<const float4 *>((half ? a.w[1] : a.w[0]))[a4c[i]];
     }
     const float *wbp = half ? a.wb[1] : a.wb[0];
@@ -821,7 +832,7 @@ __global__ __launch_bounds__(1024) void rows_scan_gate_kernel(const RScanArgs a)
             for (int u = 0; u < RS_RPW; ++u) {
                 const int r = r0 + u * nwv;
                 const int rc = r < R ? r : R - 1;
-                const long long row = gather ? a.ids[(long long)b * a.ids_ld + rc] : rc;
+                const long long row = gather ? a.ids[(long long)bi * a.ids_ld + rc] : rc;
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     pp[u][i] = reinterpret_cast<const float4 *>(Pb + row * A)[a4c[i]];
@@ -881,7 +892,7 @@ __global__ __launch_bounds__(1024) void rows_scan_gate_kernel(const RScanArgs a)
             for (int u = 0; u < RS_RPW; ++u) {
                 const int r = r0 + u * nwv;
                 const int rc = r < R ? r : R - 1;
-                const long long row = gather ? a.ids[(long long)b * a.ids_ld + rc] : rc;
+                const long long row = gather ? a.ids[(long long)bi * a.ids_ld + rc] : rc;
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     vv[u][i] = reinterpret_cast<const float4 *>(Vb + row * A)[a4c[i]];
@@ -958,8 +969,9 @@ static bool rows_scan_ok(const isc_step_plan *p) {
            (p->A & 3) == 0 && p->R >= 1 && p->Mw >= 1;
 }
 
-static int rows_scan_gate(const isc_step_plan *p, hipStream_t st) {
+static int rows_scan_gate(const isc_step_plan *p, int row_div, const int *skip, hipStream_t st) {
     RScanArgs a = {};
+    a.row_div = row_div > 1 ? row_div : 1; a.skip = skip;
     a.P[0] = p->att_p; a.V[0] = p->att_e; a.G[0] = p->gate_Gc; a.q[0] = p->qa; a.w[0] = p->w_alpha_c; a.wb[0] = p->b_alpha_c;
     a.P[1] = p->words_p; a.V[1] = p->words_e; a.G[1] = p->gate_Gs; a.q[1] = p->qw; a.w[1] = p->w_alpha_s; a.wb[1] = p->b_alpha_s;
     a.q2 = p->label_w;
@@ -1012,6 +1024,9 @@ extern "C" int isc_rows_step_fwd(const isc_step_plan *p, const isc_rows_ext *x, 
     const int rows = p->rows, H = p->H, E = p->E, A = p->A, W = p->W, V = p->V;
     const int ld1 = H + E + W, ld2 = E + H;
     const int64_t *src = x->src_row;
+    const int row_div = x->row_div > 1 ? x->row_div : 1;
+    const int *skip = x->live_in;
+    if (rows % row_div) return ISC_E_SHAPE;
     {   // att-LSTM over cat[h_lang_prev, fc, xt] (captioner.py:174-175); fc / label / biases are in pre1
         const float *As[3], *Ws[3];
         int lda[3], ldw[3], K[3], ind[3], n = 0;
@@ -1019,20 +1034,20 @@ extern "C" int isc_rows_step_fwd(const isc_step_plan *p, const isc_rows_ext *x, 
         if (!p->tab) { As[n] = p->xt; lda[n] = W; Ws[n] = p->Wih1 + H + E; ldw[n] = ld1; K[n] = W; ind[n] = 0; ++n; }
         As[n] = p->h1_prev; lda[n] = H; Ws[n] = p->Whh1; ldw[n] = H; K[n] = H; ind[n] = 1; ++n;
         RET(rows_lstm(As, lda, Ws, ldw, K, ind, n, rows, H, src, p->c1_prev, p->h1, p->c1, nullptr, nullptr, p->pre1,
-                      p->tab, p->tok, p->tok_stride, st));
+                      p->tab, p->tok, p->tok_stride, row_div, skip, st));
     }
     {   // projections of h_att: h2att (content), h2word (sentiment), the gate's h-term
         const float *Ws[3] = {p->W_h2att, p->W_h2word, p->W_gh}, *bs[3] = {p->b_h2att, p->b_h2word, p->b_gh};
         float *Cs[3] = {p->qa, p->qw, p->z};
         const int N[3] = {A, A, A}, ldc[3] = {A, A, A};
-        RET(rows_linear3(p->h1, H, H, rows, Ws, bs, Cs, N, ldc, 3, st));
+        RET(rows_linear3(p->h1, H, H, rows, Ws, bs, Cs, N, ldc, 3, skip, st));
     }
-    RET(rows_scan_gate(p, st));
+    RET(rows_scan_gate(p, row_div, skip, st));
     {   // lang-LSTM over cat[f, h_att] (captioner.py:180-181)
         const float *As[3] = {p->f, p->h1, p->h2_prev}, *Ws[3] = {p->Wih2, p->Wih2 + E, p->Whh2};
         const int lda[3] = {E, H, H}, ldw[3] = {ld2, ld2, H}, K[3] = {E, H, H}, ind[3] = {0, 0, 1};
         RET(rows_lstm(As, lda, Ws, ldw, K, ind, 3, rows, H, src, p->c2_prev, p->h2, p->c2, p->b_ih2, p->b_hh2, nullptr,
-                      nullptr, nullptr, 0, st));
+                      nullptr, nullptr, 0, 1, skip, st));
     }
     RET(rows_vocab(p->h2, H, p->W_cls, H, p->b_cls, rows, V, H, x->stats_tile, p->pmax, p->psum, p->pidx, p->logits,
                    p->ld_logits, x, st));
