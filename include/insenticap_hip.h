@@ -474,8 +474,8 @@ long long isc_rows_launches(void);    /* launches of rows kernels so far (tests 
  * candidates isc_rows_step_fwd left: per row the log-softmax normaliser is folded from (pmax, psum), the row's top-`beam`
  * (raw logit descending, ties to the smaller word id; log-prob = (x - max) - log(sum)) is merged out of its tiles'
  * sorted candidate lists, then the image's candidates are formed, scored in fp64 and stably ranked exactly as
- * isc_beam_merge does.  src_row[r] receives the PARENT row of new row r (the next step's isc_rows_ext.src_row; an ended
- * candidate's state is never read again, captioner.py:383-385, so carried rows point at their parent's state as well);
+ * isc_beam_merge does.  src_row[r] receives the PARENT row of new row r (usable as the next step's isc_rows_ext.src_row; an
+ * ended candidate's state is never read again, captioner.py:383-385, so carried rows point at their parent's state as well);
  * top_val / top_idx (optional, [n_img*beam, beam]) receive the rows' top-k for inspection. */
 typedef struct {
     int32_t n_img, beam, T, t;
@@ -498,6 +498,13 @@ typedef struct {
     float *top_val;
     int64_t *top_idx;
     const int32_t *live_in;               /* optional: reads 0 -> the launch returns at once (see isc_rows_ext.live_in) */
+    /* optional: the recurrent state re-ordered here as well (what isc_beam_gather does in a launch of its own):
+     * state_out[p, r, :] = state_in[p, parent(r), :] for the state_planes [n_img*beam, H] planes (h | c x layer) the
+     * step has just written; the next step then reads plain rows (no isc_rows_ext.src_row: its kernels stage their
+     * activations without a dependent index load in front).  state_out must not alias state_in; H % 4 == 0. */
+    const float *state_in;
+    float *state_out;
+    int32_t state_planes, H;
 } isc_beam_select_args;
 int isc_beam_select(const isc_beam_select_args *args_host, void *stream);
 

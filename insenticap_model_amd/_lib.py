@@ -114,7 +114,8 @@ class BeamSelectArgs(C.Structure):
     _fields_ = ([('n_img', C.c_int32), ('beam', C.c_int32), ('T', C.c_int32), ('t', C.c_int32), ('n_tile', C.c_int32),
                  ('V', C.c_int32), ('eos_id', C.c_int64)] +
                 _f('part_max part_sum cand_val cand_idx score_in score_out last_in last_out words_in words_out len_in '
-                   'len_out done src_row live top_val top_idx live_in', C.c_void_p))
+                   'len_out done src_row live top_val top_idx live_in state_in state_out', C.c_void_p) +
+                [('state_planes', C.c_int32), ('H', C.c_int32)])
 
 
 ISC_COLSUM_MAX_JOBS, ISC_COLSUM_MAX_OUT = 24, 3

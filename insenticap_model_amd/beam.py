@@ -330,6 +330,10 @@ class _Search:
                 b.cand_val, b.cand_idx = x.cand_val, x.cand_idx
                 b.done, b.src_row, b.live = self.done.data_ptr(), self.src_row.data_ptr(), self.live.data_ptr()
                 b.top_val, b.top_idx = self.top_val.data_ptr(), self.top_idx.data_ptr()
+                # the select re-orders the state as well: step t reads st_cur, writes st_nxt; its select gathers
+                # st_nxt -> st_cur (same buffers, same plan, every step)
+                b.state_in, b.state_out = self.st_nxt.data_ptr(), self.st_cur.data_ptr()
+                b.state_planes, b.H = 4, H
             else:
                 self.st_free = torch.empty_like(self.st_cur)   # third state buffer: target of the per-step re-ordering
 
@@ -377,15 +381,15 @@ class _Search:
         self.cur = nxt
 
     def _step_rows(self, t):
-        """Step t on the few-row kernels: rows read their parents' state through src_row (written by step t - 1's
-        select; the identity at t = 0), the state ping-pongs between two buffers, the select closes the step."""
+        """Step t on the few-row kernels: the step reads st_cur and writes st_nxt, the select that closes it gathers the
+        parents' rows of st_nxt back into st_cur (isc_beam_select_args.state_*)."""
         cap, a, x = self.cap, self.args, self.ext
         cap.last_beam_steps = t + 1
         cur = self.cur
         last_d = self.last[cur]
         if self.Pb.tab is None:
             ops.embed_relu_fwd(self.emb, last_d, self.xt)
-        fast = self._plans[t & 1] if t >= 3 else None
+        fast = self._plans[t & 1] if t >= 2 else None
         live_in = self.live.data_ptr() + 4 * t if t > 0 else None     # live[t] == 0: the step's launches return at once
         if fast is not None:
             plan, x, a = fast
@@ -393,9 +397,8 @@ class _Search:
             ops.rows_step_fwd(plan, x)
         else:
             x.last_word = last_d.data_ptr()
-            x.src_row = self.src_row.data_ptr() if t > 0 else None
             x.live_in = a.live_in = live_in
-            sc, sn = (self.st_cur, self.st_nxt) if (t & 1) == 0 else (self.st_nxt, self.st_cur)
+            sc, sn = self.st_cur, self.st_nxt
             cap._step(self.p, self.Pb, self.ws, self.xt, sc[0], sc[1], sn[0], sn[1], logits=None, tok=last_d, rows_ext=x)
         nxt = cur ^ 1
         a.t = t
@@ -404,7 +407,7 @@ class _Search:
             a.last_in, a.last_out = self.last[cur].data_ptr(), self.last[nxt].data_ptr()
             a.words_in, a.words_out = self.words[cur].data_ptr(), self.words[nxt].data_ptr()
             a.len_in, a.len_out = self.length[cur].data_ptr(), self.length[nxt].data_ptr()
-            if t in (1, 2) and '_plan' in self.ws:      # (step 0 has no source-row index: its plan is not a template)
+            if t < 2 and '_plan' in self.ws:
                 plan = self.ws['_plan']
                 self._plans[t & 1] = (type(plan).from_buffer_copy(plan), type(x).from_buffer_copy(x), type(a).from_buffer_copy(a))
         ops.beam_select(a)

@@ -50,27 +50,34 @@ __device__ __forceinline__ float isc_relu(float x) { return x < 0.f ? 0.f : x; }
 #define ROWS_STAMP 0
 #endif
 #if ROWS_STAMP
-__device__ long long *g_rows_stamp;
-#define RSTAMP(SLOT)                                                                                         \
+// (one pointer per translation unit, set through that unit's isc_*_set_stamp; a kernel stamps into region RSTAMP_KID of the
+// buffer - 1024 workgroups x 16 waves x 8 slots each - so that the kernels of one decode step do not overwrite each other)
+static __device__ long long *g_rows_stamp;
+#define RSTAMP_REGION 131072
+#define RSTAMP_K(KID, SLOT)                                                                                  \
     do {                                                                                                     \
-        if ((threadIdx.x & 63) == 0 && g_rows_stamp)                                                          \
-            g_rows_stamp[((long long)blockIdx.x * 16 + (threadIdx.x >> 6)) * 8 + (SLOT)] = wall_clock64();     \
+        if ((threadIdx.x & 63) == 0 && g_rows_stamp && blockIdx.x < 1024)                                     \
+            g_rows_stamp[(long long)(KID) * RSTAMP_REGION + ((long long)blockIdx.x * 16 + (threadIdx.x >> 6)) * 8 + (SLOT)] = wall_clock64(); \
     } while (0)
+#define RSTAMP(SLOT) RSTAMP_K(RSTAMP_KID, SLOT)
 #define RSTAMP2(W, SLOT)                                                                                     \
     do {                                                                                                     \
-        if (threadIdx.x == 0 && g_rows_stamp) g_rows_stamp[((long long)blockIdx.x * 16 + (W)) * 8 + (SLOT)] = wall_clock64(); \
+        if (threadIdx.x == 0 && g_rows_stamp) g_rows_stamp[(long long)RSTAMP_KID * RSTAMP_REGION + ((long long)blockIdx.x * 16 + (W)) * 8 + (SLOT)] = wall_clock64(); \
     } while (0)
 #define RSTAMP_CLK0() const long long rstamp_c0 = clock64()
 #define RSTAMP_CLK1()                                                                                        \
     do {                                                                                                     \
-        if ((threadIdx.x & 63) == 0 && g_rows_stamp)                                                          \
-            g_rows_stamp[((long long)blockIdx.x * 16 + (threadIdx.x >> 6)) * 8 + 7] = clock64() - rstamp_c0;   \
+        if ((threadIdx.x & 63) == 0 && g_rows_stamp && blockIdx.x < 1024)                                     \
+            g_rows_stamp[(long long)RSTAMP_KID * RSTAMP_REGION + ((long long)blockIdx.x * 16 + (threadIdx.x >> 6)) * 8 + 7] = clock64() - rstamp_c0;   \
     } while (0)
+#define RSTAMP_SETTER(NAME)                                                                                  \
+    extern "C" int NAME(long long *p) { return hipMemcpyToSymbol(HIP_SYMBOL(g_rows_stamp), &p, sizeof(p)) == hipSuccess ? 0 : 1; }
 #else
 #define RSTAMP(SLOT) do {} while (0)
 #define RSTAMP2(W, SLOT) do {} while (0)
 #define RSTAMP_CLK0() do {} while (0)
 #define RSTAMP_CLK1() do {} while (0)
+#define RSTAMP_K(KID, SLOT) do {} while (0)
 #endif
 
 // Kernel arguments are read by scalar loads where they are first used; every first touch of a 64-byte line of the

@@ -728,6 +728,10 @@ extern "C" int isc_beam_topk(const float *logits, int64_t ld_logits, const float
 // Word ids, log-probs ((x - max) - log(sum), the expression of beam_topk8_kernel) and tie order are those of the
 // three-launch path on the same logits and statistics.
 #define ISC_SEL_TILES_PER_LANE 4
+#if ROWS_STAMP
+#define RSTAMP_KID 5
+RSTAMP_SETTER(isc_pw_set_stamp)
+#endif
 // One launch, one workgroup per image, and at this size every dependent memory round trip is a visible share of the
 // kernel: every global operand - candidates, tile statistics, the candidates' bookkeeping (last words, scores, lengths,
 // the parents' word lists) - is requested in the first instructions, all lane exchanges are DPP (one cross-half swap per
@@ -850,6 +854,14 @@ __global__ __launch_bounds__(512) void beam_select_kernel(const isc_beam_select_
         for (int q = 0; q < 4; ++q) {
             const int e = tid + q * (int)blockDim.x;
             if (e < beam * T) a.words_out[(long long)base * T + e] = wv[q];
+        }
+        if (a.state_out) {
+            const int h4 = a.H >> 2, rows_all = a.n_img * beam;
+            for (int e = tid; e < a.state_planes * beam * h4; e += blockDim.x) {
+                const int c4 = e % h4, r = (e / h4) % beam, pl = e / (h4 * beam);
+                const long long o = ((long long)pl * rows_all + base + r) * h4 + c4;
+                reinterpret_cast<float4 *>(a.state_out)[o] = reinterpret_cast<const float4 *>(a.state_in)[o];
+            }
         }
         return;
     }
@@ -981,6 +993,18 @@ __global__ __launch_bounds__(512) void beam_select_kernel(const isc_beam_select_
             if (e < beam * T) wl[e] = wv[q];
         }
         __syncthreads();
+        // the recurrent state follows the candidates: new row r continues its parent's (the step's output planes -> the
+        // next step's input planes; loads first, they are the long pole of this tail)
+        if (a.state_out) {
+            const int h4 = a.H >> 2, rows_all = a.n_img * beam, nrow = n < beam ? n : beam;
+            const int total = a.state_planes * nrow * h4;
+#pragma unroll 4
+            for (int e = tid; e < total; e += (int)blockDim.x) {
+                const int c4 = e % h4, r = (e / h4) % nrow, pl = e / (h4 * nrow);
+                const float4 v = reinterpret_cast<const float4 *>(a.state_in)[((long long)pl * rows_all + base + w_par[r]) * h4 + c4];
+                reinterpret_cast<float4 *>(a.state_out)[((long long)pl * rows_all + base + r) * h4 + c4] = v;
+            }
+        }
         const int nfill = n < beam ? n : beam;               // (t == 0: one live parent still yields `beam` rows)
         for (int e = tid; e < nfill * T; e += blockDim.x) {
             const int r = e / T, pos = e - r * T;
@@ -999,6 +1023,9 @@ extern "C" int isc_beam_select(const isc_beam_select_args *args, void *stream) {
         !a.last_out || !a.words_in || !a.words_out || !a.len_in || !a.len_out || !a.done || !a.src_row || !a.live)
         return ISC_E_NULL;
     if ((a.top_val == nullptr) != (a.top_idx == nullptr)) return ISC_E_NULL;
+    if ((a.state_in == nullptr) != (a.state_out == nullptr)) return ISC_E_NULL;
+    if (a.state_out && (a.state_planes <= 0 || a.H <= 0 || (a.H & 3) || a.state_in == a.state_out)) return ISC_E_SHAPE;
+    if (a.state_out && (!isc_aligned16(a.state_in) || !isc_aligned16(a.state_out))) return ISC_E_ALIGN;
     if (a.n_img <= 0 || a.beam <= 0 || a.beam > ISC_BEAM_MAX || a.T <= 0 || a.t < 0 || a.t >= a.T || a.V <= 0)
         return ISC_E_SHAPE;
     if (a.n_tile < 1 || a.n_tile > 64 * ISC_SEL_TILES_PER_LANE) return ISC_E_SHAPE;

@@ -27,6 +27,9 @@
 #define ROWS_MAX 8
 #define ROWS_MAX_SLICE 12
 #define ROWS_KC 8                    // candidate slots per (row, column tile)
+#if ROWS_STAMP
+RSTAMP_SETTER(isc_rows_set_stamp)
+#endif
 
 struct RSlice {                      // one K-slice (<= 256 floats) of a contraction
     const float *A;                  // activations: row m at A + row(m) * lda   (already offset to the slice's k0)
@@ -129,12 +132,13 @@ __device__ __forceinline__ void rows_fma(const float *As, const float4 (&w)[NP][
     }
 }
 
-// Helper waves stage the activation slices: As[(si * MR + m) * ROWS_SK + k] = (m < M && k < klen) ? A_si[row(m), k] : 0, one
-// LDS-DMA (64 lanes x 16 B = one 1 KB slot; no staging registers, all of them in flight) per (slice, row); lanes that must
-// deliver zeros read a 16-byte zero constant.  row(m) = srow[m] for the slices of the recurrent state.  Helper `hw` of `nh`
-// takes slots hw, hw + nh, ...  The workgroup's first barrier follows the ISSUE of these DMAs (the streaming waves start
-// their weight loads behind it, so that the activation image is not queued behind 96 KB of weights per CU and the FMAs can
-// follow the weights as they arrive); rows_stage_wait (the wave's vmcnt(0)) precedes the second, which publishes the image.
+// The activation slices in LDS: As[(si * MR + m) * ROWS_SK + k] = (m < M && k < klen) ? A_si[row(m), k] : 0, one LDS-DMA
+// (64 lanes x 16 B = one 1 KB slot; no staging registers) per (slice, row); lanes that must deliver zeros read a 16-byte
+// zero constant.  row(m) = srcv's lane m for the slices of the recurrent state when the caller re-orders it.
+// The J waves that contract slice si stage it between them (wave j: rows j, j + J, ...) as the FIRST vector-memory
+// operations they issue: the requests sit at the head of every queue (a helper wave's DMAs, issued beside 96 KB of weight
+// loads per CU, took 2.5 - 3.5 us to land: stamps, tools/stamp_step.py), and since vmcnt retires in order the wave can
+// wait for exactly these - s_waitcnt vmcnt(<its weight loads>) - while its weights stay in flight.
 struct __attribute__((aligned(16))) RowsConst {
     long long ident[ROWS_MAX];
     float zero[4];
@@ -143,21 +147,26 @@ __device__ RowsConst g_rows_const = {{0, 1, 2, 3, 4, 5, 6, 7}, {0.f, 0.f, 0.f, 0
 
 // srcv: lane q (< 8) holds the source row of slot q (readlane per slot: the slot index is wave-uniform).
 template <int MR>
-__device__ __forceinline__ void rows_stage(const RSegs &g, int srcv, int M, float *As,
-                                           const RowsConst *rc, int hw, int nh, int lane) {
+__device__ __forceinline__ void rows_stage_own(const RSegs &g, int si0, int S, int j, int J, int srcv, int M, float *As,
+                                               const RowsConst *rc, int lane) {
     const unsigned lds0 = (unsigned)(size_t)As;
-    const int total = g.nslice * MR;
-    for (int idx = hw; idx < total; idx += nh) {             // wave-uniform
-        const int si = idx / MR, m = idx - si * MR;
+    for (int si = si0; si < g.nslice; si += S) {             // wave-uniform
         const RSlice s = rows_slice_of(g, si);
-        const long long r = s.indirect ? __builtin_amdgcn_readlane(srcv, m) : m;
-        const bool valid = m < M && lane * 4 < s.klen;
-        const float *src = valid ? s.A + r * s.lda + lane * 4 : rc->zero;
-        const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)idx * (ROWS_SK * 4));
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(dst), "v"(src) : "memory");      // (M0: only these statements write it in this file)
+        for (int m = j; m < MR; m += J) {
+            const long long r = s.indirect ? __builtin_amdgcn_readlane(srcv, m) : m;
+            const bool valid = m < M && lane * 4 < s.klen;
+            const float *src = valid ? s.A + r * s.lda + lane * 4 : rc->zero;
+            const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(si * MR + m) * (ROWS_SK * 4));
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(dst), "v"(src) : "memory");      // (M0: only these statements write it in this file)
+        }
     }
 }
-__device__ __forceinline__ void rows_stage_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// Wait for the wave's DMAs with its NW younger weight loads still in flight.
+template <int NW>
+__device__ __forceinline__ void rows_stage_wait() {
+    static_assert(NW >= 0 && NW < 64, "vmcnt");
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NW) : "memory");
+}
 
 static const RowsConst *rows_const() {              // device address of the constants (per process: one device code object)
     static std::atomic<const RowsConst *> p{nullptr};
@@ -185,14 +194,14 @@ extern "C" long long isc_rows_launches(void) { return g_rows_launches.load(); }
 
 // ------------------------------------------------------------------ LSTM cell
 // gates[m, g*H + u] = sum over slices; c' = sig(f) c + sig(i) tanh(g), h' = sig(o) tanh(c')  (captioner.py:175,181)
-// Workgroup = S x J streaming waves + NH helper waves.  Streaming wave (sw, j): K-slices sw, sw + S, ... of units
-// u0 + j*UPW .. +UPW-1 (lane group g = gate g of the unit): weight loads, barrier, FMAs against the staged rows, 16-lane
-// sums, partials to LDS.  Helper waves: source rows / token ids (the dependent index chains), the activation image by
-// LDS-DMA; helper 0 also fetches c_prev / hoisted term / token-table row / biases of the workgroup's U = J*UPW units and
-// applies the cell once the partials are in LDS.
+// Workgroup = S x J streaming waves + 1 epilogue wave.  Streaming wave (sw, j): K-slices sw, sw + S, ... of units
+// u0 + j*UPW .. +UPW-1 (lane group g = gate g of the unit): its share of the activation image by LDS-DMA, weight loads,
+// barrier, FMAs against the staged rows, 16-lane sums, partials to LDS.  The epilogue wave holds the dependent index
+// chain (token id -> row of the token table) and fetches c_prev / hoisted term / biases of the workgroup's U = J*UPW
+// units at kernel start; it applies the cell once the partials are in LDS.
 struct RLstmArgs {
     RSegs g;
-    int S, J, NH, M, H, row_div;     // row_div: rows per image of the per-image hoisted term `pre` (1: per row)
+    int S, J, has_src, M, H, row_div;   // row_div: rows per image of the per-image hoisted term `pre` (1: per row)
     const int *skip;                 // optional: *skip == 0 -> nothing to do (the search has ended; see isc_rows_ext.live_in)
     const long long *src;            // never null (identity when the caller has no re-ordering)
     const RowsConst *rc;
@@ -213,6 +222,8 @@ __global__ __launch_bounds__(768) void rows_lstm_kernel(const RLstmArgs a) {
     const int S = a.S, J = a.J, NWS = S * J, H = a.H, M = a.M;
     const int U = J * UPW, u0 = blockIdx.x * U;
     const int run = a.skip ? *a.skip : 1;                   // (uniform; waited for at the first barrier, not before)
+#define RSTAMP_KID (a.b_ih ? 3 : 0)
+    RSTAMP(0);
     if (wave < NWS) {
         const int sw = wave % S, j = wave / S;
         long long wrow[UPW];
@@ -230,10 +241,16 @@ __global__ __launch_bounds__(768) void rows_lstm_kernel(const RLstmArgs a) {
         int si = sw;
         const RSlice s0 = rows_slice_of(a.g, si < a.g.nslice ? si : 0);
         if (run == 0) return;
-        __syncthreads();                                    // the helpers' activation DMAs are issued: they go first
-        if (si < a.g.nslice) rows_issue<UPW, 4, NT, 0, 1>(s0, wrow, lane, w);
+        RSTAMP(1);
+        // source rows of the recurrent state (only when the caller re-orders it: a dependent load in front of the DMAs)
+        int srcv = lane & 7;
+        if (a.has_src) srcv = (int)a.src[(lane & 7) < M ? (lane & 7) : M - 1];
+        rows_stage_own<MR>(a.g, sw, S, j, J, srcv, M, As, a.rc, lane);
+        if (si < a.g.nslice) rows_issue<UPW, 4, NT>(s0, wrow, lane, w);
+        RSTAMP(2);
+        rows_stage_wait<UPW * 4>();
         __syncthreads();                                    // the staged activations
-        if (UPW > 1 && si < a.g.nslice) rows_issue<UPW, 4, NT, 1, UPW>(s0, wrow, lane, w);
+        RSTAMP(3);
         while (si < a.g.nslice) {
             rows_fma<MR, UPW, 4>(As + si * MR * ROWS_SK, w, lane, acc2);
             si += S;
@@ -250,22 +267,19 @@ __global__ __launch_bounds__(768) void rows_lstm_kernel(const RLstmArgs a) {
 #pragma unroll
                 for (int m = 0; m < MR; ++m) red[((wave * UPW + i) * 4 + g) * MR + m] = acc[i][m];
         }
+        RSTAMP(4);
         __syncthreads();
         return;
     }
-    // ---- helper waves
-    const int hw = wave - NWS;
-    const int srcv = (int)a.src[(lane & 7) < M ? (lane & 7) : M - 1];      // lane q: source row of slot q
-    // helper 0: lane e = (unit ul = e / MR of the workgroup, row m = e % MR)
+    // ---- epilogue wave: lane e = (unit ul = e / MR of the workgroup, row m = e % MR)
     const int ul = lane / MR, m = lane - ul * MR, unit = u0 + ul;
-    const bool ok = hw == 0 && ul < U && m < M && unit < H;
+    const bool ok = ul < U && m < M && unit < H;
     long long tok = 0;
     if (ok && a.tab) tok = a.tab_ids[(long long)m * a.tab_ids_stride];
-    long long rs = 0;
-    if (ok) rs = a.src[m];
+    long long rs = m;
+    if (ok && a.has_src) rs = a.src[m];
     if (run == 0) return;
-    rows_stage<MR>(a.g, srcv, M, As, a.rc, hw, a.NH, lane);
-    __syncthreads();                                        // DMAs issued
+    RSTAMP(1);
     float cp = 0.f, q[4] = {0.f, 0.f, 0.f, 0.f}, tb[4] = {0.f, 0.f, 0.f, 0.f}, b[4] = {0.f, 0.f, 0.f, 0.f};
     if (ok) {
         cp = a.c_prev[rs * H + unit];
@@ -282,9 +296,10 @@ __global__ __launch_bounds__(768) void rows_lstm_kernel(const RLstmArgs a) {
             for (int k = 0; k < 4; ++k) tb[k] = a.tab[tok * 4 * H + k * H + unit];
         }
     }
-    rows_stage_wait();
+    RSTAMP(3);
     __syncthreads();                                        // activations published
     __syncthreads();                                        // partial sums in LDS
+    RSTAMP(5);
     if (!ok) return;
     const int j = ul / UPW, i = ul - j * UPW;
     float gt[4];
@@ -303,6 +318,8 @@ __global__ __launch_bounds__(768) void rows_lstm_kernel(const RLstmArgs a) {
     const float h2 = go * isc_tanh(c2);
     a.c_out[(long long)m * H + unit] = c2;
     a.h_out[(long long)m * H + unit] = h2;
+    RSTAMP(6);
+#undef RSTAMP_KID
 }
 
 // The segment list of one [M, K] x [N, K]^T contraction, cut at 1 << cut_shift floats.  Returns the slice count or -1.
@@ -380,14 +397,14 @@ static int rows_lstm(const float *const *A, const int *lda, const float *const *
     while (J > 1 && J * upw * MR > 64) --J;
     if (J * upw * MR > 64) upw = 1;
     a.J = J;
-    a.NH = 3;
+    a.has_src = src != nullptr;
     a.M = M; a.H = H; a.row_div = row_div > 1 ? row_div : 1; a.skip = skip;
     a.rc = rows_const();
     if (!a.rc) return ISC_E_STATE;
     a.src = src ? reinterpret_cast<const long long *>(src) : a.rc->ident;
     a.c_prev = c_prev; a.h_out = h_out; a.c_out = c_out; a.b_ih = b_ih; a.b_hh = b_hh; a.pre = pre; a.tab = tab;
     a.tab_ids = reinterpret_cast<const long long *>(tab_ids); a.tab_ids_stride = tab_ids_stride;
-    const int U = J * upw, grid = (H + U - 1) / U, threads = 64 * (a.S * J + a.NH);
+    const int U = J * upw, grid = (H + U - 1) / U, threads = 64 * (a.S * J + 1);
     const size_t lds = (size_t)nslice * MR * ROWS_SK * sizeof(float);
     if (lds > ROWS_LDS_MAX) return ISC_E_SHAPE;
     int rc;
@@ -401,11 +418,10 @@ static int rows_lstm(const float *const *A, const int *lda, const float *const *
 
 // ------------------------------------------------------------------ grouped projections of h (h2att, h2word, gate)
 // C_i[m, n] = sum_k h[m, k] W_i[n, k] + b_i[n] for up to 3 problems that share the activation rows; a workgroup
-// takes 4 * J consecutive output columns of the concatenated [N_0 + N_1 + N_2] axis (N_i % 4 == 0); S x J streaming
-// waves + NH helper waves that stage h.
+// takes 4 * J consecutive output columns of the concatenated [N_0 + N_1 + N_2] axis (N_i % 4 == 0); S x J waves.
 struct RLinArgs {
     RSegs g;                         // .W is problem 0's; problem i's = W[i] + (slice.W - W[0])
-    int S, J, NH, M, nprob, pad;
+    int S, J, M, nprob;
     const int *skip;
     const RowsConst *rc;
     const float *W[3], *bias[3];
@@ -420,16 +436,8 @@ __global__ __launch_bounds__(768) void rows_linear_kernel(const RLinArgs a) {
     __shared__ float red[8 * 4 * ROWS_MAX];                 // [S*J waves][4 rows][MR]
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int S = a.S, J = a.J, NWS = S * J, M = a.M;
+    const int S = a.S, J = a.J, M = a.M;
     if (a.skip && *a.skip == 0) return;                     // (uniform)
-    if (wave >= NWS) {                                      // helper waves: the activation image
-        rows_stage<MR>(a.g, lane & 7, M, As, a.rc, wave - NWS, a.NH, lane);
-        __syncthreads();
-        rows_stage_wait();
-        __syncthreads();
-        __syncthreads();
-        return;
-    }
     const int sw = wave % S, j = wave / S;
     const int n0 = (blockIdx.x * J + j) * 4;                // this wave's 4 output columns (concatenated axis)
     int pi = 0, nl = n0;
@@ -450,8 +458,9 @@ __global__ __launch_bounds__(768) void rows_linear_kernel(const RLinArgs a) {
     const float *Wp = pi == 0 ? a.W[0] : pi == 1 ? a.W[1] : a.W[2];
     RSlice s = rows_slice_of(a.g, si < a.g.nslice ? si : 0);
     s.W = Wp + (s.W - a.W[0]);                              // the slice's k-offset inside problem pi's weights
-    __syncthreads();                                        // the helpers' DMAs go first
+    rows_stage_own<MR>(a.g, sw, S, j, J, lane & 7, M, As, a.rc, lane);
     if (si < a.g.nslice) rows_issue<1, 4, false>(s, wrow, lane, w);
+    rows_stage_wait<4>();
     __syncthreads();
     while (si < a.g.nslice) {
         rows_fma<MR, 1, 4>(As + si * MR * ROWS_SK, w, lane, acc2);
@@ -506,8 +515,7 @@ static int rows_linear3(const float *A, int lda, int K, int M, const float *cons
     if (J < 1) J = 1;
     while (J > 1 && (Ntot / 4 + J - 1) / J < 192) --J;     // enough workgroups for the chip before fat ones
     a.J = J;
-    a.NH = 2;
-    const int grid = (Ntot / 4 + J - 1) / J, threads = 64 * (a.S * J + a.NH), MR = rows_mr(M);
+    const int grid = (Ntot / 4 + J - 1) / J, threads = 64 * a.S * J, MR = rows_mr(M);
     const size_t lds = (size_t)nslice * MR * ROWS_SK * sizeof(float);
     if (lds > ROWS_LDS_MAX) return ISC_E_SHAPE;
     switch (MR) {
@@ -529,7 +537,7 @@ static int rows_linear3(const float *A, int lda, int K, int M, const float *cons
 // the smaller id - from which isc_beam_select forms the row's top-`beam` without reading any logits.
 struct RVocabArgs {
     RSegs g;
-    int S, J, NH, M, V, TW, n_tile, pad;
+    int S, J, M, V, TW, n_tile;
     const int *skip;
     const RowsConst *rc;
     const float *bias;
@@ -553,25 +561,17 @@ __global__ __launch_bounds__(768) void rows_vocab_kernel(const RVocabArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned long long kk[ROWS_MAX][64];
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, nw = blockDim.x >> 6;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int S = a.S, J = a.J, NWS = S * J, M = a.M, TW = a.TW, V = a.V;
+    const int S = a.S, J = a.J, M = a.M, TW = a.TW, V = a.V;
     const int tile = blockIdx.x, col0 = tile * TW;
     const int tw = V - col0 < TW ? V - col0 : TW;           // valid columns of this tile
+#define RSTAMP_KID 4
     RSTAMP(0);
     RSTAMP_CLK0();
     // epilogue operands, fetched ahead of the weight stream: this lane's column bias, its row's last word
     const float bias_c = (lane < tw) ? a.bias[col0 + lane] : 0.f;
     const int lastv = (a.cons && a.last_word) ? (int)a.last_word[(lane & 7) < M ? (lane & 7) : M - 1] : -1;   // lane q: row q's
     if (a.skip && *a.skip == 0) return;                     // (uniform)
-    if (wave >= NWS) {                                      // helper waves: the activation image
-        rows_stage<MR>(a.g, lane & 7, M, As, a.rc, wave - NWS, a.NH, lane);
-        __syncthreads();
-        rows_stage_wait();
-        RSTAMP(1);
-        __syncthreads();
-        RSTAMP(2);
-        __syncthreads();
-        RSTAMP(4);
-    } else {
+    {
         const int sw = wave % S, j = wave / S;
         // pass p of wave j: columns col0 + (p*J + j)*4 + g
         long long wrow[NP];
@@ -588,11 +588,11 @@ __global__ __launch_bounds__(768) void rows_vocab_kernel(const RVocabArgs a) {
         float4 w[NP][4];
         int si = sw;
         const RSlice s0 = rows_slice_of(a.g, si < a.g.nslice ? si : 0);
-        __syncthreads();                                    // the helpers' DMAs go first
-        if (si < a.g.nslice) rows_issue<NP, 4, NT, 0, 1>(s0, wrow, lane, w);
-        __syncthreads();
+        rows_stage_own<MR>(a.g, sw, S, j, J, lane & 7, M, As, a.rc, lane);
+        if (si < a.g.nslice) rows_issue<NP, 4, NT>(s0, wrow, lane, w);
         RSTAMP(1);
-        if (NP > 1 && si < a.g.nslice) rows_issue<NP, 4, NT, 1, NP>(s0, wrow, lane, w);
+        rows_stage_wait<NP * 4>();
+        __syncthreads();
         RSTAMP(2);
         while (si < a.g.nslice) {
             rows_fma<MR, NP, 4>(As + si * MR * ROWS_SK, w, lane, acc2);
@@ -677,6 +677,7 @@ __global__ __launch_bounds__(768) void rows_vocab_kernel(const RVocabArgs a) {
     }
     RSTAMP(6);
     RSTAMP_CLK1();
+#undef RSTAMP_KID
 }
 
 extern "C" int isc_rows_stats_tile(int V) {
@@ -705,7 +706,7 @@ static int rows_vocab(const float *h, int ldh, const float *W, int ldw, const fl
     int np = (passes + J - 1) / J;
     if (16 * np < TW) np = (TW + 15) / 16;
     if (np > 4) return ISC_E_SHAPE;
-    a.J = J; a.NH = 2; a.M = M; a.V = V; a.TW = TW; a.n_tile = (V + TW - 1) / TW; a.skip = x ? x->live_in : nullptr;
+    a.J = J; a.M = M; a.V = V; a.TW = TW; a.n_tile = (V + TW - 1) / TW; a.skip = x ? x->live_in : nullptr;
     a.rc = rows_const();
     if (!a.rc) return ISC_E_STATE;
     a.bias = bias; a.pmax = pmax; a.psum = psum; a.pidx = pidx; a.logits = logits; a.ld_logits = ld_logits;
@@ -718,7 +719,7 @@ static int rows_vocab(const float *h, int ldh, const float *W, int ldw, const fl
         a.cand_val = x->cand_val; a.cand_idx = x->cand_idx;
         if (a.cons && !a.last_word) return ISC_E_NULL;
     }
-    const int threads = 64 * (a.S * J + a.NH), MR = rows_mr(M), nt = g_rows_nt.load();
+    const int threads = 64 * a.S * J, MR = rows_mr(M), nt = g_rows_nt.load();
     const size_t lds = (size_t)nslice * MR * ROWS_SK * sizeof(float);
     if (lds > ROWS_LDS_MAX) return ISC_E_SHAPE;
 #define RV_LAUNCH(MRV, NPV)                                                                                     \
@@ -774,6 +775,8 @@ __global__ __launch_bounds__(1024) void rows_scan_gate_kernel(const RScanArgs a)
     float *fin = part + 16 * 2 * A;                            // [4][A]: v, Gc-sum, s, Gs-sum
     float *redw = fin + 4 * A;                                 // [16] wave partials of the gate dot
     if (a.skip && *a.skip == 0) return;                        // (uniform)
+#define RSTAMP_KID 2
+    RSTAMP(0);
     const bool gather = half && a.ids;
     const int bi = b / a.row_div;                              // the image of this row: P / V / G / ids / q2 are per image
     const float *Pb = (half ? a.P[1] : a.P[0]), *Vb = (half ? a.V[1] : a.V[0]), *Gb = (half ? a.G[1] : a.G[0]);
@@ -825,6 +828,7 @@ __global__ __launch_bounds__(1024) void rows_scan_gate_kernel(const RScanArgs a)
         qv[i].x += q2v[i].x; qv[i].y += q2v[i].y; qv[i].z += q2v[i].z; qv[i].w += q2v[i].w;
         if (lane + 64 * i >= na4) wv4[i] = z4;
     }
+    RSTAMP(1);
     // ---- scores
     for (int r0 = wv; r0 < R; r0 += nwv * RS_RPW) {
         if (r0 != wv) {
@@ -870,7 +874,9 @@ __global__ __launch_bounds__(1024) void rows_scan_gate_kernel(const RScanArgs a)
         wg4 = reinterpret_cast<const float4 *>(a.w_g)[tid];
     }
     const float b_gate = a.b_g ? a.b_g[0] : 0.f;
+    RSTAMP(2);
     __syncthreads();
+    RSTAMP(3);
     // ---- softmax (every thread folds its half's scores: LDS broadcasts)
     float mx = -INFINITY;
     for (int r = 0; r < R; ++r) mx = fmaxf(mx, sc[r]);
@@ -918,6 +924,7 @@ __global__ __launch_bounds__(1024) void rows_scan_gate_kernel(const RScanArgs a)
             reinterpret_cast<float4 *>(part + (wave * 2 + 1) * A)[a4] = og[i];
         }
     }
+    RSTAMP(4);
     __syncthreads();
     // ---- combine the waves' partials in ascending wave order: thread group k = tid / 256 -> (half, V | G)
     {
@@ -933,6 +940,7 @@ __global__ __launch_bounds__(1024) void rows_scan_gate_kernel(const RScanArgs a)
         }
     }
     __syncthreads();
+    RSTAMP(5);
     // ---- gate
     float dot = 0.f;
     float4 sv = z4, sw = z4;
@@ -962,6 +970,8 @@ __global__ __launch_bounds__(1024) void rows_scan_gate_kernel(const RScanArgs a)
         f.z = beta * sv.z + (1.0f - beta) * sw.z; f.w = beta * sv.w + (1.0f - beta) * sw.w;
         reinterpret_cast<float4 *>(a.f + (long long)b * A)[tid] = f;
     }
+    RSTAMP(6);
+#undef RSTAMP_KID
 }
 
 static bool rows_scan_ok(const isc_step_plan *p) {
