@@ -228,9 +228,13 @@ class _Search:
     def __init__(self, cap, fc_feats, att_feats, senti_words, senti_labels, beam, decoding_constraint, T):
         p = cap._p()
         n_img = fc_feats.shape[0]
+        # few rows (one image's beam): the image's sentiment-word features as per-image tensors - the vocabulary-sized
+        # tables would put an id -> row index chain in front of every step's sentiment scan, and there is one image
+        few = (fc_feats.shape[0] * beam <= cap.ROWS_STEP_MAX and beam <= 8 and getattr(cap, 'rows_step', True)
+               and getattr(cap, 'beam_device_merge', True))
         P = cap._prologue(p, 'beam', fc_feats, att_feats, None, senti_words,
                           senti_labels if senti_words is not None else None, want_table='build',
-                          words_table=getattr(cap, 'words_table', True), gate_rows=fc_feats.shape[0] * beam)
+                          words_table=getattr(cap, 'words_table', True) and not few, gate_rows=fc_feats.shape[0] * beam)
         dev = cap._dev
         H, Wd, V = cap.att_lstm.hidden_size, cap.settings['word_emb_dim'], cap.vocab_size
         rows = n_img * beam

@@ -835,6 +835,25 @@ __global__ __launch_bounds__(512) void beam_select_kernel(const isc_beam_select_
     double my_score = 0.0;
     int my_len = 0;
     if (tid < beam) { my_last = a.last_in[base + tid]; my_score = a.score_in[base + tid]; my_len = a.len_in[base + tid]; }
+    // the image's rows of the step's output state -> LDS (behind the word lists), on its way while the merges run
+    float *st_lds = reinterpret_cast<float *>(sel_smem + (((size_t)beam * T * 8 + 15) & ~(size_t)15));
+    if (a.state_out) {                       // LDS image [plane][row][H]; wave w takes (plane, row) pairs w, w + nw, ...
+        const int rows_all = a.n_img * beam, npair = a.state_planes * beam, nw = (int)blockDim.x >> 6;
+        const unsigned lds0 = (unsigned)(size_t)st_lds;
+        for (int pr = wave; pr < npair; pr += nw) {
+            const int pl = pr / beam, r = pr - pl * beam;    // (wave-uniform)
+            const float *srow = a.state_in + ((long long)pl * rows_all + base + r) * a.H;
+            if ((a.H & 255) == 0) {
+                for (int c0 = 0; c0 < a.H; c0 += 256) {     // one 1 KB LDS-DMA per 256 floats
+                    const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(pr * a.H + c0) * 4u);
+                    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(dst), "v"(srow + c0 + lane * 4) : "memory");
+                }
+            } else {                                        // small / odd widths: through registers
+                for (int c = lane * 4; c < a.H; c += 256)
+                    *reinterpret_cast<float4 *>(st_lds + pr * a.H + c) = *reinterpret_cast<const float4 *>(srow + c);
+            }
+        }
+    }
     long long wv[4];                         // element e of the image's [beam][T] block of word lists
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -856,11 +875,14 @@ __global__ __launch_bounds__(512) void beam_select_kernel(const isc_beam_select_
             if (e < beam * T) a.words_out[(long long)base * T + e] = wv[q];
         }
         if (a.state_out) {
-            const int h4 = a.H >> 2, rows_all = a.n_img * beam;
-            for (int e = tid; e < a.state_planes * beam * h4; e += blockDim.x) {
-                const int c4 = e % h4, r = (e / h4) % beam, pl = e / (h4 * beam);
-                const long long o = ((long long)pl * rows_all + base + r) * h4 + c4;
-                reinterpret_cast<float4 *>(a.state_out)[o] = reinterpret_cast<const float4 *>(a.state_in)[o];
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            const int rows_all = a.n_img * beam, npair = a.state_planes * beam, nw = (int)blockDim.x >> 6;
+            for (int pr = wave; pr < npair; pr += nw) {
+                const int pl = pr / beam, r = pr - pl * beam;
+                for (int c = lane * 4; c < a.H; c += 256)
+                    *reinterpret_cast<float4 *>(a.state_out + ((long long)pl * rows_all + base + r) * a.H + c) =
+                        *reinterpret_cast<const float4 *>(st_lds + pr * a.H + c);
             }
         }
         return;
@@ -924,6 +946,7 @@ __global__ __launch_bounds__(512) void beam_select_kernel(const isc_beam_select_
     }
     RSTAMP(4);
     RSTAMP_CLK1();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's share of the state image has landed
     __syncthreads();
     // ---- the image's candidates (captioner.py:378-411; beam_merge_kernel's bookkeeping), every thread from LDS
     const int ncand = a.t == 0 ? 1 : beam;
@@ -995,14 +1018,15 @@ __global__ __launch_bounds__(512) void beam_select_kernel(const isc_beam_select_
         __syncthreads();
         // the recurrent state follows the candidates: new row r continues its parent's (the step's output planes -> the
         // next step's input planes; loads first, they are the long pole of this tail)
-        if (a.state_out) {
-            const int h4 = a.H >> 2, rows_all = a.n_img * beam, nrow = n < beam ? n : beam;
-            const int total = a.state_planes * nrow * h4;
-#pragma unroll 4
-            for (int e = tid; e < total; e += (int)blockDim.x) {
-                const int c4 = e % h4, r = (e / h4) % nrow, pl = e / (h4 * nrow);
-                const float4 v = reinterpret_cast<const float4 *>(a.state_in)[((long long)pl * rows_all + base + w_par[r]) * h4 + c4];
-                reinterpret_cast<float4 *>(a.state_out)[((long long)pl * rows_all + base + r) * h4 + c4] = v;
+        if (a.state_out) {                                   // (every wave waited for its DMAs before the barriers above)
+            const int rows_all = a.n_img * beam, nrow = n < beam ? n : beam, npair = a.state_planes * nrow;
+            const int nw = (int)blockDim.x >> 6;
+            for (int pr = wave; pr < npair; pr += nw) {
+                const int pl = pr / nrow, r = pr - pl * nrow;        // (wave-uniform)
+                const float *srow = st_lds + (pl * beam + w_par[r]) * a.H;
+                for (int c = lane * 4; c < a.H; c += 256)
+                    *reinterpret_cast<float4 *>(a.state_out + ((long long)pl * rows_all + base + r) * a.H + c) =
+                        *reinterpret_cast<const float4 *>(srow + c);
             }
         }
         const int nfill = n < beam ? n : beam;               // (t == 0: one live parent still yields `beam` rows)
@@ -1030,13 +1054,14 @@ extern "C" int isc_beam_select(const isc_beam_select_args *args, void *stream) {
         return ISC_E_SHAPE;
     if (a.n_tile < 1 || a.n_tile > 64 * ISC_SEL_TILES_PER_LANE) return ISC_E_SHAPE;
     if (!isc_aligned16(a.cand_val) || !isc_aligned16(a.cand_idx)) return ISC_E_ALIGN;
-    const size_t lds = (size_t)a.beam * a.T * 8;                                 // the parents' word lists
+    size_t lds = (((size_t)a.beam * a.T * 8 + 15) & ~(size_t)15);                // the parents' word lists
+    if (a.state_out) lds += (size_t)a.state_planes * a.beam * a.H * 4 + 1024;    // + the image's rows of the state (whole 1 KB pieces)
+    if (lds > 150000) return ISC_E_SHAPE;
     if (a.T > 256) return ISC_E_SHAPE;
     static std::atomic<bool> attr_set{false};
     if (!attr_set.load()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&beam_select_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           ISC_BEAM_MAX * 64 * ISC_SEL_TILES_PER_LANE * 64);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 150000);
         if (e != hipSuccess) return (int)e;
         attr_set.store(true);
     }

@@ -305,8 +305,12 @@ __global__ __launch_bounds__(768) void rows_lstm_kernel(const RLstmArgs a) {
     float gt[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        float v = red[(((j * S) * UPW + i) * 4 + k) * MR + m];
-        for (int sw = 1; sw < S; ++sw) v += red[(((j * S + sw) * UPW + i) * 4 + k) * MR + m];
+        float pr[8];                                        // the slices' partials, read together (S <= 8)
+#pragma unroll
+        for (int sw = 0; sw < 8; ++sw) pr[sw] = red[(((j * S + (sw < S ? sw : 0)) * UPW + i) * 4 + k) * MR + m];
+        float v = pr[0];
+#pragma unroll
+        for (int sw = 1; sw < 8; ++sw) v += sw < S ? pr[sw] : 0.f;
         // g += (b_ih + b_hh);  g += pre;  g += table row   (the order of lstm_cells, gemm_f32.hip)
         if (a.b_ih) v += b[k];
         if (a.pre) v += q[k];
@@ -877,11 +881,23 @@ __global__ __launch_bounds__(1024) void rows_scan_gate_kernel(const RScanArgs a)
     RSTAMP(2);
     __syncthreads();
     RSTAMP(3);
-    // ---- softmax (every thread folds its half's scores: LDS broadcasts)
+    // ---- softmax statistics of this half's scores: lane r holds score r (64 at a time), wave max / sum by lane exchanges
+    // (a per-thread loop over the R scores in LDS was 2 R dependent LDS reads: 3 us of an 11 us kernel at R = 36)
     float mx = -INFINITY;
-    for (int r = 0; r < R; ++r) mx = fmaxf(mx, sc[r]);
+    for (int r0 = 0; r0 < R; r0 += 64) {
+        float v = r0 + lane < R ? sc[r0 + lane] : -INFINITY;
+        v = fmaxf(v, isc_dpp<ISC_DPP_XOR1>(v)); v = fmaxf(v, isc_dpp<ISC_DPP_XOR2>(v));
+        v = fmaxf(v, isc_dpp<ISC_DPP_HALF_MIRROR>(v)); v = fmaxf(v, isc_dpp<ISC_DPP_MIRROR>(v));
+        v = fmaxf(v, isc_swz16(v));
+        v = fmaxf(v, __shfl_xor(v, 32, 64));
+        mx = fmaxf(mx, v);
+    }
     float zs = 0.f;
-    for (int r = 0; r < R; ++r) zs += __expf(sc[r] - mx);
+    for (int r0 = 0; r0 < R; r0 += 64) {
+        float e = r0 + lane < R ? __expf(sc[r0 + lane] - mx) : 0.f;
+        e = half_sum(e);
+        zs += e + __shfl_xor(e, 32, 64);
+    }
     const float inv = 1.0f / zs;
     // ---- weighted sums of this wave's rows (ascending region order within the wave)
     float4 o[2] = {z4, z4}, og[2] = {z4, z4};
@@ -926,15 +942,27 @@ __global__ __launch_bounds__(1024) void rows_scan_gate_kernel(const RScanArgs a)
     }
     RSTAMP(4);
     __syncthreads();
-    // ---- combine the waves' partials in ascending wave order: thread group k = tid / 256 -> (half, V | G)
+    // ---- combine the waves' partials in ascending wave order: thread group k = tid / 256 -> (half, V | G); all of a
+    // thread's partials are read together
     {
         const int k = tid >> 8, t = tid & 255;                 // k: 0 = v, 1 = sum Gc, 2 = s, 3 = sum Gs
-        const int hf = k >> 1, vg = k & 1, w0 = hf ? RS_NWC : 0, w1 = hf ? 16 : RS_NWC;
+        const int hf = k >> 1, vg = k & 1;
         if (t < na4) {
-            float4 s4 = reinterpret_cast<const float4 *>(part + (w0 * 2 + vg) * A)[t];
-            for (int w = w0 + 1; w < w1; ++w) {
-                const float4 x = reinterpret_cast<const float4 *>(part + (w * 2 + vg) * A)[t];
-                s4.x += x.x; s4.y += x.y; s4.z += x.z; s4.w += x.w;
+            float4 s4;
+            if (hf == 0) {
+                float4 x[RS_NWC];
+#pragma unroll
+                for (int w = 0; w < RS_NWC; ++w) x[w] = reinterpret_cast<const float4 *>(part + (w * 2 + vg) * A)[t];
+                s4 = x[0];
+#pragma unroll
+                for (int w = 1; w < RS_NWC; ++w) { s4.x += x[w].x; s4.y += x[w].y; s4.z += x[w].z; s4.w += x[w].w; }
+            } else {
+                float4 x[RS_NWS];
+#pragma unroll
+                for (int w = 0; w < RS_NWS; ++w) x[w] = reinterpret_cast<const float4 *>(part + ((RS_NWC + w) * 2 + vg) * A)[t];
+                s4 = x[0];
+#pragma unroll
+                for (int w = 1; w < RS_NWS; ++w) { s4.x += x[w].x; s4.y += x[w].y; s4.z += x[w].z; s4.w += x[w].w; }
             }
             reinterpret_cast<float4 *>(fin + k * A)[t] = s4;
         }
