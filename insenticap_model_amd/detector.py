@@ -224,10 +224,17 @@ class Detector(nn.Module):
         # on every rank, so globally summed statistics divide by the same number everywhere
         return {k: float(v) / len(data) for k, v in sums.items()}
 
+    def invalidate_image_sentiments(self):
+        """Forget the cached image-sentiment labels.  The cache is keyed by file name (+ the feature geometry, the
+        threshold and the detector's weights): call this when the FEATURES behind a file name change - a second dataset
+        that reuses names, features edited in place - or construct with cache_image_sentiments = False."""
+        self._senti_cache, self._senti_cache_key = {}, None
+
     def _image_sentiments(self, fns, att_feats):
         if not self.cache_image_sentiments:
             return self.senti_detector.sample(att_feats, self.senti_threshold)[0].detach()
-        key = (self.senti_threshold,) + tuple((q.data_ptr(), q._version) for q in self.senti_detector.parameters())
+        key = (self.senti_threshold, tuple(att_feats.shape[1:]), att_feats.dtype) + \
+            tuple((q.data_ptr(), q._version) for q in self.senti_detector.parameters())
         if key != self._senti_cache_key:                 # weights reloaded / threshold changed
             self._senti_cache, self._senti_cache_key = {}, key
         cache = self._senti_cache

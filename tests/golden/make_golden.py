@@ -718,6 +718,173 @@ def case_det512():
     print('det512: %d arrays' % len(out))
 
 
+def _ref_detector(V, Tn, st, lr, weight_seed):
+    """The reference Detector with the build's deterministic weights (captioner + both helper nets)."""
+    from models.decoder import Detector
+    det = Detector(synth.make_idx2word(V), Tn, synth.SENTIMENT_CATEGORIES, {'cap_lr': lr}, st)
+    det.captioner.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_weights(V, st, seed=weight_seed).items()})
+    for name, mod, seed in (('senti_detector', det.senti_detector, 51), ('sent_senti_cls', det.sent_senti_cls, 52)):
+        shapes = {k: tuple(v.shape) for k, v in mod.state_dict().items()}
+        mod.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_module_weights(shapes, seed).items()})
+    return det
+
+
+class _CallSpy:
+    """Wraps forward_rl / forward_xe / forward_seq2seq of a reference captioner: index ranges of the multinomial draws
+    of every sampled roll-out and of the tokens every teacher-forced unroll fed."""
+
+    def __init__(self, cap):
+        self.cap, self.ms, self.spy = cap, MultinomialSpy(), StepSpy(cap)
+        self.rl, self.xe, self.s2s = [], [], []
+        self.orig = (cap.forward_rl, cap.forward_xe, cap.forward_seq2seq)
+        o_rl, o_xe, o_s2s = self.orig
+
+        def spy_rl(*a, **k):
+            n0 = len(self.ms.draws)
+            r = o_rl(*a, **k)
+            if not k.get('sample_max', a[-1] if len(a) >= 7 else 1):
+                self.rl.append((n0, len(self.ms.draws)))
+            return r
+
+        def spy_xe(*a, **k):
+            n0 = len(self.spy.fed)
+            r = o_xe(*a, **k)
+            self.xe.append((n0, len(self.spy.fed)))
+            return r
+
+        def spy_s2s(*a, **k):
+            n0 = len(self.spy.fed)
+            r = o_s2s(*a, **k)
+            self.s2s.append((n0, len(self.spy.fed)))
+            return r
+        cap.forward_rl, cap.forward_xe, cap.forward_seq2seq = spy_rl, spy_xe, spy_s2s
+
+    def close(self):
+        self.ms.close()
+        self.spy.close()
+        self.cap.forward_rl, self.cap.forward_xe, self.cap.forward_seq2seq = self.orig
+
+    def draws(self, i, Tn):
+        a, b = self.rl[i]
+        dr = torch.stack(self.ms.draws[a:b], dim=1).numpy()
+        return np.pad(dr, ((0, 0), (0, Tn - dr.shape[1]))), dr.shape[1]
+
+    def fed(self, bounds, i):
+        a, b = bounds[i]
+        return torch.stack(self.spy.fed[a:b], dim=1).numpy()
+
+
+def _senti_items(batches, seed):
+    """rl_senti collate layout (dataloader.py:93-109): (fns, fc, att, cpts, sentis, senti_labels)."""
+    rng = np.random.default_rng(seed)
+    items = []
+    for b in batches:
+        labels = rng.integers(0, len(synth.SENTIMENT_CATEGORIES), size=len(b[0])).astype(np.int64)
+        items.append((b[0], torch.from_numpy(b[1]), torch.from_numpy(b[2]), torch.from_numpy(b[4]), torch.from_numpy(b[5]),
+                      torch.from_numpy(labels)))
+    return items
+
+
+def case_det_senti():
+    """Detector.forward((senti_loader, scs_loader), 'senti', training) (train_rl.py:232-235; models/decoder.py:69-71,
+    100-101: sentiment labels from the batch when training, from the image detector otherwise; no CIDEr reward, no XE
+    term) on tiny dims with dropout_p = 0: two training iterations (draws of the sampled roll-outs and the tokens the
+    seq2seq unroll fed under scheduled sampling recorded; loss dictionary, iteration 2's clamped gradient, every parameter
+    after the two steps) and the same two batches with training = False on fresh weights."""
+    V, Tn, B = 64, 8, 4
+    st = dict(synth.TINY_SETTINGS, **synth.HELPER_SETTINGS)
+    st['dropout_p'] = 0.0
+    batches, _ = synth.make_rl_batches(2, B, V, st, seq_len=Tn, seed=90)
+    s = synth.make_inputs(3, V, st, regions=6, seq_len=Tn, seed=78)
+    t = torch.from_numpy
+    scs = [((t(s['captions']), s['lengths']), t(s['cpt_words']), t(s['senti_words']), t(s['senti_labels']))]
+    out = {}
+    for b_i, it in enumerate(_senti_items(batches, 91)):
+        out['ds/labels%d' % b_i] = it[5].numpy()
+    # training
+    det = _ref_detector(V, Tn, st, 4e-4, 1)
+    cs = _CallSpy(det.captioner)
+    torch.manual_seed(777)
+    losses = det((_senti_items(batches, 91), scs), 'senti', True)
+    cs.close()
+    assert len(cs.rl) == 2 and len(cs.s2s) == 2 and len(cs.xe) == 0, (cs.rl, cs.xe, cs.s2s)
+    for i in range(2):
+        out['ds/draws%d' % i], steps = cs.draws(i, Tn)
+        out['ds/steps%d' % i] = np.array([steps])
+        out['ds/fed_s2s%d' % i] = cs.fed(cs.s2s, i)
+    assert set(losses) == {'da_loss', 'cls_reward', 'all_rewards', 'cap_loss', 'seq2seq_loss'}, set(losses)
+    for k, v in losses.items():
+        out['ds/loss_' + k] = np.array([v], dtype=np.float64)
+    for k, v in det.captioner.state_dict().items():
+        out['ds/after/' + k] = v.detach().numpy().copy()
+    for k, q in det.captioner.named_parameters():
+        if q.grad is not None:
+            out['ds/grad2/' + k] = q.grad.detach().numpy().copy()
+    print('senti, training:', {k: round(v, 5) for k, v in losses.items()})
+    # evaluation (labels from the image detector)
+    det = _ref_detector(V, Tn, st, 4e-4, 1)
+    cs = _CallSpy(det.captioner)
+    torch.manual_seed(778)
+    losses = det((_senti_items(batches, 91),), 'senti', False)
+    cs.close()
+    assert len(cs.rl) == 2 and not cs.xe and not cs.s2s
+    for i in range(2):
+        out['dse/draws%d' % i], steps = cs.draws(i, Tn)
+        out['dse/steps%d' % i] = np.array([steps])
+    assert set(losses) == {'da_loss', 'cls_reward', 'all_rewards', 'cap_loss'}, set(losses)
+    for k, v in losses.items():
+        out['dse/loss_' + k] = np.array([v], dtype=np.float64)
+    print('senti, eval:', {k: round(v, 5) for k, v in losses.items()})
+    np.savez_compressed(os.path.join(HERE, 'det_senti.npz'), **out)
+    print('det_senti: %d arrays' % len(out))
+
+
+def case_det512_train():
+    """BASELINE.json configs[4] at full size, TRAINING: ONE iteration of Detector.forward(data, 'fact', True)
+    (models/decoder.py:52-180 incl. the update at :161-167) with B = 512, V = 10k, T = 20, a 6 x 6 x 2048 grid, an
+    80-caption seq2seq batch, dropout_p = 0, lr 4e-5 (opts.py:41-42).  Recorded for replay: the multinomial draws of
+    the sampled roll-out, the tokens the XE (ss_prob 0.5) and seq2seq (ss_prob 0.25) unrolls fed.  Stored: the 7-key
+    loss dictionary, a digest (sum, abs-sum, l2, 64 strided samples) of every clamped gradient and of every parameter
+    after the step."""
+    V, Tn, B, Bs = 10000, 20, 512, 80
+    st = dict(synth.DEFAULT_SETTINGS, **synth.HELPER_SETTINGS)
+    st['dropout_p'] = 0.0
+    det = _ref_detector(V, Tn, st, 4e-5, 0)
+    batches, split = synth.make_rl_batches(1, B, V, st, grid=(6, 6), seq_len=Tn, seed=60)
+    det.set_ciderd_scorer(split)
+    b = batches[0]
+    item = (b[0], torch.from_numpy(b[1]), torch.from_numpy(b[2]), (torch.from_numpy(b[3][0]), b[3][1]),
+            torch.from_numpy(b[4]), torch.from_numpy(b[5]), b[6])
+    s = synth.make_inputs(Bs, V, st, regions=6, seq_len=Tn, seed=79)
+    t = torch.from_numpy
+    scs = [((t(s['captions']), s['lengths']), t(s['cpt_words']), t(s['senti_words']), t(s['senti_labels']))]
+    cs = _CallSpy(det.captioner)
+    torch.manual_seed(5150)
+    import time
+    t0 = time.time()
+    losses = det(([item], scs), 'fact', True)
+    print('reference iteration: %.1f s' % (time.time() - t0))
+    cs.close()
+    assert len(cs.rl) == 1 and len(cs.xe) == 1 and len(cs.s2s) == 1
+    out = {}
+    out['d5t/draws'], steps = cs.draws(0, Tn)
+    out['d5t/steps'] = np.array([steps])
+    out['d5t/fed_xe'] = cs.fed(cs.xe, 0)
+    out['d5t/fed_s2s'] = cs.fed(cs.s2s, 0)
+    assert set(losses) == {'da_loss', 'fact_reward', 'cls_reward', 'all_rewards', 'cap_loss', 'xe_loss', 'seq2seq_loss'}
+    for k, v in losses.items():
+        out['d5t/loss_' + k] = np.array([v], dtype=np.float64)
+    for k, q in det.captioner.named_parameters():
+        if q.grad is not None:
+            out['d5t/grad/' + k] = grad_digest(q.grad.detach().numpy())
+            out['d5t/gmax/' + k] = np.array([float(q.grad.detach().abs().max())])
+    for k, v in det.captioner.state_dict().items():
+        out['d5t/after/' + k] = grad_digest(v.detach().numpy())
+    print({k: round(v, 5) for k, v in losses.items()})
+    np.savez_compressed(os.path.join(HERE, 'det512_train.npz'), **out)
+    print('det512_train: %d arrays' % len(out))
+
+
 def case_collate():
     """The four collate functions the decoder path consumes (dataloader.py:11-109: caption, scs, rl_fact, rl_senti).
     `dataloader.py` imports h5py at module level, which this image does not have; only its Dataset classes
@@ -790,7 +957,8 @@ def case_collate():
 
 CASES = {'tiny': case_tiny, 'cfg1': case_cfg1, 'b128': case_b128, 'cider': case_cider, 'detector': case_detector,
          'checkpoint': case_checkpoint, 'beam64': case_beam64, 'det512': case_det512,
-         'collate': case_collate, 'det_train': case_det_train}
+         'collate': case_collate, 'det_train': case_det_train, 'det_senti': case_det_senti,
+         'det512_train': case_det512_train}
 
 if __name__ == '__main__':
     which = sys.argv[1:] or list(CASES)

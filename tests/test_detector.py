@@ -204,3 +204,95 @@ def test_detector_training_iterations_match_the_reference(golden):
         gkey = 'dt/grad2/' + k
         if gkey in g.files and np.abs(g[gkey]).max() > 1e-6:       # (the alpha biases' true gradient is 0: pure noise)
             assert np.median(diff) <= 2e-6, (k, float(np.median(diff)))
+
+
+def _senti_items(batches, seed):
+    """rl_senti collate layout (dataloader.py:93-109): (fns, fc, att, cpts, sentis, senti_labels) - as the generator."""
+    rng = np.random.default_rng(seed)
+    t = torch.from_numpy
+    items = []
+    for b in batches:
+        labels = rng.integers(0, len(synth.SENTIMENT_CATEGORIES), size=len(b[0])).astype(np.int64)
+        items.append((b[0], t(b[1]), t(b[2]), t(b[4]), t(b[5]), t(labels)))
+    return items
+
+
+@pytest.mark.gpu
+def test_detector_senti_branch_matches_the_reference(golden):
+    """Detector.forward((senti_loader, scs_loader), 'senti', training) - train_rl.py:232-235; models/decoder.py:69-71,
+    100-101: the sentiment labels come from the batch when training (from the image detector otherwise), there is no
+    CIDEr reward (`fact_reward = 0`) and no XE term.  Against the reference's own run (tests/golden/det_senti.npz,
+    dropout_p = 0, draws and fed tokens replayed): training - the 5-key dictionary, iteration 2's clamped gradient, every
+    parameter after the two steps; evaluation - the 4-key dictionary."""
+    from insenticap_model_amd.detector import Detector
+    g = golden('det_senti')
+    dev = torch.device('cuda:0')
+    st = dict(ST, dropout_p=0.0)
+    batches, _ = synth.make_rl_batches(2, B, V, st, seq_len=TN, seed=90)
+    s = synth.make_inputs(3, V, st, regions=6, seq_len=TN, seed=78)
+    t = torch.from_numpy
+    scs = [((t(s['captions']), s['lengths']), t(s['cpt_words']), t(s['senti_words']), t(s['senti_labels']))]
+    for i, it in enumerate(_senti_items(batches, 91)):
+        assert (it[5].numpy() == g['ds/labels%d' % i]).all()
+
+    def make():
+        det = Detector(synth.make_idx2word(V), TN, synth.SENTIMENT_CATEGORIES, {'cap_lr': 4e-4}, st)
+        det.captioner.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_weights(V, st, seed=1).items()})
+        load_helper(det.senti_detector, 51)
+        load_helper(det.sent_senti_cls, 52)
+        return det.to(dev)
+
+    def hook(det, prefix, n):
+        cap = det.captioner
+        o_rl, o_s2s = cap.forward_rl, cap.forward_seq2seq
+
+        def replay_rl(*a, **k):
+            if not k.get('sample_max', a[-1] if len(a) >= 7 else 1):
+                k['_replay'] = torch.from_numpy(g['%s/draws%d' % (prefix, n['rl'])]).to(dev)
+                n['rl'] += 1
+            return o_rl(*a, **k)
+
+        def replay_s2s(caps, cpts, sentis, labels, ss_prob=0.0, **k):
+            assert ss_prob == 0.25
+            fed = torch.from_numpy(g['%s/fed_s2s%d' % (prefix, n['s2s'])]).to(dev)
+            n['s2s'] += 1
+            return o_s2s(torch.cat([fed, fed[:, -1:]], dim=1), cpts, sentis, labels, 0.0, **k)
+
+        def no_xe(*a, **k):
+            raise AssertionError("the 'senti' branch has no XE unroll (models/decoder.py:131)")
+        cap.forward_rl, cap.forward_seq2seq, cap.forward_xe = replay_rl, replay_s2s, no_xe
+    # ---- training
+    det = make()
+    n = {'rl': 0, 's2s': 0}
+    hook(det, 'ds', n)
+    losses = det((_senti_items(batches, 91), scs), 'senti', True)
+    assert n == {'rl': 2, 's2s': 2}
+    assert set(losses) == {'da_loss', 'cls_reward', 'all_rewards', 'cap_loss', 'seq2seq_loss'}
+    for k, v in losses.items():
+        np.testing.assert_allclose(v, g['ds/loss_' + k][0], rtol=2e-4, atol=2e-5, err_msg=k)
+    checked = 0
+    for k, q in det.captioner.named_parameters():
+        key = 'ds/grad2/' + k
+        if key in g.files:
+            ref = g[key]
+            np.testing.assert_allclose(q.grad.cpu().numpy(), ref, atol=1e-4 * np.abs(ref).max() + 1e-7, err_msg=k)
+            checked += 1
+    assert checked >= 30
+    for k, q in det.captioner.state_dict().items():
+        diff = np.abs(q.cpu().numpy() - g['ds/after/' + k])
+        assert diff.max() <= 2 * 2 * 4e-4 * 1.01, k            # (two Adam steps of lr; see the 'fact' test)
+        gkey = 'ds/grad2/' + k
+        if gkey in g.files and np.abs(g[gkey]).max() > 1e-6:
+            assert np.median(diff) <= 2e-6, (k, float(np.median(diff)))
+    # ---- evaluation: labels from the image sentiment detector, no seq2seq pass, nothing trained
+    det = make()
+    before = {k: v.detach().clone() for k, v in det.captioner.state_dict().items()}
+    n = {'rl': 0, 's2s': 0}
+    hook(det, 'dse', n)
+    losses = det((_senti_items(batches, 91),), 'senti', False)
+    assert n == {'rl': 2, 's2s': 0}
+    assert set(losses) == {'da_loss', 'cls_reward', 'all_rewards', 'cap_loss'}
+    for k, v in losses.items():
+        np.testing.assert_allclose(v, g['dse/loss_' + k][0], rtol=2e-4, atol=2e-5, err_msg=k)
+    for k, v in det.captioner.state_dict().items():
+        assert torch.equal(v, before[k])

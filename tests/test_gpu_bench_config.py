@@ -175,3 +175,86 @@ def test_detector_forward_b512_fullsize_vs_the_reference(golden):
     slack = flipped * 10.0 / B
     for k in ('fact_reward', 'all_rewards', 'cap_loss'):
         np.testing.assert_allclose(losses[k], g['det/loss_' + k][0], rtol=2e-4, atol=2e-5 + slack, err_msg=k)
+
+
+def test_config4_rl_training_iteration_at_full_size_vs_reference(golden):
+    """BASELINE config 4's TRAINING iteration at full size: ONE Detector.forward(data, 'fact', True) with B = 512,
+    V = 10k, T = 20, 6x6x2048 grid, an 80-caption seq2seq batch, dropout 0 (models/decoder.py:52-180 incl. the update at
+    :161-167) against the reference's own run (tests/golden/det512_train.npz: the sampled roll-out's multinomial draws
+    and the tokens the XE / seq2seq unrolls fed under scheduled sampling replayed): the 7-key dictionary, a digest of
+    every clamped gradient (sums, l2, 64 strided samples) and of every parameter after the step."""
+    from insenticap_model_amd.detector import Detector
+    from test_detector import load_helper
+    g = golden('det512_train')
+    V, Tn, B, Bs = 10000, 20, 512, 80
+    st = dict(synth.DEFAULT_SETTINGS, **synth.HELPER_SETTINGS)
+    st['dropout_p'] = 0.0
+    det = Detector(synth.make_idx2word(V), Tn, synth.SENTIMENT_CATEGORIES, {'cap_lr': 4e-5}, st)
+    det.captioner.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_weights(V, st, seed=0).items()})
+    load_helper(det.senti_detector, 51)
+    load_helper(det.sent_senti_cls, 52)
+    det.to(dev())
+    batches, split = synth.make_rl_batches(1, B, V, st, grid=(6, 6), seq_len=Tn, seed=60)
+    det.set_ciderd_scorer(split)
+    b = batches[0]
+    t = torch.from_numpy
+    item = (b[0], t(b[1]), t(b[2]), (t(b[3][0]), b[3][1]), t(b[4]), t(b[5]), b[6])
+    s = synth.make_inputs(Bs, V, st, regions=6, seq_len=Tn, seed=79)
+    scs = [((t(s['captions']), s['lengths']), t(s['cpt_words']), t(s['senti_words']), t(s['senti_labels']))]
+    cap = det.captioner
+    o_rl, o_xe, o_s2s = cap.forward_rl, cap.forward_xe, cap.forward_seq2seq
+    n = {'rl': 0, 'xe': 0, 's2s': 0}
+
+    def fed_as_captions(key):
+        fed = torch.from_numpy(g[key]).to(dev())
+        return torch.cat([fed, fed[:, -1:]], dim=1)
+
+    def replay_rl(*a, **k):
+        if not k.get('sample_max', a[-1] if len(a) >= 7 else 1):
+            k['_replay'] = torch.from_numpy(g['d5t/draws']).to(dev())
+            n['rl'] += 1
+        return o_rl(*a, **k)
+
+    def replay_xe(fc, att, cpts, caps, labels, ss_prob=0.0, **k):
+        assert ss_prob == 0.5
+        n['xe'] += 1
+        return o_xe(fc, att, cpts, fed_as_captions('d5t/fed_xe'), labels, 0.0, **k)
+
+    def replay_s2s(caps, cpts, sentis, labels, ss_prob=0.0, **k):
+        assert ss_prob == 0.25
+        n['s2s'] += 1
+        return o_s2s(fed_as_captions('d5t/fed_s2s'), cpts, sentis, labels, 0.0, **k)
+    cap.forward_rl, cap.forward_xe, cap.forward_seq2seq = replay_rl, replay_xe, replay_s2s
+    losses = det(([item], scs), 'fact', True)
+    assert n == {'rl': 1, 'xe': 1, 's2s': 1}
+    assert set(losses) == {'da_loss', 'fact_reward', 'cls_reward', 'all_rewards', 'cap_loss', 'xe_loss', 'seq2seq_loss'}
+    # the greedy baseline may flip a near-tie in a few of the 512 rows: CIDEr-D's range over the batch mean per such row
+    for k in ('da_loss', 'xe_loss', 'seq2seq_loss'):
+        np.testing.assert_allclose(losses[k], g['d5t/loss_' + k][0], rtol=2e-4, atol=2e-6, err_msg=k)
+    slack = 3 * 10.0 / B
+    for k in ('cls_reward', 'fact_reward', 'all_rewards', 'cap_loss'):
+        np.testing.assert_allclose(losses[k], g['d5t/loss_' + k][0], rtol=2e-4, atol=2e-5 + slack, err_msg=k)
+
+    def digest(x):
+        flat = x.reshape(-1).astype(np.float64)
+        idx = (np.arange(64, dtype=np.int64) * 2654435761 % flat.size)
+        return np.concatenate([[flat.sum(), np.abs(flat).sum(), np.sqrt((flat ** 2).sum())], flat[idx]])
+    checked = 0
+    for k, q in cap.named_parameters():
+        key = 'd5t/grad/' + k
+        if key not in g.files:
+            continue
+        ref, gmax = g[key], float(g['d5t/gmax/' + k][0])
+        got = digest(q.grad.cpu().numpy())
+        # the REINFORCE term carries the reward: a flipped greedy row shifts its sample's gradient contribution, so the
+        # bound is the SURVEY 8(d) one (1e-4 of the tensor's largest gradient) plus that share
+        tol = (1e-4 + slack / 10.0) * gmax + 1e-8
+        np.testing.assert_allclose(got[3:], ref[3:], atol=tol, err_msg=k)                 # 64 samples
+        assert abs(got[2] - ref[2]) <= 2e-3 * ref[2] + 1e-8, (k, got[2], ref[2])          # l2 norm
+        checked += 1
+    assert checked >= 38
+    for k, q in cap.state_dict().items():
+        ref = g['d5t/after/' + k]
+        got = digest(q.cpu().numpy())
+        assert np.abs(got[3:] - ref[3:]).max() <= 2 * 4e-5 * 1.01, k      # nothing further than a full Adam step (lr 4e-5)
+        assert np.median(np.abs(got[3:] - ref[3:])) <= 2e-6, k

@@ -408,7 +408,8 @@ def test_beam_device_merge_equals_host_merge():
     n, Tn = 48, 20
     d = synth.make_inputs(n, c['V'], st, regions=36, seq_len=Tn, seed=2024)
     fc, att, sw, lab = T(d, 'fc_feats'), T(d, 'att_feats'), T(d, 'senti_words'), T(d, 'senti_labels')
-    try:
+    cap.rows_step = False        # same decode kernels on both sides: this test is about the merge (the few-row kernels
+    try:                         # and their one-launch select are compared with this path in tests/test_gpu_rows.py)
         for sl, beam in ((slice(0, n), 5), (slice(0, 2), 3), (slice(5, 6), 5), (slice(0, 16), 8)):
             cap.beam_device_merge = True
             dev_out = cap.sample_batch(fc[sl], att[sl], sw[sl], lab[sl], beam, 1, Tn)
@@ -421,6 +422,7 @@ def test_beam_device_merge_equals_host_merge():
             assert steps_dev == cap.last_beam_steps
     finally:
         cap.beam_device_merge = True
+        cap.rows_step = True
 
 
 def test_beam_search_from_hip_graphs_equals_the_eager_search():

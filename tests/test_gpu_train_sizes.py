@@ -88,7 +88,21 @@ def _hip_iteration(w, V, st, d, s2s):
     return (float(xe.detach()), float(da.detach()), float(l2.detach())), grads, params
 
 
-def _compare(hip, ora, n_expected=32, ora64=None):
+def _relu_sign_flips(w, d):
+    """How many pre-activations of the two prologue ReLUs over the regions (att_embed: captioner.py:141-143, att2att:
+    :149-150) fall on different sides of zero in fp32 and in fp64 arithmetic (CPU, the oracle's operations)."""
+    att = torch.from_numpy(np.asarray(d['att_feats'])).reshape(-1, w['att_embed.0.weight'].shape[1])
+    counts, x32, x64 = {}, att.float(), att.double()
+    for name in ('att_embed', 'att2att'):
+        W, b = torch.from_numpy(w[name + '.0.weight']), torch.from_numpy(w[name + '.0.bias'])
+        p32 = x32 @ W.float().t() + b.float()
+        p64 = x64 @ W.double().t() + b.double()
+        counts[name] = int(((p32 > 0) != (p64 > 0)).sum())
+        x32, x64 = torch.relu(p32), torch.relu(p64)
+    return counts
+
+
+def _compare(hip, ora, n_expected=32, ora64=None, widen=True):
     """Gradients within 1e-4 of the tensor's max.  With `ora64` (the fp64 oracle) the comparison is
     against IT, and a tensor on which the reference's own fp32 arithmetic is further than 1e-4/3 from the fp64 result
     gets three times that error as its bound: the HIP path must be as close to the exact gradient as the fp32
@@ -104,7 +118,7 @@ def _compare(hip, ora, n_expected=32, ora64=None):
         ref = ref32 if ora64 is None else ora64[1][k]
         scale = np.abs(ref).max()
         tol = GRAD_RTOL
-        if ora64 is not None:
+        if ora64 is not None and widen:
             tol = max(GRAD_RTOL, 3.0 * float(np.abs(ref32 - ref).max() / (scale + 1e-30)))
         if scale < 1e-12:              # softmax-shift-invariant biases: the true gradient is 0, all sides hold noise
             assert np.abs(hg[k]).max() < 1e-6, k
@@ -130,9 +144,13 @@ def test_xe_train_iteration_b1024_v10k_vs_oracle_autograd():
     hip = _hip_iteration(w, V, st, d, s2s)
     ora = _oracle_iteration(w, V, d, s2s, chunk=256)
     ora64 = _oracle_iteration(w, V, d, s2s, chunk=256, dtype=torch.float64)
-    worst = _compare(hip, ora, ora64=ora64)
+    # the widened bound exists for ONE reason - a ReLU pre-activation that fp32 and fp64 put on different sides of zero -
+    # so it is granted only when the oracle's own arithmetic shows such flips on these inputs (counted here)
+    flips = _relu_sign_flips(w, d)
+    worst = _compare(hip, ora, ora64=ora64, widen=sum(flips.values()) > 0)
     loose = {k: v for k, v in worst.items() if v[0] > GRAD_RTOL}
     assert set(loose) <= {'att2att.0.weight', 'att2att.0.bias'}, loose     # every other tensor holds the plain 1e-4
+    assert not loose or sum(flips.values()) > 0, (loose, flips)
 
 
 def test_xe_train_iteration_at_196_regions_vs_oracle_autograd():
