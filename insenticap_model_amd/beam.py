@@ -156,6 +156,53 @@ def _search(cap, fc_feats, att_feats, senti_words, senti_labels, beam, decoding_
 CHUNK = 4          # decode steps per captured graph = steps between two looks at the live-image counter
 
 
+def _graph_key(cap, ins, beam, decoding_constraint, T):
+    # (the cached tables a captured graph points at are functions of these weights: token table, sentiment-word tables,
+    # and - gated scan - the sentiment-word table through attention.senti2att)
+    versions = tuple(q._version for q in (cap.word_embed[0].weight, cap.att_lstm.weight_ih, cap.senti2att[0].weight,
+                                          cap.senti2att[0].bias, cap.attention.senti2att.weight))
+    return (tuple(None if x is None else (tuple(x.shape), x.dtype) for x in ins), beam, decoding_constraint, T, versions,
+            ops.WEIGHT_EPOCH, cap.eos_id, torch.cuda.current_device())
+
+
+def _replay(cap, entry, ins, T):
+    graphs, static, search = entry[:3]
+    # inputs -> the graphs' static buffers: one launch per dtype (features, ids) instead of one per tensor
+    by_dtype = {}
+    for dst, src in zip(static, ins):
+        if dst is not None:
+            by_dtype.setdefault(dst.dtype, ([], []))
+            by_dtype[dst.dtype][0].append(dst)
+            by_dtype[dst.dtype][1].append(src)
+    for dsts, srcs in by_dtype.values():
+        torch._foreach_copy_(dsts, srcs, non_blocking=True)
+    for g, t1 in graphs:
+        g.replay()
+        cap.last_beam_steps = t1
+        if t1 < T and search.all_done(t1 - 1):
+            break
+    return search.finish()
+
+
+def replay_if_captured(cap, fc_feats, att_feats, senti_words, senti_labels, beam, decoding_constraint, T):
+    """Captioner.sample_batch's short cut: a search whose graphs exist is one key look-up, the input copies, the replay
+    and the read-back - none of the per-call set-up of the eager path (parameter dictionary, weights scope, mode walk:
+    ~100 us of host time in front of a 1 ms search).  None when there is nothing to replay."""
+    cache = cap.__dict__.get('_beam_graphs')
+    if (not cache or not getattr(cap, 'beam_device_merge', True) or beam > 8 or ops.TIMER.arm_step is not None
+            or not ops.graphs_allowed_here()):
+        return None
+    if not (fc_feats.is_cuda and att_feats.is_cuda):
+        return None
+    ins = [cap._f32(fc_feats), cap._f32(att_feats), senti_words, senti_labels]
+    key = _graph_key(cap, ins, beam, decoding_constraint, T)
+    entry = cache.get(key)
+    if not isinstance(entry, tuple):
+        return None
+    cache[key] = cache.pop(key)             # LRU order
+    return _replay(cap, entry, ins, T)
+
+
 def _graphed_search(cap, fc_feats, att_feats, senti_words, senti_labels, beam, decoding_constraint, T):
     """The search served from captured HIP graphs (Captioner.enable_beam_graphs).  A single-image beam-5 step is
     ~14 small launches behind four FFI calls and the host needs longer to enqueue them than the device to run them;
@@ -164,12 +211,7 @@ def _graphed_search(cap, fc_feats, att_feats, senti_words, senti_labels, beam, d
     <= ceil(T / CHUNK) graph launches with one counter read between them, and the read-back."""
     dev = cap._dev
     ins = [cap._f32(fc_feats), cap._f32(att_feats), senti_words, senti_labels]
-    # (the cached tables a captured graph points at are functions of these weights: token table, sentiment-word tables,
-    # and - gated scan - the sentiment-word table through attention.senti2att)
-    versions = tuple(q._version for q in (cap.word_embed[0].weight, cap.att_lstm.weight_ih, cap.senti2att[0].weight,
-                                          cap.senti2att[0].bias, cap.attention.senti2att.weight))
-    key = (tuple(None if x is None else (tuple(x.shape), x.dtype) for x in ins), beam, decoding_constraint, T, versions,
-           ops.WEIGHT_EPOCH, cap.eos_id, torch.cuda.current_device())
+    key = _graph_key(cap, ins, beam, decoding_constraint, T)
     cache = cap._beam_graphs
     entry = cache.get(key)
     if entry is None:                       # first sight: run eagerly (builds the cached tables, warms the kernels)
@@ -209,16 +251,7 @@ def _graphed_search(cap, fc_feats, att_feats, senti_words, senti_labels, beam, d
             finally:
                 scope.__exit__(None, None, None)
         entry = cache[key] = (graphs, static, search, ws, wp, pool)
-    graphs, static, search = entry[:3]
-    for dst, src in zip(static, ins):
-        if dst is not None:
-            dst.copy_(src, non_blocking=True)
-    for g, t1 in graphs:
-        g.replay()
-        cap.last_beam_steps = t1
-        if t1 < T and search.all_done(t1 - 1):
-            break
-    return search.finish()
+    return _replay(cap, entry, ins, T)
 
 
 class _Search:

@@ -746,8 +746,13 @@ class Captioner(nn.Module):
             outs, pending = on_stream(capture)
             entry = cache[key] = (graph, static, outs, pending, ops.h3_weights_scope.cold_begins(skey))
         graph, static, outs, pending = entry[:4]
+        by_dtype = {}                            # inputs -> static buffers: one launch per dtype, not one per tensor
         for dst, src in zip(static, ins):
-            dst.copy_(src, non_blocking=True)
+            by_dtype.setdefault(dst.dtype, ([], []))
+            by_dtype[dst.dtype][0].append(dst)
+            by_dtype[dst.dtype][1].append(src)
+        for dsts, srcs in by_dtype.values():
+            torch._foreach_copy_(dsts, srcs, non_blocking=True)
         graph.replay()
         self._weights_pending = pending          # attention weights of this replay (resolved lazily, as always)
         return tuple(o.clone() for o in outs)
@@ -918,8 +923,15 @@ class Captioner(nn.Module):
         and one device top-k; candidate bookkeeping follows the reference exactly (fp64 score sums,
         stable ordering, ended beams carried, captioner.py:378-411).
         Returns (captions[I][beam], scores[I][beam], id_sequences[I][beam])."""
-        from .beam import beam_search_batch
-        self.eval()
+        from .beam import beam_search_batch, replay_if_captured
+        if self.training:
+            self.eval()
+        out = replay_if_captured(self, fc_feats, att_feats, senti_words, senti_labels, beam_size, decoding_constraint,
+                                 max_seq_len)
+        if out is not None:
+            if getattr(self, 'numerics_checks', True):
+                ops.check_numerics('Captioner.sample')
+            return out
         self._p()                                  # raises on CPU parameters before anything touches the device
         with ops.h3_weights_scope(self._dev, key=self._weights_key()):     # prologue + search: weights split once
             out = beam_search_batch(self, fc_feats, att_feats, senti_words, senti_labels, beam_size,

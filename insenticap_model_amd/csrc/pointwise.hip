@@ -209,6 +209,8 @@ ISC_STATUS_DECL(pw)
 
 __device__ __forceinline__ void fold_row_stats(const float *pmax, const float *psum, const int *pidx,
                                                int n_tile, int lane, float &gmax, int &gidx, float &S) {
+    // every tile statistic of the row is requested before the first exchange (two strided passes with a reduction
+    // between them were two dependent memory round trips per decode step on the roll-out's critical path)
     float mx = -INFINITY;
     int ix = 0x7fffffff;
     for (int i = lane; i < n_tile; i += 64) {
@@ -216,10 +218,17 @@ __device__ __forceinline__ void fold_row_stats(const float *pmax, const float *p
         const int id = pidx ? pidx[i] : i;
         if (v > mx || (v == mx && id < ix)) { mx = v; ix = id; }
     }
-    wave_argmax(mx, ix);
+    // lane exchanges inside 32-lane halves by DPP, one cross-half swap (same order: value, then the smaller index)
+    half_argmax(mx, ix);
+    {
+        const float ov = __shfl_xor(mx, 32, 64);
+        const int oi = __shfl_xor(ix, 32, 64);
+        if (ov > mx || (ov == mx && oi < ix)) { mx = ov; ix = oi; }
+    }
     float s = 0.f;
     for (int i = lane; i < n_tile; i += 64) s += psum[i] * expf(pmax[i] - mx);
-    S = wave_sum(s);
+    s = half_sum(s);
+    S = s + __shfl_xor(s, 32, 64);
     gmax = mx;
     // a row whose maxima are all NaN never satisfied `v > mx`: its index is still the sentinel, and a consumer would
     // gather an embedding row 2^31 rows past the table.  Such a row decodes <PAD> (id 0) and is flagged.
@@ -835,6 +844,12 @@ __global__ __launch_bounds__(512) void beam_select_kernel(const isc_beam_select_
     double my_score = 0.0;
     int my_len = 0;
     if (tid < beam) { my_last = a.last_in[base + tid]; my_score = a.score_in[base + tid]; my_len = a.len_in[base + tid]; }
+    long long wv[4];                         // element e of the image's [beam][T] block of word lists
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int e = tid + q * (int)blockDim.x;
+        wv[q] = a.words_in[(long long)base * T + (e < beam * T ? e : 0)];
+    }
     // the image's rows of the step's output state -> LDS (behind the word lists), on its way while the merges run
     float *st_lds = reinterpret_cast<float *>(sel_smem + (((size_t)beam * T * 8 + 15) & ~(size_t)15));
     if (a.state_out) {                       // LDS image [plane][row][H]; wave w takes (plane, row) pairs w, w + nw, ...
@@ -853,12 +868,6 @@ __global__ __launch_bounds__(512) void beam_select_kernel(const isc_beam_select_
                     *reinterpret_cast<float4 *>(st_lds + pr * a.H + c) = *reinterpret_cast<const float4 *>(srow + c);
             }
         }
-    }
-    long long wv[4];                         // element e of the image's [beam][T] block of word lists
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int e = tid + q * (int)blockDim.x;
-        wv[q] = a.words_in[(long long)base * T + (e < beam * T ? e : 0)];
     }
     RSTAMP(1);
     if (go == 0) return;                  // the search has ended (block-uniform)
