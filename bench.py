@@ -69,6 +69,11 @@ def parse():
                     help='split-f16 GEMM path: 1 auto (default), 0 off = exact-fp32 MFMA tiles only, 2 force')
     ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak',
                     help='weak (default): --batch captions per GPU; strong: --batch captions over all GPUs')
+    ap.add_argument('--dry-ranks', type=int, default=0,
+                    help='rehearse the N-rank launch path on the CPU (gloo, no GPU, no product import): the parent spawns N '
+                         'ranks exactly as --gpus N does, the ranks form a group, all-reduce a token, rank 0 prints a stub line')
+    ap.add_argument('--dry-fail-rank', type=int, default=-1, help='(with --dry-ranks) this rank exits non-zero: the '
+                    'parent must relay the failure')
     return ap.parse_args()
 
 
@@ -189,6 +194,13 @@ def bench_xe_train(cap, dev, rank, world, iters=6, B=128, s2s_rows=80, curve='we
             el = timed_region(gstep, iters, dev)
             replayed = graph.replays - r0
         except Exception as e:          # noqa: BLE001 - the eager figure above stands on its own
+            if dist_on():
+                # under a process group a failed capture is not recoverable in place (the other ranks are inside a
+                # collective or a replay; a backend watchdog abort is not even an exception): this rank exits non-zero,
+                # the launcher tears the group down and the parent relays the failure - never an eager line that
+                # pretends to be the N-rank measurement, never a re-exec of this GPU-initialised process
+                sys.stderr.write('bench.py: graph capture failed under the process group: %r\n' % (e,))
+                raise
             graph_error, el, replayed = repr(e)[:300], el_eager, 0
     cap.eval()
     for q in cap.parameters():          # the arena's views must not outlive this measurement
@@ -535,34 +547,93 @@ def free_port():
     return port
 
 
-def launch_ranks(args):
+def count_gpus():
+    """GPUs this process may use, WITHOUT touching HIP: the parent of an N-rank run must stay GPU-free (a process that
+    has initialised the GPU may neither fork nor exec its ranks on this pool).  Source: the KFD topology in sysfs - a
+    node with simd_count > 0 is a GPU - narrowed by HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES.
+    Where sysfs has no KFD tree (a container without the driver's view) a throw-away CHILD asks torch; the parent
+    itself never does."""
+    root = '/sys/class/kfd/kfd/topology/nodes'
+    n = None
+    if os.path.isdir(root):
+        n = 0
+        for node in sorted(os.listdir(root)):
+            try:
+                with open(os.path.join(root, node, 'properties')) as f:
+                    props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+            except OSError:
+                continue
+            if int(props.get('simd_count', '0')) > 0:
+                n += 1
+    if n is None:
+        r = subprocess.run([sys.executable, '-c', 'import torch; print(torch.cuda.device_count())'],
+                           stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+        try:
+            n = int(r.stdout.strip().splitlines()[-1])
+        except (ValueError, IndexError):
+            n = 0
+    for var in ('HIP_VISIBLE_DEVICES', 'ROCR_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):
+        v = os.environ.get(var)
+        if v is not None:
+            listed = [x for x in v.split(',') if x.strip() != '']
+            n = min(n, len(listed))
+    return n
+
+
+def launch_ranks(args, n_ranks=None, dry=False):
     """`bench.py --gpus N` (N > 1) outside a launcher: start N rank processes.  This parent NEVER initialises HIP
-    (torch.cuda.device_count() reads the device list without creating a context on this image; nothing else here
-    touches the GPU, the product is not even imported), so there is no exec / fork of a GPU-initialised process: the
-    ranks are fresh children of torch.distributed.run."""
-    import torch as torch_
-    have = torch_.cuda.device_count()
-    if have < args.gpus:
-        sys.stderr.write('bench.py: --gpus %d requested but this box exposes %d GPU(s); refusing to report a '
-                         '%d-GPU line from fewer ranks\n' % (args.gpus, have, args.gpus))
-        return 2
+    (count_gpus reads sysfs; the product is not even imported), so there is no exec / fork of a GPU-initialised
+    process: the ranks are fresh children of torch.distributed.run.  Their stdout is relayed: the ONE result line goes to
+    this process's stdout, a non-zero exit code of any rank (the launcher's) becomes this process's."""
+    n_ranks = n_ranks or args.gpus
+    if not dry:
+        have = count_gpus()
+        if have < n_ranks:
+            sys.stderr.write('bench.py: --gpus %d requested but this box exposes %d GPU(s); refusing to report a '
+                             '%d-GPU line from fewer ranks\n' % (n_ranks, have, n_ranks))
+            return 2
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n_ranks),
            '--master-addr', '127.0.0.1', '--master-port', str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
     lines = [x for x in r.stdout.splitlines() if x.startswith('{') and '"metric"' in x]
     if r.returncode != 0 or not lines:
         sys.stderr.write('bench.py: the %d-rank run failed (launcher exit code %d, %d result line(s))\n'
-                         % (args.gpus, r.returncode, len(lines)))
+                         % (n_ranks, r.returncode, len(lines)))
         sys.stderr.write(r.stdout[-2000:])
         return r.returncode or 1
     print(lines[-1], flush=True)
     return 0
 
 
+def dry_rank(args):
+    """One rank of `--dry-ranks N`: the launch path's plumbing on the CPU - rendezvous from the launcher's environment,
+    a gloo group, one all-reduce, a barrier, rank 0's single JSON line - with neither a GPU nor the product."""
+    import torch as torch_
+    import torch.distributed as dist
+    rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+    dist.init_process_group('gloo')
+    if rank == args.dry_fail_rank:
+        sys.stderr.write('bench.py: dry rank %d fails on request\n' % rank)
+        os._exit(3)
+    tok = torch_.tensor([float(rank + 1)])
+    dist.all_reduce(tok)
+    assert float(tok) == world * (world + 1) / 2, float(tok)
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps(dict(metric='dry-run (launch path only: no GPU work)', value=float(tok), unit='token sum',
+                              n_gpus=world, steps=0, warmup=0, ms_per_step=0.0, higher_is_better=True, scaling='weak',
+                              vs_baseline=None, dtype='f32', data='none', config={'workload': 'launcher rehearsal'})),
+              flush=True)
+    dist.destroy_process_group()
+    return 0
+
+
 def main():
     args = parse()
     under_launcher = 'RANK' in os.environ and 'WORLD_SIZE' in os.environ
+    if args.dry_ranks:
+        sys.exit(dry_rank(args) if under_launcher else launch_ranks(args, n_ranks=args.dry_ranks, dry=True))
     if under_launcher and int(os.environ['WORLD_SIZE']) != args.gpus:
         sys.stderr.write('bench.py: --gpus %d but the launcher started WORLD_SIZE=%s ranks\n'
                          % (args.gpus, os.environ['WORLD_SIZE']))

@@ -15,9 +15,7 @@ def _run(args, env=None):
 
 
 def test_gpus_n_without_n_devices_refuses_instead_of_reporting_one_gpu():
-    import torch
-    n = torch.cuda.device_count() + 1
-    r = _run(['--gpus', str(max(n, 2))])
+    r = _run(['--gpus', '64'])                                  # (no box has 64)
     assert r.returncode == 2, (r.stdout, r.stderr)
     assert 'refusing' in r.stderr and '"metric"' not in r.stdout
 
@@ -25,6 +23,50 @@ def test_gpus_n_without_n_devices_refuses_instead_of_reporting_one_gpu():
 def test_launcher_world_size_must_match_gpus():
     r = _run(['--gpus', '4'], env=dict(RANK='0', WORLD_SIZE='2', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1'))
     assert r.returncode == 2 and 'WORLD_SIZE=2' in r.stderr and '"metric"' not in r.stdout
+
+
+def test_dry_ranks_two_ranks_spawn_relay_and_exit_code():
+    """The whole self-launch path, on the CPU: the parent spawns two ranks through torch.distributed.run, they form a
+    group (gloo), all-reduce a token and rank 0 prints the one JSON line, which the parent relays on ITS stdout; a rank
+    that exits non-zero makes the parent exit non-zero without a result line."""
+    import json
+    r = _run(['--dry-ranks', '2'])
+    assert r.returncode == 0, (r.stdout, r.stderr[-2000:])
+    lines = [x for x in r.stdout.splitlines() if x.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['value'] == 3.0 and 'dry-run' in d['metric']
+    bad = _run(['--dry-ranks', '2', '--dry-fail-rank', '1'])
+    assert bad.returncode != 0 and '"metric"' not in bad.stdout, (bad.returncode, bad.stdout)
+    assert 'run failed' in bad.stderr
+
+
+def test_gpu_count_comes_from_sysfs_or_a_child_never_from_torch_in_the_parent(tmp_path, monkeypatch):
+    """count_gpus: KFD topology nodes with simd_count > 0, narrowed by the *_VISIBLE_DEVICES lists; this process (the
+    would-be parent of the ranks) does not import torch for it."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('bench_mod', BENCH)
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    root = tmp_path / 'nodes'
+    for i, simd in enumerate((0, 1024, 1024, 1024)):           # node 0: the CPU
+        (root / str(i)).mkdir(parents=True)
+        (root / str(i) / 'properties').write_text('cpu_cores_count %d\nsimd_count %d\nlocal_mem_size 0\n' % (16 if simd == 0 else 0, simd))
+    real_isdir, real_listdir, real_open = os.path.isdir, os.listdir, open
+    kfd = '/sys/class/kfd/kfd/topology/nodes'
+    monkeypatch.setattr(bench.os.path, 'isdir', lambda p: True if p == kfd else real_isdir(p))
+    monkeypatch.setattr(bench.os, 'listdir', lambda p: real_listdir(str(root)) if p == kfd else real_listdir(p))
+    import builtins
+    monkeypatch.setattr(builtins, 'open', lambda p, *a, **k: real_open(str(p).replace(kfd, str(root)), *a, **k))
+    for var in ('HIP_VISIBLE_DEVICES', 'ROCR_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):
+        monkeypatch.delenv(var, raising=False)
+    assert 'torch' not in bench.__dict__ or bench.torch is None
+    assert bench.count_gpus() == 3
+    monkeypatch.setenv('HIP_VISIBLE_DEVICES', '0,2')
+    assert bench.count_gpus() == 2
+    monkeypatch.setenv('ROCR_VISIBLE_DEVICES', '1')
+    assert bench.count_gpus() == 1
+    assert bench.torch is None                                  # still not imported
 
 
 def test_launcher_parent_never_imports_the_product_or_touches_hip():
@@ -37,3 +79,4 @@ def test_launcher_parent_never_imports_the_product_or_touches_hip():
     assert main.index('launch_ranks(args)') < main.index('load_product()')
     launch = src[src.index('def launch_ranks'):src.index('def main():')]
     assert 'torch.distributed.run' in launch and 'os.exec' not in src and 'is_available()' not in launch
+    assert 'device_count()' not in launch                       # (the count comes from count_gpus: sysfs, or a child)

@@ -140,6 +140,49 @@ def test_two_rank_training_matches_single_process():
     assert arena.nbytes == sum(v.size for v in ref.values()) * 4
 
 
+def _graph_worker(rank, world, port, results):
+    """Two ranks, XE iterations through train_graph.XETrainGraph: two eager iterations on the graph's streams, the capture
+    (with the process group live: collectives BETWEEN the two graphs), replays."""
+    from insenticap_model_amd.train_graph import XETrainGraph
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK='0')
+    dp.init_from_env('gloo')
+    cfg = TINY
+    cap = _make(cfg)
+    dp.broadcast_parameters(cap)
+    arena = dp.GradArena(cap.parameters())
+    optim, xe_crit, da_crit = cap.get_optim_criterion(4e-4)
+    lo, hi = dp.shard(cfg['B'], rank, world)
+    fact, labels, scs = _batches(lo, hi, cfg)
+    graph = XETrainGraph(cap, optim, xe_crit, da_crit, grad_clip=0.1, arena=arena, warmup=2)
+    losses = [float(graph.step(fact, labels, scs, 0.0)['all_loss']) for _ in range(6)]
+    torch.cuda.synchronize()
+    results[rank] = ({k: v.detach().cpu().numpy() for k, v in cap.state_dict().items()}, losses, graph.replays)
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_training_graph_with_a_live_process_group_matches_eager():
+    """HIP-graph capture next to a multi-rank group (gloo, both ranks on this box's GPU): the forward+backward graph,
+    the gradient / normaliser / loss all-reduces between the graphs, the clamp+Adam graph - six iterations, of which at
+    least three are replays on every rank - land on the parameters of six single-process eager iterations over the
+    whole batch, and the two ranks stay bit-identical."""
+    mgr = mp.get_context('spawn').Manager()
+    results = mgr.dict()
+    mp.spawn(_graph_worker, args=(2, _free_port(), results), nprocs=2, join=True)
+    cap = _make()
+    arena = dp.GradArena(cap.parameters())
+    ref_losses, _ = _run(cap, 0, TINY['B'], arena, 6)
+    ref = {k: v.detach().cpu().numpy() for k, v in cap.state_dict().items()}
+    (p0, l0, r0), (p1, l1, r1) = results[0], results[1]
+    assert r0 >= 3 and r1 >= 3, (r0, r1)
+    np.testing.assert_allclose(l0, ref_losses, rtol=5e-5)
+    np.testing.assert_allclose(l1, l0, rtol=1e-6)
+    for k in ref:
+        np.testing.assert_array_equal(p0[k], p1[k], err_msg=k)
+        assert np.abs(p0[k] - ref[k]).max() <= 6 * 4e-4 * 1.05, k
+
+
 # ----------------------------------------------------------------------------- RL step under DP (BASELINE configs[4])
 RL_B, RL_S2S = 8, 4
 
