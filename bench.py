@@ -377,21 +377,26 @@ def bench_rl(dev, iters=3, B=512, cache_image_sentiments=True, rank=0, world=1):
         return r
     import insenticap_model_amd.detector as dmod
     dmod.get_self_critical_reward = timed
+    rewards.get_self_critical_reward = timed          # (the graph-served iteration resolves it from the module per call)
     losses = {}
 
     def one():
         losses.update(det((fact, scs), 'fact', True))
     try:
-        one()                                     # warm-up
+        for _ in range(4):                        # warm-up: two eager iterations, the graph capture, one replay
+            one()
         torch.cuda.synchronize()
         cider_t[0] = 0.0
         with no_gc():
             el = timed_region(one, iters, dev)
     finally:
         dmod.get_self_critical_reward = orig
+        rewards.get_self_critical_reward = orig
     return dict(iters=iters, global_batch=(hi - lo) * world, batch_per_gpu=hi - lo, seq2seq_rows_per_gpu=s_hi - s_lo,
                 ms_per_iter=round(el / iters * 1e3, 1), images_per_s=round((hi - lo) * world * iters / el, 1),
                 image_sentiment_cache=bool(cache_image_sentiments),
+                served_from=('HIP graphs (train_graph.RLTrainGraph: %d replays, %d eager iterations so far)'
+                             % (det._rl_graph.replays, det._rl_graph.eager_steps)) if det._rl_graph is not None else 'eager',
                 cider_ms_per_iter=round(cider_t[0] / iters * 1e3, 1), cider_threads=det.ciderd_scorer.n_threads,
                 grad_arena_all_reduces=det.dp_arena.collectives if det.dp_arena is not None else 0,
                 losses={k: round(float(v), 4) for k, v in losses.items()})

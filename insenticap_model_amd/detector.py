@@ -46,6 +46,11 @@ class Detector(nn.Module):
         # re-running 1.7-9.2 GFLOP of convolutions per image in every RL iteration.
         self.cache_image_sentiments = True
         self._senti_cache, self._senti_cache_key = {}, None
+        # 'fact' training iterations are served from HIP graphs (train_graph.RLTrainGraph: roll-outs / unrolls /
+        # backward + update captured per batch geometry after two eager iterations; CIDEr-D and the classifier reward
+        # between them).  False: every iteration runs the eager sequence below.
+        self.train_graphs = True
+        self._rl_graph = None
 
     def enable_data_parallel(self, group=None, broadcast=True):
         """Data-parallel RL training over the ranks of `group` (default process group; backend nccl = RCCL over xGMI,
@@ -121,6 +126,24 @@ class Detector(nn.Module):
 
             if data_type == 'fact' or not training:      # labels from the image sentiment detector
                 senti_labels = self._image_sentiments(fns, att_feats)
+
+            if (training and data_type == 'fact' and self.train_graphs and device.type == 'cuda'
+                    and ops.TIMER.arm_step is None and ops.graphs_allowed_here()):
+                # the same iteration from HIP graphs (train_graph.RLTrainGraph): same calls in the same order
+                from .train_graph import RLTrainGraph
+                if self._rl_graph is None or self._rl_graph.arena is not self.dp_arena:
+                    self._rl_graph = RLTrainGraph(self)
+                with torch.no_grad():
+                    xe_senti_labels = self.sent_senti_cls(caps_tensor[:, 1:], lengths)[0]
+                    xe_senti_labels = xe_senti_labels.softmax(dim=-1).argmax(dim=-1).detach()
+                (s_caps, s_lengths), s_cpts, s_sentis, s_labels = s2s_batch
+                stats = self._rl_graph.step(
+                    (fns, fc_feats, att_feats, (caps_tensor, lengths), cpts_tensor, sentis_tensor, ground_truth),
+                    ((s_caps.to(device), s_lengths), s_cpts.to(device), s_sentis.to(device), s_labels.to(device)),
+                    senti_labels, xe_senti_labels)
+                for k, v in stats.items():
+                    add(k, v)
+                continue
 
             # sampled roll-out (graph kept in train mode) and the domain-alignment loss on its prologue
             sample_captions, sample_logprobs, seq_masks = cap(

@@ -329,3 +329,277 @@ class XETrainGraph:
         for v in out.values():
             v.record_stream(caller)
         return out
+
+
+class _RLGeometry(_Geometry):
+    def __init__(self):
+        super().__init__()
+        self.g_roll = self.g_fwd = self.g_bwd = None     # (g_up: the update graph under a process group)
+        self.pool = None
+        self.host = None            # pinned host copies of the two token matrices and the sampled lengths
+        self.reward = None          # static [B, T] reward the REINFORCE loss reads
+        self.stats = None           # static [7] device statistics of the iteration
+
+
+class RLTrainGraph(XETrainGraph):
+    """The self-critical RL training iteration of `Detector.forward(data, 'fact', True)` (models/decoder.py:65-167)
+    served from HIP graphs - three of them per input geometry, with the two things that cannot live in a graph between:
+
+        g_roll   sampled roll-out (activations kept for REINFORCE), domain-align loss, greedy roll-out, the device->host
+                 copies of both token matrices                                                     [decoder.py:85-98]
+        host     waits for the copies only, then scores CIDEr-D (host library) WHILE the device runs
+        g_fwd    XE unroll (ss_prob 0.5), forward; seq2seq unroll (ss_prob 0.25) forward AND backward as a branch on the
+                 side stream, its gradients in tensors of their own                               [decoder.py:131-158]
+        eager    classifier reward (a packed-sequence LSTM: data-dependent shapes), rewards -> the static reward buffer
+        g_bwd    RewardCriterion, the sum of the losses, backward, the seq2seq gradients added, clamp + Adam + plane
+                 refresh (under a process group: the exchange, then the update as a graph of its own) [decoder.py:126-167]
+
+    Streams, weight-plane scopes, device-side Adam scalars, step counters, the run-eagerly-once-after-a-foreign-weight-
+    change rule and the re-capture after a scope rebuild are XETrainGraph's.  The phases run eagerly (same streams, same
+    order) while a geometry warms up; a replay is bit-identical to that eager form.  Against the plain eager
+    Detector.forward the gradient is the same sum with the seq2seq unroll's part added last (fp32 rounding).
+
+        graph = RLTrainGraph(detector)
+        stats = graph.step(fact_item, scs_item, senti_labels, xe_senti_labels)    # 7 device scalars of this iteration
+    """
+    KEYS = ('da_loss', 'fact_reward', 'cls_reward', 'all_rewards', 'cap_loss', 'xe_loss', 'seq2seq_loss')
+
+    def __init__(self, detector, warmup=2, max_geometries=2):
+        super().__init__(detector.captioner, detector.cap_optim, detector.cap_xe_crit, detector.cap_da_crit,
+                         grad_clip=0.1, arena=detector.dp_arena, group=detector.dp_group, warmup=warmup,
+                         max_geometries=max_geometries)
+        self.det = detector
+        self.share_rl = torch.ones(1, dtype=torch.float32, device=self.device)
+
+    # ---- phases ---------------------------------------------------------------------------------------------------
+    def _phase_roll(self, geo):
+        """Sampled roll-out (graph kept), domain-align loss, greedy baseline, token matrices on their way to the host."""
+        det, cap, i = self.det, self.cap, geo.inputs
+        cap.cpt_feats = cap.fc_feats = None
+        cap.train(True)
+        seq, lp, mk = cap(i['fc'], i['att'], i['cpts'], i['sentis'], i['labels'], det.max_seq_len, sample_max=0, mode='rl')
+        da = det.cap_da_crit(cap.cpt_feats, cap.fc_feats.detach())
+        cap.eval()
+        with torch.no_grad():
+            gseq, _, gmk = cap(i['fc'], i['att'], i['cpts'], i['sentis'], i['labels'], det.max_seq_len, sample_max=1,
+                               mode='rl')
+        cap.train(True)
+        lens = mk.sum(dim=-1).type(torch.int32)
+        geo.host[0].copy_(seq, non_blocking=True)
+        geo.host[1].copy_(gseq, non_blocking=True)
+        geo.host[2].copy_(lens, non_blocking=True)
+        return seq, lp, mk, da, gseq, gmk
+
+    def _phase_fwd(self, geo):
+        """XE unroll forward on self.stream; the seq2seq unroll - forward and backward - as a branch on self.side."""
+        from .train import _xe_loss
+        det, cap, i = self.det, self.cap, geo.inputs
+        self.side.wait_stream(self.stream)                  # the branch forks here ...
+        cap.cpt_feats = cap.fc_feats = None
+        # ... the XE unroll is ENQUEUED first (the reference's call order, hence its order of random draws: decoder.py:138,155)
+        pred = cap(i['fc'], i['att'], i['cpts'], i['caps'], i['xe_labels'], ss_prob=det.xe_ss_prob, mode='xe')
+        xe = _xe_loss(det.cap_xe_crit, pred, i['caps'][:, 1:], i['len'])
+        keep = (cap.cpt_feats, cap.fc_feats)
+        with torch.cuda.stream(self.side):
+            s2s = self._phase_s2s(geo, det.seq2seq_ss_prob)
+        cap.cpt_feats, cap.fc_feats = keep
+        self.stream.wait_stream(self.side)
+        return xe, s2s
+
+    def _phase_bwd(self, geo, roll, fwd):
+        """RewardCriterion on the static reward, the reference's sum of losses (decoder.py:160), backward, the seq2seq
+        gradients added, the statistics of the iteration; without a process group also clamp + Adam."""
+        det = self.det
+        seq, lp, mk, da, gseq, gmk = roll
+        xe, (s2s_loss, s2s_grads) = fwd
+        dist = self._dist()
+        cap_loss = det.cap_rl_crit(lp, mk, geo.reward)
+        if dist:
+            cap_loss, xe, da = cap_loss * self.share_rl[0], xe * self.shares[0], da * self.shares[2]
+        s2s_loss = det.seq_flag * s2s_loss
+        total = cap_loss + xe + da
+        if self.arena is not None:
+            self.arena.zero_()
+        else:
+            self.optim.zero_grad()
+        total.backward()
+        dst, src = [], []
+        for q, g in zip(self._params, s2s_grads):
+            if g is None:
+                continue
+            if det.seq_flag != 1.0:
+                g = g * det.seq_flag
+            if q.grad is None:
+                q.grad = g
+            else:
+                dst.append(q.grad)
+                src.append(g)
+        if dst:
+            torch._foreach_add_(dst, src)
+        r = geo.reward
+        w_rows = self.shares[2] if dist else 1.0
+        geo.stats = torch.stack([da.detach(), geo.fact0.mean() * w_rows, geo.cls.mean(-1).mean(-1) * w_rows,
+                                 r.mean(-1).mean(-1) * w_rows, cap_loss.detach(), xe.detach(), s2s_loss.detach()])
+        if not dist:
+            xe_update(self.optim, self.grad_clip)
+        return geo.stats
+
+    # ---- between the graphs -----------------------------------------------------------------------------------------
+    def _rewards(self, geo, roll, item):
+        """CIDEr-D on the host (the copies of g_roll have landed: `copied`), the classifier reward on the device, their
+        sum into the static buffer the captured RewardCriterion reads."""
+        from .rewards import get_cls_reward, get_self_critical_reward
+        det = self.det
+        seq, lp, mk, da, gseq, gmk = roll
+        fns, ground_truth = item[0], item[6]
+        geo.copied.synchronize()
+        fact = get_self_critical_reward(geo.host[0].numpy(), geo.host[1].numpy(), fns, ground_truth, self.cap.sos_id,
+                                        self.cap.eos_id, det.ciderd_scorer)
+        fact = ops.upload(fact.astype('float32'), torch.float32, self.device)
+        cls = get_cls_reward(seq, mk, gseq, gmk, geo.inputs['labels'], det.sent_senti_cls,
+                             sample_lens=geo.host[2].tolist(), on_device=True)
+        geo.fact0.copy_(fact[:, 0])
+        geo.cls.copy_(cls)
+        geo.reward.copy_(fact + det.cls_flag * cls)
+
+    def _shares(self, geo, roll, lengths, s_lengths):
+        """DP: each term's share of its global normaliser (mask sum, XE tokens, seq2seq tokens, rows): one 4-float
+        all-reduce per iteration, as Detector.forward does."""
+        if not self._dist():
+            return
+        n_local, n_global = dp.global_counts([roll[2].sum(), float(sum(lengths)), float(sum(s_lengths)),
+                                              float(geo.inputs['fc'].shape[0])], self.device, self.group)
+        w = n_local / n_global.clamp_min(1.0)
+        self.share_rl.copy_(w[0:1])
+        self.shares.copy_(w[1:4])
+
+    def _alloc(self, geo):
+        i = geo.inputs
+        B, T = i['fc'].shape[0], self.det.max_seq_len
+        geo.host = (torch.empty(B, T, dtype=torch.int64).pin_memory(), torch.empty(B, T, dtype=torch.int64).pin_memory(),
+                    torch.empty(B, dtype=torch.int32).pin_memory())
+        geo.reward = torch.zeros(B, T, dtype=torch.float32, device=self.device)
+        geo.fact0 = torch.zeros(B, dtype=torch.float32, device=self.device)
+        geo.cls = torch.zeros(B, T, dtype=torch.float32, device=self.device)
+        geo.copied = torch.cuda.Event()
+
+    # ---- eager / capture / replay -----------------------------------------------------------------------------------
+    def _run_eager(self, geo, item, lengths, s_lengths):
+        with ops.refresh_only(self._handles):
+            roll = self._phase_roll(geo)
+            geo.copied.record(self.stream)
+            self._shares(geo, roll, lengths, s_lengths)
+            fwd = self._phase_fwd(geo)
+            for g in fwd[1][1]:
+                if g is not None:
+                    g.record_stream(self.stream)
+            self._rewards(geo, roll, item)
+            stats = self._phase_bwd(geo, roll, fwd)
+            if self._dist():
+                if self.arena is not None:
+                    self.arena.all_reduce(self.group)       # (the statistics stay this rank's shares: the caller sums them)
+                xe_update(self.optim, self.grad_clip)
+        self._valid_key = self.cap._weights_key()
+        self.eager_steps += 1
+        return stats
+
+    def _capture_rl(self, geo):
+        steps_before = [float(st['step']) for st in self._states()]
+        self.optim.device_hyper = self.hyper
+        geo.pool = torch.cuda.graph_pool_handle()
+        try:
+            with ops.refresh_only(self._handles):
+                geo.g_roll = torch.cuda.CUDAGraph()
+                with ops.graph_capture(geo.g_roll, stream=self.stream, pool=geo.pool):
+                    roll = self._phase_roll(geo)
+                geo.g_fwd = torch.cuda.CUDAGraph()
+                with ops.graph_capture(geo.g_fwd, stream=self.stream, pool=geo.pool):
+                    fwd = self._phase_fwd(geo)
+                geo.g_bwd = torch.cuda.CUDAGraph()
+                with ops.graph_capture(geo.g_bwd, stream=self.stream, pool=geo.pool):
+                    self._phase_bwd(geo, roll, fwd)
+                geo.g_up = None
+                if self._dist():
+                    geo.g_up = torch.cuda.CUDAGraph()
+                    with ops.graph_capture(geo.g_up, stream=self.stream, pool=geo.pool):
+                        xe_update(self.optim, self.grad_clip)
+                geo.keep = (roll, fwd)
+        finally:
+            self.optim.device_hyper = None
+        for st, n in zip(self._states(), steps_before):
+            st['step'].fill_(n)
+        geo.g_iter = geo.g_roll                              # (the base class's "is captured" marker)
+        geo.layout = ops.h3_weights_scope.cold_begins(self._scope_keys)
+        self._valid_key = self.cap._weights_key()
+        self.captures += 1
+
+    def _replay_rl(self, geo, item, lengths, s_lengths):
+        states = self._states()
+        for st in states:
+            st['step'] += 1
+        self._set_hyper(int(states[0]['step']))
+        roll, fwd = geo.keep
+        geo.g_roll.replay()
+        geo.copied.record(self.stream)
+        self._shares(geo, roll, lengths, s_lengths)
+        geo.g_fwd.replay()
+        self._rewards(geo, roll, item)
+        geo.g_bwd.replay()
+        stats = geo.stats
+        if geo.g_up is not None:
+            if self.arena is not None:
+                self.arena.all_reduce(self.group)
+            geo.g_up.replay()
+        epoch_before = ops.WEIGHT_EPOCH
+        ops.WEIGHT_EPOCH += 1
+        ops.h3_weights_scope.rekey_epoch(self._scope_keys, epoch_before)
+        self._valid_key = self.cap._weights_key()
+        self.replays += 1
+        return stats
+
+    def step(self, item, scs_batch, senti_labels, xe_senti_labels):
+        """One iteration on a fact item of the rl_fact collate (fns, fc, att, (caps, lengths), cpts, sentis,
+        ground_truth), a seq2seq batch, the image sentiment labels and the XE labels of the captions (both from the
+        frozen helper nets, computed by the caller).  Returns {key: 0-dim device tensor} over RLTrainGraph.KEYS (under DP:
+        this rank's pre-scaled shares - their sum over the ranks is the global value, as in Detector.forward), valid on
+        the caller's current stream."""
+        fns, fc, att, (caps, lengths), cpts, sentis, ground_truth = item
+        lengths = self._as_list(lengths)
+        (s_caps, s_lengths), s_cpts, s_sentis, s_labels = scs_batch
+        s_lengths = self._as_list(s_lengths)
+        if caps.size(1) - 1 != max(lengths) or s_caps.size(1) - 1 != max(s_lengths):
+            raise ValueError('caption tensors must end at their longest caption (+1 for <SOS>)')
+        t = dict(fc=fc, att=att, caps=caps, cpts=cpts, sentis=sentis, labels=senti_labels, xe_labels=xe_senti_labels,
+                 len=torch.tensor(lengths, dtype=torch.int32), s_caps=s_caps, s_cpts=s_cpts, s_sentis=s_sentis,
+                 s_labels=s_labels, s_len=torch.tensor(s_lengths, dtype=torch.int32))
+        self.cap.cpt_feats = self.cap.fc_feats = None
+        sig = (self._signature(t, 0.0), self.det.max_seq_len, self.det.xe_ss_prob, self.det.seq2seq_ss_prob,
+               self.det.cls_flag, self.det.seq_flag)
+        geo = self._geoms.get(sig)
+        if geo is None:
+            geo = self._geoms[sig] = _RLGeometry()
+            while len(self._geoms) > self._max_geoms:
+                self._geoms.popitem(last=False)
+        else:
+            self._geoms.move_to_end(sig)
+        caller = torch.cuda.current_stream(self.device)
+        self.stream.wait_stream(caller)
+        with torch.cuda.stream(self.stream):
+            self._stage(geo, t)
+            if geo.host is None:
+                self._alloc(geo)
+            planes_ok = self._valid_key is not None and self._valid_key == self.cap._weights_key()
+            if ops.h3_weights_scope.cold_begins(self._scope_keys) != geo.layout:
+                geo.g_iter = geo.g_roll = geo.g_fwd = geo.g_bwd = geo.g_up = None
+            if geo.g_iter is None and planes_ok and geo.eager_runs >= self.warmup:
+                self._capture_rl(geo)
+            if geo.g_iter is not None and planes_ok:
+                stats = self._replay_rl(geo, item, lengths, s_lengths)
+            else:
+                stats = self._run_eager(geo, item, lengths, s_lengths)
+                geo.eager_runs += 1
+            out = dict(zip(self.KEYS, stats.clone().unbind(0)))
+        caller.wait_stream(self.stream)
+        for v in out.values():
+            v.record_stream(caller)
+        return out

@@ -1,0 +1,134 @@
+"""train_graph.RLTrainGraph - the self-critical RL training iteration of Detector.forward(data, 'fact', True)
+(models/decoder.py:65-167) from HIP graphs: replays against the same phases run eagerly (bit for bit, with the sampled
+roll-out's draws forced and scheduled sampling off: no random numbers), against the plain eager Detector.forward (the
+gradient sum in another order: fp32 rounding), counters of replays / captures, and a run with live random draws
+(train-mode dropout, sampling, scheduled sampling) that must keep training.  pytest -m gpu."""
+import numpy as np
+import pytest
+import torch
+
+from insenticap_model_amd import synth
+from insenticap_model_amd.detector import Detector
+from test_detector import load_helper
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device('cuda:0')
+V, TN, B, S = 64, 8, 8, 4
+ST = dict(synth.TINY_SETTINGS, **synth.HELPER_SETTINGS)
+
+
+def make(dropout=0.0, graphs=True, warmup=2):
+    st = dict(ST, dropout_p=dropout)
+    det = Detector(synth.make_idx2word(V), TN, synth.SENTIMENT_CATEGORIES, {'cap_lr': 4e-4}, st)
+    det.captioner.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_weights(V, st, seed=3).items()})
+    load_helper(det.senti_detector, 51)
+    load_helper(det.sent_senti_cls, 52)
+    det.to(DEV)
+    det.train_graphs = graphs
+    det._graph_warmup = warmup
+    return det
+
+
+def data(n_iter):
+    st = dict(ST, dropout_p=0.0)
+    batches, split = synth.make_rl_batches(n_iter, B, V, st, seq_len=TN, seed=70)
+    t = torch.from_numpy
+    items = [(b[0], t(b[1]), t(b[2]), (t(b[3][0]), b[3][1]), t(b[4]), t(b[5]), b[6]) for b in batches]
+    s = synth.make_inputs(S, V, st, regions=6, seq_len=TN, seed=72)
+    scs = [((t(s['captions']), s['lengths']), t(s['cpt_words']), t(s['senti_words']), t(s['senti_labels']))]
+    draws = [np.random.default_rng(80 + i).integers(2, V, size=(B, TN), dtype=np.int64) for i in range(n_iter)]
+    return items, scs, split, draws
+
+
+def force_draws(det, draws):
+    orig = det.captioner.__dict__.get('_orig_forward_rl') or det.captioner.forward_rl
+    det.captioner._orig_forward_rl = orig
+    # ONE device tensor per distinct draw matrix, alive as long as the detector: a captured graph keeps reading the
+    # address it was captured with (no host copy inside a capture either)
+    keep = det.__dict__.setdefault('_test_draws', {})
+    dev_draws, n = [keep.setdefault(d.tobytes(), torch.from_numpy(d).to(DEV)) for d in draws], {'i': 0}
+
+    def replay_rl(*a, **k):
+        if not k.get('sample_max', a[-1] if len(a) >= 7 else 1):
+            k['_replay'] = dev_draws[n['i'] % len(dev_draws)]
+            n['i'] += 1
+        return orig(*a, **k)
+    det.captioner.forward_rl = replay_rl
+
+
+def run(det, items, scs, split, draws=None):
+    det.set_ciderd_scorer(split)
+    det.xe_ss_prob = det.seq2seq_ss_prob = 0.0 if draws is not None else det.xe_ss_prob
+    out = []
+    for i, it in enumerate(items):
+        if draws is not None:
+            force_draws_for = draws[i:i + 1]
+            force_draws(det, force_draws_for)
+        if det.train_graphs and det._rl_graph is None:
+            from insenticap_model_amd.train_graph import RLTrainGraph
+            det._rl_graph = RLTrainGraph(det, warmup=det._graph_warmup)
+        out.append(det(([it], scs), 'fact', True))
+    torch.cuda.synchronize()
+    return out
+
+
+def same_params(a, b):
+    for (k, p), (_, q) in zip(a.captioner.named_parameters(), b.captioner.named_parameters()):
+        assert torch.equal(p.detach(), q.detach()), k
+
+
+def test_replays_equal_the_eager_phases_bit_for_bit_and_track_plain_eager():
+    """One batch geometry, the SAME batch and forced draws every iteration (a captured graph bakes the draws it was
+    captured with: forced draws are a test device), six iterations: graph path (two eager, capture, replays) vs the same
+    phases never captured: identical parameters and statistics; vs plain eager Detector.forward: within rounding."""
+    items, scs, split, draws = data(1)
+    items, draws = items * 6, draws * 6
+    g = make(graphs=True, warmup=2)
+    e = make(graphs=True, warmup=10 ** 6)        # the phases, never captured
+    p = make(graphs=False)                        # the plain eager sequence
+    og, oe, op_ = run(g, items, scs, split, draws), run(e, items, scs, split, draws), run(p, items, scs, split, draws)
+    assert g._rl_graph.captures == 1 and g._rl_graph.replays == 4 and g._rl_graph.eager_steps == 2
+    assert e._rl_graph.captures == 0 and e._rl_graph.eager_steps == 6
+    same_params(g, e)
+    for a, b in zip(og, oe):
+        assert a.keys() == b.keys() == set(g._rl_graph.KEYS)
+        for k in a:
+            assert a[k] == b[k], k
+    for a, c in zip(og, op_):
+        for k in a:
+            np.testing.assert_allclose(a[k], c[k], rtol=2e-4, atol=2e-6, err_msg=k)
+    for (k, x), (_, y) in zip(g.captioner.named_parameters(), p.captioner.named_parameters()):
+        assert float((x - y).abs().max()) <= 6 * 2 * 4e-4 * 1.01, k
+
+
+def test_live_draws_dropout_and_scheduled_sampling_keep_training_from_graphs():
+    """Train-mode dropout, on-device sampling and scheduled sampling inside the captured graphs: replays draw afresh
+    (the losses of consecutive replays on one batch differ), everything stays finite, the helper nets stay frozen."""
+    items, scs, split, _ = data(1)
+    det = make(dropout=0.5, graphs=True, warmup=2)
+    torch.manual_seed(5)
+    helper_before = {k: v.detach().clone() for k, v in det.sent_senti_cls.state_dict().items()}
+    outs = run(det, items * 6, scs, split)
+    assert det._rl_graph.replays == 4
+    assert all(np.isfinite(v) for o in outs for v in o.values())
+    assert len({round(o['xe_loss'], 6) for o in outs[2:]}) > 1          # fresh draws in every replay
+    assert len({round(o['cap_loss'], 6) for o in outs[2:]}) > 1
+    for k, v in det.sent_senti_cls.state_dict().items():
+        assert torch.equal(v, helper_before[k])
+
+
+def test_a_new_batch_geometry_gets_its_own_graphs():
+    items, scs, split, draws = data(1)
+    det = make(graphs=True, warmup=1)
+    run(det, items * 3, scs, split, draws * 3)
+    assert det._rl_graph.captures == 1
+    st = dict(ST, dropout_p=0.0)
+    b2, split2 = synth.make_rl_batches(1, 4, V, st, seq_len=TN, seed=71)      # four images instead of eight
+    t = torch.from_numpy
+    it2 = [(b[0], t(b[1]), t(b[2]), (t(b[3][0]), b[3][1]), t(b[4]), t(b[5]), b[6]) for b in b2]
+    det.set_ciderd_scorer(split2)
+    d2 = [np.random.default_rng(9).integers(2, V, size=(4, TN), dtype=np.int64)]
+    for _ in range(3):
+        force_draws(det, d2)
+        out = det((it2, scs), 'fact', True)
+    assert det._rl_graph.captures == 2 and all(np.isfinite(v) for v in out.values())
