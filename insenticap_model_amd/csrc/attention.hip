@@ -67,6 +67,7 @@ __device__ __forceinline__ void store_planes4(_Float16 *hi, _Float16 *lo, long l
 
 template <int NA, bool NT>  // float4 per lane along A: A <= 256*NA; NT: per-caption rows by non-temporal loads
 __global__ __launch_bounds__(256) void attn_scan_kernel(const DevScanLaunch L) {
+    rows_kernarg_warm<ROWS_KERNARG_LINES(DevScanLaunch)>();
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const DevScan &S = L.p[blockIdx.y];
     const int b = blockIdx.x;
@@ -281,6 +282,7 @@ struct DevScanGate {
 // not their sum; both keep six regions' loads in flight per thread in the weighted sums (two tensors each).
 template <int NA>
 __global__ __launch_bounds__(512) void attn_scan_gate_kernel(const DevScanGate L) {
+    rows_kernarg_warm<ROWS_KERNARG_LINES(DevScanGate)>();
     extern __shared__ __attribute__((aligned(16))) float smem_all[];
     const int b = blockIdx.x;
     const int half = threadIdx.x >> 8;                   // 0: content scan, 1: sentiment scan (wave-uniform)

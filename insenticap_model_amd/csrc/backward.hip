@@ -311,6 +311,7 @@ __device__ __forceinline__ float4 ld4b(const float4 *p, bool nt) {
 // to come from inside the row.  All row traffic is 16 bytes per lane: a thread owns 4 consecutive columns
 // (A/4 resp. D/4 threads span a row, 1024 / (A/4) region groups work in parallel).
 __global__ __launch_bounds__(1024) void attn_scan_bwd_kernel(const DevScanBwdLaunch L) {
+    rows_kernarg_warm<ROWS_KERNARG_LINES(DevScanBwdLaunch)>();
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const DevScanBwd &S = L.p[blockIdx.y];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;

@@ -86,17 +86,27 @@ static __device__ long long *g_rows_stamp;
 // one dword of each of the first NL lines in ONE batch and waits once: every later argument read hits the scalar cache.
 template <int NL>
 __device__ __forceinline__ void rows_kernarg_warm() {
-    static_assert(NL >= 1 && NL <= 8, "lines");
+    static_assert(NL >= 1 && NL <= 32, "lines");
     const unsigned long long kp = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
-    int d[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    // (the destinations stay live - inputs of the wait statement - until the loads have landed)
-#define ROWS_KA_LINE(I, OFF) \
-    if constexpr (NL > I) asm volatile("s_load_dword %0, %1, " OFF : "=&s"(d[I]) : "s"(kp) : "memory")
-    ROWS_KA_LINE(0, "0x0"); ROWS_KA_LINE(1, "0x40"); ROWS_KA_LINE(2, "0x80"); ROWS_KA_LINE(3, "0xc0");
-    ROWS_KA_LINE(4, "0x100"); ROWS_KA_LINE(5, "0x140"); ROWS_KA_LINE(6, "0x180"); ROWS_KA_LINE(7, "0x1c0");
-#undef ROWS_KA_LINE
-    asm volatile("s_waitcnt lgkmcnt(0)" :: "s"(d[0]), "s"(d[1]), "s"(d[2]), "s"(d[3]), "s"(d[4]), "s"(d[5]), "s"(d[6]), "s"(d[7])
-                 : "memory");
+    // Every load targets the SAME scratch SGPR (its value is never used; scalar loads may return in any order, which is
+    // all a write-after-write on a dead register can show) - one statement, so the register stays reserved until the wait.
+    int d;
+    // (groups of four lines: at most 192 bytes past the struct, inside the 256 bytes of implicit arguments that follow it)
+#define KA4(B) \
+    "s_load_dword %0, %1, " #B "+0x0\n\ts_load_dword %0, %1, " #B "+0x40\n\ts_load_dword %0, %1, " #B "+0x80\n\t" \
+    "s_load_dword %0, %1, " #B "+0xc0\n\t"
+#define KA_GO(BODY) asm volatile(BODY "s_waitcnt lgkmcnt(0)" : "=&s"(d) : "s"(kp) : "memory")
+    constexpr int G = (NL + 3) / 4;
+    if constexpr (G == 1) KA_GO(KA4(0x0));
+    else if constexpr (G == 2) KA_GO(KA4(0x0) KA4(0x100));
+    else if constexpr (G == 3) KA_GO(KA4(0x0) KA4(0x100) KA4(0x200));
+    else if constexpr (G == 4) KA_GO(KA4(0x0) KA4(0x100) KA4(0x200) KA4(0x300));
+    else if constexpr (G == 5) KA_GO(KA4(0x0) KA4(0x100) KA4(0x200) KA4(0x300) KA4(0x400));
+    else if constexpr (G == 6) KA_GO(KA4(0x0) KA4(0x100) KA4(0x200) KA4(0x300) KA4(0x400) KA4(0x500));
+    else if constexpr (G == 7) KA_GO(KA4(0x0) KA4(0x100) KA4(0x200) KA4(0x300) KA4(0x400) KA4(0x500) KA4(0x600));
+    else KA_GO(KA4(0x0) KA4(0x100) KA4(0x200) KA4(0x300) KA4(0x400) KA4(0x500) KA4(0x600) KA4(0x700));
+#undef KA_GO
+#undef KA4
 }
 #define ROWS_KERNARG_LINES(T) ((int)((sizeof(T) + 63) / 64))
 

@@ -459,6 +459,7 @@ __device__ __forceinline__ void epi_linear_frag(const DevProb &P, f32x16 (&acc)[
 
 template <int WM, int WN, int TN, int EPI, bool AKM, bool BKM>
 __global__ __launch_bounds__(256) void gemm_kernel(const DevLaunch L) {
+    rows_kernarg_warm<ROWS_KERNARG_LINES(DevLaunch)>();      // (one batch of scalar loads for the launch descriptor: common.h)
     constexpr int BM = 32 * WM;
     constexpr int BN = 32 * TN * WN;
     constexpr int LDC = BN + 4;
@@ -1793,6 +1794,7 @@ __global__ __launch_bounds__(512) void gemm_h3x_kernel(const DevLaunch L) {
 // Per chunk: A planes 2 x 4 KB, W planes 2 x 8 KB; four buffers = 96 KB, one workgroup per CU.
 template <bool AF32>
 __global__ __launch_bounds__(256) void gemm_h3m_kernel(const DevLaunch L) {
+    rows_kernarg_warm<ROWS_KERNARG_LINES(DevLaunch)>();      // (one batch of scalar loads for the launch descriptor: common.h)
     constexpr int TN = 2;
     constexpr int PA = 64 * 128, PB = 128 * 128;        // bytes per A / W image (row = 128 B: 32 hi | 32 lo halfs)
     constexpr int ST = PA + PB;                         // bytes per buffer
@@ -2229,6 +2231,7 @@ __device__ __forceinline__ void h3s_dma(unsigned lds_addr, const char *src) {
 // blocks - 32 KB per wave - stay in flight as in the 4-slot ring of the small tile.
 template <int EPI, int T, int NW = 4>
 __global__ __launch_bounds__(64 * NW) void gemm_h3s_kernel(const DevLaunch L) {
+    rows_kernarg_warm<ROWS_KERNARG_LINES(DevLaunch)>();      // (one batch of scalar loads for the launch descriptor: common.h)
     constexpr bool KSPLIT = EPI != EPI_VOCAB;
     static_assert(T == 1 || (T == 2 && KSPLIT), "wide skinny tile: K-split epilogues only");
     static_assert(NW == 4 || (NW == 8 && T == 1), "eight waves: the small tiles only");
@@ -2530,6 +2533,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_h3s_kernel(const DevLaunch L) {
 // Sums the ksplit partial slabs in a fixed order (deterministic) and applies the epilogue the
 // single-pass kernel would have applied.  blockIdx.y = problem.
 __global__ __launch_bounds__(256) void splitk_linear_kernel(const DevLaunch L) {
+    rows_kernarg_warm<ROWS_KERNARG_LINES(DevLaunch)>();      // (one batch of scalar loads for the launch descriptor: common.h)
     const DevProb &P = L.p[blockIdx.y];
     const long long n4 = (long long)P.M * (P.N >> 2);
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -2770,6 +2774,7 @@ __device__ __forceinline__ void gemv_accumulate(const DevProb &P, const long lon
 // two rounds of 8 rows.
 template <int EPI, int NW>
 __global__ __launch_bounds__(64 * NW) void gemv_rows_kernel(const DevLaunch L) {
+    rows_kernarg_warm<ROWS_KERNARG_LINES(DevLaunch)>();      // (one batch of scalar loads for the launch descriptor: common.h)
     constexpr int MR = GEMV_MAX_ROWS, NT = 64 * NW;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;

@@ -222,10 +222,11 @@ def _run_rl(det, lo, hi, s_lo, s_hi, steps):
     item, scs, split, draws = _rl_data(lo, hi, s_lo, s_hi)
     det.set_ciderd_scorer(split)                        # document frequencies over ALL images, on every rank
     orig = det.captioner.forward_rl
+    dev_draws = torch.from_numpy(draws).to('cuda:0')    # once, kept alive: the third iteration is captured into HIP graphs
 
     def replay_rl(*a, **k):
         if not k.get('sample_max', 1):
-            k['_replay'] = torch.from_numpy(draws).to('cuda:0')
+            k['_replay'] = dev_draws
         return orig(*a, **k)
     det.captioner.forward_rl = replay_rl
     out, first_grad = [], None
