@@ -287,3 +287,42 @@ def test_oracle_reproduces_the_references_first_rl_training_iteration(golden):
         got['seq2seq_loss'] = float(O.xe_criterion(logp2, t(s['captions'])[:, 1:], list(s['lengths']))) / n_data
     for k, v in got.items():
         np.testing.assert_allclose(v, g['dt1/loss_' + k][0], rtol=2e-4, atol=2e-6, err_msg=k)
+
+
+def test_oracle_reproduces_the_references_senti_branch_in_evaluation(golden):
+    """models/decoder.py:52-167 with data_type 'senti', training False (tests/golden/det_senti.npz, `dse/*`): labels from
+    the image sentiment detector, no CIDEr reward (`fact_reward = 0`), no XE and no seq2seq term - both batches of the
+    fixture; with the reference's multinomial draws replayed the oracle reproduces the four entries of the dictionary.
+    (The GPU test replays training and evaluation through the product.)"""
+    from insenticap_model_amd.helper_nets import SentenceSentimentClassifier, SentimentDetector
+    from insenticap_model_amd.rewards import get_cls_reward
+    from test_detector import load_helper
+    g = golden('det_senti')
+    V, Tn, B = 64, 8, 4
+    st = dict(synth.TINY_SETTINGS, **synth.HELPER_SETTINGS)
+    st['dropout_p'] = 0.0
+    idx2word = synth.make_idx2word(V)
+    ids = ids_for(V)
+    p = O.to_params(synth.make_weights(V, st, seed=1))
+    senti_det = load_helper(SentimentDetector(synth.SENTIMENT_CATEGORIES, st), 51)
+    sent_cls = load_helper(SentenceSentimentClassifier(idx2word, synth.SENTIMENT_CATEGORIES, st), 52)
+    batches, _ = synth.make_rl_batches(2, B, V, st, seq_len=Tn, seed=90)
+    t = torch.from_numpy
+    sums = {'da_loss': 0.0, 'cls_reward': 0.0, 'all_rewards': 0.0, 'cap_loss': 0.0}
+    for i, b in enumerate(batches):
+        fc, att, cpts, sentis = t(b[1]), t(b[2]), t(b[4]), t(b[5])
+        with torch.no_grad():
+            labels = senti_det.sample(att, 0.7)[0]
+            att3 = att.reshape(B, -1, att.shape[-1])
+            seq, lp, mk, P, _, _ = O.forward_rl(p, ids, fc, att3, cpts, sentis, labels, Tn, 0,
+                                                replay=t(g['dse/draws%d' % i]))
+            gseq, _, gmk, _, _, _ = O.forward_rl(p, ids, fc, att3, cpts, sentis, labels, Tn, 1)
+            sums['da_loss'] += float(O.domain_align_loss(P.cpt, P.fc_raw))
+            cls = get_cls_reward(seq, mk, gseq, gmk, labels, sent_cls, on_device=True)
+            sums['cls_reward'] += float(cls.mean(-1).mean(-1))
+            rewards = 0.4 * cls                                  # fact_reward = 0 (decoder.py:100-101), cls_flag 0.4
+            sums['all_rewards'] += float(rewards.mean(-1).mean(-1))
+            sums['cap_loss'] += float(O.reward_criterion(lp, mk, rewards))
+    n_data = 1                                                   # len(data) = len((senti_loader,)) in evaluation
+    for k, v in sums.items():
+        np.testing.assert_allclose(v / n_data, g['dse/loss_' + k][0], rtol=2e-4, atol=2e-6, err_msg=k)
