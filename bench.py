@@ -30,6 +30,7 @@ import json
 import os
 import sys
 import time
+_T0 = time.perf_counter()
 
 import socket
 import subprocess
@@ -157,6 +158,12 @@ def timed_region(fn, iters, dev):
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         el = float(tt)
     return el
+
+
+def progress(msg):
+    """A line on stderr per leg of the run (rank 0): a long default run shows where it is (and where it died)."""
+    if int(os.environ.get('RANK', '0')) == 0:
+        print('[bench %6.1f s] %s' % (time.perf_counter() - _T0, msg), file=sys.stderr, flush=True)
 
 
 def bench_xe_train(cap, dev, rank, world, iters=6, B=128, s2s_rows=80, curve='weak'):
@@ -727,6 +734,7 @@ def run(args):
                             ('table_build', lambda: bench_table_build(cap, inputs)),
                             ('rl_iteration', lambda: bench_rl(dev)),
                             ('rl_iteration_cold_sentiment_cache', lambda: bench_rl(dev, cache_image_sentiments=False))):
+                progress('extra: ' + key)
                 try:
                     extra[key] = fn()
                 except Exception as e:  # noqa: BLE001 - side measurements are reported, never fatal
@@ -745,6 +753,7 @@ def run(args):
             if 512 % world == 0 and 80 % world == 0:
                 jobs.append(('rl_iteration', lambda: bench_rl(dev, rank=rank, world=world)))
         for key, fn in jobs:
+            progress('extra: ' + key)
             try:
                 extra[key] = fn()
             except Exception as e:  # noqa: BLE001

@@ -86,27 +86,37 @@ static __device__ long long *g_rows_stamp;
 // one dword of each of the first NL lines in ONE batch and waits once: every later argument read hits the scalar cache.
 template <int NL>
 __device__ __forceinline__ void rows_kernarg_warm() {
-    static_assert(NL >= 1 && NL <= 32, "lines");
+    static_assert(NL >= 1 && NL <= 28, "lines");
     const unsigned long long kp = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
     // Every load targets the SAME scratch SGPR (its value is never used; scalar loads may return in any order, which is
     // all a write-after-write on a dead register can show) - one statement, so the register stays reserved until the wait.
+    // NOTHING past the struct is touched: a kernel that uses no hidden argument has a kernarg segment of exactly
+    // sizeof(struct) bytes, and the segment may end where the mapping ends (a read 64 ... 192 bytes past it faulted in
+    // a B = 1024 training graph).  The statement has four-line groups; the slots past line NL - 1 repeat that line.
     int d;
-    // (groups of four lines: at most 192 bytes past the struct, inside the 256 bytes of implicit arguments that follow it)
-#define KA4(B) \
-    "s_load_dword %0, %1, " #B "+0x0\n\ts_load_dword %0, %1, " #B "+0x40\n\ts_load_dword %0, %1, " #B "+0x80\n\t" \
-    "s_load_dword %0, %1, " #B "+0xc0\n\t"
-#define KA_GO(BODY) asm volatile(BODY "s_waitcnt lgkmcnt(0)" : "=&s"(d) : "s"(kp) : "memory")
+#define KA_O(i) "n"(64 * ((i) < NL ? (i) : NL - 1))
+#define KA_G(a, b, c, e) "s_load_dword %0, %1, %" #a "\n\ts_load_dword %0, %1, %" #b "\n\ts_load_dword %0, %1, %" #c \
+                         "\n\ts_load_dword %0, %1, %" #e "\n\t"
+#define KA_W "s_waitcnt lgkmcnt(0)"
     constexpr int G = (NL + 3) / 4;
-    if constexpr (G == 1) KA_GO(KA4(0x0));
-    else if constexpr (G == 2) KA_GO(KA4(0x0) KA4(0x100));
-    else if constexpr (G == 3) KA_GO(KA4(0x0) KA4(0x100) KA4(0x200));
-    else if constexpr (G == 4) KA_GO(KA4(0x0) KA4(0x100) KA4(0x200) KA4(0x300));
-    else if constexpr (G == 5) KA_GO(KA4(0x0) KA4(0x100) KA4(0x200) KA4(0x300) KA4(0x400));
-    else if constexpr (G == 6) KA_GO(KA4(0x0) KA4(0x100) KA4(0x200) KA4(0x300) KA4(0x400) KA4(0x500));
-    else if constexpr (G == 7) KA_GO(KA4(0x0) KA4(0x100) KA4(0x200) KA4(0x300) KA4(0x400) KA4(0x500) KA4(0x600));
-    else KA_GO(KA4(0x0) KA4(0x100) KA4(0x200) KA4(0x300) KA4(0x400) KA4(0x500) KA4(0x600) KA4(0x700));
-#undef KA_GO
-#undef KA4
+    if constexpr (G == 1)
+        asm volatile(KA_G(2, 3, 4, 5) KA_W : "=&s"(d) : "s"(kp), KA_O(0), KA_O(1), KA_O(2), KA_O(3) : "memory");
+    else if constexpr (G == 2)
+        asm volatile(KA_G(2, 3, 4, 5) KA_G(6, 7, 8, 9) KA_W : "=&s"(d)
+                     : "s"(kp), KA_O(0), KA_O(1), KA_O(2), KA_O(3), KA_O(4), KA_O(5), KA_O(6), KA_O(7) : "memory");
+    else if constexpr (G == 3)
+        asm volatile(KA_G(2, 3, 4, 5) KA_G(6, 7, 8, 9) KA_G(10, 11, 12, 13) KA_W : "=&s"(d)
+                     : "s"(kp), KA_O(0), KA_O(1), KA_O(2), KA_O(3), KA_O(4), KA_O(5), KA_O(6), KA_O(7), KA_O(8), KA_O(9),
+                       KA_O(10), KA_O(11) : "memory");
+    else
+        asm volatile(KA_G(2, 3, 4, 5) KA_G(6, 7, 8, 9) KA_G(10, 11, 12, 13) KA_G(14, 15, 16, 17) KA_G(18, 19, 20, 21)
+                     KA_G(22, 23, 24, 25) KA_G(26, 27, 28, 29) KA_W : "=&s"(d)
+                     : "s"(kp), KA_O(0), KA_O(1), KA_O(2), KA_O(3), KA_O(4), KA_O(5), KA_O(6), KA_O(7), KA_O(8), KA_O(9),
+                       KA_O(10), KA_O(11), KA_O(12), KA_O(13), KA_O(14), KA_O(15), KA_O(16), KA_O(17), KA_O(18), KA_O(19),
+                       KA_O(20), KA_O(21), KA_O(22), KA_O(23), KA_O(24), KA_O(25), KA_O(26), KA_O(27) : "memory");
+#undef KA_W
+#undef KA_G
+#undef KA_O
 }
 #define ROWS_KERNARG_LINES(T) ((int)((sizeof(T) + 63) / 64))
 

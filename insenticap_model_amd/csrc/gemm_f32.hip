@@ -1371,17 +1371,19 @@ __device__ __forceinline__ void h3_frag_from_f32(const char *row, int oct, int s
 }
 
 // Diagnostic build only (-DH3_STAMP=1, tools/h3_stamp.sh; the shipped library compiles none of it): s_memtime stamps
-// around gemm_h3_kernel's main loop and epilogue, summed over waves into g_h3_stamp = {waves, setup, main loop, epilogue}
-// (shader cycles), read back by isc_debug_h3_stamps.  The stamps go to memory nothing else reads.
+// around the main loop and epilogue of gemm_h3_kernel<vocab> (slot 0) and of gemm_h3x_kernel's LSTM form with K = 1024
+// (slot 1: att-LSTM), K = 1536 (slot 2: lang-LSTM) and its linear form (slot 3), summed over waves into g_h3_stamp[slot] =
+// {waves, setup, main loop, epilogue} (shader cycles), read back by isc_debug_h3_stamps (16 words).  The stamps go to
+// memory nothing else reads.
 #ifndef H3_STAMP
 #define H3_STAMP 0
 #endif
 #if H3_STAMP
-__device__ unsigned long long g_h3_stamp[4];
-extern "C" int isc_debug_h3_stamps(unsigned long long *out4_host, int reset) {
-    if (out4_host && hipMemcpyFromSymbol(out4_host, HIP_SYMBOL(g_h3_stamp), sizeof(g_h3_stamp)) != hipSuccess) return 1;
+__device__ unsigned long long g_h3_stamp[16];
+extern "C" int isc_debug_h3_stamps(unsigned long long *out16_host, int reset) {
+    if (out16_host && hipMemcpyFromSymbol(out16_host, HIP_SYMBOL(g_h3_stamp), sizeof(g_h3_stamp)) != hipSuccess) return 1;
     if (reset) {
-        const unsigned long long z[4] = {0, 0, 0, 0};
+        const unsigned long long z[16] = {};
         if (hipMemcpyToSymbol(HIP_SYMBOL(g_h3_stamp), z, sizeof(z)) != hipSuccess) return 1;
     }
     return ISC_OK;
@@ -1601,6 +1603,9 @@ __global__ __launch_bounds__(256, 2) void gemm_h3_kernel(const DevLaunch L) {
 // [4096 x 2048 x 1536] 97 -> 76 us (tools/h3_gemm_lab.hip).  Used when the launch has >= 224 such tiles.
 template <int EPI, bool AF32>
 __global__ __launch_bounds__(512) void gemm_h3x_kernel(const DevLaunch L) {
+#if H3_STAMP
+    const unsigned long long stamp0 = __builtin_amdgcn_s_memtime();
+#endif
     constexpr int BM = 256, BN = 128, TN = 4;
     constexpr int PA = 256 * 128, PB = 128 * 128;       // bytes per A / W image (row = 128 B: 32 hi | 32 lo halfs)
     constexpr int ST = PA + PB;                         // bytes per buffer (48 KB)
@@ -1746,6 +1751,9 @@ __global__ __launch_bounds__(512) void gemm_h3x_kernel(const DevLaunch L) {
     };
     // three buffers, two chunks in flight (6 DMAs per wave and chunk): vmcnt(6) leaves the younger chunk outstanding
     const int nchunks = Kp / 32;
+#if H3_STAMP
+    const unsigned long long stamp1 = __builtin_amdgcn_s_memtime();
+#endif
     stage(0);
     if (nchunks > 1) stage(1);
     if (nchunks > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
@@ -1772,6 +1780,9 @@ __global__ __launch_bounds__(512) void gemm_h3x_kernel(const DevLaunch L) {
         chunk(c, I0{}, I1{});
         if (c + 1 < nchunks) chunk(c + 1, I1{}, I0{});
     }
+#if H3_STAMP
+    const unsigned long long stamp2 = __builtin_amdgcn_s_memtime();
+#endif
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -1786,6 +1797,19 @@ __global__ __launch_bounds__(512) void gemm_h3x_kernel(const DevLaunch L) {
     } else {
         epi_linear_frag16<NB, AF32>(P, acc0, wm * 32, 0, lane, row0, col0);
     }
+#if H3_STAMP
+    if (EPI != EPI_VOCAB) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the epilogue's stores have left
+        const unsigned long long stamp3 = __builtin_amdgcn_s_memtime();
+        const int slot = EPI == EPI_LSTM ? (Kp == 1024 ? 1 : Kp == 1536 ? 2 : -1) : 3;
+        if (lane == 0 && slot >= 0) {
+            atomicAdd(&g_h3_stamp[4 * slot + 0], 1ull);
+            atomicAdd(&g_h3_stamp[4 * slot + 1], stamp1 - stamp0);
+            atomicAdd(&g_h3_stamp[4 * slot + 2], stamp2 - stamp1);
+            atomicAdd(&g_h3_stamp[4 * slot + 3], stamp3 - stamp2);
+        }
+    }
+#endif
 }
 
 #define H3M_NBUF 4

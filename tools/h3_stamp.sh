@@ -9,7 +9,7 @@ L=$R/insenticap_model_amd/lib
 mkdir -p $R/tools/_lab
 if [ "$1" = build ]; then
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -DH3_STAMP=1 -c $R/insenticap_model_amd/csrc/gemm_f32.hip -o /tmp/gemm_stamp.o
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/tools/_lab/libisc_stamp.so /tmp/gemm_stamp.o $L/attention.o $L/pointwise.o $L/backward.o $L/step.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/tools/_lab/libisc_stamp.so /tmp/gemm_stamp.o $L/attention.o $L/pointwise.o $L/backward.o $L/step.o $L/rows.o
   exit 0
 fi
 ISC_HIP_LIB=$R/tools/_lab/libisc_stamp.so timeout -k 10 300 python3 $R/tools/h3_stamp.py
