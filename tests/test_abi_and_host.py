@@ -49,6 +49,74 @@ def test_no_kernel_spills_or_uses_scratch():
     assert gemm and all(r['occupancy'] >= 2 for r in gemm)   # 2 workgroups per CU (the LDS limit)
 
 
+def _code_objects(path, tmp):
+    """The gfx950 code objects of a fat shared library: the clang offload bundles of its .hip_fatbin section."""
+    import struct
+    fat = os.path.join(tmp, 'fat.bin')
+    subprocess.check_call(['/opt/rocm/lib/llvm/bin/llvm-objcopy', '-O', 'binary', '--only-section=.hip_fatbin', path, fat])
+    raw = open(fat, 'rb').read()
+    magic, out, pos = b'__CLANG_OFFLOAD_BUNDLE__', [], 0
+    while True:
+        i = raw.find(magic, pos)
+        if i < 0:
+            return out
+        q = i + len(magic)
+        n, = struct.unpack_from('<Q', raw, q)
+        q += 8
+        for _ in range(n):
+            off, size, tl = struct.unpack_from('<QQQ', raw, q)
+            q += 24
+            if b'gfx950' in raw[q:q + tl] and size:
+                out.append(raw[i + off:i + off + size])
+            q += tl
+        pos = i + len(magic)
+
+
+def test_kernarg_warm_up_reads_stay_inside_the_kernarg_segment(tmp_path):
+    """csrc/common.h rows_kernarg_warm touches one dword per 64-byte line of the argument struct in one batch.  A kernel
+    without hidden arguments has a kernarg segment of exactly sizeof(struct) bytes: a load past it is out of bounds (it
+    faulted once, in a B = 1024 training graph, when a segment ended where its mapping ended).  Checked on the SHIPPED
+    code objects: every run of >= 4 scalar loads into one and the same register ends inside the segment."""
+    import re
+    cos = _code_objects(_build.LIB_PATH, str(tmp_path))
+    assert len(cos) >= 4
+    runs = 0
+    for n, co in enumerate(cos):
+        f = str(tmp_path / ('k%d.co' % n))
+        open(f, 'wb').write(co)
+        notes = subprocess.check_output(['/opt/rocm/lib/llvm/bin/llvm-readelf', '--notes', f]).decode()
+        size = {}
+        for m in re.finditer(r'\.kernarg_segment_size:\s*(\d+).*?\.name:\s*(\S+)', notes, re.S):
+            size[m.group(2)] = int(m.group(1))
+        dis = subprocess.check_output(['/opt/rocm/lib/llvm/bin/llvm-objdump', '-d', '--mcpu=gfx950', f]).decode()
+        cur, run = None, []
+
+        def close():
+            nonlocal runs
+            if len(run) >= 4:
+                runs += 1
+                assert cur in size, cur
+                assert max(run) + 4 <= size[cur], (cur, size[cur], [hex(x) for x in run])
+            run.clear()
+        last = None
+        for line in dis.splitlines():
+            m = re.match(r'^[0-9a-f]+ <(\S+)>:', line)
+            if m:
+                close()
+                cur, last = m.group(1), None
+                continue
+            m = re.match(r'\s+s_load_dword (s\d+), (s\[\d+:\d+\]), (0x[0-9a-f]+|\d+)\s', line)
+            if m and (m.group(1), m.group(2)) == last:
+                run.append(int(m.group(3), 0))
+            else:
+                close()
+                if m:
+                    run.append(int(m.group(3), 0))
+            last = (m.group(1), m.group(2)) if m else None
+        close()
+    assert runs >= 20           # the GEMM / scan / rows kernels carry the warm-up
+
+
 def test_ctypes_struct_layout_matches_c(tmp_path):
     """Compile a tiny C program against the header and compare sizeof/offsetof with ctypes."""
     prog = r'''
