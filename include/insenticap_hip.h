@@ -469,6 +469,11 @@ int isc_rows_vocab_fwd(const float *h, int ldh, const float *W, int ldw, const f
  * keep from step to step), 2 = every stream non-temporal.  Returns the previous value. */
 int isc_set_rows_nt(int mode);
 long long isc_rows_launches(void);    /* launches of rows kernels so far (tests assert the path was taken) */
+/* isc_step_fwd's gated scan (inference steps that carry gate_Gc / gate_Gs) runs on the rows scan kernel - one
+ * 1024-thread workgroup per row, the row's rows of P / V / G in flight at once - up to this many rows (default 256; needs
+ * R <= 36, Mw <= 12, A = E = W <= 512); above it, or with 0, on attn_scan_gate_kernel.  rows < 0 only queries.  Returns
+ * the previous value. */
+int isc_set_rows_scan_max(int rows);
 
 /* Top-k + candidate merge of one beam step in ONE launch (captioner.py:390-411), from the tile statistics and tile
  * candidates isc_rows_step_fwd left: per row the log-softmax normaliser is folded from (pmax, psum), the row's top-`beam`

@@ -48,23 +48,6 @@ __device__ __forceinline__ float4 ld4(const float4 *p, bool nt) {
     return *p;
 }
 
-// f16 planes of four consecutive outputs d .. d+3 of row `row` of a [rows, D] tensor (split-f16 GEMM operands:
-// hi = f16(x), lo = f16((x - hi) * 2048); interleaved layout of gemm_f32.hip: per row and 32-wide block 32 hi then
-// 32 lo values, lo pointer = hi pointer + 32)
-__device__ __forceinline__ void store_planes4(_Float16 *hi, _Float16 *lo, long long row, int d, int D, const float4 &x) {
-    const long long o = row * 2 * D + (d >> 5) * 64 + (d & 31);
-    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-    const float v[4] = {x.x, x.y, x.z, x.w};
-    h4 a, b;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        a[e] = (_Float16)v[e];
-        b[e] = (_Float16)((v[e] - (float)a[e]) * 2048.f);
-    }
-    *reinterpret_cast<h4 *>(hi + o) = a;
-    *reinterpret_cast<h4 *>(lo + o) = b;
-}
-
 template <int NA, bool NT>  // float4 per lane along A: A <= 256*NA; NT: per-caption rows by non-temporal loads
 __global__ __launch_bounds__(256) void attn_scan_kernel(const DevScanLaunch L) {
     rows_kernarg_warm<ROWS_KERNARG_LINES(DevScanLaunch)>();

@@ -80,6 +80,27 @@ static __device__ long long *g_rows_stamp;
 #define RSTAMP_K(KID, SLOT) do {} while (0)
 #endif
 
+// rows.hip: the gated scan on one 1024-thread workgroup per row (also isc_step_fwd's, for inference steps of few hundred rows)
+bool rows_scan_ok(const isc_step_plan *p);
+int rows_scan_gate(const isc_step_plan *p, int row_div, const int *skip, hipStream_t st, int planes);
+
+// f16 planes of four consecutive outputs d .. d+3 of row `row` of a [rows, D] tensor (split-f16 GEMM operands:
+// hi = f16(x), lo = f16((x - hi) * 2048); interleaved layout of gemm_f32.hip: per row and 32-wide block 32 hi then
+// 32 lo values, lo pointer = hi pointer + 32)
+__device__ __forceinline__ void store_planes4(_Float16 *hi, _Float16 *lo, long long row, int d, int D, const float4 &x) {
+    const long long o = row * 2 * D + (d >> 5) * 64 + (d & 31);
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    const float v[4] = {x.x, x.y, x.z, x.w};
+    h4 a, b;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        a[e] = (_Float16)v[e];
+        b[e] = (_Float16)((v[e] - (float)a[e]) * 2048.f);
+    }
+    *reinterpret_cast<h4 *>(hi + o) = a;
+    *reinterpret_cast<h4 *>(lo + o) = b;
+}
+
 // Kernel arguments are read by scalar loads where they are first used; every first touch of a 64-byte line of the
 // kernarg segment is a scalar-cache miss (a round trip to L2 or beyond), and hipcc places those loads lazily, one
 // dependent wait after the other - five lines cost five round trips in front of the first weight load.  This touches

@@ -760,6 +760,7 @@ struct RScanArgs {
     const float *zh, *b_c, *b_s, *w_g, *b_g;
     float *f, *alpha[2], *beta;
     long long alpha_ld[2], beta_ld;
+    _Float16 *f_hi, *f_lo;                     // optional split-f16 planes of f (the MFMA lang-LSTM of larger batches)
 };
 #define RS_NWC 12
 #define RS_NWS 4
@@ -997,19 +998,24 @@ __global__ __launch_bounds__(1024) void rows_scan_gate_kernel(const RScanArgs a)
         f.x = beta * sv.x + (1.0f - beta) * sw.x; f.y = beta * sv.y + (1.0f - beta) * sw.y;
         f.z = beta * sv.z + (1.0f - beta) * sw.z; f.w = beta * sv.w + (1.0f - beta) * sw.w;
         reinterpret_cast<float4 *>(a.f + (long long)b * A)[tid] = f;
+        if (a.f_hi) store_planes4(a.f_hi, a.f_lo, b, 4 * tid, A, f);
     }
     RSTAMP(6);
 #undef RSTAMP_KID
 }
 
-static bool rows_scan_ok(const isc_step_plan *p) {
+bool rows_scan_ok(const isc_step_plan *p) {
     return p->att_e && p->words_e && p->gate_Gc && p->gate_Gs && p->A == p->E && p->A == p->W && p->A <= 512 &&
            (p->A & 3) == 0 && p->R >= 1 && p->Mw >= 1;
 }
 
-static int rows_scan_gate(const isc_step_plan *p, int row_div, const int *skip, hipStream_t st) {
+// Also the gated scan of isc_step_fwd for inference steps of up to ROWS_SCAN_MAX rows (step.hip; `planes`: the f16 planes of
+// f that its MFMA lang-LSTM reads): one 1024-thread workgroup per row with the row's 290 KB in flight at once, against a
+// 256-thread workgroup walking the regions (B = 128: 15.0 -> see profiles) - one round of the chip up to 256 rows.
+int rows_scan_gate(const isc_step_plan *p, int row_div, const int *skip, hipStream_t st, int planes) {
     RScanArgs a = {};
     a.row_div = row_div > 1 ? row_div : 1; a.skip = skip;
+    if (planes) { a.f_hi = static_cast<_Float16 *>(p->f_hi); a.f_lo = static_cast<_Float16 *>(p->f_lo); }
     a.P[0] = p->att_p; a.V[0] = p->att_e; a.G[0] = p->gate_Gc; a.q[0] = p->qa; a.w[0] = p->w_alpha_c; a.wb[0] = p->b_alpha_c;
     a.P[1] = p->words_p; a.V[1] = p->words_e; a.G[1] = p->gate_Gs; a.q[1] = p->qw; a.w[1] = p->w_alpha_s; a.wb[1] = p->b_alpha_s;
     a.q2 = p->label_w;
@@ -1080,7 +1086,7 @@ extern "C" int isc_rows_step_fwd(const isc_step_plan *p, const isc_rows_ext *x, 
         const int N[3] = {A, A, A}, ldc[3] = {A, A, A};
         RET(rows_linear3(p->h1, H, H, rows, Ws, bs, Cs, N, ldc, 3, skip, st));
     }
-    RET(rows_scan_gate(p, row_div, skip, st));
+    RET(rows_scan_gate(p, row_div, skip, st, 0));
     {   // lang-LSTM over cat[f, h_att] (captioner.py:180-181)
         const float *As[3] = {p->f, p->h1, p->h2_prev}, *Ws[3] = {p->Wih2, p->Wih2 + E, p->Whh2};
         const int lda[3] = {E, H, H}, ldw[3] = {ld2, ld2, H}, K[3] = {E, H, H}, ind[3] = {0, 0, 1};

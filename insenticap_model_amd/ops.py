@@ -401,6 +401,12 @@ def rows_stats_tile(V):
     return _lib.load().isc_rows_stats_tile(int(V))
 
 
+def set_rows_scan_max(rows):
+    """Largest inference step whose gated scan runs on the one-workgroup-per-row kernel (isc_set_rows_scan_max; 0 = off,
+    negative = query).  Returns the previous value."""
+    return _lib.load().isc_set_rows_scan_max(int(rows))
+
+
 def rows_step_supported(plan):
     return bool(_lib.load().isc_rows_step_supported(C.byref(plan)))
 

@@ -23,6 +23,22 @@ def _n():
     return ops._lib.load().isc_rows_launches()
 
 
+class _region_walk_scan:
+    """The general step with its gated scan on attn_scan_gate_kernel (isc_set_rows_scan_max(0)): "the kernels this path
+    replaces" of the comparisons below; the default hands steps of up to 256 rows to the rows scan kernel as well."""
+
+    def __init__(self, on=True):
+        self.on = on
+
+    def __enter__(self):
+        self.prev = ops.set_rows_scan_max(0) if self.on else None
+
+    def __exit__(self, *exc):
+        if self.on:
+            ops.set_rows_scan_max(self.prev)
+        return False
+
+
 def _ext(V, beam=0, last=None, cons=0, special=1, cand=None):
     x = _lib.RowsExt()
     x.stats_tile, x.beam = ops.rows_stats_tile(V), beam
@@ -130,7 +146,8 @@ def test_whole_step_against_the_general_kernels(rows, V, st, R):
                 if src is not None:
                     x.src_row = src.data_ptr()
             n0 = _n()
-            cap._step(p, P, ws, None, hc, cc, hn, cn, aC, aS, bG, tok=tok, rows_ext=x)
+            with _region_walk_scan(not rows_path):
+                cap._step(p, P, ws, None, hc, cc, hn, cn, aC, aS, bG, tok=tok, rows_ext=x)
             torch.cuda.synchronize()
             assert _n() - n0 == (5 if rows_path else 0)
             mx = ws['pmax'].max(1).values
@@ -224,7 +241,8 @@ def test_beam_search_on_this_path_equals_the_general_path(V, st, n_img, beam, R)
     for on in (True, False):
         cap.rows_step = on
         n0 = _n()
-        out = cap.sample_batch(d['fc_feats'], d['att_feats'], d['senti_words'], d['senti_labels'], beam, 1, 20)
+        with _region_walk_scan(not on):
+            out = cap.sample_batch(d['fc_feats'], d['att_feats'], d['senti_words'], d['senti_labels'], beam, 1, 20)
         torch.cuda.synchronize()
         launched = _n() - n0
         # (the live-image counter is read every fourth step: a search that ends early has enqueued up to three more)
@@ -260,7 +278,7 @@ def test_small_greedy_rollout_on_this_path_equals_the_general_path(B):
     for on in (True, False):
         cap.rows_step = on
         n0 = _n()
-        with torch.no_grad():
+        with torch.no_grad(), _region_walk_scan(not on):
             seq, lp, mk = cap(d['fc_feats'], d['att_feats'], d['cpt_words'], d['senti_words'], d['senti_labels'], 20, 1, mode='rl')
         torch.cuda.synchronize()
         assert ((_n() - n0) == 5 * 20) if on else (_n() == n0)
@@ -281,3 +299,35 @@ def test_small_greedy_rollout_on_this_path_equals_the_general_path(B):
                               _replay=res[False][0].to(DEV))
     assert torch.equal(rep[0], rep0[0])
     np.testing.assert_allclose(rep[1].cpu().numpy(), rep0[1].cpu().numpy(), atol=1e-4)
+
+
+@pytest.mark.parametrize('B,R', [(9, 36), (128, 36), (200, 36), (256, 36), (64, 6)])
+def test_gated_scan_of_larger_steps_on_the_row_kernel_equals_the_region_walk(B, R):
+    """isc_step_fwd's gated scan for up to isc_set_rows_scan_max rows runs on rows_scan_gate_kernel (one 1024-thread
+    workgroup per row, f and its f16 planes written for the MFMA lang-LSTM): the same greedy roll-out with it and on
+    attn_scan_gate_kernel - tokens, log-probs, attention weights."""
+    cap = _captioner(10000, synth.DEFAULT_SETTINGS, seed=2)
+    cap.enable_rollout_graphs(False)
+    d = _inputs(B, 10000, synth.DEFAULT_SETTINGS, R, seed=13)
+    res = {}
+    prev = ops.set_rows_scan_max(-1)
+    assert prev == 256
+    try:
+        for limit in (256, 0):
+            ops.set_rows_scan_max(limit)
+            n0 = _n()
+            with torch.no_grad():
+                seq, lp, mk = cap(d['fc_feats'], d['att_feats'], d['cpt_words'], d['senti_words'], d['senti_labels'], 20, 1,
+                                  mode='rl')
+            torch.cuda.synchronize()
+            assert (_n() - n0 == 20) if limit else (_n() == n0)
+            res[limit] = (seq.cpu(), lp.cpu(), mk.cpu(), cap.cont_weights.cpu(), cap.senti_weights.cpu())
+    finally:
+        ops.set_rows_scan_max(prev)
+    a, b = res[256], res[0]
+    same = (a[0] == b[0]).all(1)
+    assert same.float().mean() >= 0.9
+    assert float((a[1][same] - b[1][same]).abs().max()) < 1e-4
+    assert torch.equal(a[2][same], b[2][same])
+    np.testing.assert_allclose(a[3][same].numpy(), b[3][same].numpy(), atol=1e-5)
+    np.testing.assert_allclose(a[4][same].numpy(), b[4][same].numpy(), atol=1e-5)
