@@ -469,11 +469,16 @@ int isc_rows_vocab_fwd(const float *h, int ldh, const float *W, int ldw, const f
  * keep from step to step), 2 = every stream non-temporal.  Returns the previous value. */
 int isc_set_rows_nt(int mode);
 long long isc_rows_launches(void);    /* launches of rows kernels so far (tests assert the path was taken) */
-/* isc_step_fwd's gated scan (inference steps that carry gate_Gc / gate_Gs) runs on the rows scan kernel - one
- * 1024-thread workgroup per row, the row's rows of P / V / G in flight at once - up to this many rows (default 256; needs
- * R <= 36, Mw <= 12, A = E = W <= 512); above it, or with 0, on attn_scan_gate_kernel.  rows < 0 only queries.  Returns
- * the previous value. */
+/* isc_attn_scan_gate_fwd (and with it isc_step_fwd's gated scan) runs launches of up to this many rows on the rows scan
+ * kernel - one 1024-thread workgroup per row, the row's rows of P / V / G in flight at once - when the shape is its own
+ * (v / s not wanted on their own, R <= 36, Mw <= 12, A = D <= 512); default 256, 0 = never (attn_scan_gate_kernel walks
+ * the regions).  rows < 0 only queries.  Returns the previous value. */
 int isc_set_rows_scan_max(int rows);
+/* Vocabulary launches of the skinny split-f16 path (isc_vocab_fwd / isc_step_fwd at a few hundred rows, one activation
+ * segment): 1 (default) = gemm_h3v_kernel (k-block stages shared by the workgroup: the activation block fetched once, two
+ * blocks in flight; taken up to 512 workgroups), 0 = the per-wave-ring gemm_h3s_kernel form it replaced (tests, A/B runs),
+ * n > 1 = on, taken up to n workgroups (tuning).  Returns the previous value. */
+int isc_set_h3v(int on);
 
 /* Top-k + candidate merge of one beam step in ONE launch (captioner.py:390-411), from the tile statistics and tile
  * candidates isc_rows_step_fwd left: per row the log-softmax normaliser is folded from (pmax, psum), the row's top-`beam`

@@ -434,6 +434,10 @@ extern "C" int isc_attn_scan_gate_fwd(const isc_scan_gate_args *a, int B, void *
     if (B <= 0) return ISC_E_SHAPE;
     if (!a->zh || !a->b_gc || !a->b_gs || !a->w_gate || !a->f || !a->G[0] || !a->G[1]) return ISC_E_NULL;
     if ((a->f_hi == nullptr) != (a->f_lo == nullptr)) return ISC_E_NULL;
+    {   // few hundred rows, <= 36 regions / 12 words: one 1024-thread workgroup per row (rows.hip)
+        int rc = ISC_OK;
+        if (rows_scan_gate_try(a, B, (hipStream_t)stream, &rc)) return rc;
+    }
     DevScanGate L = {};
     size_t lds = 0;
     const int A = a->scan[0].A, D = a->scan[0].D;

@@ -80,9 +80,9 @@ static __device__ long long *g_rows_stamp;
 #define RSTAMP_K(KID, SLOT) do {} while (0)
 #endif
 
-// rows.hip: the gated scan on one 1024-thread workgroup per row (also isc_step_fwd's, for inference steps of few hundred rows)
-bool rows_scan_ok(const isc_step_plan *p);
-int rows_scan_gate(const isc_step_plan *p, int row_div, const int *skip, hipStream_t st, int planes);
+// rows.hip: isc_attn_scan_gate_fwd's launches of up to isc_set_rows_scan_max rows on the one-workgroup-per-row kernel.
+// Returns 1 when it took the launch (*rc = its status), 0 when the shape is not its own.
+int rows_scan_gate_try(const isc_scan_gate_args *a, int rows, hipStream_t st, int *rc);
 
 // f16 planes of four consecutive outputs d .. d+3 of row `row` of a [rows, D] tensor (split-f16 GEMM operands:
 // hi = f16(x), lo = f16((x - hi) * 2048); interleaved layout of gemm_f32.hip: per row and 32-wide block 32 hi then

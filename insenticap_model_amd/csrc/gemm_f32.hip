@@ -2248,6 +2248,35 @@ __device__ __forceinline__ void h3s_dma(unsigned lds_addr, const char *src) {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(lds_addr), "v"(src) : "memory");
 }
 
+// The 128-column statistics of a BM-row vocabulary tile from its four 32-column waves' (epi_vocab_frag<1, 4, BM>).
+template <int BM>
+__device__ __forceinline__ void h3s_vocab_combine(const DevProb &P, const float *smem, int tid, int row0, int tn) {
+    const float *smx = smem;
+    const float *ssm = smem + 4 * BM;
+    const int *six = reinterpret_cast<const int *>(smem + 2 * 4 * BM);
+    if (tid < BM && row0 + tid < P.M) {
+        const int row = tid;
+        float mx = smx[row];
+        int ix = six[row];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            const float ov = smx[w * BM + row];
+            const int oi = six[w * BM + row];
+            if (ov > mx || (ov == mx && oi < ix)) { mx = ov; ix = oi; }
+        }
+        float sm = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float wm_ = smx[w * BM + row];          // -inf: that wave had no valid column
+            if (wm_ > -INFINITY) sm += ssm[w * BM + row] * __expf(wm_ - mx);
+        }
+        const long long o = (long long)(row0 + row) * P.ntile_total + tn;
+        P.pmax[o] = mx;
+        P.psum[o] = sm;
+        P.pidx[o] = ix;
+    }
+}
+
 // T = 2 (K-split epilogues only) doubles the tile to 64 x 64: a loaded row then feeds two MFMA tiles instead of one, so
 // a launch needs half the bytes per output - the shape for launches of several rounds of 32 x 32 tiles (LSTM cell at
 // M = 512 ... 1024) that are still too few 128-row tiles to fill the chip.  Its slots are 16 KB (64-row images), its
@@ -2448,31 +2477,8 @@ __global__ __launch_bounds__(64 * NW) void gemm_h3s_kernel(const DevLaunch L) {
         }
         f32x16 accv[1] = {acc0[0][0]};
         if (NW == 4 || wave < 4) epi_vocab_frag<1, 4, BM>(P, accv, 0, wave * 32, wave, lane, row0, col0, tn, smem);
-        float *smx = smem;
-        float *ssm = smem + 4 * BM;
-        int *six = reinterpret_cast<int *>(smem + 2 * 4 * BM);
         __syncthreads();
-        if (tid < BM && row0 + tid < M) {
-            const int row = tid;
-            float mx = smx[row];
-            int ix = six[row];
-#pragma unroll
-            for (int w = 1; w < 4; ++w) {
-                const float ov = smx[w * BM + row];
-                const int oi = six[w * BM + row];
-                if (ov > mx || (ov == mx && oi < ix)) { mx = ov; ix = oi; }
-            }
-            float sm = 0.f;
-#pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                const float wm_ = smx[w * BM + row];          // -inf: that wave had no valid column
-                if (wm_ > -INFINITY) sm += ssm[w * BM + row] * __expf(wm_ - mx);
-            }
-            const long long o = (long long)(row0 + row) * P.ntile_total + tn;
-            P.pmax[o] = mx;
-            P.psum[o] = sm;
-            P.pidx[o] = ix;
-        }
+        h3s_vocab_combine<BM>(P, smem, tid, row0, tn);
         return;
     } else {
         // partial tile of this wave -> LDS (C/D layout: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5))
@@ -2551,6 +2557,118 @@ __global__ __launch_bounds__(64 * NW) void gemm_h3s_kernel(const DevLaunch L) {
             lstm_cells<NR>(P, gm, tn * UN + u, ok, g);
         }
     }
+}
+
+// ---------------------------------------------------------------- H3V: the vocabulary tile of few-hundred-row launches
+// Same 32 x 128 tile, statistics and epilogue as gemm_h3s_kernel<EPI_VOCAB> (wave w owns columns 32 w .. 32 w + 31 over
+// the whole K), different operand movement.  There every wave stages its own copy of the A block next to its W block in
+// a private two-slot ring - A is fetched four times and ONE 8 KB block per wave is in flight: 64 KB per CU against a
+// ~1.7 us round trip is ~9.5 TB/s over the chip, and 316 workgroups x 512 KB take the 20 us they are measured at
+// (B = 128).  Here a k-block stage is shared by the workgroup: the A block once (each wave brings a quarter) + the four
+// waves' W blocks = 20 KB, three stages (60 KB: two workgroups per CU), two blocks in flight behind the one being
+// multiplied, one barrier per block: 320 KB per workgroup.  B = 128: 20.2 -> 18.2 us (kernel trace), roll-out 1.385 -> 1.32 ms.  (Tried first: W fragments straight from global memory into the
+// MFMA operand registers, no LDS for W - a lane then touches 16 bytes of a 128-byte row line per instruction, the L1
+// does not merge the four touches of a line, and the launch pulled ~4x its bytes from L2: 26 us.)
+#ifndef H3V_STAGES
+#define H3V_STAGES 3        // (four stages, 80 KB, measured the same: B = 128 roll-out 1.324 vs 1.323 ms)
+#endif
+#define H3V_STAGE_BYTES (5 * 4096)
+template <bool AF32>
+__global__ __launch_bounds__(256) void gemm_h3v_kernel(const DevLaunch L) {
+    rows_kernarg_warm<ROWS_KERNARG_LINES(DevLaunch)>();
+    constexpr int BM = 32, BN = 128;
+    extern __shared__ __attribute__((aligned(16))) float smem[];     // stages of [A image 4 KB | 4 W images 4 KB each]
+    char *lds = reinterpret_cast<char *>(smem);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int pi, tm, tn, ks, ksplit;
+    map_tile(L, pi, tm, tn, ks, ksplit);
+    const DevProb &P = L.p[pi];
+    const int M = P.M, N = P.N, Kp = P.Kp, nblk = Kp >> 5;
+    const int row0 = tm * BM, col0 = tn * BN;
+    const int fr = lane & 31, fh = lane >> 5, fsw = (fr >> 1) & 7;
+
+    // DMA lanes (pieces of 8 rows x 128 B; lane position lane & 7 fetches chunk pos ^ swizzle(row): the image layout of
+    // gemm_h3s_kernel).  A: wave w brings rows 8 w .. 8 w + 7 of the block; W: the wave's own 32 columns, four pieces.
+    const DevASeg a = P.ap[0];
+    const bool af32 = AF32 && a.hi == nullptr;
+    const char *asrc;
+    const char *wsrc[4];
+    {
+        const int prow = 8 * wave + (lane >> 3);
+        const int ar = row0 + prow < M ? row0 + prow : M - 1;
+        const int choff = ((lane & 7) ^ ((prow >> 1) & 7)) * 16;
+        asrc = af32 ? reinterpret_cast<const char *>(P.seg[0].A + (long long)ar * P.seg[0].lda) + choff
+                    : reinterpret_cast<const char *>(a.hi + (long long)ar * a.ld) + choff;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int r = 8 * p + (lane >> 3);
+            const int c = col0 + wave * 32 + r;
+            wsrc[p] = reinterpret_cast<const char *>(P.Wh) + (long long)(c < N ? c : N - 1) * 4 * Kp +
+                      ((lane & 7) ^ ((r >> 1) & 7)) * 16;
+        }
+    }
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds);
+    auto issue = [&](int b, int stage) __attribute__((always_inline)) {       // 5 DMA instructions per wave
+        const unsigned base = lds0 + stage * H3V_STAGE_BYTES;
+        h3s_dma(base + wave * 1024, asrc + (long long)b * 128);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) h3s_dma(base + 4096 + wave * 4096 + p * 1024, wsrc[p] + (long long)b * 128);
+    };
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    constexpr int AHEAD = H3V_STAGES - 1;                  // blocks in flight behind the one being multiplied
+    static_assert(AHEAD >= 1 && AHEAD <= 4, "stages");
+#pragma unroll
+    for (int i = 0; i < AHEAD; ++i)
+        if (i < nblk) issue(i, i);
+    int st = 0;                                            // stage of block b
+    for (int b = 0; b < nblk; ++b) {
+        const int younger = nblk - 1 - b < AHEAD - 1 ? nblk - 1 - b : AHEAD - 1;    // blocks issued after block b
+        if (younger >= 3) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+        else if (younger == 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                   // block b is in LDS for every wave; stage of block b - 1 is free
+        if (b + AHEAD < nblk) issue(b + AHEAD, st == 0 ? H3V_STAGES - 1 : st - 1);
+        const char *ia = lds + st * H3V_STAGE_BYTES + fr * 128;
+        const char *iw = ia + 4096 + wave * 4096;
+        h8 a1[2], a2[2], b1[2], b2[2];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            if (af32) {
+                const float4 v0 = *reinterpret_cast<const float4 *>(ia + (((4 * kk + 2 * fh) ^ fsw) * 16));
+                const float4 v1 = *reinterpret_cast<const float4 *>(ia + (((4 * kk + 2 * fh + 1) ^ fsw) * 16));
+                const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const _Float16 h = (_Float16)x[e];
+                    a1[kk][e] = h;
+                    a2[kk][e] = (_Float16)((x[e] - (float)h) * 2048.f);
+                }
+            } else {
+                a1[kk] = *reinterpret_cast<const h8 *>(ia + (((2 * kk + fh) ^ fsw) * 16));
+                a2[kk] = *reinterpret_cast<const h8 *>(ia + (((4 + 2 * kk + fh) ^ fsw) * 16));
+            }
+            b1[kk] = *reinterpret_cast<const h8 *>(iw + (((2 * kk + fh) ^ fsw) * 16));
+            b2[kk] = *reinterpret_cast<const h8 *>(iw + (((4 + 2 * kk + fh) ^ fsw) * 16));
+        }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[kk], b1[kk], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[kk], b2[kk], acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2[kk], b1[kk], acc1, 0, 0, 0);
+        }
+        st = st == H3V_STAGES - 1 ? 0 : st + 1;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc0[r] = fmaf(acc1[r], 1.f / 2048.f, acc0[r]);
+    __syncthreads();                                     // every wave is done with the stages: LDS is free
+    f32x16 accv[1] = {acc0};
+    epi_vocab_frag<1, 4, BM>(P, accv, 0, wave * 32, wave, lane, row0, col0, tn, smem);
+    __syncthreads();
+    h3s_vocab_combine<BM>(P, smem, tid, row0, tn);
 }
 
 // ---------------------------------------------------------------- split-K reduction + epilogue
@@ -3508,6 +3626,10 @@ extern "C" long long isc_h3s_launches(void) { return g_h3s_launches.load(); }
 #define H3S_EIGHT_WAVES_MIN_K 1024
 #define H3S_MAX_WGS_VOCAB 384
 
+// (tests / A-B runs: 0 sends vocabulary launches of the skinny path back to gemm_h3s_kernel<EPI_VOCAB>)
+static std::atomic<int> g_h3v_on{1};
+extern "C" int isc_set_h3v(int on) { return g_h3v_on.exchange(on < 0 ? 0 : on); }
+
 template <int EPI, int T, int NW = 4>
 static int launch_h3s(const DevLaunch &L, hipStream_t st) {
     // waves x ring slots x (A image + W image): 128 KB for the K-split tiles, 64 KB for the vocabulary projection
@@ -3546,7 +3668,8 @@ static int h3s_pick_tile(const DevLaunch &L, int mode) {
     }
     if (mode == 4) return wide_ok ? 2 : 1;
     if (mode == 3) return 1;
-    if (EPI == EPI_VOCAB) return w1 < H3S_MAX_WGS_VOCAB ? 1 : 0;
+    // (with gemm_h3v_kernel up to 512 workgroups = one round at two per CU: M = 160 / 192 roll-outs 1.67 / 1.79 -> 1.63 / 1.78 ms)
+    if (EPI == EPI_VOCAB) return w1 < (g_h3v_on.load() > 1 ? g_h3v_on.load() : g_h3v_on.load() == 1 ? 512 : H3S_MAX_WGS_VOCAB) ? 1 : 0;
     const double c1 = (double)((w1 + 255) / 256), c2 = wide_ok ? H3S_WIDE_COST * (double)((w2 + 255) / 256) : 1e30;
     if ((c1 < c2 ? c1 : c2) >= H3S_MAX_COST) return 0;
     return c2 < c1 ? 2 : 1;
@@ -3608,6 +3731,27 @@ static int launch_h3s_t(const DevLaunch &L, int T, hipStream_t st) {
         if (kp_min >= H3S_EIGHT_WAVES_MIN_K && h3_any_f32(L)) return launch_h3s<EPI, 1, 8>(L, st);
     }
     if constexpr (EPI == EPI_VOCAB) {
+        // one activation segment (the classifier over h_lang): workgroup-shared k-block stages (gemm_h3v_kernel)
+        bool v_ok = g_h3v_on.load() != 0;
+        for (int i = 0; i < L.nprob; ++i)
+            if (L.p[i].nap != 1 || L.p[i].ksplit > 1) v_ok = false;
+        if (v_ok) {
+            const size_t lds = H3V_STAGES * H3V_STAGE_BYTES;
+            static std::atomic<bool> attr_set{false};
+            if (lds > 65536 && !attr_set.load()) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_h3v_kernel<true>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (e == hipSuccess)
+                    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_h3v_kernel<false>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (e != hipSuccess) return (int)e;
+                attr_set.store(true);
+            }
+            if (h3_any_f32(L)) hipLaunchKernelGGL((gemm_h3v_kernel<true>), dim3(L.total_tiles), dim3(256), lds, st, L);
+            else hipLaunchKernelGGL((gemm_h3v_kernel<false>), dim3(L.total_tiles), dim3(256), lds, st, L);
+            ISC_LAUNCH_CHECK();
+            return ISC_OK;
+        }
         // one workgroup per CU at most (M <= 96 at V = 10 000; beam rows): eight waves, two per column block
         if (L.total_tiles <= 256) return launch_h3s<EPI, 1, 8>(L, st);
     }

@@ -1004,28 +1004,14 @@ __global__ __launch_bounds__(1024) void rows_scan_gate_kernel(const RScanArgs a)
 #undef RSTAMP_KID
 }
 
-bool rows_scan_ok(const isc_step_plan *p) {
+static bool rows_scan_ok(const isc_step_plan *p) {
     return p->att_e && p->words_e && p->gate_Gc && p->gate_Gs && p->A == p->E && p->A == p->W && p->A <= 512 &&
            (p->A & 3) == 0 && p->R >= 1 && p->Mw >= 1;
 }
 
-// Also the gated scan of isc_step_fwd for inference steps of up to ROWS_SCAN_MAX rows (step.hip; `planes`: the f16 planes of
-// f that its MFMA lang-LSTM reads): one 1024-thread workgroup per row with the row's 290 KB in flight at once, against a
-// 256-thread workgroup walking the regions (B = 128: 15.0 -> see profiles) - one round of the chip up to 256 rows.
-int rows_scan_gate(const isc_step_plan *p, int row_div, const int *skip, hipStream_t st, int planes) {
-    RScanArgs a = {};
-    a.row_div = row_div > 1 ? row_div : 1; a.skip = skip;
-    if (planes) { a.f_hi = static_cast<_Float16 *>(p->f_hi); a.f_lo = static_cast<_Float16 *>(p->f_lo); }
-    a.P[0] = p->att_p; a.V[0] = p->att_e; a.G[0] = p->gate_Gc; a.q[0] = p->qa; a.w[0] = p->w_alpha_c; a.wb[0] = p->b_alpha_c;
-    a.P[1] = p->words_p; a.V[1] = p->words_e; a.G[1] = p->gate_Gs; a.q[1] = p->qw; a.w[1] = p->w_alpha_s; a.wb[1] = p->b_alpha_s;
-    a.q2 = p->label_w;
-    a.ids = reinterpret_cast<const long long *>(p->words_ids); a.ids_ld = p->words_ids_ld;
-    a.R[0] = p->R; a.R[1] = p->Mw; a.A = p->A;
-    a.zh = p->z; a.b_c = p->b_gc; a.b_s = p->b_gs; a.w_g = p->w_gate; a.b_g = p->b_gate;
-    a.f = p->f; a.alpha[0] = p->alpha_c; a.alpha[1] = p->alpha_s; a.beta = p->beta;
-    a.alpha_ld[0] = p->alpha_c_ld; a.alpha_ld[1] = p->alpha_s_ld; a.beta_ld = p->beta_ld;
+static int rows_scan_gate_launch(const RScanArgs &a, int rows, hipStream_t st) {
     if (!a.q[0] || !a.q[1] || !a.zh || !a.f || !a.w[0] || !a.w[1] || !a.b_c || !a.b_s || !a.w_g) return ISC_E_NULL;
-    const size_t lds = ((size_t)((p->R + 3) & ~3) + ((p->Mw + 3) & ~3) + (size_t)(32 + 4) * p->A + 16) * sizeof(float);
+    const size_t lds = ((size_t)((a.R[0] + 3) & ~3) + ((a.R[1] + 3) & ~3) + (size_t)(32 + 4) * a.A + 16) * sizeof(float);
     if (lds > 150000) return ISC_E_SHAPE;
     static std::atomic<bool> attr_set{false};
     if (!attr_set.load()) {
@@ -1034,10 +1020,57 @@ int rows_scan_gate(const isc_step_plan *p, int row_div, const int *skip, hipStre
         if (e != hipSuccess) return (int)e;
         attr_set.store(true);
     }
-    hipLaunchKernelGGL(rows_scan_gate_kernel, dim3(p->rows), dim3(1024), lds, st, a);
+    hipLaunchKernelGGL(rows_scan_gate_kernel, dim3(rows), dim3(1024), lds, st, a);
     ISC_LAUNCH_CHECK();
     ++g_rows_launches;
     return ISC_OK;
+}
+
+static int rows_scan_gate(const isc_step_plan *p, int row_div, const int *skip, hipStream_t st) {
+    RScanArgs a = {};
+    a.row_div = row_div > 1 ? row_div : 1; a.skip = skip;
+    a.P[0] = p->att_p; a.V[0] = p->att_e; a.G[0] = p->gate_Gc; a.q[0] = p->qa; a.w[0] = p->w_alpha_c; a.wb[0] = p->b_alpha_c;
+    a.P[1] = p->words_p; a.V[1] = p->words_e; a.G[1] = p->gate_Gs; a.q[1] = p->qw; a.w[1] = p->w_alpha_s; a.wb[1] = p->b_alpha_s;
+    a.q2 = p->label_w;
+    a.ids = reinterpret_cast<const long long *>(p->words_ids); a.ids_ld = p->words_ids_ld;
+    a.R[0] = p->R; a.R[1] = p->Mw; a.A = p->A;
+    a.zh = p->z; a.b_c = p->b_gc; a.b_s = p->b_gs; a.w_g = p->w_gate; a.b_g = p->b_gate;
+    a.f = p->f; a.alpha[0] = p->alpha_c; a.alpha[1] = p->alpha_s; a.beta = p->beta;
+    a.alpha_ld[0] = p->alpha_c_ld; a.alpha_ld[1] = p->alpha_s_ld; a.beta_ld = p->beta_ld;
+    return rows_scan_gate_launch(a, p->rows, st);
+}
+
+// isc_attn_scan_gate_fwd (attention.hip) for inference steps of up to g_rows_scan_max rows: the same kernel, one
+// 1024-thread workgroup per row with the row's 290 KB in flight at once, against a 512-thread workgroup walking the
+// regions (B = 128: 15.0 -> 10.9 us; one round of the chip up to 256 rows, slower beyond).  Needs the fused form
+// (v and s not wanted on their own), <= 36 regions / 12 words, A = D <= 512.
+#define ROWS_SCAN_MAX_ROWS 256
+static std::atomic<int> g_rows_scan_max{ROWS_SCAN_MAX_ROWS};
+extern "C" int isc_set_rows_scan_max(int rows) {
+    if (rows < 0) return g_rows_scan_max.load();
+    return g_rows_scan_max.exchange(rows);
+}
+
+int rows_scan_gate_try(const isc_scan_gate_args *g, int rows, hipStream_t st, int *rc) {
+    const isc_scan_problem &c = g->scan[0], &s = g->scan[1];
+    if (rows > g_rows_scan_max.load()) return 0;
+    if (c.out || s.out || c.out_hi || s.out_hi || c.q2 || c.row_ids) return 0;
+    if (c.A != c.D || s.A != c.A || s.D != c.A || c.A > 512 || (c.A & 3) || c.R < 1 || s.R < 1) return 0;
+    if (c.R > RS_NWC * RS_RPW || s.R > RS_NWS * RS_RPW) return 0;
+    if (!c.P || !c.V || !c.q || !c.w || !s.P || !s.V || !s.q || !s.w || !g->G[0] || !g->G[1]) return 0;
+    RScanArgs a = {};
+    a.row_div = 1;
+    a.P[0] = c.P; a.V[0] = c.V; a.G[0] = g->G[0]; a.q[0] = c.q; a.w[0] = c.w; a.wb[0] = c.w_bias;
+    a.P[1] = s.P; a.V[1] = s.V; a.G[1] = g->G[1]; a.q[1] = s.q; a.w[1] = s.w; a.wb[1] = s.w_bias;
+    a.q2 = s.q2;
+    a.ids = reinterpret_cast<const long long *>(s.row_ids); a.ids_ld = s.row_ids_ld;
+    a.R[0] = c.R; a.R[1] = s.R; a.A = c.A;
+    a.zh = g->zh; a.b_c = g->b_gc; a.b_s = g->b_gs; a.w_g = g->w_gate; a.b_g = g->b_gate;
+    a.f = g->f; a.alpha[0] = c.alpha_out; a.alpha[1] = s.alpha_out; a.beta = g->beta;
+    a.alpha_ld[0] = c.alpha_ld; a.alpha_ld[1] = s.alpha_ld; a.beta_ld = g->beta_ld;
+    a.f_hi = static_cast<_Float16 *>(g->f_hi); a.f_lo = static_cast<_Float16 *>(g->f_lo);
+    *rc = rows_scan_gate_launch(a, rows, st);
+    return 1;
 }
 
 // ------------------------------------------------------------------ the step
@@ -1086,7 +1119,7 @@ extern "C" int isc_rows_step_fwd(const isc_step_plan *p, const isc_rows_ext *x, 
         const int N[3] = {A, A, A}, ldc[3] = {A, A, A};
         RET(rows_linear3(p->h1, H, H, rows, Ws, bs, Cs, N, ldc, 3, skip, st));
     }
-    RET(rows_scan_gate(p, row_div, skip, st, 0));
+    RET(rows_scan_gate(p, row_div, skip, st));
     {   // lang-LSTM over cat[f, h_att] (captioner.py:180-181)
         const float *As[3] = {p->f, p->h1, p->h2_prev}, *Ws[3] = {p->Wih2, p->Wih2 + E, p->Whh2};
         const int lda[3] = {E, H, H}, ldw[3] = {ld2, ld2, H}, K[3] = {E, H, H}, ind[3] = {0, 0, 1};

@@ -2,7 +2,6 @@
 // one BPTT step) from C++, so the host language pays one FFI call per step instead of ~10
 // descriptor-building calls (include/insenticap_hip.h, "whole decode step").  Pure host code: it
 // only fills the per-kernel descriptors and calls the library's own entry points.
-#include <atomic>
 #include "common.h"
 
 static inline isc_seg seg(const float *A, int lda, const float *W, int ldw, int K, const void *hi = nullptr,
@@ -16,14 +15,6 @@ static inline isc_seg seg(const float *A, int lda, const float *W, int ldw, int 
         int rc__ = (x);   \
         if (rc__) return rc__; \
     } while (0)
-
-// Largest inference step whose gated scan runs on rows_scan_gate_kernel (0: never); isc_set_rows_scan_max for tests / tuning.
-#define ROWS_SCAN_MAX_ROWS 256
-static std::atomic<int> g_rows_scan_max{ROWS_SCAN_MAX_ROWS};
-extern "C" int isc_set_rows_scan_max(int rows) {
-    if (rows < 0) return g_rows_scan_max.load();
-    return g_rows_scan_max.exchange(rows);
-}
 
 extern "C" int isc_step_fwd(const isc_step_plan *p, void *stream) {
     if (!p) return ISC_E_NULL;
@@ -100,11 +91,7 @@ extern "C" int isc_step_fwd(const isc_step_plan *p, void *stream) {
             g.G[0] = p->gate_Gc; g.G[1] = p->gate_Gs;
             g.zh = p->z; g.b_gc = p->b_gc; g.b_gs = p->b_gs; g.w_gate = p->w_gate; g.b_gate = p->b_gate;
             g.f = p->f; g.f_hi = PW(p->f_hi); g.f_lo = PW(p->f_lo); g.beta = p->beta; g.beta_ld = p->beta_ld;
-            // up to ROWS_SCAN_MAX_ROWS rows with at most 36 regions / 12 words: one 1024-thread workgroup per row (rows.hip)
-            if (rows <= g_rows_scan_max.load() && rows_scan_ok(p) && p->R <= 36 && p->Mw <= 12)
-                RET(rows_scan_gate(p, 1, nullptr, (hipStream_t)stream, wplanes ? 1 : 0));
-            else
-                RET(isc_attn_scan_gate_fwd(&g, rows, stream));
+            RET(isc_attn_scan_gate_fwd(&g, rows, stream));
         } else {
             RET(isc_attn_scan_fwd(sc, n, rows, stream));
         }

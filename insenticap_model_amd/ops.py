@@ -407,6 +407,12 @@ def set_rows_scan_max(rows):
     return _lib.load().isc_set_rows_scan_max(int(rows))
 
 
+def set_h3v(on):
+    """Classifier launches of the skinny split-f16 path on gemm_h3v_kernel (isc_set_h3v; 0 = the ring-staged form it
+    replaced).  Returns the previous value."""
+    return _lib.load().isc_set_h3v(int(on))
+
+
 def rows_step_supported(plan):
     return bool(_lib.load().isc_rows_step_supported(C.byref(plan)))
 

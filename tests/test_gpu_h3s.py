@@ -145,9 +145,20 @@ def test_lstm_skinny(M, H, with_pre, with_tab, skinny):
         assert torch.equal(hp.cpu(), _planes(h).cpu())            # the epilogue's planes == re-splitting h
 
 
+@pytest.mark.parametrize('h3v', [1, 0])
 @pytest.mark.parametrize('M,V,K,logits', [(5, 10000, 512, True), (128, 10000, 512, False), (70, 9487, 512, True),
-                                          (33, 130, 64, True)])
-def test_vocab_skinny(M, V, K, logits):
+                                          (33, 130, 64, True), (256, 10000, 512, False), (200, 4100, 96, True),
+                                          (1, 64, 32, True), (97, 10000, 256, False)])
+def test_vocab_skinny(M, V, K, logits, h3v):
+    """h3v = 1: gemm_h3v_kernel (workgroup-shared k-block stages), 0: the per-wave-ring form (isc_set_h3v)."""
+    prev = ops.set_h3v(h3v)
+    try:
+        _vocab_skinny(M, V, K, logits)
+    finally:
+        ops.set_h3v(prev)
+
+
+def _vocab_skinny(M, V, K, logits):
     g = torch.Generator().manual_seed(V + M)
     h, W, bias = _rand(g, M, K), _rand(g, V, K, scale=4 * K ** -0.5), _rand(g, V)
     logits_ref = h.double() @ W.double().t() + bias.double()

@@ -641,11 +641,35 @@ def test_gated_scan_equals_scans_plus_gate_gemm_plus_gate_mix():
     planes = torch.empty(2, B, A, dtype=torch.float16, device=D_)
     scans2 = [ops.scan_problem(att_p, att_e, qa, wc, bc, v, aC2),
               ops.scan_problem(tab_p, tab_e, qw, ws_, bs, s, aS2, q2=q2, row_ids=ids)]
-    ops.attn_scan_gate_fwd(scans2, (Gc, Gs), zh, bgc, bgs, wg, bg, f2, beta2, f_planes=planes)
-    torch.cuda.synchronize()
-    assert torch.equal(aC, aC2) and torch.equal(aS, aS2)              # the scans themselves are the same arithmetic
-    np.testing.assert_allclose(beta2.cpu().numpy(), beta.cpu().numpy(), atol=3e-6)
-    np.testing.assert_allclose(f2.cpu().numpy(), f.cpu().numpy(), atol=3e-6)
+    prev_rows = ops.set_rows_scan_max(0)            # attn_scan_gate_kernel (the region walk of the three launches)
+    try:
+        ops.attn_scan_gate_fwd(scans2, (Gc, Gs), zh, bgc, bgs, wg, bg, f2, beta2, f_planes=planes)
+        torch.cuda.synchronize()
+        assert torch.equal(aC, aC2) and torch.equal(aS, aS2)          # the scans themselves are the same arithmetic
+        np.testing.assert_allclose(beta2.cpu().numpy(), beta.cpu().numpy(), atol=3e-6)
+        np.testing.assert_allclose(f2.cpu().numpy(), f.cpu().numpy(), atol=3e-6)
+        # ... and on the one-workgroup-per-row kernel that takes launches of up to 256 rows by default (rows.hip): other
+        # summation orders, same values; its planes of f are the split of its f
+        ops.set_rows_scan_max(256)
+        f3, beta3 = torch.empty(B, A, device=D_), torch.empty(B, 1, device=D_)
+        aC3, aS3 = torch.empty(B, R, device=D_), torch.empty(B, M, device=D_)
+        planes3 = torch.empty(2, B, A, dtype=torch.float16, device=D_)
+        scans3 = [ops.scan_problem(att_p, att_e, qa, wc, bc, v, aC3),
+                  ops.scan_problem(tab_p, tab_e, qw, ws_, bs, s, aS3, q2=q2, row_ids=ids)]
+        n0 = ops._lib.load().isc_rows_launches()
+        ops.attn_scan_gate_fwd(scans3, (Gc, Gs), zh, bgc, bgs, wg, bg, f3, beta3, f_planes=planes3)
+        torch.cuda.synchronize()
+        assert ops._lib.load().isc_rows_launches() == n0 + 1
+        np.testing.assert_allclose(aC3.cpu().numpy(), aC.cpu().numpy(), atol=2e-6)
+        np.testing.assert_allclose(aS3.cpu().numpy(), aS.cpu().numpy(), atol=2e-6)
+        np.testing.assert_allclose(beta3.cpu().numpy(), beta.cpu().numpy(), atol=3e-6)
+        np.testing.assert_allclose(f3.cpu().numpy(), f.cpu().numpy(), atol=3e-6)
+        pl = planes3.view(B, A // 32, 2, 32)               # interleaved layout: per row and 32-block 32 hi, then 32 lo
+        hi, lo = pl[:, :, 0, :].reshape(B, A), pl[:, :, 1, :].reshape(B, A)
+        assert torch.equal(hi, f3.half())
+        assert torch.equal(lo, ((f3 - hi.float()) * 2048.0).half())
+    finally:
+        ops.set_rows_scan_max(prev_rows)
     hi, lo = planes[0].float(), planes[1].float()                     # planes of f: hi + lo 2^-11 == f to 2^-22 rel.
     # (interleaved layout: compare through the split of f2 itself)
     # end to end: roll-outs and beam searches with the fusion on / off
