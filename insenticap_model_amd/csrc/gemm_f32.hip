@@ -3996,7 +3996,16 @@ extern "C" int isc_gemm_bwd(const isc_linear_problem *pr, int n_prob, int layout
     bool k32 = true;
     for (int i = 0; i < n_prob; ++i)
         for (int s = 0; s < pr[i].nseg; ++s) k32 = k32 && (pr[i].seg[s].K & 31) == 0;
-    if (layout == ISC_LAYOUT_NN && k32 && (h3w_scope_of((hipStream_t)stream) || g_h3_mode.load() >= 2)) {
+    // ... or outside one when the contraction is large (>= 20 GFLOP: the classifier's dX over a zero-padded copy of W_c
+    // that autograd.py keeps out of the scope on purpose - B = 512: 105 GFLOP, 606 us on the fp32 tiles): planes of this
+    // call's W^T go to the workspace, one 20 MB split launch against ~0.3 ms saved
+    bool nn_big = g_h3_mode.load() == 1 && n_prob == 1;
+    if (nn_big) {
+        double fl = 0;
+        for (int s = 0; s < pr[0].nseg; ++s) fl += 2.0 * pr[0].M * pr[0].N * (double)pr[0].seg[s].K;
+        nn_big = fl >= 2.0e10;
+    }
+    if (layout == ISC_LAYOUT_NN && k32 && (h3w_scope_of((hipStream_t)stream) || g_h3_mode.load() >= 2 || nn_big)) {
         // inside a weights scope (the BPTT sweep): dX = dY W on planes of W^T built once per scope - the skinny tiles for
         // few rows, the large split-f16 kernels otherwise; dY is read as fp32 rows and split in registers
         if (try_h3s<EPI_LINEAR>(L, pr[0].splitk_ws, pr[0].splitk_ws_floats, (hipStream_t)stream, rc_h3, 1)) return rc_h3;
