@@ -348,6 +348,11 @@ int isc_beam_merge(const isc_beam_merge_args *args_host, void *stream);
 int isc_beam_gather(const float *state_next, const float *state_cur, const int64_t *gather, float *out,
                     int planes, int rows, int H, void *stream);
 
+/* Up to ISC_COPY_MULTI_MAX device-to-device copies in ONE launch (dst[i] <- src[i], bytes[i] each; non-overlapping): the
+ * input copies in front of a graph replay (features, word ids, labels into the graph's static buffers). */
+#define ISC_COPY_MULTI_MAX 8
+int isc_copy_multi(void *const *dst, const void *const *src, const int64_t *bytes, int n, void *stream);
+
 /* Masked NLL (XECriterion, captioner.py:427-440): returns sum and token count in out[0..1].
  * logp [B,T,V] contiguous, target [B,T] int64, lengths [B] int32. */
 int isc_xe_loss_fwd(const float *logp, const int64_t *target, const int32_t *lengths, int B,

@@ -168,6 +168,7 @@ SIGNATURES = {
     'isc_set_rows_nt': (C.c_int, [C.c_int]),
     'isc_set_rows_scan_max': (C.c_int, [C.c_int]),
     'isc_set_h3v': (C.c_int, [C.c_int]),
+    'isc_copy_multi': (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_int, C.c_void_p]),
     'isc_rows_launches': (C.c_longlong, []),
     'isc_beam_select': (C.c_int, [C.POINTER(BeamSelectArgs), C.c_void_p]),
     'isc_vocab_fwd': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int,

@@ -156,26 +156,29 @@ def _search(cap, fc_feats, att_feats, senti_words, senti_labels, beam, decoding_
 CHUNK = 4          # decode steps per captured graph = steps between two looks at the live-image counter
 
 
+FEW_ROW_PLANE_BYTES = 24 << 20
+
+
+def _few_rows(cap, n_img, beam):
+    """One image's beam on at most ROWS_STEP_MAX rows: the few-row step (csrc/rows.hip)."""
+    return (n_img * beam <= cap.ROWS_STEP_MAX and beam <= 8 and getattr(cap, 'rows_step', True)
+            and getattr(cap, 'beam_device_merge', True))
+
+
 def _graph_key(cap, ins, beam, decoding_constraint, T):
     # (the cached tables a captured graph points at are functions of these weights: token table, sentiment-word tables,
     # and - gated scan - the sentiment-word table through attention.senti2att)
+    # ... and - few-row searches - the prologue's weight planes, which such a graph keeps instead of re-splitting them
     versions = tuple(q._version for q in (cap.word_embed[0].weight, cap.att_lstm.weight_ih, cap.senti2att[0].weight,
-                                          cap.senti2att[0].bias, cap.attention.senti2att.weight))
+                                          cap.senti2att[0].bias, cap.attention.senti2att.weight, cap.att_embed[0].weight,
+                                          cap.att2att[0].weight, cap.attention.cont2att.weight))
     return (tuple(None if x is None else (tuple(x.shape), x.dtype) for x in ins), beam, decoding_constraint, T, versions,
             ops.WEIGHT_EPOCH, cap.eos_id, torch.cuda.current_device())
 
 
 def _replay(cap, entry, ins, T):
     graphs, static, search = entry[:3]
-    # inputs -> the graphs' static buffers: one launch per dtype (features, ids) instead of one per tensor
-    by_dtype = {}
-    for dst, src in zip(static, ins):
-        if dst is not None:
-            by_dtype.setdefault(dst.dtype, ([], []))
-            by_dtype[dst.dtype][0].append(dst)
-            by_dtype[dst.dtype][1].append(src)
-    for dsts, srcs in by_dtype.values():
-        torch._foreach_copy_(dsts, srcs, non_blocking=True)
+    ops.stage_inputs(static, ins)           # inputs -> the graphs' static buffers, one launch
     for g, t1 in graphs:
         g.replay()
         cap.last_beam_steps = t1
@@ -225,6 +228,13 @@ def _graphed_search(cap, fc_feats, att_feats, senti_words, senti_labels, beam, d
     if entry == 'seen':
         static = [None if x is None else x.clone() for x in ins]
         ws, wp = cap._graph_buffers()          # ONE workspace / plane-buffer pair for all graphs of this captioner
+        few = _few_rows(cap, ins[0].shape[0], beam)
+        if few:
+            # ... except the planes of a few-row search: its graph is ONE replay of ~1 ms, and the three split launches
+            # of its prologue's weights (att_embed, att2att / senti2att, the gate projections: 8 MB of planes) are 2 % of
+            # it.  They are built once, in front of the capture, into a buffer of this graph's own (the shared one is
+            # re-planned by every capture), and the graph key holds those weights' versions.
+            wp = torch.empty(FEW_ROW_PLANE_BYTES, dtype=torch.uint8, device=dev)
         stream = cap.__dict__.get('_beam_stream')        # one capture stream per captioner, held for itself
         if stream is None or stream.device != dev:
             stream = cap.__dict__['_beam_stream'] = ops.private_stream(dev)
@@ -235,6 +245,8 @@ def _graphed_search(cap, fc_feats, att_feats, senti_words, senti_labels, beam, d
             scope = ops.h3_weights_scope(dev)      # ONE scope over all the captures (its planes live in `wp`,
             scope.__enter__()                      # are split inside graph 0 and read by the later graphs)
             try:
+                if few:                            # (the eager prologue leaves the planes in the scope)
+                    _Search(cap, *static, beam, decoding_constraint, T)
                 search, t0 = None, 0
                 while t0 < T:
                     g = torch.cuda.CUDAGraph()
@@ -263,8 +275,7 @@ class _Search:
         n_img = fc_feats.shape[0]
         # few rows (one image's beam): the image's sentiment-word features as per-image tensors - the vocabulary-sized
         # tables would put an id -> row index chain in front of every step's sentiment scan, and there is one image
-        few = (fc_feats.shape[0] * beam <= cap.ROWS_STEP_MAX and beam <= 8 and getattr(cap, 'rows_step', True)
-               and getattr(cap, 'beam_device_merge', True))
+        few = _few_rows(cap, fc_feats.shape[0], beam)
         P = cap._prologue(p, 'beam', fc_feats, att_feats, None, senti_words,
                           senti_labels if senti_words is not None else None, want_table='build',
                           words_table=getattr(cap, 'words_table', True) and not few, gate_rows=fc_feats.shape[0] * beam)

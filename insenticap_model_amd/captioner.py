@@ -746,13 +746,7 @@ class Captioner(nn.Module):
             outs, pending = on_stream(capture)
             entry = cache[key] = (graph, static, outs, pending, ops.h3_weights_scope.cold_begins(skey))
         graph, static, outs, pending = entry[:4]
-        by_dtype = {}                            # inputs -> static buffers: one launch per dtype, not one per tensor
-        for dst, src in zip(static, ins):
-            by_dtype.setdefault(dst.dtype, ([], []))
-            by_dtype[dst.dtype][0].append(dst)
-            by_dtype[dst.dtype][1].append(src)
-        for dsts, srcs in by_dtype.values():
-            torch._foreach_copy_(dsts, srcs, non_blocking=True)
+        ops.stage_inputs(static, ins)            # inputs -> static buffers, one launch
         graph.replay()
         self._weights_pending = pending          # attention weights of this replay (resolved lazily, as always)
         return tuple(o.clone() for o in outs)

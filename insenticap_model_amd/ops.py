@@ -407,6 +407,40 @@ def set_rows_scan_max(rows):
     return _lib.load().isc_set_rows_scan_max(int(rows))
 
 
+def copy_multi(dsts, srcs):
+    """dsts[i].copy_(srcs[i]) for up to 8 pairs of contiguous same-shape, same-dtype device tensors in ONE launch
+    (isc_copy_multi); longer lists go out in groups of 8."""
+    pairs = [(d, s) for d, s in zip(dsts, srcs) if d is not None and d.numel()]
+    for d, s in pairs:
+        if d.dtype != s.dtype or d.shape != s.shape or not (d.is_contiguous() and s.is_contiguous() and d.is_cuda and s.is_cuda):
+            raise ValueError('copy_multi: contiguous device tensors of equal shape and dtype expected')
+    lib = _lib.load()
+    for i in range(0, len(pairs), 8):
+        grp = pairs[i:i + 8]
+        n = len(grp)
+        D = (C.c_void_p * n)(*[d.data_ptr() for d, _ in grp])
+        S = (C.c_void_p * n)(*[s.data_ptr() for _, s in grp])
+        Bn = (C.c_int64 * n)(*[d.numel() * d.element_size() for d, _ in grp])
+        check(lib.isc_copy_multi(D, S, Bn, n, stream()), 'isc_copy_multi')
+
+
+def stage_inputs(dsts, srcs):
+    """A call's inputs -> the static buffers of a captured graph (None entries skipped): one launch when every pair
+    is contiguous and of one dtype, torch's per-dtype copies otherwise."""
+    pairs = [(d, s) for d, s in zip(dsts, srcs) if d is not None]
+    if all(d.dtype == s.dtype and d.shape == s.shape and s.is_cuda and s.is_contiguous() and d.is_contiguous()
+           for d, s in pairs):
+        copy_multi([d for d, _ in pairs], [s for _, s in pairs])
+        return
+    by_dtype = {}
+    for d, s in pairs:
+        by_dtype.setdefault(d.dtype, ([], []))
+        by_dtype[d.dtype][0].append(d)
+        by_dtype[d.dtype][1].append(s)
+    for ds, ss in by_dtype.values():
+        torch._foreach_copy_(ds, ss, non_blocking=True)
+
+
 def set_h3v(on):
     """Classifier launches of the skinny split-f16 path on gemm_h3v_kernel (isc_set_h3v; 0 = the ring-staged form it
     replaced).  Returns the previous value."""

@@ -269,6 +269,57 @@ def test_beam_graphs_replay_equals_eager_on_this_path():
         np.testing.assert_allclose(out[1], ref[1], atol=1e-6)
 
 
+def test_few_row_beam_graph_follows_in_place_changes_of_the_prologue_weights():
+    """A few-row search's graph keeps the f16 planes of its prologue's weights (built once in front of the capture, not
+    re-split by every replay): a weight of the prologue changed in place must not be served from the old planes - the
+    graph key holds those weights' versions, the next calls run eagerly and capture anew."""
+    cap = _captioner(10000, synth.DEFAULT_SETTINGS, seed=4)
+    d = _inputs(1, 10000, synth.DEFAULT_SETTINGS, 36, seed=6)
+    args = (d['fc_feats'], d['att_feats'], d['senti_words'], d['senti_labels'], 5, 1, 20)
+    for _ in range(3):                  # eager, capture, replay
+        before = cap.sample_batch(*args)
+    h3 = ops._lib.load().isc_h3s_launches
+    n0 = h3()
+    cap.sample_batch(*args)
+    split_free = h3() - n0              # (a replay enqueues through the graph: the library's counters stand still)
+    assert split_free == 0
+    with torch.no_grad():
+        for q in (cap.att_embed[0].weight, cap.att2att[0].weight, cap.attention.cont2att.weight):
+            q.mul_(-0.75)               # in place: the version counters move
+    cap.enable_beam_graphs(False)
+    ref = cap.sample_batch(*args)
+    cap.enable_beam_graphs(True)
+    assert ref[2] != before[2] or not np.allclose(ref[1], before[1], atol=1e-3)     # the change matters
+    for _ in range(3):
+        out = cap.sample_batch(*args)
+        assert out[2] == ref[2]
+        np.testing.assert_allclose(out[1], ref[1], atol=1e-6)
+
+
+def test_copy_multi_moves_every_byte():
+    """isc_copy_multi: up to 8 copies of mixed sizes / dtypes / alignments in one launch (graph replays stage their inputs
+    with it); more pairs go out in groups."""
+    g = torch.Generator().manual_seed(3)
+    shapes = [(2048,), (36, 2048), (10,), (1,), (3, 5, 7), (16385,), (1, 1), (4097, 3), (129,), (65536 + 3,)]
+    dts = [torch.float32, torch.float32, torch.int64, torch.int64, torch.float16, torch.uint8, torch.int32, torch.float32,
+           torch.uint8, torch.uint8]
+    srcs, dsts = [], []
+    for sh, dt in zip(shapes, dts):
+        x = (torch.rand(*sh, generator=g) * 200 - 100)
+        srcs.append(x.to(dt).to(DEV))
+        dsts.append(torch.zeros(sh, dtype=dt, device=DEV))
+    # an unaligned pair: views one byte into their buffers
+    raw_s, raw_d = torch.arange(0, 5001, dtype=torch.int64).to(torch.uint8).to(DEV), torch.zeros(5001, dtype=torch.uint8, device=DEV)
+    srcs.append(raw_s[1:]); dsts.append(raw_d[1:])
+    ops.copy_multi(dsts, srcs)
+    torch.cuda.synchronize()
+    for a, b in zip(dsts, srcs):
+        assert torch.equal(a, b)
+    assert int(raw_d[0]) == 0
+    with pytest.raises(ValueError):
+        ops.copy_multi([dsts[0]], [srcs[1]])
+
+
 @pytest.mark.parametrize('B', [1, 4, 8])
 def test_small_greedy_rollout_on_this_path_equals_the_general_path(B):
     cap = _captioner(10000, synth.DEFAULT_SETTINGS, seed=1)
