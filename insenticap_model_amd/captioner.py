@@ -144,6 +144,22 @@ class Captioner(nn.Module):
     def _zeros(self, *shape, dtype=torch.float32):
         return torch.zeros(shape, dtype=dtype, device=self._dev)
 
+    def _zeros_many(self, *specs):
+        """Zero tensors for (shape, dtype) specs carved out of ONE zeroed byte arena (256-byte aligned views): one fill
+        launch instead of one per tensor - a roll-out starts from a dozen of them, 4-7 % of a small batch's time."""
+        sizes = []
+        for shape, dtype in specs:
+            n = 1
+            for d in shape:
+                n *= int(d)
+            sizes.append(n * torch.empty(0, dtype=dtype).element_size())
+        offs, total = [], 0
+        for n in sizes:
+            offs.append(total)
+            total += (n + 255) & ~255
+        arena = torch.zeros(max(total, 256), dtype=torch.uint8, device=self._dev)
+        return [arena[o:o + n].view(dtype).view(*shape) for (shape, dtype), o, n in zip(specs, offs, sizes)]
+
     def init_hidden(self, bsz):
         H = self.att_lstm.hidden_size
         return (self._zeros(2, bsz, H), self._zeros(2, bsz, H))
@@ -834,30 +850,32 @@ class Captioner(nn.Module):
         ops.TIMER.armed, ops.TIMER.phase = False, 'step'
         B, V = P.B, self.vocab_size
         H, Wd = self.att_lstm.hidden_size, self.settings['word_emb_dim']
-        h = [self._zeros(2, B, H) for _ in range(2)]
-        c = [self._zeros(2, B, H) for _ in range(2)]
-        # split-f16 planes of the state ([layer, hi|lo, B, H] f16; zero state = zero planes): the LSTM epilogues
-        # write them next to h, so the state's GEMM segments are never split again
-        hp = [torch.zeros(2, 2, B, H, dtype=torch.float16, device=self._dev) if getattr(self, 'state_planes', True)
-              else None for _ in range(2)]
         # a handful of captions, no sampling: the few-row kernels (statistics per isc_rows_stats_tile columns)
         rows_ext = None
         if (sample_max or replay is not None) and masks is None and not self.training and self._rows_step_ok(B, P):
             rows_ext = _lib.RowsExt()
             rows_ext.stats_tile = ops.rows_stats_tile(V)
-            hp = [None, None]
+        planes = rows_ext is None and getattr(self, 'state_planes', True)
+        # Everything that starts at zero comes out of TWO zeroed arenas (two fill launches, was fifteen): the initial
+        # state (the buffers step 0 writes need no zeros) with its f16 planes (zero state = zero planes) - freed with
+        # the call -, and what the caller may keep: the outputs, the device-side counters, the attention weights
+        f32, i64 = torch.float32, torch.int64
+        h0, c0, hp0 = self._zeros_many(((2, B, H), f32), ((2, B, H), f32),
+                                       ((2, 2, B, H) if planes else (0,), torch.float16))
+        seq, raw, seq_logprobs, seq_masks, alive, aC, aS, bG = self._zeros_many(
+            ((B, T), i64), ((B, T), i64), ((B, T), f32), ((B, T), f32), ((T + 1,), torch.int32), ((B, T, P.R), f32),
+            ((B, T, P.Mw), f32), ((B, T), f32))
+        h, c = [h0, self._new(2, B, H)], [c0, self._new(2, B, H)]
+        # split-f16 planes of the state ([layer, hi|lo, B, H] f16): the LSTM epilogues write them next to h, so the
+        # state's GEMM segments are never split again
+        hp = [hp0, torch.empty(2, 2, B, H, dtype=torch.float16, device=self._dev)] if planes else [None, None]
         ws = self._alloc_step_ws(B, P, rows_ext.stats_tile if rows_ext is not None else 128)
         if hp[0] is not None:
             for k in ('v', 's', 'f'):
                 if k in ws:
                     ws[k + 'p'] = torch.empty((2,) + tuple(ws[k].shape), dtype=torch.float16, device=self._dev)
-        seq = self._zeros(B, T, dtype=torch.int64)
-        seq_logprobs, seq_masks = self._zeros(B, T), self._zeros(B, T)
-        raw = self._zeros(B, T, dtype=torch.int64)
         unfinished = torch.ones(B, dtype=torch.int32, device=self._dev)
-        alive = self._zeros(T + 1, dtype=torch.int32)
         alive[0:1].fill_(B)                     # a fill kernel (a scalar assignment would be a pageable H2D copy)
-        aC, aS, bG = self._zeros(B, T, P.R), self._zeros(B, T, P.Mw), self._zeros(B, T)
         use_tab = P.tab is not None
         xt = [None, None] if use_tab else [self._new(B, Wd) for _ in range(2)]
         emb = p['word_embed.0.weight']
