@@ -765,7 +765,9 @@ class Captioner(nn.Module):
         ops.stage_inputs(static, ins)            # inputs -> static buffers, one launch
         graph.replay()
         self._weights_pending = pending          # attention weights of this replay (resolved lazily, as always)
-        return tuple(o.clone() for o in outs)
+        fresh = [torch.empty_like(o) for o in outs]       # the caller's own copies of the graph's outputs: one launch
+        ops.copy_multi(fresh, outs)
+        return tuple(fresh)
 
     GRAPH_THRASH_LIMIT = 8
 
