@@ -298,6 +298,7 @@ typedef struct {
 } isc_rollout_step;
 
 int isc_rollout_finalize(const isc_rollout_step *s_host, void *stream);
+long long isc_rollout_finalize_launches(void);   /* launches so far (tests: isc_rows_ext.fin_prev saves them) */
 
 /* Scheduled sampling of the teacher-forced unrolls (captioner.py:219-228): out_ids[b] = u_select[b] < ss_prob
  * ? a draw from exp(logp[b,:]) (inverse CDF with uniform u_draw[b], vocabulary order) : base_ids[b*stride].
@@ -461,6 +462,16 @@ typedef struct {
     int32_t mask_special, decoding_constraint;
     int32_t row_div, _pad;
     const int32_t *live_in;
+    /* optional: the PREVIOUS step's greedy roll-out finalize folded into this step's first launch (a roll-out of T steps is
+     * then T finalize launches shorter but one: only the last step's runs on its own).  fin_prev describes that step as
+     * isc_rollout_finalize would get it (t = the previous step; forced, sample_u and xt_next NULL: arg-max decoding with the
+     * token table), except that its `unfinished` is only READ - the updated flags go to fin_unfinished_out ([rows], another
+     * array: every workgroup of the launch reads the old flags) - and the plan's `tok` is ignored: the launch derives the
+     * fed tokens from the previous step's tile statistics (still in pmax / psum / pidx when it runs).  Needs plan->tab,
+     * row_div <= 1, no src_row, no live_in, at most 4 rows (measured: B = 1 0.70 -> 0.65 ms per roll-out, B = 4 0.76 ->
+     * 0.74; at 8 rows the fold outlasts the launch it saves: 0.86 -> 0.90). */
+    const isc_rollout_step *fin_prev;
+    int32_t *fin_unfinished_out;
 } isc_rows_ext;
 int isc_rows_stats_tile(int V);
 int isc_rows_step_supported(const isc_step_plan *plan_host);

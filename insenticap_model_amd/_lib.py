@@ -107,7 +107,8 @@ class RowsExt(C.Structure):
     _fields_ = [('src_row', C.c_void_p), ('stats_tile', C.c_int32), ('beam', C.c_int32), ('cand_val', C.c_void_p),
                 ('cand_idx', C.c_void_p), ('last_word', C.c_void_p), ('pad_id', C.c_int64), ('sos_id', C.c_int64),
                 ('unk_id', C.c_int64), ('mask_special', C.c_int32), ('decoding_constraint', C.c_int32),
-                ('row_div', C.c_int32), ('_pad', C.c_int32), ('live_in', C.c_void_p)]
+                ('row_div', C.c_int32), ('_pad', C.c_int32), ('live_in', C.c_void_p), ('fin_prev', C.c_void_p),
+                ('fin_unfinished_out', C.c_void_p)]
 
 
 class BeamSelectArgs(C.Structure):
@@ -193,6 +194,7 @@ SIGNATURES = {
     'isc_embed_senti_words_fwd': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int64,
                                             C.c_int, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
     'isc_rollout_finalize': (C.c_int, [C.POINTER(RolloutStep), C.c_void_p]),
+    'isc_rollout_finalize_launches': (C.c_longlong, []),
     'isc_beam_merge': (C.c_int, [C.POINTER(BeamMergeArgs), C.c_void_p]),
     'isc_beam_gather': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'isc_beam_topk': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,

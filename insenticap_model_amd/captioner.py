@@ -6,6 +6,7 @@ The nn.Module containers below exist only to own the parameters under the refere
 names (checkpoint compatibility); their `forward`s are never called.
 PyTorch is used for device memory, streams and (in train mode) random numbers only.
 """
+import ctypes as C
 import itertools
 import weakref
 
@@ -864,9 +865,9 @@ class Captioner(nn.Module):
         f32, i64 = torch.float32, torch.int64
         h0, c0, hp0 = self._zeros_many(((2, B, H), f32), ((2, B, H), f32),
                                        ((2, 2, B, H) if planes else (0,), torch.float16))
-        seq, raw, seq_logprobs, seq_masks, alive, aC, aS, bG = self._zeros_many(
+        seq, raw, seq_logprobs, seq_masks, alive, aC, aS, bG, unf = self._zeros_many(
             ((B, T), i64), ((B, T), i64), ((B, T), f32), ((B, T), f32), ((T + 1,), torch.int32), ((B, T, P.R), f32),
-            ((B, T, P.Mw), f32), ((B, T), f32))
+            ((B, T, P.Mw), f32), ((B, T), f32), ((T + 1, B), torch.int32))
         h, c = [h0, self._new(2, B, H)], [c0, self._new(2, B, H)]
         # split-f16 planes of the state ([layer, hi|lo, B, H] f16): the LSTM epilogues write them next to h, so the
         # state's GEMM segments are never split again
@@ -876,7 +877,10 @@ class Captioner(nn.Module):
             for k in ('v', 's', 'f'):
                 if k in ws:
                     ws[k + 'p'] = torch.empty((2,) + tuple(ws[k].shape), dtype=torch.float16, device=self._dev)
-        unfinished = torch.ones(B, dtype=torch.int32, device=self._dev)
+        # the rows' unfinished flags: one array that every finalize updates in place - except on the few-row greedy path,
+        # where step t + 1's first launch does step t's finalize and reads unf[t] while it writes unf[t + 1]
+        unf[0:1].fill_(1)
+        unfinished = unf[0]
         alive[0:1].fill_(B)                     # a fill kernel (a scalar assignment would be a pageable H2D copy)
         use_tab = P.tab is not None
         xt = [None, None] if use_tab else [self._new(B, Wd) for _ in range(2)]
@@ -902,16 +906,30 @@ class Captioner(nn.Module):
         rs.seq, rs.seq_logprobs, rs.seq_masks = seq.data_ptr(), seq_logprobs.data_ptr(), seq_masks.data_ptr()
         rs.unfinished, rs.alive, rs.raw_tokens = unfinished.data_ptr(), alive.data_ptr(), raw.data_ptr()
         rs.emb, rs.xt_add = emb.data_ptr(), None      # the label term lives in P.pre1
+        # up to four rows, arg-max decoding, token table: step t's finalize rides on step t + 1's att-LSTM launch
+        # (isc_rows_ext.fin_prev) - T - 1 launches fewer per roll-out; only the last step's runs on its own
+        fuse = (rows_ext is not None and sample_max and replay is None and use_tab and arm is None and B <= 4
+                and getattr(self, 'rows_fused_finalize', True))
+        rs_prev = RolloutStep.from_buffer_copy(rs) if fuse else None
         with ops.h3_weights_scope(self._dev):      # frozen weights for the whole loop: split them once, not per step
             for t in range(T):
                 cur, nxt = t & 1, (t + 1) & 1
                 om, osc = mask_for('out%d' % t, B, H)
                 ops.TIMER.armed = (arm == t)
+                if fuse:
+                    if t > 0:
+                        rs_prev.t, rs_prev.unfinished = t - 1, unf[t - 1].data_ptr()
+                        rows_ext.fin_prev, rows_ext.fin_unfinished_out = C.addressof(rs_prev), unf[t].data_ptr()
+                    else:
+                        rows_ext.fin_prev = rows_ext.fin_unfinished_out = None
                 # token fed at step t: <SOS>, then seq[:, t-1] (= it * unfinished, written by finalize)
                 self._step(p, P, ws, xt[cur], h[cur], c[cur], h[nxt], c[nxt], aC[:, t], aS[:, t], bG[:, t:t + 1],
                            logits, om, osc, tok=(sos if t == 0 else seq[:, t - 1]) if use_tab else None,
                            hp_cur=hp[cur], hp_nxt=hp[nxt], rows_ext=rows_ext)
+                if fuse and t + 1 < T:
+                    continue
                 rs.t = t
+                rs.unfinished = unf[t].data_ptr() if fuse else unfinished.data_ptr()
                 rs.xt_next = None if use_tab else xt[nxt].data_ptr()
                 ops.rollout_finalize(rs)
         ops.TIMER.armed = False

@@ -185,6 +185,39 @@ __device__ __forceinline__ void half_argmax(float &v, int &i) {
 #undef ISC_ARGMAX_STEP
 }
 
+// A row's tile statistics folded by one wave (the body of pointwise.hip's fold_row_stats; rows.hip folds with it as well):
+// gmax = the row's maximum, gidx = its vocabulary index (smallest index on ties), S = sum exp(x - gmax); all 64 lanes get
+// the result.  Returns true when the row is not finite (the caller flags the numerics status).
+__device__ __forceinline__ bool fold_row_stats_impl(const float *pmax, const float *psum, const int *pidx,
+                                                    int n_tile, int lane, float &gmax, int &gidx, float &S) {
+    // every tile statistic of the row is requested before the first exchange (two strided passes with a reduction
+    // between them were two dependent memory round trips per decode step on the roll-out's critical path)
+    float mx = -INFINITY;
+    int ix = 0x7fffffff;
+    for (int i = lane; i < n_tile; i += 64) {
+        const float v = pmax[i];
+        const int id = pidx ? pidx[i] : i;
+        if (v > mx || (v == mx && id < ix)) { mx = v; ix = id; }
+    }
+    // lane exchanges inside 32-lane halves by DPP, one cross-half swap (same order: value, then the smaller index)
+    half_argmax(mx, ix);
+    {
+        const float ov = __shfl_xor(mx, 32, 64);
+        const int oi = __shfl_xor(ix, 32, 64);
+        if (ov > mx || (ov == mx && oi < ix)) { mx = ov; ix = oi; }
+    }
+    float s = 0.f;
+    for (int i = lane; i < n_tile; i += 64) s += psum[i] * expf(pmax[i] - mx);
+    s = half_sum(s);
+    S = s + __shfl_xor(s, 32, 64);
+    gmax = mx;
+    // a row whose maxima are all NaN never satisfied `v > mx`: its index is still the sentinel, and a consumer would
+    // gather an embedding row 2^31 rows past the table.  Such a row decodes <PAD> (id 0) and is flagged.
+    gidx = ix == 0x7fffffff ? 0 : ix;
+    return !(fabsf(mx) <= 3.0e38f && S <= 3.0e38f);          // NaN fails both
+}
+
+
 // all-reduce over each 16-lane row of the wavefront (the lanes that share (lane >> 4): one output row of the 16x16 MFMA's
 // C/D layout): four DPP steps, no LDS crossbar
 __device__ __forceinline__ float row16_sum(float v) {

@@ -234,31 +234,8 @@ ISC_STATUS_DECL(pw)
 
 __device__ __forceinline__ void fold_row_stats(const float *pmax, const float *psum, const int *pidx,
                                                int n_tile, int lane, float &gmax, int &gidx, float &S) {
-    // every tile statistic of the row is requested before the first exchange (two strided passes with a reduction
-    // between them were two dependent memory round trips per decode step on the roll-out's critical path)
-    float mx = -INFINITY;
-    int ix = 0x7fffffff;
-    for (int i = lane; i < n_tile; i += 64) {
-        const float v = pmax[i];
-        const int id = pidx ? pidx[i] : i;
-        if (v > mx || (v == mx && id < ix)) { mx = v; ix = id; }
-    }
-    // lane exchanges inside 32-lane halves by DPP, one cross-half swap (same order: value, then the smaller index)
-    half_argmax(mx, ix);
-    {
-        const float ov = __shfl_xor(mx, 32, 64);
-        const int oi = __shfl_xor(ix, 32, 64);
-        if (ov > mx || (ov == mx && oi < ix)) { mx = ov; ix = oi; }
-    }
-    float s = 0.f;
-    for (int i = lane; i < n_tile; i += 64) s += psum[i] * expf(pmax[i] - mx);
-    s = half_sum(s);
-    S = s + __shfl_xor(s, 32, 64);
-    gmax = mx;
-    // a row whose maxima are all NaN never satisfied `v > mx`: its index is still the sentinel, and a consumer would
-    // gather an embedding row 2^31 rows past the table.  Such a row decodes <PAD> (id 0) and is flagged.
-    gidx = ix == 0x7fffffff ? 0 : ix;
-    if (lane == 0 && !(fabsf(mx) <= 3.0e38f && S <= 3.0e38f)) isc_flag_pw(ISC_STATUS_WORD_STATS);     // NaN fails both
+    if (fold_row_stats_impl(pmax, psum, pidx, n_tile, lane, gmax, gidx, S) && lane == 0)
+        isc_flag_pw(ISC_STATUS_WORD_STATS);
 }
 
 // ------------------------------------------------------------------ roll-out step
@@ -421,6 +398,9 @@ __global__ __launch_bounds__(1024) void rollout_finalize_wide_kernel(const DevRo
     }
 }
 
+static std::atomic<long long> g_finalize_launches{0};
+extern "C" long long isc_rollout_finalize_launches(void) { return g_finalize_launches.load(); }
+
 extern "C" int isc_rollout_finalize(const isc_rollout_step *s, void *stream) {
     if (!s) return ISC_E_NULL;
     if (!s->part_max || !s->part_sum || !s->part_idx || !s->seq || !s->seq_logprobs || !s->seq_masks ||
@@ -442,6 +422,7 @@ extern "C" int isc_rollout_finalize(const isc_rollout_step *s, void *stream) {
     else
         hipLaunchKernelGGL(rollout_finalize_kernel, dim3((s->B + 3) / 4), dim3(256), 0, (hipStream_t)stream, R);
     ISC_LAUNCH_CHECK();
+    ++g_finalize_launches;
     return ISC_OK;
 }
 

@@ -25,6 +25,7 @@
 #include "common.h"
 
 #define ROWS_MAX 8
+#define ROWS_FIN_MAX 4       // isc_rows_ext.fin_prev: rows up to which the previous step's finalize rides on the att-LSTM launch
 #define ROWS_MAX_SLICE 12
 #define ROWS_KC 8                    // candidate slots per (row, column tile)
 #if ROWS_STAMP
@@ -210,7 +211,20 @@ struct RLstmArgs {
     const float *b_ih, *b_hh, *pre, *tab;
     const long long *tab_ids;
     long long tab_ids_stride;
+    // optional (pmax != null): the PREVIOUS decode step's roll-out finalize (isc_rollout_finalize, greedy form) done by
+    // this launch - see isc_rows_ext.fin_prev
+    struct Fin {
+        const float *pmax, *psum;
+        const int *pidx;
+        int n_tile, T, t;
+        long long eos;
+        long long *seq, *raw;
+        float *lp, *masks;
+        const int *unf_in;
+        int *unf_out, *alive;
+    } fin;
 };
+ISC_STATUS_DECL(rows)
 
 template <int MR, int UPW, bool NT>
 __global__ __launch_bounds__(768) void rows_lstm_kernel(const RLstmArgs a) {
@@ -275,7 +289,113 @@ __global__ __launch_bounds__(768) void rows_lstm_kernel(const RLstmArgs a) {
     const int ul = lane / MR, m = lane - ul * MR, unit = u0 + ul;
     const bool ok = ul < U && m < M && unit < H;
     long long tok = 0;
-    if (ok && a.tab) tok = a.tab_ids[(long long)m * a.tab_ids_stride];
+    if (MR <= ROWS_FIN_MAX && a.fin.pmax) {    // (compiled for up to four rows: with more the fold outlasts the launch it saves)
+        // The previous step's finalize (captioner.py:329-344, greedy): its tile statistics folded here, by the wave that
+        // waits for the partial sums anyway - every workgroup derives the tokens it feeds (rows x 250 tiles, L2-hot),
+        // workgroup 0 writes that step's outputs.  The unfinished flags are read from one array and written to another:
+        // the other workgroups read them while workgroup 0 updates.  Same fold, same arithmetic as the finalize kernel.
+        const RLstmArgs::Fin &F = a.fin;
+        int alive_next = 0, my_tok = 0;
+        const int alive_t = F.alive[F.t];
+        if (F.n_tile <= 256) {
+            // every row's statistics requested at once, the rows' reductions side by side (independent chains), the stores
+            // last: the fold is over before the activations of this step are staged - one row after the other, with the
+            // writer's stores in between, it took longer than the finalize launch it replaces
+            float pmv[MR][4], psv[MR][4];
+            int piv[MR][4], un[MR];
+#pragma unroll
+            for (int r = 0; r < MR; ++r) {
+                const long long so = (long long)(r < M ? r : M - 1) * F.n_tile;
+                un[r] = F.unf_in[r < M ? r : M - 1];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int i = lane + 64 * q, ic = i < F.n_tile ? i : F.n_tile - 1;
+                    pmv[r][q] = F.pmax[so + ic]; psv[r][q] = F.psum[so + ic]; piv[r][q] = F.pidx[so + ic];
+                }
+            }
+            float mx[MR], sm[MR];
+            int ix[MR];
+#pragma unroll
+            for (int r = 0; r < MR; ++r) {                   // (fold_row_stats_impl, with the loads hoisted)
+                mx[r] = -INFINITY; ix[r] = 0x7fffffff;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (lane + 64 * q < F.n_tile) {
+                        const float v = pmv[r][q];
+                        const int id = piv[r][q];
+                        if (v > mx[r] || (v == mx[r] && id < ix[r])) { mx[r] = v; ix[r] = id; }
+                    }
+            }
+#pragma unroll
+            for (int r = 0; r < MR; ++r) half_argmax(mx[r], ix[r]);
+#pragma unroll
+            for (int r = 0; r < MR; ++r) {
+                const float ov = __shfl_xor(mx[r], 32, 64);
+                const int oi = __shfl_xor(ix[r], 32, 64);
+                if (ov > mx[r] || (ov == mx[r] && oi < ix[r])) { mx[r] = ov; ix[r] = oi; }
+            }
+#pragma unroll
+            for (int r = 0; r < MR; ++r) {
+                float s = 0.f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (lane + 64 * q < F.n_tile) s += psv[r][q] * expf(pmv[r][q] - mx[r]);
+                sm[r] = half_sum(s);
+            }
+#pragma unroll
+            for (int r = 0; r < MR; ++r) sm[r] += __shfl_xor(sm[r], 32, 64);
+            const bool writer = blockIdx.x == 0 && lane == 0 && alive_t != 0;    // (alive == 0: the reference has left its loop)
+#pragma unroll
+            for (int r = 0; r < MR; ++r) {
+                if (r < M) {                                 // (uniform)
+                    if (lane == 0 && !(fabsf(mx[r]) <= 3.0e38f && sm[r] <= 3.0e38f)) isc_flag_rows(ISC_STATUS_WORD_STATS);
+                    const int gidx = ix[r] == 0x7fffffff ? 0 : ix[r];
+                    const long long itm = un[r] ? gidx : 0;  // finished rows feed <PAD> (id 0): `it * unfinished`
+                    const int u2 = un[r] && (itm != F.eos);
+                    alive_next += u2;
+                    my_tok = m == r ? (int)itm : my_tok;
+                    if (writer) {
+                        const long long o = (long long)r * F.T + F.t;
+                        F.masks[o] = (float)un[r];
+                        F.seq[o] = itm;
+                        F.lp[o] = -logf(sm[r]);              // log_softmax at the arg-max: (x_max - x_max) - log S
+                        if (F.raw) F.raw[o] = gidx;
+                        F.unf_out[r] = u2;
+                    }
+                }
+            }
+            if (writer && alive_next) F.alive[F.t + 1] = alive_next;
+        } else {
+            const bool writer = blockIdx.x == 0 && lane == 0 && alive_t != 0;
+#pragma unroll
+            for (int r = 0; r < MR; ++r) {
+                if (r < M) {                                 // (uniform)
+                    float gmax, S;
+                    int gidx;
+                    const long long so = (long long)r * F.n_tile;
+                    if (fold_row_stats_impl(F.pmax + so, F.psum + so, F.pidx + so, F.n_tile, lane, gmax, gidx, S) && lane == 0)
+                        isc_flag_rows(ISC_STATUS_WORD_STATS);
+                    const int u = F.unf_in[r];
+                    const long long itm = u ? gidx : 0;
+                    const int u2 = u && (itm != F.eos);
+                    alive_next += u2;
+                    my_tok = m == r ? (int)itm : my_tok;
+                    if (writer) {
+                        const long long o = (long long)r * F.T + F.t;
+                        F.masks[o] = (float)u;
+                        F.seq[o] = itm;
+                        F.lp[o] = -logf(S);
+                        if (F.raw) F.raw[o] = gidx;
+                        F.unf_out[r] = u2;
+                    }
+                }
+            }
+            if (writer && alive_next) F.alive[F.t + 1] = alive_next;
+        }
+        tok = my_tok;
+    } else if (ok && a.tab) {
+        tok = a.tab_ids[(long long)m * a.tab_ids_stride];
+    }
     long long rs = m;
     if (ok && a.has_src) rs = a.src[m];
     if (run == 0) return;
@@ -380,8 +500,10 @@ static int rows_lstm_launch(const RLstmArgs &a, int grid, int threads, size_t ld
 static int rows_lstm(const float *const *A, const int *lda, const float *const *W, const int *ldw, const int *K,
                      const int *ind, int nseg, int M, int H, const int64_t *src, const float *c_prev, float *h_out,
                      float *c_out, const float *b_ih, const float *b_hh, const float *pre, const float *tab,
-                     const int64_t *tab_ids, int64_t tab_ids_stride, int row_div, const int *skip, hipStream_t st) {
+                     const int64_t *tab_ids, int64_t tab_ids_stride, int row_div, const int *skip, hipStream_t st,
+                     const RLstmArgs::Fin *fin = nullptr) {
     RLstmArgs a = {};
+    if (fin) a.fin = *fin;
     const int nslice = rows_make_segs(a.g, A, lda, W, ldw, K, ind, nseg, 8);
     if (nslice < 1) return ISC_E_SHAPE;
     if (M < 1 || M > ROWS_MAX || H < 1) return ISC_E_SHAPE;
@@ -1110,8 +1232,23 @@ extern "C" int isc_rows_step_fwd(const isc_step_plan *p, const isc_rows_ext *x, 
         As[n] = p->h2_prev; lda[n] = H; Ws[n] = p->Wih1; ldw[n] = ld1; K[n] = H; ind[n] = 1; ++n;
         if (!p->tab) { As[n] = p->xt; lda[n] = W; Ws[n] = p->Wih1 + H + E; ldw[n] = ld1; K[n] = W; ind[n] = 0; ++n; }
         As[n] = p->h1_prev; lda[n] = H; Ws[n] = p->Whh1; ldw[n] = H; K[n] = H; ind[n] = 1; ++n;
+        RLstmArgs::Fin fin = {};
+        const isc_rollout_step *f = x->fin_prev;
+        if (f) {        // the previous step's greedy finalize rides on this launch (isc_rows_ext.fin_prev)
+            if (!p->tab || row_div != 1 || src || skip || rows > ROWS_FIN_MAX) return ISC_E_SHAPE;
+            if (f->forced || f->sample_u || f->xt_next) return ISC_E_SHAPE;
+            if (!f->part_max || !f->part_sum || !f->part_idx || !f->seq || !f->seq_logprobs || !f->seq_masks ||
+                !f->unfinished || !f->alive || !x->fin_unfinished_out)
+                return ISC_E_NULL;
+            if (f->B != rows || f->T <= 0 || f->t < 0 || f->t + 1 >= f->T || f->n_tile <= 0) return ISC_E_SHAPE;
+            fin.pmax = f->part_max; fin.psum = f->part_sum; fin.pidx = f->part_idx;
+            fin.n_tile = f->n_tile; fin.T = f->T; fin.t = f->t; fin.eos = f->eos_id;
+            fin.seq = reinterpret_cast<long long *>(f->seq); fin.raw = reinterpret_cast<long long *>(f->raw_tokens);
+            fin.lp = f->seq_logprobs; fin.masks = f->seq_masks;
+            fin.unf_in = f->unfinished; fin.unf_out = x->fin_unfinished_out; fin.alive = f->alive;
+        }
         RET(rows_lstm(As, lda, Ws, ldw, K, ind, n, rows, H, src, p->c1_prev, p->h1, p->c1, nullptr, nullptr, p->pre1,
-                      p->tab, p->tok, p->tok_stride, row_div, skip, st));
+                      p->tab, p->tok, p->tok_stride, row_div, skip, st, f ? &fin : nullptr));
     }
     {   // projections of h_att: h2att (content), h2word (sentiment), the gate's h-term
         const float *Ws[3] = {p->W_h2att, p->W_h2word, p->W_gh}, *bs[3] = {p->b_h2att, p->b_h2word, p->b_gh};

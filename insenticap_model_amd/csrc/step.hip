@@ -218,13 +218,14 @@ extern "C" int isc_step_bwd(const isc_step_bwd_plan *p, void *stream) {
 // ------------------------------------------------------------------ numerics status
 int isc_set_status_gemm_(unsigned int *p);         // gemm_f32.hip
 int isc_set_status_pw_(unsigned int *p);           // pointwise.hip
+int isc_set_status_rows_(unsigned int *p);         // rows.hip
 #define ISC_STATUS_MAX_DEVICES 64
 static unsigned int *g_status_host[ISC_STATUS_MAX_DEVICES] = {};     // per device: the words registered for it
 
 extern "C" int isc_set_status_words(unsigned int *words2) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= ISC_STATUS_MAX_DEVICES) return 1;
-    if (isc_set_status_gemm_(words2) || isc_set_status_pw_(words2)) return 1;
+    if (isc_set_status_gemm_(words2) || isc_set_status_pw_(words2) || isc_set_status_rows_(words2)) return 1;
     g_status_host[dev] = words2;
     return ISC_OK;
 }

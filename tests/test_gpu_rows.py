@@ -269,6 +269,47 @@ def test_beam_graphs_replay_equals_eager_on_this_path():
         np.testing.assert_allclose(out[1], ref[1], atol=1e-6)
 
 
+@pytest.mark.parametrize('B', [1, 2, 3, 4])
+def test_finalize_folded_into_the_next_steps_first_launch_equals_the_finalize_launches(B):
+    """Few-row greedy roll-outs: step t's isc_rollout_finalize rides on step t + 1's att-LSTM launch
+    (isc_rows_ext.fin_prev; cap.rows_fused_finalize = False keeps one finalize launch per step).  Same fold, same
+    arithmetic: tokens, log-probs, masks, raw tokens and the executed-step counters are bit-identical - also when rows
+    end early (an <EOS> placed where a row emits it) and when every row has ended (the reference's early break)."""
+    cap = _captioner(10000, synth.DEFAULT_SETTINGS, seed=3)
+    cap.enable_rollout_graphs(False)
+    big = _inputs(160, 10000, synth.DEFAULT_SETTINGS, 36, seed=18)
+    with torch.no_grad():               # (160 x 20 token-steps: the token table is built, and cached for the small calls)
+        cap(big['fc_feats'], big['att_feats'], big['cpt_words'], big['senti_words'], big['senti_labels'], 20, 1, mode='rl')
+    d = _inputs(B, 10000, synth.DEFAULT_SETTINGS, 36, seed=17)
+    args = (d['fc_feats'], d['att_feats'], d['cpt_words'], d['senti_words'], d['senti_labels'], 20, 1)
+    fin = ops._lib.load().isc_rollout_finalize_launches
+
+    def run(fused):
+        cap.rows_fused_finalize = fused
+        n0, f0 = _n(), fin()
+        with torch.no_grad():
+            seq, lp, mk = cap(*args, mode='rl')
+        torch.cuda.synchronize()
+        assert _n() - n0 == 5 * 20
+        assert fin() - f0 == (1 if fused else 20)
+        return seq.cpu(), lp.cpu(), mk.cpu(), cap.cont_weights.cpu(), cap.senti_weights.cpu()
+    eos0 = cap.eos_id
+    try:
+        base = run(False)
+        cases = [eos0, int(base[0][0, 2]), int(base[0][B - 1, 7])]      # no early end / row 0 ends at step 2 / a later one
+        for eos in cases:
+            cap.eos_id = eos
+            a, b = run(True), run(False)
+            for x, y in zip(a, b):
+                assert torch.equal(x, y), eos
+            if eos == cases[1]:         # row 0 ends where it first emits that token (at step 2 at the latest)
+                first = int((base[0][0] == eos).nonzero()[0])
+                assert first <= 2 and float(a[2][0, first + 1:].sum()) == 0.0 and float(a[2][0, :first + 1].sum()) == first + 1
+    finally:
+        cap.eos_id = eos0
+        cap.rows_fused_finalize = True
+
+
 def test_few_row_beam_graph_follows_in_place_changes_of_the_prologue_weights():
     """A few-row search's graph keeps the f16 planes of its prologue's weights (built once in front of the capture, not
     re-split by every replay): a weight of the prologue changed in place must not be served from the old planes - the
