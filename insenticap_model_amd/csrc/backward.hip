@@ -761,6 +761,11 @@ extern "C" int isc_embed_relu_bwd(const float *emb, int V, int W, const int64_t 
 // the ids that occur, in id order, (3) every position drops itself into its id's segment (integer atomic cursor: the
 // order INSIDE a segment is arbitrary), (4) one workgroup per occurring id sorts its segment ascending in LDS and sums the
 // rows in that order, eight loads in flight - the summation order of the kernel above, so the two agree bit for bit.
+__global__ __launch_bounds__(256) void emb_zero_kernel(int *p, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = 0;
+}
+
 __global__ __launch_bounds__(256) void emb_count_kernel(EmbIds I, int n_rows, int V, int *count) {
     const int r = blockIdx.x * 256 + threadIdx.x;
     if (r >= n_rows) return;
@@ -901,8 +906,10 @@ extern "C" int isc_embed_relu_bwd_ws(const float *emb, int V, int W, const int64
     hipStream_t st = (hipStream_t)stream;
     int *count = static_cast<int *>(workspace), *cursor = count + V, *offset = cursor + V, *active = offset + V;
     int *n_active = active + V, *list = n_active + 64;
-    hipError_t e = hipMemsetAsync(count, 0, (size_t)2 * V * sizeof(int), st);           // count and cursor
-    if (e != hipSuccess) return (int)e;
+    // count and cursor start at zero - by a kernel, not hipMemsetAsync: a captured memset NODE did not always clear them on
+    // replay (training graphs: counts piled up over replays, the fill kernel wrote past the list, the accumulate kernel read
+    // slots nobody had written - GPU memory faults in emb_fill_kernel / emb_accumulate_kernel)
+    hipLaunchKernelGGL(emb_zero_kernel, dim3((unsigned)((2 * V + 255) / 256)), dim3(256), 0, st, count, 2 * V);
     EmbIds I = {ids, (long long)ids_stride, (long long)pad_id, (long long)skip_id, pad_first};
     const unsigned nb = (unsigned)((n_rows + 255) / 256);
     hipLaunchKernelGGL(emb_count_kernel, dim3(nb), dim3(256), 0, st, I, n_rows, V, count);

@@ -12,6 +12,7 @@ import torch
 from insenticap_model_amd import ops
 
 pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
 
 
 def _call(entry, emb, ids, ids_stride, n_rows, rows_per_grad, pad_first, pad_id, dout, scale, mask, mask_scale, demb,
@@ -86,3 +87,53 @@ def test_small_calls_fall_back_to_the_scanning_kernel():
     _call('scan', emb, ids, 1, 100, 1, 0, 0, dout, 1.0, None, 1.0, b, -1)
     torch.cuda.synchronize()
     assert torch.equal(a, b)
+
+
+def test_position_index_inside_a_captured_graph_with_new_ids_every_replay():
+    """Training graphs replay the indexed backward with other token ids every time (sampled roll-outs, scheduled sampling),
+    several calls per graph on one workspace.  Its counters were once cleared by hipMemsetAsync: captured as a memset
+    node that did not always clear them on replay - counts piled up, emb_fill_kernel wrote past the list and
+    emb_accumulate_kernel read slots nobody had written (GPU memory faults in the RL training graph under a process
+    group).  They are cleared by a kernel now: replays with fresh ids equal the eager launches bit for bit."""
+    g = torch.Generator().manual_seed(11)
+    V, W, n = 3000, 96, 5120
+    emb = (torch.rand(V, W, generator=g) - 0.3).to(DEV)
+    douts = [torch.randn(n, W, generator=g).to(DEV) for _ in range(3)]
+    ids = [torch.zeros(n, dtype=torch.int64, device=DEV) for _ in range(3)]
+    outs = [torch.zeros(V, W, device=DEV) for _ in range(3)]
+
+    def draw(k):
+        # skewed: a few hundred distinct ids, some of them thousands of times (window mode), <PAD> skipped in call 0
+        hot = torch.randint(0, 40, (n,), generator=g)
+        cold = torch.randint(0, V, (n,), generator=g)
+        pick = torch.rand(n, generator=g) < (0.3 + 0.2 * k)
+        return torch.where(pick, hot, cold)
+
+    def launches():
+        for o in outs:
+            o.zero_()
+        ops.embed_relu_bwd(emb, ids[0], douts[0], outs[0], n, skip_id=0)
+        ops.embed_relu_bwd(emb, ids[1], douts[1], outs[1], n, scale=0.5)
+        ops.embed_relu_bwd(emb, ids[2], douts[2], outs[2], n)
+    for k in range(3):
+        ids[k].copy_(draw(k))
+    st = torch.cuda.Stream()
+    st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        launches()                                      # warm (allocates the stream's workspace outside the capture)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=st):
+            launches()
+    torch.cuda.current_stream().wait_stream(st)
+    torch.cuda.synchronize()
+    for rep in range(5):
+        for k in range(3):
+            ids[k].copy_(draw(k + rep))
+        graph.replay()
+        torch.cuda.synchronize()
+        got = [o.clone() for o in outs]
+        with torch.cuda.stream(st):
+            launches()
+        torch.cuda.synchronize()
+        for a, b in zip(got, outs):
+            assert torch.equal(a, b), rep
