@@ -307,6 +307,13 @@ int isc_sched_sample(const float *logp, int64_t ld, int M, int V, const float *p
                      const float *part_sum, const int32_t *part_idx, const float *u_select,
                      const float *u_draw, float ss_prob, const int64_t *base_ids, int64_t base_stride,
                      int64_t *out_ids, void *stream);
+/* The same draw from the row's RAW logits (the statistics describe them: exp(x - max) against the tile masses, as
+ * isc_rollout_finalize draws): an unroll with scheduled sampling then normalises its logits once, after its last step
+ * (isc_logsoftmax_apply_steps), instead of once per step. */
+int isc_sched_sample_raw(const float *logits, int64_t ld, int M, int V, const float *part_max,
+                     const float *part_sum, const int32_t *part_idx, const float *u_select,
+                     const float *u_draw, float ss_prob, const int64_t *base_ids, int64_t base_stride,
+                     int64_t *out_ids, void *stream);
 
 /* Beam step (sample(), captioner.py:390-409), batched over images: for every live beam row
  * apply the -inf masks (PAD,SOS,UNK, last word), take its top-`beam` (value, id) pairs

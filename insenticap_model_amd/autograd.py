@@ -67,8 +67,11 @@ def _train_forward(cap, mode, fc, att, cpt_words, senti_words, tokens_in, senti_
     S.out_masks, S.out_scale = [], 1.0
     S.hdrop = None
     n_tile = (V + 127) // 128
-    pm, ps = new(B, n_tile), new(B, n_tile)
-    pi = new(B, n_tile, dtype=torch.int32)
+    # per-step tile statistics [T, B, n_tile]: the logits become log-probs in ONE launch after the last step
+    # (isc_logsoftmax_apply_steps) - in every form of the unroll: the draws of the sampled and the scheduled-sampling
+    # forms read a step's RAW logits with its statistics (20 + 20 + 20 normalising launches per RL iteration -> 3)
+    pm_st, ps_st = new(T, B, n_tile), new(T, B, n_tile)
+    pi_st = new(T, B, n_tile, dtype=torch.int32)
     out = new(B, T, V)
     emb = p['word_embed.0.weight']
     plan = cap._make_plan(p, P, B)
@@ -82,7 +85,7 @@ def _train_forward(cap, mode, fc, att, cpt_words, senti_words, tokens_in, senti_
         forced, sample_u = tokens_in.get('forced'), tokens_in.get('u')
         rs = RolloutStep()
         rs.B, rs.V, rs.T, rs.n_tile, rs.W = B, V, T, n_tile, Wd
-        rs.part_max, rs.part_sum, rs.part_idx = pm.data_ptr(), ps.data_ptr(), pi.data_ptr()
+        rs.part_max, rs.part_sum, rs.part_idx = pm_st[0].data_ptr(), ps_st[0].data_ptr(), pi_st[0].data_ptr()
         rs.ld_logits = out.stride(0)
         rs.forced, rs.sample_u, rs.eos_id = ops.ptr(forced), ops.ptr(sample_u), cap.eos_id
         rs.seq, rs.seq_logprobs, rs.seq_masks = seq.data_ptr(), seq_lp.data_ptr(), seq_masks.data_ptr()
@@ -99,8 +102,7 @@ def _train_forward(cap, mode, fc, att, cpt_words, senti_words, tokens_in, senti_
         # ... and nothing reads a step's logits before the unroll ends: the classifier runs ONCE over all steps'
         # h_lang [T*B, H] afterwards (at B = 128: 20 skinny launches of 24 us -> one [2560 x V] launch), and one
         # more launch turns its [T,B,V] logits into the [B,T,V] log-probs
-        pm_all, ps_all = new(T, B, n_tile), new(T, B, n_tile)
-        pi_all = new(T, B, n_tile, dtype=torch.int32)
+        pm_all, ps_all, pi_all = pm_st, ps_st, pi_st
     # the weights are fixed for the whole unroll: their f16 planes are built once (few-row launches then take the
     # one-launch skinny split-f16 kernels instead of split-K + reduce pairs)
     with _weights_scope(cap):
@@ -111,7 +113,8 @@ def _train_forward(cap, mode, fc, att, cpt_words, senti_words, tokens_in, senti_
             elif not fed_known:
                 if t >= 1:                                    # scheduled sampling, captioner.py:219-228:
                     u = torch.rand(2, B, device=cap._dev)     # select + draw on the device, no host test
-                    ops.sched_sample(out[:, t - 1], pm, ps, pi, u[0], u[1], ss_prob, tokens_in[:, t], S.tok[t])
+                    ops.sched_sample(out[:, t - 1], pm_st[t - 1], ps_st[t - 1], pi_st[t - 1], u[0], u[1], ss_prob,
+                                     tokens_in[:, t], S.tok[t], raw=True)
                 else:
                     S.tok[t] = tokens_in[:, t]
                 ops.embed_relu_fwd(emb, S.tok[t], S.xt[t])        # plain relu(Emb[tok]); label term is in P.pre1
@@ -123,7 +126,8 @@ def _train_forward(cap, mode, fc, att, cpt_words, senti_words, tokens_in, senti_
                 save['hdrop'] = S.hdrop[t]
                 S.out_scale = osc
             S.out_masks.append(om)
-            ws = {'_plan': plan} if pm_all is not None else {'pmax': pm, 'psum': ps, 'pidx': pi, '_plan': plan}
+            ws = {'_plan': plan} if pm_all is not None else {'pmax': pm_st[t], 'psum': ps_st[t], 'pidx': pi_st[t],
+                                                              '_plan': plan}
             if has_c:
                 ws['qa'], ws['v'] = S.qa[t], S.v[t]
             if has_s:
@@ -135,12 +139,12 @@ def _train_forward(cap, mode, fc, att, cpt_words, senti_words, tokens_in, senti_
                       (S.h1[t + 1], S.h2[t + 1]), (S.c1[t + 1], S.c2[t + 1]),
                       S.aC[:, t] if has_c else None, S.aS[:, t] if has_s else None,
                       S.bG[:, t:t + 1] if (has_c and has_s) else None, logits, om, osc, save=save,
-                      normalize=not sampling and pm_all is None)
-            if sampling:                                      # draw on the raw logits, then turn them into log-probs
+                      normalize=False)
+            if sampling:                                      # draw on the raw logits (normalised after the loop)
                 rs.t, rs.logits = t, logits.data_ptr()
+                rs.part_max, rs.part_sum, rs.part_idx = pm_st[t].data_ptr(), ps_st[t].data_ptr(), pi_st[t].data_ptr()
                 rs.xt_next = S.xt[t + 1].data_ptr() if t + 1 < T else None
                 ops.rollout_finalize(rs)
-                ops.logsoftmax_apply(logits, pm, ps)
         if pm_all is not None:
             hs = S.hdrop if S.hdrop is not None else S.h2[1:]
             raw = new(T, B, V)
@@ -148,6 +152,8 @@ def _train_forward(cap, mode, fc, att, cpt_words, senti_words, tokens_in, senti_
                           ps_all.view(T * B, n_tile), pi_all.view(T * B, n_tile), raw.view(T * B, V))
             ops.logsoftmax_apply_steps(out, pm_all, ps_all, src_tbv=raw)
             del raw
+        else:
+            ops.logsoftmax_apply_steps(out, pm_st, ps_st)     # in place: [B,T,V] raw logits -> log-probs
     if sampling:
         S.sample = (seq, seq_masks, raw, alive)
     cap._set_weights(S.aC if has_c else None, S.aS if has_s else None,

@@ -3334,7 +3334,11 @@ struct H3WScope {
     int n = 0;
     bool active = false;
 };
-#define H3W_MAX_SCOPES 16
+// 64 slots: more than the streams a process can hold (torch hands out 32 pool streams per device and priority, plus the
+// default stream), so begin never has to take over a SUSPENDED slot of another stream.  With 16 slots a test session
+// that kept many captioners / training graphs alive ran out of them, and after such a take-over a captured training
+// graph (seq2seq branch) computed its loss from planes one update old (graph vs eager 6.0207 / 6.0188; order-dependent).
+#define H3W_MAX_SCOPES 64
 static H3WScope g_h3w[H3W_MAX_SCOPES];
 static std::mutex g_h3w_mu;
 

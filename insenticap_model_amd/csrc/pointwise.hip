@@ -430,6 +430,10 @@ extern "C" int isc_rollout_finalize(const isc_rollout_step *s, void *stream) {
 // out[b] = (u_select[b] < ss_prob) ? draw from exp(logp[b, :]) with uniform u_draw[b] : base[b].
 // One launch and no host decision in place of rand / `if mask.sum() == 0` / multinomial / index_copy_:
 // the reference's host test costs a device->host sync at every step.
+// RAW: `logp` holds the raw logits of the row (the statistics describe them): the draw is then the roll-out's
+// (exp(x - max) against tile masses psum * exp(pmax - max)) and a teacher-forced unroll with scheduled sampling can turn
+// its logits into log-probs ONCE, after the last step, instead of step by step.
+template <bool RAW>
 __global__ __launch_bounds__(256) void sched_sample_kernel(const float *logp, long long ld, int M, int V,
                                                            const float *pmax, const float *psum, const int *pidx,
                                                            int n_tile, const float *u_select, const float *u_draw,
@@ -444,25 +448,47 @@ __global__ __launch_bounds__(256) void sched_sample_kernel(const float *logp, lo
         int gidx;
         fold_row_stats(pmax + (long long)b * n_tile, psum + (long long)b * n_tile, pidx + (long long)b * n_tile,
                        n_tile, lane, gmax, gidx, S);
-        const int pick = sample_two_level(logp + (long long)b * ld, 0.f, S, pmax + (long long)b * n_tile,
-                                          psum + (long long)b * n_tile, n_tile, V, gmax, u_draw[b] * S, lane);
+        const int pick = sample_two_level(logp + (long long)b * ld, RAW ? gmax : 0.f, RAW ? 1.0f : S,
+                                          pmax + (long long)b * n_tile, psum + (long long)b * n_tile, n_tile, V, gmax,
+                                          u_draw[b] * S, lane);
         it = pick < 0 ? gidx : pick;
     }
     if (lane == 0) out[b] = it;
+}
+
+static int sched_sample_launch(bool raw, const float *logp, int64_t ld, int M, int V, const float *part_max,
+                               const float *part_sum, const int32_t *part_idx, const float *u_select,
+                               const float *u_draw, float ss_prob, const int64_t *base_ids, int64_t base_stride,
+                               int64_t *out_ids, void *stream) {
+    if (!logp || !part_max || !part_sum || !part_idx || !u_select || !u_draw || !base_ids || !out_ids)
+        return ISC_E_NULL;
+    if (M <= 0 || V <= 0) return ISC_E_SHAPE;
+    if (raw)
+        hipLaunchKernelGGL(sched_sample_kernel<true>, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, logp,
+                           (long long)ld, M, V, part_max, part_sum, part_idx, (V + 127) / 128, u_select, u_draw, ss_prob,
+                           base_ids, (long long)base_stride, out_ids);
+    else
+        hipLaunchKernelGGL(sched_sample_kernel<false>, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, logp,
+                           (long long)ld, M, V, part_max, part_sum, part_idx, (V + 127) / 128, u_select, u_draw, ss_prob,
+                           base_ids, (long long)base_stride, out_ids);
+    ISC_LAUNCH_CHECK();
+    return ISC_OK;
 }
 
 extern "C" int isc_sched_sample(const float *logp, int64_t ld, int M, int V, const float *part_max,
                                 const float *part_sum, const int32_t *part_idx, const float *u_select,
                                 const float *u_draw, float ss_prob, const int64_t *base_ids, int64_t base_stride,
                                 int64_t *out_ids, void *stream) {
-    if (!logp || !part_max || !part_sum || !part_idx || !u_select || !u_draw || !base_ids || !out_ids)
-        return ISC_E_NULL;
-    if (M <= 0 || V <= 0) return ISC_E_SHAPE;
-    hipLaunchKernelGGL(sched_sample_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, logp,
-                       (long long)ld, M, V, part_max, part_sum, part_idx, (V + 127) / 128, u_select, u_draw, ss_prob,
-                       base_ids, (long long)base_stride, out_ids);
-    ISC_LAUNCH_CHECK();
-    return ISC_OK;
+    return sched_sample_launch(false, logp, ld, M, V, part_max, part_sum, part_idx, u_select, u_draw, ss_prob, base_ids,
+                               base_stride, out_ids, stream);
+}
+
+extern "C" int isc_sched_sample_raw(const float *logits, int64_t ld, int M, int V, const float *part_max,
+                                    const float *part_sum, const int32_t *part_idx, const float *u_select,
+                                    const float *u_draw, float ss_prob, const int64_t *base_ids, int64_t base_stride,
+                                    int64_t *out_ids, void *stream) {
+    return sched_sample_launch(true, logits, ld, M, V, part_max, part_sum, part_idx, u_select, u_draw, ss_prob, base_ids,
+                               base_stride, out_ids, stream);
 }
 
 // ------------------------------------------------------------------ several small device-to-device copies, one launch

@@ -628,15 +628,16 @@ def rollout_finalize(step):
     TIMER.end(e0, 'rollout_finalize[%d]' % step.B, 0.0, 4.0 * step.B * (3 * step.n_tile + 2 * step.W))
 
 
-def sched_sample(logp, part_max, part_sum, part_idx, u_select, u_draw, ss_prob, base_ids, out_ids):
-    """out_ids[b] = u_select[b] < ss_prob ? draw from exp(logp[b]) : base_ids[b]  (base_ids may be a strided column)."""
+def sched_sample(logp, part_max, part_sum, part_idx, u_select, u_draw, ss_prob, base_ids, out_ids, raw=False):
+    """out_ids[b] = u_select[b] < ss_prob ? draw from exp(logp[b]) : base_ids[b]  (base_ids may be a strided column).
+    raw: `logp` holds the row's raw logits (isc_sched_sample_raw)."""
     lib = _lib.load()
     M, V = logp.shape
     assert logp.stride(1) == 1 and out_ids.is_contiguous() and base_ids.dtype == torch.int64
-    check(lib.isc_sched_sample(logp.data_ptr(), logp.stride(0), M, V, part_max.data_ptr(), part_sum.data_ptr(),
-                               part_idx.data_ptr(), u_select.data_ptr(), u_draw.data_ptr(), float(ss_prob),
-                               base_ids.data_ptr(), base_ids.stride(0), out_ids.data_ptr(), stream()),
-          'isc_sched_sample')
+    fn = lib.isc_sched_sample_raw if raw else lib.isc_sched_sample
+    check(fn(logp.data_ptr(), logp.stride(0), M, V, part_max.data_ptr(), part_sum.data_ptr(),
+             part_idx.data_ptr(), u_select.data_ptr(), u_draw.data_ptr(), float(ss_prob),
+             base_ids.data_ptr(), base_ids.stride(0), out_ids.data_ptr(), stream()), 'isc_sched_sample')
 
 
 def beam_topk(logits, part_max, part_sum, last_word, beam, pad_id, sos_id, unk_id, mask_special,
