@@ -3843,14 +3843,28 @@ static unsigned try_h3_tn(DevLaunch &L, float *ws, long long ws_floats, hipStrea
         const long long per_k = (long long)p.M + p.N;
         chunk[i] = Kp;
         if (ok && per_k * Kp + 1024 > ws_floats) {
+            // planes larger than the workspace: K chunks that accumulate into C - a multi-segment problem segment by
+            // segment (the [fc | label] block of the att-LSTM's dW at B >= 512 is two segments of T B rows: 22-45 GFLOP
+            // that used to stay on the fp32 tiles, 0.2-0.4 ms per sweep)
             chunk[i] = ((ws_floats - 1024) / per_k) & ~31LL;
-            if (p.nseg != 1 || chunk[i] < 512) ok = false;
+            if (chunk[i] < 512) ok = false;
         }
         if (ok) take |= 1u << i;
     }
     for (int i = 0; i < L.nprob; ++i) {
         if (!(take & (1u << i))) continue;
-        const DevProb &p0 = L.p[i];
+        const DevProb &pfull = L.p[i];
+        long long Kfull = 0;
+        for (int s = 0; s < pfull.nseg; ++s) Kfull += pfull.seg[s].K;
+        const bool by_seg = pfull.nseg > 1 && chunk[i] < Kfull;      // does not fit: one single-segment pass per segment
+        const int npass = by_seg ? pfull.nseg : 1;
+        for (int pass = 0; pass < npass; ++pass) {
+        DevProb p0 = pfull;
+        if (by_seg) {
+            p0.nseg = 1;
+            p0.seg[0] = pfull.seg[pass];
+            if (pass > 0) { p0.accumulate = 1; p0.bias0 = p0.bias1 = p0.bias2 = nullptr; }
+        }
         long long Kp = 0;
         for (int s = 0; s < p0.nseg; ++s) Kp += p0.seg[s].K;
         for (long long k0 = 0; k0 < Kp; k0 += chunk[i]) {
@@ -3859,7 +3873,7 @@ static unsigned try_h3_tn(DevLaunch &L, float *ws, long long ws_floats, hipStrea
             L1.nprob = 1;
             DevProb &q = L1.p[0];
             q = p0;
-            if (p0.nseg == 1) {                                   // (multi-segment problems are never chunked)
+            if (p0.nseg == 1) {                                   // (a multi-segment problem that fits is one launch)
                 q.seg[0].A = p0.seg[0].A + k0 * p0.seg[0].lda;
                 q.seg[0].W = p0.seg[0].W + k0 * p0.seg[0].ldw;
                 q.seg[0].K = (int)kc;
@@ -3892,6 +3906,7 @@ static unsigned try_h3_tn(DevLaunch &L, float *ws, long long ws_floats, hipStrea
             }
             if (rc) return take;
             ++g_h3_launches;
+        }
         }
     }
     return take;
@@ -4000,14 +4015,15 @@ extern "C" int isc_gemm_bwd(const isc_linear_problem *pr, int n_prob, int layout
     bool k32 = true;
     for (int i = 0; i < n_prob; ++i)
         for (int s = 0; s < pr[i].nseg; ++s) k32 = k32 && (pr[i].seg[s].K & 31) == 0;
-    // ... or outside one when the contraction is large (>= 20 GFLOP: the classifier's dX over a zero-padded copy of W_c
-    // that autograd.py keeps out of the scope on purpose - B = 512: 105 GFLOP, 606 us on the fp32 tiles): planes of this
-    // call's W^T go to the workspace, one 20 MB split launch against ~0.3 ms saved
+    // ... or outside one when the contraction is large (>= 5 GFLOP: the classifier's dX over a zero-padded copy of W_c that
+    // autograd.py keeps out of the scope on purpose - B = 512: 105 GFLOP, 606 us on the fp32 tiles -, the prologue's
+    // d att_e = d att_p W at B >= 256: 19 GFLOP, 283 us at B = 1024): planes of this call's W^T go to the workspace, one
+    // split launch of at most 20 MB against 0.2-0.3 ms saved
     bool nn_big = g_h3_mode.load() == 1 && n_prob == 1;
     if (nn_big) {
         double fl = 0;
         for (int s = 0; s < pr[0].nseg; ++s) fl += 2.0 * pr[0].M * pr[0].N * (double)pr[0].seg[s].K;
-        nn_big = fl >= 2.0e10;
+        nn_big = fl >= 5.0e9;
     }
     if (layout == ISC_LAYOUT_NN && k32 && (h3w_scope_of((hipStream_t)stream) || g_h3_mode.load() >= 2 || nn_big)) {
         // inside a weights scope (the BPTT sweep): dX = dY W on planes of W^T built once per scope - the skinny tiles for
