@@ -247,12 +247,13 @@ def test_backward_nn_contraction_on_the_skinny_kernel(M, N, K1, K2, skinny):
 
 
 @pytest.mark.parametrize('K1,K2,M,N', [(2560, 0, 2048, 1536), (640, 0, 512, 512), (2560, 128, 2048, 512), (12288, 0, 2048, 2048),
-                                       (1600, 0, 10000, 512), (10240, 10240, 2048, 512)])
+                                       (1600, 0, 10000, 512), (10240, 10240, 2048, 512), (1600, 80, 2048, 512)])
 def test_backward_tn_contraction_on_split_f16(K1, K2, M, N):
     """isc_gemm_bwd, TN layout (dW = dY^T X: both operands [K rows, .]): planes of both TRANSPOSES are built into the
     workspace and the NT split-f16 kernels contract them - large / 64-row / skinny tiles by size, K chunks that
     accumulate when the planes exceed the workspace, two K-segments, an output with 10000 rows, and two K-segments whose
-    planes exceed the workspace (the [fc | label] block of the att-LSTM's dW at B = 512: one pass per segment)."""
+    planes exceed the workspace (the [fc | label] block of the att-LSTM's dW at B = 512: one pass per segment), and a large
+    segment beside one of 80 rows (K % 32 != 0: that one accumulates on the fp32 tiles in a launch of its own)."""
     g = torch.Generator().manual_seed(K1 + M)
     a1, w1 = _rand(g, K1, M), _rand(g, K1, N, scale=K1 ** -0.5)
     prior = _rand(g, M, N)
