@@ -106,9 +106,23 @@ def global_counts(local_counts, device, group=None):
     all-reduce.  `local_counts`: python numbers and / or 0-dim tensors; the vector is built on `device` - the rank's
     GPU under RCCL.  Returns (local [n], global [n]) float32 tensors on `device`."""
     device = torch.device(device)
-    parts = [c.detach().to(device=device, dtype=torch.float32).reshape(1) if torch.is_tensor(c)
-             else torch.tensor([float(c)], dtype=torch.float32, device=device) for c in local_counts]
-    local = torch.cat(parts)
+    # python numbers travel in ONE pinned buffer by a non-blocking copy: a tensor built from a python list on the device is
+    # a pageable H2D copy, i.e. a host wait for everything queued on the stream - once per iteration it serialised the
+    # host's enqueueing with the device (XE iteration from graphs under a one-rank group: 6.0 ms against 4.7 without)
+    nums = [float(c) for c in local_counts if not torch.is_tensor(c)]
+    host = None
+    if nums and device.type == 'cuda':
+        host = torch.tensor(nums, dtype=torch.float32).pin_memory().to(device, non_blocking=True)
+    elif nums:
+        host = torch.tensor(nums, dtype=torch.float32, device=device)
+    parts, k = [], 0
+    for c in local_counts:
+        if torch.is_tensor(c):
+            parts.append(c.detach().to(device=device, dtype=torch.float32).reshape(1))
+        else:
+            parts.append(host[k:k + 1])
+            k += 1
+    local = torch.cat(parts) if len(parts) > 1 else parts[0].clone()
     return local, all_reduce_(local.clone(), group)
 
 
