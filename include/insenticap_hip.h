@@ -204,7 +204,11 @@ int isc_logsoftmax_apply(float *logits, int64_t ld_logits, int M, int V,
  * src (may be NULL = in place): raw logits stacked per step, contiguous [T*B, V] - what ONE isc_vocab_fwd over all
  * steps' h_lang [T*B, H] writes (torch.stack(outputs, dim=1) of captioner.py:232 happens in this kernel's store). */
 int isc_logsoftmax_apply_steps(float *logits, int64_t ld_b, int64_t ld_t, int B, int T, int V,
-                               const float *part_max, const float *part_sum, const float *src, void *stream);
+                               const float *part_max, const float *part_sum, const float *src, int step_rows,
+                               void *stream);
+/* step_rows (0 = B): rows per step of the statistics / src stacks - row (t, b) sits at t*step_rows + b.  The stacks of a
+ * merged unroll (isc_step_plan.pair_rows_c) hold both branches' rows per step; each branch's [B,T,V] log-probs come from
+ * its own call with part_max / part_sum / src pointing at the branch's first row. */
 
 /* Additive attention scan (ContentAttention captioner.py:23-35 / SentiAttention :50-62):
  *   e_r = w . tanh(P[b,r,:] + q[b,:] (+ q2[b,:])) + *w_bias ; alpha = softmax_r(e) ;
@@ -216,7 +220,10 @@ int isc_logsoftmax_apply_steps(float *logits, int64_t ld_b, int64_t ld_t, int B,
 typedef struct {
     const float *P, *V, *q, *q2, *w;
     const float *w_bias; /* device pointer to the scalar bias of the alpha layer */
-    int32_t R, A, D, _pad;
+    int32_t R, A, D;
+    int32_t rows;     /* rows of THIS problem; 0 = the launch's B.  The two problems of a launch may differ: the merged
+                       * step of two sibling unrolls (isc_step_plan.pair_rows_c) scans the regions for its first rows and
+                       * the sentiment words for the rest in ONE launch. */
     float *out;       /* [B,D] */
     float *alpha_out; /* [B,*] row stride alpha_ld, R values written per row */
     int64_t alpha_ld;
@@ -428,6 +435,14 @@ typedef struct {
      * gate_Gc [rows,R,A] = cont2att.weight att_e rows, gate_Gs = senti2att.weight words_e rows ([rows,Mw,A], or the
      * [V,A] table in gather mode).  Both non-NULL: scans + gate sum + gate mix run as isc_attn_scan_gate_fwd. */
     const float *gate_Gc, *gate_Gs;
+    /* Merged step of two sibling unrolls (train_xe.py:160-181: the XE unroll over image regions and the seq2seq unroll
+     * over sentiment words share every LSTM / classifier weight, captioner.py:168-186).  pair_rows_c > 0: the first
+     * pair_rows_c of the `rows` rows attend to the regions only (att_p / att_e / qa / v / alpha_c index them from 0), the
+     * remaining rows to the sentiment words only (words_p / words_e / label_w / qw / s / alpha_s index THEM from 0), no
+     * gate; s must equal v + pair_rows_c * E (one [rows,E] attended-feature block feeds the lang-LSTM).  Both LSTM cells
+     * and the classifier then run once over all rows, the two h-projections as two problems of one launch and the two
+     * scans as the two problems of one isc_attn_scan_fwd launch.  fp32 rows only (no state planes).  0 = off. */
+    int32_t pair_rows_c, _pad2;
 } isc_step_plan;
 
 int isc_step_fwd(const isc_step_plan *plan_host, void *stream);
@@ -502,6 +517,12 @@ int isc_set_rows_scan_max(int rows);
  * blocks in flight; taken up to 512 workgroups), 0 = the per-wave-ring gemm_h3s_kernel form it replaced (tests, A/B runs),
  * n > 1 = on, taken up to n workgroups (tuning).  Returns the previous value. */
 int isc_set_h3v(int on);
+/* Long contractions on few large split-f16 tiles (one linear problem of < ~200 128 x 128 tiles and >= 64 k-blocks - the
+ * classifier's dX over all T x B rows of a training iteration, the prologue's region embedding at B = 128): 1 (default) =
+ * the k-blocks are cut into up to 8 slices per tile so that the launch fills the chip, partial tiles go to slabs in the
+ * caller's workspace and the split-K reduce kernel sums them in fixed order and applies the epilogue (deterministic);
+ * 0 = one slice (tests, A/B runs).  Returns the previous value. */
+int isc_set_h3_ksplit(int on);
 
 /* Top-k + candidate merge of one beam step in ONE launch (captioner.py:390-411), from the tile statistics and tile
  * candidates isc_rows_step_fwd left: per row the log-softmax normaliser is folded from (pmax, psum), the row's top-`beam`
@@ -545,7 +566,10 @@ int isc_beam_select(const isc_beam_select_args *args_host, void *stream);
  * contractions, gate / scan backward, att-LSTM cell backward, recurrent gradients for step t-1.
  * `first` = last time step (no incoming recurrent gradients), `last` = step 0 (no outgoing ones). */
 typedef struct {
-    int32_t rows, H, E, A, W, R, Mw, first, last, _pad;
+    int32_t rows, H, E, A, W, R, Mw, first, last;
+    int32_t pair_rows_c;                /* > 0: the merged step of isc_step_plan.pair_rows_c - rows [0, pair_rows_c) carry the
+                                           content scan, the rest the sentiment scan; d_feat is one [rows,E] block, dqa / de_c /
+                                           dwc_rows index the content rows from 0, dqw / de_s / dws_rows the sentiment rows */
     const float *Wih1, *Whh1, *Wih2, *Whh2;
     const float *W_h2att, *w_alpha_c, *W_h2word, *w_alpha_s, *W_gh, *W_gc, *W_gs, *w_gate;
     const float *att_p, *att_e, *words_p, *words_e, *label_w;
@@ -598,6 +622,7 @@ typedef struct {
     int32_t R, A, D, accumulate;
     float *dP, *dV, *dq, *dw_rows;
     float *de_out;            /* optional [B,R]: this step's d e (softmax backward); required when dP is NULL */
+    int32_t rows, _pad;       /* rows of THIS problem; 0 = the launch's B (see isc_scan_problem.rows) */
 } isc_scan_bwd_problem;
 
 int isc_attn_scan_bwd(const isc_scan_bwd_problem *probs_host, int n_prob, int B, void *stream);
@@ -605,7 +630,8 @@ int isc_attn_scan_bwd(const isc_scan_bwd_problem *probs_host, int n_prob, int B,
  * dV[b,r,:] = sum_{t = T-1 .. 0} alpha[b*alpha_ld_b + t*alpha_ld_t + r] * dout[(t*B + b)*D + :] (the sweep's order of
  * additions: bit-identical to the per-step accumulation), instead of re-reading and re-writing [B,R,D] at every step. */
 int isc_attn_dv_from_alpha(const float *alpha, int64_t alpha_ld_b, int64_t alpha_ld_t, const float *dout,
-                           int B, int T, int R, int D, float *dV, void *stream);
+                           int B, int T, int R, int D, float *dV, int dout_step_rows, void *stream);
+/* dout_step_rows (0 = B): rows per step of `dout` - dout row (t, b) at t*dout_step_rows + b (merged unroll, as above). */
 /* dP may be NULL as well (with de_out given): dP[b,r,a] = sum_{t = T-1 .. 0} de[(t*B + b)*R + r] * w[a] *
  * (1 - tanh^2(P[b,r,a] + q[(t*B + b)*A + a] (+ q2[b*A + a]))) is then formed once after the sweep - P read once, the
  * tanh terms recomputed; same expression and order of additions as the per-step accumulation.  Any R (the grid walks
@@ -693,7 +719,11 @@ int isc_reward_loss_bwd(const float *seq_masks, const float *reward, int B, int 
 #define ISC_SPARSE_MAX 2
 int isc_logsoftmax_bwd_sparse(const float *dlogp_dense, const float *logp, int64_t ld_in, int M, int V,
                               const int64_t *const *ids_host, const float *const *coef_host, int n_sparse,
-                              const float *scale, float *dlogits, int64_t ld_out, int remap_T, void *stream);
+                              const float *scale, float *dlogits, int64_t ld_out, int remap_T, int out_step_rows,
+                              void *stream);
+/* out_step_rows (0 = M / remap_T): rows per step of the time-major output - input row (b,t) goes to output row
+ * t*out_step_rows + b (a merged unroll's d logits hold both branches' rows per step; dlogits then points at this
+ * branch's first row). */
 
 /* Power-of-two gradient scale for a backward sweep whose contractions run on the split-f16 engine: out4[0..1] = { S, 1/S },
  * S = 2^k with max |x| over the given tensors (HOST arrays of device pointers / element counts, <= ISC_SCALE_SRC_MAX)

@@ -42,7 +42,7 @@ class LstmProblem(C.Structure):
 class ScanProblem(C.Structure):
     _fields_ = [('P', C.c_void_p), ('V', C.c_void_p), ('q', C.c_void_p), ('q2', C.c_void_p),
                 ('w', C.c_void_p), ('w_bias', C.c_void_p), ('R', C.c_int32), ('A', C.c_int32),
-                ('D', C.c_int32), ('_pad', C.c_int32), ('out', C.c_void_p), ('alpha_out', C.c_void_p),
+                ('D', C.c_int32), ('rows', C.c_int32), ('out', C.c_void_p), ('alpha_out', C.c_void_p),
                 ('alpha_ld', C.c_int64), ('out_hi', C.c_void_p), ('out_lo', C.c_void_p),
                 ('row_ids', C.c_void_p), ('row_ids_ld', C.c_int64)]
 
@@ -52,7 +52,7 @@ class ScanBwdProblem(C.Structure):
                 ('w', C.c_void_p), ('alpha', C.c_void_p), ('dout', C.c_void_p), ('alpha_ld', C.c_int64),
                 ('R', C.c_int32), ('A', C.c_int32), ('D', C.c_int32), ('accumulate', C.c_int32),
                 ('dP', C.c_void_p), ('dV', C.c_void_p), ('dq', C.c_void_p), ('dw_rows', C.c_void_p),
-                ('de_out', C.c_void_p)]
+                ('de_out', C.c_void_p), ('rows', C.c_int32), ('_pad', C.c_int32)]
 
 
 class ScanGateArgs(C.Structure):
@@ -81,12 +81,12 @@ class StepPlan(C.Structure):
                  ('splitk_ws', C.c_void_p), ('splitk_ws_floats', C.c_int64)] +
                 _f('h1_prev_hi h1_prev_lo h2_prev_hi h2_prev_lo h1_hi h1_lo h2_hi h2_lo '
                    'v_hi v_lo s_hi s_lo f_hi f_lo words_ids', C.c_void_p) + [('words_ids_ld', C.c_int64)] +
-                _f('gate_Gc gate_Gs', C.c_void_p))
+                _f('gate_Gc gate_Gs', C.c_void_p) + _f('pair_rows_c _pad2', C.c_int32))
 
 
 class StepBwdPlan(C.Structure):
     """isc_step_bwd_plan."""
-    _fields_ = (_f('rows H E A W R Mw first last _pad', C.c_int32) +
+    _fields_ = (_f('rows H E A W R Mw first last pair_rows_c', C.c_int32) +
                 _f('Wih1 Whh1 Wih2 Whh2 W_h2att w_alpha_c W_h2word w_alpha_s W_gh W_gc W_gs w_gate '
                    'att_p att_e words_p words_e label_w g1 c1_prev c1 g2 c2_prev c2 qa qw v s z '
                    'alpha_c alpha_s beta', C.c_void_p) +
@@ -169,6 +169,7 @@ SIGNATURES = {
     'isc_set_rows_nt': (C.c_int, [C.c_int]),
     'isc_set_rows_scan_max': (C.c_int, [C.c_int]),
     'isc_set_h3v': (C.c_int, [C.c_int]),
+    'isc_set_h3_ksplit': (C.c_int, [C.c_int]),
     'isc_copy_multi': (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_int, C.c_void_p]),
     'isc_rows_launches': (C.c_longlong, []),
     'isc_beam_select': (C.c_int, [C.POINTER(BeamSelectArgs), C.c_void_p]),
@@ -184,7 +185,7 @@ SIGNATURES = {
     'isc_logsoftmax_apply': (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_void_p]),
     'isc_logsoftmax_apply_steps': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p,
-                                             C.c_void_p, C.c_void_p, C.c_void_p]),
+                                             C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     'isc_attn_scan_fwd': (C.c_int, [C.POINTER(ScanProblem), C.c_int, C.c_int, C.c_void_p]),
     'isc_attn_scan_gate_fwd': (C.c_int, [C.POINTER(ScanGateArgs), C.c_int, C.c_void_p]),
     'isc_gate_mix_fwd': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
@@ -211,7 +212,7 @@ SIGNATURES = {
                                C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'isc_attn_scan_bwd': (C.c_int, [C.POINTER(ScanBwdProblem), C.c_int, C.c_int, C.c_void_p]),
     'isc_attn_dv_from_alpha': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_int,
-                                         C.c_int, C.c_void_p, C.c_void_p]),
+                                         C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     'isc_attn_dp_from_de': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                       C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     'isc_gate_mix_bwd': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
@@ -235,7 +236,7 @@ SIGNATURES = {
                                       C.c_void_p]),
     'isc_logsoftmax_bwd_sparse': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int,
                                             C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int, C.c_void_p,
-                                            C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
+                                            C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
     'isc_grad_scale': (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_int, C.c_void_p, C.c_void_p]),
     'isc_splitk_workspace_bytes': (C.c_int64, [C.c_int64, C.c_int64]),
     'isc_h3_weights_workspace_bytes': (C.c_int64, [C.c_int64, C.c_int]),

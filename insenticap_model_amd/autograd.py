@@ -551,10 +551,22 @@ def rollout_with_grad(cap, fc, att, cpt_words, senti_words, senti_labels, T, rep
 
 
 def _decode_node(logp):
-    """The DecodeFn node behind `logp` if the criterion may use its sparse side channel: `logp` must be that node's
-    own output (a slice or a copy of it has another grad_fn) - else None (dense hand-over)."""
+    """The sparse side channel behind `logp` - (decode node, slot) - if the criterion may use it: `logp` must be that
+    node's own output (a slice or a copy of it has another grad_fn), else None (dense hand-over).  A DecodeFn node has one
+    log-prob output (slot None: `_isc_sparse` is a list); the merged node of two sibling unrolls (autograd_pair) has two,
+    keyed by output number."""
     node = logp.grad_fn
-    return node if node is not None and hasattr(node, '_isc_sparse') else None
+    ch = getattr(node, '_isc_sparse', None) if node is not None else None
+    if ch is None:
+        return None
+    if isinstance(ch, dict):
+        return (node, logp.output_nr) if logp.output_nr in ch else None
+    return (node, None)
+
+
+def _sparse_append(chan, pair):
+    node, slot = chan
+    (node._isc_sparse if slot is None else node._isc_sparse[slot]).append(pair)
 
 
 class GatherLogpFn(torch.autograd.Function):
@@ -572,7 +584,7 @@ class GatherLogpFn(torch.autograd.Function):
         raw, live = ctx.saved_tensors
         coef = (g * live).contiguous()
         if ctx.node is not None:
-            ctx.node._isc_sparse.append((raw.contiguous(), coef))
+            _sparse_append(ctx.node, (raw.contiguous(), coef))
             return None, None, None, None
         d = torch.zeros(ctx.shape, dtype=coef.dtype, device=coef.device)
         d.scatter_(2, raw.unsqueeze(2), coef.unsqueeze(2))
@@ -595,7 +607,7 @@ class XELossFn(torch.autograd.Function):
         if ctx.node is not None:        # pred is a decode node's own output: hand (target, coef) over, no [B,T,V] tensor
             coef = torch.empty(ctx.shape[:2], dtype=torch.float32, device=target.device)
             ops.xe_loss_bwd_sparse(lengths_i32, ctx.shape[1], gout, out2, coef)
-            ctx.node._isc_sparse.append((target, coef))
+            _sparse_append(ctx.node, (target, coef))
             return None, None, None, None
         dlogp = torch.zeros(ctx.shape, dtype=torch.float32, device=target.device)
         ops.xe_loss_bwd(target, lengths_i32, gout, out2, dlogp)

@@ -162,7 +162,7 @@ FEW_ROW_PLANE_BYTES = 24 << 20
 def _few_rows(cap, n_img, beam):
     """One image's beam on at most ROWS_STEP_MAX rows: the few-row step (csrc/rows.hip)."""
     return (n_img * beam <= cap.ROWS_STEP_MAX and beam <= 8 and getattr(cap, 'rows_step', True)
-            and getattr(cap, 'beam_device_merge', True))
+            and getattr(cap, 'beam_device_merge', True) and cap._rows_vocab_ok())
 
 
 def _graph_key(cap, ins, beam, decoding_constraint, T):

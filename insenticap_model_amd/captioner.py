@@ -110,7 +110,10 @@ class Captioner(nn.Module):
         self.attention = Attention(settings)
         self.lang_lstm = nn.LSTMCell(H + E, H)
         self.classifier = nn.Linear(H, self.vocab_size)
-        self.fc_feats = self.cpt_feats = None
+        self.fc_feats = self.cpt_feats = self.s2s_cpt_feats = None
+        # the XE and seq2seq unrolls of one training iteration through ONE step chain (autograd_pair): None = where it is
+        # faster (eager steps: yes; inside HIP graphs: two branches - autograd_pair.use_pair), True / False = always / never
+        self.pair_unrolls = None
         self.cont_weights, self.senti_weights, self.cont_senti_weights = [], [], []
         # identity of this instance's weights in the process-wide caches keyed on weight values (ops.h3_weights_scope):
         # a one-element list so that the finalizer below sees renewals
@@ -213,7 +216,7 @@ class Captioner(nn.Module):
     ROLLOUT_GRAPH_MAX_ROWS = 256   # greedy eval roll-outs up to this many captions are served from HIP graphs
 
     def _prologue(self, p, mode, fc=None, att=None, cpt_words=None, senti_words=None, senti_labels=None,
-                  masks=None, want_table=False, words_table=False, gate_rows=0):
+                  masks=None, want_table=False, words_table=False, gate_rows=0, pre1_out=None):
         """want_table: False | 'cached' (use the embedding table only if already built) | 'build'.
         words_table: serve the sentiment words from the vocabulary-sized tables (no dropout on them, no autograd).
         gate_rows: number of decode rows of an INFERENCE call (0: training / not applicable): up to
@@ -322,7 +325,9 @@ class Captioner(nn.Module):
         segs = [(P.fc_e, Wih[:, H:H + E])]
         if P.label_e is not None:
             segs.append((P.label_e, Wih[:, H + E:]))
-        P.pre1 = self._new(B, 4 * H)
+        # (pre1_out: the caller's [B,4H] row block of a larger buffer - the merged unroll of two sibling calls keeps
+        # both calls' rows in one [B1+B2,4H] tensor)
+        P.pre1 = self._new(B, 4 * H) if pre1_out is None else pre1_out
         ops.linear_fwd([ops.linear_problem(segs, P.pre1, p['att_lstm.bias_ih'], p['att_lstm.bias_hh'])])
         if want_table:
             P.tab = self._embedding_table(p, build=(want_table == 'build'))
@@ -384,9 +389,17 @@ class Captioner(nn.Module):
         st = self.settings
         E, A, Wd, H = st['feat_emb_dim'], st['att_hid_dim'], st['word_emb_dim'], st['rnn_hid_dim']
         return (getattr(self, 'rows_step', True) and 0 < rows <= self.ROWS_STEP_MAX and not ops.TIMER.armed
+                and self._rows_vocab_ok()
                 and ops.TIMER.arm_step is None and getattr(P, 'gate_Gc', None) is not None
                 and getattr(P, 'gate_Gs', None) is not None and A == E == Wd and A <= 512 and A % 4 == 0 and H % 4 == 0
                 and H <= 1024)
+
+    def _rows_vocab_ok(self):
+        """The few-row classifier keeps statistics per isc_rows_stats_tile(V) <= 64 columns and isc_beam_select holds at
+        most 256 tile lists (64 lanes x 4): vocabularies beyond 16384 words take the general kernels."""
+        V = self.vocab_size
+        tw = ops.rows_stats_tile(V)
+        return tw > 0 and (V + tw - 1) // tw <= 256
 
     def _alloc_step_ws(self, rows, P, stats_tile=128):
         st = self.settings
@@ -679,6 +692,29 @@ class Captioner(nn.Module):
         p = self._p()
         P = self._prologue(p, 'seq2seq', None, None, cpt_words, senti_words, senti_labels, _masks)
         return self._teacher_forced(p, P, self._ids(senti_captions)[:, :-1], ss_prob, _masks)
+
+    def forward_xe_seq2seq(self, fc_feats, att_feats, cpt_words, captions, senti_labels, ss_prob,
+                           s_captions, s_cpt_words, s_senti_words, s_senti_labels, s_ss_prob=None,
+                           _masks=None, _s_masks=None):
+        """`forward_xe(...)` and `forward_seq2seq(...)` of ONE training iteration (train_xe.py:160-181,
+        models/decoder.py:138-157) as one call: returns (pred, pred2), leaves `fc_feats` / `cpt_feats` as the XE call
+        leaves them (the domain-align loss reads them right after it, train_xe.py:163) and the seq2seq call's
+        `cpt_feats` in `s2s_cpt_feats`.  With gradients the two unrolls share one step chain (autograd_pair: both LSTM
+        cells, the classifier and every backward contraction once over the rows of both calls); without, or when
+        `self.pair_unrolls` is False, it is exactly the two calls in the reference's order."""
+        s_ss_prob = ss_prob if s_ss_prob is None else s_ss_prob
+        from .autograd_pair import pair_applicable, pair_with_grad
+        if self._needs_grad() and self.pair_unrolls is not False and pair_applicable(self, _masks, _s_masks):
+            pred, pred2, self.s2s_cpt_feats = pair_with_grad(
+                self, fc_feats, att_feats, cpt_words, captions, senti_labels, ss_prob, s_captions, s_cpt_words,
+                s_senti_words, s_senti_labels, s_ss_prob, _masks, _s_masks)
+            return pred, pred2
+        pred = self.forward_xe(fc_feats, att_feats, cpt_words, captions, senti_labels, ss_prob, _masks=_masks)
+        keep = (self.fc_feats, self.cpt_feats)
+        pred2 = self.forward_seq2seq(s_captions, s_cpt_words, s_senti_words, s_senti_labels, s_ss_prob, _masks=_s_masks)
+        self.s2s_cpt_feats = self.cpt_feats
+        self.fc_feats, self.cpt_feats = keep
+        return pred, pred2
 
     def forward_rl(self, fc_feats, att_feats, cpt_words, senti_words, senti_labels, max_seq_len, sample_max,
                    _replay=None, _masks=None):

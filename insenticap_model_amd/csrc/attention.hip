@@ -26,6 +26,7 @@ struct DevScan {
     const int64_t *ids;        // gather mode: region r of row b = row ids[b*ids_ld + r] of the P / V tables
     long long ids_ld;
     int rid_off;               // float offset of the row-id staging area in dynamic LDS
+    int rows;                  // rows of THIS problem (the grid spans the longest problem of the launch)
 };
 struct DevScanLaunch {
     DevScan p[2];
@@ -54,6 +55,7 @@ __global__ __launch_bounds__(256) void attn_scan_kernel(const DevScanLaunch L) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const DevScan &S = L.p[blockIdx.y];
     const int b = blockIdx.x;
+    if (b >= S.rows) return;               // (workgroup-uniform: a shorter problem of a two-problem launch)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int R = S.R, A = S.A, D = S.D;
     float *sc = smem;                      // [R] scores -> alphas
@@ -195,11 +197,14 @@ extern "C" int isc_attn_scan_fwd(const isc_scan_problem *pr, int n_prob, int B, 
     if (!pr) return ISC_E_NULL;
     if (n_prob < 1 || n_prob > 2 || B <= 0) return ISC_E_SHAPE;
     DevScanLaunch L = {};
-    int maxA = 0;
+    int maxA = 0, max_rows = 0;
     size_t lds = 0;
     for (int i = 0; i < n_prob; ++i) {
         const isc_scan_problem &q = pr[i];
         if (!q.P || !q.V || !q.q || !q.w || !q.out) return ISC_E_NULL;
+        if (q.rows < 0) return ISC_E_SHAPE;
+        L.p[i].rows = q.rows > 0 ? q.rows : B;
+        if (L.p[i].rows > max_rows) max_rows = L.p[i].rows;
         if (q.R <= 0 || q.A <= 0 || q.D <= 0 || (q.A & 3) || (q.D & 3) || q.A > 1024) return ISC_E_SHAPE;
         if (!isc_aligned16(q.P) || !isc_aligned16(q.V) || !isc_aligned16(q.q) || !isc_aligned16(q.w) ||
             !isc_aligned16(q.out) || (q.q2 && !isc_aligned16(q.q2)))
@@ -221,9 +226,9 @@ extern "C" int isc_attn_scan_fwd(const isc_scan_problem *pr, int n_prob, int B, 
     if (lds > 60000) return ISC_E_SHAPE;
     long long streamed = 0;                                // bytes of per-caption rows (gathered tables are shared)
     for (int i = 0; i < n_prob; ++i)
-        if (!pr[i].row_ids) streamed += (long long)B * pr[i].R * ((long long)pr[i].A + pr[i].D) * 4;
+        if (!pr[i].row_ids) streamed += (long long)L.p[i].rows * pr[i].R * ((long long)pr[i].A + pr[i].D) * 4;
     L.nt = streamed > ISC_SCAN_NT_BYTES;
-    dim3 grid(B, n_prob), block(256);
+    dim3 grid(max_rows, n_prob), block(256);
     hipStream_t st = (hipStream_t)stream;
     if (L.nt) {
         if (maxA <= 256) hipLaunchKernelGGL((attn_scan_kernel<1, true>), grid, block, lds, st, L);

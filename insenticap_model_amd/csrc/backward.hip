@@ -54,10 +54,12 @@ struct SparseDlogp {
 __global__ __launch_bounds__(256) void logsoftmax_bwd_sparse_kernel(const float *dense, const float *logp,
                                                                     long long ld_in, int V, SparseDlogp sp,
                                                                     const float *scale, float *dlogits,
-                                                                    long long ld_out, int M, int remap_T) {
+                                                                    long long ld_out, int M, int remap_T,
+                                                                    int out_step_rows) {
     __shared__ float red[4];
     const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int mo = remap_T > 0 ? (m % remap_T) * (M / remap_T) + m / remap_T : m;
+    // (out_step_rows: rows per step of the time-major output - M / T, or more when it holds a sibling unroll's rows too)
+    const long long mo = remap_T > 0 ? (long long)(m % remap_T) * out_step_rows + m / remap_T : m;
     const float *lp = logp + (long long)m * ld_in;
     const float sc = scale ? scale[0] : 1.f;
     float tot = 0.f;
@@ -77,7 +79,7 @@ __global__ __launch_bounds__(256) void logsoftmax_bwd_sparse_kernel(const float 
         id[j] = -1; cf[j] = 0.f;
         if (j < sp.n) { id[j] = sp.ids[j][m]; cf[j] = sp.coef[j][m]; tot += cf[j]; }
     }
-    float *o = dlogits + (long long)mo * ld_out;
+    float *o = dlogits + mo * ld_out;
     const float *g = dense ? dense + (long long)m * ld_in : nullptr;
     for (int i = tid; i < ld_out; i += 256) {
         float v = 0.f;
@@ -95,9 +97,11 @@ __global__ __launch_bounds__(256) void logsoftmax_bwd_sparse_kernel(const float 
 extern "C" int isc_logsoftmax_bwd_sparse(const float *dlogp_dense, const float *logp, int64_t ld_in, int M, int V,
                                          const int64_t *const *ids_host, const float *const *coef_host, int n_sparse,
                                          const float *scale, float *dlogits, int64_t ld_out, int remap_T,
-                                         void *stream) {
+                                         int out_step_rows, void *stream) {
     if (!logp || !dlogits) return ISC_E_NULL;
     if (M <= 0 || V <= 0 || ld_out < V || remap_T < 0 || (remap_T > 0 && M % remap_T)) return ISC_E_SHAPE;
+    if (remap_T > 0 && out_step_rows == 0) out_step_rows = M / remap_T;
+    if (out_step_rows < 0 || (remap_T > 0 && out_step_rows < M / remap_T)) return ISC_E_SHAPE;
     if (n_sparse < 0 || n_sparse > ISC_SPARSE_MAX || (!dlogp_dense && n_sparse == 0)) return ISC_E_SHAPE;
     SparseDlogp sp = {};
     sp.n = n_sparse;
@@ -106,7 +110,7 @@ extern "C" int isc_logsoftmax_bwd_sparse(const float *dlogp_dense, const float *
         sp.ids[j] = ids_host[j]; sp.coef[j] = coef_host[j];
     }
     hipLaunchKernelGGL(logsoftmax_bwd_sparse_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, dlogp_dense, logp,
-                       (long long)ld_in, V, sp, scale, dlogits, (long long)ld_out, M, remap_T);
+                       (long long)ld_in, V, sp, scale, dlogits, (long long)ld_out, M, remap_T, out_step_rows);
     ISC_LAUNCH_CHECK();
     return ISC_OK;
 }
@@ -292,6 +296,7 @@ struct DevScanBwd {
     long long alpha_ld;
     int R, A, D, accumulate;
     float *dP, *dV, *dq, *dw_rows, *de_out;
+    int rows;                 // rows of THIS problem (the grid spans the longest problem of the launch)
 };
 struct DevScanBwdLaunch {
     DevScanBwd p[2];
@@ -315,6 +320,7 @@ __global__ __launch_bounds__(1024) void attn_scan_bwd_kernel(const DevScanBwdLau
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const DevScanBwd &S = L.p[blockIdx.y];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (b >= S.rows) return;                  // (workgroup-uniform: a shorter problem of a two-problem launch)
     const int NT = blockDim.x, NW = NT >> 6;
     const int R = S.R, A = S.A, D = S.D;
     const int A4 = A >> 2, D4 = D >> 2;
@@ -410,12 +416,17 @@ extern "C" int isc_attn_scan_bwd(const isc_scan_bwd_problem *pr, int n_prob, int
     {   // P / V rows by non-temporal loads once they exceed what stays in the Infinity Cache next to the accumulated
         // dP / dV (attention.hip, isc_attn_scan_fwd): XE iteration at B = 1024 19.9 -> 19.6 ms, B = 512 unchanged
         long long streamed = 0;
-        for (int i = 0; i < n_prob; ++i) streamed += (long long)B * pr[i].R * ((long long)pr[i].A + pr[i].D) * 4;
+        for (int i = 0; i < n_prob; ++i)
+            streamed += (long long)(pr[i].rows > 0 ? pr[i].rows : B) * pr[i].R * ((long long)pr[i].A + pr[i].D) * 4;
         L.nt = streamed > (128LL << 20);
     }
     size_t lds = 0;
+    int max_rows = 0;
     for (int i = 0; i < n_prob; ++i) {
         const isc_scan_bwd_problem &q = pr[i];
+        if (q.rows < 0) return ISC_E_SHAPE;
+        L.p[i].rows = q.rows > 0 ? q.rows : B;
+        if (L.p[i].rows > max_rows) max_rows = L.p[i].rows;
         if (!q.P || !q.V || !q.q || !q.w || !q.alpha || !q.dout || !q.dq || !q.dw_rows)
             return ISC_E_NULL;                     // (dV / dP may be null: isc_attn_dv_from_alpha / isc_attn_dp_from_de)
         if (!q.dP && !q.de_out) return ISC_E_NULL;
@@ -434,7 +445,7 @@ extern "C" int isc_attn_scan_bwd(const isc_scan_bwd_problem *pr, int n_prob, int
     }
     lds *= sizeof(float);
     if (lds > 60000) return ISC_E_SHAPE;
-    hipLaunchKernelGGL(attn_scan_bwd_kernel, dim3(B, n_prob), dim3(1024), lds, (hipStream_t)stream, L);
+    hipLaunchKernelGGL(attn_scan_bwd_kernel, dim3(max_rows, n_prob), dim3(1024), lds, (hipStream_t)stream, L);
     ISC_LAUNCH_CHECK();
     return ISC_OK;
 }
@@ -449,7 +460,7 @@ extern "C" int isc_attn_scan_bwd(const isc_scan_bwd_problem *pr, int n_prob, int
 #define ISC_POST_LDS_BYTES 60000
 __global__ __launch_bounds__(256) void attn_dv_from_alpha_kernel(const float *alpha, long long ld_b, long long ld_t,
                                                                  const float *dout, int B, int T, int R, int D, int Rc,
-                                                                 float *dV) {
+                                                                 float *dV, int step_rows) {
 #pragma clang fp contract(off)
     extern __shared__ float sa[];                  // [T][Rc]
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -466,7 +477,7 @@ __global__ __launch_bounds__(256) void attn_dv_from_alpha_kernel(const float *al
         float4 g[ISC_DV_TMAX];
 #pragma unroll
         for (int t = 0; t < ISC_DV_TMAX; ++t)
-            g[t] = t < T ? g4[((long long)t * B + b) * D4 + d4] : make_float4(0.f, 0.f, 0.f, 0.f);
+            g[t] = t < T ? g4[((long long)t * step_rows + b) * D4 + d4] : make_float4(0.f, 0.f, 0.f, 0.f);
         for (int r = grp; r < nr; r += ngrp) {
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
@@ -486,7 +497,7 @@ __global__ __launch_bounds__(256) void attn_dv_from_alpha_kernel(const float *al
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
             for (int t = T - 1; t >= 0; --t) {
                 const float al = sa[t * Rc + r];
-                const float4 g = g4[((long long)t * B + b) * D4 + d4];
+                const float4 g = g4[((long long)t * step_rows + b) * D4 + d4];
                 acc.x = al * g.x + acc.x; acc.y = al * g.y + acc.y; acc.z = al * g.z + acc.z; acc.w = al * g.w + acc.w;
             }
             o4[(long long)(r_lo + r) * D4 + d4] = acc;
@@ -495,9 +506,11 @@ __global__ __launch_bounds__(256) void attn_dv_from_alpha_kernel(const float *al
 }
 
 extern "C" int isc_attn_dv_from_alpha(const float *alpha, int64_t alpha_ld_b, int64_t alpha_ld_t, const float *dout,
-                                      int B, int T, int R, int D, float *dV, void *stream) {
+                                      int B, int T, int R, int D, float *dV, int dout_step_rows, void *stream) {
     if (!alpha || !dout || !dV) return ISC_E_NULL;
     if (B <= 0 || T <= 0 || R <= 0 || D <= 0 || (D & 3)) return ISC_E_SHAPE;
+    if (dout_step_rows == 0) dout_step_rows = B;
+    if (dout_step_rows < B) return ISC_E_SHAPE;
     if (!isc_aligned16(dout) || !isc_aligned16(dV)) return ISC_E_ALIGN;
     int Rc = ISC_POST_LDS_BYTES / (int)sizeof(float) / T;      // regions per chunk: [T][Rc] floats of LDS
     if (Rc < 1) return ISC_E_SHAPE;                             // T > 15000 steps
@@ -506,7 +519,7 @@ extern "C" int isc_attn_dv_from_alpha(const float *alpha, int64_t alpha_ld_b, in
     if (nchunk > 65535 || ncol > 65535) return ISC_E_SHAPE;
     const size_t lds = (size_t)T * Rc * sizeof(float);
     hipLaunchKernelGGL(attn_dv_from_alpha_kernel, dim3(B, nchunk, ncol), dim3(256), lds, (hipStream_t)stream, alpha,
-                       (long long)alpha_ld_b, (long long)alpha_ld_t, dout, B, T, R, D, Rc, dV);
+                       (long long)alpha_ld_b, (long long)alpha_ld_t, dout, B, T, R, D, Rc, dV, dout_step_rows);
     ISC_LAUNCH_CHECK();
     return ISC_OK;
 }

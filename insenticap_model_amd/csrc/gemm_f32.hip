@@ -1336,6 +1336,35 @@ __device__ __forceinline__ void epi_linear_frag16(const DevProb &P, f32x4 (&acc)
 #undef ISC_EPI_CASE
 }
 
+// K-split form of the large split-f16 linear tile: workgroup (tile, ks) contracts its share of the k-blocks and stores the
+// RAW partial tile to slab[ks] ([M, N] row-major); splitk_linear_kernel sums the slabs in fixed order and applies the
+// epilogue.  For long contractions on few tiles - the classifier's dX over T x (B1 + B2) = 4160 rows is 132 tiles of
+// K = 9984: a quarter of the chip's workgroup slots for 376 us; three slices of K fill it.
+template <int NB, bool CHECK>
+__device__ __forceinline__ void epi_slab_frag16(const DevProb &P, f32x4 (&acc)[2][NB], int frow0, int lane, int row0, int col0,
+                                                int ks) {
+    float *base = P.slab + (long long)ks * P.slab_stride;
+    bool bad = false;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int gm = row0 + frow0 + i * 16 + 4 * (lane >> 4) + r;
+            if (gm >= P.M) continue;
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int gn = col0 + j * 16 + (lane & 15);
+                if (gn >= P.N) continue;
+                const float o = acc[i][j][r];
+                if constexpr (CHECK) bad |= !(fabsf(o) <= 3.0e38f);
+                base[(long long)gm * P.N + gn] = o;
+            }
+        }
+    if constexpr (CHECK) {
+        if (__any(bad) && lane == 0) isc_flag_gemm(ISC_STATUS_WORD_LINEAR);
+    }
+}
+
 // ---------------------------------------------------------------- H3 tile: 128 x 128 on the f16 matrix cores
 // fp32 operands, fp32 results, f16 MFMA rate.  Every operand value is split once into two f16 planes,
 //     x = hi + lo * 2^-11,   hi = f16(x),   lo = f16((x - hi) * 2^11)
@@ -1448,7 +1477,23 @@ __global__ __launch_bounds__(256, 2) void gemm_h3_kernel(const DevLaunch L) {
             src[i] = seg_f32 ? reinterpret_cast<const _Float16 *>(P.seg[si].A + (long long)arow[i] * P.seg[si].lda) + aq[i]
                              : a.hi + (long long)arow[i] * a.ld + aq[i];
     };
-    set_aseg(0);
+    // this workgroup's share of the k-blocks (ksplit > 1, linear epilogue only: raw partial tiles go to slabs)
+    const int nchunks_all = Kp / 32;
+    const int c_lo = ksplit > 1 ? (int)((long long)nchunks_all * ks / ksplit) : 0;
+    const int c_hi = ksplit > 1 ? (int)((long long)nchunks_all * (ks + 1) / ksplit) : nchunks_all;
+    {
+        int k0 = c_lo * 32;
+        while (cs + 1 < P.nap && k0 >= P.ap[cs].K) { k0 -= P.ap[cs].K; ++cs; }
+        set_aseg(cs);
+        if (c_lo > 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                src[i] += (long long)(k0 >> 5) * 64;
+                src[4 + i] += (long long)c_lo * 64;
+            }
+            ck = k0;
+        }
+    }
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds + wm * 4096);
     auto stage = [&](int buf) __attribute__((always_inline)) {
         f32_bufs = (f32_bufs & ~(1u << buf)) | ((seg_f32 ? 1u : 0u) << buf);
@@ -1538,7 +1583,7 @@ __global__ __launch_bounds__(256, 2) void gemm_h3_kernel(const DevLaunch L) {
             mma(setc, I1{}, I1{});
         }
     };
-    const int nchunks = Kp / 32;
+    const int nchunks = c_hi - c_lo;
 #if H3_STAMP
     const unsigned long long stamp1 = __builtin_amdgcn_s_memtime();
 #endif
@@ -1581,7 +1626,8 @@ __global__ __launch_bounds__(256, 2) void gemm_h3_kernel(const DevLaunch L) {
     } else if constexpr (EPI == EPI_LSTM) {
         epi_lstm_frag16(P, acc0, wm * 32, lane, row0, tn);
     } else {
-        epi_linear_frag16<NB, AF32>(P, acc0, wm * 32, 0, lane, row0, col0);
+        if (ksplit > 1) epi_slab_frag16<NB, AF32>(P, acc0, wm * 32, lane, row0, col0, ks);
+        else epi_linear_frag16<NB, AF32>(P, acc0, wm * 32, 0, lane, row0, col0);
     }
 #if H3_STAMP
     if (EPI == EPI_VOCAB) {
@@ -3291,6 +3337,10 @@ static int try_gemv(DevLaunch &L, hipStream_t st, int &rc) {
 
 #define H3_MIN_TILES 160
 #define H3_MIN_TILES_SCOPE 16
+// (tests / A-B runs: 0 keeps long contractions on few large tiles in one slice of K)
+static std::atomic<int> g_h3_ksplit{1};
+extern "C" int isc_set_h3_ksplit(int on) { return g_h3_ksplit.exchange(on ? 1 : 0); }
+static int launch_splitk_linear_reduce(const DevLaunch &L, hipStream_t st);
 
 static bool h3_any_f32(const DevLaunch &L) {
     for (int i = 0; i < L.nprob; ++i)
@@ -3616,7 +3666,29 @@ static int try_h3(DevLaunch &L, float *ws, long long ws_floats, hipStream_t st, 
         finish_tiling(L, 1);
         rc = launch_h3m(L, st);
     } else {
+        // a long contraction on few 128 x 128 tiles (one problem, linear epilogue): S slices of K so that the launch fills
+        // the chip's 512 workgroup slots, raw partial tiles to slabs behind the planes in the workspace, then the reduce
+        int S = 1;
+        if (EPI == EPI_LINEAR && L.nprob == 1 && (L.p[0].N & 3) == 0 && g_h3_ksplit.load()) {
+            DevProb &p = L.p[0];
+            const long long t256 = (long long)((p.M + 255) / 256) * ((p.N + 127) / 128);
+            const int nblk = p.Kp / 32;
+            if (t256 < 224 && tiles <= 200 && nblk >= 64) {
+                S = (int)(512 / tiles);
+                if (S > 8) S = 8;
+                while (S > 1 && nblk / S < 24) --S;
+                const long long used = (need + 255) & ~255LL, slab = (long long)p.M * p.N;
+                while (S > 1 && used + S * slab > ws_floats) --S;
+                if (S > 1) {
+                    p.ksplit = S;
+                    p.slab = ws + used;
+                    p.slab_stride = slab;
+                }
+            }
+        }
         rc = launch_h3_big<EPI>(L, st);
+        if (!rc && S > 1) rc = launch_splitk_linear_reduce(L, st);
+        if (S > 1) L.p[0].ksplit = 0;
     }
     ++g_h3_launches;
     return 1;

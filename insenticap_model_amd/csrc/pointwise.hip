@@ -594,14 +594,17 @@ extern "C" int isc_logsoftmax_apply(float *logits, int64_t ld_logits, int M, int
 __global__ __launch_bounds__(256) void logsoftmax_apply_steps_kernel(float *logits, long long ld_b, long long ld_t,
                                                                      int B, int V, const float *pmax,
                                                                      const float *psum, int n_tile,
-                                                                     const float *src) {
+                                                                     const float *src, int step_rows) {
     __shared__ float sh[2];
-    const int m = blockIdx.x;                 // = t * B + b
+    const int mi = blockIdx.x;                // = t * B + b
+    // row of (t, b) in the per-step stacks: step_rows rows per step (>= B: the stacks of a merged unroll hold the rows
+    // of both branches per step; statistics / src then point at this branch's first row)
+    const long long m = (long long)(mi / B) * step_rows + (mi % B);
     const int tid = threadIdx.x;
     if (tid < 64) {
         float gmax, S;
         int gi;
-        fold_row_stats(pmax + (long long)m * n_tile, psum + (long long)m * n_tile, nullptr, n_tile, tid,
+        fold_row_stats(pmax + m * n_tile, psum + m * n_tile, nullptr, n_tile, tid,
                        gmax, gi, S);
         if (tid == 0) {
             sh[0] = gmax;
@@ -610,21 +613,23 @@ __global__ __launch_bounds__(256) void logsoftmax_apply_steps_kernel(float *logi
     }
     __syncthreads();
     const float gmax = sh[0], logS = sh[1];
-    float *x = logits + (long long)(m % B) * ld_b + (long long)(m / B) * ld_t;
-    const float *y = src ? src + (long long)m * V : x;       // src: raw logits stacked per step, [T*B, V]
+    float *x = logits + (long long)(mi % B) * ld_b + (long long)(mi / B) * ld_t;
+    const float *y = src ? src + m * V : x;       // src: raw logits stacked per step, [T*step_rows, V]
     for (int i = blockIdx.y * 256 + tid; i < V; i += gridDim.y * 256) x[i] = (y[i] - gmax) - logS;
 }
 
 extern "C" int isc_logsoftmax_apply_steps(float *logits, int64_t ld_b, int64_t ld_t, int B, int T, int V,
                                           const float *part_max, const float *part_sum, const float *src,
-                                          void *stream) {
+                                          int step_rows, void *stream) {
     if (!logits || !part_max || !part_sum) return ISC_E_NULL;
     if (B <= 0 || T <= 0 || V <= 0 || (long long)B * T > 2147483647LL) return ISC_E_SHAPE;
+    if (step_rows == 0) step_rows = B;
+    if (step_rows < B) return ISC_E_SHAPE;
     const int n_tile = (V + 127) / 128;
     int gy = (V + 2047) / 2048;
     if (gy < 1) gy = 1;
     hipLaunchKernelGGL(logsoftmax_apply_steps_kernel, dim3(B * T, gy), dim3(256), 0, (hipStream_t)stream, logits,
-                       (long long)ld_b, (long long)ld_t, B, V, part_max, part_sum, n_tile, src);
+                       (long long)ld_b, (long long)ld_t, B, V, part_max, part_sum, n_tile, src, step_rows);
     ISC_LAUNCH_CHECK();
     return ISC_OK;
 }

@@ -1200,7 +1200,12 @@ extern "C" int isc_rows_step_supported(const isc_step_plan *p) {
     if (!p) return 0;
     if (p->rows < 1 || p->rows > ROWS_MAX) return 0;
     if (!rows_scan_ok(p)) return 0;
-    if (p->g1 || p->g2 || p->out_mask || p->apply_logsoftmax) return 0;   // training / teacher-forced forms: isc_step_fwd
+    if (p->g1 || p->g2 || p->out_mask || p->apply_logsoftmax || p->pair_rows_c) return 0;   // training / teacher-forced forms: isc_step_fwd
+    {   // the classifier's statistics tiles (<= 64 columns each) must fit isc_beam_select's register-resident tile lists
+        // (64 lanes x 4 tiles): V <= 16384.  Larger vocabularies take the general kernels.
+        const int tw = isc_rows_stats_tile(p->V);
+        if (tw <= 0 || (p->V + tw - 1) / tw > 256) return 0;
+    }
     if ((p->H & 3) || (p->E & 3) || (p->W & 3) || (p->A & 3)) return 0;
     // slices: att-LSTM H (+ W) + H, lang-LSTM E + H + H, each cut at 256
     const int s1 = (p->H + 255) / 256 * 2 + (p->tab ? 0 : (p->W + 255) / 256);

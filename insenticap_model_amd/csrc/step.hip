@@ -20,8 +20,15 @@ extern "C" int isc_step_fwd(const isc_step_plan *p, void *stream) {
     if (!p) return ISC_E_NULL;
     const int rows = p->rows, H = p->H, E = p->E, A = p->A, W = p->W, V = p->V;
     if (rows <= 0 || H <= 0) return ISC_E_SHAPE;
-    const bool has_c = p->att_e != nullptr, has_s = p->words_e != nullptr, gate = has_c && has_s;
+    const bool has_c = p->att_e != nullptr, has_s = p->words_e != nullptr;
     if (!has_c && !has_s) return ISC_E_NULL;
+    // merged step of two sibling unrolls: rows [0, rows_c) scan the regions, rows [rows_c, rows) the sentiment words
+    const bool pair = p->pair_rows_c > 0;
+    if (p->pair_rows_c < 0 || (pair && (!has_c || !has_s || p->pair_rows_c >= rows))) return ISC_E_SHAPE;
+    const bool gate = has_c && has_s && !pair;
+    const int rows_c = pair ? p->pair_rows_c : rows, rows_s = pair ? rows - p->pair_rows_c : rows;
+    const long long off_s = pair ? p->pair_rows_c : 0;           // first sentiment row inside the step's row block
+    if (pair && (p->s != p->v + off_s * E || p->gate_Gc || p->gate_Gs)) return ISC_E_SHAPE;
     const int ld1 = H + E + W, ld2 = E + H;
     // f16 planes of the recurrent state (split-f16 path): all eight or none
     const bool planes = p->h1_prev_hi && p->h1_prev_lo && p->h2_prev_hi && p->h2_prev_lo && p->h1_hi && p->h1_lo &&
@@ -29,6 +36,7 @@ extern "C" int isc_step_fwd(const isc_step_plan *p, void *stream) {
     if (!planes && (p->h1_prev_hi || p->h1_prev_lo || p->h2_prev_hi || p->h2_prev_lo || p->h1_hi || p->h1_lo ||
                     p->h2_hi || p->h2_lo))
         return ISC_E_NULL;
+    if (pair && planes) return ISC_E_SHAPE;
 #define PL(x) (planes ? (x) : nullptr)
     const bool wplanes = planes && (!has_c || (p->v_hi && p->v_lo)) && (!has_s || (p->s_hi && p->s_lo)) &&
                          (!gate || (p->f_hi && p->f_lo));
@@ -52,14 +60,14 @@ extern "C" int isc_step_fwd(const isc_step_plan *p, void *stream) {
     {
         isc_linear_problem q[3] = {};
         int n = 0;
-        auto lin = [&](const float *Wm, const float *b, float *out) {
+        auto lin = [&](const float *Wm, const float *b, float *out, long long row0, int M) {
             isc_linear_problem &x = q[n++];
-            x.seg[0] = seg(p->h1, H, Wm, H, H, PL(p->h1_hi), PL(p->h1_lo));
-            x.nseg = 1; x.M = rows; x.N = A; x.bias0 = b; x.ldc = A; x.C = out;
+            x.seg[0] = seg(p->h1 + row0 * H, H, Wm, H, H, row0 ? nullptr : PL(p->h1_hi), row0 ? nullptr : PL(p->h1_lo));
+            x.nseg = 1; x.M = M; x.N = A; x.bias0 = b; x.ldc = A; x.C = out;
         };
-        if (has_c) lin(p->W_h2att, p->b_h2att, p->qa);
-        if (has_s) lin(p->W_h2word, p->b_h2word, p->qw);
-        if (gate) lin(p->W_gh, p->b_gh, p->z);
+        if (has_c) lin(p->W_h2att, p->b_h2att, p->qa, 0, rows_c);
+        if (has_s) lin(p->W_h2word, p->b_h2word, p->qw, off_s, rows_s);
+        if (gate) lin(p->W_gh, p->b_gh, p->z, 0, rows);
         q[0].splitk_ws = p->splitk_ws; q[0].splitk_ws_floats = p->splitk_ws_floats;
         RET(isc_linear_fwd(q, n, stream));
     }
@@ -74,6 +82,7 @@ extern "C" int isc_step_fwd(const isc_step_plan *p, void *stream) {
             x.P = p->att_p; x.V = p->att_e; x.q = p->qa; x.w = p->w_alpha_c; x.w_bias = p->b_alpha_c;
             x.R = p->R; x.A = A; x.D = E; x.out = p->v; x.alpha_out = p->alpha_c; x.alpha_ld = p->alpha_c_ld;
             x.out_hi = PW(p->v_hi); x.out_lo = PW(p->v_lo);
+            x.rows = rows_c;
         }
         if (has_s) {
             isc_scan_problem &x = sc[n++];
@@ -82,6 +91,7 @@ extern "C" int isc_step_fwd(const isc_step_plan *p, void *stream) {
             x.alpha_ld = p->alpha_s_ld;
             x.out_hi = PW(p->s_hi); x.out_lo = PW(p->s_lo);
             x.row_ids = p->words_ids; x.row_ids_ld = p->words_ids_ld;
+            x.rows = rows_s;
         }
         if (fused_gate) {
             isc_scan_gate_args g = {};
@@ -96,7 +106,7 @@ extern "C" int isc_step_fwd(const isc_step_plan *p, void *stream) {
             RET(isc_attn_scan_fwd(sc, n, rows, stream));
         }
     }
-    const float *feat = has_c ? p->v : p->s;
+    const float *feat = has_c ? p->v : p->s;          // (pair: s continues v - one [rows,E] block)
     const void *feat_hi = has_c ? PW(p->v_hi) : PW(p->s_hi), *feat_lo = has_c ? PW(p->v_lo) : PW(p->s_lo);
     if (fused_gate) {
         feat = p->f; feat_hi = PW(p->f_hi); feat_lo = PW(p->f_lo);
@@ -151,7 +161,12 @@ static inline isc_linear_problem nn_problem(const float *A, int lda, const float
 extern "C" int isc_step_bwd(const isc_step_bwd_plan *p, void *stream) {
     if (!p) return ISC_E_NULL;
     const int rows = p->rows, H = p->H, E = p->E, A = p->A, W = p->W;
-    const bool has_c = p->att_e != nullptr, has_s = p->words_e != nullptr, gate = has_c && has_s;
+    const bool has_c = p->att_e != nullptr, has_s = p->words_e != nullptr;
+    const bool pair = p->pair_rows_c > 0;             // merged step of two sibling unrolls (isc_step_plan.pair_rows_c)
+    if (p->pair_rows_c < 0 || (pair && (!has_c || !has_s || p->pair_rows_c >= rows))) return ISC_E_SHAPE;
+    const bool gate = has_c && has_s && !pair;
+    const int rows_c = pair ? p->pair_rows_c : rows, rows_s = pair ? rows - p->pair_rows_c : rows;
+    const long long off_s = pair ? p->pair_rows_c : 0;
     const int ld1 = H + E + W, ld2 = E + H, G = 4 * H;
     const int acc = p->first ? 0 : 1;      // time-accumulated buffers: the first processed step writes
 
@@ -165,7 +180,7 @@ extern "C" int isc_step_bwd(const isc_step_bwd_plan *p, void *stream) {
         q[0].splitk_ws = p->splitk_ws; q[0].splitk_ws_floats = p->splitk_ws_floats;
         RET(isc_gemm_bwd(q, 3, ISC_LAYOUT_NN, stream));
     }
-    const float *dv = p->d_feat, *dsw = p->d_feat;
+    const float *dv = p->d_feat, *dsw = p->d_feat + off_s * E;
     if (gate) {
         RET(isc_gate_mix_bwd(p->z, p->w_gate, p->v, p->s, p->beta, p->beta_ld, p->d_feat, rows, A, E, p->dv,
                              p->ds, p->dz, p->dwg_rows, p->dbg_rows, acc, stream));
@@ -185,16 +200,23 @@ extern "C" int isc_step_bwd(const isc_step_bwd_plan *p, void *stream) {
             x.P = p->att_p; x.V = p->att_e; x.q = p->qa; x.w = p->w_alpha_c; x.alpha = p->alpha_c;
             x.alpha_ld = p->alpha_c_ld; x.dout = dv; x.R = p->R; x.A = A; x.D = E; x.accumulate = acc;
             x.dP = p->dP_att; x.dV = p->dV_att; x.dq = p->dqa; x.dw_rows = p->dwc_rows; x.de_out = p->de_c;
+            x.rows = rows_c;
         }
         if (has_s) {
             isc_scan_bwd_problem &x = sc[n++];
             x.P = p->words_p; x.V = p->words_e; x.q = p->qw; x.q2 = p->label_w; x.w = p->w_alpha_s;
             x.alpha = p->alpha_s; x.alpha_ld = p->alpha_s_ld; x.dout = dsw; x.R = p->Mw; x.A = A; x.D = W;
             x.accumulate = acc; x.dP = p->dP_w; x.dV = p->dV_w; x.dq = p->dqw; x.dw_rows = p->dws_rows; x.de_out = p->de_s;
+            x.rows = rows_s;
         }
         RET(isc_attn_scan_bwd(sc, n, rows, stream));
     }
-    {   // d h_att += dqa W_h2att + dqw W_h2word
+    if (pair) {   // d h_att[content rows] += dqa W_h2att, d h_att[sentiment rows] += dqw W_h2word: two problems, one launch
+        isc_linear_problem q[2] = {nn_problem(p->dqa, A, p->W_h2att, H, A, rows_c, H, p->dh1, 1),
+                                   nn_problem(p->dqw, A, p->W_h2word, H, A, rows_s, H, p->dh1 + off_s * H, 1)};
+        q[0].splitk_ws = p->splitk_ws; q[0].splitk_ws_floats = p->splitk_ws_floats;
+        RET(isc_gemm_bwd(q, 2, ISC_LAYOUT_NN, stream));
+    } else {   // d h_att += dqa W_h2att + dqw W_h2word
         isc_linear_problem x = {};
         int n = 0;
         if (has_c) x.seg[n++] = seg(p->dqa, A, p->W_h2att, H, A);

@@ -183,7 +183,23 @@ class Detector(nn.Module):
             copied.record()
 
             xe_loss = 0.0
-            if data_type == 'fact':                      # XE on the ground truth, labelled by the classifier
+            seq2seq_loss = 0.0
+            from .autograd_pair import use_pair
+            merged = data_type == 'fact' and training and device.type == 'cuda' and use_pair(cap, False)
+            if merged:                                   # XE + seq2seq unrolls through one step chain (autograd_pair)
+                with torch.no_grad():
+                    xe_senti_labels = self.sent_senti_cls(caps_tensor[:, 1:], lengths)[0]
+                    xe_senti_labels = xe_senti_labels.softmax(dim=-1).argmax(dim=-1).detach()
+                (s_caps, s_lengths), s_cpts, s_sentis, s_labels = s2s_batch
+                s_caps, s_cpts = s_caps.to(device), s_cpts.to(device)
+                s_sentis, s_labels = s_sentis.to(device), s_labels.to(device)
+                pred, pred2 = cap(fc_feats, att_feats, cpts_tensor, caps_tensor, xe_senti_labels, self.xe_ss_prob,
+                                  s_caps, s_cpts, s_sentis, s_labels, self.seq2seq_ss_prob, mode='xe_seq2seq')
+                xe_loss = share(self.cap_xe_crit(pred, caps_tensor[:, 1:], lengths), w_xe)
+                add('xe_loss', xe_loss)
+                seq2seq_loss = share(self.seq_flag * self.cap_xe_crit(pred2, s_caps[:, 1:], s_lengths), w_s2s)
+                add('seq2seq_loss', seq2seq_loss)
+            elif data_type == 'fact':                    # XE on the ground truth, labelled by the classifier
                 with torch.no_grad():
                     xe_senti_labels = self.sent_senti_cls(caps_tensor[:, 1:], lengths)[0]
                     xe_senti_labels = xe_senti_labels.softmax(dim=-1).argmax(dim=-1).detach()
@@ -192,8 +208,7 @@ class Detector(nn.Module):
                 xe_loss = share(self.cap_xe_crit(pred, caps_tensor[:, 1:], lengths), w_xe)
                 add('xe_loss', xe_loss)
 
-            seq2seq_loss = 0.0
-            if training:
+            if training and not merged:
                 (s_caps, s_lengths), s_cpts, s_sentis, s_labels = s2s_batch
                 s_caps, s_cpts = s_caps.to(device), s_cpts.to(device)
                 s_sentis, s_labels = s_sentis.to(device), s_labels.to(device)

@@ -1,6 +1,7 @@
 """Thin torch-tensor -> C-ABI adapters. PyTorch is plumbing here (device memory + streams);
 all arithmetic happens in libinsenticap_hip.so."""
 import ctypes as C
+import gc
 import threading
 import time
 
@@ -119,7 +120,58 @@ def graph_capture(graph, **kw):
         # at its next pass (every 100 ms), so finish everything and let one pass go by.  Captures are once per geometry.
         torch.cuda.synchronize()
         time.sleep(0.25)
-    return torch.cuda.graph(graph, **kw)
+    return _Capture(torch.cuda.graph(graph, **kw))
+
+
+class _Capture:
+    """torch.cuda.graph(...) with Python's automatic garbage collection held off while the capture is open.  torch
+    collects once when a capture begins; a generational collection that fires DURING it can still run the destructor of
+    cyclic garbage from earlier work - an older captured graph, a stream's buffers - and destroying a HIP graph (or
+    freeing through the runtime) on a thread that is capturing aborts the process (seen as 'Fatal Python error: Aborted
+    ... Garbage-collecting' inside a roll-out capture).  The cycle collector is switched back on after capture_end."""
+
+    def __init__(self, inner):
+        self.inner, self.was = inner, False
+
+    def __enter__(self):
+        out = self.inner.__enter__()
+        self.was = gc.isenabled()
+        gc.disable()
+        return out
+
+    def __exit__(self, *exc):
+        try:
+            return self.inner.__exit__(*exc)
+        finally:
+            if self.was:
+                gc.enable()
+
+
+def graph_node_counts(graph):
+    """{'kernel', 'memcpy', 'memset', 'other'} node counts of a torch.cuda.CUDAGraph created with keep_graph=True
+    (measurement / tests: the launches one replay issues).  HIP runtime calls only - nothing of this package's library."""
+    hip = C.CDLL('libamdhip64.so')          # the runtime torch has already loaded
+    raw = C.c_void_p(graph.raw_cuda_graph())
+    n = C.c_size_t(0)
+    if hip.hipGraphGetNodes(raw, None, C.byref(n)) != 0:
+        raise RuntimeError('hipGraphGetNodes failed')
+    nodes = (C.c_void_p * max(n.value, 1))()
+    if hip.hipGraphGetNodes(raw, nodes, C.byref(n)) != 0:
+        raise RuntimeError('hipGraphGetNodes failed')
+    out = {'kernel': 0, 'memcpy': 0, 'memset': 0, 'other': 0}
+    names = {0: 'kernel', 1: 'memcpy', 2: 'memset'}          # hipGraphNodeTypeKernel / Memcpy / Memset
+    for i in range(n.value):
+        ty = C.c_int(-1)
+        if hip.hipGraphNodeGetType(C.c_void_p(nodes[i]), C.byref(ty)) != 0:
+            raise RuntimeError('hipGraphNodeGetType failed')
+        out[names.get(ty.value, 'other')] += 1
+    return out
+
+
+def graph_kernel_nodes(graph):
+    """Launch-issuing nodes (kernels, copies, fills) of a kept graph - what a kernel trace counts per replay."""
+    c = graph_node_counts(graph)
+    return c['kernel'] + c['memcpy'] + c['memset']
 
 
 _CAPTURE = threading.local()      # per host thread: the (workspace, weight-plane buffer) pair of a HIP-graph capture
@@ -502,16 +554,25 @@ def logsoftmax_apply(logits, part_max, part_sum, lse_out=None):
                                    part_sum.data_ptr(), ptr(lse_out), stream()), 'isc_logsoftmax_apply')
 
 
-def logsoftmax_apply_steps(logits_btv, part_max_tbn, part_sum_tbn, src_tbv=None):
+def logsoftmax_apply_steps(logits_btv, part_max_tbn, part_sum_tbn, src_tbv=None, step_rows=0):
     """log-softmax over all steps of a [B,T,V] logits tensor from the per-step tile statistics [T,B,n_tile]: in place,
-    or from raw logits stacked per step `src_tbv` [T,B,V] (one classifier launch over all steps)."""
+    or from raw logits stacked per step `src_tbv` [T,B,V] (one classifier launch over all steps).
+    step_rows > 0 (merged unroll): the statistics / src are [T, :B] row slices of stacks with `step_rows` rows per step
+    (views whose first element is this branch's first row)."""
     B, T, V = logits_btv.shape
-    assert logits_btv.stride(2) == 1 and part_max_tbn.is_contiguous() and part_sum_tbn.is_contiguous()
-    assert part_max_tbn.shape[:2] == (T, B) and part_sum_tbn.shape == part_max_tbn.shape
-    assert src_tbv is None or (src_tbv.is_contiguous() and src_tbv.shape == (T, B, V))
+    assert logits_btv.stride(2) == 1
+    if step_rows:
+        n_tile = part_max_tbn.shape[2]
+        assert step_rows >= B and part_max_tbn.shape[:2] == (T, B) and part_sum_tbn.shape == part_max_tbn.shape
+        for x, w in ((part_max_tbn, n_tile), (part_sum_tbn, n_tile)) + (((src_tbv, V),) if src_tbv is not None else ()):
+            assert x.stride(2) == 1 and x.stride(1) == w and x.stride(0) == step_rows * w, (x.shape, x.stride())
+    else:
+        assert part_max_tbn.is_contiguous() and part_sum_tbn.is_contiguous()
+        assert part_max_tbn.shape[:2] == (T, B) and part_sum_tbn.shape == part_max_tbn.shape
+        assert src_tbv is None or (src_tbv.is_contiguous() and src_tbv.shape == (T, B, V))
     check(_lib.load().isc_logsoftmax_apply_steps(logits_btv.data_ptr(), logits_btv.stride(0), logits_btv.stride(1), B, T,
                                                  V, part_max_tbn.data_ptr(), part_sum_tbn.data_ptr(), ptr(src_tbv),
-                                                 stream()),
+                                                 int(step_rows), stream()),
           'isc_logsoftmax_apply_steps')
 
 
@@ -729,9 +790,10 @@ def logsoftmax_bwd(dlogp, logp, dlogits, M, V, remap_T=0):
                                  dlogits.stride(0), remap_T, stream()), 'isc_logsoftmax_bwd')
 
 
-def logsoftmax_bwd_sparse(dense, logp, sparse, dlogits, M, V, remap_T=0, scale=None):
+def logsoftmax_bwd_sparse(dense, logp, sparse, dlogits, M, V, remap_T=0, scale=None, out_step_rows=0):
     """isc_logsoftmax_bwd_sparse: d logits from an optional dense d log-prob [M,V] plus up to two (ids [M] int64,
-    coef [M] fp32) pairs - one column per row each - times the optional device scalar `scale`."""
+    coef [M] fp32) pairs - one column per row each - times the optional device scalar `scale`.
+    out_step_rows > 0 (with remap_T): rows per step of the time-major output; `dlogits` starts at this branch's first row."""
     lib = _lib.load()
     assert logp.is_contiguous() and dlogits.stride(1) == 1 and (dense is None or dense.is_contiguous())
     n = len(sparse)
@@ -741,7 +803,7 @@ def logsoftmax_bwd_sparse(dense, logp, sparse, dlogits, M, V, remap_T=0, scale=N
         assert i.dtype == torch.int64 and c.dtype == torch.float32 and i.is_contiguous() and c.is_contiguous()
         assert i.numel() == M and c.numel() == M
     check(lib.isc_logsoftmax_bwd_sparse(ptr(dense), logp.data_ptr(), V, M, V, ids, cf, n, ptr(scale),
-                                        dlogits.data_ptr(), dlogits.stride(0), remap_T, stream()),
+                                        dlogits.data_ptr(), dlogits.stride(0), remap_T, int(out_step_rows), stream()),
           'isc_logsoftmax_bwd_sparse')
 
 
@@ -800,14 +862,20 @@ def scan_bwd_problem(P, V, q, w, alpha, dout, dP, dV, dq, dw_rows, accumulate, q
     return s
 
 
-def attn_dv_from_alpha(alpha, dout_all, dV):
+def attn_dv_from_alpha(alpha, dout_all, dV, step_rows=0):
     """dV[b,r,:] = sum_t alpha[b,t,r] * dout_all[t,b,:] in the backward sweep's order (isc_attn_dv_from_alpha).
-    alpha: [B,T,R] view with unit inner stride; dout_all [T,B,D] contiguous; dV [B,R,D] contiguous."""
+    alpha: [B,T,R] view with unit inner stride; dout_all [T,B,D] contiguous - or, step_rows > 0, the [:, :B] rows of a
+    [T,step_rows,D] stack (merged unroll); dV [B,R,D] contiguous."""
     B, T, R = alpha.shape
     D = dV.shape[2]
-    assert alpha.stride(2) == 1 and dout_all.is_contiguous() and dV.is_contiguous() and dout_all.shape == (T, B, D)
+    assert alpha.stride(2) == 1 and dV.is_contiguous() and dout_all.shape == (T, B, D)
+    if step_rows:
+        assert dout_all.stride(2) == 1 and dout_all.stride(1) == D and dout_all.stride(0) == step_rows * D
+    else:
+        assert dout_all.is_contiguous()
     check(_lib.load().isc_attn_dv_from_alpha(alpha.data_ptr(), alpha.stride(0), alpha.stride(1), dout_all.data_ptr(),
-                                             B, T, R, D, dV.data_ptr(), stream()), 'isc_attn_dv_from_alpha')
+                                             B, T, R, D, dV.data_ptr(), int(step_rows), stream()),
+          'isc_attn_dv_from_alpha')
 
 
 def attn_dp_from_de(P, q_all, w, de_all, dP, q2=None):

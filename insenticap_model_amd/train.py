@@ -49,7 +49,7 @@ def _xe_loss(xe_crit, pred, target, lengths):
 
 
 def xe_forward_backward(captioner, optim, xe_crit, da_crit, fact, xe_senti_labels, scs=None, ss_prob=0.0, arena=None,
-                        weights3=None, overlap_unrolls=True, side_stream=None):
+                        weights3=None, overlap_unrolls=True, side_stream=None, pair=None):
     """train_xe.py:160-190 on device tensors: both unrolls, the three losses, backward.  `fact` = (fc, att, caps,
     lengths, cpts), `scs` = (caps, lengths, cpts, sentis, labels) or None; `weights3` = this rank's shares of the three
     global normalisers (XE tokens, seq2seq tokens, rows) as a device tensor, or None (single process: graph
@@ -59,12 +59,27 @@ def xe_forward_backward(captioner, optim, xe_crit, da_crit, fact, xe_senti_label
     device = fc_feats.device
     share = (lambda x, w: x * w) if weights3 is not None else (lambda x, w: x)
     w_xe, w_s2s, w_rows = weights3.unbind(0) if weights3 is not None else (None, None, None)
-    pred = captioner(fc_feats, att_feats, cpts_tensor, caps_tensor, xe_senti_labels, ss_prob, mode='xe')
+    if pair is None:
+        from .autograd_pair import use_pair
+        pair = use_pair(captioner, False)
+    pair = pair and scs is not None and device.type == 'cuda'
+    if pair:
+        # both unrolls through ONE step chain (Captioner.forward_xe_seq2seq / autograd_pair): the LSTM cells, the
+        # classifier and every backward contraction run once over the 128 + 80 rows instead of once per unroll
+        s_caps, s_lengths, s_cpts, s_sentis, s_labels = scs
+        pred, pred2 = captioner(fc_feats, att_feats, cpts_tensor, caps_tensor, xe_senti_labels, ss_prob,
+                                s_caps, s_cpts, s_sentis, s_labels, ss_prob, mode='xe_seq2seq')
+    else:
+        pred = captioner(fc_feats, att_feats, cpts_tensor, caps_tensor, xe_senti_labels, ss_prob, mode='xe')
     xe_bwd = share(_xe_loss(xe_crit, pred, caps_tensor[:, 1:], lengths), w_xe)
     da_bwd = share(da_crit(captioner.cpt_feats, captioner.fc_feats.detach()), w_rows)
     total = xe_bwd + da_bwd
     s2s_d = torch.zeros((), device=device)
-    if scs is not None:
+    if pair:
+        s2s = share(_xe_loss(xe_crit, pred2, s_caps[:, 1:], s_lengths), w_s2s)
+        total = total + s2s
+        s2s_d = s2s.detach()
+    elif scs is not None:
         s_caps, s_lengths, s_cpts, s_sentis, s_labels = scs
 
         def seq2seq_unroll():

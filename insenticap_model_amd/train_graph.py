@@ -63,6 +63,8 @@ class _Geometry:
 
 
 class XETrainGraph:
+    KEEP_GRAPHS = False          # True (tests, tools): graphs keep their hipGraph_t so that ops.graph_node_counts can walk it
+
     def __init__(self, captioner, optim, xe_crit, da_crit, grad_clip=0.1, arena=None, group=None, warmup=2,
                  max_geometries=4):
         if not isinstance(optim, FusedClampAdam):
@@ -115,15 +117,47 @@ class XETrainGraph:
 
     def _signature(self, t, ss_prob):
         return (tuple((k, tuple(v.shape), v.dtype) for k, v in sorted(t.items())), float(ss_prob),
-                bool(self.cap.training), self._dist())
+                bool(self.cap.training), self._dist(), bool(self._pair()))
 
     def _stage(self, geo, t):
+        """The batch -> the geometry's static device buffers.  Device tensors go in ONE multi-copy launch per eight
+        (isc_copy_multi); host tensors (the caption lengths, host-resident batches) are packed into ONE pinned buffer of
+        the geometry and travel in one non-blocking copy + one multi-copy - an iteration used to start with 16 separate
+        copies, each a host round trip in front of the replay (0.45 ms of a 5 ms iteration)."""
         if geo.inputs is None:
             geo.inputs = {k: torch.empty(v.shape, dtype=v.dtype, device=self.device) for k, v in t.items()}
+            geo.pin = None
+        dev_d, dev_s, host = [], [], []
         for k, v in t.items():
-            if not v.is_cuda and not v.is_pinned():
-                v = v.pin_memory()
-            geo.inputs[k].copy_(v, non_blocking=True)
+            dst = geo.inputs[k]
+            if v.is_cuda and v.dtype == dst.dtype and v.is_contiguous():
+                dev_d.append(dst)
+                dev_s.append(v)
+            elif v.is_cuda:
+                dst.copy_(v, non_blocking=True)
+            else:
+                host.append((dst, v))
+        if host:
+            sizes = [(d.numel() * d.element_size() + 15) & ~15 for d, _ in host]
+            total = sum(sizes)
+            if geo.pin is None or geo.pin[0].numel() != total:
+                geo.pin = (torch.empty(total, dtype=torch.uint8).pin_memory(),
+                           torch.empty(total, dtype=torch.uint8, device=self.device), torch.cuda.Event())
+                geo.pin[2].record(torch.cuda.current_stream(self.device))
+            pin, stage, ev = geo.pin
+            ev.synchronize()                 # the previous iteration's H2D copy has read the pinned buffer
+            off = 0
+            for (d, v), n in zip(host, sizes):
+                nb = d.numel() * d.element_size()
+                pin[off:off + nb].view(d.dtype).view(d.shape).copy_(v.to(d.dtype))
+                dev_d.append(d.view(-1).view(torch.uint8))
+                dev_s.append(stage[off:off + nb])
+                off += n
+            stage.copy_(pin, non_blocking=True)
+            ev.record(torch.cuda.current_stream(self.device))
+        if dev_d:
+            ops.copy_multi([d.view(-1).view(torch.uint8) if d.dtype != torch.uint8 else d.view(-1) for d in dev_d],
+                           [s.view(-1).view(torch.uint8) if s.dtype != torch.uint8 else s.view(-1) for s in dev_s])
 
     def _phase_args(self, geo):
         i = geo.inputs
@@ -132,13 +166,22 @@ class XETrainGraph:
         return fact, i['labels'], scs
 
     # ---- the phases of an iteration (run eagerly while a geometry warms up, captured afterwards) ----------------
-    def _phase_xe(self, geo, ss_prob):
-        """XE unroll + domain-align loss, forward and backward, on self.stream; gradients land in p.grad (the arena's
-        views under DP).  Returns the detached [xe, da, 0] losses."""
-        fact, labels, _ = self._phase_args(geo)
-        self.cap.cpt_feats = self.cap.fc_feats = None
-        return xe_forward_backward(self.cap, self.optim, self.xe_crit, self.da_crit, fact, labels, None, ss_prob,
-                                   self.arena, self.shares if self._dist() else None, False, None)
+    def _pair(self):
+        """Both unrolls through one step chain on self.stream (autograd_pair: 367 nodes per B = 128 + 80 iteration, 5.3 ms)
+        or - the default inside graphs, 4.85 ms - the seq2seq unroll as a branch on self.side with its gradients added
+        afterwards (autograd_pair.use_pair; `captioner.pair_unrolls` forces either)."""
+        from .autograd_pair import use_pair
+        return use_pair(self.cap, True)
+
+    def _phase_xe(self, geo, ss_prob, with_scs=False):
+        """XE unroll + domain-align loss (with_scs: and the seq2seq unroll, merged into the same step chain), forward
+        and backward, on self.stream; gradients land in p.grad (the arena's views under DP).  Returns the detached
+        [xe, da, seq2seq or 0] losses."""
+        fact, labels, scs = self._phase_args(geo)
+        self.cap.cpt_feats = self.cap.fc_feats = self.cap.s2s_cpt_feats = None
+        return xe_forward_backward(self.cap, self.optim, self.xe_crit, self.da_crit, fact, labels,
+                                   scs if with_scs else None, ss_prob, self.arena,
+                                   self.shares if self._dist() else None, False, None, pair=with_scs)
 
     def _phase_s2s(self, geo, ss_prob):
         """seq2seq unroll, forward and backward, on self.side - concurrently with _phase_xe, so its gradients go to
@@ -148,7 +191,7 @@ class XETrainGraph:
         _, _, scs = self._phase_args(geo)
         s_caps, s_len, s_cpts, s_sentis, s_labels = scs
         params = self._params
-        self.cap.cpt_feats = self.cap.fc_feats = None          # the accumulate nodes are re-made under THIS stream
+        self.cap.cpt_feats = self.cap.fc_feats = self.cap.s2s_cpt_feats = None          # the accumulate nodes are re-made under THIS stream
         pred2 = self.cap(s_caps, s_cpts, s_sentis, s_labels, ss_prob, mode='seq2seq')
         loss = _xe_loss(self.xe_crit, pred2, s_caps[:, 1:], s_len)
         if self._dist():
@@ -213,22 +256,25 @@ class XETrainGraph:
             with ops.refresh_only(self._handles):
                 # ONE graph, two long branches: the seq2seq unroll (forward AND backward) forks off on self.side before
                 # the XE unroll starts on self.stream and joins after it
-                geo.g_iter = torch.cuda.CUDAGraph()
+                geo.g_iter = torch.cuda.CUDAGraph(keep_graph=self.KEEP_GRAPHS)
                 with ops.graph_capture(geo.g_iter, stream=self.stream):
                     s2s = None
-                    if has_s2s:
-                        self.side.wait_stream(self.stream)
-                        with torch.cuda.stream(self.side):
-                            s2s = self._phase_s2s(geo, ss_prob)
-                    vec_xe = self._phase_xe(geo, ss_prob)
-                    if has_s2s:
-                        self.stream.wait_stream(self.side)
-                    geo.vec = self._phase_add(geo, vec_xe, s2s)
+                    if has_s2s and self._pair():
+                        vec_xe = geo.vec = self._phase_xe(geo, ss_prob, True)
+                    else:
+                        if has_s2s:
+                            self.side.wait_stream(self.stream)
+                            with torch.cuda.stream(self.side):
+                                s2s = self._phase_s2s(geo, ss_prob)
+                        vec_xe = self._phase_xe(geo, ss_prob)
+                        if has_s2s:
+                            self.stream.wait_stream(self.side)
+                        geo.vec = self._phase_add(geo, vec_xe, s2s)
                     if not self._dist():
                         xe_update(self.optim, self.grad_clip)
                 geo.g_up = None
                 if self._dist():
-                    geo.g_up = torch.cuda.CUDAGraph()
+                    geo.g_up = torch.cuda.CUDAGraph(keep_graph=self.KEEP_GRAPHS)
                     with ops.graph_capture(geo.g_up, stream=self.stream):
                         xe_update(self.optim, self.grad_clip)
                 geo.keep = (vec_xe, s2s)
@@ -263,18 +309,21 @@ class XETrainGraph:
         weights): same streams, same order of dependencies."""
         with ops.refresh_only(self._handles):
             has_s2s = 's_caps' in geo.inputs
-            if has_s2s:
-                self.side.wait_stream(self.stream)
-            vec_xe = self._phase_xe(geo, ss_prob)
-            s2s = None
-            if has_s2s:
-                with torch.cuda.stream(self.side):
-                    s2s = self._phase_s2s(geo, ss_prob)
-                self.stream.wait_stream(self.side)
-                for g in s2s[1]:
-                    if g is not None:
-                        g.record_stream(self.stream)
-            vec = self._phase_add(geo, vec_xe, s2s)
+            if has_s2s and self._pair():
+                vec = self._phase_xe(geo, ss_prob, True)
+            else:
+                if has_s2s:
+                    self.side.wait_stream(self.stream)
+                vec_xe = self._phase_xe(geo, ss_prob)
+                s2s = None
+                if has_s2s:
+                    with torch.cuda.stream(self.side):
+                        s2s = self._phase_s2s(geo, ss_prob)
+                    self.stream.wait_stream(self.side)
+                    for g in s2s[1]:
+                        if g is not None:
+                            g.record_stream(self.stream)
+                vec = self._phase_add(geo, vec_xe, s2s)
             vec = self._exchange(vec)
             xe_update(self.optim, self.grad_clip)
         self._valid_key = self.cap._weights_key()
@@ -299,7 +348,7 @@ class XETrainGraph:
                 raise ValueError('seq2seq captions are %d tokens wide, max(lengths)=%d' % (s_caps.size(1), max(s_lengths)))
             t.update(s_caps=s_caps, s_cpts=s_cpts, s_sentis=s_sentis, s_labels=s_labels,
                      s_len=torch.tensor(s_lengths, dtype=torch.int32))
-        self.cap.cpt_feats = self.cap.fc_feats = None      # (see the module docstring: stale AccumulateGrad nodes)
+        self.cap.cpt_feats = self.cap.fc_feats = self.cap.s2s_cpt_feats = None      # (see the module docstring: stale AccumulateGrad nodes)
         sig = self._signature(t, ss_prob)
         geo = self._geoms.get(sig)
         if geo is None:
@@ -375,7 +424,7 @@ class RLTrainGraph(XETrainGraph):
     def _phase_roll(self, geo):
         """Sampled roll-out (graph kept), domain-align loss, greedy baseline, token matrices on their way to the host."""
         det, cap, i = self.det, self.cap, geo.inputs
-        cap.cpt_feats = cap.fc_feats = None
+        cap.cpt_feats = cap.fc_feats = cap.s2s_cpt_feats = None
         cap.train(True)
         seq, lp, mk = cap(i['fc'], i['att'], i['cpts'], i['sentis'], i['labels'], det.max_seq_len, sample_max=0, mode='rl')
         da = det.cap_da_crit(cap.cpt_feats, cap.fc_feats.detach())
@@ -394,8 +443,18 @@ class RLTrainGraph(XETrainGraph):
         """XE unroll forward on self.stream; the seq2seq unroll - forward and backward - as a branch on self.side."""
         from .train import _xe_loss
         det, cap, i = self.det, self.cap, geo.inputs
+        if self._pair():          # both unrolls through one step chain: forward only here, ONE backward in _phase_bwd
+            cap.cpt_feats = cap.fc_feats = cap.s2s_cpt_feats = None
+            pred, pred2 = cap(i['fc'], i['att'], i['cpts'], i['caps'], i['xe_labels'], det.xe_ss_prob,
+                              i['s_caps'], i['s_cpts'], i['s_sentis'], i['s_labels'], det.seq2seq_ss_prob,
+                              mode='xe_seq2seq')
+            xe = _xe_loss(det.cap_xe_crit, pred, i['caps'][:, 1:], i['len'])
+            s2s_loss = _xe_loss(det.cap_xe_crit, pred2, i['s_caps'][:, 1:], i['s_len'])
+            if self._dist():
+                s2s_loss = s2s_loss * self.shares[1]
+            return xe, (s2s_loss, None)
         self.side.wait_stream(self.stream)                  # the branch forks here ...
-        cap.cpt_feats = cap.fc_feats = None
+        cap.cpt_feats = cap.fc_feats = cap.s2s_cpt_feats = None
         # ... the XE unroll is ENQUEUED first (the reference's call order, hence its order of random draws: decoder.py:138,155)
         pred = cap(i['fc'], i['att'], i['cpts'], i['caps'], i['xe_labels'], ss_prob=det.xe_ss_prob, mode='xe')
         xe = _xe_loss(det.cap_xe_crit, pred, i['caps'][:, 1:], i['len'])
@@ -418,13 +477,15 @@ class RLTrainGraph(XETrainGraph):
             cap_loss, xe, da = cap_loss * self.share_rl[0], xe * self.shares[0], da * self.shares[2]
         s2s_loss = det.seq_flag * s2s_loss
         total = cap_loss + xe + da
+        if s2s_grads is None:                                # merged unrolls: the seq2seq loss is part of the one backward
+            total = total + s2s_loss
         if self.arena is not None:
             self.arena.zero_()
         else:
             self.optim.zero_grad()
         total.backward()
         dst, src = [], []
-        for q, g in zip(self._params, s2s_grads):
+        for q, g in zip(self._params, s2s_grads or ()):
             if g is None:
                 continue
             if det.seq_flag != 1.0:
@@ -490,7 +551,7 @@ class RLTrainGraph(XETrainGraph):
             geo.copied.record(self.stream)
             self._shares(geo, roll, lengths, s_lengths)
             fwd = self._phase_fwd(geo)
-            for g in fwd[1][1]:
+            for g in fwd[1][1] or ():
                 if g is not None:
                     g.record_stream(self.stream)
             self._rewards(geo, roll, item)
@@ -509,18 +570,18 @@ class RLTrainGraph(XETrainGraph):
         geo.pool = torch.cuda.graph_pool_handle()
         try:
             with ops.refresh_only(self._handles):
-                geo.g_roll = torch.cuda.CUDAGraph()
+                geo.g_roll = torch.cuda.CUDAGraph(keep_graph=self.KEEP_GRAPHS)
                 with ops.graph_capture(geo.g_roll, stream=self.stream, pool=geo.pool):
                     roll = self._phase_roll(geo)
-                geo.g_fwd = torch.cuda.CUDAGraph()
+                geo.g_fwd = torch.cuda.CUDAGraph(keep_graph=self.KEEP_GRAPHS)
                 with ops.graph_capture(geo.g_fwd, stream=self.stream, pool=geo.pool):
                     fwd = self._phase_fwd(geo)
-                geo.g_bwd = torch.cuda.CUDAGraph()
+                geo.g_bwd = torch.cuda.CUDAGraph(keep_graph=self.KEEP_GRAPHS)
                 with ops.graph_capture(geo.g_bwd, stream=self.stream, pool=geo.pool):
                     self._phase_bwd(geo, roll, fwd)
                 geo.g_up = None
                 if self._dist():
-                    geo.g_up = torch.cuda.CUDAGraph()
+                    geo.g_up = torch.cuda.CUDAGraph(keep_graph=self.KEEP_GRAPHS)
                     with ops.graph_capture(geo.g_up, stream=self.stream, pool=geo.pool):
                         xe_update(self.optim, self.grad_clip)
                 geo.keep = (roll, fwd)
@@ -572,7 +633,7 @@ class RLTrainGraph(XETrainGraph):
         t = dict(fc=fc, att=att, caps=caps, cpts=cpts, sentis=sentis, labels=senti_labels, xe_labels=xe_senti_labels,
                  len=torch.tensor(lengths, dtype=torch.int32), s_caps=s_caps, s_cpts=s_cpts, s_sentis=s_sentis,
                  s_labels=s_labels, s_len=torch.tensor(s_lengths, dtype=torch.int32))
-        self.cap.cpt_feats = self.cap.fc_feats = None
+        self.cap.cpt_feats = self.cap.fc_feats = self.cap.s2s_cpt_feats = None
         sig = (self._signature(t, 0.0), self.det.max_seq_len, self.det.xe_ss_prob, self.det.seq2seq_ss_prob,
                self.det.cls_flag, self.det.seq_flag)
         geo = self._geoms.get(sig)

@@ -178,7 +178,18 @@ def test_detector_training_iterations_match_the_reference(golden):
         out = o_s2s(fed_as_captions('dt/fed_s2s%d' % n['s2s']), cpts, sentis, labels, 0.0, **k)
         n['s2s'] += 1
         return out
+    o_pair = cap.forward_xe_seq2seq
+
+    def replay_pair(fc, att, cpts, caps, labels, ss_prob, s_caps, s_cpts, s_sentis, s_labels, s_ss_prob=None, **k):
+        # both unrolls through the merged step chain (Captioner.forward_xe_seq2seq): the same fed tokens
+        assert ss_prob == 0.5 and s_ss_prob == 0.25
+        out = o_pair(fc, att, cpts, fed_as_captions('dt/fed_xe%d' % n['xe']), labels, 0.0,
+                     fed_as_captions('dt/fed_s2s%d' % n['s2s']), s_cpts, s_sentis, s_labels, 0.0, **k)
+        n['xe'] += 1
+        n['s2s'] += 1
+        return out
     cap.forward_rl, cap.forward_xe, cap.forward_seq2seq = replay_rl, replay_xe, replay_s2s
+    cap.forward_xe_seq2seq = replay_pair
     losses = det(([_tensors(b) for b in batches], scs), 'fact', True)
     assert n == {'rl': 2, 'xe': 2, 's2s': 2}
     assert set(losses) == {'da_loss', 'fact_reward', 'cls_reward', 'all_rewards', 'cap_loss', 'xe_loss',

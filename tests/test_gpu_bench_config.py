@@ -224,7 +224,17 @@ def test_config4_rl_training_iteration_at_full_size_vs_reference(golden):
         assert ss_prob == 0.25
         n['s2s'] += 1
         return o_s2s(fed_as_captions('d5t/fed_s2s'), cpts, sentis, labels, 0.0, **k)
+    o_pair = cap.forward_xe_seq2seq
+
+    def replay_pair(fc, att, cpts, caps, labels, ss_prob, s_caps, s_cpts, s_sentis, s_labels, s_ss_prob=None, **k):
+        # both unrolls through the merged step chain (Captioner.forward_xe_seq2seq): the same fed tokens
+        assert ss_prob == 0.5 and s_ss_prob == 0.25
+        n['xe'] += 1
+        n['s2s'] += 1
+        return o_pair(fc, att, cpts, fed_as_captions('d5t/fed_xe'), labels, 0.0, fed_as_captions('d5t/fed_s2s'),
+                      s_cpts, s_sentis, s_labels, 0.0, **k)
     cap.forward_rl, cap.forward_xe, cap.forward_seq2seq = replay_rl, replay_xe, replay_s2s
+    cap.forward_xe_seq2seq = replay_pair
     losses = det(([item], scs), 'fact', True)
     assert n == {'rl': 1, 'xe': 1, 's2s': 1}
     assert set(losses) == {'da_loss', 'fact_reward', 'cls_reward', 'all_rewards', 'cap_loss', 'xe_loss', 'seq2seq_loss'}

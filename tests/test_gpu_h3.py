@@ -416,3 +416,69 @@ def test_optimizer_step_refreshes_the_suspended_weight_planes():
     assert l1 == l0
     for k in p0:
         assert torch.equal(p0[k], p1[k]), k
+
+
+def _set_ksplit(on):
+    from insenticap_model_amd import _lib
+    return _lib.load().isc_set_h3_ksplit(int(on))
+
+
+@pytest.mark.parametrize('M,N,K1,K2', [(4608, 512, 2048, 0), (4160, 512, 4096, 2048), (1100, 384, 8192, 0)])
+def test_linear_long_k_on_few_large_tiles_is_cut_into_k_slices(M, N, K1, K2):
+    """isc_set_h3_ksplit: a linear launch of < 200 large tiles over >= 64 k-blocks contracts in slices of K (raw partial
+    tiles in slabs, fixed-order reduce + epilogue): same result as the one-slice launch up to fp32 summation order, the
+    fp64 bound of the other split-f16 tests, every epilogue feature (bias, accumulate, ReLU, mask, pre-mask output)."""
+    g = torch.Generator().manual_seed(M + K1)
+    x1, w1, b = _rand(g, M, K1), _rand(g, N, K1, scale=K1 ** -0.5), _rand(g, N)
+    keep = (torch.rand(M, N, generator=g) > 0.5).to(torch.uint8)
+    prior = _rand(g, M, N)
+    ref = x1.double() @ w1.double().t() + b.double() + prior.double()
+    segs = [(x1.to(dev()), w1.to(dev()))]
+    if K2:
+        x2, w2 = _rand(g, M, K2), _rand(g, N, K2, scale=K2 ** -0.5)
+        ref = ref + x2.double() @ w2.double().t()
+        segs.append((x2.to(dev()), w2.to(dev())))
+    ref_pre = torch.relu(ref)
+    ref_out = ref_pre * keep.double() * 2.0
+    db, dkeep = b.to(dev()), keep.to(dev())
+    ops.set_h3_mode(2)
+    res = {}
+    try:
+        for on in (1, 0):
+            _set_ksplit(on)
+            out = prior.clone().to(dev())
+            pre = torch.full((M, N), float('nan'), device=dev())
+            ops.linear_fwd([ops.linear_problem(segs, out, db, relu=True, keep_mask=dkeep, mask_scale=2.0, out_pre=pre,
+                                               accumulate=True)])
+            torch.cuda.synchronize()
+            np.testing.assert_allclose(out.cpu().numpy(), ref_out.float().numpy(), atol=3e-5, rtol=1e-5)
+            np.testing.assert_allclose(pre.cpu().numpy(), ref_pre.float().numpy(), atol=3e-5, rtol=1e-5)
+            res[on] = (pre.clone(), _err(pre, ref_pre))
+    finally:
+        _set_ksplit(1)
+    assert res[1][1][1] <= res[0][1][1] * 1.05 + 1e-9, (res[1][1], res[0][1])
+    np.testing.assert_allclose(res[1][0].cpu().numpy(), res[0][0].cpu().numpy(), atol=8e-6, rtol=2e-6)   # fp32 summation order
+    assert ops.device_status() == 0
+
+
+def test_nn_backward_contraction_over_the_vocabulary_in_k_slices():
+    """dX = dY W with K = 9984 vocabulary rows and 4160 = 20 x (128 + 80) time-stacked rows (the classifier's input
+    gradient of a merged training iteration): K slices on the large tile vs the one-slice launch vs fp64."""
+    g = torch.Generator().manual_seed(77)
+    M, N, K = 4160, 512, 9984
+    dy, w = _rand(g, M, K, scale=1e-2), _rand(g, K, N, scale=K ** -0.5)
+    ref = dy.double() @ w.double()
+    ddy, dw = dy.to(dev()), w.to(dev())
+    ops.set_h3_mode(2)
+    outs = {}
+    try:
+        for on in (1, 0):
+            _set_ksplit(on)
+            out = torch.empty(M, N, device=dev())
+            ops.gemm_bwd([ops.gemm_problem([(ddy, dw)], out, ops.NN)], ops.NN)
+            torch.cuda.synchronize()
+            outs[on] = out
+            np.testing.assert_allclose(out.cpu().numpy(), ref.float().numpy(), atol=2e-6, rtol=1e-5)
+    finally:
+        _set_ksplit(1)
+    np.testing.assert_allclose(outs[1].cpu().numpy(), outs[0].cpu().numpy(), atol=5e-7, rtol=2e-6)

@@ -17,6 +17,14 @@ V, TN, B, S = 64, 8, 8, 4
 ST = dict(synth.TINY_SETTINGS, **synth.HELPER_SETTINGS)
 
 
+@pytest.fixture(autouse=True, params=['two_branches', 'merged_chain'])
+def unroll_form(request, monkeypatch):
+    """Graph-served and eager iterations are compared in the SAME form of the XE / seq2seq unrolls: one chain per unroll
+    (the default inside graphs) and the merged step chain (autograd_pair; the default of eager steps)."""
+    monkeypatch.setenv('ISC_PAIR_UNROLLS', '1' if request.param == 'merged_chain' else '0')
+    return request.param
+
+
 def make(dropout=0.0, graphs=True, warmup=2):
     st = dict(ST, dropout_p=dropout)
     det = Detector(synth.make_idx2word(V), TN, synth.SENTIMENT_CATEGORIES, {'cap_lr': 4e-4}, st)

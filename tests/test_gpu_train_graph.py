@@ -17,6 +17,15 @@ TINY = dict(V=64, st=synth.TINY_SETTINGS, R=6, T=8, B=8, S=4)
 FULL = dict(V=10000, st=synth.DEFAULT_SETTINGS, R=36, T=20, B=128, S=80)
 
 
+@pytest.fixture(autouse=True, params=['two_branches', 'merged_chain'])
+def unroll_form(request, monkeypatch):
+    """Every test of this file compares graph-served iterations with the eager step of the SAME form of the two unrolls:
+    one chain per unroll (the default inside graphs) and the merged step chain (autograd_pair; the default of eager
+    steps) - forced for both sides through ISC_PAIR_UNROLLS (autograd_pair.use_pair)."""
+    monkeypatch.setenv('ISC_PAIR_UNROLLS', '1' if request.param == 'merged_chain' else '0')
+    return request.param
+
+
 def make(cfg, seed=9):
     cap = Captioner(synth.make_idx2word(cfg['V']), synth.SENTIMENT_CATEGORIES, cfg['st'])
     cap.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_weights(cfg['V'], cfg['st'], seed=seed).items()})

@@ -23,3 +23,17 @@ for r in seg:
     k = (r[qkey], name(r)[:60]); per[k][0] += 1; per[k][1] += int(r['End_Timestamp']) - int(r['Start_Timestamp'])
 for (q, k), (c, t) in sorted(per.items(), key=lambda kv: -kv[1][1])[:34]:
     print(q, k.ljust(60), '%6.1f' % (c / n), '%7.0f us/iter' % (t / n / 1e3), '%6.1f' % (t / c / 1e3))
+
+# the last iteration launch by launch: offset from its first launch, duration, gap to the previous end, grid, kernel
+if len(sys.argv) > 2:
+    it = rows[adam[-2] + 1: adam[-1] + 1]
+    t_first = int(it[0]['Start_Timestamp'])
+    prev_end = t_first
+    with open(sys.argv[2], 'w') as fo:
+        for i, r in enumerate(it):
+            st, en = int(r['Start_Timestamp']), int(r['End_Timestamp'])
+            grid = r.get('Grid_Size', r.get('Grid_Size_X', '?'))
+            wg = r.get('Workgroup_Size', r.get('Workgroup_Size_X', '?'))
+            fo.write('%4d %9.1f %8.1f %7.1f %9s %5s %s\n' % (i, (st - t_first) / 1e3, (en - st) / 1e3, (st - prev_end) / 1e3,
+                                                          grid, wg, name(r)[:70]))
+            prev_end = max(prev_end, en)
