@@ -518,10 +518,11 @@ int isc_set_rows_scan_max(int rows);
  * n > 1 = on, taken up to n workgroups (tuning).  Returns the previous value. */
 int isc_set_h3v(int on);
 /* Long contractions on few large split-f16 tiles (one linear problem of < ~200 128 x 128 tiles and >= 64 k-blocks - the
- * classifier's dX over all T x B rows of a training iteration, the prologue's region embedding at B = 128): 1 (default) =
- * the k-blocks are cut into up to 8 slices per tile so that the launch fills the chip, partial tiles go to slabs in the
- * caller's workspace and the split-K reduce kernel sums them in fixed order and applies the epilogue (deterministic);
- * 0 = one slice (tests, A/B runs).  Returns the previous value. */
+ * classifier's dX over all T x B rows of a training iteration): the k-blocks are cut into up to 8 slices per tile so that
+ * the launch fills the chip, partial tiles go to slabs in the caller's workspace and the split-K reduce kernel sums them
+ * in fixed order and applies the epilogue (deterministic).  1 (default) = for isc_gemm_bwd's NN launches (dX = dY W),
+ * 2 = for forward launches as well (tests: a forward launch otherwise keeps one summation order at every batch size),
+ * 0 = never.  Returns the previous value. */
 int isc_set_h3_ksplit(int on);
 
 /* Top-k + candidate merge of one beam step in ONE launch (captioner.py:390-411), from the tile statistics and tile

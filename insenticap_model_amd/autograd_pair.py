@@ -222,7 +222,12 @@ def _pair_forward(cap, xe, s2s):
 # ------------------------------------------------------------------------------ backward
 def _pair_backward(cap, S, d1, d2, sparse1, sparse2, d_fc_feats1, d_cpt_feats1, d_cpt_feats2):
     """{param name: gradient} of both unrolls.  d1 / d2: dense d log-prob of the two outputs (None when the criteria
-    handed theirs over sparse: sparse1 / sparse2 = [(ids, coef)]); optional gradients of the attribute tensors."""
+    handed theirs over sparse: sparse1 / sparse2 = [(ids, coef)]); optional gradients of the attribute tensors.
+
+    With a gradient sink on the captioner (`cap._grad_sink`, dp.GradSink: the data-parallel step) every gradient is
+    written straight into its view of the flat arena, the parameters are finished bucket by bucket - classifier (before
+    the sweep), lang-LSTM + attention, att-LSTM + projections, embeddings + fc - and each bucket's all-reduce starts as
+    soon as its last contraction is enqueued; the returned dictionary is then empty.  Same kernels, same values."""
     p, P1, P2 = S.p, S.P1, S.P2
     B1, B2, T1, T2 = S.B1, S.B2, S.T1, S.T2
     Bt, T = B1 + B2, max(T1, T2)
@@ -234,21 +239,38 @@ def _pair_backward(cap, S, d1, d2, sparse1, sparse2, d_fc_feats1, d_cpt_feats1, 
     stack = zeros if ragged else new
     G = {}
     TB = T * Bt
+    sink = getattr(cap, '_grad_sink', None)
+    if (P1.label_e is None) != (P2.label_e is None):
+        raise ValueError('merged unrolls: sentiment labels for both calls or for neither')
 
     def nn(segs, out, acc=False):
         return ops.gemm_problem(segs, out, NN, accumulate=acc)
 
-    def tn(a, w):
-        out = new(a.shape[1], w.shape[1])
+    def gout(name, *shape):
+        """The tensor parameter `name`'s gradient is computed into: its arena view under a sink, else a new tensor."""
+        t = sink.out(name) if sink is not None else new(*p[name].shape)
+        if sink is None:
+            G[name] = t                 # (parameter-shaped: autograd checks the shape of what the node returns)
+        n = 1
+        for d in shape:
+            n *= d
+        assert t.numel() == n, (name, tuple(t.shape), shape)
+        return t.view(*shape)
+
+    def tn(a, w, name):
+        out = gout(name, a.shape[1], w.shape[1])
         ops.gemm_bwd([ops.gemm_problem([(a, w)], out, TN)], TN)
         return out
 
-    pending_sums = []
+    pending_sums = []      # bias gradients of the bucket in progress: one isc_colsum_multi per bucket
 
-    def csum(x, copies=1):
-        outs = [new(x.shape[1]) for _ in range(copies)]
-        pending_sums.append((x, outs, False))
-        return outs[0] if copies == 1 else outs
+    def csum(x, *names):
+        """Column sum of x into the gradient(s) `names` (several: tied biases share one reduction), deferred."""
+        pending_sums.append((x, [gout(n, x.shape[1]) for n in names], False))
+
+    def zero_grad_of(name):
+        if sink is None:
+            G[name] = zeros(1)          # (under a sink the arena was zeroed before the backward)
 
     # ---- gradient scale (autograd._backward): one power of two for everything that enters the sweep
     gs = None
@@ -267,6 +289,14 @@ def _pair_backward(cap, S, d1, d2, sparse1, sparse2, d_fc_feats1, d_cpt_feats1, 
         d_cpt_feats1 = d_cpt_feats1 * gs[0] if d_cpt_feats1 is not None else None
         d_cpt_feats2 = d_cpt_feats2 * gs[0] if d_cpt_feats2 is not None else None
     scale = gs[0:1] if gs is not None else None
+
+    def bucket_done(b):
+        """Every gradient of bucket b (dp.GradSink.STARTS) is enqueued: its bias sums go out, then - under a sink - the
+        bucket is unscaled in one launch and its all-reduce starts."""
+        ops.colsum_multi(pending_sums)
+        del pending_sums[:]
+        if sink is not None:
+            sink.ready(b, unscale=gs[1] if gs is not None else None)
 
     # ---- classifier + log-softmax over all T*Bt rows (time-major)
     Vp = _pad32(V)
@@ -294,16 +324,19 @@ def _pair_backward(cap, S, d1, d2, sparse1, sparse2, d_fc_feats1, d_cpt_feats1, 
         with _weights_scope(cap):
             ops.gemm_bwd([nn([(dlogits, Wc)], dhd)], NN)
     if V % 4 == 0:
-        dWc = new(V, H)
+        dWc = gout('classifier.weight', V, H)
         ops.gemm_bwd([ops.gemm_problem([(dlogits[:, :V], hdrop_tb)], dWc, TN)], TN)
     else:
         dWp = new(Vp, H)
         ops.gemm_bwd([ops.gemm_problem([(dlogits, hdrop_tb)], dWp, TN)], TN)
-        dWc = dWp[:V].contiguous()
-    G['classifier.weight'] = dWc
-    db = new(Vp)
-    ops.colsum(dlogits, db)
-    G['classifier.bias'] = db[:V].contiguous() if Vp != V else db
+        gout('classifier.weight', V, H).copy_(dWp[:V])
+    if Vp != V:
+        db = new(Vp)
+        ops.colsum(dlogits, db)
+        gout('classifier.bias', V).copy_(db[:V])
+    else:
+        ops.colsum(dlogits, gout('classifier.bias', V))
+    bucket_done(3)                      # classifier: its exchange runs behind the whole reverse sweep
     if S.hdrop is not None:
         ops.relu_mask_bwd(dhd, None, dhd, keep_mask=S.out_masks.view(TB, H), scale=S.out_scale)
 
@@ -379,40 +412,76 @@ def _pair_backward(cap, S, d1, d2, sparse1, sparse2, d_fc_feats1, d_cpt_feats1, 
                 bp.dqw, bp.de_s = F.at(dqw, t, B1, A), de_s.data_ptr() + 4 * t * B2 * Mw
             ops.step_bwd(bp)
 
-    ops.attn_dv_from_alpha(S.aC, d_feat_all[:T1, :B1], dV_att, step_rows=Bt)
-    ops.attn_dp_from_de(P1.att_p3, S.qa, p['attention.cont_att.att_alpha.weight'], de_c, dP_att)
-    ops.attn_dv_from_alpha(S.aS, d_feat_all[:T2, B1:], dV_w, step_rows=Bt)
-    ops.attn_dp_from_de(P2.words_p3, S.qw, p['attention.senti_att.word_alpha.weight'], de_s, dP_w, q2=P2.label_w)
-
-    # ---- weight gradients: one contraction over all T*Bt rows each
     dG1f, dG2f = dG1.view(TB, 4 * H), dG2.view(TB, 4 * H)
     h1_prev, h1_cur = S.h1[:T].reshape(TB, H), S.h1[1:].reshape(TB, H)
     h2_prev = S.h2[:T].reshape(TB, H)
     feat_tb = S.feat.view(TB, E)
-    if (P1.label_e is None) != (P2.label_e is None):
-        raise ValueError('merged unrolls: sentiment labels for both calls or for neither')
+    dqaf, dqwf = dqa.view(TB, A), dqw.view(TB, A)
+    emb = p['word_embed.0.weight']
+
+    # ---- bucket 2: lang-LSTM and the attention's own parameters - one contraction over all T*Bt rows each
+    gW2 = gout('lang_lstm.weight_ih', 4 * H, E + H)
+    ops.gemm_bwd([ops.gemm_problem([(dG2f, feat_tb)], gW2[:, 0:E], TN),
+                  ops.gemm_problem([(dG2f, h1_cur)], gW2[:, E:], TN),
+                  ops.gemm_problem([(dG2f, h2_prev)], gout('lang_lstm.weight_hh', 4 * H, H), TN)], TN)
+    csum(dG2f, 'lang_lstm.bias_ih', 'lang_lstm.bias_hh')
+    tn(dqaf, h1_cur, 'attention.cont_att.h2att.weight')
+    csum(dqaf, 'attention.cont_att.h2att.bias')
+    csum(dwc_rows, 'attention.cont_att.att_alpha.weight')
+    zero_grad_of('attention.cont_att.att_alpha.bias')          # softmax is shift invariant
+    tn(dqwf, h1_cur, 'attention.senti_att.h2word.weight')
+    csum(dqwf, 'attention.senti_att.h2word.bias')
+    csum(dws_rows, 'attention.senti_att.word_alpha.weight')
+    zero_grad_of('attention.senti_att.word_alpha.bias')
+    d_label_w = None
+    if P2.label_w is not None:          # label2word(label_e) enters every step's score: d label_w = sum_t dqw[t]
+        d_label_w_all = new(Bt * A)
+        ops.colsum(dqw.view(T, Bt * A), d_label_w_all)
+        d_label_w = d_label_w_all.view(Bt, A)[B1:]
+        tn(d_label_w, P2.label_e, 'attention.senti_att.label2word.weight')
+        csum(d_label_w, 'attention.senti_att.label2word.bias')
+    bucket_done(2)
+
+    # ---- bucket 1: att-LSTM, region embedding + projection (XE branch), sentiment-word projection (seq2seq branch)
     pad = [_const_zeros(cap, Bp - Bt, E)] if Bp > Bt else []
     fc_e_all = torch.cat([P1.fc_e, P2.fc_e] + pad)
     label_e_all = None
     if P1.label_e is not None:
         label_e_all = torch.cat([P1.label_e, P2.label_e] + ([_const_zeros(cap, Bp - Bt, Wd)] if Bp > Bt else []))
-    gW1 = new(4 * H, H + E + Wd)
+    gW1 = gout('att_lstm.weight_ih', 4 * H, H + E + Wd)
     wx_segs = [(dG1f, S.xt.view(TB, Wd))]
     if label_e_all is not None:
         wx_segs.append((dG1_sum_p, label_e_all))
     ops.gemm_bwd([ops.gemm_problem([(dG1f, h2_prev)], gW1[:, 0:H], TN),
                   ops.gemm_problem([(dG1_sum_p, fc_e_all)], gW1[:, H:H + E], TN),
                   ops.gemm_problem(wx_segs, gW1[:, H + E:], TN)], TN)
-    G['att_lstm.weight_ih'] = gW1
-    gW2, gwhh1 = new(4 * H, E + H), new(4 * H, H)
-    ops.gemm_bwd([ops.gemm_problem([(dG1f, h1_prev)], gwhh1, TN),
-                  ops.gemm_problem([(dG2f, feat_tb)], gW2[:, 0:E], TN),
-                  ops.gemm_problem([(dG2f, h1_cur)], gW2[:, E:], TN)], TN)
-    G['att_lstm.weight_hh'] = gwhh1
-    G['lang_lstm.weight_ih'] = gW2
-    G['lang_lstm.weight_hh'] = tn(dG2f, h2_prev)
-    G['att_lstm.bias_ih'], G['att_lstm.bias_hh'] = csum(dG1f, 2)
-    G['lang_lstm.bias_ih'], G['lang_lstm.bias_hh'] = csum(dG2f, 2)
+    tn(dG1f, h1_prev, 'att_lstm.weight_hh')
+    csum(dG1f, 'att_lstm.bias_ih', 'att_lstm.bias_hh')
+    ops.attn_dv_from_alpha(S.aC, d_feat_all[:T1, :B1], dV_att, step_rows=Bt)
+    ops.attn_dp_from_de(P1.att_p3, S.qa, p['attention.cont_att.att_alpha.weight'], de_c, dP_att)
+    ops.attn_dv_from_alpha(S.aS, d_feat_all[:T2, B1:], dV_w, step_rows=Bt)
+    ops.attn_dp_from_de(P2.words_p3, S.qw, p['attention.senti_att.word_alpha.weight'], de_s, dP_w, q2=P2.label_w)
+    BR = B1 * R
+    att_e, att_p = P1.att_e3.view(BR, E), P1.att_p3.view(BR, A)
+    dzp = new(BR, A)
+    ops.relu_mask_bwd(dP_att.view(BR, A), att_p, dzp)
+    tn(dzp, att_e, 'att2att.0.weight')
+    csum(dzp, 'att2att.0.bias')
+    dVa = dV_att.view(BR, E)
+    ops.gemm_bwd([nn([(dzp, p['att2att.0.weight'])], dVa, True)], NN)
+    dze = new(BR, E)
+    ops.relu_mask_bwd(dVa, att_e, dze, keep_mask=P1.m_att, scale=P1.sc)
+    tn(dze, P1.x_att, 'att_embed.0.weight')
+    csum(dze, 'att_embed.0.bias')
+    BM = B2 * Mw
+    w_e, w_p = P2.words_e3.view(BM, Wd), P2.words_p3.view(BM, A)
+    dzw = new(BM, A)
+    ops.relu_mask_bwd(dP_w.view(BM, A), w_p, dzw)
+    tn(dzw, w_e, 'senti2att.0.weight')
+    csum(dzw, 'senti2att.0.bias')
+    bucket_done(1)
+
+    # ---- bucket 0: the word / label embeddings, fc_embed, cpt2fc
     d_fc_e = new(Bt, E)
     d_label_e = new(Bt, Wd) if label_e_all is not None else None
     dxt = new(TB, Wd)
@@ -421,55 +490,19 @@ def _pair_backward(cap, S, d1, d2, sparse1, sparse2, d_fc_feats1, d_cpt_feats1, 
         probs.append(nn([(dG1_sum, Wih1[:, H + E:])], d_label_e))
     with _weights_scope(cap):
         ops.gemm_bwd(probs, NN)
-    emb = p['word_embed.0.weight']
-    dEmb = zeros(V, Wd)
+    dEmb = gout('word_embed.0.weight', V, Wd)
+    if sink is None:
+        dEmb.zero_()
     ops.embed_relu_bwd(emb, S.tok.view(-1), dxt, dEmb, TB, skip_id=cap.pad_id)
-
-    zero1 = lambda: zeros(1)                                          # noqa: E731
-    dqaf, dqwf = dqa.view(TB, A), dqw.view(TB, A)
-    G['attention.cont_att.h2att.weight'] = tn(dqaf, h1_cur)
-    G['attention.cont_att.h2att.bias'] = csum(dqaf)
-    G['attention.cont_att.att_alpha.weight'] = csum(dwc_rows).view(1, A)
-    G['attention.cont_att.att_alpha.bias'] = zero1()
-    G['attention.senti_att.h2word.weight'] = tn(dqwf, h1_cur)
-    G['attention.senti_att.h2word.bias'] = csum(dqwf)
-    G['attention.senti_att.word_alpha.weight'] = csum(dws_rows).view(1, A)
-    G['attention.senti_att.word_alpha.bias'] = zero1()
-    if P2.label_w is not None:
-        d_label_w_all = new(Bt * A)
-        ops.colsum(dqw.view(T, Bt * A), d_label_w_all)
-        d_label_w = d_label_w_all.view(Bt, A)[B1:]
-        G['attention.senti_att.label2word.weight'] = tn(d_label_w, P2.label_e)
-        G['attention.senti_att.label2word.bias'] = csum(d_label_w)
+    if d_label_w is not None:
         ops.gemm_bwd([nn([(d_label_w, p['attention.senti_att.label2word.weight'])], d_label_e[B1:], True)], NN)
-
-    # ---- prologue backward
     if d_label_e is not None:
-        dL = zeros(p['senti_label_embed.0.weight'].shape[0], Wd)
+        dL = gout('senti_label_embed.0.weight', p['senti_label_embed.0.weight'].shape[0], Wd)
+        if sink is None:
+            dL.zero_()
         for P, lo, hi in ((P1, 0, B1), (P2, B1, Bt)):
             ops.embed_relu_bwd(p['senti_label_embed.0.weight'], P.label_ids, d_label_e[lo:hi], dL, hi - lo,
                                keep_mask=P.m_label, mask_scale=P.sc)
-        G['senti_label_embed.0.weight'] = dL
-    # XE branch: regions
-    BR = B1 * R
-    att_e, att_p = P1.att_e3.view(BR, E), P1.att_p3.view(BR, A)
-    dzp = new(BR, A)
-    ops.relu_mask_bwd(dP_att.view(BR, A), att_p, dzp)
-    G['att2att.0.weight'] = tn(dzp, att_e)
-    G['att2att.0.bias'] = csum(dzp)
-    dVa = dV_att.view(BR, E)
-    ops.gemm_bwd([nn([(dzp, p['att2att.0.weight'])], dVa, True)], NN)
-    dze = new(BR, E)
-    ops.relu_mask_bwd(dVa, att_e, dze, keep_mask=P1.m_att, scale=P1.sc)
-    G['att_embed.0.weight'] = tn(dze, P1.x_att)
-    G['att_embed.0.bias'] = csum(dze)
-    # seq2seq branch: sentiment words
-    BM = B2 * Mw
-    w_e, w_p = P2.words_e3.view(BM, Wd), P2.words_p3.view(BM, A)
-    dzw = new(BM, A)
-    ops.relu_mask_bwd(dP_w.view(BM, A), w_p, dzw)
-    G['senti2att.0.weight'] = tn(dzw, w_e)
-    G['senti2att.0.bias'] = csum(dzw)
     dVw = dV_w.view(BM, Wd)
     ops.gemm_bwd([nn([(dzw, p['senti2att.0.weight'])], dVw, True)], NN)
     ops.embed_relu_bwd(emb, P2.sw_ids, dVw, dEmb, BM, pad_first=Mw, pad_id=cap.pad_id,
@@ -481,8 +514,8 @@ def _pair_backward(cap, S, d1, d2, sparse1, sparse2, d_fc_feats1, d_cpt_feats1, 
         extra = new(B1, E)
         ops.relu_mask_bwd(d_fc_feats1.contiguous(), cap_pre(P1, 'fc'), extra)
         dzf = dzf + extra
-    G['fc_embed.0.weight'] = tn(dzf, P1.x_fc)
-    G['fc_embed.0.bias'] = csum(dzf)
+    tn(dzf, P1.x_fc, 'fc_embed.0.weight')
+    csum(dzf, 'fc_embed.0.bias')
     d_cpt = zeros(Bt, E) if d_cpt_feats1 is None else new(Bt, E)
     if d_cpt_feats1 is not None:
         ops.relu_mask_bwd(d_cpt_feats1.contiguous(), P1.cpt, d_cpt[:B1])
@@ -492,8 +525,8 @@ def _pair_backward(cap, S, d1, d2, sparse1, sparse2, d_fc_feats1, d_cpt_feats1, 
         ops.relu_mask_bwd(d_cpt_feats2.contiguous(), cap_pre(P2, 'cpt'), extra)
         d_cpt[B1:] += extra
     cmean_all = torch.cat([P1.cmean, P2.cmean])
-    G['cpt2fc.0.weight'] = tn(d_cpt, cmean_all)
-    G['cpt2fc.0.bias'] = csum(d_cpt)
+    tn(d_cpt, cmean_all, 'cpt2fc.0.weight')
+    csum(d_cpt, 'cpt2fc.0.bias')
     dcm = new(Bt, Wd)
     ops.gemm_bwd([nn([(d_cpt, p['cpt2fc.0.weight'])], dcm)], NN)
     C = P1.cpt_ids.shape[1]
@@ -502,9 +535,8 @@ def _pair_backward(cap, S, d1, d2, sparse1, sparse2, d_fc_feats1, d_cpt_feats1, 
     cpt_ids = torch.cat([P1.cpt_ids, P2.cpt_ids]).view(-1)
     ops.embed_relu_bwd(emb, cpt_ids, dcm, dEmb, Bt * C, rows_per_grad=C, scale=1.0 / C, skip_id=cap.pad_id)
     dEmb[cap.pad_id].zero_()
-    G['word_embed.0.weight'] = dEmb
-    ops.colsum_multi(pending_sums)
-    if gs is not None:
+    bucket_done(0)
+    if sink is None and gs is not None:
         torch._foreach_mul_(list(G.values()), gs[1])
     return G
 

@@ -3339,7 +3339,7 @@ static int try_gemv(DevLaunch &L, hipStream_t st, int &rc) {
 #define H3_MIN_TILES_SCOPE 16
 // (tests / A-B runs: 0 keeps long contractions on few large tiles in one slice of K)
 static std::atomic<int> g_h3_ksplit{1};
-extern "C" int isc_set_h3_ksplit(int on) { return g_h3_ksplit.exchange(on ? 1 : 0); }
+extern "C" int isc_set_h3_ksplit(int on) { return g_h3_ksplit.exchange(on < 0 ? 0 : (on > 2 ? 2 : on)); }
 static int launch_splitk_linear_reduce(const DevLaunch &L, hipStream_t st);
 
 static bool h3_any_f32(const DevLaunch &L) {
@@ -3669,7 +3669,9 @@ static int try_h3(DevLaunch &L, float *ws, long long ws_floats, hipStream_t st, 
         // a long contraction on few 128 x 128 tiles (one problem, linear epilogue): S slices of K so that the launch fills
         // the chip's 512 workgroup slots, raw partial tiles to slabs behind the planes in the workspace, then the reduce
         int S = 1;
-        if (EPI == EPI_LINEAR && L.nprob == 1 && (L.p[0].N & 3) == 0 && g_h3_ksplit.load()) {
+        // (backward dX contractions only - `transposed` - unless forced: a forward launch keeps ONE summation order at every
+        // batch size, so that a ReLU's sign at a pre-activation of ~0 does not depend on how many rows share the launch)
+        if (EPI == EPI_LINEAR && L.nprob == 1 && (L.p[0].N & 3) == 0 && (g_h3_ksplit.load() == 2 || (transposed && g_h3_ksplit.load()))) {
             DevProb &p = L.p[0];
             const long long t256 = (long long)((p.M + 255) / 256) * ((p.N + 127) / 128);
             const int nblk = p.Kp / 32;

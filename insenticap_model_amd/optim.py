@@ -63,6 +63,40 @@ class FusedClampAdam(torch.optim.Adam):
             ops.refresh_weight_planes(epoch_before)
         return loss
 
+    @torch.no_grad()
+    def step_params(self, params, clip, first=True, last=True):
+        """clamp + Adam on a SUBSET of the parameters (one launch): the bucketed data-parallel step (dp.GradSink.finish)
+        updates each bucket as its all-reduce lands.  `first` / `last` bracket one optimizer step: the weight planes of
+        the suspended scopes are refreshed once, after the last subset."""
+        if first:
+            self._epoch_before = ops.WEIGHT_EPOCH
+        group = self.param_groups[0]
+        ps, gs, ms, vs, step_no = [], [], [], [], None
+        for q in params:
+            if q.grad is None:
+                continue
+            ops.require_device(q)
+            st = self.state[q]
+            if len(st) == 0:
+                st['step'] = torch.tensor(0.0, dtype=torch.float32)
+                st['exp_avg'] = torch.zeros_like(q, memory_format=torch.preserve_format)
+                st['exp_avg_sq'] = torch.zeros_like(q, memory_format=torch.preserve_format)
+            st['step'] += 1
+            n = int(st['step'])
+            if step_no is None:
+                step_no = n
+            elif n != step_no:
+                self._launch([q], [q.grad], [st['exp_avg']], [st['exp_avg_sq']], group, clip, n)
+                continue
+            ps.append(q)
+            gs.append(q.grad)
+            ms.append(st['exp_avg'])
+            vs.append(st['exp_avg_sq'])
+        if ps:
+            self._launch(ps, gs, ms, vs, group, clip, step_no)
+        if last and ops.WEIGHT_EPOCH != self._epoch_before and self.refresh_weight_planes:
+            ops.refresh_weight_planes(self._epoch_before)
+
     def _launch(self, ps, gs, ms, vs, group, clip, step_no):
         b1, b2 = group['betas']
         ops.clamp_adam(ps, gs, ms, vs, group['lr'], b1, b2, group['eps'], group['weight_decay'], clip, step_no,

@@ -8,7 +8,7 @@ frozen helper outside this path: the caller passes its arg-max as `xe_senti_labe
 import torch
 
 from . import dp
-from .optim import clip_gradient
+from .optim import FusedClampAdam, clip_gradient
 
 
 _SIDE_STREAMS = {}
@@ -49,7 +49,7 @@ def _xe_loss(xe_crit, pred, target, lengths):
 
 
 def xe_forward_backward(captioner, optim, xe_crit, da_crit, fact, xe_senti_labels, scs=None, ss_prob=0.0, arena=None,
-                        weights3=None, overlap_unrolls=True, side_stream=None, pair=None):
+                        weights3=None, overlap_unrolls=True, side_stream=None, pair=None, sink=None):
     """train_xe.py:160-190 on device tensors: both unrolls, the three losses, backward.  `fact` = (fc, att, caps,
     lengths, cpts), `scs` = (caps, lengths, cpts, sentis, labels) or None; `weights3` = this rank's shares of the three
     global normalisers (XE tokens, seq2seq tokens, rows) as a device tensor, or None (single process: graph
@@ -95,7 +95,17 @@ def xe_forward_backward(captioner, optim, xe_crit, da_crit, fact, xe_senti_label
         arena.zero_()
     else:
         optim.zero_grad()
-    total.backward()
+    if sink is not None and pair:
+        # data-parallel, merged unrolls: the backward writes every gradient into its arena view and starts each bucket's
+        # all-reduce as soon as the bucket is complete (dp.GradSink; autograd_pair._pair_backward)
+        sink.begin()
+        captioner._grad_sink = sink
+        try:
+            total.backward()
+        finally:
+            captioner._grad_sink = None
+    else:
+        total.backward()
     return torch.stack([xe_bwd.detach(), da_bwd.detach(), s2s_d])
 
 
@@ -121,14 +131,17 @@ def dp_shares(lengths, s_lengths, rows, device, group):
 
 
 def xe_train_step(captioner, optim, xe_crit, da_crit, fact_batch, xe_senti_labels, scs_batch=None,
-                  ss_prob=0.0, grad_clip=0.1, arena=None, group=None, device=None, overlap_unrolls=True):
+                  ss_prob=0.0, grad_clip=0.1, arena=None, group=None, device=None, overlap_unrolls=True, bucketed=True):
     """One iteration. Returns dict(xe_loss, da_loss, cap_loss, seq2seq_loss, all_loss) of 0-dim
     tensors (global values under DP).  `arena`: dp.GradArena when gradients are all-reduced.
     `overlap_unrolls`: the seq2seq unroll (80 text-only rows) runs on a side HIP stream.  It shares nothing
     with the XE unroll but the weights, and at these batch sizes both are chains of small launches that leave
     most of the chip idle; autograd replays each unroll's backward on the stream its forward ran on, so the
     two backward sweeps overlap as well.  Same numbers either way (two-operand gradient sums commute).
-    (train_graph.XETrainGraph runs the same three phases from HIP graphs.)"""
+    (train_graph.XETrainGraph runs the same three phases from HIP graphs.)
+    `bucketed` (with an arena and the merged unrolls): the gradient exchange goes out in four buckets from inside the
+    backward pass, overlapped with its dW contractions, and clamp + Adam run per bucket behind each reduction
+    (dp.GradSink); False = one flat all-reduce after the backward.  Same parameters after the step, bit for bit."""
     device = torch.device(device) if device is not None else next(captioner.parameters()).device
     _, fc_feats, att_feats, (caps_tensor, lengths), cpts_tensor = fact_batch[:5]
     fact = (fc_feats.to(device), att_feats.to(device), caps_tensor.to(device), lengths, cpts_tensor.to(device))
@@ -142,8 +155,20 @@ def xe_train_step(captioner, optim, xe_crit, da_crit, fact_batch, xe_senti_label
     dist_on = dp.distributed(group)
     weights3 = dp_shares(lengths, scs[1] if scs is not None else None, fact[0].shape[0], device, group) \
         if dist_on else None
+    from .autograd_pair import use_pair
+    sink = None
+    if (arena is not None and bucketed and scs is not None and device.type == 'cuda' and use_pair(captioner, False)
+            and isinstance(optim, FusedClampAdam)):
+        sink = captioner.__dict__.get('_dp_sink')
+        if sink is None or sink.arena is not arena or sink.group is not group:
+            sink = captioner.__dict__['_dp_sink'] = dp.GradSink(captioner, arena, group)
     vec = xe_forward_backward(captioner, optim, xe_crit, da_crit, fact, xe_senti_labels, scs, ss_prob, arena, weights3,
-                              overlap_unrolls)
+                              overlap_unrolls, sink=sink)
+    if sink is not None and sink.order:
+        if dist_on:                      # (issued before the waits: it queues behind the buckets on the backend's stream)
+            vec = dp.all_reduce_(vec, group)
+        sink.finish(optim, grad_clip)    # per bucket: wait for its reduction, clamp + Adam
+        return loss_dict(vec)
     if arena is not None:
         arena.all_reduce(group)          # one 88 MB sum over xGMI; clamp must see reduced grads
     if dist_on:                          # report global losses (sum of the pre-scaled locals): one 3-float all-reduce

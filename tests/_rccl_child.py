@@ -63,6 +63,9 @@ def main():
         m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_weights(V, st, seed=9).items()})
         m.to('cuda:0').eval()
         return m, dp.GradArena(m.parameters())
+    # (graphs run one chain per unroll, eager steps the merged chain - autograd_pair.use_pair: the twin takes the
+    # graph's form, and the flat exchange the graph object issues between its two graphs)
+    os.environ['ISC_PAIR_UNROLLS'] = '0'
     ref, ref_arena = twin()
     ro, rx, rd = ref.get_optim_criterion(4e-4)
     for _ in range(5):

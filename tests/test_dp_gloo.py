@@ -55,7 +55,7 @@ def _worker(rank, world, port, results):
         model.w.add_(torch.randn_like(model.w))
     dp.broadcast_parameters(model, src=0)              # ... until the broadcast
     arena = dp.GradArena(model.parameters())
-    assert arena.flat.numel() == 7 * 5 + 5 + 3
+    assert arena.flat.numel() == 3 * dp.GradArena.ALIGN and arena.offsets == [0, 64, 128]    # (256-byte aligned views)
     x, y, mask = _data()
     lo, hi = dp.shard(12, rank, world)
     arena.zero_()

@@ -445,7 +445,7 @@ def test_linear_long_k_on_few_large_tiles_is_cut_into_k_slices(M, N, K1, K2):
     res = {}
     try:
         for on in (1, 0):
-            _set_ksplit(on)
+            _set_ksplit(2 * on)              # (2: forward launches too - by default only backward dX launches are cut)
             out = prior.clone().to(dev())
             pre = torch.full((M, N), float('nan'), device=dev())
             ops.linear_fwd([ops.linear_problem(segs, out, db, relu=True, keep_mask=dkeep, mask_scale=2.0, out_pre=pre,
