@@ -79,6 +79,7 @@ def parse():
 
 
 import contextlib
+import functools
 
 
 @contextlib.contextmanager
@@ -93,8 +94,8 @@ def no_gc():
         gc.enable()
 
 
-def device_inputs(B, seed, dev):
-    d = synth.make_inputs(B, V, synth.DEFAULT_SETTINGS, regions=R, seq_len=T, seed=seed)
+def device_inputs(B, seed, dev, regions=R):
+    d = synth.make_inputs(B, V, synth.DEFAULT_SETTINGS, regions=regions, seq_len=T, seed=seed)
     keys = ('fc_feats', 'att_feats', 'cpt_words', 'senti_words', 'senti_labels')
     return [torch.from_numpy(d[k]).to(dev) for k in keys], d
 
@@ -160,40 +161,80 @@ def timed_region(fn, iters, dev):
     return el
 
 
+def run_jobs(jobs, extra):
+    """Side measurements: a failure is reported under the job's key, never fatal - EXCEPT FatalUnderGroup (not an
+    Exception on purpose), which must end this rank's process: its peers are inside collectives of the same job."""
+    for key, fn in jobs:
+        progress('extra: ' + key)
+        try:
+            extra[key] = fn()
+        except Exception as e:  # noqa: BLE001
+            extra[key] = {'error': repr(e)[:300]}
+
+
 def progress(msg):
     """A line on stderr per leg of the run (rank 0): a long default run shows where it is (and where it died)."""
     if int(os.environ.get('RANK', '0')) == 0:
         print('[bench %6.1f s] %s' % (time.perf_counter() - _T0, msg), file=sys.stderr, flush=True)
 
 
-def bench_xe_train(cap, dev, rank, world, iters=6, B=128, s2s_rows=80, curve='weak'):
+class FatalUnderGroup(BaseException):
+    """A failure that must END this rank's process under a process group (the other ranks are inside collectives or graph
+    replays: carrying on would desynchronise them).  Deliberately not an Exception: the side-measurement loop catches
+    Exception only, so this propagates to the top of the process, which exits non-zero; the launcher tears the group
+    down and the parent relays the failure."""
+
+
+def bench_xe_train(cap, dev, rank, world, iters=6, B=128, s2s_rows=80, curve='weak', ss_prob=0.0, regions=R):
     """BASELINE.json configs[1]/[3]: XE forward+backward+clamp+Adam on B captions per GPU plus `s2s_rows` rows of the
-    seq2seq batch (train_xe.py:132-134 uses 80), train-mode dropout; under a process group the step takes its
-    data-parallel form (normaliser all-reduce, 88 MB gradient-arena all-reduce before the clamp, loss all-reduce:
-    train_xe.py:189-192 with the exchange between :190 and :191).  `curve`: 'weak' = B fixed per GPU, 'strong' = the
-    caller divided a fixed global batch by the rank count."""
+    seq2seq batch (train_xe.py:132-134 uses 80), train-mode dropout, scheduled sampling `ss_prob` (train_xe.py:209-212:
+    0 for the first epochs, then 0.05 ... 0.25); under a process group the step takes its data-parallel form (normaliser
+    all-reduce, the gradient exchange before the clamp, loss all-reduce: train_xe.py:189-192 with the exchange between
+    :190 and :191).  `curve`: 'weak' = B fixed per GPU, 'strong' = the caller divided a fixed global batch by the rank
+    count.  Two forms are timed: the eager step (merged unrolls; under a group: four gradient buckets reduced from inside
+    the backward, dp.GradSink) and the step from HIP graphs (train_graph.XETrainGraph; under a group: one flat all-reduce
+    between its two graphs); `ms_per_iter` is the faster one."""
     from insenticap_model_amd import dp
     from insenticap_model_amd.train import xe_train_step
     cap.train()
     optim, xe_crit, da_crit = cap.get_optim_criterion(4e-4)
     arena = dp.GradArena(cap.parameters()) if dist_on() else None
-    d = synth.make_inputs(B, V, synth.DEFAULT_SETTINGS, regions=R, seq_len=T, seed=500 + rank)
-    s = synth.make_inputs(s2s_rows, V, synth.DEFAULT_SETTINGS, regions=R, seq_len=T, seed=600 + rank)
+    d = synth.make_inputs(B, V, synth.DEFAULT_SETTINGS, regions=regions, seq_len=T, seed=500 + rank)
+    s = synth.make_inputs(s2s_rows, V, synth.DEFAULT_SETTINGS, regions=regions, seq_len=T, seed=600 + rank)
     tt = lambda x: torch.from_numpy(x).to(dev)
     fact = (None, tt(d['fc_feats']), tt(d['att_feats']), (tt(d['captions']), d['lengths']), tt(d['cpt_words']))
     labels = tt(d['senti_labels'])
     scs = ((tt(s['captions']), s['lengths']), tt(s['cpt_words']), tt(s['senti_words']), tt(s['senti_labels']))
     from insenticap_model_amd.train_graph import XETrainGraph
-    step = lambda: xe_train_step(cap, optim, xe_crit, da_crit, fact, labels, scs, 0.0, 0.1, arena=arena)
+    step = lambda **kw: xe_train_step(cap, optim, xe_crit, da_crit, fact, labels, scs, ss_prob, 0.1, arena=arena, **kw)
     graph = XETrainGraph(cap, optim, xe_crit, da_crit, grad_clip=0.1, arena=arena, warmup=2)
-    gstep = lambda: graph.step(fact, labels, scs, 0.0)
+    gstep = lambda: graph.step(fact, labels, scs, ss_prob)
     graph_error = None
+    exposed = None
     with no_gc():
         c0 = dp.COLLECTIVES
         for _ in range(2):
             step()
         per_iter = (dp.COLLECTIVES - c0) // 2
         el_eager = timed_region(step, iters, dev)
+        if dist_on():
+            # what the exchange costs on top of the compute it hides behind: the same step with the collectives of the
+            # gradient buckets skipped (dp.GradSink.exchange = False: single-rank arithmetic, same launches otherwise),
+            # and the flat form (one all-reduce of the whole arena after the backward)
+            sink = cap.__dict__.get('_dp_sink')
+            if sink is not None:
+                sink.exchange = False
+                try:
+                    step()
+                    el_dry = timed_region(step, iters, dev)
+                finally:
+                    sink.exchange = True
+                step(bucketed=False)
+                el_flat = timed_region(lambda: step(bucketed=False), iters, dev)
+                exposed = dict(bucketed_ms=round((el_eager - el_dry) / iters * 1e3, 3),
+                               flat_ms=round((el_flat - el_dry) / iters * 1e3, 3),
+                               no_exchange_ms_per_iter=round(el_dry / iters * 1e3, 2),
+                               flat_ms_per_iter=round(el_flat / iters * 1e3, 2))
         try:
             for _ in range(4):          # two eager steps on the graph's own streams, the capture, two replays
                 gstep()
@@ -203,23 +244,32 @@ def bench_xe_train(cap, dev, rank, world, iters=6, B=128, s2s_rows=80, curve='we
         except Exception as e:          # noqa: BLE001 - the eager figure above stands on its own
             if dist_on():
                 # under a process group a failed capture is not recoverable in place (the other ranks are inside a
-                # collective or a replay; a backend watchdog abort is not even an exception): this rank exits non-zero,
-                # the launcher tears the group down and the parent relays the failure - never an eager line that
-                # pretends to be the N-rank measurement, never a re-exec of this GPU-initialised process
+                # collective or a replay; a backend watchdog abort is not even an exception): this rank's process ends
+                # non-zero (FatalUnderGroup is not an Exception: the side-measurement loop cannot swallow it), the
+                # launcher tears the group down and the parent relays the failure - never an eager line that pretends
+                # to be the N-rank measurement, never a re-exec of this GPU-initialised process
                 sys.stderr.write('bench.py: graph capture failed under the process group: %r\n' % (e,))
-                raise
+                raise FatalUnderGroup(repr(e)[:300])
             graph_error, el, replayed = repr(e)[:300], el_eager, 0
     cap.eval()
     for q in cap.parameters():          # the arena's views must not outlive this measurement
         q.grad = None
+    cap.__dict__.pop('_dp_sink', None)
+    best = min(el, el_eager)
     out = dict(curve=curve, iters=iters, batch_per_gpu=B, global_batch=world * B, seq2seq_rows_per_gpu=s2s_rows,
-               ms_per_iter=round(el / iters * 1e3, 2), captions_per_s=round(world * B * iters / el, 1),
-               served_from='HIP graphs (train_graph.XETrainGraph: forward+backward and clamp+Adam replayed, '
-                           'collectives between them); %d of %d timed iterations were replays' % (replayed, iters),
-               eager_ms_per_iter=round(el_eager / iters * 1e3, 2),
+               ss_prob=ss_prob, regions=regions,
+               ms_per_iter=round(best / iters * 1e3, 2), captions_per_s=round(world * B * iters / best, 1),
+               served_from=('eager step, merged unrolls (autograd_pair)' + ('; gradient exchange in 4 buckets from inside '
+                            'the backward (dp.GradSink)' if dist_on() else '')) if el_eager <= el else
+                           ('HIP graphs (train_graph.XETrainGraph: forward+backward and clamp+Adam replayed, '
+                            'collectives between them); %d of %d timed iterations were replays' % (replayed, iters)),
+               eager_ms_per_iter=round(el_eager / iters * 1e3, 2), graph_ms_per_iter=round(el / iters * 1e3, 2),
                grad_allreduce_mb=round(arena.nbytes / 1e6, 2) if arena else 0.0, all_reduces_per_iter=per_iter)
+    if exposed is not None:
+        out['exposed_allreduce_ms'] = exposed['bucketed_ms']
+        out['exchange'] = exposed
     if graph_error is not None:
-        out.update(served_from='eager (graph capture failed)', graph_error=graph_error)
+        out.update(graph_error=graph_error)
     return out
 
 
@@ -320,7 +370,7 @@ def bench_table_build(cap, inputs):
     return dict(ms=round(el * 1e3, 2), gflop=round(2.0 * V * 512 * (2048 + 512) / 1e9, 1))
 
 
-def bench_scan_sweep(dev, batches=(128, 512, 1024, 2048, 4096)):
+def bench_scan_sweep(dev, batches=(128, 512, 1024, 2048, 4096), R=R):
     """the attention scan's algorithmic GB/s at the config batch sizes as well as where its rows
     (B x 192 512 B for content + sentiment) exceed the 256 MB last-level cache.  Isolated kernel, HIP events."""
     out = {}
@@ -342,8 +392,40 @@ def bench_scan_sweep(dev, batches=(128, 512, 1024, 2048, 4096)):
         e1.record()
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) / reps * 1e3
-        out[str(B)] = dict(us=round(us, 1), gb_per_s=round(B * 192512.0 / us / 1e3, 1),
-                           row_bytes_mb=round(B * 192512.0 / 1e6, 1))
+        row_bytes = (2 * R + 2 * 11) * 512 * 4.0          # 2 R E 4 content + 2 M W 4 sentiment bytes per caption
+        out[str(B)] = dict(us=round(us, 1), gb_per_s=round(B * row_bytes / us / 1e3, 1),
+                           frac_of_8tbs=round(B * row_bytes / us / 1e3 / 8000.0, 3),
+                           row_bytes_mb=round(B * row_bytes / 1e6, 1))
+    return out
+
+
+def bench_r196(cap, dev):
+    """The reference encoder's own feature geometry: 14 x 14 = 196 regions per image (models/encoder.py:53; BASELINE.json
+    quotes the 36-region bottom-up features).  Greedy decode at B = 4096, the attention scan alone (algorithmic bytes
+    2 R E 4 + 2 M W 4 = 847 872 B per caption and step), an XE training iteration at B = 128 + 80, beam-5 one image."""
+    out = {}
+    Rg = 196
+    with torch.no_grad(), no_gc():
+        inputs, _ = device_inputs(4096, 900, dev, regions=Rg)
+        for _ in range(2):
+            cap(*inputs, T, 1, mode='rl')
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            cap(*inputs, T, 1, mode='rl')
+        torch.cuda.synchronize()
+        el = (time.perf_counter() - t0) / 3
+        out['greedy_B4096'] = dict(ms_per_rollout=round(el * 1e3, 2), captions_per_s=round(4096 / el, 1))
+        beam_in = [x[:16] for x in inputs]
+        del inputs
+    out['scan'] = bench_scan_sweep(dev, batches=(128, 1024, 4096), R=Rg)
+    try:
+        b = bench_beam(cap, beam_in, n_img=16, beam=5)
+        out['beam5'] = {k: b[k] for k in ('per_image_p50_ms', 'per_step_p50_us', 'full_search_p50_ms')}
+    except Exception as e:  # noqa: BLE001
+        out['beam5'] = {'error': repr(e)[:200]}
+    x = bench_xe_train(cap, dev, 0, 1, iters=4, B=128, regions=Rg)
+    out['xe_train_B128'] = {k: x[k] for k in ('ms_per_iter', 'eager_ms_per_iter', 'graph_ms_per_iter', 'served_from')}
     return out
 
 
@@ -745,19 +827,17 @@ def run(args):
         if 1024 % world == 0 and 80 % world == 0:
             jobs.append(('xe_train_strong', lambda: bench_xe_train(cap, dev, rank, world, iters=4, B=1024 // world,
                                                                    s2s_rows=80 // world, curve='strong')))
+        # the regime the reference trains in from epoch 5 on: scheduled sampling (train_xe.py:209-212, opts.py:35-38)
+        jobs.append(('xe_train_ss025', lambda: bench_xe_train(cap, dev, rank, world, iters=4, ss_prob=0.25)))
         if world == 1:
             jobs.append(('xe_train_by_batch', lambda: {str(b): bench_xe_train(cap, dev, rank, world, iters=3, B=b)[
                 'ms_per_iter'] for b in (512,)}))
+            jobs.append(('r196', lambda: bench_r196(cap, dev)))
         if dist_on():
             jobs.append(('grad_allreduce', lambda: bench_grad_allreduce(cap, dev, world)))
             if 512 % world == 0 and 80 % world == 0:
                 jobs.append(('rl_iteration', lambda: bench_rl(dev, rank=rank, world=world)))
-        for key, fn in jobs:
-            progress('extra: ' + key)
-            try:
-                extra[key] = fn()
-            except Exception as e:  # noqa: BLE001
-                extra[key] = {'error': repr(e)[:300]}
+        run_jobs(jobs, extra)
     if rank != 0:
         torch.distributed.destroy_process_group()
         return None
@@ -788,6 +868,11 @@ def run(args):
         e['per_rollout_ms_events'] = e['per_rollout_ms']
         e['per_rollout_ms'] = round(e['per_rollout_ms'] * scale, 3)
     entries.sort(key=lambda e: -e['per_rollout_ms'])
+    # `roofline` is ALWAYS the attention scan (north_star names it; HBM-bound) and `roofline_mfma` the classifier (the one
+    # contraction north_star puts on MFMA): the two tie at ~10 ms per roll-out, so "largest share" flipped from box to box
+    scan = next((e for e in entries if e['kernel'].startswith('attn_scan')), None)
+    mfma = next((e for e in entries if e['kernel'].startswith('vocab[')), None)
+    rest = [e for e in entries if e is not scan and e is not mfma]
     out = {
         'metric': 'captions/sec (greedy, 36-region feats, len-20)',
         'value': round(total / el, 1), 'unit': 'captions/s',
@@ -807,12 +892,30 @@ def run(args):
                    'collective_backend': torch.distributed.get_backend() if dist_on() else None,
                    'gemm_engine': {1: 'split-f16 x3 MFMA for large forward GEMMs (fp32 in/out/accumulate), fp32 MFMA elsewhere',
                                    0: 'fp32 MFMA only (--h3-mode 0)', 2: 'split-f16 forced'}[args.h3_mode]},
-        'roofline': entries[0] if entries else None,
-        'roofline_kernels': entries[1:],
+        'roofline': scan if scan is not None else (entries[0] if entries else None),
+        'roofline_mfma': mfma,
+        'roofline_kernels': rest if scan is not None else entries[1:],
         'extra': extra,
     }
     if not args.no_cpu_baseline and world == 1:
         out['cpu_baseline'] = cpu_baseline(weights, args.cpu_seconds)
+    # LAST key: the driver's record keeps the tail of this line - the other half of BASELINE's metric (beam-5 p50) and
+    # the training figures in one compact object
+    g = lambda *ks: functools.reduce(lambda d, k: d.get(k) if isinstance(d, dict) else None, ks, extra)
+    out['summary'] = {
+        'greedy_captions_per_s': out['value'], 'scan_frac_of_hbm': (scan or {}).get('frac'),
+        'classifier_frac_of_mfma': (mfma or {}).get('frac'),
+        'beam5_p50_ms': g('beam5', 'per_image_p50_ms'), 'beam5_us_per_step': g('beam5', 'per_step_p50_us'),
+        'beam5_full20_p50_ms': g('beam5', 'full_search_p50_ms'),
+        'exact_fp32_captions_per_s': g('exact_fp32_engine', 'captions_per_s'),
+        'xe128_ms': g('xe_train', 'ms_per_iter'), 'xe128_ss025_ms': g('xe_train_ss025', 'ms_per_iter'),
+        'xe512_ms': g('xe_train_by_batch', '512'), 'xe1024_ms': g('xe_train_strong', 'ms_per_iter'),
+        'exposed_allreduce_ms': g('xe_train', 'exposed_allreduce_ms'),
+        'rl512_ms': g('rl_iteration', 'ms_per_iter'),
+        'r196_greedy_captions_per_s': g('r196', 'greedy_B4096', 'captions_per_s'),
+        'r196_scan_frac_of_hbm': g('r196', 'scan', '4096', 'frac_of_8tbs'),
+        'r196_xe128_ms': g('r196', 'xe_train_B128', 'ms_per_iter'), 'r196_beam5_p50_ms': g('r196', 'beam5', 'per_image_p50_ms'),
+    }
     if world > 1 or under_launcher:
         torch.distributed.destroy_process_group()
     return json.dumps(out)

@@ -80,3 +80,42 @@ def test_launcher_parent_never_imports_the_product_or_touches_hip():
     launch = src[src.index('def launch_ranks'):src.index('def main():')]
     assert 'torch.distributed.run' in launch and 'os.exec' not in src and 'is_available()' not in launch
     assert 'device_count()' not in launch                       # (the count comes from count_gpus: sysfs, or a child)
+
+
+def test_a_rank_fatal_failure_is_not_swallowed_by_the_side_measurement_loop():
+    """Round-4 advisor finding: `bench_xe_train` raised an Exception when a graph capture failed under a process group,
+    and the jobs loop turned it into extra['xe_train'] = {'error': ...} and moved on to the next job's collectives while
+    the other ranks were still inside this job's.  The failure is a BaseException now (bench.FatalUnderGroup): ordinary
+    job failures are still reported under their key, this one leaves the loop - and, in a rank process, the interpreter
+    with a non-zero code."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('bench_mod2', BENCH)
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert not issubclass(bench.FatalUnderGroup, Exception)
+    extra, ran = {}, []
+
+    def ok():
+        ran.append('ok')
+        return 1
+
+    def soft():
+        raise RuntimeError('a side measurement failed')
+
+    def fatal():
+        raise bench.FatalUnderGroup('capture failed under the group')
+
+    def never():
+        ran.append('never')
+    try:
+        bench.run_jobs([('a', ok), ('b', soft), ('c', fatal), ('d', never)], extra)
+    except bench.FatalUnderGroup:
+        pass
+    else:
+        raise AssertionError('FatalUnderGroup was swallowed')
+    assert extra['a'] == 1 and 'error' in extra['b'] and 'c' not in extra and 'd' not in extra and ran == ['ok']
+    # ... and as a process: an uncaught BaseException ends the interpreter non-zero
+    code = ("import importlib.util as u; s = u.spec_from_file_location('b', %r); m = u.module_from_spec(s); "
+            "s.loader.exec_module(m); m.run_jobs([('c', lambda: (_ for _ in ()).throw(m.FatalUnderGroup('x')))], {})" % BENCH)
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and 'FatalUnderGroup' in r.stderr
