@@ -739,11 +739,15 @@ class _CallSpy:
         self.orig = (cap.forward_rl, cap.forward_xe, cap.forward_seq2seq)
         o_rl, o_xe, o_s2s = self.orig
 
+        self.greedy = []          # (seq, masks) of every greedy roll-out (sample_max = 1), as the reference returned them
+
         def spy_rl(*a, **k):
             n0 = len(self.ms.draws)
             r = o_rl(*a, **k)
             if not k.get('sample_max', a[-1] if len(a) >= 7 else 1):
                 self.rl.append((n0, len(self.ms.draws)))
+            else:
+                self.greedy.append((r[0].detach().numpy().copy(), r[2].detach().numpy().copy()))
             return r
 
         def spy_xe(*a, **k):
@@ -840,47 +844,58 @@ def case_det_senti():
 
 
 def case_det512_train():
-    """BASELINE.json configs[4] at full size, TRAINING: ONE iteration of Detector.forward(data, 'fact', True)
-    (models/decoder.py:52-180 incl. the update at :161-167) with B = 512, V = 10k, T = 20, a 6 x 6 x 2048 grid, an
-    80-caption seq2seq batch, dropout_p = 0, lr 4e-5 (opts.py:41-42).  Recorded for replay: the multinomial draws of
-    the sampled roll-out, the tokens the XE (ss_prob 0.5) and seq2seq (ss_prob 0.25) unrolls fed.  Stored: the 7-key
-    loss dictionary, a digest (sum, abs-sum, l2, 64 strided samples) of every clamped gradient and of every parameter
-    after the step."""
+    """BASELINE.json configs[4] at full size, TRAINING: TWO iterations of Detector.forward(data, 'fact', True)
+    (models/decoder.py:52-180 incl. the update at :161-167), one call per iteration, on two different fact batches with
+    B = 512, V = 10k, T = 20, a 6 x 6 x 2048 grid, an 80-caption seq2seq batch, dropout_p = 0, lr 4e-5 (opts.py:41-42).
+    Recorded for replay, per iteration: the multinomial draws of the sampled roll-out, the tokens the XE (ss_prob 0.5)
+    and seq2seq (ss_prob 0.25) unrolls fed, and the greedy baseline's token and mask matrices (so that a test can hand
+    the REINFORCE term the reference's own reward: a greedy near-tie flipped by fp32 reassociation changes CIDEr-D of
+    that row by up to its whole range).  Stored per iteration: the 7-key loss dictionary, a digest (sum, abs-sum, l2, 64
+    strided samples) of every clamped gradient and of every parameter after the step.  Keys of iteration 1 carry no
+    suffix (d5t/grad/..., d5t/after/...), those of iteration 2 the suffix 2 (d5t/grad2/..., d5t/after2/...)."""
     V, Tn, B, Bs = 10000, 20, 512, 80
     st = dict(synth.DEFAULT_SETTINGS, **synth.HELPER_SETTINGS)
     st['dropout_p'] = 0.0
     det = _ref_detector(V, Tn, st, 4e-5, 0)
+    # (iteration 1 = the batch of rounds 3-4: make_rl_batches(1, ..., seed=60) - its document frequencies come from ITS
+    # references alone, as before; iteration 2 = another batch of the same generator with its own references)
     batches, split = synth.make_rl_batches(1, B, V, st, grid=(6, 6), seq_len=Tn, seed=60)
-    det.set_ciderd_scorer(split)
-    b = batches[0]
-    item = (b[0], torch.from_numpy(b[1]), torch.from_numpy(b[2]), (torch.from_numpy(b[3][0]), b[3][1]),
-            torch.from_numpy(b[4]), torch.from_numpy(b[5]), b[6])
+    batches2, split2 = synth.make_rl_batches(1, B, V, st, grid=(6, 6), seq_len=Tn, seed=61)
     s = synth.make_inputs(Bs, V, st, regions=6, seq_len=Tn, seed=79)
     t = torch.from_numpy
     scs = [((t(s['captions']), s['lengths']), t(s['cpt_words']), t(s['senti_words']), t(s['senti_labels']))]
     cs = _CallSpy(det.captioner)
     torch.manual_seed(5150)
     import time
-    t0 = time.time()
-    losses = det(([item], scs), 'fact', True)
-    print('reference iteration: %.1f s' % (time.time() - t0))
-    cs.close()
-    assert len(cs.rl) == 1 and len(cs.xe) == 1 and len(cs.s2s) == 1
     out = {}
-    out['d5t/draws'], steps = cs.draws(0, Tn)
-    out['d5t/steps'] = np.array([steps])
-    out['d5t/fed_xe'] = cs.fed(cs.xe, 0)
-    out['d5t/fed_s2s'] = cs.fed(cs.s2s, 0)
-    assert set(losses) == {'da_loss', 'fact_reward', 'cls_reward', 'all_rewards', 'cap_loss', 'xe_loss', 'seq2seq_loss'}
-    for k, v in losses.items():
-        out['d5t/loss_' + k] = np.array([v], dtype=np.float64)
-    for k, q in det.captioner.named_parameters():
-        if q.grad is not None:
-            out['d5t/grad/' + k] = grad_digest(q.grad.detach().numpy())
-            out['d5t/gmax/' + k] = np.array([float(q.grad.detach().abs().max())])
-    for k, v in det.captioner.state_dict().items():
-        out['d5t/after/' + k] = grad_digest(v.detach().numpy())
-    print({k: round(v, 5) for k, v in losses.items()})
+    for it, (bb, sp) in enumerate(((batches, split), (batches2, split2))):
+        sfx = '' if it == 0 else '2'
+        det.set_ciderd_scorer(sp)
+        b = bb[0]
+        item = (b[0], torch.from_numpy(b[1]), torch.from_numpy(b[2]), (torch.from_numpy(b[3][0]), b[3][1]),
+                torch.from_numpy(b[4]), torch.from_numpy(b[5]), b[6])
+        t0 = time.time()
+        losses = det(([item], scs), 'fact', True)
+        print('reference iteration %d: %.1f s' % (it + 1, time.time() - t0))
+        assert len(cs.rl) == it + 1 and len(cs.xe) == it + 1 and len(cs.s2s) == it + 1 and len(cs.greedy) == it + 1
+        out['d5t/draws' + sfx], steps = cs.draws(it, Tn)
+        out['d5t/steps' + sfx] = np.array([steps])
+        out['d5t/fed_xe' + sfx] = cs.fed(cs.xe, it)
+        out['d5t/fed_s2s' + sfx] = cs.fed(cs.s2s, it)
+        gseq, gmk = cs.greedy[it]
+        out['d5t/greedy_seq' + sfx] = np.pad(gseq, ((0, 0), (0, Tn - gseq.shape[1]))).astype(np.int64)
+        out['d5t/greedy_masks' + sfx] = np.pad(gmk, ((0, 0), (0, Tn - gmk.shape[1]))).astype(np.float32)
+        assert set(losses) == {'da_loss', 'fact_reward', 'cls_reward', 'all_rewards', 'cap_loss', 'xe_loss', 'seq2seq_loss'}
+        for k, v in losses.items():
+            out['d5t/loss%s_%s' % (sfx, k)] = np.array([v], dtype=np.float64)
+        for k, q in det.captioner.named_parameters():
+            if q.grad is not None:
+                out['d5t/grad%s/%s' % (sfx, k)] = grad_digest(q.grad.detach().numpy())
+                out['d5t/gmax%s/%s' % (sfx, k)] = np.array([float(q.grad.detach().abs().max())])
+        for k, v in det.captioner.state_dict().items():
+            out['d5t/after%s/%s' % (sfx, k)] = grad_digest(v.detach().numpy())
+        print({k: round(v, 5) for k, v in losses.items()})
+    cs.close()
     np.savez_compressed(os.path.join(HERE, 'det512_train.npz'), **out)
     print('det512_train: %d arrays' % len(out))
 

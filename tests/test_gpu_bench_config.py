@@ -178,11 +178,18 @@ def test_detector_forward_b512_fullsize_vs_the_reference(golden):
 
 
 def test_config4_rl_training_iteration_at_full_size_vs_reference(golden):
-    """BASELINE config 4's TRAINING iteration at full size: ONE Detector.forward(data, 'fact', True) with B = 512,
-    V = 10k, T = 20, 6x6x2048 grid, an 80-caption seq2seq batch, dropout 0 (models/decoder.py:52-180 incl. the update at
-    :161-167) against the reference's own run (tests/golden/det512_train.npz: the sampled roll-out's multinomial draws
-    and the tokens the XE / seq2seq unrolls fed under scheduled sampling replayed): the 7-key dictionary, a digest of
-    every clamped gradient (sums, l2, 64 strided samples) and of every parameter after the step."""
+    """BASELINE config 4's TRAINING iteration at full size: TWO Detector.forward(data, 'fact', True) calls on two fact
+    batches with B = 512, V = 10k, T = 20, 6x6x2048 grid, an 80-caption seq2seq batch, dropout 0 (models/decoder.py:52-180
+    incl. the update at :161-167) against the reference's own run (tests/golden/det512_train.npz).  Replayed from the
+    reference: the sampled roll-out's multinomial draws, the tokens the XE / seq2seq unrolls fed under scheduled sampling
+    - and the greedy baseline's tokens and masks, so that the REINFORCE term carries the reference's own reward
+    (self_critical/utils.py:56-83: a greedy near-tie flipped by fp32 reassociation would change CIDEr-D of that row by
+    up to its range; the product's own greedy roll-out at this size is pinned, with counted flips, by
+    test_detector_forward_b512_fullsize_vs_the_reference above).  Checked per iteration at SURVEY 8(d)'s bar with no
+    allowance for flipped greedy rows: the 7-key dictionary of both iterations, all 40 clamped gradients of iteration 1
+    within 1e-4 of the tensor's largest gradient (64 strided samples + l2; iteration 2, which starts from each side's own
+    post-step weights: 1e-3), and after the SECOND step - whose Adam moments are no longer a pure sign test - every
+    parameter."""
     from insenticap_model_amd.detector import Detector
     from test_detector import load_helper
     g = golden('det512_train')
@@ -194,26 +201,27 @@ def test_config4_rl_training_iteration_at_full_size_vs_reference(golden):
     load_helper(det.senti_detector, 51)
     load_helper(det.sent_senti_cls, 52)
     det.to(dev())
-    batches, split = synth.make_rl_batches(1, B, V, st, grid=(6, 6), seq_len=Tn, seed=60)
-    det.set_ciderd_scorer(split)
-    b = batches[0]
     t = torch.from_numpy
-    item = (b[0], t(b[1]), t(b[2]), (t(b[3][0]), b[3][1]), t(b[4]), t(b[5]), b[6])
     s = synth.make_inputs(Bs, V, st, regions=6, seq_len=Tn, seed=79)
     scs = [((t(s['captions']), s['lengths']), t(s['cpt_words']), t(s['senti_words']), t(s['senti_labels']))]
     cap = det.captioner
-    o_rl, o_xe, o_s2s = cap.forward_rl, cap.forward_xe, cap.forward_seq2seq
-    n = {'rl': 0, 'xe': 0, 's2s': 0}
+    o_rl, o_xe, o_s2s, o_pair = cap.forward_rl, cap.forward_xe, cap.forward_seq2seq, cap.forward_xe_seq2seq
+    n = {'rl': 0, 'greedy': 0, 'xe': 0, 's2s': 0}
+    cur = {'sfx': ''}
 
     def fed_as_captions(key):
-        fed = torch.from_numpy(g[key]).to(dev())
+        fed = torch.from_numpy(g[key + cur['sfx']]).to(dev())
         return torch.cat([fed, fed[:, -1:]], dim=1)
 
     def replay_rl(*a, **k):
         if not k.get('sample_max', a[-1] if len(a) >= 7 else 1):
-            k['_replay'] = torch.from_numpy(g['d5t/draws']).to(dev())
+            k['_replay'] = torch.from_numpy(g['d5t/draws' + cur['sfx']]).to(dev())
             n['rl'] += 1
-        return o_rl(*a, **k)
+            return o_rl(*a, **k)
+        n['greedy'] += 1                      # the reference's greedy baseline, as it returned it
+        seq = torch.from_numpy(g['d5t/greedy_seq' + cur['sfx']]).to(dev())
+        mk = torch.from_numpy(g['d5t/greedy_masks' + cur['sfx']]).to(dev())
+        return seq, torch.zeros_like(mk), mk
 
     def replay_xe(fc, att, cpts, caps, labels, ss_prob=0.0, **k):
         assert ss_prob == 0.5
@@ -224,7 +232,6 @@ def test_config4_rl_training_iteration_at_full_size_vs_reference(golden):
         assert ss_prob == 0.25
         n['s2s'] += 1
         return o_s2s(fed_as_captions('d5t/fed_s2s'), cpts, sentis, labels, 0.0, **k)
-    o_pair = cap.forward_xe_seq2seq
 
     def replay_pair(fc, att, cpts, caps, labels, ss_prob, s_caps, s_cpts, s_sentis, s_labels, s_ss_prob=None, **k):
         # both unrolls through the merged step chain (Captioner.forward_xe_seq2seq): the same fed tokens
@@ -235,38 +242,50 @@ def test_config4_rl_training_iteration_at_full_size_vs_reference(golden):
                       s_cpts, s_sentis, s_labels, 0.0, **k)
     cap.forward_rl, cap.forward_xe, cap.forward_seq2seq = replay_rl, replay_xe, replay_s2s
     cap.forward_xe_seq2seq = replay_pair
-    losses = det(([item], scs), 'fact', True)
-    assert n == {'rl': 1, 'xe': 1, 's2s': 1}
-    assert set(losses) == {'da_loss', 'fact_reward', 'cls_reward', 'all_rewards', 'cap_loss', 'xe_loss', 'seq2seq_loss'}
-    # the greedy baseline may flip a near-tie in a few of the 512 rows: CIDEr-D's range over the batch mean per such row
-    for k in ('da_loss', 'xe_loss', 'seq2seq_loss'):
-        np.testing.assert_allclose(losses[k], g['d5t/loss_' + k][0], rtol=2e-4, atol=2e-6, err_msg=k)
-    slack = 3 * 10.0 / B
-    for k in ('cls_reward', 'fact_reward', 'all_rewards', 'cap_loss'):
-        np.testing.assert_allclose(losses[k], g['d5t/loss_' + k][0], rtol=2e-4, atol=2e-5 + slack, err_msg=k)
 
     def digest(x):
         flat = x.reshape(-1).astype(np.float64)
         idx = (np.arange(64, dtype=np.int64) * 2654435761 % flat.size)
         return np.concatenate([[flat.sum(), np.abs(flat).sum(), np.sqrt((flat ** 2).sum())], flat[idx]])
-    checked = 0
-    for k, q in cap.named_parameters():
-        key = 'd5t/grad/' + k
-        if key not in g.files:
-            continue
-        ref, gmax = g[key], float(g['d5t/gmax/' + k][0])
-        got = digest(q.grad.cpu().numpy())
-        # the REINFORCE term carries the reward: a flipped greedy row shifts its sample's gradient contribution, so the
-        # bound is the SURVEY 8(d) one (1e-4 of the tensor's largest gradient) plus that share
-        tol = (1e-4 + slack / 10.0) * gmax + 1e-8
-        np.testing.assert_allclose(got[3:], ref[3:], atol=tol, err_msg=k)                 # 64 samples
-        assert abs(got[2] - ref[2]) <= 2e-3 * ref[2] + 1e-8, (k, got[2], ref[2])          # l2 norm
-        checked += 1
-    assert checked >= 38
+    for it, seed in enumerate((60, 61)):
+        sfx = cur['sfx'] = '' if it == 0 else '2'
+        batches, split = synth.make_rl_batches(1, B, V, st, grid=(6, 6), seq_len=Tn, seed=seed)
+        det.set_ciderd_scorer(split)
+        b = batches[0]
+        item = (b[0], t(b[1]), t(b[2]), (t(b[3][0]), b[3][1]), t(b[4]), t(b[5]), b[6])
+        losses = det(([item], scs), 'fact', True)
+        assert n == {'rl': it + 1, 'greedy': it + 1, 'xe': it + 1, 's2s': it + 1}
+        assert set(losses) == {'da_loss', 'fact_reward', 'cls_reward', 'all_rewards', 'cap_loss', 'xe_loss', 'seq2seq_loss'}
+        for k in losses:                      # rewards are the reference's own: no slack for flipped greedy rows
+            np.testing.assert_allclose(losses[k], g['d5t/loss%s_%s' % (sfx, k)][0], rtol=2e-4, atol=2e-6, err_msg=k)
+        checked = 0
+        for k, q in cap.named_parameters():
+            key = 'd5t/grad%s/%s' % (sfx, k)
+            if key not in g.files:
+                continue
+            ref, gmax = g[key], float(g['d5t/gmax%s/%s' % (sfx, k)][0])
+            got = digest(q.grad.cpu().numpy())
+            # (+ 1e-8: the two alpha biases' true gradient is 0 - softmax is shift invariant - and the reference's autograd
+            # leaves rounding noise of ~3e-9 there.)
+            # Iteration 1 starts from the reference's exact weights: SURVEY 8(d)'s 1e-4, no allowance.  Iteration 2 starts
+            # from each side's OWN weights after step 1 - a first Adam step moves every element by +-lr whatever its
+            # gradient's size, so elements whose gradient is rounding noise differ by 2 lr = 8e-5 between the two sides
+            # (the post-step check below bounds how many) - and a ReLU pre-activation of ~0 in att2att / att_embed then
+            # flips for a few of the 18 432 x 512 region activations: 1e-3 there (measured worst element 9e-4).
+            tol = (1e-4 if it == 0 else 1e-3) * gmax + 1e-8
+            np.testing.assert_allclose(got[3:], ref[3:], atol=tol, err_msg='%s (iteration %d)' % (k, it + 1))
+            assert abs(got[2] - ref[2]) <= 1e-3 * ref[2] + 1e-7, (k, got[2], ref[2])          # l2 norm
+            checked += 1
+        assert checked == 40
+    # after the SECOND step: m / (sqrt(v) + eps) of two different gradients - an element steps by lr (4e-5) only where both
+    # gradients agree in sign, so the parameters are a finer pin than after a first step (always +-lr).  Elements whose
+    # gradient is ~0 on either iteration may still differ by a step; everything else to a small fraction of lr.
     for k, q in cap.state_dict().items():
-        ref = g['d5t/after/' + k]
+        ref = g['d5t/after2/' + k]
         got = digest(q.cpu().numpy())
-        assert np.abs(got[3:] - ref[3:]).max() <= 2 * 4e-5 * 1.01, k      # nothing further than a full Adam step (lr 4e-5)
-        gk = 'd5t/gmax/' + k
-        if gk in g.files and float(g[gk][0]) > 1e-6:                      # (the alpha biases' true gradient is 0: Adam steps on noise)
-            assert np.median(np.abs(got[3:] - ref[3:])) <= 2e-6, k
+        d = np.abs(got[3:] - ref[3:])
+        assert d.max() <= 2 * 2 * 4e-5 * 1.01, k
+        gk = 'd5t/gmax2/' + k
+        if gk in g.files and float(g[gk][0]) > 1e-6:          # (the alpha biases' true gradient is 0: Adam steps on noise)
+            assert np.median(d) <= 1e-6, (k, float(np.median(d)))
+            assert (d > 4e-6).mean() <= 0.1, (k, float((d > 4e-6).mean()))
