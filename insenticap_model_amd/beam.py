@@ -134,8 +134,8 @@ class _VectorMerge:
         return out
 
 
-def beam_search_batch(cap, fc_feats, att_feats, senti_words, senti_labels, beam, decoding_constraint, T):
-    if (cap.__dict__.get('_beam_graphs') is not None and getattr(cap, 'beam_device_merge', True) and beam <= 8
+def beam_search_batch(cap, fc_feats, att_feats, senti_words, senti_labels, beam, decoding_constraint, T, graphs=True):
+    if (graphs and cap.__dict__.get('_beam_graphs') is not None and getattr(cap, 'beam_device_merge', True) and beam <= 8
             and ops.TIMER.arm_step is None and ops.graphs_allowed_here()):
         return _graphed_search(cap, fc_feats, att_feats, senti_words, senti_labels, beam, decoding_constraint, T)
     return _search(cap, fc_feats, att_feats, senti_words, senti_labels, beam, decoding_constraint, T)

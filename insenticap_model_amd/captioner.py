@@ -336,7 +336,8 @@ class Captioner(nn.Module):
     def _senti_tables(self, p):
         """(relu(Emb) [V,W], relu(senti2att(relu(Emb))) [V,A]), cached until the embedding or senti2att change."""
         emb, W2, b2 = p['word_embed.0.weight'], p['senti2att.0.weight'], p['senti2att.0.bias']
-        key = (emb.data_ptr(), emb._version, W2.data_ptr(), W2._version, b2.data_ptr(), b2._version, ops.WEIGHT_EPOCH)
+        key = (emb.data_ptr(), emb._version, W2.data_ptr(), W2._version, b2.data_ptr(), b2._version, ops.WEIGHT_EPOCH,
+               ops.h3_mode() == 0)          # (a table built by one GEMM engine is not handed to a call on the other)
         cached = getattr(self, '_senti_tab_cache', None)
         if cached is not None and cached[0] == key:
             return cached[1]
@@ -352,7 +353,7 @@ class Captioner(nn.Module):
         """relu(Emb) attention.senti2att.weight^T [V,A]: the sentiment-word table carried through the gate's projection
         (isc_attn_scan_gate_fwd), cached until the embedding or that weight change."""
         emb, Wg = p['word_embed.0.weight'], p['attention.senti2att.weight']
-        key = (emb.data_ptr(), emb._version, Wg.data_ptr(), Wg._version, ops.WEIGHT_EPOCH)
+        key = (emb.data_ptr(), emb._version, Wg.data_ptr(), Wg._version, ops.WEIGHT_EPOCH, ops.h3_mode() == 0)
         cached = getattr(self, '_gate_tab_cache', None)
         if cached is not None and cached[0] == key:
             return cached[1]
@@ -365,7 +366,7 @@ class Captioner(nn.Module):
         """relu(Emb) W_x^T [V,4H], cached until the embedding or the att-LSTM weights change
         (tensor version counters). Only used without autograd; costs V*4H*W*2 flop (21 GFLOP) once."""
         emb, Wih = p['word_embed.0.weight'], p['att_lstm.weight_ih']
-        key = (emb.data_ptr(), emb._version, Wih.data_ptr(), Wih._version, ops.WEIGHT_EPOCH)
+        key = (emb.data_ptr(), emb._version, Wih.data_ptr(), Wih._version, ops.WEIGHT_EPOCH, ops.h3_mode() == 0)
         cached = getattr(self, '_tab_cache', None)
         if cached is not None and cached[0] == key:
             return cached[1]
@@ -726,7 +727,8 @@ class Captioner(nn.Module):
                                      max_seq_len, _replay, _masks)
         if (sample_max and self.__dict__.get('_rollout_graphs') is not None and not self._needs_grad()
                 and not self.training and _replay is None and _masks is None and ops.TIMER.arm_step is None
-                and fc_feats.shape[0] <= self.ROLLOUT_GRAPH_MAX_ROWS and ops.graphs_allowed_here()):
+                and fc_feats.shape[0] <= self.ROLLOUT_GRAPH_MAX_ROWS and ops.graphs_allowed_here()
+                and self._features_in_domain(fc_feats, att_feats)):     # (beyond the domain: eager, exact engine)
             return self._graphed_rollout(fc_feats, att_feats, cpt_words, senti_words, senti_labels, max_seq_len)
         return self._rollout(fc_feats, att_feats, cpt_words, senti_words, senti_labels, max_seq_len,
                              sample_max, _replay, _masks)[:3]
@@ -868,10 +870,61 @@ class Captioner(nn.Module):
     def _rollout(self, fc_feats, att_feats, cpt_words, senti_words, senti_labels, T, sample_max, replay,
                  masks):
         self._p()                                  # raises on CPU parameters before anything touches the device
+        if not self._features_in_domain(fc_feats, att_feats):
+            # features beyond the split-f16 domain: the reference decodes whatever its encoder produced
+            # (captioner.py:198-214, 294-315) - so does this call, on the exact-fp32 engine
+            with ops.exact_fp32_engine(), ops.h3_weights_scope(self._dev, key=self._weights_key()):
+                return self._rollout_impl(fc_feats, att_feats, cpt_words, senti_words, senti_labels, T, sample_max,
+                                          replay, masks)
         # frozen weights for prologue + loop: split them once per call - or, with unchanged weights, once per run of calls
         with ops.h3_weights_scope(self._dev, key=self._weights_key()):
             return self._rollout_impl(fc_feats, att_feats, cpt_words, senti_words, senti_labels, T, sample_max,
                                       replay, masks)
+
+    # ------------------------------------------------------------------ operand domain of the split-f16 engine
+    SPLIT_F16_MAX = 65504.0
+
+    def _features_in_domain(self, *feats):
+        """True when the caller's feature tensors may go through the split-f16 GEMM engine (every |x| < 65504, no NaN /
+        inf - those are decoded as they are by the exact engine too, as the reference does).  With `numerics_checks`
+        off, the engine off, inside a graph capture or while an owner does its own checking (`_domain_check_off`:
+        Detector.forward looks at the numerics flags at its own synchronisation point instead) no check.  One reduction
+        over the features and ONE host read per NEW feature tensor: the verdict is remembered per tensor OBJECT and
+        version (a loop over one batch pays once; a roll-out of 16384 captions reads 4.8 GB = 0.8 ms of its 37 ms)."""
+        if (not getattr(self, 'numerics_checks', True) or self.__dict__.get('_domain_check_off') or ops.h3_mode() == 0
+                or torch.cuda.is_current_stream_capturing()):
+            return True
+        feats = [x for x in feats if x is not None and torch.is_tensor(x) and x.is_floating_point()]
+        memo = self.__dict__.setdefault('_domain_memo', {})
+        verdict, fresh = True, []
+        for x in feats:
+            e = memo.get(id(x))
+            if e is not None and e[0]() is x and e[1] == x._version:
+                verdict = verdict and e[2]
+            else:
+                fresh.append(x)
+        if fresh:
+            worst = torch.stack([x.detach().abs().amax().float() for x in fresh]).amax()
+            v = float(worst)                 # (NaN compares False: NaN / inf inputs also take the exact engine)
+            ok = bool(v < self.SPLIT_F16_MAX)
+            for k in [k for k, e in memo.items() if e[0]() is None]:
+                del memo[k]
+            while len(memo) >= 16:
+                memo.pop(next(iter(memo)))
+            for x in fresh:
+                memo[id(x)] = (weakref.ref(x), x._version, ok)
+            verdict = verdict and ok
+            if not ok:
+                self._warn_out_of_domain('max |x| = %g' % v)
+        return verdict
+
+    def _warn_out_of_domain(self, what):
+        if not self.__dict__.get('_domain_warned'):
+            import warnings
+            self.__dict__['_domain_warned'] = True
+            warnings.warn('insenticap_model_amd: features beyond the split-f16 operand domain |x| < 65504 (%s): the call '
+                          'runs on the exact-fp32 GEMM engine (~2x slower; results as the reference\'s). Scale the '
+                          'features to keep the fast engine.' % what)
 
     def _rollout_impl(self, fc_feats, att_feats, cpt_words, senti_words, senti_labels, T, sample_max, replay,
                       masks):
@@ -994,6 +1047,13 @@ class Captioner(nn.Module):
         from .beam import beam_search_batch, replay_if_captured
         if self.training:
             self.eval()
+        if not self._features_in_domain(fc_feats, att_feats):
+            # features beyond the split-f16 domain: the reference's sample() decodes whatever the encoder produced
+            # (captioner.py:357-376) - this search runs eagerly on the exact-fp32 engine
+            self._p()
+            with ops.exact_fp32_engine(), ops.h3_weights_scope(self._dev, key=self._weights_key()):
+                return beam_search_batch(self, fc_feats, att_feats, senti_words, senti_labels, beam_size,
+                                         decoding_constraint, max_seq_len, graphs=False)
         out = replay_if_captured(self, fc_feats, att_feats, senti_words, senti_labels, beam_size, decoding_constraint,
                                  max_seq_len)
         if out is not None:

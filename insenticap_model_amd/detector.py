@@ -18,6 +18,7 @@ from .captioner import Captioner
 from .helper_nets import SentenceSentimentClassifier, SentimentDetector
 from .optim import clip_gradient
 from .train import run_on_side_stream
+from .ops import OutOfDomain
 from .rewards import RewardCriterion, get_ciderd_scorer, get_cls_reward, get_self_critical_reward
 
 
@@ -86,6 +87,16 @@ class Detector(nn.Module):
             raise Exception('data_type(%s) is wrong!' % data_type)
         cap = self.captioner
         cap.train(training)
+        # this call looks at the numerics flags at each iteration's own synchronisation point (below) instead of reducing
+        # the features in front of every roll-out (Captioner._features_in_domain: a host read per new tensor)
+        own_check, cap._domain_check_off = cap.__dict__.get('_domain_check_off'), True
+        try:
+            return self._forward(data, data_type, training)
+        finally:
+            cap._domain_check_off = own_check
+
+    def _forward(self, data, data_type, training):
+        cap = self.captioner
         # statistics stay on the device until the end of the call: every float(tensor) would stall the host
         # behind the whole queue (the reference reads them one by one, decoder.py:90-163)
         sums = defaultdict(float)
@@ -127,129 +138,148 @@ class Detector(nn.Module):
             if data_type == 'fact' or not training:      # labels from the image sentiment detector
                 senti_labels = self._image_sentiments(fns, att_feats)
 
-            if (training and data_type == 'fact' and self.train_graphs and device.type == 'cuda'
-                    and ops.TIMER.arm_step is None and ops.graphs_allowed_here()):
-                # the same iteration from HIP graphs (train_graph.RLTrainGraph): same calls in the same order
-                from .train_graph import RLTrainGraph
-                if self._rl_graph is None or self._rl_graph.arena is not self.dp_arena:
-                    self._rl_graph = RLTrainGraph(self)
-                with torch.no_grad():
-                    xe_senti_labels = self.sent_senti_cls(caps_tensor[:, 1:], lengths)[0]
-                    xe_senti_labels = xe_senti_labels.softmax(dim=-1).argmax(dim=-1).detach()
-                (s_caps, s_lengths), s_cpts, s_sentis, s_labels = s2s_batch
-                stats = self._rl_graph.step(
-                    (fns, fc_feats, att_feats, (caps_tensor, lengths), cpts_tensor, sentis_tensor, ground_truth),
-                    ((s_caps.to(device), s_lengths), s_cpts.to(device), s_sentis.to(device), s_labels.to(device)),
-                    senti_labels, xe_senti_labels)
-                for k, v in stats.items():
-                    add(k, v)
-                continue
+            def run_iteration(exact, put):
+                """One iteration (models/decoder.py:69-167).  `exact`: on the exact-fp32 GEMM engine, eagerly - the retry of
+                an iteration whose roll-outs left the split-f16 operand domain (OutOfDomain is raised at the iteration's
+                own synchronisation point, before anything is updated)."""
+                if (training and data_type == 'fact' and self.train_graphs and device.type == 'cuda'
+                        and ops.TIMER.arm_step is None and ops.graphs_allowed_here() and not exact):
+                    # the same iteration from HIP graphs (train_graph.RLTrainGraph): same calls in the same order
+                    from .train_graph import RLTrainGraph
+                    if self._rl_graph is None or self._rl_graph.arena is not self.dp_arena:
+                        self._rl_graph = RLTrainGraph(self)
+                    with torch.no_grad():
+                        xe_senti_labels = self.sent_senti_cls(caps_tensor[:, 1:], lengths)[0]
+                        xe_senti_labels = xe_senti_labels.softmax(dim=-1).argmax(dim=-1).detach()
+                    (s_caps, s_lengths), s_cpts, s_sentis, s_labels = s2s_batch
+                    stats = self._rl_graph.step(
+                        (fns, fc_feats, att_feats, (caps_tensor, lengths), cpts_tensor, sentis_tensor, ground_truth),
+                        ((s_caps.to(device), s_lengths), s_cpts.to(device), s_sentis.to(device), s_labels.to(device)),
+                        senti_labels, xe_senti_labels)
+                    for k, v in stats.items():
+                        put(k, v)
+                    return
 
-            # sampled roll-out (graph kept in train mode) and the domain-alignment loss on its prologue
-            sample_captions, sample_logprobs, seq_masks = cap(
-                fc_feats, att_feats, cpts_tensor, sentis_tensor, senti_labels, self.max_seq_len,
-                sample_max=0, mode='rl')
-            da_loss = self.cap_da_crit(cap.cpt_feats, cap.fc_feats.detach())
-            # DP: each term's share of the global normaliser (mask sum, XE tokens, seq2seq tokens, rows)
-            w_rl = w_xe = w_s2s = w_rows = None
-            share = (lambda x, w: x * w) if dist_on else (lambda x, w: x)      # single process: graph untouched
-            if dist_on:
-                n_local, n_global = dp.global_counts(
-                    [seq_masks.sum(), float(sum(lengths)) if data_type == 'fact' else 0.0,
-                     float(sum(s2s_batch[0][1])) if s2s_batch is not None else 0.0,
-                     float(fc_feats.shape[0])], device, self.dp_group)
-                w_rl, w_xe, w_s2s, w_rows = (n_local / n_global.clamp_min(1.0)).unbind(0)
-            da_loss = share(da_loss, w_rows)
-            add('da_loss', da_loss)
-
-            cap.eval()                                   # greedy baseline
-            with torch.no_grad():
-                greedy_captions, _, greedy_masks = cap(
+                # sampled roll-out (graph kept in train mode) and the domain-alignment loss on its prologue
+                sample_captions, sample_logprobs, seq_masks = cap(
                     fc_feats, att_feats, cpts_tensor, sentis_tensor, senti_labels, self.max_seq_len,
-                    sample_max=1, mode='rl')
-            cap.train(training)
+                    sample_max=0, mode='rl')
+                da_loss = self.cap_da_crit(cap.cpt_feats, cap.fc_feats.detach())
+                # DP: each term's share of the global normaliser (mask sum, XE tokens, seq2seq tokens, rows)
+                w_rl = w_xe = w_s2s = w_rows = None
+                share = (lambda x, w: x * w) if dist_on else (lambda x, w: x)      # single process: graph untouched
+                if dist_on:
+                    n_local, n_global = dp.global_counts(
+                        [seq_masks.sum(), float(sum(lengths)) if data_type == 'fact' else 0.0,
+                         float(sum(s2s_batch[0][1])) if s2s_batch is not None else 0.0,
+                         float(fc_feats.shape[0])], device, self.dp_group)
+                    w_rl, w_xe, w_s2s, w_rows = (n_local / n_global.clamp_min(1.0)).unbind(0)
+                da_loss = share(da_loss, w_rows)
+                put('da_loss', da_loss)
 
-            # The rewards need the token matrices on the host (CIDEr-D is host code).  Start their copies
-            # now, enqueue the XE / seq2seq forward passes, and only then wait: the host scores the captions
-            # while the device works through the two unrolls.  The order of the captioner calls - hence of
-            # every random draw - is the reference's; only host-side waiting moved.
-            host_sample = torch.empty(sample_captions.shape, dtype=sample_captions.dtype).pin_memory()
-            host_greedy = torch.empty(greedy_captions.shape, dtype=greedy_captions.dtype).pin_memory()
-            host_lens = torch.empty(seq_masks.shape[0], dtype=torch.int32).pin_memory()
-            host_sample.copy_(sample_captions, non_blocking=True)
-            host_greedy.copy_(greedy_captions, non_blocking=True)
-            host_lens.copy_(seq_masks.sum(dim=-1).type(torch.int32), non_blocking=True)
-            copied = torch.cuda.Event()
-            copied.record()
-
-            xe_loss = 0.0
-            seq2seq_loss = 0.0
-            from .autograd_pair import use_pair
-            merged = data_type == 'fact' and training and device.type == 'cuda' and use_pair(cap, False)
-            if merged:                                   # XE + seq2seq unrolls through one step chain (autograd_pair)
+                cap.eval()                                   # greedy baseline
                 with torch.no_grad():
-                    xe_senti_labels = self.sent_senti_cls(caps_tensor[:, 1:], lengths)[0]
-                    xe_senti_labels = xe_senti_labels.softmax(dim=-1).argmax(dim=-1).detach()
-                (s_caps, s_lengths), s_cpts, s_sentis, s_labels = s2s_batch
-                s_caps, s_cpts = s_caps.to(device), s_cpts.to(device)
-                s_sentis, s_labels = s_sentis.to(device), s_labels.to(device)
-                pred, pred2 = cap(fc_feats, att_feats, cpts_tensor, caps_tensor, xe_senti_labels, self.xe_ss_prob,
-                                  s_caps, s_cpts, s_sentis, s_labels, self.seq2seq_ss_prob, mode='xe_seq2seq')
-                xe_loss = share(self.cap_xe_crit(pred, caps_tensor[:, 1:], lengths), w_xe)
-                add('xe_loss', xe_loss)
-                seq2seq_loss = share(self.seq_flag * self.cap_xe_crit(pred2, s_caps[:, 1:], s_lengths), w_s2s)
-                add('seq2seq_loss', seq2seq_loss)
-            elif data_type == 'fact':                    # XE on the ground truth, labelled by the classifier
-                with torch.no_grad():
-                    xe_senti_labels = self.sent_senti_cls(caps_tensor[:, 1:], lengths)[0]
-                    xe_senti_labels = xe_senti_labels.softmax(dim=-1).argmax(dim=-1).detach()
-                pred = cap(fc_feats, att_feats, cpts_tensor, caps_tensor, xe_senti_labels, ss_prob=self.xe_ss_prob,
-                           mode='xe')
-                xe_loss = share(self.cap_xe_crit(pred, caps_tensor[:, 1:], lengths), w_xe)
-                add('xe_loss', xe_loss)
+                    greedy_captions, _, greedy_masks = cap(
+                        fc_feats, att_feats, cpts_tensor, sentis_tensor, senti_labels, self.max_seq_len,
+                        sample_max=1, mode='rl')
+                cap.train(training)
 
-            if training and not merged:
-                (s_caps, s_lengths), s_cpts, s_sentis, s_labels = s2s_batch
-                s_caps, s_cpts = s_caps.to(device), s_cpts.to(device)
-                s_sentis, s_labels = s_sentis.to(device), s_labels.to(device)
-                def seq2seq_unroll():                     # 80 text-only rows: a chain of small launches that
-                    pred = cap(s_caps, s_cpts, s_sentis, s_labels, ss_prob=self.seq2seq_ss_prob, mode='seq2seq')
-                    return share(self.seq_flag * self.cap_xe_crit(pred, s_caps[:, 1:], s_lengths), w_s2s)
-                # ... overlaps with the XE unroll queued above when it runs on the side stream (forward and,
-                # through autograd, backward); same numbers either way
-                seq2seq_loss = run_on_side_stream(device, seq2seq_unroll) if device.type == 'cuda' \
-                    else seq2seq_unroll()
-                add('seq2seq_loss', seq2seq_loss)
+                # The rewards need the token matrices on the host (CIDEr-D is host code).  Start their copies
+                # now, enqueue the XE / seq2seq forward passes, and only then wait: the host scores the captions
+                # while the device works through the two unrolls.  The order of the captioner calls - hence of
+                # every random draw - is the reference's; only host-side waiting moved.
+                host_sample = torch.empty(sample_captions.shape, dtype=sample_captions.dtype).pin_memory()
+                host_greedy = torch.empty(greedy_captions.shape, dtype=greedy_captions.dtype).pin_memory()
+                host_lens = torch.empty(seq_masks.shape[0], dtype=torch.int32).pin_memory()
+                host_sample.copy_(sample_captions, non_blocking=True)
+                host_greedy.copy_(greedy_captions, non_blocking=True)
+                host_lens.copy_(seq_masks.sum(dim=-1).type(torch.int32), non_blocking=True)
+                copied = torch.cuda.Event()
+                copied.record()
 
-            copied.synchronize()
-            cls_reward = get_cls_reward(sample_captions, seq_masks, greedy_captions, greedy_masks, senti_labels,
-                                        self.sent_senti_cls, sample_lens=host_lens.tolist(), on_device=True)
-            if data_type == 'fact':
-                fact_reward = get_self_critical_reward(
-                    host_sample.numpy(), host_greedy.numpy(), fns, ground_truth, cap.sos_id, cap.eos_id,
-                    self.ciderd_scorer)
-                fact_reward = ops.upload(fact_reward.astype('float32'), torch.float32, device)
-                add('fact_reward', share(fact_reward[:, 0].mean(), w_rows))
-            else:
-                fact_reward = 0
-            add('cls_reward', share(cls_reward.mean(-1).mean(-1), w_rows))
+                xe_loss = 0.0
+                seq2seq_loss = 0.0
+                from .autograd_pair import use_pair
+                merged = data_type == 'fact' and training and device.type == 'cuda' and use_pair(cap, False)
+                if merged:                                   # XE + seq2seq unrolls through one step chain (autograd_pair)
+                    with torch.no_grad():
+                        xe_senti_labels = self.sent_senti_cls(caps_tensor[:, 1:], lengths)[0]
+                        xe_senti_labels = xe_senti_labels.softmax(dim=-1).argmax(dim=-1).detach()
+                    (s_caps, s_lengths), s_cpts, s_sentis, s_labels = s2s_batch
+                    s_caps, s_cpts = s_caps.to(device), s_cpts.to(device)
+                    s_sentis, s_labels = s_sentis.to(device), s_labels.to(device)
+                    pred, pred2 = cap(fc_feats, att_feats, cpts_tensor, caps_tensor, xe_senti_labels, self.xe_ss_prob,
+                                      s_caps, s_cpts, s_sentis, s_labels, self.seq2seq_ss_prob, mode='xe_seq2seq')
+                    xe_loss = share(self.cap_xe_crit(pred, caps_tensor[:, 1:], lengths), w_xe)
+                    put('xe_loss', xe_loss)
+                    seq2seq_loss = share(self.seq_flag * self.cap_xe_crit(pred2, s_caps[:, 1:], s_lengths), w_s2s)
+                    put('seq2seq_loss', seq2seq_loss)
+                elif data_type == 'fact':                    # XE on the ground truth, labelled by the classifier
+                    with torch.no_grad():
+                        xe_senti_labels = self.sent_senti_cls(caps_tensor[:, 1:], lengths)[0]
+                        xe_senti_labels = xe_senti_labels.softmax(dim=-1).argmax(dim=-1).detach()
+                    pred = cap(fc_feats, att_feats, cpts_tensor, caps_tensor, xe_senti_labels, ss_prob=self.xe_ss_prob,
+                               mode='xe')
+                    xe_loss = share(self.cap_xe_crit(pred, caps_tensor[:, 1:], lengths), w_xe)
+                    put('xe_loss', xe_loss)
 
-            rewards = fact_reward + self.cls_flag * cls_reward
-            add('all_rewards', share(rewards.mean(-1).mean(-1), w_rows))
-            cap_loss = share(self.cap_rl_crit(sample_logprobs, seq_masks, rewards), w_rl)
-            add('cap_loss', cap_loss)
+                if training and not merged:
+                    (s_caps, s_lengths), s_cpts, s_sentis, s_labels = s2s_batch
+                    s_caps, s_cpts = s_caps.to(device), s_cpts.to(device)
+                    s_sentis, s_labels = s_sentis.to(device), s_labels.to(device)
+                    def seq2seq_unroll():                     # 80 text-only rows: a chain of small launches that
+                        pred = cap(s_caps, s_cpts, s_sentis, s_labels, ss_prob=self.seq2seq_ss_prob, mode='seq2seq')
+                        return share(self.seq_flag * self.cap_xe_crit(pred, s_caps[:, 1:], s_lengths), w_s2s)
+                    # ... overlaps with the XE unroll queued above when it runs on the side stream (forward and,
+                    # through autograd, backward); same numbers either way
+                    seq2seq_loss = run_on_side_stream(device, seq2seq_unroll) if device.type == 'cuda' \
+                        else seq2seq_unroll()
+                    put('seq2seq_loss', seq2seq_loss)
 
-            total = cap_loss + xe_loss + da_loss + seq2seq_loss
-            if training:
-                if self.dp_arena is not None:
-                    self.dp_arena.zero_()
+                copied.synchronize()
+                if not exact and getattr(cap, 'numerics_checks', True) and ops.device_status(reset=True):
+                    raise OutOfDomain()      # the roll-outs met non-finite values: nothing has been updated yet
+                cls_reward = get_cls_reward(sample_captions, seq_masks, greedy_captions, greedy_masks, senti_labels,
+                                            self.sent_senti_cls, sample_lens=host_lens.tolist(), on_device=True)
+                if data_type == 'fact':
+                    fact_reward = get_self_critical_reward(
+                        host_sample.numpy(), host_greedy.numpy(), fns, ground_truth, cap.sos_id, cap.eos_id,
+                        self.ciderd_scorer)
+                    fact_reward = ops.upload(fact_reward.astype('float32'), torch.float32, device)
+                    put('fact_reward', share(fact_reward[:, 0].mean(), w_rows))
                 else:
-                    self.cap_optim.zero_grad()
-                total.backward()
-                if self.dp_arena is not None:
-                    self.dp_arena.all_reduce(self.dp_group)      # one 88 MB sum over xGMI, before the clamp
-                clip_gradient(self.cap_optim)            # 0.1, fused into the Adam launch
-                self.cap_optim.step()
+                    fact_reward = 0
+                put('cls_reward', share(cls_reward.mean(-1).mean(-1), w_rows))
+
+                rewards = fact_reward + self.cls_flag * cls_reward
+                put('all_rewards', share(rewards.mean(-1).mean(-1), w_rows))
+                cap_loss = share(self.cap_rl_crit(sample_logprobs, seq_masks, rewards), w_rl)
+                put('cap_loss', cap_loss)
+
+                total = cap_loss + xe_loss + da_loss + seq2seq_loss
+                if training:
+                    if self.dp_arena is not None:
+                        self.dp_arena.zero_()
+                    else:
+                        self.cap_optim.zero_grad()
+                    total.backward()
+                    if self.dp_arena is not None:
+                        self.dp_arena.all_reduce(self.dp_group)      # one 88 MB sum over xGMI, before the clamp
+                    clip_gradient(self.cap_optim)            # 0.1, fused into the Adam launch
+                    self.cap_optim.step()
+
+            stats_it = []
+            try:
+                run_iteration(False, lambda k, v: stats_it.append((k, v)))
+            except OutOfDomain:
+                # features beyond |x| < 65504: the reference trains / evaluates on whatever its encoder produced
+                # (models/decoder.py:86-98) - this iteration is redone on the exact-fp32 engine
+                cap._warn_out_of_domain('non-finite values in a roll-out')
+                del stats_it[:]
+                with ops.exact_fp32_engine():
+                    run_iteration(True, lambda k, v: stats_it.append((k, v)))
+            for k, v in stats_it:
+                add(k, v)
 
         if dist_on and sums:                             # global statistics: one small all-reduce per call
             keys = sorted(sums)                          # (same keys on every rank: data_type / training were checked)

@@ -273,6 +273,41 @@ def set_h3_mode(mode):
     return _lib.load().isc_set_h3_mode(int(mode))
 
 
+class OutOfDomain(Exception):
+    """Raised inside the product when a roll-out met non-finite values with the split-f16 engine on - at a point where
+    nothing has been updated yet; the owner of the iteration redoes it on the exact-fp32 engine (Detector.forward)."""
+
+
+_EXACT = {'depth': 0, 'prev': 1, 'lock': threading.Lock()}
+
+
+class exact_fp32_engine:
+    """`with ops.exact_fp32_engine():` - every GEMM launched meanwhile runs on the exact-fp32 MFMA tiles
+    (isc_set_h3_mode(0); operand domain = fp32's), the previous mode is restored when the outermost block ends.  The mode
+    is a process-wide tuning word: launches of other host threads inside the window also take the exact tiles (same
+    results up to fp32 summation order).  Used by the product to SERVE inputs beyond the split-f16 domain |x| < 65504
+    instead of rejecting them (Captioner / Detector: numerics_checks)."""
+
+    def __enter__(self):
+        with _EXACT['lock']:
+            if _EXACT['depth'] == 0:
+                _EXACT['prev'] = set_h3_mode(0)
+            _EXACT['depth'] += 1
+        return self
+
+    def __exit__(self, *exc):
+        with _EXACT['lock']:
+            _EXACT['depth'] -= 1
+            if _EXACT['depth'] == 0:
+                set_h3_mode(_EXACT['prev'])
+        return False
+
+
+def h3_mode():
+    """The current split-f16 mode (isc_set_h3_mode) without changing it."""
+    return _lib.load().isc_set_h3_mode(-1)
+
+
 def set_gemv_rows(rows):
     """Few-row launches (M <= rows <= 8) as fused matrix-vector kernels; 0 = off.  Returns the previous value."""
     return _lib.load().isc_set_gemv_rows(int(rows))
@@ -1026,12 +1061,17 @@ def private_stream(device):
     device = torch.device(device)
     idx = device.index if device.index is not None else torch.cuda.current_device()
     cur = torch.cuda.current_stream(idx).cuda_stream
-    for _ in range(48):
-        st = torch.cuda.Stream(device=idx)
-        key = (idx, st.cuda_stream)
-        if key not in _OWNED_STREAMS and st.cuda_stream != cur:
-            _OWNED_STREAMS.add(key)
-            return st
+    for attempt in range(2):
+        for _ in range(48):
+            st = torch.cuda.Stream(device=idx)
+            key = (idx, st.cuda_stream)
+            if key not in _OWNED_STREAMS and st.cuda_stream != cur:
+                _OWNED_STREAMS.add(key)
+                return st
+        # every pool stream is held: owners that are garbage but sit in reference cycles (training-graph objects, captioners
+        # with captured graphs) give theirs back in their finalizers - collect once and look again
+        if attempt == 0 and not torch.cuda.is_current_stream_capturing():
+            gc.collect()
     raise RuntimeError('no free stream left in the pool of device %d (%d held by this package)' % (idx, len(_OWNED_STREAMS)))
 
 

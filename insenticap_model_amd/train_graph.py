@@ -514,6 +514,10 @@ class RLTrainGraph(XETrainGraph):
         seq, lp, mk, da, gseq, gmk = roll
         fns, ground_truth = item[0], item[6]
         geo.copied.synchronize()
+        if getattr(self.cap, 'numerics_checks', True) and ops.device_status(reset=True):
+            # the roll-outs met non-finite values (features beyond the split-f16 domain): nothing has been updated yet -
+            # Detector.forward redoes this iteration eagerly on the exact-fp32 engine
+            raise ops.OutOfDomain()
         fact = get_self_critical_reward(geo.host[0].numpy(), geo.host[1].numpy(), fns, ground_truth, self.cap.sos_id,
                                         self.cap.eos_id, det.ciderd_scorer)
         fact = ops.upload(fact.astype('float32'), torch.float32, self.device)
@@ -604,7 +608,12 @@ class RLTrainGraph(XETrainGraph):
         geo.copied.record(self.stream)
         self._shares(geo, roll, lengths, s_lengths)
         geo.g_fwd.replay()
-        self._rewards(geo, roll, item)
+        try:
+            self._rewards(geo, roll, item)
+        except ops.OutOfDomain:
+            for st in states:               # this iteration will be redone elsewhere: it has not stepped
+                st['step'] -= 1
+            raise
         geo.g_bwd.replay()
         stats = geo.stats
         if geo.g_up is not None:
@@ -645,21 +654,26 @@ class RLTrainGraph(XETrainGraph):
             self._geoms.move_to_end(sig)
         caller = torch.cuda.current_stream(self.device)
         self.stream.wait_stream(caller)
-        with torch.cuda.stream(self.stream):
-            self._stage(geo, t)
-            if geo.host is None:
-                self._alloc(geo)
-            planes_ok = self._valid_key is not None and self._valid_key == self.cap._weights_key()
-            if ops.h3_weights_scope.cold_begins(self._scope_keys) != geo.layout:
-                geo.g_iter = geo.g_roll = geo.g_fwd = geo.g_bwd = geo.g_up = None
-            if geo.g_iter is None and planes_ok and geo.eager_runs >= self.warmup:
-                self._capture_rl(geo)
-            if geo.g_iter is not None and planes_ok:
-                stats = self._replay_rl(geo, item, lengths, s_lengths)
-            else:
-                stats = self._run_eager(geo, item, lengths, s_lengths)
-                geo.eager_runs += 1
-            out = dict(zip(self.KEYS, stats.clone().unbind(0)))
+        try:
+            with torch.cuda.stream(self.stream):
+                self._stage(geo, t)
+                if geo.host is None:
+                    self._alloc(geo)
+                planes_ok = self._valid_key is not None and self._valid_key == self.cap._weights_key()
+                if ops.h3_weights_scope.cold_begins(self._scope_keys) != geo.layout:
+                    geo.g_iter = geo.g_roll = geo.g_fwd = geo.g_bwd = geo.g_up = None
+                if geo.g_iter is None and planes_ok and geo.eager_runs >= self.warmup:
+                    self._capture_rl(geo)
+                if geo.g_iter is not None and planes_ok:
+                    stats = self._replay_rl(geo, item, lengths, s_lengths)
+                else:
+                    stats = self._run_eager(geo, item, lengths, s_lengths)
+                    geo.eager_runs += 1
+                out = dict(zip(self.KEYS, stats.clone().unbind(0)))
+        except ops.OutOfDomain:
+            caller.wait_stream(self.stream)          # the caller redoes the iteration on ITS stream: behind what was queued
+            self.cap.cpt_feats = self.cap.fc_feats = self.cap.s2s_cpt_feats = None
+            raise
         caller.wait_stream(self.stream)
         for v in out.values():
             v.record_stream(caller)

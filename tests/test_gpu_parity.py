@@ -554,18 +554,23 @@ def test_sampled_rollout_b1024_replayed_by_the_oracle():
     assert lp.cpu()[:, 0].mean().item() > -9.0
 
 
-def test_features_beyond_the_split_f16_domain_are_reported_not_decoded_silently():
+def test_features_beyond_the_split_f16_domain_are_served_on_the_exact_engine():
     """Round-2 finding: |x| >= 65504 in caller data turns the hi plane of x = hi + lo 2^-11 into inf and the roll-out
-    into NaN-derived garbage without any error.  Now: the prologue's linear epilogue flags the non-finite
-    pre-activation and every decode step flags non-finite vocabulary statistics (isc_status); beam search and the RL
-    step raise on it, a roll-out reports it through ops.check_numerics, and the exact-fp32 engine decodes the same
-    input (its domain is fp32's)."""
+    into NaN-derived garbage.  Rounds 2-4 flagged and raised; the reference decodes whatever its encoder produced
+    (captioner.py:198-214, 294-315), so the product now SERVES such a call - on its exact-fp32 GEMM engine, in the same
+    process, with one warning: the default-mode results equal the results of the engine switched off by hand
+    (isc_set_h3_mode(0)), token for token, for a roll-out (eager and at a graph-served size), `sample`, and
+    `Detector.forward`; `numerics_checks = False` keeps the old behaviour (no host read: flags only)."""
+    import warnings
     from insenticap_model_amd import _lib
     from conftest import case_setup
     c, st, w, d, _ = case_setup('cfg1')
-    cap = Captioner(synth.make_idx2word(c['V']), synth.SENTIMENT_CATEGORIES, st)
-    cap.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()})
-    cap.to(dev()).eval()
+
+    def make():
+        m = Captioner(synth.make_idx2word(c['V']), synth.SENTIMENT_CATEGORIES, st)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()})
+        return m.to(dev()).eval()
+    cap = make()
     B = 512                                   # enough rows for the split-f16 prologue kernels in auto mode
     big = synth.make_inputs(B, c['V'], st, regions=36, seq_len=6, seed=77)
     a = [torch.from_numpy(np.asarray(big[k])).to(dev()) for k in ('fc_feats', 'att_feats', 'cpt_words', 'senti_words',
@@ -577,27 +582,116 @@ def test_features_beyond_the_split_f16_domain_are_reported_not_decoded_silently(
     assert ops.device_status(reset=True) == 0                     # healthy input: nothing flagged
     bad = [x.clone() for x in a]
     bad[1][3, 5, 100] = 1.0e5                                     # one region feature beyond the f16 range
-    with torch.no_grad():
+
+    def exact(fn):
+        prev = ops.set_h3_mode(0)
+        try:
+            with torch.no_grad():
+                return fn()
+        finally:
+            ops.set_h3_mode(prev)
+    # ---- roll-out, eager size
+    seq0, lp0, mk0 = exact(lambda: make()(*bad, 6, 1, mode='rl'))
+    with warnings.catch_warnings(record=True) as rec, torch.no_grad():
+        warnings.simplefilter('always')
         seq, lp, mk = cap(*bad, 6, 1, mode='rl')
+        seq_b, _, _ = cap(*bad, 6, 1, mode='rl')                  # (the verdict on these tensors is remembered)
+    torch.cuda.synchronize()
+    assert any('split-f16 operand domain' in str(x.message) for x in rec)
+    assert ops.device_status(reset=True) == 0 and ops.h3_mode() == 1          # nothing flagged; the engine is back on
+    assert torch.equal(seq, seq0) and torch.equal(mk, mk0) and torch.equal(seq_b, seq0)
+    np.testing.assert_allclose(lp.cpu().numpy(), lp0.cpu().numpy(), atol=1e-6)
+    assert bool(torch.isfinite(lp).all())
+    # ---- roll-out at a graph-served size (<= 256 rows), twice: never captured with out-of-domain inputs
+    small = [x[:8].clone() for x in bad]
+    s0 = exact(lambda: make()(*small, 6, 1, mode='rl'))[0]
+    with torch.no_grad():
+        for _ in range(3):
+            assert torch.equal(cap(*small, 6, 1, mode='rl')[0], s0)
+    # ---- beam search, one image
+    cp0, sc0 = exact(lambda: make().sample(bad[0][3], bad[1][3], bad[3][3], bad[4][3:4], 3, 1, 6))
+    cp, sc = cap.sample(bad[0][3], bad[1][3], bad[3][3], bad[4][3:4], 3, 1, 6)
+    assert cp == cp0
+    np.testing.assert_allclose(sc, sc0, atol=1e-5)
+    assert ops.device_status(reset=True) == 0
+    # ---- numerics_checks = False: no host read in front of the call, the flags report as before
+    loose = make()
+    loose.numerics_checks = False
+    with torch.no_grad():
+        loose(*bad, 6, 1, mode='rl')
     torch.cuda.synchronize()
     st_bits = ops.device_status(reset=False)
-    assert st_bits & ops.STATUS_NONFINITE_STATS, st_bits          # the NaN reached the step's vocabulary statistics
+    assert st_bits & ops.STATUS_NONFINITE_STATS and st_bits & ops.STATUS_NONFINITE_LINEAR, st_bits
     assert _lib.load().isc_status(0) == st_bits                   # the C entry point reads the same words
-    assert st_bits & ops.STATUS_NONFINITE_LINEAR, st_bits
     with pytest.raises(_lib.HipLibraryError, match='split-f16 domain'):
         ops.check_numerics('test')
     assert ops.device_status(reset=True) == 0                     # check_numerics cleared it
-    with pytest.raises(_lib.HipLibraryError, match='split-f16 domain'):
-        cap.sample(bad[0][3], bad[1][3], bad[3][3], bad[4][3:4], 3, 1, 6)
-    # the exact-fp32 engine takes the same features
+
+
+def test_detector_forward_serves_features_beyond_the_split_f16_domain():
+    """Detector.forward (models/decoder.py:52-180) on a batch with one region feature of 1e5: evaluation and a training
+    iteration (eager and with the RL graphs on) give the results of the exact-fp32 engine - the iteration whose
+    roll-outs flagged non-finite values is redone on it before anything is updated - and the parameters stay finite."""
+    import warnings
+    from insenticap_model_amd.detector import Detector
+    from test_detector import load_helper
+    V, Tn, B = 64, 8, 8
+    st = dict(synth.TINY_SETTINGS, **synth.HELPER_SETTINGS)
+    st['dropout_p'] = 0.0
+
+    def make(graphs):
+        det = Detector(synth.make_idx2word(V), Tn, synth.SENTIMENT_CATEGORIES, {'cap_lr': 4e-4}, st)
+        det.captioner.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_weights(V, st, seed=3).items()})
+        load_helper(det.senti_detector, 51)
+        load_helper(det.sent_senti_cls, 52)
+        det.to(dev())
+        det.train_graphs = graphs
+        det.xe_ss_prob = det.seq2seq_ss_prob = 0.0
+        return det
+    batches, split = synth.make_rl_batches(1, B, V, st, seq_len=Tn, seed=70)
+    t = torch.from_numpy
+    b = batches[0]
+    att = b[2].copy()
+    att.reshape(B, -1)[2, 17] = 1.0e5
+    item = (b[0], t(b[1]), t(att), (t(b[3][0]), b[3][1]), t(b[4]), t(b[5]), b[6])
+    s = synth.make_inputs(4, V, st, regions=6, seq_len=Tn, seed=72)
+    scs = [((t(s['captions']), s['lengths']), t(s['cpt_words']), t(s['senti_words']), t(s['senti_labels']))]
+    draws = torch.from_numpy(np.random.default_rng(80).integers(2, V, size=(B, Tn), dtype=np.int64)).to(dev())
+
+    def run(det, training, n=1):
+        det.set_ciderd_scorer(split)
+        orig = det.captioner.forward_rl
+
+        def replay_rl(*a, **k):
+            if not k.get('sample_max', a[-1] if len(a) >= 7 else 1):
+                k['_replay'] = draws
+            return orig(*a, **k)
+        det.captioner.forward_rl = replay_rl
+        out = [det(([item], scs), 'fact', training) for _ in range(n)]
+        torch.cuda.synchronize()
+        return out
     prev = ops.set_h3_mode(0)
     try:
-        with torch.no_grad():
-            seq0, lp0, _ = cap(*bad, 6, 1, mode='rl')
-        torch.cuda.synchronize()
-        assert ops.device_status(reset=True) == 0 and bool(torch.isfinite(lp0).all())
+        ref_eval = run(make(False), False)
+        ref_det = make(False)
+        ref_train = run(ref_det, True, 3)
     finally:
         ops.set_h3_mode(prev)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        got_eval = run(make(False), False)
+        for k in ref_eval[0]:
+            np.testing.assert_allclose(got_eval[0][k], ref_eval[0][k], rtol=1e-5, atol=1e-7, err_msg=k)
+        for graphs in (False, True):
+            det = make(graphs)
+            got = run(det, True, 3)
+            for i in range(3):
+                for k in ref_train[i]:
+                    np.testing.assert_allclose(got[i][k], ref_train[i][k], rtol=2e-4, atol=1e-6, err_msg='%s %d' % (k, i))
+            for (k, p), (_, q) in zip(det.captioner.named_parameters(), ref_det.captioner.named_parameters()):
+                assert bool(torch.isfinite(p).all()), k
+                assert float((p - q).abs().max()) <= 3 * 2 * 4e-4 * 1.01, k
+    assert ops.h3_mode() == 1 and ops.device_status(reset=True) == 0
 
 
 def test_gated_scan_equals_scans_plus_gate_gemm_plus_gate_mix():

@@ -257,6 +257,41 @@ def test_beam_search_on_this_path_equals_the_general_path(V, st, n_img, beam, R)
     assert sum(a == b for a, b in zip(i1, i0)) >= (len(i1) + 1) // 2
 
 
+def test_a_vocabulary_beyond_the_tile_lists_takes_the_general_kernels():
+    """Round-4 advisor finding: the few-row classifier keeps statistics per <= 64 columns and isc_beam_select holds 256 tile
+    lists, so V > 16384 does not fit this path - and the path was chosen without looking at V: a single-image beam search
+    raised ISC_E_SHAPE instead of running on the general kernels.  Now the gate (Captioner._rows_vocab_ok,
+    isc_rows_step_supported) sends such a vocabulary to the general kernels: same captions as with the path switched off,
+    no rows launch, also for a small greedy roll-out and from the default beam graphs."""
+    V, st = 20000, synth.DEFAULT_SETTINGS
+    cap = _captioner(V, st, seed=4)
+    assert not cap._rows_vocab_ok() and _captioner(16384 - 384, synth.TINY_SETTINGS)._rows_vocab_ok()
+    d = _inputs(2, V, st, 36, seed=6)
+    n0 = _n()
+    outs = []
+    with _region_walk_scan(True):                      # (the general step's own use of the row scan kernel off: it counts too)
+        for graphs in (False, True, True):
+            cap.enable_beam_graphs(graphs)
+            outs.append(cap.sample(d['fc_feats'][0], d['att_feats'][0], d['senti_words'][0], d['senti_labels'][0:1], 5, 1, 20))
+        with torch.no_grad():
+            seq = cap(d['fc_feats'], d['att_feats'], d['cpt_words'], d['senti_words'], d['senti_labels'], 20, 1, mode='rl')[0]
+        torch.cuda.synchronize()
+    assert _n() == n0                                  # nothing went to the few-row kernels
+    cap.rows_step = False
+    cap.enable_beam_graphs(False)
+    ref = cap.sample(d['fc_feats'][0], d['att_feats'][0], d['senti_words'][0], d['senti_labels'][0:1], 5, 1, 20)
+    with torch.no_grad():
+        seq0 = cap(d['fc_feats'], d['att_feats'], d['cpt_words'], d['senti_words'], d['senti_labels'], 20, 1, mode='rl')[0]
+    for o in outs:
+        assert o[0] == ref[0]
+        np.testing.assert_allclose(o[1], ref[1], atol=1e-5)
+    assert torch.equal(seq, seq0)
+    plan = cap._make_plan(cap._p(), cap._prologue(cap._p(), 'beam', d['fc_feats'][:1], d['att_feats'][:1], None,
+                                                 d['senti_words'][:1], d['senti_labels'][:1], want_table='build',
+                                                 gate_rows=5), 5)
+    assert not ops.rows_step_supported(plan)           # the library says so too
+
+
 def test_beam_graphs_replay_equals_eager_on_this_path():
     cap = _captioner(10000, synth.DEFAULT_SETTINGS, seed=4)
     d = _inputs(1, 10000, synth.DEFAULT_SETTINGS, 36, seed=6)
