@@ -80,8 +80,9 @@ long long isc_h3s_launches(void);
  * to the forward entry points changes (a roll-out's decode loop): each weight operand is then split into its planes
  * once, into `buf` (device memory, 256-byte aligned; 64 MB holds the decoder's matrices), and later launches with
  * the same weight segments reuse them instead of re-splitting per step.  A scope belongs to ONE stream: only
- * launches on `stream` see it, and they must be issued in one order (as a stream's launches are anyway); up to 16
- * streams may hold a scope at once (ISC_E_WORKSPACE beyond that: run without).  Without a scope, or when `buf` is
+ * launches on `stream` see it, and they must be issued in one order (as a stream's launches are anyway); up to 64
+ * streams may hold a scope - active or suspended - at once (ISC_E_WORKSPACE beyond that: run without; a suspended scope
+ * of another stream is never taken over).  Without a scope, or when `buf` is
  * full, every launch splits its weights into the workspace.  _begin discards the stream's earlier entries; _end
  * closes its scope (`buf` may then be reused). */
 int isc_h3_weights_begin(void *buf, long long bytes, void *stream);

@@ -923,6 +923,7 @@ extern "C" int isc_embed_relu_bwd_ws(const float *emb, int V, int W, const int64
     // replay (training graphs: counts piled up over replays, the fill kernel wrote past the list, the accumulate kernel read
     // slots nobody had written - GPU memory faults in emb_fill_kernel / emb_accumulate_kernel)
     hipLaunchKernelGGL(emb_zero_kernel, dim3((unsigned)((2 * V + 255) / 256)), dim3(256), 0, st, count, 2 * V);
+    ISC_LAUNCH_CHECK();             // (a failed clear must not let count / fill / accumulate run on stale counters)
     EmbIds I = {ids, (long long)ids_stride, (long long)pad_id, (long long)skip_id, pad_first};
     const unsigned nb = (unsigned)((n_rows + 255) / 256);
     hipLaunchKernelGGL(emb_count_kernel, dim3(nb), dim3(256), 0, st, I, n_rows, V, count);

@@ -3384,8 +3384,8 @@ struct H3WScope {
     int n = 0;
     bool active = false;
 };
-// 64 slots: more than the streams a process can hold (torch hands out 32 pool streams per device and priority, plus the
-// default stream), so begin never has to take over a SUSPENDED slot of another stream.  With 16 slots a test session
+// 64 slots: more than the streams a process can hold per device (torch hands out 32 pool streams per device and priority,
+// plus the default stream); begin never takes over a SUSPENDED slot of another stream.  With 16 slots a test session
 // that kept many captioners / training graphs alive ran out of them, and after such a take-over a captured training
 // graph (seq2seq branch) computed its loss from planes one update old (graph vs eager 6.0207 / 6.0188; order-dependent).
 #define H3W_MAX_SCOPES 64
@@ -3420,9 +3420,10 @@ extern "C" int isc_h3_weights_begin(void *buf, long long bytes, void *stream) {
         if (g_h3w[i].buf && g_h3w[i].stream == (hipStream_t)stream) slot = &g_h3w[i];
     for (int i = 0; !slot && i < H3W_MAX_SCOPES; ++i)            // a free one
         if (!g_h3w[i].buf) slot = &g_h3w[i];
-    for (int i = 0; !slot && i < H3W_MAX_SCOPES; ++i)            // a suspended one (its owner will rebuild)
-        if (!g_h3w[i].active) slot = &g_h3w[i];
-    if (!slot) return ISC_E_WORKSPACE;               // more concurrent scopes than slots: the caller runs without one
+    // No take-over of another stream's SUSPENDED slot: its owner may be a captured graph that still reads those planes
+    // (round 4: a training graph computed a loss from planes one update old after such a take-over).  More live scopes
+    // than slots: this caller runs without one (every launch splits its weights into the workspace).
+    if (!slot) return ISC_E_WORKSPACE;
     slot->stream = (hipStream_t)stream;
     slot->buf = static_cast<char *>(buf); slot->bytes = (size_t)bytes; slot->used = 0; slot->n = 0;
     slot->active = true;

@@ -146,7 +146,13 @@ class Detector(nn.Module):
                         and ops.TIMER.arm_step is None and ops.graphs_allowed_here() and not exact):
                     # the same iteration from HIP graphs (train_graph.RLTrainGraph): same calls in the same order
                     from .train_graph import RLTrainGraph
-                    if self._rl_graph is None or self._rl_graph.arena is not self.dp_arena:
+                    g = self._rl_graph
+                    if g is None or g.arena is not self.dp_arena or g.group is not self.dp_group or \
+                            g.optim is not self.cap_optim or g.xe_crit is not self.cap_xe_crit or \
+                            g.da_crit is not self.cap_da_crit:
+                        # (the graph object holds its own references to the optimizer, the criteria, the arena and the
+                        # group: a replaced optimizer - a new learning-rate schedule object, say - must not leave replays
+                        # updating through the old one)
                         self._rl_graph = RLTrainGraph(self)
                     with torch.no_grad():
                         xe_senti_labels = self.sent_senti_cls(caps_tensor[:, 1:], lengths)[0]

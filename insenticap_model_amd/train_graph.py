@@ -280,8 +280,8 @@ class XETrainGraph:
                 geo.keep = (vec_xe, s2s)
         finally:
             self.optim.device_hyper = None
-        for st, n in zip(self._states(), steps_before):
-            st['step'].fill_(n)
+            for st, n in zip(self._states(), steps_before):      # (also when the capture fails half-way)
+                st['step'].fill_(n)
         geo.layout = ops.h3_weights_scope.cold_begins(self._scope_keys)
         self._valid_key = self.cap._weights_key()
         self.captures += 1
@@ -591,8 +591,8 @@ class RLTrainGraph(XETrainGraph):
                 geo.keep = (roll, fwd)
         finally:
             self.optim.device_hyper = None
-        for st, n in zip(self._states(), steps_before):
-            st['step'].fill_(n)
+            for st, n in zip(self._states(), steps_before):      # (also when the capture fails half-way)
+                st['step'].fill_(n)
         geo.g_iter = geo.g_roll                              # (the base class's "is captured" marker)
         geo.layout = ops.h3_weights_scope.cold_begins(self._scope_keys)
         self._valid_key = self.cap._weights_key()
