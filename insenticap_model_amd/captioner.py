@@ -891,10 +891,11 @@ class Captioner(nn.Module):
         Detector.forward looks at the numerics flags at its own synchronisation point instead) no check.  One reduction
         over the features and ONE host read per NEW feature tensor: the verdict is remembered per tensor OBJECT and
         version (a loop over one batch pays once; a roll-out of 16384 captions reads 4.8 GB = 0.8 ms of its 37 ms)."""
-        if (not getattr(self, 'numerics_checks', True) or self.__dict__.get('_domain_check_off') or ops.h3_mode() == 0
-                or torch.cuda.is_current_stream_capturing()):
-            return True
         feats = [x for x in feats if x is not None and torch.is_tensor(x) and x.is_floating_point()]
+        if (not getattr(self, 'numerics_checks', True) or self.__dict__.get('_domain_check_off') or not feats
+                or not all(x.is_cuda for x in feats)          # (CPU tensors: the call itself raises - no CPU path)
+                or ops.h3_mode() == 0 or torch.cuda.is_current_stream_capturing()):
+            return True
         memo = self.__dict__.setdefault('_domain_memo', {})
         verdict, fresh = True, []
         for x in feats:
