@@ -510,9 +510,13 @@ int isc_set_rows_nt(int mode);
 long long isc_rows_launches(void);    /* launches of rows kernels so far (tests assert the path was taken) */
 /* isc_attn_scan_gate_fwd (and with it isc_step_fwd's gated scan) runs launches of up to this many rows on the rows scan
  * kernel - one 1024-thread workgroup per row, the row's rows of P / V / G in flight at once - when the shape is its own
- * (v / s not wanted on their own, R <= 36, Mw <= 12, A = D <= 512); default 256, 0 = never (attn_scan_gate_kernel walks
+ * (v / s not wanted on their own, R <= isc_set_rows_scan_regions, Mw <= 12, A = D <= 512); default 256, 0 = never (attn_scan_gate_kernel walks
  * the regions).  rows < 0 only queries.  Returns the previous value. */
 int isc_set_rows_scan_max(int rows);
+/* ... and up to this many content regions (default 256; up to 36 all of a row's regions are in flight at once, larger
+ * grids - the reference encoder's 14 x 14 = 196 - are walked 36 regions at a time by the same kernel).  regions < 0
+ * only queries.  Returns the previous value. */
+int isc_set_rows_scan_regions(int regions);
 /* Vocabulary launches of the skinny split-f16 path (isc_vocab_fwd / isc_step_fwd at a few hundred rows, one activation
  * segment): 1 (default) = gemm_h3v_kernel (k-block stages shared by the workgroup: the activation block fetched once, two
  * blocks in flight; taken up to 512 workgroups), 0 = the per-wave-ring gemm_h3s_kernel form it replaced (tests, A/B runs),

@@ -168,6 +168,7 @@ SIGNATURES = {
                                      C.c_void_p]),
     'isc_set_rows_nt': (C.c_int, [C.c_int]),
     'isc_set_rows_scan_max': (C.c_int, [C.c_int]),
+    'isc_set_rows_scan_regions': (C.c_int, [C.c_int]),
     'isc_set_h3v': (C.c_int, [C.c_int]),
     'isc_set_h3_ksplit': (C.c_int, [C.c_int]),
     'isc_copy_multi': (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_int, C.c_void_p]),

@@ -1173,12 +1173,22 @@ extern "C" int isc_set_rows_scan_max(int rows) {
     return g_rows_scan_max.exchange(rows);
 }
 
+// Regions up to which such a launch takes the row kernel.  Up to 36 every region's rows are in flight at once (one round
+// trip); beyond, the kernel walks the regions 36 at a time (the reference encoder's 14 x 14 = 196-region grid: six trips)
+// and still beats the 512-thread region walk of attn_scan_gate_kernel: greedy roll-outs at 196 regions, B = 128 2.33 ->
+// 1.9-2.0 ms, B = 256 3.78 -> 3.36 ms, B = 64 equal (tools/r5_r196_scan.py, round 5; rounds 3-4 gated this at 36).
+static std::atomic<int> g_rows_scan_regions{256};
+extern "C" int isc_set_rows_scan_regions(int regions) {
+    if (regions < 0) return g_rows_scan_regions.load();
+    return g_rows_scan_regions.exchange(regions);
+}
+
 int rows_scan_gate_try(const isc_scan_gate_args *g, int rows, hipStream_t st, int *rc) {
     const isc_scan_problem &c = g->scan[0], &s = g->scan[1];
     if (rows > g_rows_scan_max.load()) return 0;
     if (c.out || s.out || c.out_hi || s.out_hi || c.q2 || c.row_ids) return 0;
     if (c.A != c.D || s.A != c.A || s.D != c.A || c.A > 512 || (c.A & 3) || c.R < 1 || s.R < 1) return 0;
-    if (c.R > RS_NWC * RS_RPW || s.R > RS_NWS * RS_RPW) return 0;
+    if (c.R > g_rows_scan_regions.load() || s.R > RS_NWS * RS_RPW) return 0;
     if (!c.P || !c.V || !c.q || !c.w || !s.P || !s.V || !s.q || !s.w || !g->G[0] || !g->G[1]) return 0;
     RScanArgs a = {};
     a.row_div = 1;

@@ -428,7 +428,7 @@ def test_small_greedy_rollout_on_this_path_equals_the_general_path(B):
     np.testing.assert_allclose(rep[1].cpu().numpy(), rep0[1].cpu().numpy(), atol=1e-4)
 
 
-@pytest.mark.parametrize('B,R', [(9, 36), (128, 36), (200, 36), (256, 36), (64, 6)])
+@pytest.mark.parametrize('B,R', [(9, 36), (128, 36), (200, 36), (256, 36), (64, 6), (100, 196), (12, 49)])
 def test_gated_scan_of_larger_steps_on_the_row_kernel_equals_the_region_walk(B, R):
     """isc_step_fwd's gated scan for up to isc_set_rows_scan_max rows runs on rows_scan_gate_kernel (one 1024-thread
     workgroup per row, f and its f16 planes written for the MFMA lang-LSTM): the same greedy roll-out with it and on

@@ -11,7 +11,8 @@ dev = torch.device('cuda:0')
 cap = Captioner(synth.make_idx2word(bench.V), synth.SENTIMENT_CATEGORIES, synth.DEFAULT_SETTINGS)
 cap.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_weights(bench.V, synth.DEFAULT_SETTINGS).items()})
 cap.to(dev).eval()
-inputs, _ = bench.device_inputs(16, 100, dev)
+REG = int(os.environ.get('ISC_REGIONS', bench.R))
+inputs, _ = bench.device_inputs(16, 100, dev, regions=REG)
 fc, att, _, sw, lab = inputs
 cap.eos_id = -7
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10
@@ -24,4 +25,4 @@ with torch.no_grad():
         cap.sample(fc[i % 16], att[i % 16], sw[i % 16], lab[i % 16:i % 16 + 1], 5, 1, bench.T)
         torch.cuda.synchronize()
     el = time.perf_counter() - t0
-print('beam-5 full 20-step search: %.3f ms per image, %.1f us per step' % (el / n * 1e3, el / n / bench.T * 1e6))
+print('beam-5 full 20-step search, %d regions: %.3f ms per image, %.1f us per step' % (REG, el / n * 1e3, el / n / bench.T * 1e6))
