@@ -346,21 +346,23 @@ def _backward(cap, S, dlogp, d_fc_feats, d_cpt_feats, sparse=()):
     h2_prev = S.h2[:T].reshape(TB, H)
     feat_tb = (S.f if gate else (S.v if has_c else S.s)).view(TB, E)
     gW1 = new(4 * H, H + E + Wd)
-    # xt = relu(Emb[tok]) + label_e: the per-step part contracts over T*B rows, the label part over B
-    wx_segs = [(dG1f, S.xt.view(TB, Wd))]
-    if P.label_e is not None:
-        wx_segs.append((dG1_sum, P.label_e))
+    gW2, gwhh1, gwhh2 = new(4 * H, E + H), new(4 * H, H), new(4 * H, H)
+    # problems grouped by their dY operand: isc_gemm_bwd splits a shared dY once and runs the group as one launch
     ops.gemm_bwd([ops.gemm_problem([(dG1f, h2_prev)], gW1[:, 0:H], TN),
-                  ops.gemm_problem([(dG1_sum, P.fc_e)], gW1[:, H:H + E], TN),
-                  ops.gemm_problem(wx_segs, gW1[:, H + E:], TN)], TN)
+                  ops.gemm_problem([(dG1f, S.xt.view(TB, Wd))], gW1[:, H + E:], TN),
+                  ops.gemm_problem([(dG1f, h1_prev)], gwhh1, TN)], TN)
+    ops.gemm_bwd([ops.gemm_problem([(dG2f, feat_tb)], gW2[:, 0:E], TN),
+                  ops.gemm_problem([(dG2f, h1_cur)], gW2[:, E:], TN),
+                  ops.gemm_problem([(dG2f, h2_prev)], gwhh2, TN)], TN)
+    # xt = relu(Emb[tok]) + label_e: the per-step part contracted over T*B rows above, the label part over B here
+    once = [ops.gemm_problem([(dG1_sum, P.fc_e)], gW1[:, H:H + E], TN)]
+    if P.label_e is not None:
+        once.append(ops.gemm_problem([(dG1_sum, P.label_e)], gW1[:, H + E:], TN, accumulate=True))
+    ops.gemm_bwd(once, TN)
     G['att_lstm.weight_ih'] = gW1
-    gW2, gwhh1 = new(4 * H, E + H), new(4 * H, H)
-    ops.gemm_bwd([ops.gemm_problem([(dG1f, h1_prev)], gwhh1, TN),
-                  ops.gemm_problem([(dG2f, feat_tb)], gW2[:, 0:E], TN),
-                  ops.gemm_problem([(dG2f, h1_cur)], gW2[:, E:], TN)], TN)
     G['att_lstm.weight_hh'] = gwhh1
     G['lang_lstm.weight_ih'] = gW2
-    G['lang_lstm.weight_hh'] = tn(dG2f, h2_prev)
+    G['lang_lstm.weight_hh'] = gwhh2
     G['att_lstm.bias_ih'], G['att_lstm.bias_hh'] = csum(dG1f, 2)
     G['lang_lstm.bias_ih'], G['lang_lstm.bias_hh'] = csum(dG2f, 2)
     # inputs of the att-LSTM: fc (step-invariant), xt = relu(Emb[tok]) + label_e

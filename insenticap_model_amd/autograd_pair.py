@@ -449,13 +449,14 @@ def _pair_backward(cap, S, d1, d2, sparse1, sparse2, d_fc_feats1, d_cpt_feats1, 
     if P1.label_e is not None:
         label_e_all = torch.cat([P1.label_e, P2.label_e] + ([_const_zeros(cap, Bp - Bt, Wd)] if Bp > Bt else []))
     gW1 = gout('att_lstm.weight_ih', 4 * H, H + E + Wd)
-    wx_segs = [(dG1f, S.xt.view(TB, Wd))]
-    if label_e_all is not None:
-        wx_segs.append((dG1_sum_p, label_e_all))
+    # (problems grouped by their dY operand: isc_gemm_bwd splits a shared dY once and runs the group as one launch)
     ops.gemm_bwd([ops.gemm_problem([(dG1f, h2_prev)], gW1[:, 0:H], TN),
-                  ops.gemm_problem([(dG1_sum_p, fc_e_all)], gW1[:, H:H + E], TN),
-                  ops.gemm_problem(wx_segs, gW1[:, H + E:], TN)], TN)
-    tn(dG1f, h1_prev, 'att_lstm.weight_hh')
+                  ops.gemm_problem([(dG1f, S.xt.view(TB, Wd))], gW1[:, H + E:], TN),
+                  ops.gemm_problem([(dG1f, h1_prev)], gout('att_lstm.weight_hh', 4 * H, H), TN)], TN)
+    once = [ops.gemm_problem([(dG1_sum_p, fc_e_all)], gW1[:, H:H + E], TN)]
+    if label_e_all is not None:      # xt = relu(Emb[tok]) + label_e: the label part contracts over the rows, once per caption
+        once.append(ops.gemm_problem([(dG1_sum_p, label_e_all)], gW1[:, H + E:], TN, accumulate=True))
+    ops.gemm_bwd(once, TN)
     csum(dG1f, 'att_lstm.bias_ih', 'att_lstm.bias_hh')
     ops.attn_dv_from_alpha(S.aC, d_feat_all[:T1, :B1], dV_att, step_rows=Bt)
     ops.attn_dp_from_de(P1.att_p3, S.qa, p['attention.cont_att.att_alpha.weight'], de_c, dP_att)

@@ -3926,6 +3926,49 @@ static unsigned try_h3_tn(DevLaunch &L, float *ws, long long ws_floats, hipStrea
         }
         if (ok) take |= 1u << i;
     }
+    // Several dW contractions from ONE dY (the weight gradients of the layers that consumed the same pre-activation
+    // gradient: lang-LSTM's three input blocks from dG2, att-LSTM's from dG1): the transposing split of dY happens once,
+    // the problems share one launch of the skinny tiles - 3 x (split + GEMM) -> 1 + 1 launches, and dY^T's planes
+    // (the larger operand: [2048, T B] against [512, T B]) are built once instead of three times.
+    if (L.nprob >= 2 && take == (1u << L.nprob) - 1u) {
+        bool same = true;
+        long long n_sum = 0;
+        const DevProb &p0 = L.p[0];
+        for (int i = 0; i < L.nprob; ++i) {
+            const DevProb &p = L.p[i];
+            same = same && p.nseg == 1 && p.seg[0].A == p0.seg[0].A && p.seg[0].lda == p0.seg[0].lda &&
+                   p.seg[0].K == p0.seg[0].K && p.M == p0.M && chunk[i] == p.seg[0].K &&
+                   (long long)((p.M + 127) / 128) * ((p.N + 127) / 128) < H3_MIN_TILES / 2;
+            n_sum += p.N;
+        }
+        const long long K = p0.nseg == 1 ? p0.seg[0].K : 0;
+        if (same && ((long long)p0.M + n_sum) * K + 1024LL * (L.nprob + 1) <= ws_floats) {
+            DevLaunch Lc = {};
+            Lc.nprob = L.nprob;
+            H3Planner pl(ws, nullptr);
+            const _Float16 *ah = nullptr, *al = nullptr;
+            pl.add(p0, false, p0.M, ah, al, 0, -1, 1);
+            for (int i = 0; i < L.nprob; ++i) {
+                DevProb &q = Lc.p[i];
+                q = L.p[i];
+                pl.add(q, true, q.N, q.Wh, q.Wl, 0, -1, 1);
+                q.nap = 1;
+                q.ap[0] = DevASeg{ah, al, 2 * (int)K, (int)K};
+                q.nseg = 1;
+                q.Kp = (int)K;
+                q.ksplit = 1;
+            }
+            rc = pl.launch(st);
+            if (rc) return take;
+            int T = h3s_pick_tile<EPI_LINEAR>(Lc, mode == 2 ? 1 : mode), start = 0;
+            if (!T) T = 2;
+            for (int i = 0; i < Lc.nprob; ++i) h3s_tile_problem(Lc.p[i], 32 * T, 32 * T, start);
+            Lc.total_tiles = start;
+            rc = launch_h3s_t<EPI_LINEAR>(Lc, T, st);
+            if (!rc) ++g_h3_launches;
+            return take;
+        }
+    }
     for (int i = 0; i < L.nprob; ++i) {
         if (!(take & (1u << i))) continue;
         const DevProb &pfull = L.p[i];

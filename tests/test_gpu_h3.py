@@ -482,3 +482,31 @@ def test_nn_backward_contraction_over_the_vocabulary_in_k_slices():
     finally:
         _set_ksplit(1)
     np.testing.assert_allclose(outs[1].cpu().numpy(), outs[0].cpu().numpy(), atol=5e-7, rtol=2e-6)
+
+
+def test_dw_contractions_that_share_their_dy_split_it_once():
+    """isc_gemm_bwd, TN layout: several dW = dY^T X problems over ONE dY (the weight gradients of the layers that consumed
+    the same pre-activation gradient) - the transposing split of dY once, one skinny launch for the group - against the
+    same problems issued one by one and against fp64; an `accumulate` problem in the group adds to what is there."""
+    g = torch.Generator().manual_seed(5)
+    K, M = 4160, 2048
+    dy = _rand(g, K, M, scale=1e-2).to(dev())
+    xs = [_rand(g, K, n).to(dev()) for n in (512, 512, 384)]
+    prior = _rand(g, M, 384).to(dev())
+    from insenticap_model_amd import _lib
+    n0 = _lib.load().isc_h3_launches()
+    outs = [torch.empty(M, x.shape[1], device=dev()) for x in xs]
+    outs[2].copy_(prior)
+    ops.gemm_bwd([ops.gemm_problem([(dy, x)], o, ops.TN, accumulate=(i == 2)) for i, (x, o) in enumerate(zip(xs, outs))],
+                 ops.TN)
+    torch.cuda.synchronize()
+    assert _lib.load().isc_h3_launches() - n0 == 1                     # one GEMM launch for the three problems
+    single = [torch.empty(M, x.shape[1], device=dev()) for x in xs]
+    single[2].copy_(prior)
+    for i, (x, o) in enumerate(zip(xs, single)):
+        ops.gemm_bwd([ops.gemm_problem([(dy, x)], o, ops.TN, accumulate=(i == 2))], ops.TN)
+    torch.cuda.synchronize()
+    for i, (a, b, x) in enumerate(zip(outs, single, xs)):
+        ref = dy.double().cpu().t() @ x.double().cpu() + (prior.double().cpu() if i == 2 else 0.0)
+        np.testing.assert_allclose(a.cpu().numpy(), ref.float().numpy(), atol=3e-6, rtol=1e-5)
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), atol=1e-6, rtol=1e-6)
