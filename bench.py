@@ -564,7 +564,7 @@ def bench_beam(cap, inputs, n_img=64, beam=5):
                            batched_images_per_s=round(n_img / el, 1)))
 
 
-PMC_SUMMARY = os.path.join(ROOT, 'profiles', 'r04_f_pmc_summary_B16384.json')
+PMC_SUMMARY = os.path.join(ROOT, 'profiles', 'r05_a_pmc_summary_B16384.json')
 # bench kernel label -> device symbols it may run as (first one present in the PMC summary wins)
 KERNEL_SYMBOL = {'vocab[': ['void gemm_h3_kernel<2, false>', 'void gemm_h3_kernel<2>', 'void gemm_ld_kernel<2>', 'void gemm_kernel<4, 1, 4, 2, false, false>'],
                  'lstm[': ['void gemm_h3x_kernel<1, false>', 'void gemm_h3x_kernel<1>', 'void gemm_h3_kernel<1>', 'void gemm_ld_kernel<1>', 'void gemm_kernel<4, 1, 4, 1, false, false>', 'void gemm_xl_kernel<1>'],
