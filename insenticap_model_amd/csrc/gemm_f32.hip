@@ -3937,35 +3937,52 @@ static unsigned try_h3_tn(DevLaunch &L, float *ws, long long ws_floats, hipStrea
         for (int i = 0; i < L.nprob; ++i) {
             const DevProb &p = L.p[i];
             same = same && p.nseg == 1 && p.seg[0].A == p0.seg[0].A && p.seg[0].lda == p0.seg[0].lda &&
-                   p.seg[0].K == p0.seg[0].K && p.M == p0.M && chunk[i] == p.seg[0].K &&
+                   p.seg[0].K == p0.seg[0].K && p.M == p0.M &&
                    (long long)((p.M + 127) / 128) * ((p.N + 127) / 128) < H3_MIN_TILES / 2;
             n_sum += p.N;
         }
         const long long K = p0.nseg == 1 ? p0.seg[0].K : 0;
-        if (same && ((long long)p0.M + n_sum) * K + 1024LL * (L.nprob + 1) <= ws_floats) {
-            DevLaunch Lc = {};
-            Lc.nprob = L.nprob;
-            H3Planner pl(ws, nullptr);
-            const _Float16 *ah = nullptr, *al = nullptr;
-            pl.add(p0, false, p0.M, ah, al, 0, -1, 1);
-            for (int i = 0; i < L.nprob; ++i) {
-                DevProb &q = Lc.p[i];
-                q = L.p[i];
-                pl.add(q, true, q.N, q.Wh, q.Wl, 0, -1, 1);
-                q.nap = 1;
-                q.ap[0] = DevASeg{ah, al, 2 * (int)K, (int)K};
-                q.nseg = 1;
-                q.Kp = (int)K;
-                q.ksplit = 1;
+        // planes of dY^T and of every X^T for kc rows at a time: the whole K when it fits the workspace, else equal chunks
+        // (multiples of 32) that accumulate into C - the B = 512 / 1024 iterations contract over 10 240 / 22 080 rows
+        const long long per_k = (long long)p0.M + n_sum;
+        const long long kc_max = ((ws_floats - 1024LL * (L.nprob + 1)) / (per_k > 0 ? per_k : 1)) & ~31LL;
+        if (same && K > 0 && kc_max >= 2048) {
+            const long long nchunk = (K + kc_max - 1) / kc_max;
+            const long long kc0 = ((K + nchunk - 1) / nchunk + 31) & ~31LL;
+            for (long long k0 = 0; k0 < K; k0 += kc0) {
+                const long long kc = K - k0 < kc0 ? K - k0 : kc0;
+                DevLaunch Lc = {};
+                Lc.nprob = L.nprob;
+                H3Planner pl(ws, nullptr);
+                const _Float16 *ah = nullptr, *al = nullptr;
+                DevProb a0 = p0;
+                a0.seg[0].A = p0.seg[0].A + k0 * p0.seg[0].lda;
+                a0.seg[0].K = (int)kc;
+                pl.add(a0, false, a0.M, ah, al, 0, -1, 1);
+                for (int i = 0; i < L.nprob; ++i) {
+                    DevProb &q = Lc.p[i];
+                    q = L.p[i];
+                    q.seg[0].A = L.p[i].seg[0].A + k0 * L.p[i].seg[0].lda;
+                    q.seg[0].W = L.p[i].seg[0].W + k0 * L.p[i].seg[0].ldw;
+                    q.seg[0].K = (int)kc;
+                    if (k0 > 0) { q.accumulate = 1; q.bias0 = q.bias1 = q.bias2 = nullptr; }
+                    pl.add(q, true, q.N, q.Wh, q.Wl, 0, -1, 1);
+                    q.nap = 1;
+                    q.ap[0] = DevASeg{ah, al, 2 * (int)kc, (int)kc};
+                    q.nseg = 1;
+                    q.Kp = (int)kc;
+                    q.ksplit = 1;
+                }
+                rc = pl.launch(st);
+                if (rc) return take;
+                int T = h3s_pick_tile<EPI_LINEAR>(Lc, mode == 2 ? 1 : mode), start = 0;
+                if (!T) T = 2;
+                for (int i = 0; i < Lc.nprob; ++i) h3s_tile_problem(Lc.p[i], 32 * T, 32 * T, start);
+                Lc.total_tiles = start;
+                rc = launch_h3s_t<EPI_LINEAR>(Lc, T, st);
+                if (rc) return take;
+                ++g_h3_launches;
             }
-            rc = pl.launch(st);
-            if (rc) return take;
-            int T = h3s_pick_tile<EPI_LINEAR>(Lc, mode == 2 ? 1 : mode), start = 0;
-            if (!T) T = 2;
-            for (int i = 0; i < Lc.nprob; ++i) h3s_tile_problem(Lc.p[i], 32 * T, 32 * T, start);
-            Lc.total_tiles = start;
-            rc = launch_h3s_t<EPI_LINEAR>(Lc, T, st);
-            if (!rc) ++g_h3_launches;
             return take;
         }
     }

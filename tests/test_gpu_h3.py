@@ -484,12 +484,13 @@ def test_nn_backward_contraction_over_the_vocabulary_in_k_slices():
     np.testing.assert_allclose(outs[1].cpu().numpy(), outs[0].cpu().numpy(), atol=5e-7, rtol=2e-6)
 
 
-def test_dw_contractions_that_share_their_dy_split_it_once():
+@pytest.mark.parametrize('K,launches', [(4160, 1), (22080, 3)], ids=['one_pass', 'k_chunks'])
+def test_dw_contractions_that_share_their_dy_split_it_once(K, launches):
     """isc_gemm_bwd, TN layout: several dW = dY^T X problems over ONE dY (the weight gradients of the layers that consumed
     the same pre-activation gradient) - the transposing split of dY once, one skinny launch for the group - against the
     same problems issued one by one and against fp64; an `accumulate` problem in the group adds to what is there."""
     g = torch.Generator().manual_seed(5)
-    K, M = 4160, 2048
+    M = 2048               # (K = 22 080 = 20 steps x 1104 rows: the planes exceed the 128 MB workspace - three chunks of K)
     dy = _rand(g, K, M, scale=1e-2).to(dev())
     xs = [_rand(g, K, n).to(dev()) for n in (512, 512, 384)]
     prior = _rand(g, M, 384).to(dev())
@@ -500,7 +501,7 @@ def test_dw_contractions_that_share_their_dy_split_it_once():
     ops.gemm_bwd([ops.gemm_problem([(dy, x)], o, ops.TN, accumulate=(i == 2)) for i, (x, o) in enumerate(zip(xs, outs))],
                  ops.TN)
     torch.cuda.synchronize()
-    assert _lib.load().isc_h3_launches() - n0 == 1                     # one GEMM launch for the three problems
+    assert _lib.load().isc_h3_launches() - n0 == launches              # one GEMM launch (per K chunk) for the three problems
     single = [torch.empty(M, x.shape[1], device=dev()) for x in xs]
     single[2].copy_(prior)
     for i, (x, o) in enumerate(zip(xs, single)):
@@ -508,5 +509,5 @@ def test_dw_contractions_that_share_their_dy_split_it_once():
     torch.cuda.synchronize()
     for i, (a, b, x) in enumerate(zip(outs, single, xs)):
         ref = dy.double().cpu().t() @ x.double().cpu() + (prior.double().cpu() if i == 2 else 0.0)
-        np.testing.assert_allclose(a.cpu().numpy(), ref.float().numpy(), atol=3e-6, rtol=1e-5)
-        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), atol=1e-6, rtol=1e-6)
+        np.testing.assert_allclose(a.cpu().numpy(), ref.float().numpy(), atol=6e-6, rtol=1e-5)
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), atol=2e-6, rtol=2e-6)
