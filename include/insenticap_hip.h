@@ -731,6 +731,24 @@ int isc_logsoftmax_bwd_sparse(const float *dlogp_dense, const float *logp, int64
  * t*out_step_rows + b (a merged unroll's d logits hold both branches' rows per step; dlogits then points at this
  * branch's first row). */
 
+/* The criteria on RAW logits (training iterations that never materialise the [B,T,V] log-probs, captioner.py:183 + 232):
+ * the criteria read one column per (caption, step) row, and log p(id) = (x[id] - max) - log(sum exp) follows from the raw
+ * logits and the classifier's tile statistics - the same bits isc_logsoftmax_apply_steps would have stored.
+ * Logits row (b,t) at raw + b*ld_b + t*ld_t; statistics row of (b,t) = t*step_rows + b (0 = B); ids / out / coef in
+ * [B,T] order.
+ *   isc_gather_logp_raw:     out[b,t] = log p(ids[b,t]) (* live[t] when given: captioner.py:336 after the early break)
+ *   isc_xe_loss_tokens_fwd:  XECriterion on such per-token log-probs: out2 = { -sum_{t < len_b} tlp[b,t], count }
+ *   isc_logsoftmax_bwd_raw:  d logits (time-major rows t*out_step_rows + b, zero-padded to ld_out) from up to
+ *                            ISC_SPARSE_MAX (ids, coef) pairs, as isc_logsoftmax_bwd_sparse forms it from stored log-probs. */
+int isc_gather_logp_raw(const float *raw, int64_t ld_b, int64_t ld_t, int B, int T, int V, const float *part_max,
+                        const float *part_sum, int step_rows, const int64_t *ids, const float *live, float *out,
+                        void *stream);
+int isc_xe_loss_tokens_fwd(const float *tlp, const int32_t *lengths, int B, int T, float *out2, void *stream);
+int isc_logsoftmax_bwd_raw(const float *raw, int64_t ld_b, int64_t ld_t, int B, int T, int V, const float *part_max,
+                           const float *part_sum, int step_rows, const int64_t *const *ids_host,
+                           const float *const *coef_host, int n_sparse, const float *scale, float *dlogits, int64_t ld_out,
+                           int out_step_rows, void *stream);
+
 /* Power-of-two gradient scale for a backward sweep whose contractions run on the split-f16 engine: out4[0..1] = { S, 1/S },
  * S = 2^k with max |x| over the given tensors (HOST arrays of device pointers / element counts, <= ISC_SCALE_SRC_MAX)
  * brought into [2^-4, 2^-3); S = 1 when they are all zero.  out4[2..3] are state words of the multi-workgroup reduction:

@@ -238,6 +238,12 @@ SIGNATURES = {
     'isc_logsoftmax_bwd_sparse': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int,
                                             C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int, C.c_void_p,
                                             C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
+    'isc_gather_logp_raw': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                      C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'isc_xe_loss_tokens_fwd': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    'isc_logsoftmax_bwd_raw': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                         C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int, C.c_void_p,
+                                         C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
     'isc_grad_scale': (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_int, C.c_void_p, C.c_void_p]),
     'isc_splitk_workspace_bytes': (C.c_int64, [C.c_int64, C.c_int64]),
     'isc_h3_weights_workspace_bytes': (C.c_int64, [C.c_int64, C.c_int]),

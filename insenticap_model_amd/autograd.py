@@ -35,12 +35,16 @@ def _pad32(v):
 
 
 # ------------------------------------------------------------------------------ forward
-def _train_forward(cap, mode, fc, att, cpt_words, senti_words, tokens_in, senti_labels, ss_prob, masks):
+def _train_forward(cap, mode, fc, att, cpt_words, senti_words, tokens_in, senti_labels, ss_prob, masks, lazy=None):
     """Returns (logp [B,T,V], S). tokens_in [B,T]: ground-truth inputs (column 0 = <SOS>) - or, for the sampled
     roll-out with gradients, a dict {'T', 'u' (uniforms [B,T]) or 'forced' (raw draws [B,T])}: every step then
     draws its own next token on the device (isc_rollout_finalize) while the activations the backward pass
     needs are kept, so sampling and the differentiable forward are ONE unroll (captioner.py:290-349 does the
-    same inside autograd).  The draws land in S.sample = (seq, masks, raw, alive)."""
+    same inside autograd).  The draws land in S.sample = (seq, masks, raw, alive).
+    lazy: None, or the [B,T] int64 ids whose log-probs the caller's criterion reads (XECriterion's targets; True for the
+    sampled roll-out: its own draws): the [B,T,V] log-probs are then NOT formed - the first return value is log p(id)
+    [B,T] straight from the raw logits + tile statistics (isc_gather_logp_raw; the bits the tensor would have held), and
+    the backward recomputes the softmax term from them (isc_logsoftmax_bwd_raw)."""
     p = cap._p()
     P = cap._prologue(p, mode, fc, att, cpt_words, senti_words, senti_labels, masks)
     st = cap.settings
@@ -72,7 +76,8 @@ def _train_forward(cap, mode, fc, att, cpt_words, senti_words, tokens_in, senti_
     # forms read a step's RAW logits with its statistics (20 + 20 + 20 normalising launches per RL iteration -> 3)
     pm_st, ps_st = new(T, B, n_tile), new(T, B, n_tile)
     pi_st = new(T, B, n_tile, dtype=torch.int32)
-    out = new(B, T, V)
+    fed_known_ = not sampling and not (cap.training and ss_prob > 0.0)
+    out = None if (lazy is not None and fed_known_) else new(B, T, V)     # (lazy + every fed token known: raw logits only)
     emb = p['word_embed.0.weight']
     plan = cap._make_plan(p, P, B)
     if sampling:
@@ -86,7 +91,7 @@ def _train_forward(cap, mode, fc, att, cpt_words, senti_words, tokens_in, senti_
         rs = RolloutStep()
         rs.B, rs.V, rs.T, rs.n_tile, rs.W = B, V, T, n_tile, Wd
         rs.part_max, rs.part_sum, rs.part_idx = pm_st[0].data_ptr(), ps_st[0].data_ptr(), pi_st[0].data_ptr()
-        rs.ld_logits = out.stride(0)
+        rs.ld_logits = out.stride(0)          # (sampling: `out` always exists - every step's draw reads its raw logits)
         rs.forced, rs.sample_u, rs.eos_id = ops.ptr(forced), ops.ptr(sample_u), cap.eos_id
         rs.seq, rs.seq_logprobs, rs.seq_masks = seq.data_ptr(), seq_lp.data_ptr(), seq_masks.data_ptr()
         rs.unfinished, rs.alive, rs.raw_tokens = unfinished.data_ptr(), alive.data_ptr(), raw.data_ptr()
@@ -145,19 +150,38 @@ def _train_forward(cap, mode, fc, att, cpt_words, senti_words, tokens_in, senti_
                 rs.part_max, rs.part_sum, rs.part_idx = pm_st[t].data_ptr(), ps_st[t].data_ptr(), pi_st[t].data_ptr()
                 rs.xt_next = S.xt[t + 1].data_ptr() if t + 1 < T else None
                 ops.rollout_finalize(rs)
+        S.lazy = None
         if pm_all is not None:
             hs = S.hdrop if S.hdrop is not None else S.h2[1:]
-            raw = new(T, B, V)
+            rawl = new(T, B, V)
             ops.vocab_fwd(hs.reshape(T * B, H), p['classifier.weight'], p['classifier.bias'], pm_all.view(T * B, n_tile),
-                          ps_all.view(T * B, n_tile), pi_all.view(T * B, n_tile), raw.view(T * B, V))
-            ops.logsoftmax_apply_steps(out, pm_all, ps_all, src_tbv=raw)
-            del raw
+                          ps_all.view(T * B, n_tile), pi_all.view(T * B, n_tile), rawl.view(T * B, V))
+            if lazy is not None:
+                S.lazy = (rawl, V, B * V)                     # raw logits time-major: row (b,t) at b*V + t*B*V
+            else:
+                ops.logsoftmax_apply_steps(out, pm_all, ps_all, src_tbv=rawl)
+            del rawl
+        elif lazy is not None:
+            S.lazy = (out, out.stride(0), out.stride(1))      # raw logits [B,T,V]: row (b,t) at b*T*V + t*V
         else:
             ops.logsoftmax_apply_steps(out, pm_st, ps_st)     # in place: [B,T,V] raw logits -> log-probs
     if sampling:
         S.sample = (seq, seq_masks, raw, alive)
     cap._set_weights(S.aC if has_c else None, S.aS if has_s else None,
                      S.bG if (has_c and has_s) else None, T)
+    if S.lazy is not None:
+        S.pm, S.ps = pm_st, ps_st
+        S.lazy_live = None
+        if sampling:      # log p(drawn token) * live (captioner.py:336; zero after the reference's early break)
+            S.lazy_ids = raw
+            S.lazy_live = (alive[:T] > 0).to(torch.float32)
+        else:
+            S.lazy_ids = lazy.contiguous()
+        tlp = new(B, T)
+        rl, ld_b, ld_t = S.lazy
+        ops.gather_logp_raw(rl, ld_b, ld_t, B, T, V, pm_st, ps_st, B, S.lazy_ids, tlp, live=S.lazy_live)
+        S.logp = None
+        return tlp, S
     S.logp = out
     return out, S
 
@@ -213,6 +237,10 @@ def _backward(cap, S, dlogp, d_fc_feats, d_cpt_feats, sparse=()):
             d_cpt_feats = d_cpt_feats * gs[0]
     if dlogp is None and not sparse:
         dlogits.zero_()
+    elif getattr(S, 'lazy', None) is not None:               # the log-probs were never formed: softmax from raw logits + stats
+        rl, ld_b, ld_t = S.lazy
+        ops.logsoftmax_bwd_raw(rl, ld_b, ld_t, B, T, V, S.pm, S.ps, B, list(sparse), dlogits,
+                               scale=gs[0:1] if gs is not None else None, out_step_rows=B)
     else:
         ops.logsoftmax_bwd_sparse(dlogp, S.logp, list(sparse), dlogits, B * T, V, remap_T=T,
                                   scale=gs[0:1] if gs is not None else None)
@@ -485,10 +513,10 @@ class DecodeFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, cap, mode, fc, att, cpt_words, senti_words, tokens_in, senti_labels, ss_prob, masks,
-                names, *params):
+                names, lazy, *params):
         with torch.no_grad():
             logp, S = _train_forward(cap, mode, fc, att, cpt_words, senti_words, tokens_in, senti_labels,
-                                     ss_prob, masks)
+                                     ss_prob, masks, lazy)
         S.P.fc_pre = cap.fc_feats if mode != 'seq2seq' else None
         S.P.cpt_pre = cap.cpt_feats
         cap._last_sample = getattr(S, 'sample', None)
@@ -508,18 +536,28 @@ class DecodeFn(torch.autograd.Function):
         cap, S = ctx.cap, ctx.S
         sparse, ctx._isc_sparse = ctx._isc_sparse, []
         with torch.no_grad():
+            if getattr(S, 'lazy', None) is not None:         # dlogp is d log p(id) [B,T]: one column per row
+                if dlogp is not None:
+                    coef = dlogp.contiguous() if S.lazy_live is None else (dlogp * S.lazy_live).contiguous()
+                    sparse, dlogp = [(S.lazy_ids, coef)], None
             G = _backward(cap, S, dlogp.contiguous() if dlogp is not None else None, d_fc, d_cpt, sparse)
         grads = tuple(G.get(n) for n in ctx.names)
         ctx.S = None
-        return (None,) * 11 + grads
+        return (None,) * 12 + grads
 
 
-def xe_with_grad(cap, mode, fc, att, cpt_words, senti_words, captions, senti_labels, ss_prob, masks):
+def xe_with_grad(cap, mode, fc, att, cpt_words, senti_words, captions, senti_labels, ss_prob, masks, targets=None):
     names = [n for n, q in cap.named_parameters() if q.requires_grad]
     params = [q for _, q in cap.named_parameters() if q.requires_grad]
-    tokens_in = cap._ids(captions)[:, :-1].contiguous()
+    ids = cap._ids(captions)
+    tokens_in = ids[:, :-1].contiguous()
+    # inside `with captioner.token_logprobs():` (the package's own training steps) the call returns log p(target) [B,T]
+    # instead of the [B,T,V] log-probs - XECriterion takes either (captioner.py:427-440 reads one column per row)
+    lazy = None
+    if cap.__dict__.get('_token_logprobs'):
+        lazy = ids[:, 1:].contiguous() if targets is None else cap._ids(targets).contiguous()
     outs = DecodeFn.apply(cap, mode, fc, att, cpt_words, senti_words, tokens_in, senti_labels, ss_prob, masks,
-                          names, *params)
+                          names, lazy, *params)
     logp = outs[0]
     cap.cpt_feats = outs[1]
     if mode != 'seq2seq':
@@ -540,15 +578,15 @@ def rollout_with_grad(cap, fc, att, cpt_words, senti_words, senti_labels, T, rep
     else:
         draws['u'] = torch.rand(B, T, device=cap._dev)
     was = cap.training
+    # the roll-out's [B,T,V] log-probs are never an API output (captioner.py:336 keeps log p(drawn token) only): the
+    # decode node returns that column - already times `live` - from the raw logits (lazy = True; DecodeFn.backward)
     outs = DecodeFn.apply(cap, 'rl', fc, att, cpt_words, senti_words, draws, senti_labels, 0.0,
-                          masks, names, *params)
+                          masks, names, True, *params)
     cap.train(was)
-    logp = outs[0]
+    lp = outs[0]
     cap.cpt_feats, cap.fc_feats = outs[1], outs[2]
     seq, seq_masks, raw, alive = cap._last_sample
     cap._last_sample = None
-    live = (alive[:T] > 0).to(logp.dtype)    # step t ran iff some row was unfinished before it: zero after the early break
-    lp = GatherLogpFn.apply(logp, raw, live, _decode_node(logp))
     return seq, lp, seq_masks
 
 
@@ -616,9 +654,31 @@ class XELossFn(torch.autograd.Function):
         return dlogp, None, None, None
 
 
+class XETokenLossFn(torch.autograd.Function):
+    """XECriterion (captioner.py:427-440) on per-token log-probs tlp [B,T] = log p(target) (Captioner.token_logprobs):
+    the same masked mean, the same summation order as on the [B,T,V] tensor."""
+
+    @staticmethod
+    def forward(ctx, tlp, lengths_i32):
+        out2 = torch.empty(2, dtype=torch.float32, device=tlp.device)
+        ops.xe_loss_tokens_fwd(tlp, lengths_i32, out2)
+        ctx.save_for_backward(lengths_i32, out2)
+        ctx.shape = tlp.shape
+        return out2[0] / out2[1]
+
+    @staticmethod
+    def backward(ctx, g):
+        lengths_i32, out2 = ctx.saved_tensors
+        coef = torch.empty(ctx.shape, dtype=torch.float32, device=out2.device)
+        ops.xe_loss_bwd_sparse(lengths_i32, ctx.shape[1], g.reshape(1).contiguous().float(), out2, coef)
+        return coef, None
+
+
 def xe_criterion_with_grad(pred, target, lengths):
     ops.require_device(pred, target)
     ln = ops.upload(lengths, torch.int32, pred.device)
+    if pred.dim() == 2:                 # log p(target) [B,T] of a call inside Captioner.token_logprobs()
+        return XETokenLossFn.apply(pred.contiguous(), ln)
     node = _decode_node(pred) if pred.is_contiguous() else None
     return XELossFn.apply(pred.contiguous(), target.long().contiguous(), ln, node)
 

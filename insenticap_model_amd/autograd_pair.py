@@ -70,9 +70,11 @@ class _Fill:
 
 
 # ------------------------------------------------------------------------------ forward
-def _pair_forward(cap, xe, s2s):
+def _pair_forward(cap, xe, s2s, lazy=None):
     """xe = (fc, att, cpt_words, tokens_in [B1,T1], senti_labels, ss_prob, masks); s2s = (cpt_words, senti_words,
-    tokens_in [B2,T2], senti_labels, ss_prob, masks).  Returns (logp1 [B1,T1,V], logp2 [B2,T2,V], S)."""
+    tokens_in [B2,T2], senti_labels, ss_prob, masks).  Returns (logp1 [B1,T1,V], logp2 [B2,T2,V], S) - or, with
+    lazy = (targets1 [B1,T1], targets2 [B2,T2]) (Captioner.token_logprobs), log p(target) [B1,T1] / [B2,T2] straight from
+    the raw logits: the two [B,T,V] log-prob tensors are then never formed (autograd._train_forward, `lazy`)."""
     p = cap._p()
     st = cap.settings
     E, A, H, Wd, V = st['feat_emb_dim'], st['att_hid_dim'], st['rnn_hid_dim'], st['word_emb_dim'], cap.vocab_size
@@ -105,7 +107,7 @@ def _pair_forward(cap, xe, s2s):
     n_tile = (V + 127) // 128
     pm, ps = new(T, Bt, n_tile), new(T, Bt, n_tile)
     pi = new(T, Bt, n_tile, dtype=torch.int32)
-    out1, out2 = new(B1, T1, V), new(B2, T2, V)
+    out1, out2 = (new(B1, T1, V), new(B2, T2, V)) if lazy is None else (new(B1, T1), new(B2, T2))
     raw = new(T, Bt, V)                       # raw logits, time-major: normalised per branch after the last step
     emb = p['word_embed.0.weight']
 
@@ -210,8 +212,14 @@ def _pair_forward(cap, xe, s2s):
             hs = S.hdrop if S.hdrop is not None else S.h2[1:]
             ops.vocab_fwd(hs.reshape(T * Bt, H), p['classifier.weight'], p['classifier.bias'], pm.view(T * Bt, n_tile),
                           ps.view(T * Bt, n_tile), pi.view(T * Bt, n_tile), raw.view(T * Bt, V))
-        ops.logsoftmax_apply_steps(out1, pm[:T1, :B1], ps[:T1, :B1], src_tbv=raw[:T1, :B1], step_rows=Bt)
-        ops.logsoftmax_apply_steps(out2, pm[:T2, B1:], ps[:T2, B1:], src_tbv=raw[:T2, B1:], step_rows=Bt)
+        S.lazy = None
+        if lazy is None:
+            ops.logsoftmax_apply_steps(out1, pm[:T1, :B1], ps[:T1, :B1], src_tbv=raw[:T1, :B1], step_rows=Bt)
+            ops.logsoftmax_apply_steps(out2, pm[:T2, B1:], ps[:T2, B1:], src_tbv=raw[:T2, B1:], step_rows=Bt)
+        else:                                  # log p(target) per row from the raw logits; the backward reads them again
+            S.lazy = (raw, pm, ps, lazy[0].contiguous(), lazy[1].contiguous())
+            ops.gather_logp_raw(raw, V, Bt * V, B1, T1, V, pm, ps, Bt, S.lazy[3], out1)
+            ops.gather_logp_raw(raw[0, B1:], V, Bt * V, B2, T2, V, pm[0, B1:], ps[0, B1:], Bt, S.lazy[4], out2)
     del raw
     # the state the reference's attributes are in after its second call (forward_seq2seq): sentiment weights only
     cap._set_weights(None, S.aS, None, T2)
@@ -302,12 +310,21 @@ def _pair_backward(cap, S, d1, d2, sparse1, sparse2, d_fc_feats1, d_cpt_feats1, 
     Vp = _pad32(V)
     idle1, idle2 = d1 is None and not sparse1, d2 is None and not sparse2
     dlogits = zeros(TB, Vp) if (ragged or idle1 or idle2) else new(TB, Vp)
-    if not idle1:
-        ops.logsoftmax_bwd_sparse(d1, S.logp1, list(sparse1), dlogits, B1 * T1, V, remap_T=T1, scale=scale,
-                                  out_step_rows=Bt)
-    if not idle2:
-        ops.logsoftmax_bwd_sparse(d2, S.logp2, list(sparse2), dlogits[B1:], B2 * T2, V, remap_T=T2, scale=scale,
-                                  out_step_rows=Bt)
+    if S.lazy is not None:                     # d1 / d2 arrived as [B,T] coefficients of the target columns (DecodePairFn)
+        raw, pm, ps = S.lazy[:3]
+        if not idle1:
+            ops.logsoftmax_bwd_raw(raw, V, Bt * V, B1, T1, V, pm, ps, Bt, list(sparse1), dlogits, scale=scale,
+                                   out_step_rows=Bt)
+        if not idle2:
+            ops.logsoftmax_bwd_raw(raw[0, B1:], V, Bt * V, B2, T2, V, pm[0, B1:], ps[0, B1:], Bt, list(sparse2),
+                                   dlogits[B1:], scale=scale, out_step_rows=Bt)
+    else:
+        if not idle1:
+            ops.logsoftmax_bwd_sparse(d1, S.logp1, list(sparse1), dlogits, B1 * T1, V, remap_T=T1, scale=scale,
+                                      out_step_rows=Bt)
+        if not idle2:
+            ops.logsoftmax_bwd_sparse(d2, S.logp2, list(sparse2), dlogits[B1:], B2 * T2, V, remap_T=T2, scale=scale,
+                                      out_step_rows=Bt)
     Wc = p['classifier.weight']
     hdrop_tb = (S.hdrop if S.hdrop is not None else S.h2[1:]).reshape(TB, H)
     dhd = new(TB, H)
@@ -561,9 +578,9 @@ class DecodePairFn(torch.autograd.Function):
     LOGP_SLOTS = (0, 3)          # output numbers of the two log-prob tensors (the criteria's sparse side channels)
 
     @staticmethod
-    def forward(ctx, cap, xe, s2s, names, *params):
+    def forward(ctx, cap, xe, s2s, names, lazy, *params):
         with torch.no_grad():
-            out1, out2, S = _pair_forward(cap, xe, s2s)
+            out1, out2, S = _pair_forward(cap, xe, s2s, lazy)
         ctx.cap, ctx.S, ctx.names = cap, S, names
         ctx._isc_sparse = {0: [], 3: []}          # per log-prob output (autograd.sparse_channel)
         ctx.set_materialize_grads(False)
@@ -574,23 +591,32 @@ class DecodePairFn(torch.autograd.Function):
         cap, S = ctx.cap, ctx.S
         sp, ctx._isc_sparse = ctx._isc_sparse, {0: [], 3: []}
         with torch.no_grad():
+            if S.lazy is not None:             # d1 / d2 = d log p(target) [B,T]: one column per row
+                if d1 is not None:
+                    sp[0], d1 = [(S.lazy[3], d1.contiguous())], None
+                if d2 is not None:
+                    sp[3], d2 = [(S.lazy[4], d2.contiguous())], None
             G = _pair_backward(cap, S, d1.contiguous() if d1 is not None else None,
                                d2.contiguous() if d2 is not None else None, sp[0], sp[3], d_fc1, d_cpt1, d_cpt2)
         ctx.S = None
-        return (None,) * 4 + tuple(G.get(n) for n in ctx.names)
+        return (None,) * 5 + tuple(G.get(n) for n in ctx.names)
 
 
 def pair_with_grad(cap, fc, att, cpt_words, captions, senti_labels, ss_prob, s_captions, s_cpt_words, s_senti_words,
-                   s_senti_labels, s_ss_prob, masks, s_masks):
+                   s_senti_labels, s_ss_prob, masks, s_masks, targets=None, s_targets=None):
     """forward_xe + forward_seq2seq of one iteration through one step chain.  Returns (logp_xe, logp_s2s, cpt_feats of
     the seq2seq call); captioner.fc_feats / .cpt_feats are left as the XE call leaves them (what the domain-align loss
     reads, train_xe.py:163)."""
     names = [n for n, q in cap.named_parameters() if q.requires_grad]
     params = [q for _, q in cap.named_parameters() if q.requires_grad]
-    tok1 = cap._ids(captions)[:, :-1].contiguous()
-    tok2 = cap._ids(s_captions)[:, :-1].contiguous()
+    ids1, ids2 = cap._ids(captions), cap._ids(s_captions)
+    tok1, tok2 = ids1[:, :-1].contiguous(), ids2[:, :-1].contiguous()
     xe = (fc, att, cpt_words, tok1, senti_labels, float(ss_prob), masks)
     s2s = (s_cpt_words, s_senti_words, tok2, s_senti_labels, float(s_ss_prob), s_masks)
-    outs = DecodePairFn.apply(cap, xe, s2s, names, *params)
+    lazy = None
+    if cap.__dict__.get('_token_logprobs'):
+        lazy = (ids1[:, 1:].contiguous() if targets is None else cap._ids(targets).contiguous(),
+                ids2[:, 1:].contiguous() if s_targets is None else cap._ids(s_targets).contiguous())
+    outs = DecodePairFn.apply(cap, xe, s2s, names, lazy, *params)
     cap.cpt_feats, cap.fc_feats = outs[1], outs[2]
     return outs[0], outs[3], outs[4]

@@ -676,27 +676,50 @@ class Captioner(nn.Module):
         self._set_weights(aC, aS, bG, T)
         return out
 
-    def forward_xe(self, fc_feats, att_feats, cpt_words, captions, senti_labels, ss_prob=0.0, _masks=None):
+    def token_logprobs(self, on=True):
+        """`with captioner.token_logprobs():` - teacher-forced calls WITH gradients (`forward_xe`, `forward_seq2seq`,
+        `forward_xe_seq2seq`) return log p(target) [B,T] (targets = captions[:, 1:], what XECriterion gathers:
+        captioner.py:427-440) instead of the [B,T,V] log-probs, and `XECriterion` takes that tensor.  The [B,T,V] tensor
+        is then never written or read in the iteration - forward or backward (0.56 ms of 15.6 at B = 1024) - and the loss
+        and every gradient keep their bits: log p comes from the raw logits by the expression the tensor would have been
+        stored with.  The package's own training steps (train.py, train_graph.py, Detector.forward) run inside it; the
+        reference's call surface (a caller that wants `pred`) is untouched outside."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def scope():
+            prev = self.__dict__.get('_token_logprobs')
+            self.__dict__['_token_logprobs'] = bool(on) and getattr(self, 'fused_criteria', True)
+            try:
+                yield self
+            finally:
+                self.__dict__['_token_logprobs'] = prev
+        return scope()
+
+    def forward_xe(self, fc_feats, att_feats, cpt_words, captions, senti_labels, ss_prob=0.0, _masks=None, _targets=None):
+        """(_targets: test hook for token_logprobs() - the criterion's targets when `captions` carries replayed FED tokens
+        instead of the ground truth; default captions[:, 1:].)"""
         if self._needs_grad():
             from .autograd import xe_with_grad
             return xe_with_grad(self, 'xe', fc_feats, att_feats, cpt_words, None, captions, senti_labels,
-                                ss_prob, _masks)
+                                ss_prob, _masks, _targets)
         p = self._p()
         P = self._prologue(p, 'xe', fc_feats, att_feats, cpt_words, None, senti_labels, _masks)
         return self._teacher_forced(p, P, self._ids(captions)[:, :-1], ss_prob, _masks)
 
-    def forward_seq2seq(self, senti_captions, cpt_words, senti_words, senti_labels, ss_prob=0.0, _masks=None):
+    def forward_seq2seq(self, senti_captions, cpt_words, senti_words, senti_labels, ss_prob=0.0, _masks=None,
+                        _targets=None):
         if self._needs_grad():
             from .autograd import xe_with_grad
             return xe_with_grad(self, 'seq2seq', None, None, cpt_words, senti_words, senti_captions,
-                                senti_labels, ss_prob, _masks)
+                                senti_labels, ss_prob, _masks, _targets)
         p = self._p()
         P = self._prologue(p, 'seq2seq', None, None, cpt_words, senti_words, senti_labels, _masks)
         return self._teacher_forced(p, P, self._ids(senti_captions)[:, :-1], ss_prob, _masks)
 
     def forward_xe_seq2seq(self, fc_feats, att_feats, cpt_words, captions, senti_labels, ss_prob,
                            s_captions, s_cpt_words, s_senti_words, s_senti_labels, s_ss_prob=None,
-                           _masks=None, _s_masks=None):
+                           _masks=None, _s_masks=None, _targets=None, _s_targets=None):
         """`forward_xe(...)` and `forward_seq2seq(...)` of ONE training iteration (train_xe.py:160-181,
         models/decoder.py:138-157) as one call: returns (pred, pred2), leaves `fc_feats` / `cpt_feats` as the XE call
         leaves them (the domain-align loss reads them right after it, train_xe.py:163) and the seq2seq call's
@@ -708,11 +731,13 @@ class Captioner(nn.Module):
         if self._needs_grad() and self.pair_unrolls is not False and pair_applicable(self, _masks, _s_masks):
             pred, pred2, self.s2s_cpt_feats = pair_with_grad(
                 self, fc_feats, att_feats, cpt_words, captions, senti_labels, ss_prob, s_captions, s_cpt_words,
-                s_senti_words, s_senti_labels, s_ss_prob, _masks, _s_masks)
+                s_senti_words, s_senti_labels, s_ss_prob, _masks, _s_masks, _targets, _s_targets)
             return pred, pred2
-        pred = self.forward_xe(fc_feats, att_feats, cpt_words, captions, senti_labels, ss_prob, _masks=_masks)
+        pred = self.forward_xe(fc_feats, att_feats, cpt_words, captions, senti_labels, ss_prob, _masks=_masks,
+                               _targets=_targets)
         keep = (self.fc_feats, self.cpt_feats)
-        pred2 = self.forward_seq2seq(s_captions, s_cpt_words, s_senti_words, s_senti_labels, s_ss_prob, _masks=_s_masks)
+        pred2 = self.forward_seq2seq(s_captions, s_cpt_words, s_senti_words, s_senti_labels, s_ss_prob, _masks=_s_masks,
+                                     _targets=_s_targets)
         self.s2s_cpt_feats = self.cpt_feats
         self.fc_feats, self.cpt_feats = keep
         return pred, pred2

@@ -115,6 +115,72 @@ extern "C" int isc_logsoftmax_bwd_sparse(const float *dlogp_dense, const float *
     return ISC_OK;
 }
 
+// The same gradient from the RAW logits and their tile statistics (isc_gather_logp_raw's counterpart: the training
+// iteration that never wrote the [B,T,V] log-probs): exp(logp) = exp((x - max) - log(sum)), the expression the log-probs
+// would have been stored with - the same d logits bits.  Rows in [B,T] order for ids / coef; logits row (b,t) at
+// b*ld_b + t*ld_t, statistics row t*step_rows + b, output row t*out_step_rows + b (time-major).
+__global__ __launch_bounds__(256) void logsoftmax_bwd_raw_kernel(const float *raw, long long ld_b, long long ld_t, int B, int T,
+                                                                 int V, const float *pmax, const float *psum, int n_tile,
+                                                                 int step_rows, SparseDlogp sp, const float *scale,
+                                                                 float *dlogits, long long ld_out, int out_step_rows) {
+    __shared__ float sh[2];
+    const int mi = blockIdx.x, tid = threadIdx.x;
+    const int b = mi / T, t = mi - b * T;
+    const long long ms = (long long)t * step_rows + b;
+    if (tid < 64) {
+        float gmax, S;
+        int gi;
+        fold_row_stats_impl(pmax + ms * n_tile, psum + ms * n_tile, nullptr, n_tile, tid, gmax, gi, S);
+        if (tid == 0) { sh[0] = gmax; sh[1] = logf(S); }
+    }
+    __syncthreads();
+    const float gmax = sh[0], logS = sh[1];
+    const float sc = scale ? scale[0] : 1.f;
+    float tot = 0.f;
+    long long id[ISC_SPARSE_MAX];
+    float cf[ISC_SPARSE_MAX];
+#pragma unroll
+    for (int j = 0; j < ISC_SPARSE_MAX; ++j) {
+        id[j] = -1; cf[j] = 0.f;
+        if (j < sp.n) { id[j] = sp.ids[j][mi]; cf[j] = sp.coef[j][mi]; tot += cf[j]; }
+    }
+    const float *y = raw + (long long)b * ld_b + (long long)t * ld_t;
+    float *o = dlogits + ((long long)t * out_step_rows + b) * ld_out;
+    for (int i = tid; i < ld_out; i += 256) {
+        float v = 0.f;
+        if (i < V) {
+#pragma unroll
+            for (int j = 0; j < ISC_SPARSE_MAX; ++j)
+                if ((long long)i == id[j]) v += cf[j];
+            v = (v - expf((y[i] - gmax) - logS) * tot) * sc;
+        }
+        o[i] = v;
+    }
+}
+
+extern "C" int isc_logsoftmax_bwd_raw(const float *raw, int64_t ld_b, int64_t ld_t, int B, int T, int V, const float *part_max,
+                                      const float *part_sum, int step_rows, const int64_t *const *ids_host,
+                                      const float *const *coef_host, int n_sparse, const float *scale, float *dlogits,
+                                      int64_t ld_out, int out_step_rows, void *stream) {
+    if (!raw || !part_max || !part_sum || !dlogits) return ISC_E_NULL;
+    if (B <= 0 || T <= 0 || V <= 0 || ld_out < V || (long long)B * T > 2147483647LL) return ISC_E_SHAPE;
+    if (n_sparse < 1 || n_sparse > ISC_SPARSE_MAX) return ISC_E_SHAPE;
+    if (step_rows == 0) step_rows = B;
+    if (out_step_rows == 0) out_step_rows = B;
+    if (step_rows < B || out_step_rows < B) return ISC_E_SHAPE;
+    SparseDlogp sp = {};
+    sp.n = n_sparse;
+    for (int j = 0; j < n_sparse; ++j) {
+        if (!ids_host || !coef_host || !ids_host[j] || !coef_host[j]) return ISC_E_NULL;
+        sp.ids[j] = ids_host[j]; sp.coef[j] = coef_host[j];
+    }
+    hipLaunchKernelGGL(logsoftmax_bwd_raw_kernel, dim3((unsigned)(B * T)), dim3(256), 0, (hipStream_t)stream, raw,
+                       (long long)ld_b, (long long)ld_t, B, T, V, part_max, part_sum, (V + 127) / 128, step_rows, sp, scale,
+                       dlogits, (long long)ld_out, out_step_rows);
+    ISC_LAUNCH_CHECK();
+    return ISC_OK;
+}
+
 // Power-of-two gradient scale ("loss scaling" for the split-f16 backward contractions).  The backward pass is linear
 // in the gradients that enter it, and those are small - a token-mean loss hands in |d log-prob| <= 1/N_tokens, 5e-5 at
 // B = 1024 - i.e. below the f16 normal range (2^-14), where the hi plane of x = hi + lo 2^-11 holds subnormals and an

@@ -1210,5 +1210,75 @@ extern "C" int isc_xe_loss_fwd(const float *logp, const int64_t *target, const i
     return ISC_OK;
 }
 
+// ------------------------------------------------------------------ criteria on RAW logits (training: no [B,T,V] log-probs)
+// The criteria of this path read ONE column per (caption, step) row - XECriterion the target (captioner.py:427-440), the
+// REINFORCE term the drawn token (captioner.py:336).  log p(id) = (x[id] - max) - log(sum exp) comes straight from the raw
+// logits and the classifier's tile statistics: the [B,T,V] log-prob tensor (F.log_softmax at captioner.py:183 over every
+// step) is then never written or read in a training iteration (0.56 ms of a 15.6 ms iteration at B = 1024).  Same
+// expression as logsoftmax_apply_steps_kernel: the values are the bits that tensor would have held.
+// One wave per row; rows in [B,T] order (ids / out), logits row (b,t) at b*ld_b + t*ld_t, statistics row t*step_rows + b.
+__global__ __launch_bounds__(256) void gather_logp_raw_kernel(const float *raw, long long ld_b, long long ld_t, int B, int T,
+                                                              const float *pmax, const float *psum, int n_tile,
+                                                              int step_rows, const int64_t *ids, const float *live,
+                                                              float *out) {
+    const int lane = threadIdx.x & 63;
+    const int mi = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (mi >= B * T) return;
+    const int b = mi / T, t = mi - b * T;
+    const long long ms = (long long)t * step_rows + b;
+    float gmax, S;
+    int gi;
+    fold_row_stats(pmax + ms * n_tile, psum + ms * n_tile, nullptr, n_tile, lane, gmax, gi, S);
+    if (lane == 0) {
+        const float x = raw[(long long)b * ld_b + (long long)t * ld_t + ids[mi]];
+        const float lp = (x - gmax) - logf(S);
+        out[mi] = live ? lp * live[t] : lp;
+    }
+}
+
+extern "C" int isc_gather_logp_raw(const float *raw, int64_t ld_b, int64_t ld_t, int B, int T, int V, const float *part_max,
+                                   const float *part_sum, int step_rows, const int64_t *ids, const float *live, float *out,
+                                   void *stream) {
+    if (!raw || !part_max || !part_sum || !ids || !out) return ISC_E_NULL;
+    if (B <= 0 || T <= 0 || V <= 0 || (long long)B * T > 2147483647LL) return ISC_E_SHAPE;
+    if (step_rows == 0) step_rows = B;
+    if (step_rows < B) return ISC_E_SHAPE;
+    hipLaunchKernelGGL(gather_logp_raw_kernel, dim3((unsigned)((B * T + 3) / 4)), dim3(256), 0, (hipStream_t)stream, raw,
+                       (long long)ld_b, (long long)ld_t, B, T, part_max, part_sum, (V + 127) / 128, step_rows, ids, live, out);
+    ISC_LAUNCH_CHECK();
+    return ISC_OK;
+}
+
+// XECriterion on per-token log-probs tlp [B,T] = log p(target): out2 = { -sum_{t < len_b} tlp, count }.  The summation
+// order of xe_loss_kernel (single workgroup, thread-strided) - the same loss bits.
+__global__ __launch_bounds__(256) void xe_loss_tokens_kernel(const float *tlp, const int *lengths, int B, int T, float *out2) {
+    __shared__ float ss[4], sn[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float s = 0.f, n = 0.f;
+    for (int i = tid; i < B * T; i += 256) {
+        const int b = i / T, t = i % T;
+        if (t < lengths[b]) {
+            s -= tlp[i];
+            n += 1.f;
+        }
+    }
+    s = wave_sum(s);
+    n = wave_sum(n);
+    if (lane == 0) { ss[wave] = s; sn[wave] = n; }
+    __syncthreads();
+    if (tid == 0) {
+        out2[0] = (ss[0] + ss[1]) + (ss[2] + ss[3]);
+        out2[1] = (sn[0] + sn[1]) + (sn[2] + sn[3]);
+    }
+}
+
+extern "C" int isc_xe_loss_tokens_fwd(const float *tlp, const int32_t *lengths, int B, int T, float *out2, void *stream) {
+    if (!tlp || !lengths || !out2) return ISC_E_NULL;
+    if (B <= 0 || T <= 0) return ISC_E_SHAPE;
+    hipLaunchKernelGGL(xe_loss_tokens_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, tlp, lengths, B, T, out2);
+    ISC_LAUNCH_CHECK();
+    return ISC_OK;
+}
+
 extern "C" int isc_abi_version(void) { return 1; }
 extern "C" const char *isc_target_arch(void) { return "gfx950"; }

@@ -214,8 +214,9 @@ class Detector(nn.Module):
                     (s_caps, s_lengths), s_cpts, s_sentis, s_labels = s2s_batch
                     s_caps, s_cpts = s_caps.to(device), s_cpts.to(device)
                     s_sentis, s_labels = s_sentis.to(device), s_labels.to(device)
-                    pred, pred2 = cap(fc_feats, att_feats, cpts_tensor, caps_tensor, xe_senti_labels, self.xe_ss_prob,
-                                      s_caps, s_cpts, s_sentis, s_labels, self.seq2seq_ss_prob, mode='xe_seq2seq')
+                    with cap.token_logprobs():       # (log p(target) [B,T]: the [B,T,V] log-probs are never formed)
+                        pred, pred2 = cap(fc_feats, att_feats, cpts_tensor, caps_tensor, xe_senti_labels, self.xe_ss_prob,
+                                          s_caps, s_cpts, s_sentis, s_labels, self.seq2seq_ss_prob, mode='xe_seq2seq')
                     xe_loss = share(self.cap_xe_crit(pred, caps_tensor[:, 1:], lengths), w_xe)
                     put('xe_loss', xe_loss)
                     seq2seq_loss = share(self.seq_flag * self.cap_xe_crit(pred2, s_caps[:, 1:], s_lengths), w_s2s)
@@ -224,8 +225,9 @@ class Detector(nn.Module):
                     with torch.no_grad():
                         xe_senti_labels = self.sent_senti_cls(caps_tensor[:, 1:], lengths)[0]
                         xe_senti_labels = xe_senti_labels.softmax(dim=-1).argmax(dim=-1).detach()
-                    pred = cap(fc_feats, att_feats, cpts_tensor, caps_tensor, xe_senti_labels, ss_prob=self.xe_ss_prob,
-                               mode='xe')
+                    with cap.token_logprobs():
+                        pred = cap(fc_feats, att_feats, cpts_tensor, caps_tensor, xe_senti_labels,
+                                   ss_prob=self.xe_ss_prob, mode='xe')
                     xe_loss = share(self.cap_xe_crit(pred, caps_tensor[:, 1:], lengths), w_xe)
                     put('xe_loss', xe_loss)
 
@@ -234,7 +236,8 @@ class Detector(nn.Module):
                     s_caps, s_cpts = s_caps.to(device), s_cpts.to(device)
                     s_sentis, s_labels = s_sentis.to(device), s_labels.to(device)
                     def seq2seq_unroll():                     # 80 text-only rows: a chain of small launches that
-                        pred = cap(s_caps, s_cpts, s_sentis, s_labels, ss_prob=self.seq2seq_ss_prob, mode='seq2seq')
+                        with cap.token_logprobs():
+                            pred = cap(s_caps, s_cpts, s_sentis, s_labels, ss_prob=self.seq2seq_ss_prob, mode='seq2seq')
                         return share(self.seq_flag * self.cap_xe_crit(pred, s_caps[:, 1:], s_lengths), w_s2s)
                     # ... overlaps with the XE unroll queued above when it runs on the side stream (forward and,
                     # through autograd, backward); same numbers either way

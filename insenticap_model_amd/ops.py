@@ -842,6 +842,39 @@ def logsoftmax_bwd_sparse(dense, logp, sparse, dlogits, M, V, remap_T=0, scale=N
           'isc_logsoftmax_bwd_sparse')
 
 
+def gather_logp_raw(raw, ld_b, ld_t, B, T, V, part_max, part_sum, step_rows, ids, out, live=None):
+    """out[b,t] = log p(ids[b,t]) from the RAW logits (row (b,t) at raw + b*ld_b + t*ld_t floats) and the step-stacked
+    tile statistics (row t*step_rows + b) - isc_gather_logp_raw; `live` [T] optionally multiplies column t."""
+    assert ids.dtype == torch.int64 and ids.is_contiguous() and ids.numel() == B * T and out.is_contiguous()
+    assert out.numel() == B * T and out.dtype == torch.float32
+    check(_lib.load().isc_gather_logp_raw(raw.data_ptr(), int(ld_b), int(ld_t), B, T, V, part_max.data_ptr(),
+                                          part_sum.data_ptr(), int(step_rows), ids.data_ptr(), ptr(live), out.data_ptr(),
+                                          stream()), 'isc_gather_logp_raw')
+
+
+def xe_loss_tokens_fwd(tlp, lengths_i32, out2):
+    B, T = tlp.shape
+    assert tlp.is_contiguous() and tlp.dtype == torch.float32
+    check(_lib.load().isc_xe_loss_tokens_fwd(tlp.data_ptr(), lengths_i32.data_ptr(), B, T, out2.data_ptr(), stream()),
+          'isc_xe_loss_tokens_fwd')
+
+
+def logsoftmax_bwd_raw(raw, ld_b, ld_t, B, T, V, part_max, part_sum, step_rows, sparse, dlogits, scale=None,
+                       out_step_rows=0):
+    """isc_logsoftmax_bwd_raw: d logits (time-major rows t*out_step_rows + b of `dlogits`) from (ids, coef) pairs in
+    [B,T] order, the softmax term recomputed from the raw logits and their tile statistics."""
+    n = len(sparse)
+    assert 1 <= n <= 2 and dlogits.stride(1) == 1
+    for i, c in sparse:
+        assert i.dtype == torch.int64 and c.dtype == torch.float32 and i.is_contiguous() and c.is_contiguous()
+        assert i.numel() == B * T and c.numel() == B * T
+    ids = (C.c_void_p * n)(*[i.data_ptr() for i, _ in sparse])
+    cf = (C.c_void_p * n)(*[c.data_ptr() for _, c in sparse])
+    check(_lib.load().isc_logsoftmax_bwd_raw(raw.data_ptr(), int(ld_b), int(ld_t), B, T, V, part_max.data_ptr(),
+                                             part_sum.data_ptr(), int(step_rows), ids, cf, n, ptr(scale), dlogits.data_ptr(),
+                                             dlogits.stride(0), int(out_step_rows), stream()), 'isc_logsoftmax_bwd_raw')
+
+
 def grad_scale(sources, out2):
     """isc_grad_scale: out[0:2] = {S, 1/S}, S the power of two that brings max |x| over `sources` into [2^-4, 2^-3);
     `out2` is a ZEROED float32[4] (its last two words are the reduction's state, left zeroed)."""

@@ -63,14 +63,17 @@ def xe_forward_backward(captioner, optim, xe_crit, da_crit, fact, xe_senti_label
         from .autograd_pair import use_pair
         pair = use_pair(captioner, False)
     pair = pair and scs is not None and device.type == 'cuda'
+    # (token_logprobs: the unrolls hand the criterion log p(target) [B,T] - the [B,T,V] log-probs are never formed)
     if pair:
         # both unrolls through ONE step chain (Captioner.forward_xe_seq2seq / autograd_pair): the LSTM cells, the
         # classifier and every backward contraction run once over the 128 + 80 rows instead of once per unroll
         s_caps, s_lengths, s_cpts, s_sentis, s_labels = scs
-        pred, pred2 = captioner(fc_feats, att_feats, cpts_tensor, caps_tensor, xe_senti_labels, ss_prob,
-                                s_caps, s_cpts, s_sentis, s_labels, ss_prob, mode='xe_seq2seq')
+        with captioner.token_logprobs():
+            pred, pred2 = captioner(fc_feats, att_feats, cpts_tensor, caps_tensor, xe_senti_labels, ss_prob,
+                                    s_caps, s_cpts, s_sentis, s_labels, ss_prob, mode='xe_seq2seq')
     else:
-        pred = captioner(fc_feats, att_feats, cpts_tensor, caps_tensor, xe_senti_labels, ss_prob, mode='xe')
+        with captioner.token_logprobs():
+            pred = captioner(fc_feats, att_feats, cpts_tensor, caps_tensor, xe_senti_labels, ss_prob, mode='xe')
     xe_bwd = share(_xe_loss(xe_crit, pred, caps_tensor[:, 1:], lengths), w_xe)
     da_bwd = share(da_crit(captioner.cpt_feats, captioner.fc_feats.detach()), w_rows)
     total = xe_bwd + da_bwd
@@ -83,7 +86,8 @@ def xe_forward_backward(captioner, optim, xe_crit, da_crit, fact, xe_senti_label
         s_caps, s_lengths, s_cpts, s_sentis, s_labels = scs
 
         def seq2seq_unroll():
-            pred2 = captioner(s_caps, s_cpts, s_sentis, s_labels, ss_prob, mode='seq2seq')
+            with captioner.token_logprobs():
+                pred2 = captioner(s_caps, s_cpts, s_sentis, s_labels, ss_prob, mode='seq2seq')
             return share(_xe_loss(xe_crit, pred2, s_caps[:, 1:], s_lengths), w_s2s)
         if overlap_unrolls and device.type == 'cuda':
             s2s = run_on_side_stream(device, seq2seq_unroll, side_stream)

@@ -192,7 +192,8 @@ class XETrainGraph:
         s_caps, s_len, s_cpts, s_sentis, s_labels = scs
         params = self._params
         self.cap.cpt_feats = self.cap.fc_feats = self.cap.s2s_cpt_feats = None          # the accumulate nodes are re-made under THIS stream
-        pred2 = self.cap(s_caps, s_cpts, s_sentis, s_labels, ss_prob, mode='seq2seq')
+        with self.cap.token_logprobs():
+            pred2 = self.cap(s_caps, s_cpts, s_sentis, s_labels, ss_prob, mode='seq2seq')
         loss = _xe_loss(self.xe_crit, pred2, s_caps[:, 1:], s_len)
         if self._dist():
             loss = loss * self.shares[1]
@@ -445,9 +446,10 @@ class RLTrainGraph(XETrainGraph):
         det, cap, i = self.det, self.cap, geo.inputs
         if self._pair():          # both unrolls through one step chain: forward only here, ONE backward in _phase_bwd
             cap.cpt_feats = cap.fc_feats = cap.s2s_cpt_feats = None
-            pred, pred2 = cap(i['fc'], i['att'], i['cpts'], i['caps'], i['xe_labels'], det.xe_ss_prob,
-                              i['s_caps'], i['s_cpts'], i['s_sentis'], i['s_labels'], det.seq2seq_ss_prob,
-                              mode='xe_seq2seq')
+            with cap.token_logprobs():
+                pred, pred2 = cap(i['fc'], i['att'], i['cpts'], i['caps'], i['xe_labels'], det.xe_ss_prob,
+                                  i['s_caps'], i['s_cpts'], i['s_sentis'], i['s_labels'], det.seq2seq_ss_prob,
+                                  mode='xe_seq2seq')
             xe = _xe_loss(det.cap_xe_crit, pred, i['caps'][:, 1:], i['len'])
             s2s_loss = _xe_loss(det.cap_xe_crit, pred2, i['s_caps'][:, 1:], i['s_len'])
             if self._dist():
@@ -456,7 +458,8 @@ class RLTrainGraph(XETrainGraph):
         self.side.wait_stream(self.stream)                  # the branch forks here ...
         cap.cpt_feats = cap.fc_feats = cap.s2s_cpt_feats = None
         # ... the XE unroll is ENQUEUED first (the reference's call order, hence its order of random draws: decoder.py:138,155)
-        pred = cap(i['fc'], i['att'], i['cpts'], i['caps'], i['xe_labels'], ss_prob=det.xe_ss_prob, mode='xe')
+        with cap.token_logprobs():
+            pred = cap(i['fc'], i['att'], i['cpts'], i['caps'], i['xe_labels'], ss_prob=det.xe_ss_prob, mode='xe')
         xe = _xe_loss(det.cap_xe_crit, pred, i['caps'][:, 1:], i['len'])
         keep = (cap.cpt_feats, cap.fc_feats)
         with torch.cuda.stream(self.side):

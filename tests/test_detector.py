@@ -169,13 +169,13 @@ def test_detector_training_iterations_match_the_reference(golden):
 
     def replay_xe(fc, att, cpts, caps, labels, ss_prob=0.0, **k):
         assert ss_prob == 0.5                                    # models/decoder.py:139
-        out = o_xe(fc, att, cpts, fed_as_captions('dt/fed_xe%d' % n['xe']), labels, 0.0, **k)
+        out = o_xe(fc, att, cpts, fed_as_captions('dt/fed_xe%d' % n['xe']), labels, 0.0, _targets=caps[:, 1:], **k)
         n['xe'] += 1
         return out
 
     def replay_s2s(caps, cpts, sentis, labels, ss_prob=0.0, **k):
         assert ss_prob == 0.25                                   # models/decoder.py:155
-        out = o_s2s(fed_as_captions('dt/fed_s2s%d' % n['s2s']), cpts, sentis, labels, 0.0, **k)
+        out = o_s2s(fed_as_captions('dt/fed_s2s%d' % n['s2s']), cpts, sentis, labels, 0.0, _targets=caps[:, 1:], **k)
         n['s2s'] += 1
         return out
     o_pair = cap.forward_xe_seq2seq
@@ -184,7 +184,7 @@ def test_detector_training_iterations_match_the_reference(golden):
         # both unrolls through the merged step chain (Captioner.forward_xe_seq2seq): the same fed tokens
         assert ss_prob == 0.5 and s_ss_prob == 0.25
         out = o_pair(fc, att, cpts, fed_as_captions('dt/fed_xe%d' % n['xe']), labels, 0.0,
-                     fed_as_captions('dt/fed_s2s%d' % n['s2s']), s_cpts, s_sentis, s_labels, 0.0, **k)
+                     fed_as_captions('dt/fed_s2s%d' % n['s2s']), s_cpts, s_sentis, s_labels, 0.0, _targets=caps[:, 1:], _s_targets=s_caps[:, 1:], **k)
         n['xe'] += 1
         n['s2s'] += 1
         return out
@@ -267,7 +267,7 @@ def test_detector_senti_branch_matches_the_reference(golden):
             assert ss_prob == 0.25
             fed = torch.from_numpy(g['%s/fed_s2s%d' % (prefix, n['s2s'])]).to(dev)
             n['s2s'] += 1
-            return o_s2s(torch.cat([fed, fed[:, -1:]], dim=1), cpts, sentis, labels, 0.0, **k)
+            return o_s2s(torch.cat([fed, fed[:, -1:]], dim=1), cpts, sentis, labels, 0.0, _targets=caps[:, 1:], **k)
 
         def no_xe(*a, **k):
             raise AssertionError("the 'senti' branch has no XE unroll (models/decoder.py:131)")

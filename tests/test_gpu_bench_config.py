@@ -226,12 +226,12 @@ def test_config4_rl_training_iteration_at_full_size_vs_reference(golden):
     def replay_xe(fc, att, cpts, caps, labels, ss_prob=0.0, **k):
         assert ss_prob == 0.5
         n['xe'] += 1
-        return o_xe(fc, att, cpts, fed_as_captions('d5t/fed_xe'), labels, 0.0, **k)
+        return o_xe(fc, att, cpts, fed_as_captions('d5t/fed_xe'), labels, 0.0, _targets=caps[:, 1:], **k)
 
     def replay_s2s(caps, cpts, sentis, labels, ss_prob=0.0, **k):
         assert ss_prob == 0.25
         n['s2s'] += 1
-        return o_s2s(fed_as_captions('d5t/fed_s2s'), cpts, sentis, labels, 0.0, **k)
+        return o_s2s(fed_as_captions('d5t/fed_s2s'), cpts, sentis, labels, 0.0, _targets=caps[:, 1:], **k)
 
     def replay_pair(fc, att, cpts, caps, labels, ss_prob, s_caps, s_cpts, s_sentis, s_labels, s_ss_prob=None, **k):
         # both unrolls through the merged step chain (Captioner.forward_xe_seq2seq): the same fed tokens
@@ -239,7 +239,7 @@ def test_config4_rl_training_iteration_at_full_size_vs_reference(golden):
         n['xe'] += 1
         n['s2s'] += 1
         return o_pair(fc, att, cpts, fed_as_captions('d5t/fed_xe'), labels, 0.0, fed_as_captions('d5t/fed_s2s'),
-                      s_cpts, s_sentis, s_labels, 0.0, **k)
+                      s_cpts, s_sentis, s_labels, 0.0, _targets=caps[:, 1:], _s_targets=s_caps[:, 1:], **k)
     cap.forward_rl, cap.forward_xe, cap.forward_seq2seq = replay_rl, replay_xe, replay_s2s
     cap.forward_xe_seq2seq = replay_pair
 

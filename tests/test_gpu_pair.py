@@ -161,3 +161,37 @@ def test_launch_count_of_a_merged_iteration():
     geo = next(iter(g._geoms.values()))
     nodes = ops.graph_kernel_nodes(geo.g_iter)
     assert 0 < nodes <= 380, nodes
+
+
+@pytest.mark.parametrize('pair', [True, False], ids=['merged', 'two_calls'])
+@pytest.mark.parametrize('cfg,ss', [(TINY, 0.0), (TINY, 0.3), (FULL, 0.0)], ids=['tiny', 'tiny_scheduled_sampling', 'b128_v10k'])
+def test_token_logprobs_keep_the_bits_of_the_full_logprob_tensor(cfg, ss, pair):
+    """`with captioner.token_logprobs():` - the unrolls return log p(target) [B,T] from the raw logits + tile statistics
+    (isc_gather_logp_raw) and the backward recomputes the softmax term from them (isc_logsoftmax_bwd_raw); the [B,T,V]
+    log-probs are never formed.  Against the same calls outside the context (full tensor, XECriterion's gather, the stored
+    log-probs in the backward): the returned values equal the gathered ones, the losses and ALL gradients are the same
+    bits - with scheduled sampling too (same seed: same draws)."""
+    fact, labels, scs = batch(cfg, 75)
+    _, fc, att, (caps, lengths), cpts = fact
+    (s_caps, s_len), s_cpts, s_sentis, s_labels = scs
+    res = {}
+    for lazy in (True, False):
+        cap = make(cfg, pair=pair)
+        if ss:
+            cap.train()
+            cap.drop.p = 0.0             # (scheduled sampling needs train mode; no dropout: the draws are the only randomness)
+        _, xc, dc = cap.get_optim_criterion(4e-4)
+        torch.manual_seed(11)
+        with cap.token_logprobs(lazy):
+            pred, pred2 = cap.forward_xe_seq2seq(fc, att, cpts, caps, labels, ss, s_caps, s_cpts, s_sentis, s_labels, ss)
+        assert pred.dim() == (2 if lazy else 3)
+        xe, s2s = xc(pred, caps[:, 1:], lengths), xc(pred2, s_caps[:, 1:], s_len)
+        (xe + s2s + dc(cap.cpt_feats, cap.fc_feats.detach())).backward()
+        tl = pred.detach() if lazy else pred.detach().gather(2, caps[:, 1:].unsqueeze(2)).squeeze(2)
+        res[lazy] = (tl, float(xe.detach()), float(s2s.detach()),
+                     {k: q.grad.detach().clone() for k, q in cap.named_parameters() if q.grad is not None})
+    assert torch.equal(res[True][0], res[False][0])
+    assert res[True][1:3] == res[False][1:3]
+    assert res[True][3].keys() == res[False][3].keys()
+    for k in res[True][3]:
+        assert torch.equal(res[True][3][k], res[False][3][k]), k
