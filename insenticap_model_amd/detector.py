@@ -154,9 +154,13 @@ class Detector(nn.Module):
                         # group: a replaced optimizer - a new learning-rate schedule object, say - must not leave replays
                         # updating through the old one)
                         self._rl_graph = RLTrainGraph(self)
-                    with torch.no_grad():
-                        xe_senti_labels = self.sent_senti_cls(caps_tensor[:, 1:], lengths)[0]
-                        xe_senti_labels = xe_senti_labels.softmax(dim=-1).argmax(dim=-1).detach()
+                    def xe_senti_labels():
+                        with torch.no_grad():
+                            logits = self.sent_senti_cls(caps_tensor[:, 1:], lengths)[0]
+                            return logits.softmax(dim=-1).argmax(dim=-1).detach()
+                    if self.sent_senti_cls.training:         # (dropout draws: keep the reference's order of random numbers)
+                        xe_senti_labels = xe_senti_labels()
+                    # else: a callable - the graph object runs it behind its first roll-out, whose input it is not
                     (s_caps, s_lengths), s_cpts, s_sentis, s_labels = s2s_batch
                     stats = self._rl_graph.step(
                         (fns, fc_feats, att_feats, (caps_tensor, lengths), cpts_tensor, sentis_tensor, ground_truth),

@@ -86,7 +86,10 @@ class SentenceSentimentClassifier(nn.Module):
         x = self.word_embed(seqs[:, :Lmax])                                   # [B,Lmax,W]
         out, _ = self.rnn(x.transpose(0, 1))                                  # time-major LSTM
         out = out.transpose(0, 1)                                             # [B,Lmax,H]
-        lens = torch.as_tensor(lengths, device=seqs.device)
+        if seqs.is_cuda:        # (through pinned memory: a pageable copy would hold the host until the stream reaches it)
+            lens = torch.tensor(lengths, dtype=torch.int64).pin_memory().to(seqs.device, non_blocking=True)
+        else:
+            lens = torch.as_tensor(lengths, device=seqs.device)
         valid = (torch.arange(Lmax, device=seqs.device).unsqueeze(0) < lens.unsqueeze(1)).to(out.dtype)
         out = self.drop(out * valid.unsqueeze(-1))
         weights = (self.excitation(out) * valid.unsqueeze(-1)).mean(dim=-1)  # [B,Lmax]

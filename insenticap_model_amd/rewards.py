@@ -141,6 +141,16 @@ def get_ciderd_scorer(split_captions, sos_token, eos_token):
     return CiderD(list(captions.values()), sos_token, eos_token)
 
 
+def self_critical_scores(captions, fns, ground_truth, scorer):
+    """CIDEr-D of one token matrix [B,T] (host ndarray) against the images' references -> float64 [B]: one half of
+    get_self_critical_reward, for callers that score the sampled captions while the device still decodes the greedy ones."""
+    if not isinstance(scorer, CiderD):
+        raise Exception('do not support this scorer: %s' % type(scorer))
+    assert captions.shape[0] == len(fns)
+    flat = scorer.flatten_refs([ground_truth[fn] for fn in fns], keys=list(fns))
+    return scorer.score_arrays(captions, None, flat)
+
+
 def get_self_critical_reward(sample_captions, greedy_captions, fns, ground_truth, sos_token, eos_token, scorer):
     """utils.py:56-83: CIDEr-D(sample) - CIDEr-D(greedy), repeated over T -> float64 ndarray [B,T]."""
     batch_size = len(fns)

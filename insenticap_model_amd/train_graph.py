@@ -130,6 +130,8 @@ class XETrainGraph:
         dev_d, dev_s, host = [], [], []
         for k, v in t.items():
             dst = geo.inputs[k]
+            if v.device.type == 'meta':          # a late input (RLTrainGraph._late_inputs): shape and dtype only
+                continue
             if v.is_cuda and v.dtype == dst.dtype and v.is_contiguous():
                 dev_d.append(dst)
                 dev_s.append(v)
@@ -384,23 +386,27 @@ class XETrainGraph:
 class _RLGeometry(_Geometry):
     def __init__(self):
         super().__init__()
-        self.g_roll = self.g_fwd = self.g_bwd = None     # (g_up: the update graph under a process group)
+        self.g_roll = self.g_greedy = self.g_fwd = self.g_bwd = None     # (g_up: the update graph under a process group)
         self.pool = None
         self.host = None            # pinned host copies of the two token matrices and the sampled lengths
         self.reward = None          # static [B, T] reward the REINFORCE loss reads
+        self.late = {}              # inputs handed over as callables, still to be produced this iteration
         self.stats = None           # static [7] device statistics of the iteration
 
 
 class RLTrainGraph(XETrainGraph):
     """The self-critical RL training iteration of `Detector.forward(data, 'fact', True)` (models/decoder.py:65-167)
-    served from HIP graphs - three of them per input geometry, with the two things that cannot live in a graph between:
+    served from HIP graphs - four of them per input geometry, with the two things that cannot live in a graph between:
 
-        g_roll   sampled roll-out (activations kept for REINFORCE), domain-align loss, greedy roll-out, the device->host
-                 copies of both token matrices                                                     [decoder.py:85-98]
-        host     waits for the copies only, then scores CIDEr-D (host library) WHILE the device runs
+        g_roll   sampled roll-out (activations kept for REINFORCE), domain-align loss, the device->host copy of its token
+                 matrix and lengths                                                                [decoder.py:85-91]
+        g_greedy greedy baseline roll-out, the copy of its token matrix                            [decoder.py:93-98]
+        host     as soon as the sampled tokens have landed: enqueues the classifier reward (a packed-sequence LSTM:
+                 data-dependent shapes, eager launches that queue up behind the graphs), scores CIDEr-D of the sampled
+                 captions (host library) while the device decodes the greedy ones, then theirs while the device runs g_fwd
         g_fwd    XE unroll (ss_prob 0.5), forward; seq2seq unroll (ss_prob 0.25) forward AND backward as a branch on the
                  side stream, its gradients in tensors of their own                               [decoder.py:131-158]
-        eager    classifier reward (a packed-sequence LSTM: data-dependent shapes), rewards -> the static reward buffer
+        eager    rewards -> the static reward buffer
         g_bwd    RewardCriterion, the sum of the losses, backward, the seq2seq gradients added, clamp + Adam + plane
                  refresh (under a process group: the exchange, then the update as a graph of its own) [decoder.py:126-167]
 
@@ -423,22 +429,28 @@ class RLTrainGraph(XETrainGraph):
 
     # ---- phases ---------------------------------------------------------------------------------------------------
     def _phase_roll(self, geo):
-        """Sampled roll-out (graph kept), domain-align loss, greedy baseline, token matrices on their way to the host."""
+        """Sampled roll-out (graph kept), domain-align loss; its token matrix and lengths on their way to the host."""
         det, cap, i = self.det, self.cap, geo.inputs
         cap.cpt_feats = cap.fc_feats = cap.s2s_cpt_feats = None
         cap.train(True)
         seq, lp, mk = cap(i['fc'], i['att'], i['cpts'], i['sentis'], i['labels'], det.max_seq_len, sample_max=0, mode='rl')
         da = det.cap_da_crit(cap.cpt_feats, cap.fc_feats.detach())
+        lens = mk.sum(dim=-1).type(torch.int32)
+        geo.host[0].copy_(seq, non_blocking=True)
+        geo.host[2].copy_(lens, non_blocking=True)
+        return seq, lp, mk, da
+
+    def _phase_greedy(self, geo):
+        """Greedy baseline, its token matrix on its way to the host.  A phase (and a graph) of its own: the host scores the
+        SAMPLED captions while the device decodes these."""
+        det, cap, i = self.det, self.cap, geo.inputs
         cap.eval()
         with torch.no_grad():
             gseq, _, gmk = cap(i['fc'], i['att'], i['cpts'], i['sentis'], i['labels'], det.max_seq_len, sample_max=1,
                                mode='rl')
         cap.train(True)
-        lens = mk.sum(dim=-1).type(torch.int32)
-        geo.host[0].copy_(seq, non_blocking=True)
         geo.host[1].copy_(gseq, non_blocking=True)
-        geo.host[2].copy_(lens, non_blocking=True)
-        return seq, lp, mk, da, gseq, gmk
+        return gseq, gmk
 
     def _phase_fwd(self, geo):
         """XE unroll forward on self.stream; the seq2seq unroll - forward and backward - as a branch on self.side."""
@@ -510,25 +522,44 @@ class RLTrainGraph(XETrainGraph):
 
     # ---- between the graphs -----------------------------------------------------------------------------------------
     def _rewards(self, geo, roll, item):
-        """CIDEr-D on the host (the copies of g_roll have landed: `copied`), the classifier reward on the device, their
-        sum into the static buffer the captured RewardCriterion reads."""
-        from .rewards import get_cls_reward, get_self_critical_reward
+        """The rewards into the static buffer the captured RewardCriterion reads.  Host and device work interleaved so that
+        neither waits for the other: as soon as the SAMPLED tokens have landed (`copied_s`; the device is in the greedy
+        roll-out) the classifier reward - eager launches over data-dependent shapes - is enqueued behind the graphs already
+        queued, then the host scores CIDEr-D of the sampled captions; the greedy captions are scored when they land
+        (`copied`; the device is in g_fwd by then)."""
+        from .rewards import get_cls_reward, self_critical_scores
         det = self.det
         seq, lp, mk, da, gseq, gmk = roll
         fns, ground_truth = item[0], item[6]
+        geo.copied_s.synchronize()
+        # (on the side stream, behind the sampled roll-out only: a chain of ~100 small launches that shares the device with the
+        # greedy roll-out and g_fwd instead of standing between g_fwd and g_bwd; nothing else runs on that stream between
+        # the graphs)
+        self.side.wait_event(geo.copied_s)
+        with torch.cuda.stream(self.side):
+            cls = get_cls_reward(seq, mk, gseq, gmk, geo.inputs['labels'], det.sent_senti_cls,
+                                 sample_lens=geo.host[2].tolist(), on_device=True)
+            geo.cls.copy_(cls)
+        sampled = self_critical_scores(geo.host[0].numpy(), fns, ground_truth, det.ciderd_scorer)
         geo.copied.synchronize()
         if getattr(self.cap, 'numerics_checks', True) and ops.device_status(reset=True):
             # the roll-outs met non-finite values (features beyond the split-f16 domain): nothing has been updated yet -
             # Detector.forward redoes this iteration eagerly on the exact-fp32 engine
+            self.stream.wait_stream(self.side)
             raise ops.OutOfDomain()
-        fact = get_self_critical_reward(geo.host[0].numpy(), geo.host[1].numpy(), fns, ground_truth, self.cap.sos_id,
-                                        self.cap.eos_id, det.ciderd_scorer)
-        fact = ops.upload(fact.astype('float32'), torch.float32, self.device)
-        cls = get_cls_reward(seq, mk, gseq, gmk, geo.inputs['labels'], det.sent_senti_cls,
-                             sample_lens=geo.host[2].tolist(), on_device=True)
-        geo.fact0.copy_(fact[:, 0])
-        geo.cls.copy_(cls)
-        geo.reward.copy_(fact + det.cls_flag * cls)
+        greedy = self_critical_scores(geo.host[1].numpy(), fns, ground_truth, det.ciderd_scorer)
+        fact0 = ops.upload((sampled - greedy).astype('float32'), torch.float32, self.device)     # (utils.py:56-83: one per row)
+        geo.fact0.copy_(fact0)
+        self.stream.wait_stream(self.side)
+        geo.reward.copy_(fact0.unsqueeze(1) + det.cls_flag * geo.cls)
+
+    def _late_inputs(self, geo):
+        """Inputs the roll-outs do not read, handed to step() as callables: produced now, with the sampled roll-out already
+        queued - the host work of producing them (a frozen helper net's eager launches) no longer stands in front of the
+        iteration's first graph."""
+        for k, fn in geo.late.items():
+            geo.inputs[k].copy_(fn(), non_blocking=True)
+        geo.late = {}
 
     def _shares(self, geo, roll, lengths, s_lengths):
         """DP: each term's share of its global normaliser (mask sum, XE tokens, seq2seq tokens, rows): one 4-float
@@ -549,12 +580,15 @@ class RLTrainGraph(XETrainGraph):
         geo.reward = torch.zeros(B, T, dtype=torch.float32, device=self.device)
         geo.fact0 = torch.zeros(B, dtype=torch.float32, device=self.device)
         geo.cls = torch.zeros(B, T, dtype=torch.float32, device=self.device)
-        geo.copied = torch.cuda.Event()
+        geo.copied, geo.copied_s = torch.cuda.Event(), torch.cuda.Event()
 
     # ---- eager / capture / replay -----------------------------------------------------------------------------------
     def _run_eager(self, geo, item, lengths, s_lengths):
         with ops.refresh_only(self._handles):
             roll = self._phase_roll(geo)
+            geo.copied_s.record(self.stream)
+            self._late_inputs(geo)
+            roll = roll + self._phase_greedy(geo)
             geo.copied.record(self.stream)
             self._shares(geo, roll, lengths, s_lengths)
             fwd = self._phase_fwd(geo)
@@ -580,6 +614,9 @@ class RLTrainGraph(XETrainGraph):
                 geo.g_roll = torch.cuda.CUDAGraph(keep_graph=self.KEEP_GRAPHS)
                 with ops.graph_capture(geo.g_roll, stream=self.stream, pool=geo.pool):
                     roll = self._phase_roll(geo)
+                geo.g_greedy = torch.cuda.CUDAGraph(keep_graph=self.KEEP_GRAPHS)
+                with ops.graph_capture(geo.g_greedy, stream=self.stream, pool=geo.pool):
+                    roll = roll + self._phase_greedy(geo)
                 geo.g_fwd = torch.cuda.CUDAGraph(keep_graph=self.KEEP_GRAPHS)
                 with ops.graph_capture(geo.g_fwd, stream=self.stream, pool=geo.pool):
                     fwd = self._phase_fwd(geo)
@@ -608,6 +645,9 @@ class RLTrainGraph(XETrainGraph):
         self._set_hyper(int(states[0]['step']))
         roll, fwd = geo.keep
         geo.g_roll.replay()
+        geo.copied_s.record(self.stream)
+        self._late_inputs(geo)
+        geo.g_greedy.replay()
         geo.copied.record(self.stream)
         self._shares(geo, roll, lengths, s_lengths)
         geo.g_fwd.replay()
@@ -633,7 +673,8 @@ class RLTrainGraph(XETrainGraph):
     def step(self, item, scs_batch, senti_labels, xe_senti_labels):
         """One iteration on a fact item of the rl_fact collate (fns, fc, att, (caps, lengths), cpts, sentis,
         ground_truth), a seq2seq batch, the image sentiment labels and the XE labels of the captions (both from the
-        frozen helper nets, computed by the caller).  Returns {key: 0-dim device tensor} over RLTrainGraph.KEYS (under DP:
+        frozen helper nets, computed by the caller; `xe_senti_labels` may be a callable returning them - it is then run behind
+        the sampled roll-out, which does not read them, so that its host work overlaps the device's).  Returns {key: 0-dim device tensor} over RLTrainGraph.KEYS (under DP:
         this rank's pre-scaled shares - their sum over the ranks is the global value, as in Detector.forward), valid on
         the caller's current stream."""
         fns, fc, att, (caps, lengths), cpts, sentis, ground_truth = item
@@ -645,6 +686,10 @@ class RLTrainGraph(XETrainGraph):
         t = dict(fc=fc, att=att, caps=caps, cpts=cpts, sentis=sentis, labels=senti_labels, xe_labels=xe_senti_labels,
                  len=torch.tensor(lengths, dtype=torch.int32), s_caps=s_caps, s_cpts=s_cpts, s_sentis=s_sentis,
                  s_labels=s_labels, s_len=torch.tensor(s_lengths, dtype=torch.int32))
+        late = {}
+        if callable(xe_senti_labels):       # [B] int64, read by g_fwd only: produced behind the first roll-out (_late_inputs)
+            late['xe_labels'] = xe_senti_labels
+            t['xe_labels'] = torch.empty(fc.shape[0], dtype=torch.int64, device='meta')
         self.cap.cpt_feats = self.cap.fc_feats = self.cap.s2s_cpt_feats = None
         sig = (self._signature(t, 0.0), self.det.max_seq_len, self.det.xe_ss_prob, self.det.seq2seq_ss_prob,
                self.det.cls_flag, self.det.seq_flag)
@@ -660,11 +705,12 @@ class RLTrainGraph(XETrainGraph):
         try:
             with torch.cuda.stream(self.stream):
                 self._stage(geo, t)
+                geo.late = late
                 if geo.host is None:
                     self._alloc(geo)
                 planes_ok = self._valid_key is not None and self._valid_key == self.cap._weights_key()
                 if ops.h3_weights_scope.cold_begins(self._scope_keys) != geo.layout:
-                    geo.g_iter = geo.g_roll = geo.g_fwd = geo.g_bwd = geo.g_up = None
+                    geo.g_iter = geo.g_roll = geo.g_greedy = geo.g_fwd = geo.g_bwd = geo.g_up = None
                 if geo.g_iter is None and planes_ok and geo.eager_runs >= self.warmup:
                     self._capture_rl(geo)
                 if geo.g_iter is not None and planes_ok:

@@ -29,6 +29,9 @@ def test_native_reward_matches_reference(golden, name):
     raw = scorer.score_arrays(np.concatenate([sample, greedy]), [gt[f] for f in fns] * 2)
     np.testing.assert_allclose(raw, g[name + '/scores'], rtol=0, atol=1e-12)
     assert raw.max() > 1.0                                # the fixture has real n-gram overlap
+    # the two halves the graph-served RL iteration scores at different moments (train_graph.RLTrainGraph._rewards)
+    halves = rewards.self_critical_scores(sample, fns, gt, scorer) - rewards.self_critical_scores(greedy, fns, gt, scorer)
+    assert (halves == rew[:, 0]).all()
 
 
 def test_oracle_matches_reference(golden):
