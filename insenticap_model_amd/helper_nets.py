@@ -77,19 +77,26 @@ class SentenceSentimentClassifier(nn.Module):
                                             nn.Linear(H, len(sentiment_categories)))
 
     def forward(self, seqs, lengths):
-        """seqs [B,L] int64, lengths: B ints (>= 1). Returns (logits [B,k], token weights [B,max(lengths)]).
+        """seqs [B,L] int64, lengths: B ints (>= 1), or a device tensor [B]. Returns (logits [B,k], token weights
+        [B,max(lengths)] - [B,L] for device lengths).
         Positions at or beyond a row's length contribute nothing (the reference packs the sequences;
         here the padded LSTM outputs are masked instead - the recurrence is causal, so valid positions
         are unaffected by what follows them)."""
-        lengths = [int(x) for x in lengths]
-        Lmax = max(lengths)
+        if torch.is_tensor(lengths) and lengths.device == seqs.device and seqs.is_cuda:
+            # lengths that live on the device: no host read - the LSTM runs over all L columns (it is causal and the
+            # positions at or beyond a row's length are masked below, so the valid positions are what the packed form
+            # computes; the token weights come back [B,L] with zeros behind each row's length)
+            Lmax, lens = seqs.shape[1], lengths.to(torch.int64)
+        else:
+            lengths = [int(x) for x in lengths]
+            Lmax = max(lengths)
+            if seqs.is_cuda:    # (through pinned memory: a pageable copy would hold the host until the stream reaches it)
+                lens = torch.tensor(lengths, dtype=torch.int64).pin_memory().to(seqs.device, non_blocking=True)
+            else:
+                lens = torch.as_tensor(lengths, device=seqs.device)
         x = self.word_embed(seqs[:, :Lmax])                                   # [B,Lmax,W]
         out, _ = self.rnn(x.transpose(0, 1))                                  # time-major LSTM
         out = out.transpose(0, 1)                                             # [B,Lmax,H]
-        if seqs.is_cuda:        # (through pinned memory: a pageable copy would hold the host until the stream reaches it)
-            lens = torch.tensor(lengths, dtype=torch.int64).pin_memory().to(seqs.device, non_blocking=True)
-        else:
-            lens = torch.as_tensor(lengths, device=seqs.device)
         valid = (torch.arange(Lmax, device=seqs.device).unsqueeze(0) < lens.unsqueeze(1)).to(out.dtype)
         out = self.drop(out * valid.unsqueeze(-1))
         weights = (self.excitation(out) * valid.unsqueeze(-1)).mean(dim=-1)  # [B,Lmax]

@@ -170,8 +170,10 @@ def get_cls_reward(sample_captions, sample_masks, greedy_captions, greedy_masks,
                    sample_lens=None, on_device=False):
     """utils.py:120-151: 1[classifier(sample) == label] x per-token squeeze-excite weights, zero-padded
     to T. `sent_senti_cls` is the frozen helper net (helper_nets.SentenceSentimentClassifier).
-    `sample_lens` (host ints) skips the device->host read of the mask sums; `on_device=True` returns the
-    [B,T] float tensor without a host round trip (the trainer adds it to the CIDEr reward on the device)."""
+    `sample_lens` (host ints) skips the device->host read of the mask sums - or a device tensor [B]: the classifier then
+    runs over all T columns and needs no host value at all (the launches can be enqueued before the roll-out has
+    finished); `on_device=True` returns the [B,T] float tensor without a host round trip (the trainer adds it to the
+    CIDEr reward on the device)."""
     training = sent_senti_cls.training
     if sample_lens is None:
         sample_lens = list(sample_masks.sum(dim=-1).type(torch.int).cpu().numpy())

@@ -400,14 +400,17 @@ class RLTrainGraph(XETrainGraph):
 
         g_roll   sampled roll-out (activations kept for REINFORCE), domain-align loss, the device->host copy of its token
                  matrix and lengths                                                                [decoder.py:85-91]
-        g_greedy greedy baseline roll-out, the copy of its token matrix                            [decoder.py:93-98]
-        host     as soon as the sampled tokens have landed: enqueues the classifier reward (a packed-sequence LSTM:
-                 data-dependent shapes, eager launches that queue up behind the graphs), scores CIDEr-D of the sampled
-                 captions (host library) while the device decodes the greedy ones, then theirs while the device runs g_fwd
-        g_fwd    XE unroll (ss_prob 0.5), forward; seq2seq unroll (ss_prob 0.25) forward AND backward as a branch on the
-                 side stream, its gradients in tensors of their own                               [decoder.py:131-158]
+        g_greedy greedy baseline roll-out, the copy of its token matrix - on a stream of its own, next to g_roll and g_fwd
+                 (it draws no random numbers and writes nothing they read)                        [decoder.py:93-98]
+        eager    the classifier reward on the side stream, behind g_roll (a frozen helper net: an LSTM of the stock library;
+                 lengths stay on the device, so its launches are enqueued at once)                [utils.py:120-151]
+        host     scores CIDEr-D of the sampled captions (host library) as soon as their tokens have landed, while the device
+                 decodes the greedy ones and runs g_fwd; then theirs
+        g_fwd    XE unroll (ss_prob 0.5), forward, as a branch on a stream of its own; seq2seq unroll (ss_prob 0.25) forward
+                 AND backward as a branch on the side stream, its gradients in tensors of their own [decoder.py:131-158]
         eager    rewards -> the static reward buffer
-        g_bwd    RewardCriterion, the sum of the losses, backward, the seq2seq gradients added, clamp + Adam + plane
+        g_bwd    RewardCriterion, the sum of the losses, backward (two branches: the roll-out's reverse sweep and the XE
+                 unroll's, each on the stream of its forward), the seq2seq gradients added, clamp + Adam + plane
                  refresh (under a process group: the exchange, then the update as a graph of its own) [decoder.py:126-167]
 
     Streams, weight-plane scopes, device-side Adam scalars, step counters, the run-eagerly-once-after-a-foreign-weight-
@@ -426,6 +429,22 @@ class RLTrainGraph(XETrainGraph):
                          max_geometries=max_geometries)
         self.det = detector
         self.share_rl = torch.ones(1, dtype=torch.float32, device=self.device)
+        # A third stream: the XE unroll's forward runs there, so autograd replays its reverse sweep there as well - next
+        # to the sampled roll-out's on self.stream.  At 512 rows a sweep's launches are 128-192 workgroups on 256 compute
+        # units; as two branches of g_bwd the two sweeps fill each other's gaps.
+        self.xe_stream = ops.private_stream(self.device)
+        # ... and a fourth: the greedy baseline reads what the sampled roll-out reads and draws no random numbers - the two
+        # roll-outs run side by side (a graph and a memory pool of its own: graphs that share a pool must not overlap)
+        import os
+        self.greedy_stream = ops.private_stream(self.device) if os.environ.get('ISC_RL_GREEDY_STREAM', '1') != '0' else self.stream
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self._scope_keys = self._scope_keys + ((idx, self.xe_stream.cuda_stream), (idx, self.greedy_stream.cuda_stream))
+        self._handles = self._handles + (self.xe_stream.cuda_stream, self.greedy_stream.cuda_stream)
+        self._finalizer.detach()
+        self._finalizer = weakref.finalize(self, XETrainGraph._release, self._scope_keys)
+        warn_off = getattr(torch.autograd.graph, 'set_warn_on_accumulate_grad_stream_mismatch', None)
+        if warn_off is not None:            # gradients of one parameter arrive from two streams by design
+            warn_off(False)
 
     # ---- phases ---------------------------------------------------------------------------------------------------
     def _phase_roll(self, geo):
@@ -435,7 +454,7 @@ class RLTrainGraph(XETrainGraph):
         cap.train(True)
         seq, lp, mk = cap(i['fc'], i['att'], i['cpts'], i['sentis'], i['labels'], det.max_seq_len, sample_max=0, mode='rl')
         da = det.cap_da_crit(cap.cpt_feats, cap.fc_feats.detach())
-        lens = mk.sum(dim=-1).type(torch.int32)
+        lens = geo.lens_d = mk.sum(dim=-1).type(torch.int32)
         geo.host[0].copy_(seq, non_blocking=True)
         geo.host[2].copy_(lens, non_blocking=True)
         return seq, lp, mk, da
@@ -453,7 +472,8 @@ class RLTrainGraph(XETrainGraph):
         return gseq, gmk
 
     def _phase_fwd(self, geo):
-        """XE unroll forward on self.stream; the seq2seq unroll - forward and backward - as a branch on self.side."""
+        """XE unroll forward as a branch on self.xe_stream (its backward then runs there too, inside g_bwd); the seq2seq unroll -
+        forward and backward - as a branch on self.side."""
         from .train import _xe_loss
         det, cap, i = self.det, self.cap, geo.inputs
         if self._pair():          # both unrolls through one step chain: forward only here, ONE backward in _phase_bwd
@@ -467,17 +487,20 @@ class RLTrainGraph(XETrainGraph):
             if self._dist():
                 s2s_loss = s2s_loss * self.shares[1]
             return xe, (s2s_loss, None)
-        self.side.wait_stream(self.stream)                  # the branch forks here ...
+        self.side.wait_stream(self.stream)                  # the branches fork here ...
+        self.xe_stream.wait_stream(self.stream)
         cap.cpt_feats = cap.fc_feats = cap.s2s_cpt_feats = None
         # ... the XE unroll is ENQUEUED first (the reference's call order, hence its order of random draws: decoder.py:138,155)
-        with cap.token_logprobs():
-            pred = cap(i['fc'], i['att'], i['cpts'], i['caps'], i['xe_labels'], ss_prob=det.xe_ss_prob, mode='xe')
-        xe = _xe_loss(det.cap_xe_crit, pred, i['caps'][:, 1:], i['len'])
+        with torch.cuda.stream(self.xe_stream):
+            with cap.token_logprobs():
+                pred = cap(i['fc'], i['att'], i['cpts'], i['caps'], i['xe_labels'], ss_prob=det.xe_ss_prob, mode='xe')
+            xe = _xe_loss(det.cap_xe_crit, pred, i['caps'][:, 1:], i['len'])
         keep = (cap.cpt_feats, cap.fc_feats)
         with torch.cuda.stream(self.side):
             s2s = self._phase_s2s(geo, det.seq2seq_ss_prob)
         cap.cpt_feats, cap.fc_feats = keep
         self.stream.wait_stream(self.side)
+        self.stream.wait_stream(self.xe_stream)
         return xe, s2s
 
     def _phase_bwd(self, geo, roll, fwd):
@@ -521,25 +544,26 @@ class RLTrainGraph(XETrainGraph):
         return geo.stats
 
     # ---- between the graphs -----------------------------------------------------------------------------------------
-    def _rewards(self, geo, roll, item):
-        """The rewards into the static buffer the captured RewardCriterion reads.  Host and device work interleaved so that
-        neither waits for the other: as soon as the SAMPLED tokens have landed (`copied_s`; the device is in the greedy
-        roll-out) the classifier reward - eager launches over data-dependent shapes - is enqueued behind the graphs already
-        queued, then the host scores CIDEr-D of the sampled captions; the greedy captions are scored when they land
-        (`copied`; the device is in g_fwd by then)."""
-        from .rewards import get_cls_reward, self_critical_scores
-        det = self.det
-        seq, lp, mk, da, gseq, gmk = roll
-        fns, ground_truth = item[0], item[6]
-        geo.copied_s.synchronize()
-        # (on the side stream, behind the sampled roll-out only: a chain of ~100 small launches that shares the device with the
-        # greedy roll-out and g_fwd instead of standing between g_fwd and g_bwd; nothing else runs on that stream between
-        # the graphs)
+    def _cls_reward(self, geo, roll):
+        """The classifier reward of the sampled captions (utils.py:120-151) -> geo.cls, enqueued on the side stream behind the
+        sampled roll-out: eager launches of a frozen helper net (an LSTM of the stock library), with the lengths read on the
+        device - the host does not wait for anything here, the launches queue up while the roll-out runs."""
+        from .rewards import get_cls_reward
+        seq, mk = roll[0], roll[2]
         self.side.wait_event(geo.copied_s)
         with torch.cuda.stream(self.side):
-            cls = get_cls_reward(seq, mk, gseq, gmk, geo.inputs['labels'], det.sent_senti_cls,
-                                 sample_lens=geo.host[2].tolist(), on_device=True)
+            cls = get_cls_reward(seq, mk, None, None, geo.inputs['labels'], self.det.sent_senti_cls,
+                                 sample_lens=geo.lens_d, on_device=True)
             geo.cls.copy_(cls)
+
+    def _rewards(self, geo, roll, item):
+        """CIDEr-D on the host -> with geo.cls the static reward buffer the captured RewardCriterion reads.  The sampled
+        captions are scored as soon as they have landed (`copied_s`; the device is in the greedy roll-out and g_fwd), the
+        greedy ones when they land (`copied`)."""
+        from .rewards import self_critical_scores
+        det = self.det
+        fns, ground_truth = item[0], item[6]
+        geo.copied_s.synchronize()
         sampled = self_critical_scores(geo.host[0].numpy(), fns, ground_truth, det.ciderd_scorer)
         geo.copied.synchronize()
         if getattr(self.cap, 'numerics_checks', True) and ops.device_status(reset=True):
@@ -580,16 +604,20 @@ class RLTrainGraph(XETrainGraph):
         geo.reward = torch.zeros(B, T, dtype=torch.float32, device=self.device)
         geo.fact0 = torch.zeros(B, dtype=torch.float32, device=self.device)
         geo.cls = torch.zeros(B, T, dtype=torch.float32, device=self.device)
-        geo.copied, geo.copied_s = torch.cuda.Event(), torch.cuda.Event()
+        geo.copied, geo.copied_s, geo.staged = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
 
     # ---- eager / capture / replay -----------------------------------------------------------------------------------
     def _run_eager(self, geo, item, lengths, s_lengths):
         with ops.refresh_only(self._handles):
+            geo.staged.record(self.stream)
+            self.greedy_stream.wait_event(geo.staged)
             roll = self._phase_roll(geo)
             geo.copied_s.record(self.stream)
+            with torch.cuda.stream(self.greedy_stream):
+                roll = roll + self._phase_greedy(geo)
+                geo.copied.record(self.greedy_stream)
+            self._cls_reward(geo, roll)
             self._late_inputs(geo)
-            roll = roll + self._phase_greedy(geo)
-            geo.copied.record(self.stream)
             self._shares(geo, roll, lengths, s_lengths)
             fwd = self._phase_fwd(geo)
             for g in fwd[1][1] or ():
@@ -615,7 +643,7 @@ class RLTrainGraph(XETrainGraph):
                 with ops.graph_capture(geo.g_roll, stream=self.stream, pool=geo.pool):
                     roll = self._phase_roll(geo)
                 geo.g_greedy = torch.cuda.CUDAGraph(keep_graph=self.KEEP_GRAPHS)
-                with ops.graph_capture(geo.g_greedy, stream=self.stream, pool=geo.pool):
+                with ops.graph_capture(geo.g_greedy, stream=self.greedy_stream):
                     roll = roll + self._phase_greedy(geo)
                 geo.g_fwd = torch.cuda.CUDAGraph(keep_graph=self.KEEP_GRAPHS)
                 with ops.graph_capture(geo.g_fwd, stream=self.stream, pool=geo.pool):
@@ -644,11 +672,15 @@ class RLTrainGraph(XETrainGraph):
             st['step'] += 1
         self._set_hyper(int(states[0]['step']))
         roll, fwd = geo.keep
+        geo.staged.record(self.stream)
+        self.greedy_stream.wait_event(geo.staged)            # (the inputs are staged, the last update's plane refresh is done)
         geo.g_roll.replay()
         geo.copied_s.record(self.stream)
+        with torch.cuda.stream(self.greedy_stream):
+            geo.g_greedy.replay()
+            geo.copied.record(self.greedy_stream)
+        self._cls_reward(geo, roll)
         self._late_inputs(geo)
-        geo.g_greedy.replay()
-        geo.copied.record(self.stream)
         self._shares(geo, roll, lengths, s_lengths)
         geo.g_fwd.replay()
         try:
