@@ -187,8 +187,8 @@ class XETrainGraph:
 
     def _phase_s2s(self, geo, ss_prob):
         """seq2seq unroll, forward and backward, on self.side - concurrently with _phase_xe, so its gradients go to
-        tensors of their own (p.grad is swapped out around the backward) and are added afterwards (_phase_add): the
-        same two-operand sums autograd's accumulation forms in the eager step.  Returns (loss, gradient list)."""
+        tensors of their own and are added afterwards (_phase_add): the same two-operand sums autograd's accumulation
+        forms in the eager step.  Returns (loss, gradient list)."""
         from .train import _xe_loss
         _, _, scs = self._phase_args(geo)
         s_caps, s_len, s_cpts, s_sentis, s_labels = scs
@@ -199,15 +199,9 @@ class XETrainGraph:
         loss = _xe_loss(self.xe_crit, pred2, s_caps[:, 1:], s_len)
         if self._dist():
             loss = loss * self.shares[1]
-        main = [q.grad for q in params]
-        for q in params:
-            q.grad = None
-        try:
-            loss.backward()
-            own = [q.grad for q in params]
-        finally:
-            for q, g in zip(params, main):
-                q.grad = g
+        # (autograd.grad, not backward(): the gradients come back as tensors, no parameter's .grad or accumulation node is
+        # touched - those belong to the stream of the main backward, which may not be part of the capture this runs in)
+        own = list(torch.autograd.grad(loss, params, allow_unused=True))
         self.cap.cpt_feats = None
         return loss.detach(), own
 
@@ -406,8 +400,9 @@ class RLTrainGraph(XETrainGraph):
                  lengths stay on the device, so its launches are enqueued at once)                [utils.py:120-151]
         host     scores CIDEr-D of the sampled captions (host library) as soon as their tokens have landed, while the device
                  decodes the greedy ones and runs g_fwd; then theirs
-        g_fwd    XE unroll (ss_prob 0.5), forward, as a branch on a stream of its own; seq2seq unroll (ss_prob 0.25) forward
-                 AND backward as a branch on the side stream, its gradients in tensors of their own [decoder.py:131-158]
+        g_fwd    XE unroll (ss_prob 0.5), forward, on a stream of its own NEXT TO the roll-outs (it reads the batch and the
+                 weights only); seq2seq unroll (ss_prob 0.25) forward AND backward as a branch on the side stream, its
+                 gradients in tensors of their own                                                [decoder.py:131-158]
         eager    rewards -> the static reward buffer
         g_bwd    RewardCriterion, the sum of the losses, backward (two branches: the roll-out's reverse sweep and the XE
                  unroll's, each on the stream of its forward), the seq2seq gradients added, clamp + Adam + plane
@@ -435,8 +430,7 @@ class RLTrainGraph(XETrainGraph):
         self.xe_stream = ops.private_stream(self.device)
         # ... and a fourth: the greedy baseline reads what the sampled roll-out reads and draws no random numbers - the two
         # roll-outs run side by side (a graph and a memory pool of its own: graphs that share a pool must not overlap)
-        import os
-        self.greedy_stream = ops.private_stream(self.device) if os.environ.get('ISC_RL_GREEDY_STREAM', '1') != '0' else self.stream
+        self.greedy_stream = ops.private_stream(self.device)
         idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
         self._scope_keys = self._scope_keys + ((idx, self.xe_stream.cuda_stream), (idx, self.greedy_stream.cuda_stream))
         self._handles = self._handles + (self.xe_stream.cuda_stream, self.greedy_stream.cuda_stream)
@@ -472,8 +466,8 @@ class RLTrainGraph(XETrainGraph):
         return gseq, gmk
 
     def _phase_fwd(self, geo):
-        """XE unroll forward as a branch on self.xe_stream (its backward then runs there too, inside g_bwd); the seq2seq unroll -
-        forward and backward - as a branch on self.side."""
+        """Runs on self.xe_stream (the caller sets it), next to the roll-outs: XE unroll forward (its backward then runs there
+        too, inside g_bwd); the seq2seq unroll - forward and backward - as a branch on self.side."""
         from .train import _xe_loss
         det, cap, i = self.det, self.cap, geo.inputs
         if self._pair():          # both unrolls through one step chain: forward only here, ONE backward in _phase_bwd
@@ -487,8 +481,9 @@ class RLTrainGraph(XETrainGraph):
             if self._dist():
                 s2s_loss = s2s_loss * self.shares[1]
             return xe, (s2s_loss, None)
-        self.side.wait_stream(self.stream)                  # the branches fork here ...
-        self.xe_stream.wait_stream(self.stream)
+        origin = torch.cuda.current_stream(self.device)
+        self.side.wait_stream(origin)                       # the branches fork here ...
+        self.xe_stream.wait_stream(origin)
         cap.cpt_feats = cap.fc_feats = cap.s2s_cpt_feats = None
         # ... the XE unroll is ENQUEUED first (the reference's call order, hence its order of random draws: decoder.py:138,155)
         with torch.cuda.stream(self.xe_stream):
@@ -499,8 +494,8 @@ class RLTrainGraph(XETrainGraph):
         with torch.cuda.stream(self.side):
             s2s = self._phase_s2s(geo, det.seq2seq_ss_prob)
         cap.cpt_feats, cap.fc_feats = keep
-        self.stream.wait_stream(self.side)
-        self.stream.wait_stream(self.xe_stream)
+        origin.wait_stream(self.side)
+        origin.wait_stream(self.xe_stream)
         return xe, s2s
 
     def _phase_bwd(self, geo, roll, fwd):
@@ -570,12 +565,22 @@ class RLTrainGraph(XETrainGraph):
             # the roll-outs met non-finite values (features beyond the split-f16 domain): nothing has been updated yet -
             # Detector.forward redoes this iteration eagerly on the exact-fp32 engine
             self.stream.wait_stream(self.side)
+            self.stream.wait_event(geo.fwd_done)
             raise ops.OutOfDomain()
         greedy = self_critical_scores(geo.host[1].numpy(), fns, ground_truth, det.ciderd_scorer)
         fact0 = ops.upload((sampled - greedy).astype('float32'), torch.float32, self.device)     # (utils.py:56-83: one per row)
         geo.fact0.copy_(fact0)
         self.stream.wait_stream(self.side)
         geo.reward.copy_(fact0.unsqueeze(1) + det.cls_flag * geo.cls)
+
+    def _fork_fwd(self, geo, roll, lengths, s_lengths):
+        """self.xe_stream may start g_fwd: it reads the staged inputs and the weights only - not the roll-outs - so it runs
+        next to them.  Under a process group it reads the loss shares as well, whose one small all-reduce carries the
+        roll-out's mask sum: the branch then starts behind that."""
+        if self._dist():
+            self._shares(geo, roll, lengths, s_lengths)
+            geo.staged.record(self.stream)
+        self.xe_stream.wait_event(geo.staged)
 
     def _late_inputs(self, geo):
         """Inputs the roll-outs do not read, handed to step() as callables: produced now, with the sampled roll-out already
@@ -604,7 +609,7 @@ class RLTrainGraph(XETrainGraph):
         geo.reward = torch.zeros(B, T, dtype=torch.float32, device=self.device)
         geo.fact0 = torch.zeros(B, dtype=torch.float32, device=self.device)
         geo.cls = torch.zeros(B, T, dtype=torch.float32, device=self.device)
-        geo.copied, geo.copied_s, geo.staged = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
+        geo.copied, geo.copied_s, geo.staged, geo.fwd_done = [torch.cuda.Event() for _ in range(4)]
 
     # ---- eager / capture / replay -----------------------------------------------------------------------------------
     def _run_eager(self, geo, item, lengths, s_lengths):
@@ -617,13 +622,16 @@ class RLTrainGraph(XETrainGraph):
                 roll = roll + self._phase_greedy(geo)
                 geo.copied.record(self.greedy_stream)
             self._cls_reward(geo, roll)
-            self._late_inputs(geo)
-            self._shares(geo, roll, lengths, s_lengths)
-            fwd = self._phase_fwd(geo)
-            for g in fwd[1][1] or ():
+            self._fork_fwd(geo, roll, lengths, s_lengths)
+            with torch.cuda.stream(self.xe_stream):
+                self._late_inputs(geo)
+                fwd = self._phase_fwd(geo)
+                geo.fwd_done.record(self.xe_stream)
+            for g in (fwd[0], fwd[1][0]) + tuple(fwd[1][1] or ()):
                 if g is not None:
                     g.record_stream(self.stream)
             self._rewards(geo, roll, item)
+            self.stream.wait_event(geo.fwd_done)
             stats = self._phase_bwd(geo, roll, fwd)
             if self._dist():
                 if self.arena is not None:
@@ -646,7 +654,10 @@ class RLTrainGraph(XETrainGraph):
                 with ops.graph_capture(geo.g_greedy, stream=self.greedy_stream):
                     roll = roll + self._phase_greedy(geo)
                 geo.g_fwd = torch.cuda.CUDAGraph(keep_graph=self.KEEP_GRAPHS)
-                with ops.graph_capture(geo.g_fwd, stream=self.stream, pool=geo.pool):
+                # (a pool of its own: it runs next to g_roll.  Captured from self.stream with self.xe_stream and self.side as
+                # two branches of it - a branch forked off a branch ended in a segmentation fault inside the runtime's
+                # end-of-capture here - and replayed on self.xe_stream)
+                with ops.graph_capture(geo.g_fwd, stream=self.stream):
                     fwd = self._phase_fwd(geo)
                 geo.g_bwd = torch.cuda.CUDAGraph(keep_graph=self.KEEP_GRAPHS)
                 with ops.graph_capture(geo.g_bwd, stream=self.stream, pool=geo.pool):
@@ -680,15 +691,18 @@ class RLTrainGraph(XETrainGraph):
             geo.g_greedy.replay()
             geo.copied.record(self.greedy_stream)
         self._cls_reward(geo, roll)
-        self._late_inputs(geo)
-        self._shares(geo, roll, lengths, s_lengths)
-        geo.g_fwd.replay()
+        self._fork_fwd(geo, roll, lengths, s_lengths)
+        with torch.cuda.stream(self.xe_stream):
+            self._late_inputs(geo)
+            geo.g_fwd.replay()
+            geo.fwd_done.record(self.xe_stream)
         try:
             self._rewards(geo, roll, item)
         except ops.OutOfDomain:
             for st in states:               # this iteration will be redone elsewhere: it has not stepped
                 st['step'] -= 1
             raise
+        self.stream.wait_event(geo.fwd_done)
         geo.g_bwd.replay()
         stats = geo.stats
         if geo.g_up is not None:
