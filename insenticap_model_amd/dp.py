@@ -3,11 +3,12 @@ torch.distributed; backend "nccl" is RCCL over xGMI on ROCm, "gloo" on CPU for t
 
 The reference is single-device (opts.py:98-99); DP is a capability of this build
 (SURVEY 8(e)).  Design for xGMI (point-to-point links, no switch):
-  * ONE collective per iteration: all 40 gradient tensors live in one flat fp32 arena
-    (22,063,379 elements = 88.25 MB at V=10k), `p.grad` are views into it, so autograd
-    accumulates in place and the all-reduce needs no flatten / unflatten copies.
-    Weights are shared across time steps, so no gradient is final before BPTT ends - there is
-    nothing to overlap with except the optimiser, hence no bucketing.
+  * all 40 gradient tensors live in one flat fp32 arena (22,063,379 elements = 88.25 MB at V=10k), `p.grad` are views
+    into it, so autograd accumulates in place and the exchange needs no flatten / unflatten copies: ONE all-reduce of
+    the arena after the backward (GradArena.all_reduce; the graph-served steps), or - the eager merged step - four
+    buckets whose all-reduces start from inside the backward as each bucket's last dW is enqueued (GradSink), with
+    clamp + Adam per bucket behind each reduction.  The small collectives around them (normaliser counts, the loss
+    statistics) are asynchronous: the compute stream waits for each only where its result is read.
   * the reduction is a SUM; each rank pre-scales its loss by local_tokens / global_tokens so the
     result equals the single-process loss exactly even when ranks hold different token counts
     (XECriterion / RewardCriterion divide by the *global* mask sum: captioner.py:438, utils.py:175).
@@ -63,6 +64,19 @@ def all_reduce_(t, group=None, op=None):
     global COLLECTIVES
     COLLECTIVES += 1
     return t
+
+
+def all_reduce_async_(t, group=None):
+    """all_reduce_ that does not make the current stream wait: returns (t, work); `work.wait()` orders the CURRENT stream
+    behind the reduction (the host never blocks under nccl).  work is None without a process group."""
+    if not distributed(group):
+        return t, None
+    if dist.get_backend(group) == 'nccl' and t.device.type != 'cuda':
+        raise TypeError('collective on a %s tensor with backend nccl (RCCL): build it on the rank\'s GPU' % t.device.type)
+    work = dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=True)
+    global COLLECTIVES
+    COLLECTIVES += 1
+    return t, work
 
 
 class GradArena:
@@ -189,10 +203,11 @@ class GradSink:
             first = False
 
 
-def global_counts(local_counts, device, group=None):
+def global_counts(local_counts, device, group=None, asynchronous=False):
     """Sum over ranks of a short list of per-rank normalisers (token counts, mask sums, row counts): ONE small
     all-reduce.  `local_counts`: python numbers and / or 0-dim tensors; the vector is built on `device` - the rank's
-    GPU under RCCL.  Returns (local [n], global [n]) float32 tensors on `device`."""
+    GPU under RCCL.  Returns (local [n], global [n]) float32 tensors on `device`; `asynchronous`: (local, global, work) -
+    the current stream does not wait for the reduction until `work.wait()` (work is None without a group)."""
     device = torch.device(device)
     # python numbers travel in ONE pinned buffer by a non-blocking copy: a tensor built from a python list on the device is
     # a pageable H2D copy, i.e. a host wait for everything queued on the stream - once per iteration it serialised the
@@ -211,6 +226,9 @@ def global_counts(local_counts, device, group=None):
             parts.append(host[k:k + 1])
             k += 1
     local = torch.cat(parts) if len(parts) > 1 else parts[0].clone()
+    if asynchronous:
+        glob, work = all_reduce_async_(local.clone(), group)
+        return local, glob, work
     return local, all_reduce_(local.clone(), group)
 
 

@@ -52,13 +52,12 @@ def xe_forward_backward(captioner, optim, xe_crit, da_crit, fact, xe_senti_label
                         weights3=None, overlap_unrolls=True, side_stream=None, pair=None, sink=None):
     """train_xe.py:160-190 on device tensors: both unrolls, the three losses, backward.  `fact` = (fc, att, caps,
     lengths, cpts), `scs` = (caps, lengths, cpts, sentis, labels) or None; `weights3` = this rank's shares of the three
-    global normalisers (XE tokens, seq2seq tokens, rows) as a device tensor, or None (single process: graph
-    untouched).  Returns the detached [xe, da, seq2seq] losses as one device tensor.  No collective, no host read:
+    global normalisers (XE tokens, seq2seq tokens, rows) as a device tensor (or a callable returning it, resolved after
+    the unrolls' forward: dp_shares_async), or None (single process: graph untouched).  Returns the detached [xe, da, seq2seq] losses as one device tensor.  No collective, no host read:
     this is the part of an iteration that train_graph.XETrainGraph captures into a HIP graph."""
     fc_feats, att_feats, caps_tensor, lengths, cpts_tensor = fact
     device = fc_feats.device
     share = (lambda x, w: x * w) if weights3 is not None else (lambda x, w: x)
-    w_xe, w_s2s, w_rows = weights3.unbind(0) if weights3 is not None else (None, None, None)
     if pair is None:
         from .autograd_pair import use_pair
         pair = use_pair(captioner, False)
@@ -74,6 +73,9 @@ def xe_forward_backward(captioner, optim, xe_crit, da_crit, fact, xe_senti_label
     else:
         with captioner.token_logprobs():
             pred = captioner(fc_feats, att_feats, cpts_tensor, caps_tensor, xe_senti_labels, ss_prob, mode='xe')
+    if callable(weights3):            # (dp_shares_async: the counts' all-reduce ran next to the unroll; wait for it here)
+        weights3 = weights3()
+    w_xe, w_s2s, w_rows = weights3.unbind(0) if weights3 is not None else (None, None, None)
     xe_bwd = share(_xe_loss(xe_crit, pred, caps_tensor[:, 1:], lengths), w_xe)
     da_bwd = share(da_crit(captioner.cpt_feats, captioner.fc_feats.detach()), w_rows)
     total = xe_bwd + da_bwd
@@ -134,6 +136,20 @@ def dp_shares(lengths, s_lengths, rows, device, group):
     return local / glob.clamp_min(1.0)
 
 
+def dp_shares_async(lengths, s_lengths, rows, device, group):
+    """dp_shares whose all-reduce does not hold the compute stream: returns a callable that waits for the reduction (on
+    the then-current stream) and returns the shares - the eager step calls it after the unrolls' forward passes, where
+    the first loss is scaled, so the collective's latency is behind ~2 ms of launches instead of in front of them."""
+    local, glob, work = dp.global_counts([float(sum(lengths)), float(sum(s_lengths)) if s_lengths is not None else 0.0,
+                                          float(rows)], device, group, asynchronous=True)
+
+    def shares():
+        if work is not None:
+            work.wait()
+        return local / glob.clamp_min(1.0)
+    return shares
+
+
 def xe_train_step(captioner, optim, xe_crit, da_crit, fact_batch, xe_senti_labels, scs_batch=None,
                   ss_prob=0.0, grad_clip=0.1, arena=None, group=None, device=None, overlap_unrolls=True, bucketed=True):
     """One iteration. Returns dict(xe_loss, da_loss, cap_loss, seq2seq_loss, all_loss) of 0-dim
@@ -157,7 +173,7 @@ def xe_train_step(captioner, optim, xe_crit, da_crit, fact_batch, xe_senti_label
     # data-parallel: taken whenever a process group exists (also a one-rank one: shares are then exactly 1.0), so the
     # single-GPU RCCL test crosses every branch an 8-rank run does
     dist_on = dp.distributed(group)
-    weights3 = dp_shares(lengths, scs[1] if scs is not None else None, fact[0].shape[0], device, group) \
+    weights3 = dp_shares_async(lengths, scs[1] if scs is not None else None, fact[0].shape[0], device, group) \
         if dist_on else None
     from .autograd_pair import use_pair
     sink = None
@@ -169,9 +185,12 @@ def xe_train_step(captioner, optim, xe_crit, da_crit, fact_batch, xe_senti_label
     vec = xe_forward_backward(captioner, optim, xe_crit, da_crit, fact, xe_senti_labels, scs, ss_prob, arena, weights3,
                               overlap_unrolls, sink=sink)
     if sink is not None and sink.order:
-        if dist_on:                      # (issued before the waits: it queues behind the buckets on the backend's stream)
-            vec = dp.all_reduce_(vec, group)
+        # the loss statistics: queued behind the buckets on the backend's stream, NOT waited for here - the compute stream
+        # would otherwise stand behind every bucket's reduction before the first bucket's update
+        vec, work = dp.all_reduce_async_(vec, group) if dist_on else (vec, None)
         sink.finish(optim, grad_clip)    # per bucket: wait for its reduction, clamp + Adam
+        if work is not None:
+            work.wait()
         return loss_dict(vec)
     if arena is not None:
         arena.all_reduce(group)          # one 88 MB sum over xGMI; clamp must see reduced grads
