@@ -119,6 +119,7 @@ extern "C" int isc_logsoftmax_bwd_sparse(const float *dlogp_dense, const float *
 // iteration that never wrote the [B,T,V] log-probs): exp(logp) = exp((x - max) - log(sum)), the expression the log-probs
 // would have been stored with - the same d logits bits.  Rows in [B,T] order for ids / coef; logits row (b,t) at
 // b*ld_b + t*ld_t, statistics row t*step_rows + b, output row t*out_step_rows + b (time-major).
+template <bool VEC4>
 __global__ __launch_bounds__(256) void logsoftmax_bwd_raw_kernel(const float *raw, long long ld_b, long long ld_t, int B, int T,
                                                                  int V, const float *pmax, const float *psum, int n_tile,
                                                                  int step_rows, SparseDlogp sp, const float *scale,
@@ -146,15 +147,24 @@ __global__ __launch_bounds__(256) void logsoftmax_bwd_raw_kernel(const float *ra
     }
     const float *y = raw + (long long)b * ld_b + (long long)t * ld_t;
     float *o = dlogits + ((long long)t * out_step_rows + b) * ld_out;
-    for (int i = tid; i < ld_out; i += 256) {
+    auto one = [&](int i, float yi) __attribute__((always_inline)) {
         float v = 0.f;
-        if (i < V) {
 #pragma unroll
-            for (int j = 0; j < ISC_SPARSE_MAX; ++j)
-                if ((long long)i == id[j]) v += cf[j];
-            v = (v - expf((y[i] - gmax) - logS) * tot) * sc;
+        for (int j = 0; j < ISC_SPARSE_MAX; ++j)
+            if ((long long)i == id[j]) v += cf[j];
+        return (v - expf((yi - gmax) - logS) * tot) * sc;
+    };
+    if (VEC4) {                          // rows start on 16-byte boundaries, V % 4 == 0: four columns per lane and access
+        for (int i = tid * 4; i < ld_out; i += 1024) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < V) {
+                const float4 yv = *reinterpret_cast<const float4 *>(y + i);
+                v.x = one(i, yv.x); v.y = one(i + 1, yv.y); v.z = one(i + 2, yv.z); v.w = one(i + 3, yv.w);
+            }
+            *reinterpret_cast<float4 *>(o + i) = v;
         }
-        o[i] = v;
+    } else {
+        for (int i = tid; i < ld_out; i += 256) o[i] = i < V ? one(i, y[i]) : 0.f;
     }
 }
 
@@ -174,9 +184,16 @@ extern "C" int isc_logsoftmax_bwd_raw(const float *raw, int64_t ld_b, int64_t ld
         if (!ids_host || !coef_host || !ids_host[j] || !coef_host[j]) return ISC_E_NULL;
         sp.ids[j] = ids_host[j]; sp.coef[j] = coef_host[j];
     }
-    hipLaunchKernelGGL(logsoftmax_bwd_raw_kernel, dim3((unsigned)(B * T)), dim3(256), 0, (hipStream_t)stream, raw,
-                       (long long)ld_b, (long long)ld_t, B, T, V, part_max, part_sum, (V + 127) / 128, step_rows, sp, scale,
-                       dlogits, (long long)ld_out, out_step_rows);
+    const bool vec4 = (V & 3) == 0 && (ld_out & 3) == 0 && (ld_b & 3) == 0 && (ld_t & 3) == 0 && isc_aligned16(raw) &&
+                      isc_aligned16(dlogits);
+    if (vec4)
+        hipLaunchKernelGGL(logsoftmax_bwd_raw_kernel<true>, dim3((unsigned)(B * T)), dim3(256), 0, (hipStream_t)stream, raw,
+                           (long long)ld_b, (long long)ld_t, B, T, V, part_max, part_sum, (V + 127) / 128, step_rows, sp,
+                           scale, dlogits, (long long)ld_out, out_step_rows);
+    else
+        hipLaunchKernelGGL(logsoftmax_bwd_raw_kernel<false>, dim3((unsigned)(B * T)), dim3(256), 0, (hipStream_t)stream, raw,
+                           (long long)ld_b, (long long)ld_t, B, T, V, part_max, part_sum, (V + 127) / 128, step_rows, sp,
+                           scale, dlogits, (long long)ld_out, out_step_rows);
     ISC_LAUNCH_CHECK();
     return ISC_OK;
 }
