@@ -598,7 +598,11 @@ extern "C" int isc_attn_dv_from_alpha(const float *alpha, int64_t alpha_ld_b, in
     int Rc = ISC_POST_LDS_BYTES / (int)sizeof(float) / T;      // regions per chunk: [T][Rc] floats of LDS
     if (Rc < 1) return ISC_E_SHAPE;                             // T > 15000 steps
     if (Rc > R) Rc = R;
-    const int nchunk = (R + Rc - 1) / Rc, ncol = (D / 4 + 255) / 256;
+    const int ncol = (D / 4 + 255) / 256;
+    // few rows: more region chunks until the grid covers the chip twice (an output element's additions do not depend on
+    // the chunking; B = 128 with 36 regions was 128 workgroups)
+    while (Rc > 4 && (long long)B * ((R + Rc - 1) / Rc) * ncol < 512) Rc = (Rc + 1) / 2;
+    const int nchunk = (R + Rc - 1) / Rc;
     if (nchunk > 65535 || ncol > 65535) return ISC_E_SHAPE;
     const size_t lds = (size_t)T * Rc * sizeof(float);
     hipLaunchKernelGGL(attn_dv_from_alpha_kernel, dim3(B, nchunk, ncol), dim3(256), lds, (hipStream_t)stream, alpha,
@@ -670,7 +674,12 @@ extern "C" int isc_attn_dp_from_de(const float *P, const float *q, const float *
     if (!isc_aligned16(P) || !isc_aligned16(q) || !isc_aligned16(w) || !isc_aligned16(dP) || (q2 && !isc_aligned16(q2)))
         return ISC_E_ALIGN;
     const int A4 = A / 4, cols = A4 < 256 ? A4 : 256;          // (a ragged last column block only has MORE groups)
-    int Rc = ISC_DP_RMAX * (256 / cols);                        // what a workgroup's threads hold in registers
+    int rmax = ISC_DP_RMAX;                                     // regions a thread keeps in registers
+    const int ncol0 = (A4 + 255) / 256;
+    // few rows (B = 128, 36 regions: 128 workgroups on 256 CUs, each bound by its 47 M tanh): fewer regions per thread,
+    // more region chunks - every (row, region, column) is computed by one thread either way: the same values
+    while (rmax > 3 && (long long)B * ((R + rmax * (256 / cols) - 1) / (rmax * (256 / cols))) * ncol0 < 512) rmax = (rmax + 1) / 2;
+    int Rc = rmax * (256 / cols);                               // what a workgroup's threads hold in registers
     const int lds_cap = ISC_POST_LDS_BYTES / (int)sizeof(float) / T;
     if (lds_cap < 1) return ISC_E_SHAPE;
     if (Rc > lds_cap) Rc = lds_cap;
