@@ -434,7 +434,7 @@ def bench_r196(cap, dev):
     return out
 
 
-def bench_rl(dev, iters=3, B=512, cache_image_sentiments=True, rank=0, world=1):
+def bench_rl(dev, iters=8, B=512, cache_image_sentiments=True, rank=0, world=1):
     """BASELINE.json configs[4]: self-critical RL iteration (Detector.forward, training=True): sampled +
     greedy roll-out per image, CIDEr-D + classifier rewards, XE (ss 0.5) + seq2seq (ss 0.25) passes,
     backward, clamp, Adam; GLOBAL B=512, T=20, 6x6x2048 grid for the sentiment detector, 5 GT captions/image.
@@ -576,7 +576,7 @@ def bench_beam(cap, inputs, n_img=64, beam=5):
                            batched_images_per_s=round(n_img / el, 1)))
 
 
-PMC_SUMMARY = os.path.join(ROOT, 'profiles', 'r05_a_pmc_summary_B16384.json')
+PMC_SUMMARY = os.path.join(ROOT, 'profiles', 'r05_b_pmc_summary_B16384.json')
 # bench kernel label -> device symbols it may run as (first one present in the PMC summary wins)
 KERNEL_SYMBOL = {'vocab[': ['void gemm_h3_kernel<2, false>', 'void gemm_h3_kernel<2>', 'void gemm_ld_kernel<2>', 'void gemm_kernel<4, 1, 4, 2, false, false>'],
                  'lstm[': ['void gemm_h3x_kernel<1, false>', 'void gemm_h3x_kernel<1>', 'void gemm_h3_kernel<1>', 'void gemm_ld_kernel<1>', 'void gemm_kernel<4, 1, 4, 1, false, false>', 'void gemm_xl_kernel<1>'],
@@ -827,7 +827,7 @@ def run(args):
                             ('scan_sweep', lambda: bench_scan_sweep(dev)),
                             ('table_build', lambda: bench_table_build(cap, inputs)),
                             ('rl_iteration', lambda: bench_rl(dev)),
-                            ('rl_iteration_cold_sentiment_cache', lambda: bench_rl(dev, cache_image_sentiments=False))):
+                            ('rl_iteration_cold_sentiment_cache', lambda: bench_rl(dev, iters=3, cache_image_sentiments=False))):
                 progress('extra: ' + key)
                 try:
                     extra[key] = fn()
