@@ -382,7 +382,7 @@ class _RLGeometry(_Geometry):
         super().__init__()
         self.g_roll = self.g_greedy = self.g_fwd = self.g_bwd = None     # (g_up: the update graph under a process group)
         self.pool = None
-        self.host = None            # pinned host copies of the two token matrices and the sampled lengths
+        self.host = None            # pinned host copies of the two token matrices
         self.reward = None          # static [B, T] reward the REINFORCE loss reads
         self.late = {}              # inputs handed over as callables, still to be produced this iteration
         self.stats = None           # static [7] device statistics of the iteration
@@ -442,15 +442,15 @@ class RLTrainGraph(XETrainGraph):
 
     # ---- phases ---------------------------------------------------------------------------------------------------
     def _phase_roll(self, geo):
-        """Sampled roll-out (graph kept), domain-align loss; its token matrix and lengths on their way to the host."""
+        """Sampled roll-out (graph kept), domain-align loss; its token matrix on its way to the host (the lengths stay on the
+        device: the classifier reward reads them there)."""
         det, cap, i = self.det, self.cap, geo.inputs
         cap.cpt_feats = cap.fc_feats = cap.s2s_cpt_feats = None
         cap.train(True)
         seq, lp, mk = cap(i['fc'], i['att'], i['cpts'], i['sentis'], i['labels'], det.max_seq_len, sample_max=0, mode='rl')
         da = det.cap_da_crit(cap.cpt_feats, cap.fc_feats.detach())
-        lens = geo.lens_d = mk.sum(dim=-1).type(torch.int32)
+        geo.lens_d = mk.sum(dim=-1).type(torch.int32)
         geo.host[0].copy_(seq, non_blocking=True)
-        geo.host[2].copy_(lens, non_blocking=True)
         return seq, lp, mk, da
 
     def _phase_greedy(self, geo):
@@ -604,8 +604,7 @@ class RLTrainGraph(XETrainGraph):
     def _alloc(self, geo):
         i = geo.inputs
         B, T = i['fc'].shape[0], self.det.max_seq_len
-        geo.host = (torch.empty(B, T, dtype=torch.int64).pin_memory(), torch.empty(B, T, dtype=torch.int64).pin_memory(),
-                    torch.empty(B, dtype=torch.int32).pin_memory())
+        geo.host = (torch.empty(B, T, dtype=torch.int64).pin_memory(), torch.empty(B, T, dtype=torch.int64).pin_memory())
         geo.reward = torch.zeros(B, T, dtype=torch.float32, device=self.device)
         geo.fact0 = torch.zeros(B, dtype=torch.float32, device=self.device)
         geo.cls = torch.zeros(B, T, dtype=torch.float32, device=self.device)
