@@ -307,3 +307,29 @@ def test_detector_senti_branch_matches_the_reference(golden):
         np.testing.assert_allclose(v, g['dse/loss_' + k][0], rtol=2e-4, atol=2e-5, err_msg=k)
     for k, v in det.captioner.state_dict().items():
         assert torch.equal(v, before[k])
+
+
+@pytest.mark.gpu
+def test_classifier_reward_with_the_lengths_on_the_device_equals_the_host_lengths_form():
+    """rewards.get_cls_reward (self_critical/utils.py:120-151): the graph-served RL iteration hands the sampled lengths
+    over as a DEVICE tensor - the sentence classifier then runs over all T columns with nothing read by the host - where
+    the reference (and the eager path) packs to the longest row.  Same rewards: the LSTM is causal and positions at or
+    beyond a row's length are masked, so the values agree to rounding and the padding is exactly zero."""
+    from insenticap_model_amd.rewards import get_cls_reward
+    DEV = torch.device('cuda:0')
+    st = dict(synth.TINY_SETTINGS, **synth.HELPER_SETTINGS)
+    Vn, Tn, Bn = 64, 12, 33
+    cls_net = load_helper(SentenceSentimentClassifier(synth.make_idx2word(Vn), synth.SENTIMENT_CATEGORIES, st), 52).to(DEV)
+    cls_net.eval()
+    rng = np.random.default_rng(4)
+    lens = rng.integers(1, Tn - 2, size=Bn)                 # every row shorter than T: the host form packs to max(lens) < T
+    seq = torch.from_numpy(rng.integers(2, Vn, size=(Bn, Tn), dtype=np.int64)).to(DEV)
+    mk = (torch.arange(Tn)[None, :] < torch.from_numpy(lens)[:, None]).float().to(DEV)
+    labels = torch.from_numpy(rng.integers(0, len(synth.SENTIMENT_CATEGORIES), size=Bn, dtype=np.int64)).to(DEV)
+    host = get_cls_reward(seq, mk, None, None, labels, cls_net, sample_lens=lens.tolist(), on_device=True)
+    dev = get_cls_reward(seq, mk, None, None, labels, cls_net, sample_lens=mk.sum(-1).to(torch.int32), on_device=True)
+    assert host.shape == dev.shape == (Bn, Tn)
+    np.testing.assert_allclose(dev.cpu().numpy(), host.cpu().numpy(), rtol=1e-5, atol=1e-7)
+    pad = (torch.arange(Tn, device=DEV)[None, :] >= mk.sum(-1, keepdim=True))
+    assert float(dev[pad].abs().max()) == 0.0 and float(host[pad].abs().max()) == 0.0
+    assert float(dev.abs().max()) > 0.0

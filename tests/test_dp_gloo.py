@@ -125,6 +125,8 @@ def _guard_worker(rank, world, port, results):
     try:
         for name, fn in (('global_count', lambda: dp.global_count(5.0)),
                          ('global_counts', lambda: dp.global_counts([1.0, 2.0], 'cpu')),
+                         ('global_counts_async', lambda: dp.global_counts([1.0, 2.0], 'cpu', asynchronous=True)),
+                         ('all_reduce_async', lambda: dp.all_reduce_async_(torch.ones(3))),
                          ('dp_token_mean', lambda: dp.dp_token_mean(torch.tensor(1.0), 3.0)),
                          ('arena', lambda: dp.GradArena(Toy().parameters()).all_reduce()),
                          ('same', lambda: dp.assert_same_across_ranks(3, 'cpu')),
@@ -140,6 +142,12 @@ def _guard_worker(rank, world, port, results):
     before = dp.COLLECTIVES
     n = dp.global_count(5.0 + rank)
     loc, glob = dp.global_counts([1.0, torch.tensor(2.0 * (rank + 1))], 'cpu')
+    # the asynchronous forms (the eager data-parallel step's normaliser counts and loss statistics): same sums, read after wait()
+    loc_a, glob_a, work = dp.global_counts([1.0, torch.tensor(2.0 * (rank + 1))], 'cpu', asynchronous=True)
+    vec, work2 = dp.all_reduce_async_(torch.tensor([1.0 + rank, 10.0]))
+    work.wait()
+    work2.wait()
+    out['async'] = (loc_a.tolist(), glob_a.tolist(), vec.tolist())
     dp.assert_same_across_ranks(7, 'cpu')
     try:
         dp.assert_same_across_ranks(7 + rank, 'cpu', what='trip count')
@@ -161,12 +169,14 @@ def test_collectives_refuse_cpu_tensors_under_rccl_and_mismatched_ranks_raise():
     mp.spawn(_guard_worker, args=(world, port, results), nprocs=world, join=True)
     for r in (0, 1):
         g = results[r]['guard']
-        assert set(g) == {'global_count', 'global_counts', 'dp_token_mean', 'arena', 'same', 'broadcast'}
+        assert g.pop('async') == ([1.0, 2.0 * (r + 1)], [2.0, 6.0], [3.0, 20.0])
+        assert set(g) == {'global_count', 'global_counts', 'global_counts_async', 'all_reduce_async', 'dp_token_mean',
+                          'arena', 'same', 'broadcast'}
         for k, msg in g.items():
             assert 'nccl' in msg, (k, msg)
         assert results[r]['n'] == 11.0
         assert results[r]['glob'] == [2.0, 6.0] and results[r]['loc'] == [1.0, 2.0 * (r + 1)]
-        assert results[r]['issued'] == 4
+        assert results[r]['issued'] == 6
         assert 'trip count differs across ranks' in results[r]['mismatch']
 
 
