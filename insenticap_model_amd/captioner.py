@@ -946,6 +946,21 @@ class Captioner(nn.Module):
                 self._warn_out_of_domain('max |x| = %g' % v)
         return verdict
 
+    def _known_out_of_domain(self, *feats, remember=False):
+        """Feature tensors a search was already redone for (Captioner.sample_batch): keyed by storage address, size and
+        version - `sample` hands in views, whose object identity changes from call to call.  A stale entry (another
+        tensor at the same address) only costs the fast engine for that call, never a wrong result."""
+        bad = self.__dict__.setdefault('_domain_bad', {})
+        keys = [(x.data_ptr(), x.numel(), x._version) for x in feats
+                if x is not None and torch.is_tensor(x) and x.is_floating_point()]
+        if remember:
+            while len(bad) >= 16:
+                bad.pop(next(iter(bad)))
+            for k in keys:
+                bad[k] = True
+            return True
+        return any(k in bad for k in keys)
+
     def _warn_out_of_domain(self, what):
         if not self.__dict__.get('_domain_warned'):
             import warnings
@@ -1075,24 +1090,34 @@ class Captioner(nn.Module):
         from .beam import beam_search_batch, replay_if_captured
         if self.training:
             self.eval()
-        if not self._features_in_domain(fc_feats, att_feats):
+        checks = getattr(self, 'numerics_checks', True)
+
+        def on_exact_engine():
             # features beyond the split-f16 domain: the reference's sample() decodes whatever the encoder produced
             # (captioner.py:357-376) - this search runs eagerly on the exact-fp32 engine
             self._p()
             with ops.exact_fp32_engine(), ops.h3_weights_scope(self._dev, key=self._weights_key()):
-                return beam_search_batch(self, fc_feats, att_feats, senti_words, senti_labels, beam_size,
-                                         decoding_constraint, max_seq_len, graphs=False)
+                res = beam_search_batch(self, fc_feats, att_feats, senti_words, senti_labels, beam_size,
+                                        decoding_constraint, max_seq_len, graphs=False)
+            ops.device_status(reset=True)          # (NaN / inf features flag there as well: decoded as they are)
+            return res
+        # A search ends with a host read of its results, so the numerics flags are visible right behind it: no pass over
+        # the features in front of the call (that pass + its host read were 6 % of a one-image search) - a flagged search
+        # is redone on the exact engine, and the verdict on these feature tensors is remembered.
+        if checks and ops.h3_mode() != 0 and self._known_out_of_domain(fc_feats, att_feats):
+            return on_exact_engine()
         out = replay_if_captured(self, fc_feats, att_feats, senti_words, senti_labels, beam_size, decoding_constraint,
                                  max_seq_len)
-        if out is not None:
-            if getattr(self, 'numerics_checks', True):
-                ops.check_numerics('Captioner.sample')
-            return out
-        self._p()                                  # raises on CPU parameters before anything touches the device
-        with ops.h3_weights_scope(self._dev, key=self._weights_key()):     # prologue + search: weights split once
-            out = beam_search_batch(self, fc_feats, att_feats, senti_words, senti_labels, beam_size,
-                                    decoding_constraint, max_seq_len)
-        if getattr(self, 'numerics_checks', True):     # the host has the results, i.e. has waited: read the status too
+        if out is None:
+            self._p()                              # raises on CPU parameters before anything touches the device
+            with ops.h3_weights_scope(self._dev, key=self._weights_key()):     # prologue + search: weights split once
+                out = beam_search_batch(self, fc_feats, att_feats, senti_words, senti_labels, beam_size,
+                                        decoding_constraint, max_seq_len)
+        if checks:                                 # the host has the results, i.e. has waited: read the status too
+            if ops.h3_mode() != 0 and ops.device_status(reset=True):
+                self._known_out_of_domain(fc_feats, att_feats, remember=True)
+                self._warn_out_of_domain('non-finite values in a beam search')
+                return on_exact_engine()
             ops.check_numerics('Captioner.sample')
         return out
 
