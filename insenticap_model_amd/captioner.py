@@ -338,38 +338,50 @@ class Captioner(nn.Module):
         emb, W2, b2 = p['word_embed.0.weight'], p['senti2att.0.weight'], p['senti2att.0.bias']
         key = (emb.data_ptr(), emb._version, W2.data_ptr(), W2._version, b2.data_ptr(), b2._version, ops.WEIGHT_EPOCH,
                ops.h3_mode() == 0)          # (a table built by one GEMM engine is not handed to a call on the other)
-        cached = getattr(self, '_senti_tab_cache', None)
-        if cached is not None and cached[0] == key:
-            return cached[1]
+        cached = self._table_cache('_senti_tab_cache', key)
+        if cached is not None:
+            return cached
         V, Wd, A = self.vocab_size, self.settings['word_emb_dim'], self.settings['att_hid_dim']
         act = self._new(V, Wd)
         ops.embed_relu_fwd(emb, torch.arange(V, dtype=torch.int64, device=self._dev), act)
         proj = self._new(V, A)
         ops.linear_fwd([ops.linear_problem([(act, W2)], proj, b2, relu=True)])
-        self._senti_tab_cache = (key, (act, proj))
+        self._table_cache('_senti_tab_cache', key, (act, proj))
         return act, proj
+
+    def _table_cache(self, name, key, value=None):
+        """Weight-derived tables, ONE entry per GEMM engine (the last element of `key`: exact-fp32 engine or not): a call
+        served on the other engine - an out-of-domain input, `--h3-mode 0` - builds its own table and leaves the first
+        engine's in place (a single slot made every switch back rebuild, or miss, the 82 MB token table)."""
+        slots = self.__dict__.setdefault(name, {})
+        if not isinstance(slots, dict):
+            slots = self.__dict__[name] = {}
+        if value is None:
+            e = slots.get(key[-1])
+            return e[1] if e is not None and e[0] == key else None
+        slots[key[-1]] = (key, value)
+        return value
 
     def _gate_senti_table(self, p, act):
         """relu(Emb) attention.senti2att.weight^T [V,A]: the sentiment-word table carried through the gate's projection
         (isc_attn_scan_gate_fwd), cached until the embedding or that weight change."""
         emb, Wg = p['word_embed.0.weight'], p['attention.senti2att.weight']
         key = (emb.data_ptr(), emb._version, Wg.data_ptr(), Wg._version, ops.WEIGHT_EPOCH, ops.h3_mode() == 0)
-        cached = getattr(self, '_gate_tab_cache', None)
-        if cached is not None and cached[0] == key:
-            return cached[1]
+        cached = self._table_cache('_gate_tab_cache', key)
+        if cached is not None:
+            return cached
         tab = self._new(act.shape[0], Wg.shape[0])
         ops.linear_fwd([ops.linear_problem([(act, Wg)], tab)])
-        self._gate_tab_cache = (key, tab)
-        return tab
+        return self._table_cache('_gate_tab_cache', key, tab)
 
     def _embedding_table(self, p, build):
         """relu(Emb) W_x^T [V,4H], cached until the embedding or the att-LSTM weights change
         (tensor version counters). Only used without autograd; costs V*4H*W*2 flop (21 GFLOP) once."""
         emb, Wih = p['word_embed.0.weight'], p['att_lstm.weight_ih']
         key = (emb.data_ptr(), emb._version, Wih.data_ptr(), Wih._version, ops.WEIGHT_EPOCH, ops.h3_mode() == 0)
-        cached = getattr(self, '_tab_cache', None)
-        if cached is not None and cached[0] == key:
-            return cached[1]
+        cached = self._table_cache('_tab_cache', key)
+        if cached is not None:
+            return cached
         if not build:
             return None
         st = self.settings
@@ -378,8 +390,7 @@ class Captioner(nn.Module):
         ops.embed_relu_fwd(emb, torch.arange(V, dtype=torch.int64, device=self._dev), act)
         tab = self._new(V, 4 * H)
         ops.linear_fwd([ops.linear_problem([(act, Wih[:, H + E:])], tab)])
-        self._tab_cache = (key, tab)
-        return tab
+        return self._table_cache('_tab_cache', key, tab)
 
     # ------------------------------------------------------------------ one decode step
     ROWS_STEP_MAX = 8              # decode rows up to which an inference step runs on the few-row kernels (csrc/rows.hip)

@@ -73,7 +73,7 @@ def test_greedy_at_the_bench_batch_in_auto_mode_is_the_bench_path_and_matches_th
     n_h3, n_h3x = lib.isc_h3_launches() - h3_0, lib.isc_h3x_launches() - h3x_0
     assert n_h3 >= 5 * Tn, n_h3            # classifier, 2 LSTM cells, h-projections, gate sum - every step
     assert n_h3x >= 2 * Tn, n_h3x          # both LSTM cells on the 256-row kernel, every step
-    assert cap._tab_cache is not None and cap._senti_tab_cache is not None      # token / sentiment-word tables
+    assert cap._tab_cache.get(False) is not None and cap._senti_tab_cache.get(False) is not None   # token / sentiment-word tables (split-f16 engine's slot)
     del a
     oseq, olp, omk, margins = oracle_greedy(w, c, d, Tn)
     check_rollout(seq, lp, mk, oseq, olp, omk, margins, Tn)
