@@ -83,8 +83,14 @@ class CiderD:
                                        n, sigma)
         if not self._h:
             raise RuntimeError('isc_cider_create failed')
-        self.n_threads = n_threads or min(16, len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity')
-                                          else (os.cpu_count() or 1))
+        # up to 16 scoring threads, of this process's share of the host's cores (one process per GPU: LOCAL_WORLD_SIZE ranks of
+        # a launcher share them - eight ranks x 16 threads on a 64-core host would only queue behind each other)
+        cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+        try:
+            local_ranks = max(1, int(os.environ.get('LOCAL_WORLD_SIZE', '1')))
+        except ValueError:
+            local_ranks = 1
+        self.n_threads = n_threads or max(1, min(16, cores // local_ranks))
         self._gt_cache = {}
 
     def __del__(self):
