@@ -110,6 +110,8 @@ def _train_forward(cap, mode, fc, att, cpt_words, senti_words, tokens_in, senti_
         pm_all, ps_all, pi_all = pm_st, ps_st, pi_st
     # the weights are fixed for the whole unroll: their f16 planes are built once (few-row launches then take the
     # one-launch skinny split-f16 kernels instead of split-K + reduce pairs)
+    # scheduled sampling: the uniforms of every step (select, draw) in ONE launch in front of the loop (was one per step)
+    u_all = torch.rand(max(T - 1, 1), 2, B, device=cap._dev) if (not sampling and not fed_known) else None
     with _weights_scope(cap):
         for t in range(T):
             if sampling:
@@ -117,7 +119,7 @@ def _train_forward(cap, mode, fc, att, cpt_words, senti_words, tokens_in, senti_
                     S.tok[t].copy_(seq[:, t - 1])             # it * unfinished, written by the previous finalize
             elif not fed_known:
                 if t >= 1:                                    # scheduled sampling, captioner.py:219-228:
-                    u = torch.rand(2, B, device=cap._dev)     # select + draw on the device, no host test
+                    u = u_all[t - 1]                          # select + draw on the device, no host test
                     ops.sched_sample(out[:, t - 1], pm_st[t - 1], ps_st[t - 1], pi_st[t - 1], u[0], u[1], ss_prob,
                                      tokens_in[:, t], S.tok[t], raw=True)
                 else:
