@@ -839,3 +839,32 @@ def test_gated_scan_odd_shapes_vs_fp64(B, R, M, A, table):
     np.testing.assert_allclose(aS.cpu().numpy(), as_.float().numpy(), atol=3e-6)
     np.testing.assert_allclose(b2.cpu().numpy(), beta.float().numpy(), atol=5e-6)
     np.testing.assert_allclose(f2.cpu().numpy(), f.float().numpy(), atol=1e-5)
+
+
+def test_weight_tables_keep_one_slot_per_engine():
+    """The token / sentiment-word tables derive from the weights through a GEMM, so each GEMM engine builds its own
+    (Captioner._table_cache).  A call served on the exact-fp32 engine - `--h3-mode 0`, an out-of-domain input - must not
+    evict the split-f16 engine's table: few-caption roll-outs only USE a cached table ('cached'), so after an eviction they
+    silently ran without it (round 5: B = 4 roll-outs 0.75 -> 0.82 ms after bench.py's exact-engine leg)."""
+    from conftest import case_setup
+    c, st, w, d, _ = case_setup('cfg1')
+    cap = Captioner(synth.make_idx2word(c['V']), synth.SENTIMENT_CATEGORIES, st)
+    cap.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()})
+    cap.to(dev()).eval()
+    Tn = 8
+    rows = c['V'] // (4 * Tn) + 8                                          # rows x steps >= V / 4: the roll-out builds the table
+    big = synth.make_inputs(rows, c['V'], st, regions=36, seq_len=Tn, seed=31)
+    a = [torch.from_numpy(np.asarray(big[k])).to(dev()) for k in ('fc_feats', 'att_feats', 'cpt_words', 'senti_words',
+                                                                   'senti_labels')]
+    with torch.no_grad():
+        cap(*a, Tn, 1, mode='rl')
+        tab = cap._tab_cache[False][1]
+        with ops.exact_fp32_engine():
+            cap(*a, Tn, 1, mode='rl')
+        assert cap._tab_cache[True][1] is not tab and cap._tab_cache[False][1] is tab
+        small = [x[:4].contiguous() for x in a]
+        rows0 = ops._lib.load().isc_rows_launches()
+        cap(*small, Tn, 1, mode='rl')                                      # four captions: the table, if it is still cached
+        assert cap._tab_cache[False][1] is tab
+        assert ops._lib.load().isc_rows_launches() > rows0                 # ... on the few-row kernels
+    torch.cuda.synchronize()
