@@ -101,6 +101,26 @@ class XETrainGraph:
             except Exception:           # interpreter shutdown: the library may be gone
                 pass
 
+    def _claim(self):
+        """One training-graph object drives a captioner at a time.  The graphs of this class keep the autograd graph of their
+        captured forward passes alive between replays, and with it the parameters' AccumulateGrad nodes - which run on the
+        stream they were created under (the module docstring's last point).  Another object (an XETrainGraph next to a
+        Detector's RLTrainGraph, say) that captured a backward reaching those nodes would pull a stream of the first
+        object into its capture: the runtime's end-of-capture then crashes (seen: 600 RL iterations, then the first XE
+        capture).  So the object that steps takes the captioner over: the previous owner's captured graphs are dropped
+        (it captures again when it steps next - two eager iterations per geometry)."""
+        import gc
+        ref = self.cap.__dict__.get('_train_graph_owner')
+        other = ref() if ref is not None else None
+        if other is not None and other is not self and other._geoms:
+            torch.cuda.synchronize(self.device)         # its replays have finished before their graphs go
+            other._geoms.clear()
+            other._valid_key = None
+            self.cap.cpt_feats = self.cap.fc_feats = self.cap.s2s_cpt_feats = None
+            gc.collect()                                # (autograd graphs sit in reference cycles with the geometry objects)
+        if other is not self:
+            self.cap.__dict__['_train_graph_owner'] = weakref.ref(self)
+
     def close(self):
         """Drop the graphs and this object's per-stream state now (also happens when the object is collected)."""
         self._geoms.clear()
@@ -345,6 +365,7 @@ class XETrainGraph:
                 raise ValueError('seq2seq captions are %d tokens wide, max(lengths)=%d' % (s_caps.size(1), max(s_lengths)))
             t.update(s_caps=s_caps, s_cpts=s_cpts, s_sentis=s_sentis, s_labels=s_labels,
                      s_len=torch.tensor(s_lengths, dtype=torch.int32))
+        self._claim()
         self.cap.cpt_feats = self.cap.fc_feats = self.cap.s2s_cpt_feats = None      # (see the module docstring: stale AccumulateGrad nodes)
         sig = self._signature(t, ss_prob)
         geo = self._geoms.get(sig)
@@ -735,6 +756,7 @@ class RLTrainGraph(XETrainGraph):
         if callable(xe_senti_labels):       # [B] int64, read by g_fwd only: produced behind the first roll-out (_late_inputs)
             late['xe_labels'] = xe_senti_labels
             t['xe_labels'] = torch.empty(fc.shape[0], dtype=torch.int64, device='meta')
+        self._claim()
         self.cap.cpt_feats = self.cap.fc_feats = self.cap.s2s_cpt_feats = None
         sig = (self._signature(t, 0.0), self.det.max_seq_len, self.det.xe_ss_prob, self.det.seq2seq_ss_prob,
                self.det.cls_flag, self.det.seq_flag)

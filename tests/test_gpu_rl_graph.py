@@ -183,3 +183,31 @@ def test_a_new_batch_geometry_gets_its_own_graphs():
         force_draws(det, d2)
         out = det((it2, scs), 'fact', True)
     assert det._rl_graph.captures == 2 and all(np.isfinite(v) for v in out.values())
+
+
+def test_an_xe_training_graph_and_the_rl_graph_take_turns_on_one_captioner():
+    """Two training-graph objects on ONE captioner (an XE stage's XETrainGraph next to the Detector's RLTrainGraph): each
+    keeps the autograd graph of its captured forward alive, hence the parameters' accumulation nodes on ITS stream - the
+    other object's capture used to pull that stream in and the runtime's end-of-capture crashed (a soak run: 600 RL
+    iterations, then the first XE capture).  The object that steps takes the captioner over and the other's graphs are
+    dropped; it captures again when its turn comes."""
+    from insenticap_model_amd.train_graph import XETrainGraph
+    items, scs, split, draws = data(1)
+    det = make(graphs=True, warmup=1)
+    run(det, items * 3, scs, split, draws * 3)
+    assert det._rl_graph.captures == 1 and det._rl_graph._geoms
+    cap = det.captioner
+    g = XETrainGraph(cap, det.cap_optim, det.cap_xe_crit, det.cap_da_crit, grad_clip=0.1, warmup=1)
+    fns, fc, att, (caps, lengths), cpts = items[0][:5]
+    fact = (None, fc.to(DEV), att.to(DEV), (caps.to(DEV), lengths), cpts.to(DEV))
+    labels = torch.zeros(fc.shape[0], dtype=torch.int64, device=DEV)
+    (s_caps, s_len), s_cpts, s_sentis, s_labels = scs[0]
+    scs_d = ((s_caps.to(DEV), s_len), s_cpts.to(DEV), s_sentis.to(DEV), s_labels.to(DEV))
+    for _ in range(3):
+        out = g.step(fact, labels, scs_d, 0.0)
+    torch.cuda.synchronize()
+    assert g.captures == 1 and not det._rl_graph._geoms            # the RL graphs went when the XE object took over
+    assert all(np.isfinite(float(v)) for v in out.values())
+    outs = run(det, items * 3, scs, split, draws * 3)              # ... and back: two eager phases' worth, a new capture
+    assert det._rl_graph.captures == 2 and not g._geoms
+    assert all(np.isfinite(v) for o in outs for v in o.values())
