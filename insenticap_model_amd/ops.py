@@ -97,7 +97,8 @@ def graphs_allowed_here():
 
 
 def graph_capture(graph, **kw):
-    """torch.cuda.graph(graph, **kw) for this package's captures, safe next to a torch.distributed process group.
+    """torch.cuda.graph(graph, **kw) for this package's captures, safe next to a torch.distributed process group
+    (`settle=False`: skip the wait described below - for the second and later captures of one owner in a row).
     The backend's watchdog thread polls the completion event of every collective still on its list (hipEventQuery,
     every ~100 ms) and retires finished work only at such a pass.  On ROCm a poll of a collective issued shortly before a
     capture opened, landing INSIDE the capture window, fails with hipErrorCapturedEvent - in the watchdog thread, which
@@ -115,7 +116,8 @@ def graph_capture(graph, **kw):
     # 'thread_local' always: another host thread serving its own captioner on its own stream (include/insenticap_hip.h
     # allows that) may allocate or synchronise while this one captures; 'global' would fail ITS calls
     kw.setdefault('capture_error_mode', 'thread_local')
-    if grouped:
+    settle = kw.pop('settle', True)     # False: a capture right behind another one of the same owner (nothing was issued between)
+    if grouped and settle:
         # ... and no collective may still be on the watchdog's list when the capture opens: it retires finished work
         # at its next pass (every 100 ms), so finish everything and let one pass go by.  Captures are once per geometry.
         torch.cuda.synchronize()

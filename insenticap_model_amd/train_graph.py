@@ -292,7 +292,7 @@ class XETrainGraph:
                 geo.g_up = None
                 if self._dist():
                     geo.g_up = torch.cuda.CUDAGraph(keep_graph=self.KEEP_GRAPHS)
-                    with ops.graph_capture(geo.g_up, stream=self.stream):
+                    with ops.graph_capture(geo.g_up, stream=self.stream, settle=False):
                         xe_update(self.optim, self.grad_clip)
                 geo.keep = (vec_xe, s2s)
         finally:
@@ -671,21 +671,21 @@ class RLTrainGraph(XETrainGraph):
                 with ops.graph_capture(geo.g_roll, stream=self.stream, pool=geo.pool):
                     roll = self._phase_roll(geo)
                 geo.g_greedy = torch.cuda.CUDAGraph(keep_graph=self.KEEP_GRAPHS)
-                with ops.graph_capture(geo.g_greedy, stream=self.greedy_stream):
+                with ops.graph_capture(geo.g_greedy, stream=self.greedy_stream, settle=False):
                     roll = roll + self._phase_greedy(geo)
                 geo.g_fwd = torch.cuda.CUDAGraph(keep_graph=self.KEEP_GRAPHS)
                 # (a pool of its own: it runs next to g_roll.  Captured from self.stream with self.xe_stream and self.side as
                 # two branches of it - a branch forked off a branch ended in a segmentation fault inside the runtime's
                 # end-of-capture here - and replayed on self.xe_stream)
-                with ops.graph_capture(geo.g_fwd, stream=self.stream):
+                with ops.graph_capture(geo.g_fwd, stream=self.stream, settle=False):
                     fwd = self._phase_fwd(geo)
                 geo.g_bwd = torch.cuda.CUDAGraph(keep_graph=self.KEEP_GRAPHS)
-                with ops.graph_capture(geo.g_bwd, stream=self.stream, pool=geo.pool):
+                with ops.graph_capture(geo.g_bwd, stream=self.stream, pool=geo.pool, settle=False):
                     self._phase_bwd(geo, roll, fwd)
                 geo.g_up = None
                 if self._dist():
                     geo.g_up = torch.cuda.CUDAGraph(keep_graph=self.KEEP_GRAPHS)
-                    with ops.graph_capture(geo.g_up, stream=self.stream, pool=geo.pool):
+                    with ops.graph_capture(geo.g_up, stream=self.stream, pool=geo.pool, settle=False):
                         xe_update(self.optim, self.grad_clip)
                 geo.keep = (roll, fwd)
         finally:

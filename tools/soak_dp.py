@@ -34,17 +34,17 @@ scs = ((tt(s['captions']).to(dev), s['lengths']), tt(s['cpt_words']).to(dev), tt
 labels = tt(d['senti_labels']).to(dev)
 c0 = dp.COLLECTIVES
 t0 = time.perf_counter()
-for i in range(n):
+for i in range(0 if os.environ.get('SKIP_EAGER') else n):
     l = xe_train_step(cap, det.cap_optim, det.cap_xe_crit, det.cap_da_crit, fact, labels, scs, 0.25, 0.1, arena=arena)
 torch.cuda.synchronize()
-print('eager bucketed: %d steps, %.2f ms each, %d collectives, loss %.4f' % (n, (time.perf_counter() - t0) / n * 1e3, dp.COLLECTIVES - c0, float(l['all_loss'])), flush=True)
+if not os.environ.get('SKIP_EAGER'): print('eager bucketed: %d steps, %.2f ms each, %d collectives, loss %.4f' % (n, (time.perf_counter() - t0) / n * 1e3, dp.COLLECTIVES - c0, float(l['all_loss'])), flush=True)
 cap.cpt_feats = cap.fc_feats = None
 g = XETrainGraph(cap, det.cap_optim, det.cap_xe_crit, det.cap_da_crit, grad_clip=0.1, arena=arena, warmup=2)
 t0 = time.perf_counter()
-for i in range(n):
+for i in range(0 if os.environ.get('SKIP_GRAPH') else n):
     l = g.step(fact, labels, scs, 0.25)
 torch.cuda.synchronize()
-print('graph + flat exchange: %d steps, %.2f ms each, %d replays, loss %.4f' % (n, (time.perf_counter() - t0) / n * 1e3, g.replays, float(l['all_loss'])), flush=True)
+if not os.environ.get('SKIP_GRAPH'): print('graph + flat exchange: %d steps, %.2f ms each, %d replays, loss %.4f' % (n, (time.perf_counter() - t0) / n * 1e3, g.replays, float(l['all_loss'])), flush=True)
 batches, split = synth.make_rl_batches(2, 64, V, st, grid=(6, 6), seq_len=T, seed=90)
 det.set_ciderd_scorer(split)
 facts = [[(b[0], tt(b[1]).to(dev), tt(b[2]).to(dev), (tt(b[3][0]).to(dev), b[3][1]), tt(b[4]).to(dev), tt(b[5]).to(dev), b[6])] for b in batches]
