@@ -1142,9 +1142,11 @@ class XECriterion(nn.Module):
     """Masked NLL with a global token mean (captioner.py:427-440)."""
 
     def forward(self, pred, target, lengths):
+        # (the reference slices the targets to max(lengths) and masks by row: a `pred` WIDER than the longest caption -
+        # captions padded to a fixed width so that every batch has one geometry - gives the same loss; narrower cannot)
         max_len = max(lengths)
-        if pred.size(1) != max_len:
-            raise ValueError('pred.size(1)=%d must equal max(lengths)=%d' % (pred.size(1), max_len))
+        if pred.size(1) < max_len:
+            raise ValueError('pred.size(1)=%d is shorter than max(lengths)=%d' % (pred.size(1), max_len))
         if pred.requires_grad:
             from .autograd import xe_criterion_with_grad
             return xe_criterion_with_grad(pred, target, lengths)

@@ -28,9 +28,14 @@ def _pad_rows(seqs, width, pad_index, limit=None):
     return torch.from_numpy(out)
 
 
-def _caps(caps, max_seq_len, pad_index):
+def _caps(caps, max_seq_len, pad_index, caption_width=None):
     lengths = [min(len(c), max_seq_len) for c in caps]
-    tensor = _pad_rows(caps, lengths[0], pad_index)        # rows are sorted: lengths[0] is the maximum
+    width = lengths[0]                                     # rows are sorted: lengths[0] is the maximum
+    if caption_width == 'full':
+        width = max_seq_len
+    elif caption_width:                                    # an int m: the batch's width rounded up to a multiple of m
+        width = min(max_seq_len, (width - 1 + int(caption_width) - 1) // int(caption_width) * int(caption_width) + 1)
+    tensor = _pad_rows(caps, width, pad_index, limit=max_seq_len)
     return tensor, [l - 1 for l in lengths]
 
 
@@ -38,18 +43,23 @@ def _feats(xs):
     return torch.from_numpy(np.ascontiguousarray(np.asarray(xs, dtype=np.float32)))
 
 
-def create_collate_fn(name, pad_index=0, max_seq_len=17, num_concepts=5, num_sentiments=10):
+def create_collate_fn(name, pad_index=0, max_seq_len=17, num_concepts=5, num_sentiments=10, caption_width=None):
+    """The reference's collate functions (dataloader.py:11-58).  `caption_width` (not in the reference): None pads a batch's
+    captions to its longest one, as the reference does - every distinct longest length is then another input geometry for
+    the graph-served training steps (train_graph: a capture per geometry, four kept); 'full' pads every batch to
+    max_seq_len, an int m rounds the unroll length (width - 1) up to a multiple of m.  Lengths are returned unchanged and the
+    criteria mask by row, so losses and gradients are those of the tight batch - the extra steps run on <PAD>."""
     def caption(dataset):
         rows = [(fn, fc, att, cap, cpts) for fn, fc, att, caps_idx, cpts in dataset for cap in caps_idx]
         rows.sort(key=lambda p: len(p[3]), reverse=True)          # stable, like the reference
         fns, fcs, atts, caps, cpts = zip(*rows)
-        return fns, _feats(fcs), _feats(atts), _caps(caps, max_seq_len, pad_index), \
+        return fns, _feats(fcs), _feats(atts), _caps(caps, max_seq_len, pad_index, caption_width), \
             _pad_rows(cpts, num_concepts, pad_index)
 
     def scs(dataset):
         rows = sorted(dataset, key=lambda p: len(p[0]), reverse=True)
         caps, cpts, sentis, senti_ids = zip(*rows)
-        return _caps(caps, max_seq_len, pad_index), _pad_rows(cpts, num_concepts, pad_index), \
+        return _caps(caps, max_seq_len, pad_index, caption_width), _pad_rows(cpts, num_concepts, pad_index), \
             _pad_rows(sentis, num_sentiments, pad_index), torch.from_numpy(np.asarray(senti_ids, dtype=np.int64))
 
     def rl_fact(dataset):
@@ -59,7 +69,7 @@ def create_collate_fn(name, pad_index=0, max_seq_len=17, num_concepts=5, num_sen
             rows.append((fn, random.sample(caps_idx, 1)[0], fc, att, cpts, sentis))
         rows.sort(key=lambda p: len(p[1]), reverse=True)
         fns, caps, fcs, atts, cpts, sentis = zip(*rows)
-        return fns, _feats(fcs), _feats(atts), _caps(caps, max_seq_len, pad_index), \
+        return fns, _feats(fcs), _feats(atts), _caps(caps, max_seq_len, pad_index, caption_width), \
             _pad_rows(cpts, num_concepts, pad_index), _pad_rows(sentis, num_sentiments, pad_index), ground_truth
 
     def rl_senti(dataset):
@@ -183,27 +193,32 @@ def _loader(dataset, batch_size, num_workers, shuffle, collate):
 
 
 def get_caption_dataloader(fc_feats, att_feats, img_captions, img_det_concepts, pad_index, max_seq_len,
-                           num_concepts, batch_size, num_workers=0, shuffle=True):
-    """dataloader.py:267-278 (note max_seq_len + 1: the <SOS> column)."""
+                           num_concepts, batch_size, num_workers=0, shuffle=True, caption_width=None):
+    """dataloader.py:267-278 (note max_seq_len + 1: the <SOS> column).  caption_width: create_collate_fn."""
     return _loader(CaptionDataset(fc_feats, att_feats, img_captions, img_det_concepts), batch_size, num_workers,
-                   shuffle, create_collate_fn('caption', pad_index, max_seq_len + 1, num_concepts))
+                   shuffle, create_collate_fn('caption', pad_index, max_seq_len + 1, num_concepts,
+                                              caption_width=caption_width))
 
 
 def get_senti_corpus_with_sentis_dataloader(senti_corpus_with_sentis, pad_index, max_seq_len, num_concepts,
-                                            num_sentiments, batch_size, num_workers=0, shuffle=True):
+                                            num_sentiments, batch_size, num_workers=0, shuffle=True,
+                                            caption_width=None):
     """dataloader.py:281-294."""
     return _loader(SCSDataset(senti_corpus_with_sentis), batch_size, num_workers, shuffle,
                    create_collate_fn('senti_corpus_with_sentis', pad_index, max_seq_len + 1,
-                                     num_concepts=num_concepts, num_sentiments=num_sentiments))
+                                     num_concepts=num_concepts, num_sentiments=num_sentiments,
+                                     caption_width=caption_width))
 
 
 def get_rl_fact_dataloader(fc_feats, att_feats, img_captions, img_det_concepts, img_det_sentiments, pad_index,
-                           max_seq_len, num_concepts, num_sentiments, batch_size, num_workers=0, shuffle=True):
+                           max_seq_len, num_concepts, num_sentiments, batch_size, num_workers=0, shuffle=True,
+                           caption_width=None):
     """dataloader.py:297-312."""
     return _loader(RLFactDataset(fc_feats, att_feats, img_captions, img_det_concepts, img_det_sentiments),
                    batch_size, num_workers, shuffle,
                    create_collate_fn('rl_fact', pad_index=pad_index, max_seq_len=max_seq_len + 1,
-                                     num_concepts=num_concepts, num_sentiments=num_sentiments))
+                                     num_concepts=num_concepts, num_sentiments=num_sentiments,
+                                     caption_width=caption_width))
 
 
 def get_rl_senti_dataloader(fc_feats, att_feats, img_det_concepts, img_det_sentiments, img_senti_labels, pad_index,

@@ -353,7 +353,9 @@ class XETrainGraph:
         tensors, global values under DP), valid on the caller's current stream."""
         _, fc, att, (caps, lengths), cpts = fact_batch[:5]
         lengths = self._as_list(lengths)
-        if caps.size(1) - 1 != max(lengths):
+        # (wider is fine - the criterion masks by row: captions padded to a fixed width keep ONE geometry, i.e. one captured
+        # graph, for batches whose longest caption varies: data.create_collate_fn(caption_width=...))
+        if caps.size(1) - 1 < max(lengths):
             raise ValueError('captions are %d tokens wide, max(lengths)=%d (+1 for <SOS>)' % (caps.size(1), max(lengths)))
         t = dict(fc=fc, att=att, caps=caps, cpts=cpts, labels=xe_senti_labels,
                  len=torch.tensor(lengths, dtype=torch.int32))
@@ -361,7 +363,7 @@ class XETrainGraph:
         if scs_batch is not None:
             (s_caps, s_lengths), s_cpts, s_sentis, s_labels = scs_batch
             s_lengths = self._as_list(s_lengths)
-            if s_caps.size(1) - 1 != max(s_lengths):
+            if s_caps.size(1) - 1 < max(s_lengths):
                 raise ValueError('seq2seq captions are %d tokens wide, max(lengths)=%d' % (s_caps.size(1), max(s_lengths)))
             t.update(s_caps=s_caps, s_cpts=s_cpts, s_sentis=s_sentis, s_labels=s_labels,
                      s_len=torch.tensor(s_lengths, dtype=torch.int32))
@@ -747,8 +749,8 @@ class RLTrainGraph(XETrainGraph):
         lengths = self._as_list(lengths)
         (s_caps, s_lengths), s_cpts, s_sentis, s_labels = scs_batch
         s_lengths = self._as_list(s_lengths)
-        if caps.size(1) - 1 != max(lengths) or s_caps.size(1) - 1 != max(s_lengths):
-            raise ValueError('caption tensors must end at their longest caption (+1 for <SOS>)')
+        if caps.size(1) - 1 < max(lengths) or s_caps.size(1) - 1 < max(s_lengths):
+            raise ValueError('caption tensors are narrower than their longest caption (+1 for <SOS>)')
         t = dict(fc=fc, att=att, caps=caps, cpts=cpts, sentis=sentis, labels=senti_labels, xe_labels=xe_senti_labels,
                  len=torch.tensor(lengths, dtype=torch.int32), s_caps=s_caps, s_cpts=s_cpts, s_sentis=s_sentis,
                  s_labels=s_labels, s_len=torch.tensor(s_lengths, dtype=torch.int32))

@@ -32,6 +32,24 @@ def test_caption_collate_expands_sorts_truncates():
     assert torch.equal(fc[0], fc[1])                       # both rows of image a share its features
 
 
+def test_caption_width_pads_beyond_the_longest_caption_and_leaves_the_lengths():
+    """caption_width (not in the reference): 'full' pads every batch to max_seq_len, an int m rounds the unroll length
+    (width - 1) up to a multiple of m - one input geometry for the graph-served training steps whatever the longest caption
+    of a batch is; rows and lengths are those of the tight collate."""
+    a = _img('a', [[1, 5, 6, 2], [1, 7, 8, 2]])
+    b = _img('b', [[1, 4, 2]])
+    ds = [(a[0], a[1], a[2], a[3], a[4]), (b[0], b[1], b[2], b[3], b[4])]
+    tight = data.create_collate_fn('caption', pad_index=0, max_seq_len=9, num_concepts=4)(ds)
+    assert tight[3][0].shape == (3, 4) and tight[3][1] == [3, 3, 2]
+    full = data.create_collate_fn('caption', pad_index=0, max_seq_len=9, num_concepts=4, caption_width='full')(ds)
+    assert full[3][0].shape == (3, 9) and full[3][1] == tight[3][1]
+    assert full[3][0][:, :4].tolist() == tight[3][0].tolist() and int(full[3][0][:, 4:].abs().sum()) == 0
+    by4 = data.create_collate_fn('caption', pad_index=0, max_seq_len=9, num_concepts=4, caption_width=4)(ds)
+    assert by4[3][0].shape == (3, 5) and by4[3][1] == tight[3][1]          # unroll length 3 -> 4 steps (+ <SOS>)
+    capped = data.create_collate_fn('caption', pad_index=0, max_seq_len=4, num_concepts=4, caption_width=8)(ds)
+    assert capped[3][0].shape == (3, 4)                                     # never beyond max_seq_len
+
+
 def test_scs_and_rl_collates():
     f = data.create_collate_fn('scs', max_seq_len=6, num_concepts=2, num_sentiments=3)
     (caps, lengths), cpts, sentis, ids = f([([1, 9, 2], [5, 6, 7], [8], 1), ([1, 3, 4, 5, 2], [5], [8, 9, 9, 9], 0)])

@@ -207,3 +207,48 @@ def test_graph_after_eager_iterations_on_the_default_stream():
     torch.cuda.synchronize()
     assert g.replays == 3
     assert_same_state(ref, ref_opt, cap, optim)
+
+
+def test_captions_padded_beyond_the_longest_one_train_alike_and_share_one_graph():
+    """Real batches differ in their longest caption, and every distinct width is another input geometry (a capture each,
+    four kept).  The criteria mask by row (captioner.py:427-440 slices to max(lengths)), so captions padded to a FIXED
+    width (data.create_collate_fn(caption_width=...)) give the losses and parameters of the tight batches to rounding (the
+    extra steps run on <PAD> and receive no gradient) - and batches with different longest captions replay ONE graph."""
+    cfg = TINY
+    capA, capB = make(cfg), make(cfg)
+    # (eval mode, as make() leaves them: no dropout, and nothing else is random at ss_prob 0)
+    optA, xc, dc = capA.get_optim_criterion(4e-4)
+    optB = capB.get_optim_criterion(4e-4)[0]
+    pad = capA.pad_id
+    batches = [batch(cfg, 41 + i) for i in range(3)]
+
+    def widen(b, extra):
+        (_, fc, att, (caps, lengths), cpts), labels, ((s_caps, s_len), s_cpts, s_sentis, s_labels) = b
+        fill = lambda x: torch.cat([x, x.new_full((x.shape[0], extra), pad)], 1)     # noqa: E731
+        return (None, fc, att, (fill(caps), lengths), cpts), labels, ((fill(s_caps), s_len), s_cpts, s_sentis, s_labels)
+
+    def shorten(b, k):           # the same rows with their last k target words cut: another longest caption
+        (_, fc, att, (caps, lengths), cpts), labels, scs = b
+        L = max(lengths) - k
+        return (None, fc, att, (caps[:, :L + 1], [min(l, L) for l in lengths]), cpts), labels, scs
+    for b in batches[:2]:
+        fact, labels, scs = b
+        la = xe_train_step(capA, optA, xc, dc, fact, labels, scs, 0.0, 0.1)
+        fact, labels, scs = widen(b, 3)
+        lb = xe_train_step(capB, optB, xc, dc, fact, labels, scs, 0.0, 0.1)
+        for k in la:
+            np.testing.assert_allclose(float(lb[k]), float(la[k]), rtol=2e-6, atol=1e-7, err_msg=k)
+    for (n, p), (_, q) in zip(capA.named_parameters(), capB.named_parameters()):
+        np.testing.assert_allclose(q.detach().cpu().numpy(), p.detach().cpu().numpy(), rtol=0, atol=2e-6, err_msg=n)
+    # one captured graph serves batches whose longest caption differs once they are padded to one width
+    capB.cpt_feats = capB.fc_feats = None
+    g = XETrainGraph(capB, optB, xc, dc, grad_clip=0.1, warmup=1)
+    W = batches[2][0][3][0].shape[1]
+    for k in (0, 2, 1, 3, 0):
+        fact, labels, scs = shorten(batches[2], k)
+        (_, fc, att, (caps, lengths), cpts) = fact
+        caps = torch.cat([caps, caps.new_full((caps.shape[0], W - caps.shape[1]), pad)], 1)
+        out = g.step((None, fc, att, (caps, lengths), cpts), labels, scs, 0.0)
+        assert np.isfinite(float(out['all_loss']))
+    torch.cuda.synchronize()
+    assert g.captures == 1 and g.replays == 4 and len(g._geoms) == 1
