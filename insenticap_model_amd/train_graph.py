@@ -121,6 +121,19 @@ class XETrainGraph:
         if other is not self:
             self.cap.__dict__['_train_graph_owner'] = weakref.ref(self)
 
+    def _evicted(self, geo):
+        """A captured geometry fell out of the `max_geometries` this object keeps.  Real batches differ in their longest
+        caption; padded to that length each width is a geometry of its own, and a trainer that cycles through more widths
+        than are kept pays two eager iterations + a capture every few steps - say so once."""
+        if geo.g_iter is None:
+            return
+        self.evictions = getattr(self, 'evictions', 0) + 1
+        if self.evictions == 8:
+            import warnings
+            warnings.warn('insenticap_model_amd: 8 captured training geometries evicted - the batch geometry keeps changing '
+                          '(a geometry = batch size x padded caption length). Pad captions to a fixed width '
+                          '(data.create_collate_fn(caption_width="full" or a multiple)) or raise max_geometries.')
+
     def close(self):
         """Drop the graphs and this object's per-stream state now (also happens when the object is collected)."""
         self._geoms.clear()
@@ -374,7 +387,7 @@ class XETrainGraph:
         if geo is None:
             geo = self._geoms[sig] = _Geometry()
             while len(self._geoms) > self._max_geoms:
-                self._geoms.popitem(last=False)
+                self._evicted(self._geoms.popitem(last=False)[1])
         else:
             self._geoms.move_to_end(sig)
         caller = torch.cuda.current_stream(self.device)
@@ -766,7 +779,7 @@ class RLTrainGraph(XETrainGraph):
         if geo is None:
             geo = self._geoms[sig] = _RLGeometry()
             while len(self._geoms) > self._max_geoms:
-                self._geoms.popitem(last=False)
+                self._evicted(self._geoms.popitem(last=False)[1])
         else:
             self._geoms.move_to_end(sig)
         caller = torch.cuda.current_stream(self.device)
