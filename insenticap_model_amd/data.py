@@ -43,17 +43,43 @@ def _feats(xs):
     return torch.from_numpy(np.ascontiguousarray(np.asarray(xs, dtype=np.float32)))
 
 
-def create_collate_fn(name, pad_index=0, max_seq_len=17, num_concepts=5, num_sentiments=10, caption_width=None):
+class RowGather:
+    """A batch tensor whose rows repeat: `base` [U, ...] holds each distinct row once, `index` [B] says which one a batch row
+    is.  The 'caption' collate makes one row per CAPTION, so an image's 6 x 6 x 2048 regions appear once per caption (4-5x):
+    with `dedup=True` it hands the features over in this form - a quarter of the bytes to stack, pin and copy to the device
+    - and DevicePrefetcher expands them there (index_select on its stream): the consumer sees the plain [B, ...] tensors.
+    `dense()` gives the expanded tensor where it stands (host or device)."""
+
+    def __init__(self, base, index):
+        self.base, self.index = base, index
+
+    @property
+    def shape(self):
+        return (self.index.shape[0],) + tuple(self.base.shape[1:])
+
+    def dense(self):
+        return self.base.index_select(0, self.index)
+
+
+def create_collate_fn(name, pad_index=0, max_seq_len=17, num_concepts=5, num_sentiments=10, caption_width=None,
+                      dedup=False):
     """The reference's collate functions (dataloader.py:11-58).  `caption_width` (not in the reference): None pads a batch's
     captions to its longest one, as the reference does - every distinct longest length is then another input geometry for
     the graph-served training steps (train_graph: a capture per geometry, four kept); 'full' pads every batch to
     max_seq_len, an int m rounds the unroll length (width - 1) up to a multiple of m.  Lengths are returned unchanged and the
-    criteria mask by row, so losses and gradients are those of the tight batch - the extra steps run on <PAD>."""
+    criteria mask by row, so losses and gradients are those of the tight batch - the extra steps run on <PAD>.
+    `dedup` ('caption' only; not in the reference): features as RowGather (each image once + a row index)."""
     def caption(dataset):
-        rows = [(fn, fc, att, cap, cpts) for fn, fc, att, caps_idx, cpts in dataset for cap in caps_idx]
+        rows = [(fn, fc, att, cap, cpts, u) for u, (fn, fc, att, caps_idx, cpts) in enumerate(dataset) for cap in caps_idx]
         rows.sort(key=lambda p: len(p[3]), reverse=True)          # stable, like the reference
-        fns, fcs, atts, caps, cpts = zip(*rows)
-        return fns, _feats(fcs), _feats(atts), _caps(caps, max_seq_len, pad_index, caption_width), \
+        fns, fcs, atts, caps, cpts, img = zip(*rows)
+        if dedup:           # an image's features once (RowGather); same rows after DevicePrefetcher / .dense()
+            index = torch.from_numpy(np.asarray(img, dtype=np.int64))
+            fc_t = RowGather(_feats([d[1] for d in dataset]), index)
+            att_t = RowGather(_feats([d[2] for d in dataset]), index)
+        else:
+            fc_t, att_t = _feats(fcs), _feats(atts)
+        return fns, fc_t, att_t, _caps(caps, max_seq_len, pad_index, caption_width), \
             _pad_rows(cpts, num_concepts, pad_index)
 
     def scs(dataset):
@@ -193,11 +219,11 @@ def _loader(dataset, batch_size, num_workers, shuffle, collate):
 
 
 def get_caption_dataloader(fc_feats, att_feats, img_captions, img_det_concepts, pad_index, max_seq_len,
-                           num_concepts, batch_size, num_workers=0, shuffle=True, caption_width=None):
-    """dataloader.py:267-278 (note max_seq_len + 1: the <SOS> column).  caption_width: create_collate_fn."""
+                           num_concepts, batch_size, num_workers=0, shuffle=True, caption_width=None, dedup=False):
+    """dataloader.py:267-278 (note max_seq_len + 1: the <SOS> column).  caption_width, dedup: create_collate_fn."""
     return _loader(CaptionDataset(fc_feats, att_feats, img_captions, img_det_concepts), batch_size, num_workers,
                    shuffle, create_collate_fn('caption', pad_index, max_seq_len + 1, num_concepts,
-                                              caption_width=caption_width))
+                                              caption_width=caption_width, dedup=dedup))
 
 
 def get_senti_corpus_with_sentis_dataloader(senti_corpus_with_sentis, pad_index, max_seq_len, num_concepts,
@@ -233,6 +259,9 @@ def get_rl_senti_dataloader(fc_feats, att_feats, img_det_concepts, img_det_senti
 def _map_tensors(obj, fn):
     if torch.is_tensor(obj):
         return fn(obj)
+    if isinstance(obj, RowGather):          # both parts through fn, expanded where they land
+        base, index = fn(obj.base), fn(obj.index)
+        return base.index_select(0, index) if base.is_cuda else RowGather(base, index)
     if isinstance(obj, tuple):
         return tuple(_map_tensors(o, fn) for o in obj)
     if isinstance(obj, list) and obj and torch.is_tensor(obj[0]):
@@ -247,14 +276,48 @@ class DevicePrefetcher:
     def __init__(self, loader, device):
         self.loader, self.device = loader, torch.device(device)
         self.stream = torch.cuda.Stream(device=self.device)
+        # pinned staging buffers, kept: two slots (the batch being consumed, the batch on its way) x the tensors of a
+        # batch, each a byte buffer that only grows.  `tensor.pin_memory()` per batch page-locks fresh memory every time
+        # here - 38 ms for the 38 MB of a 128-row batch of 6 x 6 x 2048 regions, against 4.7 ms to collate it and 4.6 ms
+        # to train on it (tools/loader_probe.py)
+        self._pins, self._slot = {}, 0
 
     def __len__(self):
         return len(self.loader)
 
+    def _pinned(self, key, t):
+        need = t.numel() * t.element_size()
+        ent = self._pins.get(key)
+        if ent is None or ent[0].numel() < need:
+            ent = self._pins[key] = [torch.empty(max(need + need // 2, 256), dtype=torch.uint8).pin_memory(),
+                                     torch.cuda.Event()]
+        else:
+            ent[1].synchronize()                 # the copy that last read this buffer has finished (two batches ago)
+        return ent[0][:need].view(t.dtype).view(t.shape), ent[1]
+
     def _stage(self, batch):
+        self._slot ^= 1
+        n = [0]
+
+        def put(t):
+            if t.is_cuda:
+                return t
+            if t.is_pinned():
+                return t.to(self.device, non_blocking=True)
+            buf, ev = self._pinned((self._slot, n[0]), t)
+            n[0] += 1
+            # a plain memcpy on THIS thread: torch's copy_ of a 38 MB tensor opens an OpenMP region on every core the HOST
+            # has (128) even when the process may use 16 of them, and the pool's threads then spin for a while - the next
+            # batch's collate (numpy, this thread) ran 5x slower next to them (tools/pf_probe.py: 25 -> 5.7 ms)
+            if t.is_contiguous() and t.dtype != torch.bool:
+                np.copyto(buf.numpy(), t.numpy())
+            else:
+                buf.copy_(t)
+            out = buf.to(self.device, non_blocking=True)
+            ev.record(self.stream)
+            return out
         with torch.cuda.stream(self.stream):
-            return _map_tensors(batch, lambda t: (t if t.is_pinned() else t.pin_memory()).to(self.device,
-                                                                                             non_blocking=True))
+            return _map_tensors(batch, put)
 
     def __iter__(self):
         it = iter(self.loader)

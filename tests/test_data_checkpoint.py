@@ -50,6 +50,20 @@ def test_caption_width_pads_beyond_the_longest_caption_and_leaves_the_lengths():
     assert capped[3][0].shape == (3, 4)                                     # never beyond max_seq_len
 
 
+def test_caption_collate_dedup_hands_each_image_over_once():
+    """dedup=True (not in the reference): the 'caption' collate makes one row per caption, so an image's features repeat;
+    as data.RowGather (distinct rows + a row index) they are a quarter of the bytes, and dense() is the reference layout."""
+    a = _img('a', [[1, 5, 6, 2], [1, 7, 8, 9, 10, 11, 2], [1, 3, 2]])
+    b = _img('b', [[1, 4, 2], [1, 4, 4, 4, 2]])
+    ds = [(a[0], a[1], a[2], a[3], a[4]), (b[0], b[1], b[2], b[3], b[4])]
+    plain = data.create_collate_fn('caption', pad_index=0, max_seq_len=9, num_concepts=4)(ds)
+    dd = data.create_collate_fn('caption', pad_index=0, max_seq_len=9, num_concepts=4, dedup=True)(ds)
+    assert isinstance(dd[1], data.RowGather) and dd[1].base.shape[0] == 2 and dd[2].base.shape[0] == 2
+    assert dd[1].shape == tuple(plain[1].shape) and dd[2].shape == tuple(plain[2].shape)
+    assert torch.equal(dd[1].dense(), plain[1]) and torch.equal(dd[2].dense(), plain[2])
+    assert dd[0] == plain[0] and torch.equal(dd[3][0], plain[3][0]) and dd[3][1] == plain[3][1] and torch.equal(dd[4], plain[4])
+
+
 def test_scs_and_rl_collates():
     f = data.create_collate_fn('scs', max_seq_len=6, num_concepts=2, num_sentiments=3)
     (caps, lengths), cpts, sentis, ids = f([([1, 9, 2], [5, 6, 7], [8], 1), ([1, 3, 4, 5, 2], [5], [8, 9, 9, 9], 0)])
@@ -167,6 +181,18 @@ def test_device_prefetcher_delivers_identical_batches():
         assert g[0] == ref[0] and g[3][1] == ref[3][1]                            # host objects pass through
         for a, b in ((ref[1], g[1]), (ref[2], g[2]), (ref[3][0], g[3][0]), (ref[4], g[4])):
             assert b.is_cuda and torch.equal(a, b.cpu())
+    # ... and with the features handed over once per image (dedup): the same device tensors, expanded on the device;
+    # batches of different sizes go through the same (growing) pinned staging buffers
+    fd = data.create_collate_fn('caption', max_seq_len=6, dedup=True)
+    sizes = (3, 5, 2, 5, 3)
+    plain, dd = [], []
+    for k, n in enumerate(sizes):
+        ds = [(x[0], x[1], x[2], x[3], x[4]) for x in (_img('j%d_%d' % (k, j), [[1, 4 + j, 2], [1, 5, 6, 2], [1, 2]]) for j in range(n))]
+        plain.append(f(ds))
+        dd.append(fd(ds))
+    for ref, g in zip(plain, data.DevicePrefetcher(dd, dev)):
+        assert g[1].is_cuda and torch.is_tensor(g[1]) and g[1].shape == ref[1].shape
+        assert torch.equal(ref[1], g[1].cpu()) and torch.equal(ref[2], g[2].cpu()) and torch.equal(ref[3][0], g[3][0].cpu())
 
 
 # ----------------------------------------------------------------------------- checkpoints
