@@ -40,6 +40,8 @@ def _caps(caps, max_seq_len, pad_index, caption_width=None):
 
 
 def _feats(xs):
+    if len(xs) and hasattr(xs[0], 'row') and hasattr(xs[0], 'tensor'):     # rows of a DeviceFeatureStore: gathered on the device
+        return RowGather(xs[0].tensor, torch.from_numpy(np.asarray([x.row for x in xs], dtype=np.int64)))
     return torch.from_numpy(np.ascontiguousarray(np.asarray(xs, dtype=np.float32)))
 
 
@@ -58,7 +60,17 @@ class RowGather:
         return (self.index.shape[0],) + tuple(self.base.shape[1:])
 
     def dense(self):
-        return self.base.index_select(0, self.index)
+        return self.base.index_select(0, self.index.to(self.base.device))
+
+    def to(self, device, non_blocking=False):
+        """The expanded tensor on `device` (what a consumer's `batch_tensor.to(device)` expects to get)."""
+        device = torch.device(device)
+        base = self.base if self.base.device == device else self.base.to(device, non_blocking=non_blocking)
+        return base.index_select(0, self.index.to(device, non_blocking=non_blocking))
+
+    @property
+    def is_cuda(self):
+        return self.base.is_cuda
 
 
 def create_collate_fn(name, pad_index=0, max_seq_len=17, num_concepts=5, num_sentiments=10, caption_width=None,
@@ -75,8 +87,11 @@ def create_collate_fn(name, pad_index=0, max_seq_len=17, num_concepts=5, num_sen
         fns, fcs, atts, caps, cpts, img = zip(*rows)
         if dedup:           # an image's features once (RowGather); same rows after DevicePrefetcher / .dense()
             index = torch.from_numpy(np.asarray(img, dtype=np.int64))
-            fc_t = RowGather(_feats([d[1] for d in dataset]), index)
-            att_t = RowGather(_feats([d[2] for d in dataset]), index)
+            fc_u, att_u = _feats([d[1] for d in dataset]), _feats([d[2] for d in dataset])
+            if isinstance(fc_u, RowGather):      # device-resident store: rows of rows - one gather
+                fc_t, att_t = RowGather(fc_u.base, fc_u.index[index]), RowGather(att_u.base, att_u.index[index])
+            else:
+                fc_t, att_t = RowGather(fc_u, index), RowGather(att_u, index)
         else:
             fc_t, att_t = _feats(fcs), _feats(atts)
         return fns, fc_t, att_t, _caps(caps, max_seq_len, pad_index, caption_width), \
@@ -145,8 +160,69 @@ class FeatureStore:
         return len(self.index)
 
 
+class _Row:
+    """What a DeviceFeatureStore hands a dataset item instead of the feature array: which row of which device tensor."""
+    __slots__ = ('tensor', 'row')
+
+    def __init__(self, tensor, row):
+        self.tensor, self.row = tensor, row
+
+
+class DeviceFeatureStore:
+    """All features of a dataset RESIDENT ON THE DEVICE: fn -> row of one [N, ...] fp32 tensor in HBM.  The reference reads
+    an image's features from an h5 file per item (dataloader.py:164-178) and a 512-image RL batch of 6 x 6 x 2048 regions is
+    151 MB to read, stack, pin and copy - 55-76 ms on the host per iteration, against 22.5 ms for the iteration itself
+    (tools/rl_loop_probe.py).  An MI355X has 288 GB: the 113 k training images of COCO are 34 GB at 6 x 6 regions (160 GB
+    at the encoder's own 14 x 14), so the whole set is uploaded once and a batch is an index_select on the device (151 MB
+    in ~50 us).  Datasets take it where they take a FeatureStore / dict; their items then carry row handles, the collates
+    turn them into a RowGather over the store's tensor, and DevicePrefetcher (or RowGather.to(device) / .dense()) gives the
+    consumer the plain [B, ...] tensor.  Loader workers: num_workers = 0 (a batch is a few KB of indices and captions).
+
+        fc_store  = data.DeviceFeatureStore.from_arrays(fns, fc_array,  device)      # or .from_store(FeatureStore / dict)
+        att_store = data.DeviceFeatureStore.from_arrays(fns, att_array, device)
+        loader = data.get_rl_fact_dataloader(fc_store, att_store, ...)"""
+
+    def __init__(self, index, tensor):
+        self.index, self.tensor = index, tensor
+
+    @classmethod
+    def from_arrays(cls, fns, array, device, chunk_rows=4096):
+        assert len(fns) == len(array) and len(set(fns)) == len(fns)
+        device = torch.device(device)
+        first = np.asarray(array[0], dtype=np.float32)
+        out = torch.empty((len(fns),) + first.shape, dtype=torch.float32, device=device)
+        pin = torch.empty((min(chunk_rows, len(fns)),) + first.shape, dtype=torch.float32).pin_memory()
+        for lo in range(0, len(fns), chunk_rows):                 # through one kept pinned chunk: no 34 GB host copy
+            hi = min(lo + chunk_rows, len(fns))
+            np.stack([np.asarray(array[i], dtype=np.float32) for i in range(lo, hi)], out=pin.numpy()[:hi - lo])
+            out[lo:hi].copy_(pin[:hi - lo], non_blocking=True)
+            torch.cuda.current_stream(device).synchronize()       # (the chunk buffer is reused)
+        return cls({fn: i for i, fn in enumerate(fns)}, out)
+
+    @classmethod
+    def from_store(cls, store, device, fns=None):
+        store = _store(store)
+        fns = list(fns if fns is not None else (store.index if isinstance(store, FeatureStore) else store.keys()))
+        return cls.from_arrays(fns, [store[fn] for fn in fns], device)
+
+    def __getitem__(self, fn):
+        return _Row(self.tensor, self.index[fn])
+
+    def __contains__(self, fn):
+        return fn in self.index
+
+    def __len__(self):
+        return len(self.index)
+
+
 def _store(x):
     return FeatureStore(x) if isinstance(x, str) else x
+
+
+def _item(x):
+    """A dataset item's feature: a copy of the array (the reference reads it out of its h5 file), or the row handle of a
+    device-resident store."""
+    return x if isinstance(x, _Row) else np.array(x)
 
 
 class SCSDataset(torch.utils.data.Dataset):
@@ -173,7 +249,7 @@ class CaptionDataset(torch.utils.data.Dataset):
 
     def __getitem__(self, index):
         fn, caps = self.captions[index]
-        return fn, np.array(self.fc_feats[fn]), np.array(self.att_feats[fn]), caps, self.det_concepts[fn]
+        return fn, _item(self.fc_feats[fn]), _item(self.att_feats[fn]), caps, self.det_concepts[fn]
 
     def __len__(self):
         return len(self.captions)
@@ -189,7 +265,7 @@ class RLFactDataset(torch.utils.data.Dataset):
 
     def __getitem__(self, index):
         fn, caps = self.captions[index]
-        return fn, caps, np.array(self.fc_feats[fn]), np.array(self.att_feats[fn]), self.det_concepts[fn], \
+        return fn, caps, _item(self.fc_feats[fn]), _item(self.att_feats[fn]), self.det_concepts[fn], \
             self.det_sentiments[fn]
 
     def __len__(self):
@@ -206,7 +282,7 @@ class RLSentiDataset(torch.utils.data.Dataset):
 
     def __getitem__(self, index):
         fn, senti_label = self.img_senti_labels[index]
-        return fn, np.array(self.fc_feats[fn]), np.array(self.att_feats[fn]), self.det_concepts[fn], \
+        return fn, _item(self.fc_feats[fn]), _item(self.att_feats[fn]), self.det_concepts[fn], \
             self.det_sentiments[fn], senti_label
 
     def __len__(self):

@@ -195,6 +195,39 @@ def test_device_prefetcher_delivers_identical_batches():
         assert torch.equal(ref[1], g[1].cpu()) and torch.equal(ref[2], g[2].cpu()) and torch.equal(ref[3][0], g[3][0].cpu())
 
 
+@pytest.mark.gpu
+def test_device_resident_feature_store_yields_the_same_batches():
+    """data.DeviceFeatureStore: the features live on the device, a batch is gathered there by row index.  Same batches as
+    the dict-backed loaders (caption collate plain and dedup, rl_fact), through DevicePrefetcher and through
+    RowGather.to(device) (what Detector.forward's `.to(device)` gets)."""
+    dev = torch.device('cuda:0')
+    imgs = [_img('k%d' % j, [[1, 4 + j, 2], [1, 5, 6, 2], [1, 2]]) for j in range(7)]
+    fns = [x[0] for x in imgs]
+    fc, att = {x[0]: x[1] for x in imgs}, {x[0]: x[2] for x in imgs}
+    caps, cpts = {x[0]: x[3] for x in imgs}, {x[0]: x[4] for x in imgs}
+    sentis = {fn: [3, 4] for fn in fns}
+    dfc = data.DeviceFeatureStore.from_arrays(fns, [fc[f] for f in fns], dev, chunk_rows=3)
+    datt = data.DeviceFeatureStore.from_store(att, dev)
+    assert len(dfc) == 7 and 'k3' in dfc and torch.equal(datt.tensor[datt.index['k2']].cpu(), torch.from_numpy(att['k2']))
+    for dedup in (False, True):
+        ref = list(data.get_caption_dataloader(fc, att, caps, cpts, 0, 6, 4, 3, shuffle=False))
+        got = list(data.DevicePrefetcher(data.get_caption_dataloader(dfc, datt, caps, cpts, 0, 6, 4, 3, shuffle=False,
+                                                                     dedup=dedup), dev))
+        assert len(ref) == len(got) == 3
+        for r, g in zip(ref, got):
+            assert r[0] == g[0] and torch.is_tensor(g[1]) and g[1].is_cuda
+            assert torch.equal(r[1], g[1].cpu()) and torch.equal(r[2], g[2].cpu()) and torch.equal(r[3][0], g[3][0].cpu())
+    import random
+    random.seed(3)
+    ref = list(data.get_rl_fact_dataloader(fc, att, caps, cpts, sentis, 0, 6, 4, 4, 4, shuffle=False))
+    random.seed(3)
+    got = list(data.get_rl_fact_dataloader(dfc, datt, caps, cpts, sentis, 0, 6, 4, 4, 4, shuffle=False))
+    for r, g in zip(ref, got):
+        assert isinstance(g[1], data.RowGather) and g[1].shape == tuple(r[1].shape)
+        assert torch.equal(r[1], g[1].to(dev).cpu()) and torch.equal(r[2], g[2].dense().cpu())
+        assert torch.equal(r[3][0], g[3][0]) and r[0] == g[0]
+
+
 # ----------------------------------------------------------------------------- checkpoints
 def _cap(V=64):
     c = Captioner(synth.make_idx2word(V), synth.SENTIMENT_CATEGORIES, synth.TINY_SETTINGS)

@@ -37,11 +37,12 @@ def epoch(mode):
     cap.to(dev).train()
     optim, xc, dc = cap.get_optim_criterion(4e-4)
     width = 'full' if mode == 'graph, fixed width' else None
-    cl = data.get_caption_dataloader(fc, att, caps, cpts, 0, T, 5, 32, num_workers=0, shuffle=True, caption_width=width,
-                                     dedup='dedup' in mode)
+    res = 'resident' in mode
+    cl = data.get_caption_dataloader(DFC if res else fc, DATT if res else att, caps, cpts, 0, T, 5, 32, num_workers=0, shuffle=True,
+                                     caption_width=width, dedup='dedup' in mode)
     sl = data.get_senti_corpus_with_sentis_dataloader(scs_rows, 0, T, 5, 10, 80, num_workers=0, shuffle=True,
                                                       caption_width=width)
-    g = XETrainGraph(cap, optim, xc, dc, grad_clip=0.1, warmup=2) if mode != 'eager' else None
+    g = XETrainGraph(cap, optim, xc, dc, grad_clip=0.1, warmup=2) if not mode.startswith('eager') else None
     import warnings
     n, widths = 0, set()
     with warnings.catch_warnings():
@@ -60,10 +61,12 @@ def epoch(mode):
                 n += 1
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
-    print('%-20s %3d iterations, %6.2f ms each (loader + H2D + step), %2d caption-width pairs%s, last loss %.3f' % (
+    print('%-42s %3d iterations, %6.2f ms each (loader + H2D + step), %2d caption-width pairs%s, last loss %.3f' % (
         mode, n, el / n * 1e3, len(widths), '' if g is None else ', %d captures, %d replays, %d eager' % (
             g.captures, g.replays, g.eager_steps), float(out['all_loss'])), flush=True)
 
 
-for m in ('eager', 'graph, tight', 'graph, fixed width', 'graph, tight, dedup'):
+DFC = data.DeviceFeatureStore.from_arrays(fns, [fc[f] for f in fns], dev)
+DATT = data.DeviceFeatureStore.from_arrays(fns, [att[f] for f in fns], dev)
+for m in ('eager', 'graph, tight', 'graph, tight, dedup', 'graph, features resident on the device', 'eager, features resident on the device'):
     epoch(m)
