@@ -404,6 +404,81 @@ def bench_scan_sweep(dev, batches=(128, 512, 1024, 2048, 4096), R=R):
     return out
 
 
+def bench_epoch_loops(dev, n_img_xe=512, n_img_rl=1024):
+    """A training EPOCH the way the reference's trainers run it (train_xe.py:132-192, train_rl.py:232-242): the package's
+    loaders over synthetic images (captions of different lengths, 6 x 6 x 2048 regions) feeding one iteration per batch -
+    loader, hand-over to the device and the iteration together.  `resident`: the features in HBM (data.DeviceFeatureStore:
+    a batch is an index_select on the device); `host`: dict-backed stores + DevicePrefetcher (XE: dedup collate)."""
+    from insenticap_model_amd import Captioner, Detector, data
+    from insenticap_model_amd.train_graph import XETrainGraph
+    import warnings
+    import numpy as np
+    rng = np.random.default_rng(7)
+    st = dict(synth.DEFAULT_SETTINGS, **synth.HELPER_SETTINGS)
+    n_img = max(n_img_xe, n_img_rl)
+    fns = ['img%05d' % i for i in range(n_img)]
+    fc = {fn: rng.standard_normal(2048, dtype=np.float32) * 0.5 for fn in fns}
+    att = {fn: rng.standard_normal((6, 6, 2048), dtype=np.float32) * 0.5 for fn in fns}
+
+    def caption():
+        return [1] + rng.integers(4, V, size=int(rng.integers(6, T))).tolist() + [2]
+    caps = {fn: [caption() for _ in range(4)] for fn in fns}
+    cpts = {fn: rng.integers(4, V, size=5).tolist() for fn in fns}
+    sentis = {fn: rng.integers(4, V, size=10).tolist() for fn in fns}
+    scs_rows = [(caption(), rng.integers(4, V, size=5).tolist(), rng.integers(4, V, size=10).tolist(), int(rng.integers(0, 3)))
+                for _ in range(80 * 16)]
+    dfc = data.DeviceFeatureStore.from_arrays(fns, [fc[f] for f in fns], dev)
+    datt = data.DeviceFeatureStore.from_arrays(fns, [att[f] for f in fns], dev)
+    out = {}
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        # ---- XE: 32 images x 4 captions = 128 rows + 80 seq2seq rows per iteration, graph-served step
+        xe_caps = {fn: caps[fn] for fn in fns[:n_img_xe]}
+        for tag, a, b, kw in (('resident', dfc, datt, {}), ('host', fc, att, dict(dedup=True))):
+            cap = Captioner(synth.make_idx2word(V), synth.SENTIMENT_CATEGORIES, synth.DEFAULT_SETTINGS)
+            cap.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_weights(V, synth.DEFAULT_SETTINGS).items()})
+            cap.to(dev).train()
+            optim, xc, dc = cap.get_optim_criterion(4e-4)
+            cl = data.get_caption_dataloader(a, b, xe_caps, cpts, 0, T, 5, 32, shuffle=True, caption_width='full', **kw)
+            sl = data.get_senti_corpus_with_sentis_dataloader(scs_rows, 0, T, 5, 10, 80, shuffle=True, caption_width='full')
+            g = XETrainGraph(cap, optim, xc, dc, grad_clip=0.1, warmup=2)
+            n = 0
+            for ep in range(2):                      # the first epoch warms up and captures, the second is timed
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                src = (cl, sl) if tag == 'resident' else (data.DevicePrefetcher(cl, dev), data.DevicePrefetcher(sl, dev))
+                for fact, scs in zip(*src):
+                    labels = torch.zeros(fact[1].shape[0], dtype=torch.int64, device=dev)
+                    # (resident: the features come as RowGather over the store; captions, concepts and the seq2seq batch
+                    # are a few KB of host tensors that the graph object stages itself)
+                    fact = tuple(x.to(dev) if isinstance(x, data.RowGather) else x for x in fact)
+                    g.step(fact, labels, scs, 0.0)
+                    n += 1
+                torch.cuda.synchronize()
+                el = time.perf_counter() - t0
+            out['xe128_' + tag + '_ms_per_iter'] = round(el / len(cl) * 1e3, 2)
+            del g, cap
+        # ---- RL: 512 images per iteration through Detector.forward (graph-served), image sentiments cached after epoch 1
+        rl_caps = {fn: caps[fn] for fn in fns[:n_img_rl]}
+        det = Detector(synth.make_idx2word(V), T, synth.SENTIMENT_CATEGORIES, {'cap_lr': 4e-5}, st)
+        det.captioner.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_weights(V, st, seed=0).items()})
+        det.to(dev)
+        det.set_ciderd_scorer({'train': rl_caps})
+        for tag, a, b in (('resident', dfc, datt), ('host', fc, att)):
+            fl = data.get_rl_fact_dataloader(a, b, rl_caps, cpts, sentis, 0, T, 5, 10, 512, shuffle=True, caption_width='full')
+            sl = data.get_senti_corpus_with_sentis_dataloader(scs_rows, 0, T, 5, 10, 80, shuffle=True, caption_width='full')
+            for ep in range(4):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                det((fl, sl), 'fact', True)
+                torch.cuda.synchronize()
+                el = time.perf_counter() - t0
+            out['rl512_' + tag + '_ms_per_iter'] = round(el / len(fl) * 1e3, 1)
+    out['note'] = ('loader + hand-over + iteration per batch; resident = data.DeviceFeatureStore (features in HBM), host = dict '
+                   'stores (+ DevicePrefetcher, dedup collate for XE); %d / %d images' % (n_img_xe, n_img_rl))
+    return out
+
+
 def bench_r196(cap, dev):
     """The reference encoder's own feature geometry: 14 x 14 = 196 regions per image (models/encoder.py:53; BASELINE.json
     quotes the 36-region bottom-up features).  Greedy decode at B = 4096, the attention scan alone (algorithmic bytes
@@ -845,6 +920,7 @@ def run(args):
             jobs.append(('xe_train_by_batch', lambda: {str(b): bench_xe_train(cap, dev, rank, world, iters=3, B=b)[
                 'ms_per_iter'] for b in (512,)}))
             jobs.append(('r196', lambda: bench_r196(cap, dev)))
+            jobs.append(('epoch_loops', lambda: bench_epoch_loops(dev)))
         if dist_on():
             jobs.append(('grad_allreduce', lambda: bench_grad_allreduce(cap, dev, world)))
             if 512 % world == 0 and 80 % world == 0:
@@ -927,6 +1003,8 @@ def run(args):
         'r196_greedy_captions_per_s': g('r196', 'greedy_B4096', 'captions_per_s'),
         'r196_scan_frac_of_hbm': g('r196', 'scan', '4096', 'frac_of_8tbs'),
         'r196_xe128_ms': g('r196', 'xe_train_B128', 'ms_per_iter'), 'r196_beam5_p50_ms': g('r196', 'beam5', 'per_image_p50_ms'),
+        'xe128_epoch_ms_per_iter': g('epoch_loops', 'xe128_resident_ms_per_iter'),
+        'rl512_epoch_ms_per_iter': g('epoch_loops', 'rl512_resident_ms_per_iter'),
     }
     if world > 1 or under_launcher:
         torch.distributed.destroy_process_group()
