@@ -142,7 +142,7 @@ class Detector(nn.Module):
                 """One iteration (models/decoder.py:69-167).  `exact`: on the exact-fp32 GEMM engine, eagerly - the retry of
                 an iteration whose roll-outs left the split-f16 operand domain (OutOfDomain is raised at the iteration's
                 own synchronisation point, before anything is updated)."""
-                if (training and data_type == 'fact' and self.train_graphs and device.type == 'cuda'
+                if (training and self.train_graphs and device.type == 'cuda'
                         and ops.TIMER.arm_step is None and ops.graphs_allowed_here() and not exact):
                     # the same iteration from HIP graphs (train_graph.RLTrainGraph): same calls in the same order
                     from .train_graph import RLTrainGraph
@@ -154,18 +154,22 @@ class Detector(nn.Module):
                         # group: a replaced optimizer - a new learning-rate schedule object, say - must not leave replays
                         # updating through the old one)
                         self._rl_graph = RLTrainGraph(self)
-                    def xe_senti_labels():
-                        with torch.no_grad():
-                            logits = self.sent_senti_cls(caps_tensor[:, 1:], lengths)[0]
-                            return logits.softmax(dim=-1).argmax(dim=-1).detach()
-                    if self.sent_senti_cls.training:         # (dropout draws: keep the reference's order of random numbers)
-                        xe_senti_labels = xe_senti_labels()
-                    # else: a callable - the graph object runs it behind its first roll-out, whose input it is not
                     (s_caps, s_lengths), s_cpts, s_sentis, s_labels = s2s_batch
-                    stats = self._rl_graph.step(
-                        (fns, fc_feats, att_feats, (caps_tensor, lengths), cpts_tensor, sentis_tensor, ground_truth),
-                        ((s_caps.to(device), s_lengths), s_cpts.to(device), s_sentis.to(device), s_labels.to(device)),
-                        senti_labels, xe_senti_labels)
+                    scs_dev = ((s_caps.to(device), s_lengths), s_cpts.to(device), s_sentis.to(device), s_labels.to(device))
+                    if data_type == 'fact':
+                        def xe_senti_labels():
+                            with torch.no_grad():
+                                logits = self.sent_senti_cls(caps_tensor[:, 1:], lengths)[0]
+                                return logits.softmax(dim=-1).argmax(dim=-1).detach()
+                        if self.sent_senti_cls.training:     # (dropout draws: keep the reference's order of random numbers)
+                            xe_senti_labels = xe_senti_labels()
+                        # else: a callable - the graph object runs it behind its first roll-out, whose input it is not
+                        stats = self._rl_graph.step(
+                            (fns, fc_feats, att_feats, (caps_tensor, lengths), cpts_tensor, sentis_tensor, ground_truth),
+                            scs_dev, senti_labels, xe_senti_labels)
+                    else:                                    # 'senti': labelled images, no captions (decoder.py:75-78)
+                        stats = self._rl_graph.step((fns, fc_feats, att_feats, cpts_tensor, sentis_tensor, senti_labels),
+                                                    scs_dev, senti_labels)
                     for k, v in stats.items():
                         put(k, v)
                     return

@@ -196,7 +196,7 @@ class XETrainGraph:
 
     def _phase_args(self, geo):
         i = geo.inputs
-        fact = (i['fc'], i['att'], i['caps'], i['len'], i['cpts'])
+        fact = (i['fc'], i['att'], i['caps'], i['len'], i['cpts']) if 'caps' in i else None     # (RL 'senti' iterations: no captions)
         scs = (i['s_caps'], i['s_len'], i['s_cpts'], i['s_sentis'], i['s_labels']) if 's_caps' in i else None
         return fact, i['labels'], scs
 
@@ -425,7 +425,9 @@ class _RLGeometry(_Geometry):
 
 
 class RLTrainGraph(XETrainGraph):
-    """The self-critical RL training iteration of `Detector.forward(data, 'fact', True)` (models/decoder.py:65-167)
+    """The self-critical RL training iteration of `Detector.forward(data, 'fact', True)` (models/decoder.py:65-167) - and
+    of `Detector.forward(data, 'senti', True)`, the other half of the reference's RL epochs (train_rl.py:232-235: images
+    with sentiment labels, no captions: the same phases without the XE unroll and without the CIDEr-D reward) -
     served from HIP graphs - four of them per input geometry, with the two things that cannot live in a graph between:
 
         g_roll   sampled roll-out (activations kept for REINFORCE), domain-align loss, the device->host copy of its token
@@ -506,6 +508,14 @@ class RLTrainGraph(XETrainGraph):
         too, inside g_bwd); the seq2seq unroll - forward and backward - as a branch on self.side."""
         from .train import _xe_loss
         det, cap, i = self.det, self.cap, geo.inputs
+        if 'caps' not in i:       # a 'senti' iteration (decoder.py:52-167 with data_type 'senti'): no ground-truth captions,
+            origin = torch.cuda.current_stream(self.device)          # no XE unroll - the seq2seq branch alone
+            self.side.wait_stream(origin)
+            cap.cpt_feats = cap.fc_feats = cap.s2s_cpt_feats = None
+            with torch.cuda.stream(self.side):
+                s2s = self._phase_s2s(geo, det.seq2seq_ss_prob)
+            origin.wait_stream(self.side)
+            return None, s2s
         if self._pair():          # both unrolls through one step chain: forward only here, ONE backward in _phase_bwd
             cap.cpt_feats = cap.fc_feats = cap.s2s_cpt_feats = None
             with cap.token_logprobs():
@@ -542,6 +552,8 @@ class RLTrainGraph(XETrainGraph):
         xe, (s2s_loss, s2s_grads) = fwd
         dist = self._dist()
         cap_loss = det.cap_rl_crit(lp, mk, geo.reward)
+        if xe is None:                                       # 'senti' iteration: no XE term
+            xe = torch.zeros((), dtype=torch.float32, device=self.device)
         if dist:
             cap_loss, xe, da = cap_loss * self.share_rl[0], xe * self.shares[0], da * self.shares[2]
         s2s_loss = det.seq_flag * s2s_loss
@@ -593,9 +605,12 @@ class RLTrainGraph(XETrainGraph):
         greedy ones when they land (`copied`)."""
         from .rewards import self_critical_scores
         det = self.det
-        fns, ground_truth = item[0], item[6]
+        fact = 'caps' in geo.inputs                           # ('senti' iterations: classifier reward only, decoder.py:120-124)
+        if fact:
+            fns, ground_truth = item[0], item[6]
+            geo.copied_s.synchronize()
+            sampled = self_critical_scores(geo.host[0].numpy(), fns, ground_truth, det.ciderd_scorer)
         geo.copied_s.synchronize()
-        sampled = self_critical_scores(geo.host[0].numpy(), fns, ground_truth, det.ciderd_scorer)
         geo.copied.synchronize()
         if getattr(self.cap, 'numerics_checks', True) and ops.device_status(reset=True):
             # the roll-outs met non-finite values (features beyond the split-f16 domain): nothing has been updated yet -
@@ -603,6 +618,10 @@ class RLTrainGraph(XETrainGraph):
             self.stream.wait_stream(self.side)
             self.stream.wait_event(geo.fwd_done)
             raise ops.OutOfDomain()
+        if not fact:
+            self.stream.wait_stream(self.side)
+            geo.reward.copy_(0 + det.cls_flag * geo.cls)     # (`fact_reward = 0` there: the same expression as the eager path's)
+            return
         greedy = self_critical_scores(geo.host[1].numpy(), fns, ground_truth, det.ciderd_scorer)
         fact0 = ops.upload((sampled - greedy).astype('float32'), torch.float32, self.device)     # (utils.py:56-83: one per row)
         geo.fact0.copy_(fact0)
@@ -631,7 +650,7 @@ class RLTrainGraph(XETrainGraph):
         all-reduce per iteration, as Detector.forward does."""
         if not self._dist():
             return
-        n_local, n_global = dp.global_counts([roll[2].sum(), float(sum(lengths)), float(sum(s_lengths)),
+        n_local, n_global = dp.global_counts([roll[2].sum(), float(sum(lengths or ())), float(sum(s_lengths)),
                                               float(geo.inputs['fc'].shape[0])], self.device, self.group)
         w = n_local / n_global.clamp_min(1.0)
         self.share_rl.copy_(w[0:1])
@@ -751,24 +770,33 @@ class RLTrainGraph(XETrainGraph):
         self.replays += 1
         return stats
 
-    def step(self, item, scs_batch, senti_labels, xe_senti_labels):
+    def step(self, item, scs_batch, senti_labels, xe_senti_labels=None):
         """One iteration on a fact item of the rl_fact collate (fns, fc, att, (caps, lengths), cpts, sentis,
-        ground_truth), a seq2seq batch, the image sentiment labels and the XE labels of the captions (both from the
+        ground_truth) - or a senti item of the rl_senti collate (fns, fc, att, cpts, sentis, labels: no captions, hence no
+        XE unroll and no CIDEr-D reward; the statistics then lack 'fact_reward' and 'xe_loss') -, a seq2seq batch, the image sentiment labels and the XE labels of the captions (both from the
         frozen helper nets, computed by the caller; `xe_senti_labels` may be a callable returning them - it is then run behind
         the sampled roll-out, which does not read them, so that its host work overlaps the device's).  Returns {key: 0-dim device tensor} over RLTrainGraph.KEYS (under DP:
         this rank's pre-scaled shares - their sum over the ranks is the global value, as in Detector.forward), valid on
         the caller's current stream."""
-        fns, fc, att, (caps, lengths), cpts, sentis, ground_truth = item
-        lengths = self._as_list(lengths)
         (s_caps, s_lengths), s_cpts, s_sentis, s_labels = scs_batch
         s_lengths = self._as_list(s_lengths)
-        if caps.size(1) - 1 < max(lengths) or s_caps.size(1) - 1 < max(s_lengths):
-            raise ValueError('caption tensors are narrower than their longest caption (+1 for <SOS>)')
-        t = dict(fc=fc, att=att, caps=caps, cpts=cpts, sentis=sentis, labels=senti_labels, xe_labels=xe_senti_labels,
-                 len=torch.tensor(lengths, dtype=torch.int32), s_caps=s_caps, s_cpts=s_cpts, s_sentis=s_sentis,
-                 s_labels=s_labels, s_len=torch.tensor(s_lengths, dtype=torch.int32))
+        if len(item) == 6:        # a 'senti' item of the rl_senti collate: (fns, fc, att, cpts, sentis, labels) - no captions
+            fns, fc, att, cpts, sentis, _ = item
+            lengths = None
+            if s_caps.size(1) - 1 < max(s_lengths):
+                raise ValueError('caption tensors are narrower than their longest caption (+1 for <SOS>)')
+            t = dict(fc=fc, att=att, cpts=cpts, sentis=sentis, labels=senti_labels, s_caps=s_caps, s_cpts=s_cpts,
+                     s_sentis=s_sentis, s_labels=s_labels, s_len=torch.tensor(s_lengths, dtype=torch.int32))
+        else:
+            fns, fc, att, (caps, lengths), cpts, sentis, ground_truth = item
+            lengths = self._as_list(lengths)
+            if caps.size(1) - 1 < max(lengths) or s_caps.size(1) - 1 < max(s_lengths):
+                raise ValueError('caption tensors are narrower than their longest caption (+1 for <SOS>)')
+            t = dict(fc=fc, att=att, caps=caps, cpts=cpts, sentis=sentis, labels=senti_labels, xe_labels=xe_senti_labels,
+                     len=torch.tensor(lengths, dtype=torch.int32), s_caps=s_caps, s_cpts=s_cpts, s_sentis=s_sentis,
+                     s_labels=s_labels, s_len=torch.tensor(s_lengths, dtype=torch.int32))
         late = {}
-        if callable(xe_senti_labels):       # [B] int64, read by g_fwd only: produced behind the first roll-out (_late_inputs)
+        if lengths is not None and callable(xe_senti_labels):       # [B] int64, read by g_fwd only: produced behind the first roll-out (_late_inputs)
             late['xe_labels'] = xe_senti_labels
             t['xe_labels'] = torch.empty(fc.shape[0], dtype=torch.int64, device='meta')
         self._claim()
@@ -801,6 +829,8 @@ class RLTrainGraph(XETrainGraph):
                     stats = self._run_eager(geo, item, lengths, s_lengths)
                     geo.eager_runs += 1
                 out = dict(zip(self.KEYS, stats.clone().unbind(0)))
+                if lengths is None:                  # ('senti': no fact_reward, no xe_loss - decoder.py:120-158)
+                    out = {k: v for k, v in out.items() if k not in ('fact_reward', 'xe_loss')}
         except ops.OutOfDomain:
             caller.wait_stream(self.stream)          # the caller redoes the iteration on ITS stream: behind what was queued
             self.cap.cpt_feats = self.cap.fc_feats = self.cap.s2s_cpt_feats = None

@@ -211,3 +211,38 @@ def test_an_xe_training_graph_and_the_rl_graph_take_turns_on_one_captioner():
     outs = run(det, items * 3, scs, split, draws * 3)              # ... and back: two eager phases' worth, a new capture
     assert det._rl_graph.captures == 2 and not g._geoms
     assert all(np.isfinite(v) for o in outs for v in o.values())
+
+
+def test_senti_iterations_from_graphs_equal_the_eager_phases_and_track_plain_eager():
+    """The other half of the reference's RL epochs (train_rl.py:232-235, decoder.py with data_type 'senti'): images with
+    sentiment labels and no captions - no XE unroll, no CIDEr-D reward.  Served from the same graphs (sampled roll-out,
+    greedy baseline, seq2seq branch, backward): replays == the phases run eagerly, bit for bit; against the plain eager
+    Detector.forward within rounding; the dictionary has the reference's five keys."""
+    items, scs, split, draws = data(1)
+    fns, fc, att, _, cpts, sentis, _ = items[0]
+    labels = torch.from_numpy(np.random.default_rng(5).integers(0, len(synth.SENTIMENT_CATEGORIES), size=fc.shape[0]))
+    senti_items = [(fns, fc, att, cpts, sentis, labels)] * 6
+
+    def run_senti(det):
+        det.set_ciderd_scorer(split)
+        det.xe_ss_prob = det.seq2seq_ss_prob = 0.0
+        out = []
+        for it in senti_items:
+            force_draws(det, draws)
+            if det.train_graphs and det._rl_graph is None:
+                from insenticap_model_amd.train_graph import RLTrainGraph
+                det._rl_graph = RLTrainGraph(det, warmup=det._graph_warmup)
+            out.append(det(([it], scs), 'senti', True))
+        torch.cuda.synchronize()
+        return out
+    g, e, p = make(graphs=True, warmup=2), make(graphs=True, warmup=10 ** 6), make(graphs=False)
+    og, oe, op_ = run_senti(g), run_senti(e), run_senti(p)
+    assert g._rl_graph.captures == 1 and g._rl_graph.replays == 4 and e._rl_graph.captures == 0
+    same_params(g, e)
+    for a, b, c in zip(og, oe, op_):
+        assert set(a) == set(b) == set(c) == {'da_loss', 'cls_reward', 'all_rewards', 'cap_loss', 'seq2seq_loss'}
+        for k in a:
+            assert a[k] == b[k], k
+            np.testing.assert_allclose(a[k], c[k], rtol=2e-4, atol=2e-6, err_msg=k)
+    for (k, x), (_, y) in zip(g.captioner.named_parameters(), p.captioner.named_parameters()):
+        assert float((x - y).abs().max()) <= 6 * 2 * 4e-4 * 1.01, k
