@@ -32,3 +32,12 @@ for kind, data in (('senti', senti), ('fact', fact)):
         out = det((data, scs), kind, True)
     torch.cuda.synchronize()
     print("Detector.forward(data, '%s', True), B=%d: %.1f ms per iteration  %s" % (kind, B, (time.perf_counter() - t0) / 20 * 1e3, {k: round(v, 4) for k, v in out.items()}), flush=True)
+with torch.no_grad():
+    for kind, data in (('fact', fact), ('senti', senti)):
+        for i in range(3):
+            out = det((data,), kind, False)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for i in range(10):
+            out = det((data,), kind, False)
+        torch.cuda.synchronize()
+        print("Detector.forward(data, '%s', False) [validation], B=%d: %.1f ms per iteration  %s" % (kind, B, (time.perf_counter() - t0) / 10 * 1e3, {k: round(v, 4) for k, v in out.items()}), flush=True)

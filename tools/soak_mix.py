@@ -36,6 +36,9 @@ for r in range(rounds):
     for i in range(4):
         out = det((facts[i % 2], scs), 'fact', True)
         assert all(v == v for v in out.values()), out
+    out = det(([(facts[r % 2][0][0], facts[r % 2][0][1], facts[r % 2][0][2], facts[r % 2][0][4], facts[r % 2][0][5],
+                 torch.zeros(B, dtype=torch.int64, device=dev))], scs), 'senti', True)      # a 'senti' iteration: same graph object
+    assert all(v == v for v in out.values()), out
     if r % 3 == 0:
         l = xe_train_step(cap, det.cap_optim, det.cap_xe_crit, det.cap_da_crit, fact, labels, scs[0], 0.25, 0.1)
         assert float(l['all_loss']) == float(l['all_loss'])
