@@ -429,6 +429,7 @@ def bench_epoch_loops(dev, n_img_xe=512, n_img_rl=1024):
                 for _ in range(80 * 16)]
     dfc = data.DeviceFeatureStore.from_arrays(fns, [fc[f] for f in fns], dev)
     datt = data.DeviceFeatureStore.from_arrays(fns, [att[f] for f in fns], dev)
+    data.freeze_host_objects()          # (the caption tables: millions of small objects the cyclic collector would re-walk)
     out = {}
     with warnings.catch_warnings():
         warnings.simplefilter('ignore')
