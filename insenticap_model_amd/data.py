@@ -59,14 +59,26 @@ class RowGather:
     def shape(self):
         return (self.index.shape[0],) + tuple(self.base.shape[1:])
 
+    def _index_on(self, device):
+        # (through pinned memory, asynchronously: a pageable copy to the device is stream-ordered AND blocks the host - the
+        # few KB of row numbers would make every batch wait for the previous iteration's whole graph)
+        if self.index.device == device:
+            return self.index
+        if device.type == 'cuda' and not self.index.is_cuda:
+            src = self.index if self.index.is_pinned() else self.index.pin_memory()
+            return src.to(device, non_blocking=True)
+        return self.index.to(device)
+
     def dense(self):
-        return self.base.index_select(0, self.index.to(self.base.device))
+        return self.base.index_select(0, self._index_on(self.base.device))
 
     def to(self, device, non_blocking=False):
         """The expanded tensor on `device` (what a consumer's `batch_tensor.to(device)` expects to get)."""
         device = torch.device(device)
+        if device.type == 'cuda' and device.index is None:
+            device = torch.device('cuda', torch.cuda.current_device())
         base = self.base if self.base.device == device else self.base.to(device, non_blocking=non_blocking)
-        return base.index_select(0, self.index.to(device, non_blocking=non_blocking))
+        return base.index_select(0, self._index_on(device))
 
     @property
     def is_cuda(self):
