@@ -127,12 +127,14 @@ class Detector(nn.Module):
                     s2s_batch = next(seq2seq_iter)
             if data_type == 'fact':
                 fns, fc_feats, att_feats, (caps_tensor, lengths), cpts_tensor, sentis_tensor, ground_truth = item
-                caps_tensor = caps_tensor.to(device)
+                caps_tensor = ops.to_device(caps_tensor, device)
             else:
                 fns, fc_feats, att_feats, cpts_tensor, sentis_tensor, senti_labels = item
-                senti_labels = senti_labels.to(device)
-            fc_feats, att_feats = fc_feats.to(device), att_feats.to(device)
-            cpts_tensor, sentis_tensor = cpts_tensor.to(device), sentis_tensor.to(device)
+                senti_labels = ops.to_device(senti_labels, device)
+            fc_feats, att_feats = ops.to_device(fc_feats, device), ops.to_device(att_feats, device)
+            # (ops.to_device: through pinned memory, non-blocking - `x.to(device)` from pageable memory holds the host until the
+            # stream gets there, i.e. until the previous iteration has finished)
+            cpts_tensor, sentis_tensor = ops.to_device(cpts_tensor, device), ops.to_device(sentis_tensor, device)
             del item
 
             if data_type == 'fact' or not training:      # labels from the image sentiment detector
@@ -155,7 +157,8 @@ class Detector(nn.Module):
                         # updating through the old one)
                         self._rl_graph = RLTrainGraph(self)
                     (s_caps, s_lengths), s_cpts, s_sentis, s_labels = s2s_batch
-                    scs_dev = ((s_caps.to(device), s_lengths), s_cpts.to(device), s_sentis.to(device), s_labels.to(device))
+                    scs_dev = ((ops.to_device(s_caps, device), s_lengths), ops.to_device(s_cpts, device),
+                               ops.to_device(s_sentis, device), ops.to_device(s_labels, device))
                     if data_type == 'fact':
                         def xe_senti_labels():
                             with torch.no_grad():
@@ -220,8 +223,8 @@ class Detector(nn.Module):
                         xe_senti_labels = self.sent_senti_cls(caps_tensor[:, 1:], lengths)[0]
                         xe_senti_labels = xe_senti_labels.softmax(dim=-1).argmax(dim=-1).detach()
                     (s_caps, s_lengths), s_cpts, s_sentis, s_labels = s2s_batch
-                    s_caps, s_cpts = s_caps.to(device), s_cpts.to(device)
-                    s_sentis, s_labels = s_sentis.to(device), s_labels.to(device)
+                    s_caps, s_cpts = ops.to_device(s_caps, device), ops.to_device(s_cpts, device)
+                    s_sentis, s_labels = ops.to_device(s_sentis, device), ops.to_device(s_labels, device)
                     with cap.token_logprobs():       # (log p(target) [B,T]: the [B,T,V] log-probs are never formed)
                         pred, pred2 = cap(fc_feats, att_feats, cpts_tensor, caps_tensor, xe_senti_labels, self.xe_ss_prob,
                                           s_caps, s_cpts, s_sentis, s_labels, self.seq2seq_ss_prob, mode='xe_seq2seq')
@@ -241,8 +244,8 @@ class Detector(nn.Module):
 
                 if training and not merged:
                     (s_caps, s_lengths), s_cpts, s_sentis, s_labels = s2s_batch
-                    s_caps, s_cpts = s_caps.to(device), s_cpts.to(device)
-                    s_sentis, s_labels = s_sentis.to(device), s_labels.to(device)
+                    s_caps, s_cpts = ops.to_device(s_caps, device), ops.to_device(s_cpts, device)
+                    s_sentis, s_labels = ops.to_device(s_sentis, device), ops.to_device(s_labels, device)
                     def seq2seq_unroll():                     # 80 text-only rows: a chain of small launches that
                         with cap.token_logprobs():
                             pred = cap(s_caps, s_cpts, s_sentis, s_labels, ss_prob=self.seq2seq_ss_prob, mode='seq2seq')

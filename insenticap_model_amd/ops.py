@@ -238,6 +238,24 @@ def upload(values, dtype, device):
     return torch.tensor(values, dtype=dtype).pin_memory().to(device, non_blocking=True)
 
 
+def to_device(x, device):
+    """A batch tensor on `device` without stalling the host: a tensor in pageable host memory goes through pinned memory
+    and a non-blocking copy (`x.to(device)` from pageable memory is stream-ordered AND blocks the host - it waits for
+    everything queued, i.e. for the previous iteration); device tensors and data.RowGather pass through / expand."""
+    if not torch.is_tensor(x):
+        return x.to(device)                  # (data.RowGather: expanded on the device)
+    if x.is_cuda or torch.device(device).type != 'cuda':
+        return x.to(device)
+    if x.is_pinned():
+        return x.to(device, non_blocking=True)
+    if x.numel() * x.element_size() > (1 << 20):
+        # whole feature batches from pageable memory (151 MB for 512 images): page-locking a fresh buffer per batch costs
+        # more than the runtime's own staged copy - data.DevicePrefetcher (kept pinned buffers) or data.DeviceFeatureStore
+        # are the ways to take these off the host's critical path
+        return x.to(device)
+    return x.pin_memory().to(device, non_blocking=True)
+
+
 def require_device(*tensors):
     for t in tensors:
         if t is not None and not t.is_cuda:

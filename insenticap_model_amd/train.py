@@ -7,7 +7,7 @@ frozen helper outside this path: the caller passes its arg-max as `xe_senti_labe
 """
 import torch
 
-from . import dp
+from . import dp, ops
 from .optim import FusedClampAdam, clip_gradient
 
 
@@ -164,12 +164,14 @@ def xe_train_step(captioner, optim, xe_crit, da_crit, fact_batch, xe_senti_label
     (dp.GradSink); False = one flat all-reduce after the backward.  Same parameters after the step, bit for bit."""
     device = torch.device(device) if device is not None else next(captioner.parameters()).device
     _, fc_feats, att_feats, (caps_tensor, lengths), cpts_tensor = fact_batch[:5]
-    fact = (fc_feats.to(device), att_feats.to(device), caps_tensor.to(device), lengths, cpts_tensor.to(device))
-    xe_senti_labels = xe_senti_labels.to(device)
+    fact = (ops.to_device(fc_feats, device), ops.to_device(att_feats, device), ops.to_device(caps_tensor, device), lengths,
+            ops.to_device(cpts_tensor, device))
+    xe_senti_labels = ops.to_device(xe_senti_labels, device)
     scs = None
     if scs_batch is not None:
         (s_caps, s_lengths), s_cpts, s_sentis, s_labels = scs_batch
-        scs = (s_caps.to(device), s_lengths, s_cpts.to(device), s_sentis.to(device), s_labels.to(device))
+        scs = (ops.to_device(s_caps, device), s_lengths, ops.to_device(s_cpts, device), ops.to_device(s_sentis, device),
+               ops.to_device(s_labels, device))
     # data-parallel: taken whenever a process group exists (also a one-rank one: shares are then exactly 1.0), so the
     # single-GPU RCCL test crosses every branch an 8-rank run does
     dist_on = dp.distributed(group)
