@@ -246,3 +246,45 @@ def test_senti_iterations_from_graphs_equal_the_eager_phases_and_track_plain_eag
             np.testing.assert_allclose(a[k], c[k], rtol=2e-4, atol=2e-6, err_msg=k)
     for (k, x), (_, y) in zip(g.captioner.named_parameters(), p.captioner.named_parameters()):
         assert float((x - y).abs().max()) <= 6 * 2 * 4e-4 * 1.01, k
+
+
+def test_graph_served_iterations_between_the_other_things_a_trainer_does():
+    """A short form of tools/soak_mix.py: 'fact' and 'senti' iterations from the graphs with an eager XE step, an evaluation
+    roll-out and a beam search on the same captioner in between (weights moved behind the graphs' back: an eager iteration
+    and, when a scope was rebuilt, a new capture), every result finite, the stream pool and the kept geometries bounded."""
+    from insenticap_model_amd import ops
+    from insenticap_model_amd.train import xe_train_step
+    items, scs, split, _ = data(2)
+    det = make(dropout=0.0, graphs=True, warmup=1)
+    det.set_ciderd_scorer(split)
+    cap = det.captioner
+    fns, fc, att, (caps, lengths), cpts, sentis, _ = items[0]
+    labels = torch.zeros(fc.shape[0], dtype=torch.int64)
+    senti_item = (fns, fc, att, cpts, sentis, labels)
+    fact = (None, fc.to(DEV), att.to(DEV), (caps.to(DEV), lengths), cpts.to(DEV))
+    (s_caps, s_len), s_cpts, s_sentis, s_labels = scs[0]
+    scs_d = ((s_caps.to(DEV), s_len), s_cpts.to(DEV), s_sentis.to(DEV), s_labels.to(DEV))
+    streams0 = None
+    for r in range(5):
+        for it in items:
+            out = det(([it], scs), 'fact', True)
+            assert all(np.isfinite(v) for v in out.values())
+        out = det(([senti_item], scs), 'senti', True)
+        assert set(out) == {'da_loss', 'cls_reward', 'all_rewards', 'cap_loss', 'seq2seq_loss'}
+        assert all(np.isfinite(v) for v in out.values())
+        if r % 2 == 0:
+            l = xe_train_step(cap, det.cap_optim, det.cap_xe_crit, det.cap_da_crit, fact, labels.to(DEV), scs_d, 0.0, 0.1)
+            assert np.isfinite(float(l['all_loss']))
+            cap.cpt_feats = cap.fc_feats = None
+        cap.eval()
+        with torch.no_grad():
+            seq, lp, mk = cap(fc.to(DEV), att.to(DEV), cpts.to(DEV), sentis.to(DEV), labels.to(DEV), TN, 1, mode='rl')
+            words, scores = cap.sample(fc[0].to(DEV), att[0].to(DEV), sentis[0].to(DEV), labels[:1].to(DEV), 3, 1, TN)
+        assert bool(torch.isfinite(lp).all()) and len(words) == 3
+        cap.train()
+        if r == 1:
+            streams0 = len(ops._OWNED_STREAMS)
+    torch.cuda.synchronize()
+    ops.check_numerics('mixed use')
+    g = det._rl_graph
+    assert len(g._geoms) <= 2 and g.replays >= 4 and len(ops._OWNED_STREAMS) == streams0
