@@ -764,7 +764,7 @@ class Captioner(nn.Module):
         if (sample_max and self.__dict__.get('_rollout_graphs') is not None and not self._needs_grad()
                 and not self.training and _replay is None and _masks is None and ops.TIMER.arm_step is None
                 and fc_feats.shape[0] <= self.ROLLOUT_GRAPH_MAX_ROWS and ops.graphs_allowed_here()
-                and not torch.cuda.is_current_stream_capturing()       # (a training graph's capture runs its greedy baseline
+                and fc_feats.is_cuda and not torch.cuda.is_current_stream_capturing()   # (a training graph's capture runs its greedy baseline
                                                                         # here: it IS being captured - no graph inside a graph)
                 and self._features_in_domain(fc_feats, att_feats)):     # (beyond the domain: eager, exact engine)
             return self._graphed_rollout(fc_feats, att_feats, cpt_words, senti_words, senti_labels, max_seq_len)

@@ -252,3 +252,40 @@ def test_captions_padded_beyond_the_longest_one_train_alike_and_share_one_graph(
         assert np.isfinite(float(out['all_loss']))
     torch.cuda.synchronize()
     assert g.captures == 1 and g.replays == 4 and len(g._geoms) == 1
+
+
+def test_epochs_with_validation_schedules_and_a_checkpoint_reload():
+    """A short form of tools/soak_xe_epochs.py: graph-served training steps, then a validation pass (eval mode, no_grad),
+    scheduled sampling and the learning rate changing per epoch (a new geometry per ss_prob), and - once - the weights
+    reloaded from a checkpoint written before (the graphs notice: one eager iteration, then replays again)."""
+    import io
+    cfg = TINY
+    cap = make(cfg)
+    optim, xc, dc = cap.get_optim_criterion(4e-4)
+    train = [batch(cfg, 60 + i) for i in range(3)]
+    val = batch(cfg, 90)
+    g = XETrainGraph(cap, optim, xc, dc, grad_clip=0.1, warmup=1)
+    saved = None
+    for ep in range(4):
+        ss = 0.1 * ep
+        for grp in optim.param_groups:
+            grp['lr'] = 4e-4 * 0.5 ** ep
+        cap.train()
+        for it in range(6):
+            out = g.step(*train[it % 3], ss)
+            assert np.isfinite(float(out['all_loss']))
+        cap.eval()
+        with torch.no_grad():
+            fact, labels, _ = val
+            pred = cap(fact[1], fact[2], fact[4], fact[3][0], labels, 0.0, mode='xe')
+            vl = float(xc(pred, fact[3][0][:, 1:], fact[3][1]))
+        assert np.isfinite(vl)
+        if ep == 1:
+            buf = io.BytesIO()
+            torch.save({k: v.clone() for k, v in cap.state_dict().items()}, buf)
+            saved = buf.getvalue()
+        if ep == 2:
+            cap.load_state_dict(torch.load(io.BytesIO(saved)))
+    torch.cuda.synchronize()
+    ops.check_numerics('epochs')
+    assert g.captures >= 4 and g.replays >= 4 * 6 - 2 * 4 - 2 and len(g._geoms) <= 4
