@@ -1,6 +1,7 @@
 // Embedding gathers, roll-out bookkeeping, log-softmax finalisation, beam top-k and the
 // masked-NLL criterion (captioner.py:170-172, 201-202, 307-311, 329-344, 394-408, 427-440).
 #include <atomic>
+#include <cstddef>
 
 #include "common.h"
 
@@ -821,15 +822,23 @@ extern "C" int isc_beam_topk(const float *logits, int64_t ld_logits, const float
 
 // ------------------------------------------------------------------ beam step tail in one launch
 // isc_beam_select: what isc_beam_topk + isc_beam_merge + isc_beam_gather do in three launches, from the tile
-// statistics and per-tile sorted candidate lists the few-row classifier (rows.hip) leaves.  One workgroup per image,
-// one wave per beam row:
-//   1. the row's normaliser from (pmax, psum) - fold_row_stats, as every decode path;
-//   2. the row's tile candidates (value, id) [n_tile][8]: a lane owns tiles lane, lane + 64, ... and holds their lists
-//      in registers (one round trip, no staging);
-//   3. a `beam`-round k-way merge over the tiles' list heads: per round a lane's best head enters a wave arg-max (value
-//      descending, then (tile, position) ascending = word id ascending, since tiles are column ranges and lists are
-//      sorted), the winning lane pops that list;
-//   4. after a workgroup barrier the image's candidate bookkeeping, the same code path as beam_merge_kernel.
+// statistics and per-tile sorted candidate lists the few-row classifier (rows.hip) leaves.  One workgroup per image.  A
+// lone wave retires an instruction every ~8 cycles here, so the launch is as long as the LONGEST dependent instruction
+// chain of any wave: the work is cut so that no wave carries more than its share.
+//   merge waves (one per beam row):
+//   1. every global operand requested in the first instructions: the two block-uniform switches (search ended / image
+//      frozen), the row's tile candidates (value, id) [n_tile][8] - a lane owns tiles lane, lane + 64, ... and holds their
+//      lists in registers -, the tile statistics, the parents' bookkeeping (lanes 0..7 of every wave hold parents 0..7: no
+//      staging, no barrier), the row's word list;
+//   2. the row's normaliser from (pmax, psum) - fold_row_stats, as every decode path;
+//   3. a `beam`-round k-way merge over the tiles' list heads: ONE 32-bit DPP maximum per round, ties by ballots and scalar
+//      bit scans (value descending, then tile ascending = word id ascending: tiles are column ranges, lists are sorted),
+//      the winning lane's list moves up one place; round k's winner stays in lane k's registers;
+//   4. parent k's candidates scored in fp64 by lanes 0..beam-1 of wave k (captioner.py:378-411, beam_merge_kernel's
+//      rules) -> LDS, barrier, stable descending rank with EIGHT lanes per candidate (each counts an eighth of the
+//      others), ranks < beam write the new rows' bookkeeping, barrier, wave r writes new row r's word list;
+//   state waves (one per beam row, only when the recurrent state is re-ordered here): row r's planes -> LDS by LDS-DMA
+//   while the merges run, then - winners known - new row r's planes from its parent's LDS image.
 // Word ids, log-probs ((x - max) - log(sum), the expression of beam_topk8_kernel) and tie order are those of the
 // three-launch path on the same logits and statistics.
 #define ISC_SEL_TILES_PER_LANE 4
@@ -837,123 +846,117 @@ extern "C" int isc_beam_topk(const float *logits, int64_t ld_logits, const float
 #define RSTAMP_KID 5
 RSTAMP_SETTER(isc_pw_set_stamp)
 #endif
-// One launch, one workgroup per image, and at this size every dependent memory round trip is a visible share of the
-// kernel: every global operand - candidates, tile statistics, the candidates' bookkeeping (last words, scores, lengths,
-// the parents' word lists) - is requested in the first instructions, all lane exchanges are DPP (one cross-half swap per
-// reduction), and the bookkeeping runs on every thread from LDS copies instead of one thread walking global memory.
-__device__ __forceinline__ void sel_argmax(float &v, int &k) {       // (value desc, key asc) over the wavefront
-    half_argmax(v, k);
-    const float ov = __shfl_xor(v, 32, 64);
-    const int ok = __shfl_xor(k, 32, 64);
-    if (ov > v || (ov == v && ok < k)) { v = ov; k = ok; }
+// Wave-wide maximum / sum that never leave the VALU: four DPP steps leave every 16-lane row holding its reduction, the
+// four row values then meet through row_bcast15 / row_bcast31 (maximum) or four v_readlane (sum: the association of
+// half_sum + the cross-half add, so the normaliser keeps its bits).  The ds_swizzle / ds_bpermute steps these replace are
+// LDS round trips (~100+ cycles each) - in a kernel that is ONE dependent chain they were a third of its time.
+__device__ __forceinline__ float sel_wave_fmax(float v) {               // -> the wave's maximum, wave-uniform (NaNs are dropped)
+    // v_max_f32 with the DPP operand folded in (the compiler keeps v_mov_dpp + a canonicalising v_max + v_max per step);
+    // s_nop 1 = the two wait states a DPP read needs behind the VALU write of its source.  row_bcast15 / 31 write rows
+    // 1, 3 / 2, 3 only (row_mask), the other rows keep their value.
+    asm volatile("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+                 "s_nop 1" : "+v"(v));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
-// The same order as ONE unsigned 64-bit maximum: high word = the float's order-preserving bits, low word = 0x7fffffff - key.
-// A step of the reduction is then two lane moves, one 64-bit compare and two selects - no compound conditions, which
-// hipcc turns into exec-masked branches (the merge loop of the select kernel ran 2 400 cycles per round that way).
-__device__ __forceinline__ unsigned long long sel_pack(float v, int key) {
-    const unsigned u = __float_as_uint(v);
-    const unsigned hi = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-    return ((unsigned long long)hi << 32) | (unsigned)(0x7fffffff - key);
-}
-__device__ __forceinline__ float sel_unpack_value(unsigned long long p) {
-    const unsigned hi = (unsigned)(p >> 32);
-    return __uint_as_float((hi & 0x80000000u) ? (hi & 0x7fffffffu) : ~hi);
-}
-__device__ __forceinline__ int sel_unpack_key(unsigned long long p) { return 0x7fffffff - (int)(unsigned)(p & 0xffffffffu); }
-template <int CTRL>
-__device__ __forceinline__ unsigned long long sel_dpp64(unsigned long long p) {
-    const unsigned lo = (unsigned)isc_dpp<CTRL>((int)(unsigned)p), hi = (unsigned)isc_dpp<CTRL>((int)(unsigned)(p >> 32));
-    return ((unsigned long long)hi << 32) | lo;
-}
-__device__ __forceinline__ unsigned long long sel_max64(unsigned long long a, unsigned long long b) { return b > a ? b : a; }
-__device__ __forceinline__ unsigned long long sel_wave_max64(unsigned long long p) {
-    p = sel_max64(p, sel_dpp64<ISC_DPP_XOR1>(p));
-    p = sel_max64(p, sel_dpp64<ISC_DPP_XOR2>(p));
-    p = sel_max64(p, sel_dpp64<ISC_DPP_HALF_MIRROR>(p));
-    p = sel_max64(p, sel_dpp64<ISC_DPP_MIRROR>(p));
-    {
-        const unsigned lo = (unsigned)isc_swz16((int)(unsigned)p), hi = (unsigned)isc_swz16((int)(unsigned)(p >> 32));
-        p = sel_max64(p, ((unsigned long long)hi << 32) | lo);
-    }
-    {
-        const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)p, 32, 64), hi = (unsigned)__shfl_xor((int)(unsigned)(p >> 32), 32, 64);
-        p = sel_max64(p, ((unsigned long long)hi << 32) | lo);
-    }
-    return p;
+__device__ __forceinline__ float sel_wave_sum(float v) {                // == half_sum(v) + the other half's, bit for bit
+    v += isc_dpp<ISC_DPP_XOR1>(v);
+    v += isc_dpp<ISC_DPP_XOR2>(v);
+    v += isc_dpp<ISC_DPP_HALF_MIRROR>(v);
+    v += isc_dpp<ISC_DPP_MIRROR>(v);
+    const int b = __float_as_int(v);
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(b, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(b, 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(b, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(b, 48));
+    return (r0 + r1) + (r2 + r3);
 }
 // The winner's list (tile index Q of its lane: wave-uniform, so each of the four copies of this runs under a scalar
-// branch) advances: the lists stay where they are (register arrays with static indices), the lane's cursor moves and its
-// cached head is re-selected; the winner's word id is selected the same way and read from its lane.
+// branch) moves up one place in its lane - static register indices, position 0 is always the head.  A search pops at most
+// `beam` <= 8 entries and a list holds 8, so no list runs dry before the last round; positions past the fifth are only
+// ever heads for beam > 5.
 #define SEL_POP(Q)                                                                          \
     do {                                                                                    \
-        const int cq_ = cur[Q], cn_ = cq_ + 1;                                              \
-        int ids_ = cid[Q][0];                                                               \
-        float hn_ = -INFINITY;                                                              \
-        _Pragma("unroll") for (int s_ = 1; s_ < 8; ++s_) {                                  \
-            ids_ = (cq_ == s_) ? cid[Q][s_] : ids_;                                         \
-            hn_ = (cn_ == s_) ? cvv[Q][s_] : hn_;                                           \
-        }                                                                                   \
-        wid = __builtin_amdgcn_readlane(ids_, wl);                                          \
+        wid = __builtin_amdgcn_readlane(cid[Q][0], wl);                                     \
         const bool me_ = lane == wl;                                                        \
-        cur[Q] = me_ ? cn_ : cq_;                                                           \
-        head[Q] = me_ ? hn_ : head[Q];                                                      \
+        _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) {                                  \
+            cvv[Q][s_] = me_ ? cvv[Q][s_ + 1] : cvv[Q][s_];                                 \
+            cid[Q][s_] = me_ ? cid[Q][s_ + 1] : cid[Q][s_];                                 \
+        }                                                                                   \
+        if (beam > 5) {                                                                     \
+            _Pragma("unroll") for (int s_ = 4; s_ < 7; ++s_) {                              \
+                cvv[Q][s_] = me_ ? cvv[Q][s_ + 1] : cvv[Q][s_];                             \
+                cid[Q][s_] = me_ ? cid[Q][s_ + 1] : cid[Q][s_];                             \
+            }                                                                               \
+            cvv[Q][7] = me_ ? -INFINITY : cvv[Q][7];                                        \
+        }                                                                                   \
     } while (0)
 
-__global__ __launch_bounds__(512) void beam_select_kernel(const isc_beam_select_args a) {
+__global__ __launch_bounds__(1024) void beam_select_kernel(const isc_beam_select_args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sel_smem[];
-    __shared__ double cs[ISC_BEAM_MAX * ISC_BEAM_MAX], s_score[ISC_BEAM_MAX];
-    __shared__ long long ctok[ISC_BEAM_MAX * ISC_BEAM_MAX], s_last[ISC_BEAM_MAX];
-    __shared__ int cpar[ISC_BEAM_MAX * ISC_BEAM_MAX], ccar[ISC_BEAM_MAX * ISC_BEAM_MAX], s_len[ISC_BEAM_MAX];
-    __shared__ float tv[ISC_BEAM_MAX][ISC_BEAM_MAX];
-    __shared__ int ti[ISC_BEAM_MAX][ISC_BEAM_MAX];
+    __shared__ double cs[64];                          // the image's candidates (<= beam x beam): score,
+    __shared__ long long ctk[64];                      //   token
     __shared__ int w_par[ISC_BEAM_MAX], w_car[ISC_BEAM_MAX], w_len[ISC_BEAM_MAX];     // winners by rank
     __shared__ long long w_tok[ISC_BEAM_MAX];
     rows_kernarg_warm<ROWS_KERNARG_LINES(isc_beam_select_args)>();
     const int i = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int beam = a.beam, T = a.T, base = i * beam, n_tile = a.n_tile;
+    const bool merger = wave < beam;                  // (wave-uniform) else: a state wave
+    const int wrow = merger ? wave : wave - beam;     // the beam row this wave serves
     RSTAMP(0);
-    // ---- everything this thread will need from memory, requested now: the image's `done` flag, the row's tile lists
-    // (a lane owns tiles lane, lane + 64, ..: 8 values + 8 ids each, straight to registers), the tile statistics, the
-    // candidates' bookkeeping and the parents' word lists
-    const int done_flag = a.done[i];
-    const int go = a.live_in ? *a.live_in : 1;
-    const int row = base + wave;
+    // ---- the two block-uniform switches first (their round trip runs under everything requested behind them; without
+    // live_in the same load reads this launch's own `beam` > 0 out of the argument block - no branch in front of a load)
+    typedef const __attribute__((address_space(1))) int *sel_gint_p;      // (global, not flat: counted in order with the rest)
+    const sel_gint_p gop = a.live_in ? (sel_gint_p)(unsigned long long)a.live_in
+                                     : (sel_gint_p)((unsigned long long)__builtin_amdgcn_kernarg_segment_ptr() +
+                                                    offsetof(isc_beam_select_args, beam));
+    const int done_v = a.done[i];
+    const int go_v = *gop;
+    const int row = base + wrow;
     float cvv[ISC_SEL_TILES_PER_LANE][8];
     int cid[ISC_SEL_TILES_PER_LANE][8];
     float pm[ISC_SEL_TILES_PER_LANE], ps[ISC_SEL_TILES_PER_LANE];
+    long long wv[4];                                  // the row's word list, positions lane, lane + 64, ..
+    float *st_lds = reinterpret_cast<float *>(sel_smem + (((size_t)beam * T * 8 + 15) & ~(size_t)15));   // [plane][row][H]
+    const int rows_all = a.n_img * beam;
+    if (merger) {
 #pragma unroll
-    for (int q = 0; q < ISC_SEL_TILES_PER_LANE; ++q) {
-        const int tl = lane + 64 * q, tc = tl < n_tile ? tl : n_tile - 1;
-        const float4 *gv = reinterpret_cast<const float4 *>(a.cand_val + ((long long)row * n_tile + tc) * 8);
-        const int4 *gi = reinterpret_cast<const int4 *>(a.cand_idx + ((long long)row * n_tile + tc) * 8);
-        const float4 v0 = gv[0], v1 = gv[1];
-        const int4 i0 = gi[0], i1 = gi[1];
-        cvv[q][0] = v0.x; cvv[q][1] = v0.y; cvv[q][2] = v0.z; cvv[q][3] = v0.w;
-        cvv[q][4] = v1.x; cvv[q][5] = v1.y; cvv[q][6] = v1.z; cvv[q][7] = v1.w;
-        cid[q][0] = i0.x; cid[q][1] = i0.y; cid[q][2] = i0.z; cid[q][3] = i0.w;
-        cid[q][4] = i1.x; cid[q][5] = i1.y; cid[q][6] = i1.z; cid[q][7] = i1.w;
-        pm[q] = a.part_max[(long long)row * n_tile + tc];
-        ps[q] = a.part_sum[(long long)row * n_tile + tc];
+        for (int q = 0; q < ISC_SEL_TILES_PER_LANE; ++q) {
+            const int tl = lane + 64 * q, tc = tl < n_tile ? tl : n_tile - 1;
+            const float4 *gv = reinterpret_cast<const float4 *>(a.cand_val + ((long long)row * n_tile + tc) * 8);
+            const int4 *gi = reinterpret_cast<const int4 *>(a.cand_idx + ((long long)row * n_tile + tc) * 8);
+            const float4 v0 = gv[0], v1 = gv[1];
+            const int4 i0 = gi[0], i1 = gi[1];
+            cvv[q][0] = v0.x; cvv[q][1] = v0.y; cvv[q][2] = v0.z; cvv[q][3] = v0.w;
+            cvv[q][4] = v1.x; cvv[q][5] = v1.y; cvv[q][6] = v1.z; cvv[q][7] = v1.w;
+            cid[q][0] = i0.x; cid[q][1] = i0.y; cid[q][2] = i0.z; cid[q][3] = i0.w;
+            cid[q][4] = i1.x; cid[q][5] = i1.y; cid[q][6] = i1.z; cid[q][7] = i1.w;
+            pm[q] = a.part_max[(long long)row * n_tile + tc];
+            ps[q] = a.part_sum[(long long)row * n_tile + tc];
+        }
     }
-    long long my_last = 0;
+    // parents' bookkeeping: lane l of EVERY wave holds parent min(l & 7, beam - 1)
+    const int pk = (lane & 7) < beam ? (lane & 7) : beam - 1;
+    const long long my_last = a.last_in[base + pk];
     double my_score = 0.0;
     int my_len = 0;
-    if (tid < beam) { my_last = a.last_in[base + tid]; my_score = a.score_in[base + tid]; my_len = a.len_in[base + tid]; }
-    long long wv[4];                         // element e of the image's [beam][T] block of word lists
+    if (merger) {
+        my_score = a.score_in[base + pk];
+        my_len = a.len_in[base + pk];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int e = tid + q * (int)blockDim.x;
-        wv[q] = a.words_in[(long long)base * T + (e < beam * T ? e : 0)];
-    }
-    // the image's rows of the step's output state -> LDS (behind the word lists), on its way while the merges run
-    float *st_lds = reinterpret_cast<float *>(sel_smem + (((size_t)beam * T * 8 + 15) & ~(size_t)15));
-    if (a.state_out) {                       // LDS image [plane][row][H]; wave w takes (plane, row) pairs w, w + nw, ...
-        const int rows_all = a.n_img * beam, npair = a.state_planes * beam, nw = (int)blockDim.x >> 6;
+        for (int q = 0; q < 4; ++q) {
+            const int pos = lane + 64 * q;
+            wv[q] = a.words_in[(long long)row * T + (pos < T ? pos : T - 1)];
+        }
+    } else if (a.state_out) {
+        // state wave: this row's planes -> LDS image [plane][row][H], on their way while the merges run
         const unsigned lds0 = (unsigned)(size_t)st_lds;
-        for (int pr = wave; pr < npair; pr += nw) {
-            const int pl = pr / beam, r = pr - pl * beam;    // (wave-uniform)
-            const float *srow = a.state_in + ((long long)pl * rows_all + base + r) * a.H;
+        for (int pl = 0; pl < a.state_planes; ++pl) {
+            const float *srow = a.state_in + ((long long)pl * rows_all + row) * a.H;
+            const int pr = pl * beam + wrow;
             if ((a.H & 255) == 0) {
                 for (int c0 = 0; c0 < a.H; c0 += 256) {     // one 1 KB LDS-DMA per 256 floats
                     const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(pr * a.H + c0) * 4u);
@@ -966,182 +969,160 @@ __global__ __launch_bounds__(512) void beam_select_kernel(const isc_beam_select_
         }
     }
     RSTAMP(1);
-    if (go == 0) return;                  // the search has ended (block-uniform)
-    if (done_flag) {                      // frozen image: everything carried over unchanged (block-uniform)
-        if (tid < beam) {
-            a.src_row[base + tid] = base + tid;
-            a.last_out[base + tid] = my_last;
-            a.score_out[base + tid] = my_score;
-            a.len_out[base + tid] = my_len;
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int e = tid + q * (int)blockDim.x;
-            if (e < beam * T) a.words_out[(long long)base * T + e] = wv[q];
-        }
-        if (a.state_out) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            const int rows_all = a.n_img * beam, npair = a.state_planes * beam, nw = (int)blockDim.x >> 6;
-            for (int pr = wave; pr < npair; pr += nw) {
-                const int pl = pr / beam, r = pr - pl * beam;
-                for (int c = lane * 4; c < a.H; c += 256)
-                    *reinterpret_cast<float4 *>(a.state_out + ((long long)pl * rows_all + base + r) * a.H + c) =
-                        *reinterpret_cast<const float4 *>(st_lds + pr * a.H + c);
+    if (__builtin_amdgcn_readfirstlane(go_v) == 0) return;       // the search has ended (block-uniform)
+    if (__builtin_amdgcn_readfirstlane(done_v)) {                // frozen image: everything carried over unchanged (block-uniform)
+        if (merger) {
+            if (wave == 0 && lane < beam) {
+                a.src_row[base + lane] = base + lane;
+                a.last_out[base + lane] = my_last;
+                a.score_out[base + lane] = my_score;
+                a.len_out[base + lane] = my_len;
             }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int pos = lane + 64 * q;
+                if (pos < T) a.words_out[(long long)row * T + pos] = wv[q];
+            }
+        } else if (a.state_out) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (a wave reads back only what it fetched itself)
+            for (int pl = 0; pl < a.state_planes; ++pl)
+                for (int c = lane * 4; c < a.H; c += 256)
+                    *reinterpret_cast<float4 *>(a.state_out + ((long long)pl * rows_all + row) * a.H + c) =
+                        *reinterpret_cast<const float4 *>(st_lds + (pl * beam + wrow) * a.H + c);
         }
         return;
     }
+    // ---- which parents have ended, where each parent's candidates start, how many there are: scalar work on one ballot
+    const int ncand = a.t == 0 ? 1 : beam;
+    const unsigned endm = a.t > 0 ? (unsigned)__ballot(my_last == a.eos_id) & ((1u << beam) - 1u) : 0u;
+    const int n = ncand * beam - (beam - 1) * __builtin_popcount(endm & ((1u << ncand) - 1u));
+    float myv = -INFINITY;                // lane k < beam of a merge wave: the row's k-th best (log-prob, word id)
+    int myid = 0;
+    if (merger) {
 #pragma unroll
-    for (int q = 0; q < ISC_SEL_TILES_PER_LANE; ++q)
-        if (lane + 64 * q >= n_tile) {
-            pm[q] = -INFINITY; ps[q] = 0.f;
+        for (int q = 0; q < ISC_SEL_TILES_PER_LANE; ++q)
+            if (lane + 64 * q >= n_tile) {
+                pm[q] = -INFINITY; ps[q] = 0.f;
 #pragma unroll
-            for (int s_ = 0; s_ < 8; ++s_) cvv[q][s_] = -INFINITY;
-        }
-    // ---- the row's normaliser: max over the tile maxima, sum of the rescaled tile sums
-    float gmax = fmaxf(fmaxf(pm[0], pm[1]), fmaxf(pm[2], pm[3]));
-    {
-        int dummy = lane;
-        sel_argmax(gmax, dummy);
-    }
-    float ssum = 0.f;
+                for (int s_ = 0; s_ < 8; ++s_) cvv[q][s_] = -INFINITY;
+            }
+        // ---- the row's normaliser: max over the tile maxima, sum of the rescaled tile sums
+        const float gmax = sel_wave_fmax(fmaxf(fmaxf(pm[0], pm[1]), fmaxf(pm[2], pm[3])));
+        float ssum = 0.f;
 #pragma unroll
-    for (int q = 0; q < ISC_SEL_TILES_PER_LANE; ++q) ssum += ps[q] * expf(pm[q] - gmax);
-    ssum = half_sum(ssum);
-    ssum += __shfl_xor(ssum, 32, 64);
-    if (lane == 0 && !(fabsf(gmax) <= 3.0e38f && ssum <= 3.0e38f)) isc_flag_pw(ISC_STATUS_WORD_STATS);     // NaN fails both
-    const float logS = logf(ssum);
-    if (tid < beam) { s_last[tid] = my_last; s_score[tid] = my_score; s_len[tid] = my_len; }
-    RSTAMP(2);
-    // ---- k-way merge over the tiles' list heads: per round the lanes' best heads meet in a wave arg-max (value
-    // descending, then (tile, position) ascending = word id ascending: tiles are column ranges, lists are sorted)
-    int cur[ISC_SEL_TILES_PER_LANE] = {0, 0, 0, 0};
-    float head[ISC_SEL_TILES_PER_LANE] = {cvv[0][0], cvv[1][0], cvv[2][0], cvv[3][0]};
-    RSTAMP(3);
-    RSTAMP_CLK0();
-    for (int k = 0; k < beam; ++k) {
-        unsigned long long best = 0;                            // (below every packed pair)
+        for (int q = 0; q < ISC_SEL_TILES_PER_LANE; ++q) ssum += ps[q] * expf(pm[q] - gmax);
+        ssum = sel_wave_sum(ssum);
+        if (lane == 0 && !(fabsf(gmax) <= 3.0e38f && ssum <= 3.0e38f)) isc_flag_pw(ISC_STATUS_WORD_STATS);     // NaN fails both
+        const float logS = logf(ssum);
+        RSTAMP(2);
+        // ---- k-way merge over the tiles' list heads: per round ONE 32-bit wave maximum of the lanes' best heads; ties
+        // (equal values) go to the smaller word id = the smaller tile index = the first q with a lane at the maximum, then
+        // its lowest lane - four ballots and scalar bit scans, no 64-bit keys in the lanes
+        unsigned long long own[ISC_SEL_TILES_PER_LANE];         // lanes whose tile q exists (wave-uniform)
 #pragma unroll
-        for (int q = 0; q < ISC_SEL_TILES_PER_LANE; ++q) {     // tiles past the end / exhausted lists: -inf under a key past all
-            const bool ok = (lane + 64 * q < n_tile) & (cur[q] < 8);
-            const int kq = ok ? (lane + 64 * q) * 8 + cur[q] : 0x7ffffff0;
-            best = sel_max64(best, sel_pack(head[q], kq));
+        for (int q = 0; q < ISC_SEL_TILES_PER_LANE; ++q) own[q] = __ballot(lane + 64 * q < n_tile);
+        for (int k = 0; k < beam; ++k) {
+            const float mx = sel_wave_fmax(fmaxf(fmaxf(cvv[0][0], cvv[1][0]), fmaxf(cvv[2][0], cvv[3][0])));
+            const unsigned long long h0 = __ballot(cvv[0][0] == mx) & own[0], h1 = __ballot(cvv[1][0] == mx) & own[1];
+            const unsigned long long h2 = __ballot(cvv[2][0] == mx) & own[2], h3 = __ballot(cvv[3][0] == mx) & own[3];
+            const bool have = (h0 | h1 | h2 | h3) != 0;         // (false: a NaN maximum)
+            int wid = 0;
+            if (have) {
+                const int wq = h0 ? 0 : h1 ? 1 : h2 ? 2 : 3;
+                const int wl = __builtin_ctzll(h0 ? h0 : h1 ? h1 : h2 ? h2 : h3);
+                if (wq == 0) SEL_POP(0); else if (wq == 1) SEL_POP(1); else if (wq == 2) SEL_POP(2); else SEL_POP(3);
+            }
+            const float lp = have ? (mx - gmax) - logS : -INFINITY;
+            myv = lane == k ? lp : myv;
+            myid = lane == k ? wid : myid;
         }
-        best = sel_wave_max64(best);
-        const float mx = sel_unpack_value(best);
-        const int key = sel_unpack_key(best);
-        const bool have = key < 0x7ffffff0;                    // wave-uniform, as are key and mx
-        int wid = 0;
-        if (have) {
-            const int wt = __builtin_amdgcn_readfirstlane(key >> 3);
-            const int wl = wt & 63, wq = wt >> 6;
-            if (wq == 0) SEL_POP(0); else if (wq == 1) SEL_POP(1); else if (wq == 2) SEL_POP(2); else SEL_POP(3);
+        RSTAMP(3);
+        if (a.top_val && lane < beam) {
+            a.top_val[(long long)row * beam + lane] = myv;
+            a.top_idx[(long long)row * beam + lane] = (unsigned)myid < (unsigned)a.V ? myid : 0;
         }
-        if (lane == 0) {
-            tv[wave][k] = have ? (mx - gmax) - logS : -INFINITY;
-            ti[wave][k] = wid;
+        // ---- parent `wave`'s candidates (captioner.py:378-411; beam_merge_kernel's rules): an ended parent is carried as
+        // ONE candidate with its score, a live one expands into its `beam` best words
+        if (wave < ncand) {
+            const int ended = (endm >> wave) & 1u;
+            const int ck = wave * beam - (beam - 1) * __builtin_popcount(endm & ((1u << wave) - 1u));
+            const double sc_k = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(my_score), wave),
+                                                 __builtin_amdgcn_readlane(__double2loint(my_score), wave));
+            if (lane < (ended ? 1 : beam)) {
+                cs[ck + lane] = ended ? sc_k : sc_k + (double)myv;
+                ctk[ck + lane] = ended ? a.eos_id : (long long)((unsigned)myid < (unsigned)a.V ? myid : 0);
+            }
         }
-    }
-    if (a.top_val && lane < beam) {
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        a.top_val[(long long)row * beam + lane] = tv[wave][lane];
-        const int id = ti[wave][lane];
-        a.top_idx[(long long)row * beam + lane] = (unsigned)id < (unsigned)a.V ? id : 0;
+        // the parents' word lists -> LDS (read back by whichever new row continues them)
+        {
+            long long *wl = reinterpret_cast<long long *>(sel_smem);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int pos = lane + 64 * q;
+                if (pos < T) wl[wave * T + pos] = wv[q];
+            }
+        }
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's share of the state image has landed
     }
     RSTAMP(4);
-    RSTAMP_CLK1();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's share of the state image has landed
     __syncthreads();
-    // ---- the image's candidates (captioner.py:378-411; beam_merge_kernel's bookkeeping), every thread from LDS
-    const int ncand = a.t == 0 ? 1 : beam;
-    int coff[ISC_BEAM_MAX + 1];
-    int all_ended = 1;
-    {
-        int off = 0;
-#pragma unroll
-        for (int k = 0; k < ISC_BEAM_MAX; ++k) {
-            coff[k] = off;
-            if (k < ncand) {
-                const int ended = a.t > 0 && s_last[k] == a.eos_id;
-                off += ended ? 1 : beam;
-                all_ended &= ended;
-            }
-        }
-        coff[ISC_BEAM_MAX] = off;
-    }
-    const int n = coff[ISC_BEAM_MAX];
-    if (tid < ncand * beam) {
-        const int k = tid / beam, j = tid - k * beam;
-        const int ended = a.t > 0 && s_last[k] == a.eos_id;
-        int ck = 0;
-#pragma unroll
-        for (int q = 0; q < ISC_BEAM_MAX; ++q) ck = (k == q) ? coff[q] : ck;
-        if (ended) {
-            if (j == 0) { cs[ck] = s_score[k]; ctok[ck] = s_last[k]; cpar[ck] = k; ccar[ck] = 1; }
-        } else {
-            const int c = ck + j;
-            const int id = ti[k][j];
-            cs[c] = s_score[k] + (double)tv[k][j];
-            ctok[c] = (unsigned)id < (unsigned)a.V ? id : 0;
-            cpar[c] = k; ccar[c] = 0;
-        }
-    }
-    __syncthreads();
-    if (wave == 0) {
-        // stable descending rank of candidate `lane` (< n <= 64): the scores sit one per lane, candidate j's is read from
-        // its lane (no memory inside the loop)
-        const double sc = cs[lane < n ? lane : 0];
-        const int sc_lo = __double2loint(sc), sc_hi = __double2hiint(sc);
-        int rank = 0;
-        for (int j = 0; j < n; ++j) {
-            const double o = __hiloint2double(__builtin_amdgcn_readlane(sc_hi, j), __builtin_amdgcn_readlane(sc_lo, j));
-            rank += (int)(o > sc) | ((int)(o == sc) & (int)(j < lane));
-        }
-        if (lane < n && rank < beam) {
-            const int par = cpar[tid], car = ccar[tid], dst = base + rank, len = s_len[par];
-            a.score_out[dst] = sc;
-            a.last_out[dst] = ctok[tid];
-            a.src_row[dst] = base + par;
-            a.len_out[dst] = len + (car ? 0 : 1);
-            w_par[rank] = par; w_car[rank] = car; w_len[rank] = len; w_tok[rank] = ctok[tid];
-        }
-    }
-    if (tid == 0) {
-        if (all_ended) a.done[i] = 1;
-        else atomicAdd(&a.live[a.t + 1], 1);
-    }
     RSTAMP(5);
-    // ---- word lists: element (rank r, position pos) = the parent's word, or the new token at the parent's length
-    {
-        long long *wl = reinterpret_cast<long long *>(sel_smem);
+    if (merger) {
+        if (wave < ncand) {
+            // stable descending rank of candidate c = ck + j: lanes 8 j .. 8 j + 7 each count an eighth of the others
+            const int ended = (endm >> wave) & 1u;
+            const int ck = wave * beam - (beam - 1) * __builtin_popcount(endm & ((1u << wave) - 1u));
+            const int j = lane >> 3, s_ = lane & 7, c = ck + j;
+            const bool mine_ok = j < (ended ? 1 : beam);
+            const double mine = cs[mine_ok ? c : 0];
+            int cnt = 0;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int e = tid + q * (int)blockDim.x;
-            if (e < beam * T) wl[e] = wv[q];
-        }
-        __syncthreads();
-        // the recurrent state follows the candidates: new row r continues its parent's (the step's output planes -> the
-        // next step's input planes; loads first, they are the long pole of this tail)
-        if (a.state_out) {                                   // (every wave waited for its DMAs before the barriers above)
-            const int rows_all = a.n_img * beam, nrow = n < beam ? n : beam, npair = a.state_planes * nrow;
-            const int nw = (int)blockDim.x >> 6;
-            for (int pr = wave; pr < npair; pr += nw) {
-                const int pl = pr / nrow, r = pr - pl * nrow;        // (wave-uniform)
-                const float *srow = st_lds + (pl * beam + w_par[r]) * a.H;
-                for (int c = lane * 4; c < a.H; c += 256)
-                    *reinterpret_cast<float4 *>(a.state_out + ((long long)pl * rows_all + base + r) * a.H + c) =
-                        *reinterpret_cast<const float4 *>(srow + c);
+            for (int u = 0; u < 8; ++u) {
+                const int it = s_ + 8 * u;
+                const double o = cs[it];                        // (it < 64: inside the array; counted only below n)
+                cnt += (it < n) & ((int)(o > mine) | ((int)(o == mine) & (int)(it < c)));
+            }
+            cnt += isc_dpp<ISC_DPP_XOR1>(cnt);
+            cnt += isc_dpp<ISC_DPP_XOR2>(cnt);
+            cnt += isc_dpp<ISC_DPP_HALF_MIRROR>(cnt);
+            if (s_ == 0 && mine_ok && cnt < beam) {
+                const int len = __builtin_amdgcn_readlane(my_len, wave);
+                const int dst = base + cnt;
+                const long long tok = ctk[c];
+                a.score_out[dst] = mine;
+                a.last_out[dst] = tok;
+                a.src_row[dst] = base + wave;
+                a.len_out[dst] = len + (ended ? 0 : 1);
+                w_par[cnt] = wave; w_car[cnt] = ended; w_len[cnt] = len; w_tok[cnt] = tok;
             }
         }
-        const int nfill = n < beam ? n : beam;               // (t == 0: one live parent still yields `beam` rows)
-        for (int e = tid; e < nfill * T; e += blockDim.x) {
-            const int r = e / T, pos = e - r * T;
-            const long long w = (!w_car[r] && pos == w_len[r]) ? w_tok[r] : wl[w_par[r] * T + pos];
-            a.words_out[(long long)(base + r) * T + pos] = w;
+        if (tid == 0) {
+            const unsigned all = (1u << ncand) - 1u;
+            if ((endm & all) == all) a.done[i] = 1;
+            else atomicAdd(&a.live[a.t + 1], 1);
         }
     }
+    __syncthreads();
     RSTAMP(6);
+    const int nrow = n < beam ? n : beam;                        // (t == 0: one live parent still yields `beam` rows)
+    if (wrow >= nrow) return;
+    const int par = w_par[wrow];
+    if (merger) {
+        // ---- new row `wave`'s word list: its parent's, with the new token at the parent's length
+        const long long *wl = reinterpret_cast<const long long *>(sel_smem);
+        const int car = w_car[wrow], len = w_len[wrow];
+        const long long tok = w_tok[wrow];
+        for (int pos = lane; pos < T; pos += 64)
+            a.words_out[(long long)row * T + pos] = (!car && pos == len) ? tok : wl[par * T + pos];
+    } else if (a.state_out) {
+        // ---- the recurrent state follows the candidates: new row r continues its parent's
+        for (int pl = 0; pl < a.state_planes; ++pl)
+            for (int c = lane * 4; c < a.H; c += 256)
+                *reinterpret_cast<float4 *>(a.state_out + ((long long)pl * rows_all + row) * a.H + c) =
+                    *reinterpret_cast<const float4 *>(st_lds + (pl * beam + par) * a.H + c);
+    }
+    RSTAMP(7);
 }
 #undef SEL_POP
 
@@ -1170,7 +1151,8 @@ extern "C" int isc_beam_select(const isc_beam_select_args *args, void *stream) {
         if (e != hipSuccess) return (int)e;
         attr_set.store(true);
     }
-    hipLaunchKernelGGL(beam_select_kernel, dim3(a.n_img), dim3(64 * a.beam), lds, (hipStream_t)stream, a);
+    // one merge wave per beam row (+ one state wave per beam row when the recurrent state is re-ordered here)
+    hipLaunchKernelGGL(beam_select_kernel, dim3(a.n_img), dim3(64 * a.beam * (a.state_out ? 2 : 1)), lds, (hipStream_t)stream, a);
     ISC_LAUNCH_CHECK();
     return ISC_OK;
 }

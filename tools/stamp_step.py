@@ -16,7 +16,7 @@ SLOTS = {0: ['start', 'pre-B0', 'issued/DMA', 'staged(B1)', 'partials', 'after B
          3: ['start', 'pre-B0', 'issued/DMA', 'staged(B1)', 'partials', 'after B2', 'end'],
          2: ['start', 'loads issued', 'scores', 'after B', 'sums', 'combined', 'end'],
          4: ['start', 'B1', 'all issued', 'partials', 'after B2', '-', 'end'],
-         5: ['start', 'loads issued', 'normaliser', '-', 'merged', 'bookkeeping', 'end']}
+         5: ['start', 'loads issued', 'normaliser', 'merged', 'candidates', 'after barrier 1', 'after barrier 2', 'end']}
 
 
 def main():
@@ -54,6 +54,11 @@ def main():
             v = r[..., s][r[..., s] > 0] - t0
             if v.size:
                 print('   %-14s median %6d  max %6d  (n=%d)' % (nm, np.median(v), v.max(), v.size))
+        if kid == 5:
+            continue
+        c = r[..., 7][r[..., 7] > 0]
+        if c.size:
+            print('   shader cycles between CLK0 and CLK1: median %d  max %d' % (np.median(c), c.max()))
 
 
 if __name__ == '__main__':
