@@ -823,22 +823,20 @@ extern "C" int isc_beam_topk(const float *logits, int64_t ld_logits, const float
 // ------------------------------------------------------------------ beam step tail in one launch
 // isc_beam_select: what isc_beam_topk + isc_beam_merge + isc_beam_gather do in three launches, from the tile
 // statistics and per-tile sorted candidate lists the few-row classifier (rows.hip) leaves.  One workgroup per image.  A
-// lone wave retires an instruction every ~8 cycles here, so the launch is as long as the LONGEST dependent instruction
-// chain of any wave: the work is cut so that no wave carries more than its share.
-//   merge waves (one per beam row):
-//   1. every global operand requested in the first instructions: the two block-uniform switches (search ended / image
-//      frozen), the row's tile candidates (value, id) [n_tile][8] - a lane owns tiles lane, lane + 64, ... and holds their
-//      lists in registers -, the tile statistics, the parents' bookkeeping (lanes 0..7 of every wave hold parents 0..7: no
-//      staging, no barrier), the row's word list;
-//   2. the row's normaliser from (pmax, psum) - fold_row_stats, as every decode path;
-//   3. a `beam`-round k-way merge over the tiles' list heads: ONE 32-bit DPP maximum per round, ties by ballots and scalar
-//      bit scans (value descending, then tile ascending = word id ascending: tiles are column ranges, lists are sorted),
-//      the winning lane's list moves up one place; round k's winner stays in lane k's registers;
-//   4. parent k's candidates scored in fp64 by lanes 0..beam-1 of wave k (captioner.py:378-411, beam_merge_kernel's
-//      rules) -> LDS, barrier, stable descending rank with EIGHT lanes per candidate (each counts an eighth of the
-//      others), ranks < beam write the new rows' bookkeeping, barrier, wave r writes new row r's word list;
-//   state waves (one per beam row, only when the recurrent state is re-ordered here): row r's planes -> LDS by LDS-DMA
-//   while the merges run, then - winners known - new row r's planes from its parent's LDS image.
+// lone wave retires an instruction every ~6-8 cycles here (and a launch that returns at once already takes 4.6 us:
+// tools/select_lab.py), so the launch is as long as the LONGEST dependent instruction chain of any wave.  The chain is
+// merge -> scores -> rank -> new rows; everything that is not on it runs beside it on waves of its own:
+//   merge wave r (one per beam row): the row's tile candidates (value, id) [n_tile][8] - a lane owns tiles lane,
+//     lane + 64, ... and holds their lists in registers - and a `beam`-round k-way merge over the lists' heads: ONE 32-bit
+//     DPP maximum per round, ties by ballots and scalar bit scans (value descending, then tile ascending = word id
+//     ascending: tiles are column ranges, lists are sorted), the winner's list moves up one place, round k's winner
+//     stays in lane k's registers;  barrier;  parent r's candidates scored in fp64 by lanes 0..beam-1 (captioner.py:
+//     378-411, beam_merge_kernel's rules: the parents' bookkeeping sits in lanes 0..7 of every wave, no staging) -> LDS;
+//     barrier;  stable descending rank with EIGHT lanes per candidate (each counts an eighth of the others), ranks
+//     < beam write the new rows' bookkeeping;  barrier;  new row r's word list;
+//   side wave r (one per beam row): row r's normaliser from (pmax, psum) - fold_row_stats, as every decode path - and its
+//     word list -> LDS, row r's planes of the recurrent state -> LDS by LDS-DMA (when the state is re-ordered here), all
+//     while the merges run; winners known: new row r's planes from its parent's LDS image.
 // Word ids, log-probs ((x - max) - log(sum), the expression of beam_topk8_kernel) and tie order are those of the
 // three-launch path on the same logits and statistics.
 #define ISC_SEL_TILES_PER_LANE 4
@@ -873,38 +871,29 @@ __device__ __forceinline__ float sel_wave_sum(float v) {                // == ha
     const float r2 = __int_as_float(__builtin_amdgcn_readlane(b, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(b, 48));
     return (r0 + r1) + (r2 + r3);
 }
-// The winner's list (tile index Q of its lane: wave-uniform, so each of the four copies of this runs under a scalar
-// branch) moves up one place in its lane - static register indices, position 0 is always the head.  A search pops at most
-// `beam` <= 8 entries and a list holds 8, so no list runs dry before the last round; positions past the fifth are only
-// ever heads for beam > 5.
-#define SEL_POP(Q)                                                                          \
-    do {                                                                                    \
-        wid = __builtin_amdgcn_readlane(cid[Q][0], wl);                                     \
-        const bool me_ = lane == wl;                                                        \
-        _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) {                                  \
-            cvv[Q][s_] = me_ ? cvv[Q][s_ + 1] : cvv[Q][s_];                                 \
-            cid[Q][s_] = me_ ? cid[Q][s_ + 1] : cid[Q][s_];                                 \
-        }                                                                                   \
-        if (beam > 5) {                                                                     \
-            _Pragma("unroll") for (int s_ = 4; s_ < 7; ++s_) {                              \
-                cvv[Q][s_] = me_ ? cvv[Q][s_ + 1] : cvv[Q][s_];                             \
-                cid[Q][s_] = me_ ? cid[Q][s_ + 1] : cid[Q][s_];                             \
-            }                                                                               \
-            cvv[Q][7] = me_ ? -INFINITY : cvv[Q][7];                                        \
-        }                                                                                   \
-    } while (0)
+// The winner's list (list Q of lane wl, both wave-uniform) moves up one place in its lane - static register indices,
+// position 0 is always the head.  Branch-free: each list shifts under its own lane mask (empty for the three lists that did
+// not win) - four copies under scalar branches cost more in the register copies that rejoin them than the idle selects do.
+// A search pops at most `beam` <= 8 entries and a list holds 8, so no list runs dry before the last round; positions past
+// the fifth are only ever heads for beam > 5.
+#define SEL_SHIFT(Q, LO, HI)                                                                \
+    _Pragma("unroll") for (int s_ = LO; s_ < HI; ++s_) {                                    \
+        cvv[Q][s_] = me##Q ? cvv[Q][s_ + 1] : cvv[Q][s_];                                   \
+        cid[Q][s_] = me##Q ? cid[Q][s_ + 1] : cid[Q][s_];                                   \
+    }
 
 __global__ __launch_bounds__(1024) void beam_select_kernel(const isc_beam_select_args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sel_smem[];
     __shared__ double cs[64];                          // the image's candidates (<= beam x beam): score,
     __shared__ long long ctk[64];                      //   token
+    __shared__ float nrm[ISC_BEAM_MAX][2];             // per row: max, log(sum)
     __shared__ int w_par[ISC_BEAM_MAX], w_car[ISC_BEAM_MAX], w_len[ISC_BEAM_MAX];     // winners by rank
     __shared__ long long w_tok[ISC_BEAM_MAX];
     rows_kernarg_warm<ROWS_KERNARG_LINES(isc_beam_select_args)>();
     const int i = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int beam = a.beam, T = a.T, base = i * beam, n_tile = a.n_tile;
-    const bool merger = wave < beam;                  // (wave-uniform) else: a state wave
+    const bool merger = wave < beam;                  // (wave-uniform) else: a side wave
     const int wrow = merger ? wave : wave - beam;     // the beam row this wave serves
     RSTAMP(0);
     // ---- the two block-uniform switches first (their round trip runs under everything requested behind them; without
@@ -920,56 +909,68 @@ __global__ __launch_bounds__(1024) void beam_select_kernel(const isc_beam_select
     int cid[ISC_SEL_TILES_PER_LANE][8];
     float pm[ISC_SEL_TILES_PER_LANE], ps[ISC_SEL_TILES_PER_LANE];
     long long wv[4];                                  // the row's word list, positions lane, lane + 64, ..
+    long long *wl = reinterpret_cast<long long *>(sel_smem);                                              // [row][T]
     float *st_lds = reinterpret_cast<float *>(sel_smem + (((size_t)beam * T * 8 + 15) & ~(size_t)15));   // [plane][row][H]
     const int rows_all = a.n_img * beam;
+    // parents' bookkeeping: lane l of EVERY wave holds parent min(l & 7, beam - 1)
+    const int pk = (lane & 7) < beam ? (lane & 7) : beam - 1;
+    double my_score = 0.0;
+    int my_len = 0;
     if (merger) {
+        const float *cvp = a.cand_val + (long long)row * n_tile * 8;        // (wave-uniform bases, 32-bit lane offsets)
+        const int *cip = a.cand_idx + (long long)row * n_tile * 8;
 #pragma unroll
         for (int q = 0; q < ISC_SEL_TILES_PER_LANE; ++q) {
-            const int tl = lane + 64 * q, tc = tl < n_tile ? tl : n_tile - 1;
-            const float4 *gv = reinterpret_cast<const float4 *>(a.cand_val + ((long long)row * n_tile + tc) * 8);
-            const int4 *gi = reinterpret_cast<const int4 *>(a.cand_idx + ((long long)row * n_tile + tc) * 8);
+            const unsigned tl = lane + 64 * q, tc = tl < (unsigned)n_tile ? tl : (unsigned)n_tile - 1u;
+            const float4 *gv = reinterpret_cast<const float4 *>(cvp + tc * 8u);
+            const int4 *gi = reinterpret_cast<const int4 *>(cip + tc * 8u);
             const float4 v0 = gv[0], v1 = gv[1];
             const int4 i0 = gi[0], i1 = gi[1];
             cvv[q][0] = v0.x; cvv[q][1] = v0.y; cvv[q][2] = v0.z; cvv[q][3] = v0.w;
             cvv[q][4] = v1.x; cvv[q][5] = v1.y; cvv[q][6] = v1.z; cvv[q][7] = v1.w;
             cid[q][0] = i0.x; cid[q][1] = i0.y; cid[q][2] = i0.z; cid[q][3] = i0.w;
             cid[q][4] = i1.x; cid[q][5] = i1.y; cid[q][6] = i1.z; cid[q][7] = i1.w;
-            pm[q] = a.part_max[(long long)row * n_tile + tc];
-            ps[q] = a.part_sum[(long long)row * n_tile + tc];
         }
-    }
-    // parents' bookkeeping: lane l of EVERY wave holds parent min(l & 7, beam - 1)
-    const int pk = (lane & 7) < beam ? (lane & 7) : beam - 1;
-    const long long my_last = a.last_in[base + pk];
-    double my_score = 0.0;
-    int my_len = 0;
-    if (merger) {
         my_score = a.score_in[base + pk];
         my_len = a.len_in[base + pk];
+    }
+    const long long my_last = a.last_in[base + pk];
+    if (!merger) {
+        const float *pmp = a.part_max + (long long)row * n_tile, *psp = a.part_sum + (long long)row * n_tile;
+#pragma unroll
+        for (int q = 0; q < ISC_SEL_TILES_PER_LANE; ++q) {
+            const unsigned tl = lane + 64 * q, tc = tl < (unsigned)n_tile ? tl : (unsigned)n_tile - 1u;
+            pm[q] = pmp[tc];
+            ps[q] = psp[tc];
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int pos = lane + 64 * q;
             wv[q] = a.words_in[(long long)row * T + (pos < T ? pos : T - 1)];
         }
-    } else if (a.state_out) {
-        // state wave: this row's planes -> LDS image [plane][row][H], on their way while the merges run
-        const unsigned lds0 = (unsigned)(size_t)st_lds;
-        for (int pl = 0; pl < a.state_planes; ++pl) {
-            const float *srow = a.state_in + ((long long)pl * rows_all + row) * a.H;
-            const int pr = pl * beam + wrow;
-            if ((a.H & 255) == 0) {
-                for (int c0 = 0; c0 < a.H; c0 += 256) {     // one 1 KB LDS-DMA per 256 floats
-                    const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(pr * a.H + c0) * 4u);
-                    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(dst), "v"(srow + c0 + lane * 4) : "memory");
+        if (a.state_out) {
+            // this row's planes -> LDS image [plane][row][H], on their way while the merges run
+            const unsigned lds0 = (unsigned)(size_t)st_lds;
+            for (int pl = 0; pl < a.state_planes; ++pl) {
+                const float *srow = a.state_in + ((long long)pl * rows_all + row) * a.H;
+                const int pr = pl * beam + wrow;
+                if ((a.H & 255) == 0) {
+                    for (int c0 = 0; c0 < a.H; c0 += 256) {     // one 1 KB LDS-DMA per 256 floats
+                        const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(pr * a.H + c0) * 4u);
+                        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(dst), "v"(srow + c0 + lane * 4) : "memory");
+                    }
+                } else {                                        // small / odd widths: through registers
+                    for (int c = lane * 4; c < a.H; c += 256)
+                        *reinterpret_cast<float4 *>(st_lds + pr * a.H + c) = *reinterpret_cast<const float4 *>(srow + c);
                 }
-            } else {                                        // small / odd widths: through registers
-                for (int c = lane * 4; c < a.H; c += 256)
-                    *reinterpret_cast<float4 *>(st_lds + pr * a.H + c) = *reinterpret_cast<const float4 *>(srow + c);
             }
         }
     }
     RSTAMP(1);
-    if (__builtin_amdgcn_readfirstlane(go_v) == 0) return;       // the search has ended (block-uniform)
+    if (__builtin_amdgcn_readfirstlane(go_v) == 0) {             // the search has ended (block-uniform)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // (no LDS-DMA may land after the workgroup has gone)
+        return;
+    }
     if (__builtin_amdgcn_readfirstlane(done_v)) {                // frozen image: everything carried over unchanged (block-uniform)
         if (merger) {
             if (wave == 0 && lane < beam) {
@@ -978,17 +979,18 @@ __global__ __launch_bounds__(1024) void beam_select_kernel(const isc_beam_select
                 a.score_out[base + lane] = my_score;
                 a.len_out[base + lane] = my_len;
             }
+        } else {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int pos = lane + 64 * q;
                 if (pos < T) a.words_out[(long long)row * T + pos] = wv[q];
             }
-        } else if (a.state_out) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (a wave reads back only what it fetched itself)
-            for (int pl = 0; pl < a.state_planes; ++pl)
-                for (int c = lane * 4; c < a.H; c += 256)
-                    *reinterpret_cast<float4 *>(a.state_out + ((long long)pl * rows_all + row) * a.H + c) =
-                        *reinterpret_cast<const float4 *>(st_lds + (pl * beam + wrow) * a.H + c);
+            if (a.state_out)
+                for (int pl = 0; pl < a.state_planes; ++pl)
+                    for (int c = lane * 4; c < a.H; c += 256)
+                        *reinterpret_cast<float4 *>(a.state_out + ((long long)pl * rows_all + row) * a.H + c) =
+                            *reinterpret_cast<const float4 *>(st_lds + (pl * beam + wrow) * a.H + c);
         }
         return;
     }
@@ -996,47 +998,71 @@ __global__ __launch_bounds__(1024) void beam_select_kernel(const isc_beam_select
     const int ncand = a.t == 0 ? 1 : beam;
     const unsigned endm = a.t > 0 ? (unsigned)__ballot(my_last == a.eos_id) & ((1u << beam) - 1u) : 0u;
     const int n = ncand * beam - (beam - 1) * __builtin_popcount(endm & ((1u << ncand) - 1u));
-    float myv = -INFINITY;                // lane k < beam of a merge wave: the row's k-th best (log-prob, word id)
+    const int nrow = n < beam ? n : beam;             // (t == 0: one live parent still yields `beam` rows)
+    float myraw = -INFINITY;              // lane k < beam of a merge wave: the row's k-th best (raw logit, word id)
     int myid = 0;
     if (merger) {
 #pragma unroll
         for (int q = 0; q < ISC_SEL_TILES_PER_LANE; ++q)
             if (lane + 64 * q >= n_tile) {
-                pm[q] = -INFINITY; ps[q] = 0.f;
 #pragma unroll
                 for (int s_ = 0; s_ < 8; ++s_) cvv[q][s_] = -INFINITY;
             }
-        // ---- the row's normaliser: max over the tile maxima, sum of the rescaled tile sums
-        const float gmax = sel_wave_fmax(fmaxf(fmaxf(pm[0], pm[1]), fmaxf(pm[2], pm[3])));
-        float ssum = 0.f;
-#pragma unroll
-        for (int q = 0; q < ISC_SEL_TILES_PER_LANE; ++q) ssum += ps[q] * expf(pm[q] - gmax);
-        ssum = sel_wave_sum(ssum);
-        if (lane == 0 && !(fabsf(gmax) <= 3.0e38f && ssum <= 3.0e38f)) isc_flag_pw(ISC_STATUS_WORD_STATS);     // NaN fails both
-        const float logS = logf(ssum);
-        RSTAMP(2);
         // ---- k-way merge over the tiles' list heads: per round ONE 32-bit wave maximum of the lanes' best heads; ties
         // (equal values) go to the smaller word id = the smaller tile index = the first q with a lane at the maximum, then
         // its lowest lane - four ballots and scalar bit scans, no 64-bit keys in the lanes
         unsigned long long own[ISC_SEL_TILES_PER_LANE];         // lanes whose tile q exists (wave-uniform)
 #pragma unroll
         for (int q = 0; q < ISC_SEL_TILES_PER_LANE; ++q) own[q] = __ballot(lane + 64 * q < n_tile);
+        RSTAMP(2);
         for (int k = 0; k < beam; ++k) {
             const float mx = sel_wave_fmax(fmaxf(fmaxf(cvv[0][0], cvv[1][0]), fmaxf(cvv[2][0], cvv[3][0])));
             const unsigned long long h0 = __ballot(cvv[0][0] == mx) & own[0], h1 = __ballot(cvv[1][0] == mx) & own[1];
             const unsigned long long h2 = __ballot(cvv[2][0] == mx) & own[2], h3 = __ballot(cvv[3][0] == mx) & own[3];
-            const bool have = (h0 | h1 | h2 | h3) != 0;         // (false: a NaN maximum)
-            int wid = 0;
-            if (have) {
-                const int wq = h0 ? 0 : h1 ? 1 : h2 ? 2 : 3;
-                const int wl = __builtin_ctzll(h0 ? h0 : h1 ? h1 : h2 ? h2 : h3);
-                if (wq == 0) SEL_POP(0); else if (wq == 1) SEL_POP(1); else if (wq == 2) SEL_POP(2); else SEL_POP(3);
+            // the winning list as four lane masks, three of them empty (all empty: a NaN maximum - nothing moves)
+            const unsigned long long f0 = h0, f1 = h0 ? 0 : h1, f2 = (h0 | h1) ? 0 : h2, f3 = (h0 | h1 | h2) ? 0 : h3;
+            const unsigned long long fa = f0 | f1 | f2 | f3;
+            const int wl = fa ? __builtin_ctzll(fa) : 0;        // its lowest lane
+            const bool mel = lane == wl;
+            const bool me0 = mel & (f0 != 0), me1 = mel & (f1 != 0), me2 = mel & (f2 != 0), me3 = mel & (f3 != 0);
+            const int hidv = me0 ? cid[0][0] : me1 ? cid[1][0] : me2 ? cid[2][0] : cid[3][0];
+            const int wid = fa ? __builtin_amdgcn_readlane(hidv, wl) : 0;
+            SEL_SHIFT(0, 0, 4) SEL_SHIFT(1, 0, 4) SEL_SHIFT(2, 0, 4) SEL_SHIFT(3, 0, 4)
+            if (beam > 5) {
+                SEL_SHIFT(0, 4, 7) SEL_SHIFT(1, 4, 7) SEL_SHIFT(2, 4, 7) SEL_SHIFT(3, 4, 7)
+                cvv[0][7] = me0 ? -INFINITY : cvv[0][7]; cvv[1][7] = me1 ? -INFINITY : cvv[1][7];
+                cvv[2][7] = me2 ? -INFINITY : cvv[2][7]; cvv[3][7] = me3 ? -INFINITY : cvv[3][7];
             }
-            const float lp = have ? (mx - gmax) - logS : -INFINITY;
-            myv = lane == k ? lp : myv;
+            myraw = lane == k ? (fa ? mx : -INFINITY) : myraw;
             myid = lane == k ? wid : myid;
         }
         RSTAMP(3);
+    } else {
+        // ---- side wave: the row's normaliser - max over the tile maxima, sum of the rescaled tile sums - and its word
+        // list -> LDS
+#pragma unroll
+        for (int q = 0; q < ISC_SEL_TILES_PER_LANE; ++q)
+            if (lane + 64 * q >= n_tile) { pm[q] = -INFINITY; ps[q] = 0.f; }
+        const float gmax = sel_wave_fmax(fmaxf(fmaxf(pm[0], pm[1]), fmaxf(pm[2], pm[3])));
+        float ssum = 0.f;
+#pragma unroll
+        for (int q = 0; q < ISC_SEL_TILES_PER_LANE; ++q) ssum += ps[q] * expf(pm[q] - gmax);
+        ssum = sel_wave_sum(ssum);
+        if (lane == 0) {
+            if (!(fabsf(gmax) <= 3.0e38f && ssum <= 3.0e38f)) isc_flag_pw(ISC_STATUS_WORD_STATS);     // NaN fails both
+            nrm[wrow][0] = gmax;
+            nrm[wrow][1] = logf(ssum);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int pos = lane + 64 * q;
+            if (pos < T) wl[wrow * T + pos] = wv[q];
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's share of the state image has landed
+    }
+    __syncthreads();                                              // normalisers, word lists, state image
+    if (merger) {
+        const float myv = (myraw - nrm[wave][0]) - nrm[wave][1];  // (-inf stays -inf)
         if (a.top_val && lane < beam) {
             a.top_val[(long long)row * beam + lane] = myv;
             a.top_idx[(long long)row * beam + lane] = (unsigned)myid < (unsigned)a.V ? myid : 0;
@@ -1053,20 +1079,9 @@ __global__ __launch_bounds__(1024) void beam_select_kernel(const isc_beam_select
                 ctk[ck + lane] = ended ? a.eos_id : (long long)((unsigned)myid < (unsigned)a.V ? myid : 0);
             }
         }
-        // the parents' word lists -> LDS (read back by whichever new row continues them)
-        {
-            long long *wl = reinterpret_cast<long long *>(sel_smem);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int pos = lane + 64 * q;
-                if (pos < T) wl[wave * T + pos] = wv[q];
-            }
-        }
-    } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's share of the state image has landed
     }
     RSTAMP(4);
-    __syncthreads();
+    __syncthreads();                                              // candidates
     RSTAMP(5);
     if (merger) {
         if (wave < ncand) {
@@ -1090,11 +1105,11 @@ __global__ __launch_bounds__(1024) void beam_select_kernel(const isc_beam_select
                 const int len = __builtin_amdgcn_readlane(my_len, wave);
                 const int dst = base + cnt;
                 const long long tok = ctk[c];
+                w_par[cnt] = wave; w_car[cnt] = ended; w_len[cnt] = len; w_tok[cnt] = tok;
                 a.score_out[dst] = mine;
                 a.last_out[dst] = tok;
                 a.src_row[dst] = base + wave;
                 a.len_out[dst] = len + (ended ? 0 : 1);
-                w_par[cnt] = wave; w_car[cnt] = ended; w_len[cnt] = len; w_tok[cnt] = tok;
             }
         }
         if (tid == 0) {
@@ -1103,14 +1118,12 @@ __global__ __launch_bounds__(1024) void beam_select_kernel(const isc_beam_select
             else atomicAdd(&a.live[a.t + 1], 1);
         }
     }
-    __syncthreads();
+    __syncthreads();                                              // winners
     RSTAMP(6);
-    const int nrow = n < beam ? n : beam;                        // (t == 0: one live parent still yields `beam` rows)
     if (wrow >= nrow) return;
     const int par = w_par[wrow];
     if (merger) {
         // ---- new row `wave`'s word list: its parent's, with the new token at the parent's length
-        const long long *wl = reinterpret_cast<const long long *>(sel_smem);
         const int car = w_car[wrow], len = w_len[wrow];
         const long long tok = w_tok[wrow];
         for (int pos = lane; pos < T; pos += 64)
@@ -1124,7 +1137,7 @@ __global__ __launch_bounds__(1024) void beam_select_kernel(const isc_beam_select
     }
     RSTAMP(7);
 }
-#undef SEL_POP
+#undef SEL_SHIFT
 
 extern "C" int isc_beam_select(const isc_beam_select_args *args, void *stream) {
     if (!args) return ISC_E_NULL;
@@ -1151,8 +1164,8 @@ extern "C" int isc_beam_select(const isc_beam_select_args *args, void *stream) {
         if (e != hipSuccess) return (int)e;
         attr_set.store(true);
     }
-    // one merge wave per beam row (+ one state wave per beam row when the recurrent state is re-ordered here)
-    hipLaunchKernelGGL(beam_select_kernel, dim3(a.n_img), dim3(64 * a.beam * (a.state_out ? 2 : 1)), lds, (hipStream_t)stream, a);
+    // one merge wave + one side wave per beam row
+    hipLaunchKernelGGL(beam_select_kernel, dim3(a.n_img), dim3(128 * a.beam), lds, (hipStream_t)stream, a);
     ISC_LAUNCH_CHECK();
     return ISC_OK;
 }

@@ -16,7 +16,7 @@ SLOTS = {0: ['start', 'pre-B0', 'issued/DMA', 'staged(B1)', 'partials', 'after B
          3: ['start', 'pre-B0', 'issued/DMA', 'staged(B1)', 'partials', 'after B2', 'end'],
          2: ['start', 'loads issued', 'scores', 'after B', 'sums', 'combined', 'end'],
          4: ['start', 'B1', 'all issued', 'partials', 'after B2', '-', 'end'],
-         5: ['start', 'loads issued', 'normaliser', 'merged', 'candidates', 'after barrier 1', 'after barrier 2', 'end']}
+         5: ['start', 'loads issued', 'rounds start', 'merged', 'scored', 'after barrier 2', 'after barrier 3', 'end']}
 
 
 def main():
