@@ -232,7 +232,11 @@ def test_select_equals_topk_then_merge():
 
 @pytest.mark.parametrize('V,st,n_img,beam,R', [(10000, synth.DEFAULT_SETTINGS, 1, 5, 36), (10000, synth.DEFAULT_SETTINGS, 1, 3, 36),
                                                (10000, synth.DEFAULT_SETTINGS, 2, 4, 36), (10000, synth.DEFAULT_SETTINGS, 1, 5, 196),
-                                               (256, synth.TINY_SETTINGS, 1, 5, 12), (64, synth.TINY_SETTINGS, 2, 3, 5)])
+                                               (256, synth.TINY_SETTINGS, 1, 5, 12), (64, synth.TINY_SETTINGS, 2, 3, 5),
+                                               # (beam 6 .. 8: the select's lists move up past their fifth place; 1, 2: its smallest workgroups)
+                                               (10000, synth.DEFAULT_SETTINGS, 1, 8, 36), (10000, synth.DEFAULT_SETTINGS, 1, 6, 36),
+                                               (256, synth.TINY_SETTINGS, 1, 7, 12), (256, synth.TINY_SETTINGS, 1, 1, 12),
+                                               (256, synth.TINY_SETTINGS, 4, 2, 12)])
 def test_beam_search_on_this_path_equals_the_general_path(V, st, n_img, beam, R):
     cap = _captioner(V, st, seed=2)
     cap.enable_beam_graphs(False)
