@@ -225,9 +225,14 @@ def _backward(cap, S, dlogp, d_fc_feats, d_cpt_feats, sparse=()):
     # ---- classifier + log-softmax: outside the recurrence, all T*B rows at once (time-major rows)
     Vp = _pad32(V)
     dlogits = new(TB, Vp)
+    # everything the sweep wants zeroed comes out of ONE fill (each fill is a launch of its own, ~4.5 us at any size)
+    n_lab = p['senti_label_embed.0.weight'].shape[0] if P.label_e is not None else 1
+    f32 = torch.float32
+    gs_z, dG1_sum, zero_a, zero_b, dL_z, dEmb = cap._zeros_many(((4,), f32), ((B, 4 * H), f32), ((1,), f32), ((1,), f32),
+                                                                ((n_lab, Wd), f32), ((V, Wd), f32))
     gs = None
     if getattr(cap, 'grad_scaling', True):
-        gs = zeros(4)
+        gs = gs_z
         srcs = [c for _, c in sparse] + [d_fc_feats.contiguous() if d_fc_feats is not None else None,
                                          d_cpt_feats.contiguous() if d_cpt_feats is not None else None]
         if dlogp is not None:
@@ -288,7 +293,6 @@ def _backward(cap, S, dlogp, d_fc_feats, d_cpt_feats, sparse=()):
     Wih1, Whh1 = p['att_lstm.weight_ih'], p['att_lstm.weight_hh']
     Wih2, Whh2 = p['lang_lstm.weight_ih'], p['lang_lstm.weight_hh']
     dG1, dG2 = new(T, B, 4 * H), new(T, B, 4 * H)
-    dG1_sum = zeros(B, 4 * H)
     # d feat of every step is kept ([T,B,E]): where it is the scan's output gradient, dV = sum_t alpha_t x dout_t is
     # formed once after the sweep (ops.attn_dv_from_alpha) instead of a read-modify-write of [B,R,E] at every step
     d_feat_all, dh1 = new(T, B, E), new(B, H)
@@ -405,22 +409,21 @@ def _backward(cap, S, dlogp, d_fc_feats, d_cpt_feats, sparse=()):
     with _weights_scope(cap):      # dX over all T*B rows: split-f16 on planes of the W_ih slices' transposes
         ops.gemm_bwd(probs, NN)
     emb = p['word_embed.0.weight']
-    dEmb = zeros(V, Wd)
-    ops.embed_relu_bwd(emb, S.tok.view(-1), dxt, dEmb, TB, skip_id=cap.pad_id)    # the <PAD> row is zeroed below
+    # nn.Embedding(padding_idx=pad_id): the <PAD> row never gets a gradient - every accumulation into dEmb skips it
+    ops.embed_relu_bwd(emb, S.tok.view(-1), dxt, dEmb, TB, skip_id=cap.pad_id)
 
-    zero1 = lambda: zeros(1)
     if has_c:
         dqaf = dqa.view(TB, A)
         G['attention.cont_att.h2att.weight'] = tn(dqaf, h1_cur)
         G['attention.cont_att.h2att.bias'] = csum(dqaf)
         G['attention.cont_att.att_alpha.weight'] = csum(dwc_rows).view(1, A)
-        G['attention.cont_att.att_alpha.bias'] = zero1()       # softmax is shift invariant
+        G['attention.cont_att.att_alpha.bias'] = zero_a        # softmax is shift invariant
     if has_s:
         dqwf = dqw.view(TB, A)
         G['attention.senti_att.h2word.weight'] = tn(dqwf, h1_cur)
         G['attention.senti_att.h2word.bias'] = csum(dqwf)
         G['attention.senti_att.word_alpha.weight'] = csum(dws_rows).view(1, A)
-        G['attention.senti_att.word_alpha.bias'] = zero1()
+        G['attention.senti_att.word_alpha.bias'] = zero_b
         # label2word(label_e) enters every step's score: d label_w = sum_t dqw[t]
         d_label_w = new(B * A)
         ops.colsum(dqw.view(T, B * A), d_label_w)
@@ -439,7 +442,7 @@ def _backward(cap, S, dlogp, d_fc_feats, d_cpt_feats, sparse=()):
 
     # ---- prologue backward
     if d_label_e is not None:
-        dL = zeros(p['senti_label_embed.0.weight'].shape[0], Wd)
+        dL = dL_z
         ops.embed_relu_bwd(p['senti_label_embed.0.weight'], P.label_ids, d_label_e, dL, B,
                            keep_mask=P.m_label, mask_scale=P.sc)
         G['senti_label_embed.0.weight'] = dL
@@ -496,7 +499,6 @@ def _backward(cap, S, dlogp, d_fc_feats, d_cpt_feats, sparse=()):
         C = P.cpt_ids.shape[1]
         ops.embed_relu_bwd(emb, P.cpt_ids.view(-1), dcm, dEmb, B * C, rows_per_grad=C, scale=1.0 / C,
                            skip_id=cap.pad_id)
-    dEmb[cap.pad_id].zero_()     # nn.Embedding(padding_idx=pad_id): the <PAD> row never gets a gradient
     G['word_embed.0.weight'] = dEmb
     ops.colsum_multi(pending_sums)
     if gs is not None:           # undo the gradient scale: x 1/S, a power of two

@@ -281,9 +281,16 @@ def _pair_backward(cap, S, d1, d2, sparse1, sparse2, d_fc_feats1, d_cpt_feats1, 
             G[name] = zeros(1)          # (under a sink the arena was zeroed before the backward)
 
     # ---- gradient scale (autograd._backward): one power of two for everything that enters the sweep
+    # the sweep's zeroed buffers out of ONE fill (each fill is a launch of its own, ~4.5 us at any size): the gradient
+    # scale's words, running sums and recurrent gradients (the sweep always accumulates), per-row partials of the alpha
+    # weights, the h-projection gradients of each branch padded to all rows
+    Bp = (Bt + 31) // 32 * 32
+    f32 = torch.float32
+    gs_z, dG1_sum_p, rec, dq2, dw_rows = cap._zeros_many(((4,), f32), ((Bp, 4 * H), f32), ((7, Bt, H), f32),
+                                                         ((2, T, Bt, A), f32), ((Bt, A), f32))
     gs = None
     if getattr(cap, 'grad_scaling', True):
-        gs = zeros(4)
+        gs = gs_z
         srcs = [c for _, c in list(sparse1) + list(sparse2)]
         srcs += [x.contiguous() for x in (d_fc_feats1, d_cpt_feats1, d_cpt_feats2) if x is not None]
         dense = [d.abs().amax().reshape(1) for d in (d1, d2) if d is not None]
@@ -364,13 +371,9 @@ def _pair_backward(cap, S, d1, d2, sparse1, sparse2, d_fc_feats1, d_cpt_feats1, 
     # and the h-projection gradients of each branch padded to all rows (their dW contractions run over all T*Bt rows)
     # (rows padded to a multiple of 32 with zeros: its two dW contractions - over the B1 + B2 rows, e.g. 208 - then run on
     # the split-f16 kernels, whose contraction length is a multiple of 32; 190 us on the fp32 tiles otherwise)
-    Bp = (Bt + 31) // 32 * 32
-    dG1_sum_p = zeros(Bp, 4 * H)
     dG1_sum = dG1_sum_p[:Bt]
-    rec = zeros(7, Bt, H)
     dh1 = rec[6]
-    dqa, dqw = zeros(2, T, Bt, A).unbind(0)
-    dw_rows = zeros(Bt, A)
+    dqa, dqw = dq2.unbind(0)
     dwc_rows, dws_rows = dw_rows[:B1], dw_rows[B1:]
     de_c, de_s = new(T1, B1, R), new(T2, B2, Mw)
     dP_att, dV_att = new(B1, R, A), new(B1, R, E)
@@ -551,8 +554,8 @@ def _pair_backward(cap, S, d1, d2, sparse1, sparse2, d_fc_feats1, d_cpt_feats1, 
     if P2.cpt_ids.shape[1] != C:
         raise ValueError('merged unrolls: the two calls carry different numbers of concept words')
     cpt_ids = torch.cat([P1.cpt_ids, P2.cpt_ids]).view(-1)
+    # (nn.Embedding(padding_idx=pad_id): the <PAD> row never gets a gradient - every accumulation into dEmb skips it)
     ops.embed_relu_bwd(emb, cpt_ids, dcm, dEmb, Bt * C, rows_per_grad=C, scale=1.0 / C, skip_id=cap.pad_id)
-    dEmb[cap.pad_id].zero_()
     bucket_done(0)
     if sink is None and gs is not None:
         torch._foreach_mul_(list(G.values()), gs[1])

@@ -161,7 +161,8 @@ class Captioner(nn.Module):
         for n in sizes:
             offs.append(total)
             total += (n + 255) & ~255
-        arena = torch.zeros(max(total, 256), dtype=torch.uint8, device=self._dev)
+        # (a float fill: the same kernel and rate as torch.zeros of a float tensor, whatever the views' types)
+        arena = torch.zeros(max(total, 256) // 4, dtype=torch.float32, device=self._dev).view(torch.uint8)
         return [arena[o:o + n].view(dtype).view(*shape) for (shape, dtype), o, n in zip(specs, offs, sizes)]
 
     def init_hidden(self, bsz):
