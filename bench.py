@@ -75,6 +75,13 @@ def parse():
                          'ranks exactly as --gpus N does, the ranks form a group, all-reduce a token, rank 0 prints a stub line')
     ap.add_argument('--dry-fail-rank', type=int, default=-1, help='(with --dry-ranks) this rank exits non-zero: the '
                     'parent must relay the failure')
+    ap.add_argument('--dry-fail-late-rank', type=int, default=-1, help='(with --dry-ranks) this rank exits non-zero AFTER '
+                    'the headline, while rank 0 sits in a collective of a side measurement: rank 0 must still print its line')
+    ap.add_argument('--dry-hang', action='store_true', help='(with --dry-ranks) rank 0\'s side measurements never return: '
+                    'the line must go out at --extras-deadline')
+    ap.add_argument('--extras-deadline', type=float, default=420.0,
+                    help='under a process group: seconds the side measurements may take before rank 0 writes the line '
+                         'with what it has and leaves (HeadlineGuard)')
     return ap.parse_args()
 
 
@@ -161,11 +168,14 @@ def timed_region(fn, iters, dev):
     return el
 
 
-def run_jobs(jobs, extra):
+def run_jobs(jobs, extra, at=None):
     """Side measurements: a failure is reported under the job's key, never fatal - EXCEPT FatalUnderGroup (not an
-    Exception on purpose), which must end this rank's process: its peers are inside collectives of the same job."""
+    Exception on purpose), which must end this rank's process: its peers are inside collectives of the same job.
+    `at(key)` is told which job starts (HeadlineGuard's note)."""
     for key, fn in jobs:
         progress('extra: ' + key)
+        if at is not None:
+            at(key)
         try:
             extra[key] = fn()
         except Exception as e:  # noqa: BLE001
@@ -183,6 +193,68 @@ class FatalUnderGroup(BaseException):
     replays: carrying on would desynchronise them).  Deliberately not an Exception: the side-measurement loop catches
     Exception only, so this propagates to the top of the process, which exits non-zero; the launcher tears the group
     down and the parent relays the failure."""
+
+
+_REAL_STDOUT = 1          # the descriptor the ONE result line goes to (main() points fd 1 at stderr while libraries talk)
+
+
+class HeadlineGuard:
+    """Rank 0 under a process group: the headline has been measured when the side measurements start, and it must reach
+    stdout even when one of them fails or hangs ON ANY RANK.  A peer that dies makes the launcher send SIGTERM while this
+    rank may sit inside a collective or a device synchronise (a Python-level handler would never run: the main thread is
+    in C), and a deadlocked collective never returns at all.  So: the C-level signal handler writes to a wake-up pipe
+    (signal.set_wakeup_fd), a daemon thread waits on that pipe with the side measurements' deadline as its timeout, and
+    on either event it writes the line - headline plus the side measurements finished so far plus a note saying what
+    happened - and ends the process non-zero (no teardown: the group is broken)."""
+
+    def __init__(self, compose, deadline_s):
+        self.compose, self.deadline_s = compose, deadline_s
+        self.job = 'start'
+        self._thread = self._r = self._w = self._old = self._old_fd = None
+
+    def __enter__(self):
+        import select
+        import signal
+        import threading
+        self._r, self._w = os.pipe()
+        os.set_blocking(self._w, False)
+        self._old = signal.signal(signal.SIGTERM, lambda *a: None)       # (registers the C handler that feeds the pipe)
+        self._old_fd = signal.set_wakeup_fd(self._w, warn_on_full_buffer=False)
+        t_end = time.monotonic() + self.deadline_s
+
+        def watch():
+            while True:
+                left = t_end - time.monotonic()
+                ready, _, _ = select.select([self._r], [], [], max(left, 0.0))
+                if ready:
+                    data = os.read(self._r, 64)
+                    if data == b'disarm':
+                        return
+                    if signal.SIGTERM not in data:
+                        continue
+                    why = 'SIGTERM from the launcher (another rank failed) during %r' % self.job
+                else:
+                    why = 'side measurements passed their deadline of %.0f s inside %r' % (self.deadline_s, self.job)
+                self.emit_and_exit(why)
+        self._thread = threading.Thread(target=watch, daemon=True)
+        self._thread.start()
+        return self
+
+    def emit_and_exit(self, why, code=1):
+        sys.stderr.write('bench.py: %s - writing the headline line and leaving\n' % why)
+        os.write(_REAL_STDOUT, (self.compose(why) + '\n').encode())
+        os._exit(code)
+
+    def __exit__(self, et, ev, tb):
+        import signal
+        signal.set_wakeup_fd(self._old_fd if self._old_fd is not None else -1)
+        signal.signal(signal.SIGTERM, self._old if self._old is not None else signal.SIG_DFL)
+        os.set_blocking(self._w, True)
+        os.write(self._w, b'disarm')
+        self._thread.join(5)
+        os.close(self._r)
+        os.close(self._w)
+        return False
 
 
 def bench_xe_train(cap, dev, rank, world, iters=6, B=128, s2s_rows=80, curve='weak', ss_prob=0.0, regions=R):
@@ -782,7 +854,11 @@ def launch_ranks(args, n_ranks=None, dry=False):
     if r.returncode != 0 or not lines:
         sys.stderr.write('bench.py: the %d-rank run failed (launcher exit code %d, %d result line(s))\n'
                          % (n_ranks, r.returncode, len(lines)))
-        sys.stderr.write(r.stdout[-2000:])
+        if lines:
+            # the headline was measured before a side measurement failed (HeadlineGuard wrote it): relay it, keep the code
+            print(lines[-1], flush=True)
+        else:
+            sys.stderr.write(r.stdout[-2000:])
         return r.returncode or 1
     print(lines[-1], flush=True)
     return 0
@@ -802,13 +878,38 @@ def dry_rank(args):
     dist.all_reduce(tok)
     assert float(tok) == world * (world + 1) / 2, float(tok)
     dist.barrier()
+
+    def compose(note=None):
+        d = dict(metric='dry-run (launch path only: no GPU work)', value=float(tok), unit='token sum',
+                 n_gpus=world, steps=0, warmup=0, ms_per_step=0.0, higher_is_better=True, scaling='weak',
+                 vs_baseline=None, dtype='f32', data='none', config={'workload': 'launcher rehearsal'})
+        if note is not None:
+            d['extra'] = {'side_measurements_aborted': note}
+        return json.dumps(d)
+    if args.dry_fail_late_rank >= 0 or args.dry_hang:
+        # the "side measurements" of the rehearsal: the headline (the token sum) exists; one rank dies, or rank 0 hangs
+        if rank == args.dry_fail_late_rank:
+            time.sleep(1.0)                       # (rank 0 is inside its wait by then)
+            sys.stderr.write('bench.py: dry rank %d fails late on request\n' % rank)
+            os._exit(3)
+        if rank == 0:
+            global _REAL_STDOUT
+            _REAL_STDOUT = 1
+            with HeadlineGuard(compose, args.extras_deadline) as guard:
+                guard.job = 'dry side measurement'
+                threading_event_wait_forever()
+        else:
+            threading_event_wait_forever()
     if rank == 0:
-        print(json.dumps(dict(metric='dry-run (launch path only: no GPU work)', value=float(tok), unit='token sum',
-                              n_gpus=world, steps=0, warmup=0, ms_per_step=0.0, higher_is_better=True, scaling='weak',
-                              vs_baseline=None, dtype='f32', data='none', config={'workload': 'launcher rehearsal'})),
-              flush=True)
+        print(compose(), flush=True)
     dist.destroy_process_group()
     return 0
+
+
+def threading_event_wait_forever():
+    """Stands in for a collective whose peer is gone (a C-level wait that no Python signal handler interrupts)."""
+    import threading
+    threading.Event().wait()
 
 
 def main():
@@ -826,16 +927,24 @@ def main():
     # stdout must carry exactly ONE JSON line: send everything libraries print (RCCL's version banner,
     # MIOpen notices ...) to stderr until the result is ready
     sys.stdout.flush()
+    global _REAL_STDOUT
     saved_stdout = os.dup(1)
     os.dup2(2, 1)
+    _REAL_STDOUT = saved_stdout          # (HeadlineGuard writes the line there if the side measurements never return)
     try:
-        line = run(args)
+        line, rc = run(args)
     finally:
         sys.stdout.flush()
         os.dup2(saved_stdout, 1)
+        _REAL_STDOUT = 1
         os.close(saved_stdout)
     if line is not None:
         print(line, flush=True)
+    if rc:
+        # rank 0 failed inside a side measurement under a group: the headline is out; no teardown (the peers sit in
+        # collectives this rank will not join) - leave at once so that the launcher ends them
+        sys.stderr.flush()
+        os._exit(rc)
 
 
 def run(args):
@@ -891,46 +1000,7 @@ def run(args):
         tt = torch.tensor([el], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         el = float(tt)
-    extra = {}
-    if not args.no_extras:
-        # secondary measurements (never part of `value`); failures are reported, not fatal
-        if world == 1:
-            # measurements on the headline's own weights first; the training benches (which update them) last
-            for key, fn in (('exact_fp32_engine', lambda: bench_exact_fp32(cap, inputs, B)),
-                            ('greedy_small_batches', lambda: bench_small_batches(cap, dev)),
-                            ('batch_sweep', lambda: bench_batch_sweep(cap, dev)),
-                            ('beam5', lambda: bench_beam(cap, inputs)),
-                            ('scan_sweep', lambda: bench_scan_sweep(dev)),
-                            ('table_build', lambda: bench_table_build(cap, inputs)),
-                            ('rl_iteration', lambda: bench_rl(dev)),
-                            ('rl_iteration_cold_sentiment_cache', lambda: bench_rl(dev, iters=3, cache_image_sentiments=False))):
-                progress('extra: ' + key)
-                try:
-                    extra[key] = fn()
-                except Exception as e:  # noqa: BLE001 - side measurements are reported, never fatal
-                    extra[key] = {'error': repr(e)[:300]}
-        # training curves of BASELINE configs[3] (XE) and [4] (RL); every rank runs them (they hold collectives).
-        # weak: 128 captions + 80 seq2seq rows per GPU; strong: GLOBAL 1024 captions + 80 seq2seq rows over the ranks
-        jobs = [('xe_train', lambda: bench_xe_train(cap, dev, rank, world))]
-        if 1024 % world == 0 and 80 % world == 0:
-            jobs.append(('xe_train_strong', lambda: bench_xe_train(cap, dev, rank, world, iters=4, B=1024 // world,
-                                                                   s2s_rows=80 // world, curve='strong')))
-        # the regime the reference trains in from epoch 5 on: scheduled sampling (train_xe.py:209-212, opts.py:35-38)
-        jobs.append(('xe_train_ss025', lambda: bench_xe_train(cap, dev, rank, world, iters=4, ss_prob=0.25)))
-        if world == 1:
-            jobs.append(('xe_train_by_batch', lambda: {str(b): bench_xe_train(cap, dev, rank, world, iters=3, B=b)[
-                'ms_per_iter'] for b in (512,)}))
-            jobs.append(('r196', lambda: bench_r196(cap, dev)))
-            jobs.append(('epoch_loops', lambda: bench_epoch_loops(dev)))
-        if dist_on():
-            jobs.append(('grad_allreduce', lambda: bench_grad_allreduce(cap, dev, world)))
-            if 512 % world == 0 and 80 % world == 0:
-                jobs.append(('rl_iteration', lambda: bench_rl(dev, rank=rank, world=world)))
-        run_jobs(jobs, extra)
-    if rank != 0:
-        torch.distributed.destroy_process_group()
-        return None
-
+    # ---- the line's own part: everything the headline's measurements determine, BEFORE any side measurement runs
     total = world * B * args.steps
     summ = ops.TIMER.summary()
     # share of one roll-out: step kernels run T times, prologue kernels once
@@ -962,54 +1032,119 @@ def run(args):
     scan = next((e for e in entries if e['kernel'].startswith('attn_scan')), None)
     mfma = next((e for e in entries if e['kernel'].startswith('vocab[')), None)
     rest = [e for e in entries if e is not scan and e is not mfma]
-    out = {
-        'metric': 'captions/sec (greedy, 36-region feats, len-20)',
-        'value': round(total / el, 1), 'unit': 'captions/s',
-        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-        'ms_per_step': round(el / args.steps * 1e3, 3),
-        'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None,
-        'dtype': 'f32', 'data': 'synthetic',
-        'config': {'workload': 'greedy decode forward_rl(sample_max=1): B=%d captions/GPU/step, R=%d '
-                               'regions x 2048, V=%d, T=%d, sentiment-word attention + gate on, '
-                               'prologue included, random-init reference-architecture weights; the weight-only '
-                               'tables (relu(Emb) W_x^T [V,4H], sentiment-word tables 2 x [V,512]; 26 GFLOP) and '
-                               'the f16 weight planes are built by the first roll-out after a weight change, i.e. '
-                               'in warm-up, and reused by the timed ones (extra.table_build)' % (B, R, V, T),
-                   'batch_per_gpu': B, 'global_batch': B * world,
-                   'parallelism': 'dp%d (batch shard, no collective)' % world,
-                   'ranks': torch.distributed.get_world_size() if dist_on() else 1,
-                   'collective_backend': torch.distributed.get_backend() if dist_on() else None,
-                   'gemm_engine': {1: 'split-f16 x3 MFMA for large forward GEMMs (fp32 in/out/accumulate), fp32 MFMA elsewhere',
-                                   0: 'fp32 MFMA only (--h3-mode 0)', 2: 'split-f16 forced'}[args.h3_mode]},
-        'roofline': scan if scan is not None else (entries[0] if entries else None),
-        'roofline_mfma': mfma,
-        'roofline_kernels': rest if scan is not None else entries[1:],
-        'extra': extra,
-    }
-    if not args.no_cpu_baseline and world == 1:
-        out['cpu_baseline'] = cpu_baseline(weights, args.cpu_seconds)
-    # LAST key: the driver's record keeps the tail of this line - the other half of BASELINE's metric (beam-5 p50) and
-    # the training figures in one compact object
-    g = lambda *ks: functools.reduce(lambda d, k: d.get(k) if isinstance(d, dict) else None, ks, extra)
-    out['summary'] = {
-        'greedy_captions_per_s': out['value'], 'scan_frac_of_hbm': (scan or {}).get('frac'),
-        'classifier_frac_of_mfma': (mfma or {}).get('frac'),
-        'beam5_p50_ms': g('beam5', 'per_image_p50_ms'), 'beam5_us_per_step': g('beam5', 'per_step_p50_us'),
-        'beam5_full20_p50_ms': g('beam5', 'full_search_p50_ms'),
-        'exact_fp32_captions_per_s': g('exact_fp32_engine', 'captions_per_s'),
-        'xe128_ms': g('xe_train', 'ms_per_iter'), 'xe128_ss025_ms': g('xe_train_ss025', 'ms_per_iter'),
-        'xe512_ms': g('xe_train_by_batch', '512'), 'xe1024_ms': g('xe_train_strong', 'ms_per_iter'),
-        'exposed_allreduce_ms': g('xe_train', 'exposed_allreduce_ms'),
-        'rl512_ms': g('rl_iteration', 'ms_per_iter'),
-        'r196_greedy_captions_per_s': g('r196', 'greedy_B4096', 'captions_per_s'),
-        'r196_scan_frac_of_hbm': g('r196', 'scan', '4096', 'frac_of_8tbs'),
-        'r196_xe128_ms': g('r196', 'xe_train_B128', 'ms_per_iter'), 'r196_beam5_p50_ms': g('r196', 'beam5', 'per_image_p50_ms'),
-        'xe128_epoch_ms_per_iter': g('epoch_loops', 'xe128_resident_ms_per_iter'),
-        'rl512_epoch_ms_per_iter': g('epoch_loops', 'rl512_resident_ms_per_iter'),
-    }
-    if world > 1 or under_launcher:
+    extra = {}
+
+    def compose(note=None):
+        """The ONE result line: the headline + the side measurements finished so far.  `note`: why the side measurements
+        were cut short (HeadlineGuard / a failure on this rank) - the headline was measured before they started."""
+        ex = dict(extra)
+        if note is not None:
+            ex['side_measurements_aborted'] = note
+        out = {
+            'metric': 'captions/sec (greedy, 36-region feats, len-20)',
+            'value': round(total / el, 1), 'unit': 'captions/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(el / args.steps * 1e3, 3),
+            'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'greedy decode forward_rl(sample_max=1): B=%d captions/GPU/step, R=%d '
+                                   'regions x 2048, V=%d, T=%d, sentiment-word attention + gate on, '
+                                   'prologue included, random-init reference-architecture weights; the weight-only '
+                                   'tables (relu(Emb) W_x^T [V,4H], sentiment-word tables 2 x [V,512]; 26 GFLOP) and '
+                                   'the f16 weight planes are built by the first roll-out after a weight change, i.e. '
+                                   'in warm-up, and reused by the timed ones (extra.table_build)' % (B, R, V, T),
+                       'batch_per_gpu': B, 'global_batch': B * world,
+                       'parallelism': 'dp%d (batch shard, no collective)' % world,
+                       'ranks': torch.distributed.get_world_size() if dist_on() else 1,
+                       'collective_backend': torch.distributed.get_backend() if dist_on() else None,
+                       'gemm_engine': {1: 'split-f16 x3 MFMA for large forward GEMMs (fp32 in/out/accumulate), fp32 MFMA elsewhere',
+                                       0: 'fp32 MFMA only (--h3-mode 0)', 2: 'split-f16 forced'}[args.h3_mode]},
+            'roofline': scan if scan is not None else (entries[0] if entries else None),
+            'roofline_mfma': mfma,
+            'roofline_kernels': rest if scan is not None else entries[1:],
+            'extra': ex,
+        }
+        if not args.no_cpu_baseline and world == 1 and note is None:
+            out['cpu_baseline'] = cpu_baseline(weights, args.cpu_seconds)
+        # LAST key: the driver's record keeps the tail of this line - the other half of BASELINE's metric (beam-5 p50) and
+        # the training figures in one compact object
+        g = lambda *ks: functools.reduce(lambda d, k: d.get(k) if isinstance(d, dict) else None, ks, ex)
+        out['summary'] = {
+            'greedy_captions_per_s': out['value'], 'scan_frac_of_hbm': (scan or {}).get('frac'),
+            'classifier_frac_of_mfma': (mfma or {}).get('frac'),
+            'beam5_p50_ms': g('beam5', 'per_image_p50_ms'), 'beam5_us_per_step': g('beam5', 'per_step_p50_us'),
+            'beam5_full20_p50_ms': g('beam5', 'full_search_p50_ms'),
+            'exact_fp32_captions_per_s': g('exact_fp32_engine', 'captions_per_s'),
+            'xe128_ms': g('xe_train', 'ms_per_iter'), 'xe128_ss025_ms': g('xe_train_ss025', 'ms_per_iter'),
+            'xe512_ms': g('xe_train_by_batch', '512'), 'xe1024_ms': g('xe_train_strong', 'ms_per_iter'),
+            'exposed_allreduce_ms': g('xe_train', 'exposed_allreduce_ms'),
+            'rl512_ms': g('rl_iteration', 'ms_per_iter'),
+            'r196_greedy_captions_per_s': g('r196', 'greedy_B4096', 'captions_per_s'),
+            'r196_scan_frac_of_hbm': g('r196', 'scan', '4096', 'frac_of_8tbs'),
+            'r196_xe128_ms': g('r196', 'xe_train_B128', 'ms_per_iter'), 'r196_beam5_p50_ms': g('r196', 'beam5', 'per_image_p50_ms'),
+            'xe128_epoch_ms_per_iter': g('epoch_loops', 'xe128_resident_ms_per_iter'),
+            'rl512_epoch_ms_per_iter': g('epoch_loops', 'rl512_resident_ms_per_iter'),
+        }
+        return json.dumps(out)
+
+    def side_measurements(at):
+        """`at(key)`: the job now running (HeadlineGuard's note)."""
+        # secondary measurements (never part of `value`); failures are reported, not fatal
+        if world == 1:
+            # measurements on the headline's own weights first; the training benches (which update them) last
+            for key, fn in (('exact_fp32_engine', lambda: bench_exact_fp32(cap, inputs, B)),
+                            ('greedy_small_batches', lambda: bench_small_batches(cap, dev)),
+                            ('batch_sweep', lambda: bench_batch_sweep(cap, dev)),
+                            ('beam5', lambda: bench_beam(cap, inputs)),
+                            ('scan_sweep', lambda: bench_scan_sweep(dev)),
+                            ('table_build', lambda: bench_table_build(cap, inputs)),
+                            ('rl_iteration', lambda: bench_rl(dev)),
+                            ('rl_iteration_cold_sentiment_cache', lambda: bench_rl(dev, iters=3, cache_image_sentiments=False))):
+                progress('extra: ' + key)
+                at(key)
+                try:
+                    extra[key] = fn()
+                except Exception as e:  # noqa: BLE001 - side measurements are reported, never fatal
+                    extra[key] = {'error': repr(e)[:300]}
+        # training curves of BASELINE configs[3] (XE) and [4] (RL); every rank runs them (they hold collectives).
+        # weak: 128 captions + 80 seq2seq rows per GPU; strong: GLOBAL 1024 captions + 80 seq2seq rows over the ranks
+        jobs = [('xe_train', lambda: bench_xe_train(cap, dev, rank, world))]
+        if 1024 % world == 0 and 80 % world == 0:
+            jobs.append(('xe_train_strong', lambda: bench_xe_train(cap, dev, rank, world, iters=4, B=1024 // world,
+                                                                   s2s_rows=80 // world, curve='strong')))
+        # the regime the reference trains in from epoch 5 on: scheduled sampling (train_xe.py:209-212, opts.py:35-38)
+        jobs.append(('xe_train_ss025', lambda: bench_xe_train(cap, dev, rank, world, iters=4, ss_prob=0.25)))
+        if world == 1:
+            jobs.append(('xe_train_by_batch', lambda: {str(b): bench_xe_train(cap, dev, rank, world, iters=3, B=b)[
+                'ms_per_iter'] for b in (512,)}))
+            jobs.append(('r196', lambda: bench_r196(cap, dev)))
+            jobs.append(('epoch_loops', lambda: bench_epoch_loops(dev)))
+        if dist_on():
+            jobs.append(('grad_allreduce', lambda: bench_grad_allreduce(cap, dev, world)))
+            if 512 % world == 0 and 80 % world == 0:
+                jobs.append(('rl_iteration', lambda: bench_rl(dev, rank=rank, world=world)))
+        run_jobs(jobs, extra, at)
+
+    grouped = world > 1 or under_launcher
+    if not args.no_extras:
+        if grouped and rank == 0:
+            # the headline must reach stdout even if a side measurement fails or hangs on ANY rank (HeadlineGuard)
+            guard = HeadlineGuard(compose, args.extras_deadline)
+            try:
+                with guard:
+                    side_measurements(lambda key: setattr(guard, 'job', key))
+            except BaseException as e:  # noqa: BLE001 - FatalUnderGroup and whatever else ends this rank
+                sys.stderr.write('bench.py: rank 0 left the side measurements in %r: %r\n' % (guard.job, e))
+                return compose('rank 0 failed in %r: %s' % (guard.job, repr(e)[:300])), 1
+        else:
+            side_measurements(lambda key: None)
+    if rank != 0:
         torch.distributed.destroy_process_group()
-    return json.dumps(out)
+        return None, 0
+    line = compose()
+    if grouped:
+        torch.distributed.destroy_process_group()
+    return line, 0
 
 
 if __name__ == '__main__':

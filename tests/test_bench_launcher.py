@@ -41,6 +41,38 @@ def test_dry_ranks_two_ranks_spawn_relay_and_exit_code():
     assert 'run failed' in bad.stderr
 
 
+def test_the_headline_survives_a_side_measurement_that_fails_or_hangs_under_a_group():
+    """The N-rank line is the only multi-GPU measurement there is: once the headline has been timed, a side measurement
+    that dies on another rank (the launcher then SIGTERMs rank 0, which may sit in a collective - a C-level wait no Python
+    signal handler interrupts) or that never returns must not take the line with it.  bench.HeadlineGuard: wake-up pipe +
+    watcher thread + deadline; rank 0 writes the line with a note and leaves non-zero, the parent relays line AND code."""
+    import json
+    late = _run(['--dry-ranks', '2', '--dry-fail-late-rank', '1'])
+    assert late.returncode != 0, (late.stdout, late.stderr[-2000:])
+    lines = [x for x in late.stdout.splitlines() if x.strip()]
+    assert len(lines) == 1, late.stdout
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['value'] == 3.0
+    assert 'SIGTERM' in d['extra']['side_measurements_aborted'], d
+    hang = _run(['--dry-ranks', '2', '--dry-hang', '--extras-deadline', '3'])
+    assert hang.returncode != 0, (hang.stdout, hang.stderr[-2000:])
+    lines = [x for x in hang.stdout.splitlines() if x.strip()]
+    assert len(lines) == 1, hang.stdout
+    d = json.loads(lines[0])
+    assert d['value'] == 3.0 and 'deadline' in d['extra']['side_measurements_aborted'], d
+
+
+def test_the_result_line_is_composed_before_the_side_measurements_start():
+    """run(): everything the headline's own measurements determine (roofline entries from the kernel timer, value) is
+    computed before the first side measurement, so that HeadlineGuard's thread only formats - no device call from it."""
+    src = open(BENCH).read()
+    run = src[src.index('def run(args):'):src.index("if __name__ == '__main__':")]
+    assert run.index('summ = ops.TIMER.summary()') < run.index('def compose(') < run.index('def side_measurements(')
+    assert run.index('def side_measurements(') < run.index('HeadlineGuard(compose')
+    comp = run[run.index('def compose('):run.index('def side_measurements(')]
+    assert 'torch.cuda' not in comp and 'TIMER' not in comp and 'note is None' in comp     # (cpu_baseline: normal path only)
+
+
 def test_gpu_count_comes_from_sysfs_or_a_child_never_from_torch_in_the_parent(tmp_path, monkeypatch):
     """count_gpus: KFD topology nodes with simd_count > 0, narrowed by the *_VISIBLE_DEVICES lists; this process (the
     would-be parent of the ranks) does not import torch for it."""
