@@ -8,11 +8,14 @@
 * `FeatureStore` + `CaptionDataset` / `SCSDataset` / `RLFactDataset` / `RLSentiDataset` and the four
   `get_*_dataloader` factories (dataloader.py:152-222,267-328): same constructor arguments and item tuples as
   the reference's classes, but the per-item `h5py.File(...)[fn][:]` (dataloader.py:171-178: two file opens per
-  image) is replaced by one memory-mapped `[N, ...]` fp32 array + a name index, so a batch is a row gather.
+  image) is replaced by one memory-mapped `[N, ...]` fp32 array + a name index, so a batch is a row gather.  The
+  reference's own `.h5` feature files are taken as they are where h5py exists (`H5FeatureStore`: a path ending in
+  .h5 / .hdf5 handed to a Dataset class; opened once per process) and converted once with `FeatureStore.from_h5`.
 * `DevicePrefetcher` - pinned host staging + asynchronous H2D copies on a side HIP stream, one batch
   ahead of the consumer: at >10k captions/s the 303 KB of fp32 region features per caption
   (~3 GB/s and more) must overlap with decoding instead of serialising in front of it.
 """
+import os
 import random
 
 import numpy as np
@@ -162,14 +165,76 @@ class FeatureStore:
             json.dump({fn: i for i, fn in enumerate(fns)}, f)
         return path
 
+    @classmethod
+    def from_h5(cls, h5_path, npy_path, fns=None):
+        """One-off conversion of a reference feature file (an h5 dataset per image, dataloader.py:171-178) into the
+        memory-mapped `.npy` + index pair; returns the opened store.  Needs h5py (H5FeatureStore says so)."""
+        src = H5FeatureStore(h5_path)
+        fns = list(fns if fns is not None else src.keys())
+        first = src[fns[0]]
+        path = npy_path if npy_path.endswith('.npy') else npy_path + '.npy'
+        out = np.lib.format.open_memmap(path, mode='w+', dtype=np.float32, shape=(len(fns),) + first.shape)
+        for i, fn in enumerate(fns):            # row by row: the set does not have to fit in host memory
+            out[i] = src[fn]
+        out.flush()
+        del out
+        import json
+        with open(path + '.index.json', 'w') as f:
+            json.dump({fn: i for i, fn in enumerate(fns)}, f)
+        return cls(path)
+
     def __getitem__(self, fn):
         return np.array(self.array[self.index[fn]])
 
     def __contains__(self, fn):
         return fn in self.index
 
+    def keys(self):
+        return list(self.index)
+
     def __len__(self):
         return len(self.index)
+
+
+class H5FeatureStore:
+    """fn -> fp32 feature array straight out of the reference's own feature files: one h5 dataset per image file name
+    (dataloader.py:171-178 `h5py.File(path, mode='r')[fn][:]`).  A caller that hands the Dataset classes the `.h5` / `.hdf5`
+    paths it handed the reference's gets this store (`_store`).  Differences to the reference's access pattern, none
+    visible in what an item holds: the file is opened ONCE per process (per loader worker: the handle is dropped on
+    pickling and re-opened lazily) instead of twice per item.  Needs `h5py`, imported here and nowhere else - without
+    it the call raises with the one-off conversion named (`FeatureStore.from_h5`, run wherever h5py exists).
+    Parity: unpinned against real h5 files in this build's image (no h5py); the tests drive it through a stand-in
+    module with h5py's `File(path, 'r')[fn][:]` surface."""
+
+    def __init__(self, path):
+        self.path, self._file = path, None
+        self._open()
+
+    def _open(self):
+        if self._file is None:
+            try:
+                import h5py
+            except ImportError as e:
+                raise ImportError('%r is an h5 feature file and h5py is not importable here: install h5py, or convert the '
+                                  'file once with data.FeatureStore.from_h5(h5_path, npy_path) on a machine that has it '
+                                  '(the .npy + index pair needs numpy only)' % (self.path,)) from e
+            self._file = h5py.File(self.path, mode='r')
+        return self._file
+
+    def __getstate__(self):                     # loader workers get the path, not the open handle
+        return {'path': self.path, '_file': None}
+
+    def __getitem__(self, fn):
+        return np.asarray(self._open()[fn][:], dtype=np.float32)
+
+    def __contains__(self, fn):
+        return fn in self._open()
+
+    def __len__(self):
+        return len(self._open())
+
+    def keys(self):
+        return list(self._open().keys())
 
 
 class _Row:
@@ -214,7 +279,7 @@ class DeviceFeatureStore:
     @classmethod
     def from_store(cls, store, device, fns=None):
         store = _store(store)
-        fns = list(fns if fns is not None else (store.index if isinstance(store, FeatureStore) else store.keys()))
+        fns = list(fns if fns is not None else store.keys())
         return cls.from_arrays(fns, [store[fn] for fn in fns], device)
 
     def __getitem__(self, fn):
@@ -228,7 +293,12 @@ class DeviceFeatureStore:
 
 
 def _store(x):
-    return FeatureStore(x) if isinstance(x, str) else x
+    """What the Dataset classes take for `fc_feats` / `att_feats`: a path - the reference's `.h5` / `.hdf5` file
+    (H5FeatureStore) or this package's `.npy` (FeatureStore) - or any fn -> array mapping (dict, DeviceFeatureStore)."""
+    if isinstance(x, (str, os.PathLike)):
+        x = os.fspath(x)
+        return H5FeatureStore(x) if x.lower().endswith(('.h5', '.hdf5', '.hdf')) else FeatureStore(x)
+    return x
 
 
 def _item(x):

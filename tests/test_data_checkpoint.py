@@ -167,6 +167,72 @@ def test_collates_vs_reference_goldens(golden, tmp_path):
     assert sorted(seen) == sorted(fns)
 
 
+class _FakeH5File:
+    """h5py's surface as dataloader.py:171-178 uses it - File(path, mode='r')[fn][:] - over an .npz (h5py is not in this
+    image; the h5 path's parity against real h5 files is unpinned, the store's logic is what this covers)."""
+    opened = 0
+
+    def __init__(self, path, mode='r'):
+        assert mode == 'r'
+        type(self).opened += 1
+        self._z = np.load(path + '.npz')
+
+    def __getitem__(self, fn):
+        return self._z[fn]                    # ndarray: `[:]` works as on an h5 dataset
+
+    def __contains__(self, fn):
+        return fn in self._z.files
+
+    def __len__(self):
+        return len(self._z.files)
+
+    def keys(self):
+        return list(self._z.files)
+
+
+def test_reference_h5_feature_files_are_taken_as_they_are(golden, tmp_path, monkeypatch):
+    """A caller that hands the Dataset classes the `.h5` paths it handed the reference's (dataloader.py:164-178) gets the
+    same batches as from the .npy stores: data.H5FeatureStore (one open per process instead of two per item), and the
+    one-off conversion data.FeatureStore.from_h5.  Without h5py the call says what to do instead of failing inside numpy."""
+    import sys
+    import types
+    g = golden('collate')
+    fns, fcs, atts, caps5, cpts, sentis, labels = _collate_inputs(g)
+    n = len(fns)
+    fc_h5, att_h5 = str(tmp_path / 'fc_feats.h5'), str(tmp_path / 'att_feats.hdf5')
+    np.savez(fc_h5 + '.npz', **{fn: fcs[i] for i, fn in enumerate(fns)})
+    np.savez(att_h5 + '.npz', **{fn: atts[i] for i, fn in enumerate(fns)})
+    captions = {fn: caps5[i] for i, fn in enumerate(fns)}
+    det_c = dict(zip(fns, cpts))
+
+    monkeypatch.setitem(sys.modules, 'h5py', None)               # h5py absent: a loud, actionable error
+    with pytest.raises(ImportError, match='FeatureStore.from_h5'):
+        data.get_caption_dataloader(fc_h5, att_h5, captions, det_c, 0, 8, 5, batch_size=n, shuffle=False)
+
+    fake = types.ModuleType('h5py')
+    fake.File = _FakeH5File
+    monkeypatch.setitem(sys.modules, 'h5py', fake)
+    _FakeH5File.opened = 0
+    (b,) = list(data.get_caption_dataloader(fc_h5, att_h5, captions, det_c, 0, 8, 5, batch_size=n, shuffle=False))
+    assert _FakeH5File.opened == 2                              # one open per file, not two per item
+    assert list(b[0]) == [str(x) for x in g['caption/fns']]
+    for t, key in ((b[1], 'caption/fc'), (b[2], 'caption/att'), (b[3][0], 'caption/caps'), (b[4], 'caption/cpts')):
+        np.testing.assert_array_equal(t.numpy(), g[key], err_msg=key)
+    # a store travels to loader workers as its path (the handle is re-opened there)
+    import pickle
+    st = data.H5FeatureStore(fc_h5)
+    st2 = pickle.loads(pickle.dumps(st))
+    assert st2._file is None and fns[0] in st2 and len(st2) == n
+    np.testing.assert_array_equal(st2[fns[1]], fcs[1])
+    # one-off conversion: same rows from the memory-mapped pair
+    conv = data.FeatureStore.from_h5(att_h5, str(tmp_path / 'att_conv'))
+    assert sorted(conv.keys()) == sorted(fns)
+    for i, fn in enumerate(fns):
+        np.testing.assert_array_equal(conv[fn], atts[i])
+    (b2,) = list(data.get_caption_dataloader(fc_h5, conv.path, captions, det_c, 0, 8, 5, batch_size=n, shuffle=False))
+    np.testing.assert_array_equal(b2[2].numpy(), g['caption/att'])
+
+
 @pytest.mark.gpu
 def test_device_prefetcher_delivers_identical_batches():
     dev = torch.device('cuda:0')
