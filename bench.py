@@ -1113,9 +1113,9 @@ def run(args):
             jobs.append(('xe_train_strong', lambda: bench_xe_train(cap, dev, rank, world, iters=4, B=1024 // world,
                                                                    s2s_rows=80 // world, curve='strong')))
         # the regime the reference trains in from epoch 5 on: scheduled sampling (train_xe.py:209-212, opts.py:35-38)
-        jobs.append(('xe_train_ss025', lambda: bench_xe_train(cap, dev, rank, world, iters=4, ss_prob=0.25)))
+        jobs.append(('xe_train_ss025', lambda: bench_xe_train(cap, dev, rank, world, iters=8, ss_prob=0.25)))
         if world == 1:
-            jobs.append(('xe_train_by_batch', lambda: {str(b): bench_xe_train(cap, dev, rank, world, iters=3, B=b)[
+            jobs.append(('xe_train_by_batch', lambda: {str(b): bench_xe_train(cap, dev, rank, world, iters=6, B=b)[
                 'ms_per_iter'] for b in (512,)}))
             jobs.append(('r196', lambda: bench_r196(cap, dev)))
             jobs.append(('epoch_loops', lambda: bench_epoch_loops(dev)))
