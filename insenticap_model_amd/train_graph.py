@@ -308,6 +308,9 @@ class XETrainGraph:
                     with ops.graph_capture(geo.g_up, stream=self.stream, settle=False):
                         xe_update(self.optim, self.grad_clip)
                 geo.keep = (vec_xe, s2s)
+        except BaseException:
+            geo.g_iter = geo.g_up = None        # a half-captured graph must not read as "captured" to the next step
+            raise
         finally:
             self.optim.device_hyper = None
             for st, n in zip(self._states(), steps_before):      # (also when the capture fails half-way)
