@@ -448,6 +448,18 @@ typedef struct {
 
 int isc_step_fwd(const isc_step_plan *plan_host, void *stream);
 
+/* Stream gate: the general kernels' form of isc_rows_ext.live_in.  While a gate is set for `stream`, the forward
+ * launches enqueued on it - isc_linear_fwd, isc_lstm_fwd, isc_vocab_fwd (hence every launch of isc_step_fwd),
+ * isc_attn_scan_fwd, isc_attn_scan_gate_fwd, isc_beam_topk - carry `flag` (a device int32) and return at once when it
+ * reads 0 at RUN time.  A batched beam search (captioner.py:351-420 for many images at a time) gates step t by live[t]
+ * of isc_beam_merge, the images still searching before it: the host looks at that counter only every fourth step
+ * (graphs of four steps), and the up to three steps enqueued past the end of the search then cost their launches
+ * instead of a full step each.  The small launches of a step (embedding gather, state re-order, merge) are not gated:
+ * after the end they copy the finished images' rows along, as they always did.
+ * Host state read at enqueue / capture time, per stream; flag == NULL clears it - do that as soon as the gated run of
+ * launches is enqueued.  The reference has no counterpart (its loop breaks on the host, captioner.py:379-381). */
+int isc_set_stream_gate(const int32_t *flag, void *stream);
+
 /* ------------------------------------------------------------------ decode rows (at most 8 rows, inference)
  * The same forward_step (captioner.py:168-186) for the few-row regimes of the reference: the `beam_size` rows of one
  * image inside sample() (captioner.py:380-411, one batch-1 forward_step per live candidate there), a greedy roll-out

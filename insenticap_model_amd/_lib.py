@@ -159,6 +159,7 @@ SIGNATURES = {
     'isc_gemm_bwd': (C.c_int, [C.POINTER(LinearProblem), C.c_int, C.c_int, C.c_void_p]),
     'isc_lstm_fwd': (C.c_int, [C.POINTER(LstmProblem), C.c_void_p]),
     'isc_step_fwd': (C.c_int, [C.POINTER(StepPlan), C.c_void_p]),
+    'isc_set_stream_gate': (C.c_int, [C.c_void_p, C.c_void_p]),
     'isc_step_bwd': (C.c_int, [C.POINTER(StepBwdPlan), C.c_void_p]),
     'isc_rows_stats_tile': (C.c_int, [C.c_int]),
     'isc_rows_step_supported': (C.c_int, [C.POINTER(StepPlan)]),

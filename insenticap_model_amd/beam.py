@@ -173,7 +173,7 @@ def _graph_key(cap, ins, beam, decoding_constraint, T):
                                           cap.senti2att[0].bias, cap.attention.senti2att.weight, cap.att_embed[0].weight,
                                           cap.att2att[0].weight, cap.attention.cont2att.weight))
     return (tuple(None if x is None else (tuple(x.shape), x.dtype) for x in ins), beam, decoding_constraint, T, versions,
-            ops.WEIGHT_EPOCH, cap.eos_id, torch.cuda.current_device())
+            ops.WEIGHT_EPOCH, cap.eos_id, torch.cuda.current_device(), bool(getattr(cap, 'beam_step_gate', True)))
 
 
 def _replay(cap, entry, ins, T):
@@ -254,7 +254,12 @@ def _graphed_search(cap, fc_feats, att_feats, senti_words, senti_labels, beam, d
                         if search is None:
                             search = _Search(cap, *static, beam, decoding_constraint, T)
                         # few-row searches end themselves on the device (isc_rows_ext.live_in): ONE graph, no counter
-                        # read in between; the general kernels run CHUNK steps per graph
+                        # read in between; the general kernels run CHUNK steps per graph with a look at the counter after
+                        # each - their steps are gated as well (isc_set_stream_gate), so the up to CHUNK - 1 steps a graph
+                        # runs past the end of the search cost a third of a step each.  (ONE gated graph for the whole
+                        # search was measured: the same 3.4 ms for 64 images x 20 steps - the looks at the counter hide
+                        # behind the device's queue - and slower for searches that end early, whose every remaining step
+                        # still costs its launches: tools/beam64_probe.py)
                         t1 = T if search.rows_mode else min(t0 + CHUNK, T)
                         for t in range(t0, t1):
                             search.step(t)
@@ -287,6 +292,9 @@ class _Search:
         # per-tile candidates out of the classifier, top-k + merge in one launch (isc_beam_select): six launches per step.
         # The rows of an image share its step-invariant tensors there (isc_rows_ext.row_div): nothing is expanded.
         self.rows_mode = self.device_merge and cap._rows_step_ok(rows, P)
+        # the general kernels under the device-side merge: a step past the search's end skips its heavy launches on the
+        # device (ops.stream_gate; `beam_step_gate = False` on the captioner restores the ungated steps for A/B runs)
+        self.gated = self.device_merge and not self.rows_mode and getattr(cap, 'beam_step_gate', True)
         if self.rows_mode:
             Pb = P
         else:
@@ -405,13 +413,19 @@ class _Search:
         # kept and re-used, so that a later step costs four library calls and no struct filling - the eager loop is
         # then bound by the device (~110 us per step), not by ~55 us of host work in front of each step's first launch
         fast = self._plans[t & 1] if t >= 2 and not ops.TIMER.armed else None
-        if fast is not None:
-            ops.step_fwd(fast[0])
-        else:
-            h_cur, c_cur, h_nxt, c_nxt = self.st_cur[0], self.st_cur[1], self.st_nxt[0], self.st_nxt[1]
-            cap._step(self.p, self.Pb, self.ws, self.xt, h_cur, c_cur, h_nxt, c_nxt, logits=self.logits, tok=last_d)
-        ops.beam_topk(self.logits, self.ws['pmax'], self.ws['psum'], last_d, self.beam, cap.pad_id, cap.sos_id,
-                      cap.unk_id, self.mask_special, self.dc, self.top_val, self.top_idx)
+        # live[t] == 0 (every image has ended): the step's contractions, scans and top-k return at once on the device
+        # (isc_set_stream_gate) - the steps enqueued past the end of the search (up to three: the host looks at the counter
+        # every fourth step) cost their launches only.  The small launches around them (state re-order, embedding gather,
+        # merge) still run: they copy the frozen rows along.
+        live_in = self.live.data_ptr() + 4 * t if (t > 0 and self.gated) else None
+        with ops.stream_gate(live_in):
+            if fast is not None:
+                ops.step_fwd(fast[0])
+            else:
+                h_cur, c_cur, h_nxt, c_nxt = self.st_cur[0], self.st_cur[1], self.st_nxt[0], self.st_nxt[1]
+                cap._step(self.p, self.Pb, self.ws, self.xt, h_cur, c_cur, h_nxt, c_nxt, logits=self.logits, tok=last_d)
+            ops.beam_topk(self.logits, self.ws['pmax'], self.ws['psum'], last_d, self.beam, cap.pad_id, cap.sos_id,
+                          cap.unk_id, self.mask_special, self.dc, self.top_val, self.top_idx)
         nxt = cur ^ 1
         if fast is not None:
             a = fast[1]
@@ -485,15 +499,18 @@ class _Search:
         # kernels (a frozen image's rows are copied along), the last executed one on the few-row kernels (later launches
         # return at once: isc_rows_ext.live_in)
         cur = (executed if self.rows_mode else steps) & 1
+        # (plain lists once, then list slicing: 64 images x 5 beams as 320 numpy slices + generator joins took 0.55 ms
+        # behind a 2.85 ms search - tools/beam64_probe.py)
         sc = host('score')[cur].reshape(n_img, beam).tolist()
-        wd = host('words')[cur].reshape(n_img, beam, T)
-        ln = host('length')[cur].reshape(n_img, beam)
+        wd = host('words')[cur].reshape(n_img, beam, T).tolist()
+        ln = host('length')[cur].reshape(n_img, beam).tolist()
         cap.last_beam_steps = executed
+        i2w, eos = cap.idx2word, cap.eos_id
         captions, scores, ids = [], [], []
-        for i in range(n_img):
-            cand = [wd[i, k, :ln[i, k]].tolist() for k in range(beam)]
-            captions.append([' '.join(cap.idx2word[w] for w in words_k if w != cap.eos_id) for words_k in cand])
-            scores.append([float(x) for x in sc[i]])
+        for wd_i, ln_i, sc_i in zip(wd, ln, sc):
+            cand = [words_k[:n_k] for words_k, n_k in zip(wd_i, ln_i)]
+            captions.append([' '.join([i2w[w] for w in words_k if w != eos]) for words_k in cand])
+            scores.append(sc_i)
             ids.append(cand)
         return captions, scores, ids
 

@@ -31,6 +31,7 @@ struct DevScan {
 struct DevScanLaunch {
     DevScan p[2];
     int nt;                    // the per-caption P / V rows are streamed with non-temporal loads (host decides)
+    const int *gate;           // optional: *gate == 0 -> the launch returns at once (isc_set_stream_gate)
 };
 // A launch whose per-caption rows do not fit the Infinity Cache (256 MB) next to the step's other traffic re-reads
 // them from HBM every step anyway; loading them non-temporally (no allocation on the way) measured 149 -> 128 us at
@@ -51,6 +52,7 @@ __device__ __forceinline__ float4 ld4(const float4 *p, bool nt) {
 
 template <int NA, bool NT>  // float4 per lane along A: A <= 256*NA; NT: per-caption rows by non-temporal loads
 __global__ __launch_bounds__(256) void attn_scan_kernel(const DevScanLaunch L) {
+    ISC_GATE_RETURN(L);
     rows_kernarg_warm<ROWS_KERNARG_LINES(DevScanLaunch)>();
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const DevScan &S = L.p[blockIdx.y];
@@ -197,6 +199,7 @@ extern "C" int isc_attn_scan_fwd(const isc_scan_problem *pr, int n_prob, int B, 
     if (!pr) return ISC_E_NULL;
     if (n_prob < 1 || n_prob > 2 || B <= 0) return ISC_E_SHAPE;
     DevScanLaunch L = {};
+    L.gate = isc_stream_gate_(stream);
     int maxA = 0, max_rows = 0;
     size_t lds = 0;
     for (int i = 0; i < n_prob; ++i) {
@@ -263,6 +266,7 @@ struct DevScanGate {
     long long beta_ld;
     _Float16 *f_hi, *f_lo;
     int lds_half;              // floats of LDS per scan (the two scans of a row run side by side)
+    const int *gate;           // optional: *gate == 0 -> the launch returns at once (isc_set_stream_gate)
 };
 
 // 512 threads per row: threads 0..255 run the content scan, threads 256..511 the sentiment scan AT THE SAME TIME (same
@@ -270,6 +274,7 @@ struct DevScanGate {
 // not their sum; both keep six regions' loads in flight per thread in the weighted sums (two tensors each).
 template <int NA>
 __global__ __launch_bounds__(512) void attn_scan_gate_kernel(const DevScanGate L) {
+    ISC_GATE_RETURN(L);
     rows_kernarg_warm<ROWS_KERNARG_LINES(DevScanGate)>();
     extern __shared__ __attribute__((aligned(16))) float smem_all[];
     const int b = blockIdx.x;
@@ -444,6 +449,7 @@ extern "C" int isc_attn_scan_gate_fwd(const isc_scan_gate_args *a, int B, void *
         if (rows_scan_gate_try(a, B, (hipStream_t)stream, &rc)) return rc;
     }
     DevScanGate L = {};
+    L.gate = isc_stream_gate_(stream);
     size_t lds = 0;
     const int A = a->scan[0].A, D = a->scan[0].D;
     if (A <= 0 || A != D || (A & 3) || A > 1024) return ISC_E_SHAPE;       // (a thread holds four columns: A / 4 <= 256)

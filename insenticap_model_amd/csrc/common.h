@@ -9,6 +9,15 @@
 
 static inline int isc_aligned16(const void *p) { return (((uintptr_t)p) & 15u) == 0; }
 
+// Stream gate (isc_set_stream_gate, step.hip): the device int the forward launches enqueued on `stream` look at first -
+// 0 there and the launch returns at once, every thread, before any barrier.  nullptr: no gate (the normal case).
+const int *isc_stream_gate_(void *stream);
+// ... in a kernel whose descriptor L carries the pointer as L.gate (uniform: a scalar load and a scalar branch)
+#define ISC_GATE_RETURN(L)                                          \
+    do {                                                            \
+        if ((L).gate != nullptr && *(L).gate == 0) return;          \
+    } while (0)
+
 #define ISC_LAUNCH_CHECK()                         \
     do {                                           \
         hipError_t e__ = hipGetLastError();        \

@@ -92,6 +92,7 @@ struct DevProb {
 struct DevLaunch {
     DevProb p[3];
     int nprob, total_tiles;
+    const int *gate;            // optional: *gate == 0 -> the launch returns at once (isc_set_stream_gate; forward entry points)
 };
 
 // Operand layouts. "k-minor": element (row, k) at ptr[row*ld + k] (contraction index contiguous;
@@ -459,6 +460,7 @@ __device__ __forceinline__ void epi_linear_frag(const DevProb &P, f32x16 (&acc)[
 
 template <int WM, int WN, int TN, int EPI, bool AKM, bool BKM>
 __global__ __launch_bounds__(256) void gemm_kernel(const DevLaunch L) {
+    ISC_GATE_RETURN(L);
     rows_kernarg_warm<ROWS_KERNARG_LINES(DevLaunch)>();      // (one batch of scalar loads for the launch descriptor: common.h)
     constexpr int BM = 32 * WM;
     constexpr int BN = 32 * TN * WN;
@@ -761,6 +763,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const DevLaunch L) {
 // compiler would otherwise drain every DMA (vmcnt(0)) in front of the next ds_read.
 template <int EPI>
 __global__ __launch_bounds__(256) void gemm_xl_kernel(const DevLaunch L) {
+    ISC_GATE_RETURN(L);
     constexpr int BM = 256, BN = 128, TN = 4;
     constexpr int TSA = BM * BK, TSB = BN * BK;         // floats per ring slot
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -939,6 +942,7 @@ __global__ __launch_bounds__(256) void gemm_xl_kernel(const DevLaunch L) {
 // previous barrier) and retired with vmcnt(0) in front of the one barrier per chunk.
 template <int EPI>
 __global__ __launch_bounds__(256) void gemm_ld_kernel(const DevLaunch L) {
+    ISC_GATE_RETURN(L);
     constexpr int BM = 128, BN = 128, TN = 4;
     constexpr int TS = 128 * BK;                        // floats per operand buffer
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1423,6 +1427,7 @@ extern "C" int isc_debug_h3_stamps(unsigned long long *out16_host, int reset) {
 // and the per-buffer test is compiled out of the fragment loads (it cost the all-planes decode loop ~5-10 %).
 template <int EPI, bool AF32>
 __global__ __launch_bounds__(256, 2) void gemm_h3_kernel(const DevLaunch L) {
+    ISC_GATE_RETURN(L);
 #if H3_STAMP
     const unsigned long long stamp0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -1649,6 +1654,7 @@ __global__ __launch_bounds__(256, 2) void gemm_h3_kernel(const DevLaunch L) {
 // [4096 x 2048 x 1536] 97 -> 76 us (tools/h3_gemm_lab.hip).  Used when the launch has >= 224 such tiles.
 template <int EPI, bool AF32>
 __global__ __launch_bounds__(512) void gemm_h3x_kernel(const DevLaunch L) {
+    ISC_GATE_RETURN(L);
 #if H3_STAMP
     const unsigned long long stamp0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -1864,6 +1870,7 @@ __global__ __launch_bounds__(512) void gemm_h3x_kernel(const DevLaunch L) {
 // Per chunk: A planes 2 x 4 KB, W planes 2 x 8 KB; four buffers = 96 KB, one workgroup per CU.
 template <bool AF32>
 __global__ __launch_bounds__(256) void gemm_h3m_kernel(const DevLaunch L) {
+    ISC_GATE_RETURN(L);
     rows_kernarg_warm<ROWS_KERNARG_LINES(DevLaunch)>();      // (one batch of scalar loads for the launch descriptor: common.h)
     constexpr int TN = 2;
     constexpr int PA = 64 * 128, PB = 128 * 128;        // bytes per A / W image (row = 128 B: 32 hi | 32 lo halfs)
@@ -2144,6 +2151,7 @@ __global__ __launch_bounds__(256) void h3_split_kernel(const SplitLaunch S) {
 // N = 512: their 64-row tiles are what balances 4096 x 512 outputs over 256 CUs, and at one to three workgroups
 // per CU the register-staged form of that tile leaves the matrix pipe idle over its chunk-boundary round trips.
 __global__ __launch_bounds__(256) void gemm_md_kernel(const DevLaunch L) {
+    ISC_GATE_RETURN(L);
     constexpr int TN = 2;
     constexpr int TSA = 64 * BK, TSB = 128 * BK;      // floats per operand buffer
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -2330,6 +2338,7 @@ __device__ __forceinline__ void h3s_vocab_combine(const DevProb &P, const float 
 // blocks - 32 KB per wave - stay in flight as in the 4-slot ring of the small tile.
 template <int EPI, int T, int NW = 4>
 __global__ __launch_bounds__(64 * NW) void gemm_h3s_kernel(const DevLaunch L) {
+    ISC_GATE_RETURN(L);
     rows_kernarg_warm<ROWS_KERNARG_LINES(DevLaunch)>();      // (one batch of scalar loads for the launch descriptor: common.h)
     constexpr bool KSPLIT = EPI != EPI_VOCAB;
     static_assert(T == 1 || (T == 2 && KSPLIT), "wide skinny tile: K-split epilogues only");
@@ -2621,6 +2630,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_h3s_kernel(const DevLaunch L) {
 #define H3V_STAGE_BYTES (5 * 4096)
 template <bool AF32>
 __global__ __launch_bounds__(256) void gemm_h3v_kernel(const DevLaunch L) {
+    ISC_GATE_RETURN(L);
     rows_kernarg_warm<ROWS_KERNARG_LINES(DevLaunch)>();
     constexpr int BM = 32, BN = 128;
     extern __shared__ __attribute__((aligned(16))) float smem[];     // stages of [A image 4 KB | 4 W images 4 KB each]
@@ -2721,6 +2731,7 @@ __global__ __launch_bounds__(256) void gemm_h3v_kernel(const DevLaunch L) {
 // Sums the ksplit partial slabs in a fixed order (deterministic) and applies the epilogue the
 // single-pass kernel would have applied.  blockIdx.y = problem.
 __global__ __launch_bounds__(256) void splitk_linear_kernel(const DevLaunch L) {
+    ISC_GATE_RETURN(L);
     rows_kernarg_warm<ROWS_KERNARG_LINES(DevLaunch)>();      // (one batch of scalar loads for the launch descriptor: common.h)
     const DevProb &P = L.p[blockIdx.y];
     const long long n4 = (long long)P.M * (P.N >> 2);
@@ -2763,6 +2774,7 @@ __global__ __launch_bounds__(256) void splitk_linear_kernel(const DevLaunch L) {
 }
 
 __global__ __launch_bounds__(256) void splitk_lstm_kernel(const DevLaunch L) {
+    ISC_GATE_RETURN(L);
     const DevProb &P = L.p[0];
     const int H = P.H;
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -2811,6 +2823,7 @@ __global__ __launch_bounds__(256) void splitk_lstm_kernel(const DevLaunch L) {
 // writes the logits, and emits the per-128-column (max, arg-max, sum exp) the single-pass kernel's epilogue
 // would have produced.  One wavefront per (row, column tile): lane l holds columns l and l + 64 of the tile.
 __global__ __launch_bounds__(256) void splitk_vocab_kernel(const DevLaunch L) {
+    ISC_GATE_RETURN(L);
     const DevProb &P = L.p[0];
     const int lane = threadIdx.x & 63;
     const long long w = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -2962,6 +2975,7 @@ __device__ __forceinline__ void gemv_accumulate(const DevProb &P, const long lon
 // two rounds of 8 rows.
 template <int EPI, int NW>
 __global__ __launch_bounds__(64 * NW) void gemv_rows_kernel(const DevLaunch L) {
+    ISC_GATE_RETURN(L);
     rows_kernarg_warm<ROWS_KERNARG_LINES(DevLaunch)>();      // (one batch of scalar loads for the launch descriptor: common.h)
     constexpr int MR = GEMV_MAX_ROWS, NT = 64 * NW;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -4096,6 +4110,7 @@ extern "C" int isc_linear_fwd(const isc_linear_problem *pr, int n_prob, void *st
     if (n_prob < 1 || n_prob > 3) return ISC_E_SHAPE;
     DevLaunch L = {};
     L.nprob = n_prob;
+    L.gate = isc_stream_gate_(stream);
     for (int i = 0; i < n_prob; ++i) {
         const isc_linear_problem &q = pr[i];
         int rc = check_segs(q.seg, q.nseg);
@@ -4221,6 +4236,7 @@ extern "C" int isc_lstm_fwd(const isc_lstm_problem *q, void *stream) {
     if (q->h_keep_mask && !q->hdrop_out) return ISC_E_NULL;
     DevLaunch L = {};
     L.nprob = 1;
+    L.gate = isc_stream_gate_(stream);
     DevProb &d = L.p[0];
     copy_segs(d, q->seg, q->nseg);
     d.M = q->M; d.N = 4 * q->H; d.H = q->H;
@@ -4265,6 +4281,7 @@ extern "C" int isc_vocab_fwd(const float *h, int ldh, const float *W, int ldw, c
     if (M <= 0 || V <= 0) return ISC_E_SHAPE;
     DevLaunch L = {};
     L.nprob = 1;
+    L.gate = isc_stream_gate_(stream);
     DevProb &d = L.p[0];
     copy_segs(d, &sg, 1);
     d.M = M; d.N = V; d.bias0 = bias;

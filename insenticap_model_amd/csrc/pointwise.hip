@@ -648,7 +648,8 @@ __global__ __launch_bounds__(256) void beam_topk8_kernel(const float *logits, lo
                                                          int V, int beam, const int64_t *last_word,
                                                          long long pad_id, long long sos_id,
                                                          long long unk_id, int mask_special, int cons,
-                                                         float *top_val, int64_t *top_idx) {
+                                                         float *top_val, int64_t *top_idx, const int *gate) {
+    if (gate != nullptr && *gate == 0) return;      // (uniform; isc_set_stream_gate: the search has ended)
     constexpr int K = 8;
     __shared__ float sv[2][4];
     __shared__ int si[2][4];
@@ -754,7 +755,8 @@ __global__ __launch_bounds__(256) void beam_topk_kernel(const float *logits, lon
                                                         int V, int beam, const int64_t *last_word,
                                                         long long pad_id, long long sos_id,
                                                         long long unk_id, int mask_special, int cons,
-                                                        float *top_val, int64_t *top_idx) {
+                                                        float *top_val, int64_t *top_idx, const int *gate) {
+    if (gate != nullptr && *gate == 0) return;      // (uniform; isc_set_stream_gate: the search has ended)
     __shared__ float sv[4];
     __shared__ int si[4];
     __shared__ float sh[2];
@@ -806,16 +808,17 @@ extern "C" int isc_beam_topk(const float *logits, int64_t ld_logits, const float
                              int64_t *top_idx, void *stream) {
     if (!logits || !part_max || !part_sum || !last_word || !top_val || !top_idx) return ISC_E_NULL;
     if (rows <= 0 || V <= 0 || beam <= 0 || beam > 16 || beam > V) return ISC_E_SHAPE;
+    const int *gate = isc_stream_gate_(stream);
     if (beam <= 8 && n_tile <= 256 && V >= (beam + 4) * 128)
         hipLaunchKernelGGL(beam_topk8_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, logits,
                            (long long)ld_logits, part_max, part_sum, n_tile, V, beam, last_word,
                            (long long)pad_id, (long long)sos_id, (long long)unk_id, mask_special,
-                           decoding_constraint, top_val, top_idx);
+                           decoding_constraint, top_val, top_idx, gate);
     else
         hipLaunchKernelGGL(beam_topk_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, logits,
                            (long long)ld_logits, part_max, part_sum, n_tile, V, beam, last_word,
                            (long long)pad_id, (long long)sos_id, (long long)unk_id, mask_special,
-                           decoding_constraint, top_val, top_idx);
+                           decoding_constraint, top_val, top_idx, gate);
     ISC_LAUNCH_CHECK();
     return ISC_OK;
 }

@@ -1192,6 +1192,7 @@ int rows_scan_gate_try(const isc_scan_gate_args *g, int rows, hipStream_t st, in
     if (!c.P || !c.V || !c.q || !c.w || !s.P || !s.V || !s.q || !s.w || !g->G[0] || !g->G[1]) return 0;
     RScanArgs a = {};
     a.row_div = 1;
+    a.skip = isc_stream_gate_(st);         // (isc_set_stream_gate: a batched search that has ended skips its remaining steps)
     a.P[0] = c.P; a.V[0] = c.V; a.G[0] = g->G[0]; a.q[0] = c.q; a.w[0] = c.w; a.wb[0] = c.w_bias;
     a.P[1] = s.P; a.V[1] = s.V; a.G[1] = g->G[1]; a.q[1] = s.q; a.w[1] = s.w; a.wb[1] = s.w_bias;
     a.q2 = s.q2;

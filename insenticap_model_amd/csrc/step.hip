@@ -3,6 +3,7 @@
 // descriptor-building calls (include/insenticap_hip.h, "whole decode step").  Pure host code: it
 // only fills the per-kernel descriptors and calls the library's own entry points.
 #include "common.h"
+#include <atomic>
 
 static inline isc_seg seg(const float *A, int lda, const float *W, int ldw, int K, const void *hi = nullptr,
                           const void *lo = nullptr) {
@@ -234,6 +235,46 @@ extern "C" int isc_step_bwd(const isc_step_bwd_plan *p, void *stream) {
         q[0].splitk_ws = p->splitk_ws; q[0].splitk_ws_floats = p->splitk_ws_floats;
         RET(isc_gemm_bwd(q, 2, ISC_LAYOUT_NN, stream));
     }
+    return ISC_OK;
+}
+
+// ------------------------------------------------------------------ stream gate
+// The decode steps a batched beam search enqueues past its own end (the host looks at the live-image counter every fourth
+// step only) should cost their launches, not a full step each - the few-row step has isc_rows_ext.live_in for that; the
+// general kernels take the flag from here instead of from every problem struct of the ABI: while a gate is set
+// for a stream, the forward launches enqueued on it (isc_linear_fwd, isc_lstm_fwd, isc_vocab_fwd - hence isc_step_fwd -,
+// isc_attn_scan_fwd, isc_attn_scan_gate_fwd, isc_beam_topk) carry the pointer and return at once when it reads 0.
+// Host state, read at enqueue (= capture) time; the caller clears it when the gated run of launches is enqueued.
+#include <mutex>
+#define ISC_GATE_SLOTS 64
+static struct { void *stream; const int *flag; bool used; } g_gates[ISC_GATE_SLOTS] = {};
+static std::mutex g_gates_mu;
+static std::atomic<int> g_gates_set{0};            // (fast path: nobody has a gate)
+
+const int *isc_stream_gate_(void *stream) {
+    if (g_gates_set.load(std::memory_order_relaxed) == 0) return nullptr;
+    std::lock_guard<std::mutex> lk(g_gates_mu);
+    for (int i = 0; i < ISC_GATE_SLOTS; ++i)
+        if (g_gates[i].used && g_gates[i].stream == stream) return g_gates[i].flag;
+    return nullptr;
+}
+
+extern "C" int isc_set_stream_gate(const int32_t *flag, void *stream) {
+    std::lock_guard<std::mutex> lk(g_gates_mu);
+    int free_slot = -1;
+    for (int i = 0; i < ISC_GATE_SLOTS; ++i) {
+        if (g_gates[i].used && g_gates[i].stream == stream) {
+            if (flag) { g_gates[i].flag = flag; return ISC_OK; }
+            g_gates[i].used = false;
+            g_gates_set.fetch_sub(1);
+            return ISC_OK;
+        }
+        if (!g_gates[i].used && free_slot < 0) free_slot = i;
+    }
+    if (!flag) return ISC_OK;                      // nothing to clear
+    if (free_slot < 0) return ISC_E_WORKSPACE;
+    g_gates[free_slot].stream = stream; g_gates[free_slot].flag = flag; g_gates[free_slot].used = true;
+    g_gates_set.fetch_add(1);
     return ISC_OK;
 }
 

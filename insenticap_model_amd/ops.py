@@ -503,6 +503,28 @@ def step_fwd(plan):
     check(_lib.load().isc_step_fwd(C.byref(plan), stream()), 'isc_step_fwd')
 
 
+class stream_gate:
+    """`with ops.stream_gate(ptr):` - the forward launches enqueued on the current stream inside the block return at once
+    when the device int32 at address `ptr` reads 0 at run time (isc_set_stream_gate: a batched beam search's step t under
+    live[t]).  ptr None / 0: no gate, the block is plain."""
+
+    def __init__(self, ptr):
+        self.ptr = int(ptr) if ptr else 0
+        self.st = None
+
+    def __enter__(self):
+        if self.ptr:
+            self.st = stream()
+            check(_lib.load().isc_set_stream_gate(C.c_void_p(self.ptr), self.st), 'isc_set_stream_gate')
+        return self
+
+    def __exit__(self, et, ev, tb):
+        if self.st is not None:
+            _lib.load().isc_set_stream_gate(None, self.st)
+            self.st = None
+        return False
+
+
 def rows_stats_tile(V):
     """Column-tile width of the few-row classifier's statistics (isc_rows_stats_tile)."""
     return _lib.load().isc_rows_stats_tile(int(V))

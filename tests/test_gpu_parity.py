@@ -1,5 +1,7 @@
 """Parity of the HIP path (through the C-ABI library) against the CPU oracle and the golden
 vectors produced by the reference. Run on the MI355X box: pytest -m gpu."""
+import contextlib
+
 import numpy as np
 import pytest
 import torch
@@ -485,6 +487,136 @@ def test_beam_search_from_hip_graphs_equals_the_eager_search():
             np.testing.assert_array_equal(np.asarray(got[0][1]), np.asarray(ref3[0][1]))
     finally:
         cap.eos_id = eos
+        cap.enable_beam_graphs(True)
+
+
+def test_stream_gate_skips_the_gated_launches_only_when_the_flag_reads_zero():
+    """isc_set_stream_gate: forward launches enqueued inside ops.stream_gate(ptr) return at once when the device int at
+    `ptr` is 0 at RUN time (outputs untouched), run normally when it is not, and launches outside the block never look -
+    for the GEMM families a decode step can take (exact tiles, split-f16 tiles, the skinny path under a weights scope),
+    the LSTM cell, the classifier and the attention scan."""
+    g = torch.Generator().manual_seed(5)
+    d = dev()
+    flag = torch.zeros(2, dtype=torch.int32, device=d)
+    flag[1] = 3
+    SENT = -123.0
+
+    def lin(M, N, K):
+        x = torch.randn(M, K, generator=g).to(d)
+        w = (torch.randn(N, K, generator=g) / K ** 0.5).to(d)
+        out = torch.full((M, N), SENT, device=d)
+        return (lambda: ops.linear_fwd([ops.linear_problem([(x, w)], out)])), out, (x.double() @ w.double().t())
+
+    def lstm(M, H, K):
+        x = torch.randn(M, K, generator=g).to(d)
+        w = (torch.randn(4 * H, K, generator=g) / K ** 0.5).to(d)
+        b = torch.zeros(4 * H, device=d)
+        c0 = torch.zeros(M, H, device=d)
+        h, c = torch.full((M, H), SENT, device=d), torch.full((M, H), SENT, device=d)
+        return (lambda: ops.lstm_fwd([(x, w)], b, b, c0, h, c)), h, None
+
+    def vocab(M, V, K):
+        x = torch.randn(M, K, generator=g).to(d)
+        w = (torch.randn(V, K, generator=g) / K ** 0.5).to(d)
+        b = torch.zeros(V, device=d)
+        nt = (V + 127) // 128
+        pm, ps = torch.full((M, nt), SENT, device=d), torch.full((M, nt), SENT, device=d)
+        pi = torch.zeros(M, nt, dtype=torch.int32, device=d)
+        return (lambda: ops.vocab_fwd(x, w, b, pm, ps, pi)), pm, None
+
+    def scan(B, R, A):
+        P, V_ = torch.randn(B, R, A, generator=g).to(d), torch.randn(B, R, A, generator=g).to(d)
+        q, w = torch.randn(B, A, generator=g).to(d), torch.randn(A, generator=g).to(d)
+        out, al = torch.full((B, A), SENT, device=d), torch.zeros(B, R, device=d)
+        return (lambda: ops.attn_scan_fwd([ops.scan_problem(P, V_, q, w, None, out, al)], B)), out, None
+
+    cases = [lin(37, 64, 96), lin(320, 512, 512), lin(2048, 512, 512), lstm(320, 512, 1024), lstm(4096, 512, 1024),
+             vocab(320, 10000, 512), vocab(4096, 10000, 512), scan(320, 36, 512)]
+    for scope in (False, True):
+        ctx = ops.h3_weights_scope(d) if scope else contextlib.nullcontext()
+        with ctx:
+            for run, out, ref in cases:
+                out.fill_(SENT)
+                with ops.stream_gate(flag[0:1].data_ptr()):          # flag 0: nothing runs
+                    run()
+                torch.cuda.synchronize()
+                assert bool((out == SENT).all()), 'a gated launch wrote its output although the flag read 0'
+                with ops.stream_gate(flag[1:2].data_ptr()):          # flag != 0: the launch runs
+                    run()
+                torch.cuda.synchronize()
+                assert not bool((out == SENT).any())
+                got = out.clone()
+                out.fill_(SENT)
+                run()                                                # no gate: same bits
+                torch.cuda.synchronize()
+                assert torch.equal(got, out)
+                if ref is not None:
+                    assert float((out.double() - ref).abs().max()) < 1e-3
+    # the flag is read when the launch RUNS, not when it is enqueued: set behind the enqueue, on the same stream
+    run, out, _ = cases[1]
+    out.fill_(SENT)
+    f2 = torch.ones(1, dtype=torch.int32, device=d)
+    f2.zero_()
+    with ops.stream_gate(f2.data_ptr()):
+        run()
+    torch.cuda.synchronize()
+    assert bool((out == SENT).all())
+    # the host state is gone with the block
+    out.fill_(SENT)
+    run()
+    torch.cuda.synchronize()
+    assert not bool((out == SENT).any())
+
+
+def test_batched_beam_search_ends_itself_on_the_device():
+    """The general kernels' batched search (more than 8 rows): a step enqueued past the end of every image's search skips
+    its contractions, scans and top-k on the device (the stream gate under live[t]) - same captions, ids, fp64 scores and
+    executed-step counts as the ungated search, eager and from graphs, for a batch that ends early (and NOT on a multiple
+    of the four steps between two looks at the counter, so that gated steps do run) and for one forced through all steps."""
+    cap, c, st, w, _, _ = make_captioner('cfg1')
+    n, Tn, beam = 24, 20, 5
+    d = synth.make_inputs(n, c['V'], st, regions=36, seq_len=Tn, seed=4242)
+    fc, att, sw, lab = T(d, 'fc_feats'), T(d, 'att_feats'), T(d, 'senti_words'), T(d, 'senti_labels')
+
+    def search():
+        out = cap.sample_batch(fc, att, sw, lab, beam, 1, Tn)
+        return out, cap.last_beam_steps
+    eos = cap.eos_id
+    try:
+        cap.enable_beam_graphs(False)
+        cap.beam_step_gate = False
+        # push <EOS> until the whole batch ends well before the last step (random-init captions rarely end on their own)
+        for bump in (0.0, 2.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 2.0, 2.0):
+            with torch.no_grad():
+                cap.classifier.bias[eos] += bump
+            ref = search()
+            if ref[1] <= Tn - 6 and ref[1] % 4 != 0:
+                break
+        assert 2 <= ref[1] <= Tn - 6 and ref[1] % 4 != 0, ref[1]
+        cap.eos_id = -7
+        ref_full = search()
+        cap.eos_id = eos
+        assert ref_full[1] == Tn
+
+        def same(got, want, what):
+            assert got[0][0] == want[0][0] and got[0][2] == want[0][2], what
+            np.testing.assert_array_equal(np.asarray(got[0][1]), np.asarray(want[0][1]), err_msg=str(what))
+            assert got[1] == want[1], (what, got[1], want[1])
+        cap.beam_step_gate = True
+        same(search(), ref, 'eager, gated')
+        cap.enable_beam_graphs(True, max_graphs=4)
+        for rep in range(4):                                       # first sight, capture, replays
+            same(search(), ref, ('graphs', rep))
+        cap.eos_id = -7
+        for rep in range(3):
+            same(search(), ref_full, ('graphs, all steps', rep))
+        cap.eos_id = eos
+        cap.beam_step_gate = False                                 # the ungated form is still there (its own graphs)
+        for rep in range(3):
+            same(search(), ref, ('graphs, ungated', rep))
+    finally:
+        cap.eos_id = eos
+        cap.__dict__.pop('beam_step_gate', None)
         cap.enable_beam_graphs(True)
 
 
