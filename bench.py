@@ -146,7 +146,7 @@ def cpu_baseline(weights, seconds):
 
 
 def dist_on():
-    return torch.distributed.is_available() and torch.distributed.is_initialized()
+    return torch is not None and torch.distributed.is_available() and torch.distributed.is_initialized()
 
 
 def timed_region(fn, iters, dev):
@@ -179,6 +179,11 @@ def run_jobs(jobs, extra, at=None):
         try:
             extra[key] = fn()
         except Exception as e:  # noqa: BLE001
+            if dist_on():
+                # every job under a group holds collectives (timed_region's barriers at the least): a rank that carried on
+                # alone would pair its next job's collectives with its peers' current ones
+                sys.stderr.write('bench.py: side measurement %r failed under the process group: %r\n' % (key, e))
+                raise FatalUnderGroup('%s: %s' % (key, repr(e)[:300])) from e
             extra[key] = {'error': repr(e)[:300]}
 
 
