@@ -240,6 +240,8 @@ def _graphed_search(cap, fc_feats, att_feats, senti_words, senti_labels, beam, d
             stream = cap.__dict__['_beam_stream'] = ops.private_stream(dev)
         pool = torch.cuda.graph_pool_handle()
         graphs = []
+        # (few-row searches are ONE graph: its last node copies the results into this pinned buffer)
+        pinned = torch.empty(_Search.result_bytes(ins[0].shape[0], beam, T), dtype=torch.uint8).pin_memory() if few else None
         torch.cuda.synchronize()
         with ops.capture_buffers(ws, wp), torch.cuda.stream(stream):
             scope = ops.h3_weights_scope(dev)      # ONE scope over all the captures (its planes live in `wp`,
@@ -263,11 +265,13 @@ def _graphed_search(cap, fc_feats, att_feats, senti_words, senti_labels, beam, d
                         t1 = T if search.rows_mode else min(t0 + CHUNK, T)
                         for t in range(t0, t1):
                             search.step(t)
+                        if search.rows_mode and t1 == T and pinned is not None:
+                            search.stage_result(pinned)
                     graphs.append((g, t1))
                     t0 = t1
             finally:
                 scope.__exit__(None, None, None)
-        entry = cache[key] = (graphs, static, search, ws, wp, pool)
+        entry = cache[key] = (graphs, static, search, ws, wp, pool, pinned)
     return _replay(cap, entry, ins, T)
 
 
@@ -360,6 +364,7 @@ class _Search:
             self.done = carve_host('done', torch.int32, np.int32, n_img)
             self.live = carve_host('live', torch.int32, np.int32, T + 1)
             self._result_span, self._result_views = arena[span0:off], spans
+            self._result_host = None                      # pinned image of the span, filled by the graph itself (stage_result)
             self.score, self.words, self.length = [sc2[0], sc2[1]], [wd2[0], wd2[1]], [ln2[0], ln2[1]]
             la2 = torch.full((2, rows), cap.sos_id, dtype=torch.int64, device=dev)
             self.last = [la2[0], la2[1]]
@@ -478,12 +483,32 @@ class _Search:
     def all_done(self, t):
         return int(self.live[t + 1].item()) == 0
 
+    @staticmethod
+    def result_bytes(n_img, beam, T):
+        """Upper bound of the result span (scores, words, lengths, done flags, live counters + alignment)."""
+        rows = n_img * beam
+        return 2 * 8 * rows + 2 * 8 * rows * T + 2 * 4 * rows + 4 * n_img + 4 * (T + 1) + 16 * 8
+
+    def stage_result(self, pinned):
+        """Inside a capture, behind the last step: the result span -> `pinned` (a pinned host buffer allocated before the
+        capture opened) as a copy node of the graph.  A replayed search then costs one stream synchronise and no copy
+        call on the host (the pageable read-back was ~20 us of a 1 ms one-image search: tools/beam64_probe.py)."""
+        n = self._result_span.numel()
+        if pinned is None or pinned.numel() < n:
+            return
+        self._result_host = pinned[:n]
+        self._result_host.copy_(self._result_span, non_blocking=True)
+
     def finish(self):
         cap, n_img, beam, T = self.cap, self.n_img, self.beam, self.T
         cap.cont_weights, cap.senti_weights, cap.cont_senti_weights = [], [], []
         # executed steps as the reference counts them: up to and including the step after which nobody was live
         steps = cap.last_beam_steps
-        hb = self._result_span.cpu().numpy()             # one device->host copy: scores, words, lengths, counters
+        if self._result_host is not None:                # replayed from a graph that ends in the copy (stage_result)
+            torch.cuda.current_stream().synchronize()
+            hb = self._result_host.numpy()
+        else:
+            hb = self._result_span.cpu().numpy()         # one device->host copy: scores, words, lengths, counters
 
         def host(name):
             o, dt, shape = self._result_views[name]
