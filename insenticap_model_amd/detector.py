@@ -337,7 +337,9 @@ class Detector(nn.Module):
         """One image: detect its sentiment, then beam search (decoder.py:182-192)."""
         self.eval()
         att_feats = att_feats.unsqueeze(0)
-        senti_label, _, det_img_sentis, _ = self.senti_detector.sample(att_feats, self.senti_threshold)
+        # the label stays on the device until the search is queued: the category name (a host read) is looked up behind the
+        # search's own read-back instead of draining the device between the two (tools/eval_loop_probe.py)
+        senti_label, _, _ = self.senti_detector.sample_device(att_feats, self.senti_threshold)
         captions, _ = self.captioner.sample(fc_feats, att_feats, sentis_tensor, senti_label, beam_size,
                                             decoding_constraint, self.max_seq_len)
-        return captions, det_img_sentis
+        return captions, self.senti_detector.names(senti_label)

@@ -44,14 +44,25 @@ class SentimentDetector(nn.Module):
         return logits, weighted.reshape(B, h, w)
 
     @torch.no_grad()
-    def sample(self, features, senti_threshold=0):
-        """-> (labels [B] int64, sentiment map [B,h,w], category names, max-probabilities [B]);
-        a maximum probability below the threshold falls back to `neutral`."""
+    def sample_device(self, features, senti_threshold=0):
+        """`sample` without the category names: (labels [B] int64, sentiment map, max-probabilities), all on the device -
+        nothing is read back, so the caller can queue its next step (the beam search takes the labels as a tensor) before
+        the host looks at them (`names`)."""
         self.eval()
         logits, maps = self.forward(features)
         scores, labels = logits.softmax(dim=-1).max(dim=-1)
         labels = torch.where(scores < senti_threshold, torch.full_like(labels, self.neu_idx), labels)
-        return labels, maps, [self.sentiment_categories[int(i)] for i in labels], scores
+        return labels, maps, scores
+
+    def names(self, labels):
+        return [self.sentiment_categories[i] for i in labels.tolist()]          # (one read-back, not one per label)
+
+    @torch.no_grad()
+    def sample(self, features, senti_threshold=0):
+        """-> (labels [B] int64, sentiment map [B,h,w], category names, max-probabilities [B]);
+        a maximum probability below the threshold falls back to `neutral`."""
+        labels, maps, scores = self.sample_device(features, senti_threshold)
+        return labels, maps, self.names(labels), scores
 
     def get_optim_criterion(self, lr, weight_decay=0):
         return torch.optim.Adam(self.parameters(), lr=lr, weight_decay=weight_decay), nn.CrossEntropyLoss()
