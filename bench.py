@@ -355,6 +355,24 @@ def bench_xe_train(cap, dev, rank, world, iters=6, B=128, s2s_rows=80, curve='we
     return out
 
 
+def bench_xe_exchange_one_rank(timeout=240):
+    """N=1 without a launcher has no process group, so `xe_train` cannot time the gradient exchange.  A CHILD process
+    (never an exec of this GPU-initialised one) runs the same eager merged XE step (B=128+80) under a ONE-RANK RCCL group:
+    bucketed exchange (dp.GradSink), the buckets with their collectives skipped, and one flat all-reduce.  With one rank
+    nothing crosses a link: the figure is the fixed cost of issuing and waiting for the collectives."""
+    import subprocess
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(29000 + os.getpid() % 2000))
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'profile_xe_dp.py'), '16', '128', '--json'],
+                       env=env, capture_output=True, text=True, timeout=timeout)
+    if r.returncode != 0:
+        raise RuntimeError('one-rank child rc %d: %s' % (r.returncode, r.stderr[-200:]))
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    out['note'] = 'one-rank RCCL group in a child process: the fixed cost of the collectives, nothing to transfer'
+    return out
+
+
 def bench_grad_allreduce(cap, dev, world, reps=10):
     """The gradient exchange alone: one sum-all-reduce of the flat 22 063 379-float arena (RCCL over xGMI), nothing
     to overlap it with (no gradient is final before BPTT ends) - this is the exposed time inside every DP iteration."""
@@ -1082,11 +1100,14 @@ def run(args):
             'exact_fp32_captions_per_s': g('exact_fp32_engine', 'captions_per_s'),
             'xe128_ms': g('xe_train', 'ms_per_iter'), 'xe128_ss025_ms': g('xe_train_ss025', 'ms_per_iter'),
             'xe512_ms': g('xe_train_by_batch', '512'), 'xe1024_ms': g('xe_train_strong', 'ms_per_iter'),
-            'exposed_allreduce_ms': g('xe_train', 'exposed_allreduce_ms'),
+            'exposed_allreduce_ms': (g('xe_train', 'exposed_allreduce_ms') if g('xe_train', 'exposed_allreduce_ms') is not None
+                                     else g('xe_exchange_one_rank', 'exposed_allreduce_ms')),
+            'exposed_allreduce_ranks': (world if g('xe_train', 'exposed_allreduce_ms') is not None
+                                        else g('xe_exchange_one_rank', 'ranks')),
             'rl512_ms': g('rl_iteration', 'ms_per_iter'),
             'r196_greedy_captions_per_s': g('r196', 'greedy_B4096', 'captions_per_s'),
             'r196_scan_frac_of_hbm': g('r196', 'scan', '4096', 'frac_of_8tbs'),
-            'r196_xe128_ms': g('r196', 'xe_train_B128', 'ms_per_iter'), 'r196_beam5_p50_ms': g('r196', 'beam5', 'per_image_p50_ms'),
+            'r196_xe128_ms': g('r196', 'xe_train_B128', 'ms_per_iter'), 'r196_beam5_full20_p50_ms': g('r196', 'beam5', 'full_search_p50_ms'),
             'xe128_epoch_ms_per_iter': g('epoch_loops', 'xe128_resident_ms_per_iter'),
             'rl512_epoch_ms_per_iter': g('epoch_loops', 'rl512_resident_ms_per_iter'),
         }
@@ -1124,6 +1145,8 @@ def run(args):
                 'ms_per_iter'] for b in (512,)}))
             jobs.append(('r196', lambda: bench_r196(cap, dev)))
             jobs.append(('epoch_loops', lambda: bench_epoch_loops(dev)))
+            if not dist_on():
+                jobs.append(('xe_exchange_one_rank', bench_xe_exchange_one_rank))
         if dist_on():
             jobs.append(('grad_allreduce', lambda: bench_grad_allreduce(cap, dev, world)))
             if 512 % world == 0 and 80 % world == 0:

@@ -2,8 +2,9 @@
 """The eager merged XE step under a ONE-RANK RCCL group (the data-parallel code path on a one-GPU box): ms per iteration
 with the bucketed exchange, with the buckets' collectives skipped, and with one flat all-reduce; under rocprofv3
 --kernel-trace the last iterations are the bucketed form.
-    python tools/profile_xe_dp.py [iterations [batch]]"""
-import os, sys, time
+    python tools/profile_xe_dp.py [iterations [batch]] [--json]
+--json: the last line of stdout is one JSON object (bench.py's `xe_exchange_one_rank` job reads it)."""
+import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
 os.environ.setdefault('MASTER_PORT', '29655')
@@ -17,8 +18,10 @@ from insenticap_model_amd.train import xe_train_step
 dev = torch.device('cuda:0')
 torch.cuda.set_device(0)
 dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
-iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20
-B = int(sys.argv[2]) if len(sys.argv) > 2 else 128
+as_json = '--json' in sys.argv
+argv = [a for a in sys.argv[1:] if a != '--json']
+iters = int(argv[0]) if len(argv) > 0 else 20
+B = int(argv[1]) if len(argv) > 1 else 128
 V, R, T = bench.V, bench.R, bench.T
 cap = Captioner(synth.make_idx2word(V), synth.SENTIMENT_CATEGORIES, synth.DEFAULT_SETTINGS)
 cap.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_weights(V, synth.DEFAULT_SETTINGS).items()})
@@ -53,4 +56,11 @@ dry = run(iters)
 sink.exchange = True
 buck2 = run(iters)
 print('ms per iteration: flat %.3f  bucketed %.3f / %.3f  buckets without their collectives %.3f' % (flat, buck, buck2, dry))
+if as_json:
+    best = min(buck, buck2)
+    print(json.dumps(dict(ranks=1, backend=dist.get_backend(), batch_per_gpu=B, seq2seq_rows_per_gpu=80, iters=iters,
+                          bucketed_ms_per_iter=round(best, 3), flat_ms_per_iter=round(flat, 3),
+                          no_exchange_ms_per_iter=round(dry, 3), exposed_allreduce_ms=round(best - dry, 3),
+                          exposed_allreduce_flat_ms=round(flat - dry, 3), buckets=len(sink.buckets) if hasattr(sink, 'buckets') else None,
+                          all_reduce_mb=round(arena.nbytes / 1e6, 2))))
 dist.destroy_process_group()
