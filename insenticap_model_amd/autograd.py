@@ -58,9 +58,22 @@ def _train_forward(cap, mode, fc, att, cpt_words, senti_words, tokens_in, senti_
     S = _Saved()
     S.p, S.P, S.mode, S.B, S.T = p, P, mode, B, T
     new, zeros = cap._new, cap._zeros
+    # Ragged unroll (Captioner.row_counts): the batch is sorted by caption length (the reference's collates,
+    # dataloader.py:17,37,68,124), so the rows still inside their caption at step t are the prefix [0, counts[t]) - step t
+    # runs on those rows only.  The criteria never read a position behind a caption's end (XECriterion's mask,
+    # captioner.py:431-436), and its gradient is exactly zero: same loss, same gradients.  The [T,B] layout stays; what a
+    # skipped row would have written must read as ZERO (gradients) or at least finite (activations next to a zero
+    # gradient in the contractions over all T*B rows) - every buffer such a row belongs to comes out of a fill.
+    counts = cap.__dict__.get('_row_counts')
+    if counts is not None and (sampling or lazy is None or (cap.training and ss_prob > 0.0) or len(counts) != T
+                               or counts[0] != B or ops.TIMER.armed):
+        counts = None
+    S.row_counts = counts
     S.h1, S.c1, S.h2, S.c2 = zeros(4, T + 1, B, H).unbind(0)             # slot 0 = initial zero state (one fill)
-    S.g1, S.g2 = new(T, B, 4 * H), new(T, B, 4 * H)
-    S.xt, S.tok = new(T, B, Wd), torch.empty(T, B, dtype=torch.int64, device=cap._dev)
+    S.g1, S.g2 = new(T, B, 4 * H), new(T, B, 4 * H)                      # (read back row by row, by the same step only)
+    if counts is not None:
+        new = zeros
+    S.xt, S.tok = cap._new(T, B, Wd), torch.empty(T, B, dtype=torch.int64, device=cap._dev)   # (every row written)
     if has_c:
         S.qa, S.v, S.aC = new(T, B, A), new(T, B, E), new(B, T, P.R)
     if has_s:
@@ -74,8 +87,8 @@ def _train_forward(cap, mode, fc, att, cpt_words, senti_words, tokens_in, senti_
     # per-step tile statistics [T, B, n_tile]: the logits become log-probs in ONE launch after the last step
     # (isc_logsoftmax_apply_steps) - in every form of the unroll: the draws of the sampled and the scheduled-sampling
     # forms read a step's RAW logits with its statistics (20 + 20 + 20 normalising launches per RL iteration -> 3)
-    pm_st, ps_st = new(T, B, n_tile), new(T, B, n_tile)
-    pi_st = new(T, B, n_tile, dtype=torch.int32)
+    pm_st, ps_st = cap._new(T, B, n_tile), cap._new(T, B, n_tile)
+    pi_st = cap._new(T, B, n_tile, dtype=torch.int32)
     fed_known_ = not sampling and not (cap.training and ss_prob > 0.0)
     out = None if (lazy is not None and fed_known_) else new(B, T, V)     # (lazy + every fed token known: raw logits only)
     emb = p['word_embed.0.weight']
@@ -142,6 +155,8 @@ def _train_forward(cap, mode, fc, att, cpt_words, senti_words, tokens_in, senti_
             if has_c and has_s:
                 ws['z'], ws['f'] = S.z[t], S.f[t]
             logits = out[:, t] if pm_all is None else None
+            if counts is not None:
+                plan.rows = counts[t]
             cap._step(p, P, ws, S.xt[t], (S.h1[t], S.h2[t]), (S.c1[t], S.c2[t]),
                       (S.h1[t + 1], S.h2[t + 1]), (S.c1[t + 1], S.c2[t + 1]),
                       S.aC[:, t] if has_c else None, S.aS[:, t] if has_s else None,
@@ -155,7 +170,7 @@ def _train_forward(cap, mode, fc, att, cpt_words, senti_words, tokens_in, senti_
         S.lazy = None
         if pm_all is not None:
             hs = S.hdrop if S.hdrop is not None else S.h2[1:]
-            rawl = new(T, B, V)
+            rawl = cap._new(T, B, V)                           # (every row is written: no fill in the ragged form)
             ops.vocab_fwd(hs.reshape(T * B, H), p['classifier.weight'], p['classifier.bias'], pm_all.view(T * B, n_tile),
                           ps_all.view(T * B, n_tile), pi_all.view(T * B, n_tile), rawl.view(T * B, V))
             if lazy is not None:
@@ -292,6 +307,12 @@ def _backward(cap, S, dlogp, d_fc_feats, d_cpt_feats, sparse=()):
 
     Wih1, Whh1 = p['att_lstm.weight_ih'], p['att_lstm.weight_hh']
     Wih2, Whh2 = p['lang_lstm.weight_ih'], p['lang_lstm.weight_hh']
+    # ragged unroll (see _train_forward): step t sweeps rows [0, counts[t]); everything a skipped row would have written
+    # - its gradients, and the carries a row reads at the LAST step of its caption - is zero from a fill
+    counts = getattr(S, 'row_counts', None)
+    new_full = new
+    if counts is not None:
+        new = zeros
     dG1, dG2 = new(T, B, 4 * H), new(T, B, 4 * H)
     # d feat of every step is kept ([T,B,E]): where it is the scan's output gradient, dV = sum_t alpha_t x dout_t is
     # formed once after the sweep (ops.attn_dv_from_alpha) instead of a read-modify-write of [B,R,E] at every step
@@ -300,12 +321,12 @@ def _backward(cap, S, dlogp, d_fc_feats, d_cpt_feats, sparse=()):
     dc1_rec, dc2_rec = [new(B, H), new(B, H)], [new(B, H), new(B, H)]
     if has_c:
         dqa, dv_all = new(T, B, A), (new(T, B, E) if gate else d_feat_all)
-        dP_att, dV_att = new(B, P.R, A), new(B, P.R, E)
+        dP_att, dV_att = new_full(B, P.R, A), new_full(B, P.R, E)
         de_c = new(T, B, P.R)           # d e of every step: dP is formed once after the sweep (ops.attn_dp_from_de)
         dwc_rows = new(B, A)
     if has_s:
         dqw, ds_all = new(T, B, A), (new(T, B, E) if gate else d_feat_all)
-        dP_w, dV_w = new(B, P.Mw, A), new(B, P.Mw, Wd)
+        dP_w, dV_w = new_full(B, P.Mw, A), new_full(B, P.Mw, Wd)
         de_s = new(T, B, P.Mw)
         dws_rows = new(B, A)
     if gate:
@@ -347,6 +368,10 @@ def _backward(cap, S, dlogp, d_fc_feats, d_cpt_feats, sparse=()):
         for t in range(T - 1, -1, -1):
             cur, nxt = t & 1, (t + 1) & 1
             bp.first, bp.last = int(t == T - 1), int(t == 0)
+            if counts is not None:
+                # (no "first" step: a row's own last step is wherever its caption ends - carries and time-accumulated
+                # buffers start from the fill instead)
+                bp.rows, bp.first = counts[t], 0
             bp.g1, bp.c1_prev, bp.c1 = S.g1[t].data_ptr(), S.c1[t].data_ptr(), S.c1[t + 1].data_ptr()
             bp.g2, bp.c2_prev, bp.c2 = S.g2[t].data_ptr(), S.c2[t].data_ptr(), S.c2[t + 1].data_ptr()
             bp.dhd, bp.dG1, bp.dG2 = dhd[t].data_ptr(), dG1[t].data_ptr(), dG2[t].data_ptr()
@@ -367,6 +392,7 @@ def _backward(cap, S, dlogp, d_fc_feats, d_cpt_feats, sparse=()):
                 bp.z, bp.beta, bp.dz = S.z[t].data_ptr(), S.bG[:, t:t + 1].data_ptr(), dz[t].data_ptr()
             ops.step_bwd(bp)
 
+    new = new_full
     if has_c:
         ops.attn_dv_from_alpha(S.aC, dv_all, dV_att)
         ops.attn_dp_from_de(P.att_p3, S.qa, p['attention.cont_att.att_alpha.weight'], de_c, dP_att)

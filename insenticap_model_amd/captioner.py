@@ -708,6 +708,31 @@ class Captioner(nn.Module):
                 self.__dict__['_token_logprobs'] = prev
         return scope()
 
+    def row_counts(self, lengths, T=None):
+        """`with captioner.row_counts(lengths):` - the teacher-forced unroll WITH gradients inside (one `forward_xe` or
+        `forward_seq2seq` call under `token_logprobs()`, scheduled sampling off) runs step t on the rows whose caption has
+        not ended yet.  `lengths`: XECriterion's host list (captioner.py:431-436: row i counts for steps < lengths[i]),
+        sorted longest first as the reference's collates hand it over (dataloader.py:17,37,68,124) - anything else (a device
+        tensor, an unsorted list) leaves the unroll as it is.  Loss and gradients are the full unroll's: positions behind
+        a caption's end are masked by the criterion, so nothing reads them and their gradient is exactly zero."""
+        import contextlib
+        counts = None
+        if isinstance(lengths, (list, tuple)) and len(lengths) > 0 and getattr(self, 'ragged_unroll', False):
+            ls = [int(x) for x in lengths]
+            steps = max(ls) if T is None else T
+            if all(a >= b for a, b in zip(ls, ls[1:])) and ls[-1] >= 1:
+                counts = [sum(1 for x in ls if x > t) for t in range(steps)]
+
+        @contextlib.contextmanager
+        def scope():
+            prev = self.__dict__.get('_row_counts')
+            self.__dict__['_row_counts'] = counts
+            try:
+                yield self
+            finally:
+                self.__dict__['_row_counts'] = prev
+        return scope()
+
     def forward_xe(self, fc_feats, att_feats, cpt_words, captions, senti_labels, ss_prob=0.0, _masks=None, _targets=None):
         """(_targets: test hook for token_logprobs() - the criterion's targets when `captions` carries replayed FED tokens
         instead of the ground truth; default captions[:, 1:].)"""

@@ -71,7 +71,7 @@ def xe_forward_backward(captioner, optim, xe_crit, da_crit, fact, xe_senti_label
             pred, pred2 = captioner(fc_feats, att_feats, cpts_tensor, caps_tensor, xe_senti_labels, ss_prob,
                                     s_caps, s_cpts, s_sentis, s_labels, ss_prob, mode='xe_seq2seq')
     else:
-        with captioner.token_logprobs():
+        with captioner.token_logprobs(), captioner.row_counts(lengths):
             pred = captioner(fc_feats, att_feats, cpts_tensor, caps_tensor, xe_senti_labels, ss_prob, mode='xe')
     if callable(weights3):            # (dp_shares_async: the counts' all-reduce ran next to the unroll; wait for it here)
         weights3 = weights3()
@@ -88,7 +88,7 @@ def xe_forward_backward(captioner, optim, xe_crit, da_crit, fact, xe_senti_label
         s_caps, s_lengths, s_cpts, s_sentis, s_labels = scs
 
         def seq2seq_unroll():
-            with captioner.token_logprobs():
+            with captioner.token_logprobs(), captioner.row_counts(s_lengths):
                 pred2 = captioner(s_caps, s_cpts, s_sentis, s_labels, ss_prob, mode='seq2seq')
             return share(_xe_loss(xe_crit, pred2, s_caps[:, 1:], s_lengths), w_s2s)
         if overlap_unrolls and device.type == 'cuda':
