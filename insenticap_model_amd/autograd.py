@@ -168,7 +168,34 @@ def _train_forward(cap, mode, fc, att, cpt_words, senti_words, tokens_in, senti_
                 rs.xt_next = S.xt[t + 1].data_ptr() if t + 1 < T else None
                 ops.rollout_finalize(rs)
         S.lazy = None
-        if pm_all is not None:
+        S.packed = None
+        if pm_all is not None and counts is not None and lazy is not None and sum(counts) < T * B:
+            # ragged: the classifier and everything behind it see the N = sum(counts) rows inside their captions only -
+            # h_lang gathered into packed time-major order (row n = (t, b), b < counts[t]), the statistics, raw logits,
+            # log p(target) and - in the backward - d logits, d h and the classifier's gradients over N rows
+            # (the row indices are built on the device from the T counts: a host-built index would travel through a
+            # freshly pinned buffer every iteration; N is known here, so nonzero needs no read-back)
+            N = int(sum(counts))
+            cnt = ops.to_device(torch.tensor(counts, dtype=torch.int64), cap._dev)
+            live = torch.arange(B, device=cap._dev).unsqueeze(0) < cnt.unsqueeze(1)              # [T,B]
+            i_tb = torch.nonzero_static(live.reshape(-1), size=N).reshape(-1)                    # t*B + b, time-major
+            idx = torch.stack([i_tb, (i_tb % B) * T + i_tb // B])
+            # (N rounded up to whole tiles / k-blocks of the split-f16 kernels - the row count is the contraction length of
+            # the classifier's dW; the pad rows are zero in h_lang and in d logits)
+            Np = (N + 255) // 256 * 256
+            hs = zeros(Np, H)
+            torch.index_select((S.hdrop if S.hdrop is not None else S.h2[1:]).reshape(T * B, H), 0, idx[0], out=hs[:N])
+            pm_p, ps_p = cap._new(Np, n_tile), cap._new(Np, n_tile)
+            pi_p = cap._new(Np, n_tile, dtype=torch.int32)
+            rawl = cap._new(Np, V)
+            ops.vocab_fwd(hs, p['classifier.weight'], p['classifier.bias'], pm_p, ps_p, pi_p, rawl)
+            ids_p = lazy.reshape(-1).index_select(0, idx[1]).contiguous()
+            tlp_p = cap._new(N)
+            ops.gather_logp_raw(rawl, V, 0, N, 1, V, pm_p, ps_p, N, ids_p, tlp_p)
+            tlp = zeros(B * T).index_copy_(0, idx[1], tlp_p).view(B, T)
+            S.packed = dict(N=N, Np=Np, idx_tb=idx[0], idx_bt=idx[1], hs=hs, raw=rawl, pm=pm_p, ps=ps_p, tlp=tlp)
+            del rawl
+        elif pm_all is not None:
             hs = S.hdrop if S.hdrop is not None else S.h2[1:]
             rawl = cap._new(T, B, V)                           # (every row is written: no fill in the ragged form)
             ops.vocab_fwd(hs.reshape(T * B, H), p['classifier.weight'], p['classifier.bias'], pm_all.view(T * B, n_tile),
@@ -186,6 +213,9 @@ def _train_forward(cap, mode, fc, att, cpt_words, senti_words, tokens_in, senti_
         S.sample = (seq, seq_masks, raw, alive)
     cap._set_weights(S.aC if has_c else None, S.aS if has_s else None,
                      S.bG if (has_c and has_s) else None, T)
+    if S.packed is not None:
+        S.logp, S.lazy_ids, S.lazy_live = None, lazy.contiguous(), None
+        return S.packed.pop('tlp'), S
     if S.lazy is not None:
         S.pm, S.ps = pm_st, ps_st
         S.lazy_live = None
@@ -239,7 +269,8 @@ def _backward(cap, S, dlogp, d_fc_feats, d_cpt_feats, sparse=()):
 
     # ---- classifier + log-softmax: outside the recurrence, all T*B rows at once (time-major rows)
     Vp = _pad32(V)
-    dlogits = new(TB, Vp)
+    pk = getattr(S, 'packed', None)
+    dlogits = new(TB if pk is None else pk['Np'], Vp)
     # everything the sweep wants zeroed comes out of ONE fill (each fill is a launch of its own, ~4.5 us at any size)
     n_lab = p['senti_label_embed.0.weight'].shape[0] if P.label_e is not None else 1
     f32 = torch.float32
@@ -257,7 +288,19 @@ def _backward(cap, S, dlogp, d_fc_feats, d_cpt_feats, sparse=()):
             d_fc_feats = d_fc_feats * gs[0]
         if d_cpt_feats is not None:
             d_cpt_feats = d_cpt_feats * gs[0]
-    if dlogp is None and not sparse:
+    if pk is not None:
+        # ragged, packed classifier block (see _train_forward): d logits over the N rows inside their captions
+        N = pk['N']
+        sp = [(i.reshape(-1).index_select(0, pk['idx_bt']).contiguous(), c.reshape(-1).index_select(0, pk['idx_bt']).contiguous())
+              for i, c in sparse]
+        if sp:
+            ops.logsoftmax_bwd_raw(pk['raw'], V, 0, N, 1, V, pk['pm'], pk['ps'], N, sp, dlogits,
+                                   scale=gs[0:1] if gs is not None else None, out_step_rows=N)
+            if pk['Np'] > N:
+                dlogits[N:].zero_()
+        else:
+            dlogits.zero_()
+    elif dlogp is None and not sparse:
         dlogits.zero_()
     elif getattr(S, 'lazy', None) is not None:               # the log-probs were never formed: softmax from raw logits + stats
         rl, ld_b, ld_t = S.lazy
@@ -267,11 +310,12 @@ def _backward(cap, S, dlogp, d_fc_feats, d_cpt_feats, sparse=()):
         ops.logsoftmax_bwd_sparse(dlogp, S.logp, list(sparse), dlogits, B * T, V, remap_T=T,
                                   scale=gs[0:1] if gs is not None else None)
     Wc = p['classifier.weight']
-    hdrop_tb = (S.hdrop if S.hdrop is not None else S.h2[1:]).reshape(TB, H)
-    dhd = new(TB, H)
+    hdrop_tb = (S.hdrop if S.hdrop is not None else S.h2[1:]).reshape(TB, H) if pk is None else pk['hs']
+    n_rows = TB if pk is None else pk['Np']
+    dhd = new(n_rows, H)
     # d h = d logits . W_c contracts over the vocabulary; the split-f16 kernels want a multiple of 32
     Vm = V // 32 * 32
-    if Vp != V and TB >= 8192:
+    if Vp != V and n_rows >= 8192:
         # d logits is already zero-padded to Vp columns: give W_c the matching zero rows (a 20 MB copy; worth it from
         # ~100 GFLOP on, where the large kernels run the contraction)
         # NOT inside the weights scope: a scope keeps (pointer, planes) of every W operand it sees and the optimizer
@@ -300,6 +344,8 @@ def _backward(cap, S, dlogp, d_fc_feats, d_cpt_feats, sparse=()):
     db = new(Vp)
     ops.colsum(dlogits, db)
     G['classifier.bias'] = db[:V].contiguous() if Vp != V else db
+    if pk is not None:          # d h_lang back in [T,B] order, zero behind the captions' ends
+        dhd = zeros(TB, H).index_copy_(0, pk['idx_tb'], dhd[:pk['N']])
     if S.hdrop is not None:     # nn.Dropout on h_lang (captioner.py:182)
         mk = torch.stack(S.out_masks).reshape(TB, H)
         ops.relu_mask_bwd(dhd, None, dhd, keep_mask=mk, scale=S.out_scale)
@@ -566,7 +612,8 @@ class DecodeFn(torch.autograd.Function):
         cap, S = ctx.cap, ctx.S
         sparse, ctx._isc_sparse = ctx._isc_sparse, []
         with torch.no_grad():
-            if getattr(S, 'lazy', None) is not None:         # dlogp is d log p(id) [B,T]: one column per row
+            if getattr(S, 'lazy', None) is not None or getattr(S, 'packed', None) is not None:
+                # dlogp is d log p(id) [B,T]: one column per row
                 if dlogp is not None:
                     coef = dlogp.contiguous() if S.lazy_live is None else (dlogp * S.lazy_live).contiguous()
                     sparse, dlogp = [(S.lazy_ids, coef)], None
