@@ -276,8 +276,10 @@ def bench_xe_train(cap, dev, rank, world, iters=6, B=128, s2s_rows=80, curve='we
     cap.train()
     optim, xe_crit, da_crit = cap.get_optim_criterion(4e-4)
     arena = dp.GradArena(cap.parameters()) if dist_on() else None
-    d = synth.make_inputs(B, V, synth.DEFAULT_SETTINGS, regions=regions, seq_len=T, seed=500 + rank)
-    s = synth.make_inputs(s2s_rows, V, synth.DEFAULT_SETTINGS, regions=regions, seq_len=T, seed=600 + rank)
+    # (longest caption first, as the reference's collates hand batches over: dataloader.py:17,37)
+    d = synth.sort_by_length(synth.make_inputs(B, V, synth.DEFAULT_SETTINGS, regions=regions, seq_len=T, seed=500 + rank))
+    s = synth.sort_by_length(synth.make_inputs(s2s_rows, V, synth.DEFAULT_SETTINGS, regions=regions, seq_len=T,
+                                               seed=600 + rank))
     tt = lambda x: torch.from_numpy(x).to(dev)
     fact = (None, tt(d['fc_feats']), tt(d['att_feats']), (tt(d['captions']), d['lengths']), tt(d['cpt_words']))
     labels = tt(d['senti_labels'])
@@ -333,6 +335,23 @@ def bench_xe_train(cap, dev, rank, world, iters=6, B=128, s2s_rows=80, curve='we
                 sys.stderr.write('bench.py: graph capture failed under the process group: %r\n' % (e,))
                 raise FatalUnderGroup(repr(e)[:300])
             graph_error, el, replayed = repr(e)[:300], el_eager, 0
+        # third form, large batches without a group: the eager step with one chain per unroll and the RAGGED unroll
+        # (Captioner.row_counts: step t runs on the rows whose caption has not ended, the classifier block over the
+        # sum(lengths) rows inside their captions; same loss, same gradients - tests/test_gpu_ragged.py).  Not
+        # graph-servable: the row counts are baked into the launches.
+        el_ragged = None
+        if not dist_on() and B >= 512 and ss_prob == 0.0:
+            keep = (getattr(cap, 'pair_unrolls', None), getattr(cap, 'ragged_unroll', False))
+            cap.pair_unrolls, cap.ragged_unroll = False, True
+            try:
+                for _ in range(3):
+                    step()
+                n3 = max(iters, 10)     # (4 iterations after a change of form read 5 % high: allocator and plan warm-up)
+                el_ragged = timed_region(step, n3, dev) * iters / n3
+            except Exception as e:      # noqa: BLE001 - the other two forms stand on their own
+                graph_error = (graph_error or '') + ' ragged: ' + repr(e)[:200]
+            finally:
+                cap.pair_unrolls, cap.ragged_unroll = keep
     cap.eval()
     for q in cap.parameters():          # the arena's views must not outlive this measurement
         q.grad = None
@@ -347,6 +366,15 @@ def bench_xe_train(cap, dev, rank, world, iters=6, B=128, s2s_rows=80, curve='we
                             'collectives between them); %d of %d timed iterations were replays' % (replayed, iters)),
                eager_ms_per_iter=round(el_eager / iters * 1e3, 2), graph_ms_per_iter=round(el / iters * 1e3, 2),
                grad_allreduce_mb=round(arena.nbytes / 1e6, 2) if arena else 0.0, all_reduces_per_iter=per_iter)
+    out['active_positions'] = round(sum(d['lengths']) / float(T * B), 3)
+    if el_ragged is not None:
+        out['ragged_eager_ms_per_iter'] = round(el_ragged / iters * 1e3, 2)
+        if el_ragged < best:
+            out['ms_per_iter'] = out['ragged_eager_ms_per_iter']
+            out['captions_per_s'] = round(world * B * iters / el_ragged, 1)
+            out['served_from'] = ('eager step, one chain per unroll, ragged unroll (captioner.ragged_unroll = True: per-step '
+                                  'launches and the classifier block on the positions inside the captions only; batches '
+                                  'sorted by length as the reference\'s collates sort them)')
     if exposed is not None:
         out['exposed_allreduce_ms'] = exposed['bucketed_ms']
         out['exchange'] = exposed
@@ -1100,6 +1128,7 @@ def run(args):
             'exact_fp32_captions_per_s': g('exact_fp32_engine', 'captions_per_s'),
             'xe128_ms': g('xe_train', 'ms_per_iter'), 'xe128_ss025_ms': g('xe_train_ss025', 'ms_per_iter'),
             'xe512_ms': g('xe_train_by_batch', '512'), 'xe1024_ms': g('xe_train_strong', 'ms_per_iter'),
+            'xe1024_graph_ms': g('xe_train_strong', 'graph_ms_per_iter'),
             'exposed_allreduce_ms': (g('xe_train', 'exposed_allreduce_ms') if g('xe_train', 'exposed_allreduce_ms') is not None
                                      else g('xe_exchange_one_rank', 'exposed_allreduce_ms')),
             'exposed_allreduce_ranks': (world if g('xe_train', 'exposed_allreduce_ms') is not None

@@ -161,6 +161,21 @@ def make_inputs(batch, vocab_size, settings, regions=36, n_cpt=5, n_senti_words=
     return d
 
 
+def sort_by_length(d):
+    """make_inputs' batch with the longest caption first (stable), every per-row array permuted alike - the order the
+    reference's collates hand a batch over in (dataloader.py:17,37,68,124)."""
+    order = sorted(range(len(d['lengths'])), key=lambda i: -d['lengths'][i])
+    out = {}
+    for k, v in d.items():
+        if k == 'lengths':
+            out[k] = [v[i] for i in order]
+        elif isinstance(v, np.ndarray) and v.shape[:1] == (len(order),):
+            out[k] = np.ascontiguousarray(v[order])
+        else:
+            out[k] = v
+    return out
+
+
 def make_cider_data(n_images, vocab_size, batch, seq_len=20, n_refs=5, seed=7):
     """Synthetic RL-reward inputs: per image `n_refs` ground-truth captions
     [<SOS>, 8..18 Zipf-distributed ids, <EOS>]; a batch of sampled / greedy roll-out rows built by

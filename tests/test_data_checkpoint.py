@@ -370,3 +370,18 @@ def test_resume_from_reference_checkpoint_reproduces_its_next_step(golden):
             assert (diff > 4e-5).mean() < 0.2, (k, float((diff > 4e-5).mean()))
         else:
             assert diff.max() <= 1e-6, (k, float(diff.max()))
+
+
+def test_synthetic_batches_sorted_by_length_like_the_reference_collates():
+    """synth.sort_by_length: longest caption first (stable), every per-row array permuted alike (dataloader.py:17,37)."""
+    import numpy as np
+    from insenticap_model_amd import synth
+    d = synth.make_inputs(12, 64, synth.TINY_SETTINGS, regions=6, seq_len=8, seed=3)
+    s = synth.sort_by_length(d)
+    assert s['lengths'] == sorted(d['lengths'], reverse=True) and s['lengths'] != d['lengths']
+    order = sorted(range(12), key=lambda i: -d['lengths'][i])
+    for k in ('captions', 'fc_feats', 'att_feats', 'cpt_words', 'senti_words', 'senti_labels'):
+        np.testing.assert_array_equal(s[k], d[k][order])
+    for b, L in enumerate(s['lengths']):
+        assert s['captions'][b, L] == 2 and (s['captions'][b, L + 1:] == 0).all()
+

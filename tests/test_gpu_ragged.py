@@ -26,25 +26,11 @@ def make(cfg, ragged, seed=9):
     return cap.to(DEV).eval()
 
 
-def sorted_rows(d):
-    """Longest caption first (stable), every per-row array permuted alike - what the reference's collates hand over."""
-    order = sorted(range(len(d['lengths'])), key=lambda i: -d['lengths'][i])
-    out = {}
-    for k, v in d.items():
-        if k == 'lengths':
-            out[k] = [v[i] for i in order]
-        elif isinstance(v, np.ndarray) and v.shape[:1] == (len(order),):
-            out[k] = np.ascontiguousarray(v[order])
-        else:
-            out[k] = v
-    return out
-
-
 def batch(cfg, seed, sort=True):
     d = synth.make_inputs(cfg['B'], cfg['V'], cfg['st'], regions=cfg['R'], seq_len=cfg['T'], seed=seed)
     s = synth.make_inputs(cfg['S'], cfg['V'], cfg['st'], regions=cfg['R'], seq_len=cfg['T'], seed=seed + 1000)
     if sort:
-        d, s = sorted_rows(d), sorted_rows(s)
+        d, s = synth.sort_by_length(d), synth.sort_by_length(s)
     t = lambda x: torch.from_numpy(x).to(DEV)      # noqa: E731
     fact = (t(d['fc_feats']), t(d['att_feats']), t(d['captions']), d['lengths'], t(d['cpt_words']))
     scs = (t(s['captions']), s['lengths'], t(s['cpt_words']), t(s['senti_words']), t(s['senti_labels']))

@@ -15,16 +15,9 @@ iters = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 V, R, T = bench.V, bench.R, bench.T
 
 
-def sorted_rows(d):
-    order = sorted(range(len(d['lengths'])), key=lambda i: -d['lengths'][i])
-    return {k: ([v[i] for i in order] if k == 'lengths' else
-                (np.ascontiguousarray(v[order]) if isinstance(v, np.ndarray) and v.shape[:1] == (len(order),) else v))
-            for k, v in d.items()}
-
-
 for B in (128, 512, 1024):
-    d = sorted_rows(synth.make_inputs(B, V, synth.DEFAULT_SETTINGS, regions=R, seq_len=T, seed=500))
-    s = sorted_rows(synth.make_inputs(80, V, synth.DEFAULT_SETTINGS, regions=R, seq_len=T, seed=600))
+    d = synth.sort_by_length(synth.make_inputs(B, V, synth.DEFAULT_SETTINGS, regions=R, seq_len=T, seed=500))
+    s = synth.sort_by_length(synth.make_inputs(80, V, synth.DEFAULT_SETTINGS, regions=R, seq_len=T, seed=600))
     tt = lambda x: torch.from_numpy(x).to(dev)
     fact = (None, tt(d['fc_feats']), tt(d['att_feats']), (tt(d['captions']), d['lengths']), tt(d['cpt_words']))
     scs = ((tt(s['captions']), s['lengths']), tt(s['cpt_words']), tt(s['senti_words']), tt(s['senti_labels']))
