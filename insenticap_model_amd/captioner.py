@@ -708,6 +708,18 @@ class Captioner(nn.Module):
                 self.__dict__['_token_logprobs'] = prev
         return scope()
 
+    # `ragged_unroll = 'auto'`: from this many rows on the eager step with the ragged unroll beats the merged eager step (and,
+    # from ~1024 rows, the graph-served iteration): tools/ragged_probe.py, bench.py xe_train*.ragged_eager_ms_per_iter
+    RAGGED_AUTO_ROWS = 512
+
+    def ragged_applies(self, lengths):
+        """Whether `row_counts(lengths)` would shorten the unroll: the flag is on, `lengths` is a host list sorted longest
+        first with at least one caption shorter than the longest (train.xe_forward_backward then runs one chain per unroll
+        instead of the merged chain, whose two row blocks are not one prefix)."""
+        with self.row_counts(lengths):
+            c = self.__dict__.get('_row_counts')
+        return c is not None and c[-1] < c[0]
+
     def row_counts(self, lengths, T=None):
         """`with captioner.row_counts(lengths):` - the teacher-forced unroll WITH gradients inside (one `forward_xe` or
         `forward_seq2seq` call under `token_logprobs()`, scheduled sampling off) runs step t on the rows whose caption has
@@ -717,7 +729,9 @@ class Captioner(nn.Module):
         a caption's end are masked by the criterion, so nothing reads them and their gradient is exactly zero."""
         import contextlib
         counts = None
-        if isinstance(lengths, (list, tuple)) and len(lengths) > 0 and getattr(self, 'ragged_unroll', False):
+        mode = getattr(self, 'ragged_unroll', False)      # False | True | 'auto' (batches of >= RAGGED_AUTO_ROWS rows)
+        if isinstance(lengths, (list, tuple)) and len(lengths) > 0 and mode and (
+                mode != 'auto' or len(lengths) >= self.RAGGED_AUTO_ROWS):
             ls = [int(x) for x in lengths]
             steps = max(ls) if T is None else T
             if all(a >= b for a, b in zip(ls, ls[1:])) and ls[-1] >= 1:

@@ -98,3 +98,22 @@ def test_unsorted_or_device_lengths_keep_the_full_unroll():
     a = iteration(cap, fact, labels, scs)                # unsorted batch through the flag: the full unroll, same numbers
     b = iteration(make(cfg, False), fact, labels, scs)
     np.testing.assert_array_equal(a[0], b[0])
+
+
+def test_policy_flag_takes_the_eager_step_off_the_merged_chain_and_auto_waits_for_large_batches():
+    cfg = TINY
+    fact, labels, scs = batch(cfg, 93)
+    cap = make(cfg, True)
+    cap.pair_unrolls = None                              # (the default: merged eager steps - unless the ragged form applies)
+    assert cap.ragged_applies(fact[3]) and not cap.ragged_applies(torch.tensor(fact[3]))
+    calls, orig = [], cap.row_counts
+    cap.row_counts = lambda lengths, T=None: (calls.append(len(lengths)), orig(lengths, T))[1]
+    optim, xc, dc = cap.get_optim_criterion(4e-4)
+    vec = xe_forward_backward(cap, optim, xc, dc, fact, labels, scs, 0.0)
+    assert calls == [cfg['B'], cfg['B'], cfg['S']]       # asked once, then one chain per unroll inside the contexts
+    ref = iteration(make(cfg, False), fact, labels, scs)
+    np.testing.assert_allclose(vec.cpu().numpy(), ref[0], rtol=3e-6, atol=3e-6)
+    cap.ragged_unroll = 'auto'                           # 8 rows: far below RAGGED_AUTO_ROWS
+    assert not cap.ragged_applies(fact[3])
+    cap.RAGGED_AUTO_ROWS = 4
+    assert cap.ragged_applies(fact[3])
