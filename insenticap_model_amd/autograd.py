@@ -359,7 +359,18 @@ def _backward(cap, S, dlogp, d_fc_feats, d_cpt_feats, sparse=()):
     new_full = new
     if counts is not None:
         new = zeros
-    dG1, dG2 = new(T, B, 4 * H), new(T, B, 4 * H)
+    if pk is not None:
+        # packed: step t's gate gradients at rows [offs[t], offs[t] + counts[t]) - the sweep takes per-step pointers, so the
+        # contractions over all rows behind it (both LSTM cells' dW groups, dxt, the bias sums) see N rows, no gather
+        Np, offs = pk['Np'], [0]
+        for m in counts:
+            offs.append(offs[-1] + m)
+        dG1, dG2 = new_full(Np, 4 * H), new_full(Np, 4 * H)
+        if Np > pk['N']:
+            dG1[pk['N']:].zero_()
+            dG2[pk['N']:].zero_()
+    else:
+        dG1, dG2 = new(T, B, 4 * H), new(T, B, 4 * H)
     # d feat of every step is kept ([T,B,E]): where it is the scan's output gradient, dV = sum_t alpha_t x dout_t is
     # formed once after the sweep (ops.attn_dv_from_alpha) instead of a read-modify-write of [B,R,E] at every step
     d_feat_all, dh1 = new(T, B, E), new(B, H)
@@ -420,7 +431,9 @@ def _backward(cap, S, dlogp, d_fc_feats, d_cpt_feats, sparse=()):
                 bp.rows, bp.first = counts[t], 0
             bp.g1, bp.c1_prev, bp.c1 = S.g1[t].data_ptr(), S.c1[t].data_ptr(), S.c1[t + 1].data_ptr()
             bp.g2, bp.c2_prev, bp.c2 = S.g2[t].data_ptr(), S.c2[t].data_ptr(), S.c2[t + 1].data_ptr()
-            bp.dhd, bp.dG1, bp.dG2 = dhd[t].data_ptr(), dG1[t].data_ptr(), dG2[t].data_ptr()
+            bp.dhd = dhd[t].data_ptr()
+            bp.dG1, bp.dG2 = (dG1[t].data_ptr(), dG2[t].data_ptr()) if pk is None else \
+                (dG1[offs[t]:].data_ptr(), dG2[offs[t]:].data_ptr())
             bp.d_feat = d_feat_all[t].data_ptr()
             if gate:
                 bp.dv, bp.ds = dv_all[t].data_ptr(), ds_all[t].data_ptr()
@@ -447,18 +460,34 @@ def _backward(cap, S, dlogp, d_fc_feats, d_cpt_feats, sparse=()):
         ops.attn_dp_from_de(P.words_p3, S.qw, p['attention.senti_att.word_alpha.weight'], de_s, dP_w, q2=P.label_w)
 
     # ---- weight gradients: one contraction over all T*B rows each
-    dG1f, dG2f = dG1.view(TB, 4 * H), dG2.view(TB, 4 * H)
     h1_prev, h1_cur = S.h1[:T].reshape(TB, H), S.h1[1:].reshape(TB, H)
     h2_prev = S.h2[:T].reshape(TB, H)
     feat_tb = (S.f if gate else (S.v if has_c else S.s)).view(TB, E)
+    xt_tb, tok_tb, lstm_rows = S.xt.view(TB, Wd), S.tok.view(-1), TB
+    h1_cur_l = h1_cur               # (the LSTM groups' copy: the attention contractions below stay on [T,B] rows)
+    if pk is None:
+        dG1f, dG2f = dG1.view(TB, 4 * H), dG2.view(TB, 4 * H)
+    else:
+        # packed gate gradients: their partners gathered to the same rows (pad rows zero / <PAD>)
+        def pack(x):
+            out = new(pk['Np'], x.shape[1], dtype=x.dtype)
+            torch.index_select(x, 0, pk['idx_tb'], out=out[:pk['N']])
+            if pk['Np'] > pk['N']:
+                out[pk['N']:].zero_()
+            return out
+        dG1f, dG2f, lstm_rows = dG1, dG2, pk['Np']
+        h1_prev, h1_cur_l, h2_prev, feat_tb, xt_tb = pack(h1_prev), pack(h1_cur), pack(h2_prev), pack(feat_tb), pack(xt_tb)
+        tok_tb = pack(tok_tb.view(TB, 1)).view(-1)
+        if pk['Np'] > pk['N']:
+            tok_tb[pk['N']:].fill_(cap.pad_id)
     gW1 = new(4 * H, H + E + Wd)
     gW2, gwhh1, gwhh2 = new(4 * H, E + H), new(4 * H, H), new(4 * H, H)
     # problems grouped by their dY operand: isc_gemm_bwd splits a shared dY once and runs the group as one launch
     ops.gemm_bwd([ops.gemm_problem([(dG1f, h2_prev)], gW1[:, 0:H], TN),
-                  ops.gemm_problem([(dG1f, S.xt.view(TB, Wd))], gW1[:, H + E:], TN),
+                  ops.gemm_problem([(dG1f, xt_tb)], gW1[:, H + E:], TN),
                   ops.gemm_problem([(dG1f, h1_prev)], gwhh1, TN)], TN)
     ops.gemm_bwd([ops.gemm_problem([(dG2f, feat_tb)], gW2[:, 0:E], TN),
-                  ops.gemm_problem([(dG2f, h1_cur)], gW2[:, E:], TN),
+                  ops.gemm_problem([(dG2f, h1_cur_l)], gW2[:, E:], TN),
                   ops.gemm_problem([(dG2f, h2_prev)], gwhh2, TN)], TN)
     # xt = relu(Emb[tok]) + label_e: the per-step part contracted over T*B rows above, the label part over B here
     once = [ops.gemm_problem([(dG1_sum, P.fc_e)], gW1[:, H:H + E], TN)]
@@ -474,7 +503,7 @@ def _backward(cap, S, dlogp, d_fc_feats, d_cpt_feats, sparse=()):
     # inputs of the att-LSTM: fc (step-invariant), xt = relu(Emb[tok]) + label_e
     d_fc_e = new(B, E)
     d_label_e = new(B, Wd) if P.label_e is not None else None
-    dxt = new(TB, Wd)
+    dxt = new(lstm_rows, Wd)
     probs = [nn([(dG1_sum, Wih1[:, H:H + E])], d_fc_e), nn([(dG1f, Wih1[:, H + E:])], dxt)]
     if d_label_e is not None:
         probs.append(nn([(dG1_sum, Wih1[:, H + E:])], d_label_e))
@@ -482,7 +511,7 @@ def _backward(cap, S, dlogp, d_fc_feats, d_cpt_feats, sparse=()):
         ops.gemm_bwd(probs, NN)
     emb = p['word_embed.0.weight']
     # nn.Embedding(padding_idx=pad_id): the <PAD> row never gets a gradient - every accumulation into dEmb skips it
-    ops.embed_relu_bwd(emb, S.tok.view(-1), dxt, dEmb, TB, skip_id=cap.pad_id)
+    ops.embed_relu_bwd(emb, tok_tb, dxt, dEmb, lstm_rows, skip_id=cap.pad_id)
 
     if has_c:
         dqaf = dqa.view(TB, A)

@@ -708,9 +708,11 @@ class Captioner(nn.Module):
                 self.__dict__['_token_logprobs'] = prev
         return scope()
 
-    # `ragged_unroll = 'auto'`: from this many rows on the eager step with the ragged unroll beats the merged eager step (and,
-    # from ~1024 rows, the graph-served iteration): tools/ragged_probe.py, bench.py xe_train*.ragged_eager_ms_per_iter
-    RAGGED_AUTO_ROWS = 512
+    # `ragged_unroll = 'auto'`: from this many rows on the eager step with the ragged unroll beats both the merged eager step
+    # and the graph-served iteration (13.5-13.9 ms against 15.8 / 15.0 at 1024 + 80 rows; at 512 rows it is a tie with the
+    # eager steps, 9.2-10.1 against 9.5-9.9, and behind the graphs' 8.7): tools/ragged_probe.py, bench.py
+    # xe_train*.ragged_eager_ms_per_iter
+    RAGGED_AUTO_ROWS = 1024
 
     def ragged_applies(self, lengths):
         """Whether `row_counts(lengths)` would shorten the unroll: the flag is on, `lengths` is a host list sorted longest

@@ -115,5 +115,5 @@ def test_policy_flag_takes_the_eager_step_off_the_merged_chain_and_auto_waits_fo
     np.testing.assert_allclose(vec.cpu().numpy(), ref[0], rtol=3e-6, atol=3e-6)
     cap.ragged_unroll = 'auto'                           # 8 rows: far below RAGGED_AUTO_ROWS
     assert not cap.ragged_applies(fact[3])
-    cap.RAGGED_AUTO_ROWS = 4
+    cap.RAGGED_AUTO_ROWS = 4                             # (instance override)
     assert cap.ragged_applies(fact[3])
