@@ -61,7 +61,9 @@ def xe_forward_backward(captioner, optim, xe_crit, da_crit, fact, xe_senti_label
     if pair is None:
         from .autograd_pair import use_pair
         pair = use_pair(captioner, False)
-        if pair and sink is None and getattr(captioner, 'pair_unrolls', None) is None and captioner.ragged_applies(lengths):
+        if (pair and sink is None and getattr(captioner, 'pair_unrolls', None) is None
+                and not (captioner.training and ss_prob > 0.0)        # (scheduled sampling keeps the full unroll)
+                and captioner.ragged_applies(lengths)):
             pair = False               # (captioner.ragged_unroll: one chain per unroll, each on the rows inside their captions)
     pair = pair and scs is not None and device.type == 'cuda'
     # (token_logprobs: the unrolls hand the criterion log p(target) [B,T] - the [B,T,V] log-probs are never formed)

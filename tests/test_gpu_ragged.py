@@ -117,3 +117,8 @@ def test_policy_flag_takes_the_eager_step_off_the_merged_chain_and_auto_waits_fo
     assert not cap.ragged_applies(fact[3])
     cap.RAGGED_AUTO_ROWS = 4                             # (instance override)
     assert cap.ragged_applies(fact[3])
+    # scheduled sampling keeps the full unroll - and therefore the merged chain
+    cap.ragged_unroll = True
+    calls.clear()
+    xe_forward_backward(cap.train(), optim, xc, dc, fact, labels, scs, 0.25)
+    assert calls == []
