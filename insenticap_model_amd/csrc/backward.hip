@@ -128,6 +128,27 @@ __global__ __launch_bounds__(256) void logsoftmax_bwd_raw_kernel(const float *ra
     const int mi = blockIdx.x, tid = threadIdx.x;
     const int b = mi / T, t = mi - b * T;
     const long long ms = (long long)t * step_rows + b;
+    float tot = 0.f;
+    long long id[ISC_SPARSE_MAX];
+    float cf[ISC_SPARSE_MAX];
+    bool any = false;
+#pragma unroll
+    for (int j = 0; j < ISC_SPARSE_MAX; ++j) {
+        id[j] = -1; cf[j] = 0.f;
+        if (j < sp.n) { id[j] = sp.ids[j][mi]; cf[j] = sp.coef[j][mi]; tot += cf[j]; any = any || cf[j] != 0.f; }
+    }
+    float *o = dlogits + ((long long)t * out_step_rows + b) * ld_out;
+    if (!any) {
+        // every coefficient of this position is zero (a position behind its caption's end: XECriterion's mask,
+        // captioner.py:431-436): its d logits row is zero whatever the logits hold - written without reading them or
+        // their statistics (block-uniform: the coefficients are per row)
+        if (VEC4) {
+            for (int i = tid * 4; i < ld_out; i += 1024) *reinterpret_cast<float4 *>(o + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+        } else {
+            for (int i = tid; i < ld_out; i += 256) o[i] = 0.f;
+        }
+        return;
+    }
     if (tid < 64) {
         float gmax, S;
         int gi;
@@ -137,16 +158,7 @@ __global__ __launch_bounds__(256) void logsoftmax_bwd_raw_kernel(const float *ra
     __syncthreads();
     const float gmax = sh[0], logS = sh[1];
     const float sc = scale ? scale[0] : 1.f;
-    float tot = 0.f;
-    long long id[ISC_SPARSE_MAX];
-    float cf[ISC_SPARSE_MAX];
-#pragma unroll
-    for (int j = 0; j < ISC_SPARSE_MAX; ++j) {
-        id[j] = -1; cf[j] = 0.f;
-        if (j < sp.n) { id[j] = sp.ids[j][mi]; cf[j] = sp.coef[j][mi]; tot += cf[j]; }
-    }
     const float *y = raw + (long long)b * ld_b + (long long)t * ld_t;
-    float *o = dlogits + ((long long)t * out_step_rows + b) * ld_out;
     auto one = [&](int i, float yi) __attribute__((always_inline)) {
         float v = 0.f;
 #pragma unroll

@@ -122,3 +122,38 @@ def test_policy_flag_takes_the_eager_step_off_the_merged_chain_and_auto_waits_fo
     calls.clear()
     xe_forward_backward(cap.train(), optim, xc, dc, fact, labels, scs, 0.25)
     assert calls == []
+
+
+@pytest.mark.parametrize('V', [64, 10000, 9999], ids=['v64', 'v10k', 'v_odd'])
+def test_dlogits_of_a_position_with_zero_coefficients_is_zero_whatever_its_logits_hold(V):
+    """isc_logsoftmax_bwd_raw: a row whose coefficients are all zero (behind its caption's end) is written as zeros
+    without its logits or statistics being read - NaN there must not reach d logits; every other row keeps its bits."""
+    B, T, n_tile, Vp = 6, 5, (V + 127) // 128, (V + 31) // 32 * 32
+    g = torch.Generator().manual_seed(4)
+    raw = torch.randn(T, B, V, generator=g).to(DEV)
+    pm, ps = torch.empty(T, B, n_tile, device=DEV), torch.empty(T, B, n_tile, device=DEV)
+    for k in range(n_tile):                      # tile statistics as the classifier's epilogue leaves them
+        tile = raw[:, :, k * 128:(k + 1) * 128]
+        pm[:, :, k] = tile.amax(-1)
+        ps[:, :, k] = (tile - pm[:, :, k:k + 1]).exp().sum(-1)
+    ids = torch.randint(0, V, (B, T), generator=g).to(DEV)
+    coef = torch.randn(B, T, generator=g).to(DEV)
+    dead = torch.zeros(B, T, dtype=torch.bool, device=DEV)
+    dead[1, 3:] = dead[4, 1:] = dead[5, 4:] = True
+    coef = torch.where(dead, torch.zeros_like(coef), coef).contiguous()
+
+    def run(r, m, s):
+        out = torch.full((T * B, Vp), 7.0, device=DEV)
+        ops.logsoftmax_bwd_raw(r, V, B * V, B, T, V, m, s, B, [(ids, coef)], out, out_step_rows=B)
+        return out.view(T, B, Vp)
+    clean = run(raw, pm, ps)
+    dead_tb = dead.t()
+    raw2, pm2, ps2 = raw.clone(), pm.clone(), ps.clone()
+    raw2[dead_tb], pm2[dead_tb], ps2[dead_tb] = float('nan'), float('inf'), 0.0
+    poisoned = run(raw2, pm2, ps2)
+    assert torch.equal(poisoned, clean)
+    assert (clean[dead_tb] == 0).all() and (clean[~dead_tb][:, :V].abs().sum(-1) > 0).all() and (clean[:, :, V:] == 0).all()
+    # the live rows against the definition: coef * (onehot - softmax)
+    ref = -torch.softmax(raw.double(), -1) * coef.t().double().unsqueeze(-1)
+    ref.scatter_add_(2, ids.t().unsqueeze(-1), coef.t().double().unsqueeze(-1))
+    np.testing.assert_allclose(clean[:, :, :V].cpu().numpy(), ref.cpu().numpy(), atol=2e-6)
