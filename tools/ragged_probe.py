@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Eager XE iteration (one chain per unroll, two streams) on batches sorted by caption length: ragged unroll on / off.
-    python tools/ragged_probe.py [iterations]"""
+    python tools/ragged_probe.py [iterations [ss_prob]]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -12,6 +12,7 @@ from insenticap_model_amd.train import xe_train_step
 
 dev = torch.device('cuda:0')
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+ss = float(sys.argv[2]) if len(sys.argv) > 2 else 0.0
 V, R, T = bench.V, bench.R, bench.T
 
 
@@ -29,13 +30,13 @@ for B in (128, 512, 1024):
         cap.pair_unrolls, cap.ragged_unroll = pair, ragged
         optim, xc, dc = cap.get_optim_criterion(4e-4)
         for _ in range(3):
-            xe_train_step(cap, optim, xc, dc, fact, labels, scs, 0.0, 0.1)
+            xe_train_step(cap, optim, xc, dc, fact, labels, scs, ss, 0.1)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(iters):
-            out = xe_train_step(cap, optim, xc, dc, fact, labels, scs, 0.0, 0.1)
+            out = xe_train_step(cap, optim, xc, dc, fact, labels, scs, ss, 0.1)
         torch.cuda.synchronize()
-        print('B %4d  merged %-5s ragged %-5s  %.3f ms/iter  xe_loss %.5f  active %.2f' % (
-            B, pair, ragged, (time.perf_counter() - t0) / iters * 1e3, float(out['xe_loss']),
+        print('ss %.2f  B %4d  merged %-5s ragged %-5s  %.3f ms/iter  xe_loss %.5f  active %.2f' % (
+            ss, B, pair, ragged, (time.perf_counter() - t0) / iters * 1e3, float(out['xe_loss']),
             sum(d['lengths']) / (T * B)), flush=True)
         del cap, optim
